@@ -1,0 +1,30 @@
+"""Module-level FLAGS namespace.
+
+Mirrors the ``tf.app.flags`` globals the reference reads inside library code
+(/root/reference/atvsnet/example.py:25-48; read at homography_warping.py:149,
+215,301,321,369,378, model.py:96,248).  Same attribute names and defaults, so
+call sites stay drop-in.
+"""
+
+
+class _Flags(object):
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.root_path = '../example/'
+        self.example_index = 2
+        self.view_num = 5
+        self.pretrained_model_ckpt_path = '../model/model.ckpt'
+        self.max_d = 128
+        self.num_gpus = 1
+        self.gpu_id = 0
+        self.sample_scale = 0.25
+        self.batch_size = 1
+        self.inverse_depth = True
+
+
+FLAGS = _Flags()
+
+# stand-in for tf.AUTO_REUSE (model.py:132 ...): variables are always shared by name here
+AUTO_REUSE = 'AUTO_REUSE'
