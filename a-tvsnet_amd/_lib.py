@@ -1,0 +1,86 @@
+"""Build and load ``libatvsnet_hip.so`` (the C-ABI of include/atvsnet_hip.h).
+
+The library is built IN-TREE with hipcc for gfx950 (cross-compiles without a
+GPU) and loaded with ctypes.  There is no fallback: if it is missing or fails
+to load, every op raises.
+"""
+import ctypes
+import glob
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+LIB_PATH = os.path.join(_HERE, 'libatvsnet_hip.so')
+HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'atvsnet_hip.h')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
+         '-Wno-unused-function', '-Wno-unused-result']
+
+_lib = None
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, '*.hip')))
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [HEADER]
+    return any(os.path.getmtime(p) > t for p in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 every csrc/*.hip into one shared library."""
+    if not force and not _stale():
+        return LIB_PATH
+    objs = []
+    procs = []
+    for src in sources():
+        obj = src[:-4] + '.o'
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+                [os.path.getmtime(src), os.path.getmtime(HEADER)] +
+                [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))]):
+            continue
+        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        if verbose:
+            print(' '.join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for cmd, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode('utf-8', 'replace')))
+        if verbose and out:
+            print(out.decode('utf-8', 'replace'))
+    cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if p.returncode != 0:
+        raise RuntimeError('link failed: %s\n%s' % (' '.join(cmd), p.stdout.decode('utf-8', 'replace')))
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Every function name declared in include/atvsnet_hip.h."""
+    with open(HEADER) as f:
+        text = re.sub(r'/\*.*?\*/', '', f.read(), flags=re.S)
+    return sorted(set(re.findall(r'\b(atvs_[a-z0-9_]+)\s*\(', text)))
+
+
+def lib():
+    """The loaded library; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libatvsnet_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"`; '
+                'there is no CPU fallback for the HIP path.' % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name in declared_symbols():
+            fn = getattr(_lib, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = ctypes.c_int
+        _lib.atvs_target_arch.restype = ctypes.c_char_p
+    return _lib

@@ -1,0 +1,94 @@
+// Shared helpers for the gfx950 kernels behind include/atvsnet_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/atvsnet_hip.h"
+
+#define ATVS_LAUNCH_CHECK()                                   \
+  do {                                                        \
+    hipError_t e_ = hipGetLastError();                        \
+    if (e_ != hipSuccess) return ATVS_ERR_LAUNCH;             \
+  } while (0)
+
+static inline hipStream_t as_stream(atvs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// Sampling coordinates, exactly the reference's order of operations
+// (homography_warping.py:31-104, 230-257).  Built with -ffp-contract=off so
+// that the oracle (oracle/homography_warping.py) matches bit for bit.
+// ---------------------------------------------------------------------------
+struct Tap4 {
+  int i00, i01, i10, i11;   // pixel indices y*W+x of the four taps
+  float wa, wb, wc, wd;     // area weights
+  float valid;              // 1.f / 0.f
+};
+
+__device__ __forceinline__ Tap4 bilinear_taps(float xw, float yw, int H, int W) {
+  Tap4 t;
+  float x = xw - 0.5f, y = yw - 0.5f;
+  bool v = (x >= 0.f) && (y >= 0.f) && (x < (float)(W - 1)) && (y < (float)(H - 1));
+  int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+  if (v) {
+    x0 = (int)floorf(x);
+    y0 = (int)floorf(y);
+    x1 = x0 + 1;
+    y1 = y0 + 1;
+  }
+  float m = v ? 1.f : 0.f;
+  x = x * m;  // a non-finite coordinate stays NaN, as tf.multiply does
+  y = y * m;
+  x0 = min(max(x0, 0), W - 1);
+  x1 = min(max(x1, 0), W - 1);
+  y0 = min(max(y0, 0), H - 1);
+  y1 = min(max(y1, 0), H - 1);
+  float x0f = (float)x0, x1f = (float)x1, y0f = (float)y0, y1f = (float)y1;
+  t.wa = (y1f - y) * (x1f - x);
+  t.wb = (y1f - y) * (x - x0f);
+  t.wc = (y - y0f) * (x1f - x);
+  t.wd = (y - y0f) * (x - x0f);
+  t.i00 = y0 * W + x0;
+  t.i01 = y0 * W + x1;
+  t.i10 = y1 * W + x0;
+  t.i11 = y1 * W + x1;
+  t.valid = m;
+  return t;
+}
+
+// nearest: tf.round (half to even), invalid -> pixel (0,0), value not masked (quirk C4)
+__device__ __forceinline__ int nearest_tap(float xw, float yw, int H, int W, float* valid) {
+  float x = xw - 0.5f, y = yw - 0.5f;
+  bool v = (x >= 0.f) && (y >= 0.f) && (x < (float)(W - 1)) && (y < (float)(H - 1));
+  int x0 = 0, y0 = 0;
+  if (v) {
+    x0 = (int)rintf(x);
+    y0 = (int)rintf(y);
+  }
+  *valid = v ? 1.f : 0.f;
+  return y0 * W + x0;
+}
+
+// p' = H (x+.5, y+.5, 1), projective divide with the reference's /0 guard (:251-254)
+__device__ __forceinline__ void homography_apply(const float* __restrict__ Hm, int x, int y, float* xw, float* yw) {
+  float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  float xa = (Hm[0] * px + Hm[1] * py) + Hm[2];
+  float ya = (Hm[3] * px + Hm[4] * py) + Hm[5];
+  float dv = (Hm[6] * px + Hm[7] * py) + Hm[8];
+  dv = dv + ((dv == 0.0f) ? 1.f : 0.f) * 1e-7f;
+  *xw = xa / dv;
+  *yw = ya / dv;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+__device__ __forceinline__ float4 blend4(const Tap4& t, float4 a, float4 b, float4 c, float4 d) {
+  float4 o;
+  o.x = ((t.wa * a.x + t.wb * b.x) + t.wc * c.x) + t.wd * d.x;
+  o.y = ((t.wa * a.y + t.wb * b.y) + t.wc * c.y) + t.wd * d.y;
+  o.z = ((t.wa * a.z + t.wb * b.z) + t.wc * c.z) + t.wd * d.z;
+  o.w = ((t.wa * a.w + t.wb * b.w) + t.wc * c.w) + t.wd * d.w;
+  return o;
+}

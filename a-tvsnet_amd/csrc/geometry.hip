@@ -1,0 +1,499 @@
+// Plane-sweep geometry kernels (gfx950): homographies, homography warps feeding
+// the cost / photo / geo volumes, per-pixel-depth warp, depth transform, visual hull.
+//
+// Reference semantics: /root/reference/atvsnet/homography_warping.py (whole
+// file) and the volume construction of /root/reference/atvsnet/model.py:157-200,
+// 270-336.  All HBM-bound: the D x h x w x C output volume is written once,
+// coalesced along the channel-last rows (a wavefront covers 64*16 B = 1 KiB of
+// consecutive output); the small source map (h x w x C) is gathered through L2.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// 3x3 helpers, fixed operation order (matches oracle mm3 / inv3)
+// ---------------------------------------------------------------------------
+struct M3 { float m[9]; };
+
+__device__ __forceinline__ M3 mm3(const M3& a, const M3& b) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      r.m[i * 3 + j] = (a.m[i * 3 + 0] * b.m[0 * 3 + j] + a.m[i * 3 + 1] * b.m[1 * 3 + j]) + a.m[i * 3 + 2] * b.m[2 * 3 + j];
+  return r;
+}
+__device__ __forceinline__ void mv3(const M3& a, const float* v, float* o) {
+  for (int i = 0; i < 3; ++i) o[i] = (a.m[i * 3 + 0] * v[0] + a.m[i * 3 + 1] * v[1]) + a.m[i * 3 + 2] * v[2];
+}
+__device__ __forceinline__ M3 transpose3(const M3& a) {
+  M3 r;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) r.m[i * 3 + j] = a.m[j * 3 + i];
+  return r;
+}
+__device__ __forceinline__ M3 inv3(const M3& k) {
+  float a = k.m[0], b = k.m[1], c = k.m[2], d = k.m[3], e = k.m[4], f = k.m[5], g = k.m[6], h = k.m[7], i = k.m[8];
+  float c00 = e * i - f * h, c01 = c * h - b * i, c02 = b * f - c * e;
+  float c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
+  float c20 = d * h - e * g, c21 = b * g - a * h, c22 = a * e - b * d;
+  float det = (a * c00 + b * c10) + c * c20;
+  M3 r;
+  r.m[0] = c00 / det; r.m[1] = c01 / det; r.m[2] = c02 / det;
+  r.m[3] = c10 / det; r.m[4] = c11 / det; r.m[5] = c12 / det;
+  r.m[6] = c20 / det; r.m[7] = c21 / det; r.m[8] = c22 / det;
+  return r;
+}
+// cam (2,4,4): [0] = extrinsic [R|t], [1][:3,:3] = K
+__device__ __forceinline__ void split_cam(const float* cam, M3* R, float* t, M3* K) {
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) {
+      R->m[i * 3 + j] = cam[i * 4 + j];
+      K->m[i * 3 + j] = cam[16 + i * 4 + j];
+    }
+    t[i] = cam[i * 4 + 3];
+  }
+}
+
+// H_d = K_r R_r (I - (c_r - c_l) n_l^T delta_d) R_l^T K_l^-1   (homography_warping.py:179-227)
+__global__ void homographies_kernel(const float* __restrict__ left_cam, const float* __restrict__ right_cam,
+                                    const float* __restrict__ depth_start, const float* __restrict__ depth_interval,
+                                    float* __restrict__ Hout, int depth_num, int inverse_depth) {
+  int d = blockIdx.x * blockDim.x + threadIdx.x;
+  if (d >= depth_num) return;
+  M3 Rl, Kl, Rr, Kr;
+  float tl[3], tr[3];
+  split_cam(left_cam, &Rl, tl, &Kl);
+  split_cam(right_cam, &Rr, tr, &Kr);
+  float depth = depth_start[0] + (float)d * depth_interval[0];
+  M3 Kli = inv3(Kl);
+  M3 RlT = transpose3(Rl), RrT = transpose3(Rr);
+  float cl[3], cr[3], crel[3];
+  mv3(RlT, tl, cl);
+  mv3(RrT, tr, cr);
+  for (int i = 0; i < 3; ++i) crel[i] = (-cr[i]) - (-cl[i]);
+  M3 mid0;
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      float tv = crel[i] * Rl.m[2 * 3 + j];
+      float e = (i == j) ? 1.f : 0.f;
+      mid0.m[i * 3 + j] = inverse_depth ? (e - tv * depth) : (e - tv / depth);
+    }
+  M3 mid1 = mm3(RlT, Kli);
+  M3 mid2 = mm3(mid0, mid1);
+  M3 Hm = mm3(Kr, mm3(Rr, mid2));
+  for (int i = 0; i < 9; ++i) Hout[d * 9 + i] = Hm.m[i];
+}
+
+extern "C" int atvs_get_homographies(const float* left_cam, const float* right_cam, const float* depth_start,
+                                     const float* depth_interval, float* homographies, int depth_num,
+                                     int inverse_depth, atvs_stream_t stream) {
+  if (!left_cam || !right_cam || !depth_start || !depth_interval || !homographies) return ATVS_ERR_NULL;
+  if (depth_num <= 0) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL(homographies_kernel, dim3(cdiv(depth_num, 64)), dim3(64), 0, as_stream(stream), left_cam,
+                     right_cam, depth_start, depth_interval, homographies, depth_num, inverse_depth);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Homography warp of an (h, w, C) map onto D planes -> out (D, h, w, ld) at
+// channel offset c_off.  MODE selects the fused epilogue:
+//   0 plain warp                              (model.py:190-194, cost volume)
+//   1 |warp - ref| * mask                     (model.py:272-279, photo volume)
+//   2 (|warp - delta_d| / interval / D) * mask replicated to `rep` channels,
+//     source has one channel                  (model.py:292-297, geo view volume)
+// VEC = 4: C % 4 == 0, float4 per lane.  VEC = 1: scalar per lane.
+// ---------------------------------------------------------------------------
+template <int MODE, int VEC>
+__global__ __launch_bounds__(256) void warp_planes_kernel(
+    const float* __restrict__ src, const float* __restrict__ Hmats, const float* __restrict__ ref,
+    const float* __restrict__ depth_start, const float* __restrict__ depth_interval, float* __restrict__ out,
+    float* __restrict__ mask_out, int D, int h, int w, int C, int ld, int c_off, int rep) {
+  const int d = blockIdx.y;
+  const int cg = (MODE == 2) ? 1 : C / VEC;   // lanes per pixel
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long npix = (long)h * w;
+  if (gid >= npix * cg) return;
+  int pix = (int)(gid / cg);
+  int c = (int)(gid % cg) * VEC;
+  int y = pix / w, x = pix % w;
+  float Hm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Hm[i] = Hmats[d * 9 + i];
+  float xw, yw;
+  homography_apply(Hm, x, y, &xw, &yw);
+  Tap4 t = bilinear_taps(xw, yw, h, w);
+  size_t obase = ((size_t)d * npix + pix) * (size_t)ld + c_off;
+  if (MODE == 2) {
+    float v = ((t.wa * src[t.i00] + t.wb * src[t.i01]) + t.wc * src[t.i10]) + t.wd * src[t.i11];
+    float val = depth_start[0] + (float)d * depth_interval[0];
+    float g = (fabsf(v - val) / depth_interval[0] / (float)D) * t.valid;
+    for (int r = 0; r < rep; ++r) out[obase + r] = g;
+    if (mask_out) mask_out[(size_t)d * npix + pix] = t.valid;
+    return;
+  }
+  if (VEC == 4) {
+    float4 a = ld4(src + (size_t)t.i00 * C + c), b = ld4(src + (size_t)t.i01 * C + c);
+    float4 cc = ld4(src + (size_t)t.i10 * C + c), dd = ld4(src + (size_t)t.i11 * C + c);
+    float4 o = blend4(t, a, b, cc, dd);
+    if (MODE == 1) {
+      float4 r = ld4(ref + (size_t)pix * C + c);
+      o.x = fabsf(o.x - r.x) * t.valid;
+      o.y = fabsf(o.y - r.y) * t.valid;
+      o.z = fabsf(o.z - r.z) * t.valid;
+      o.w = fabsf(o.w - r.w) * t.valid;
+    }
+    st4(out + obase + c, o);
+  } else {
+    float o = ((t.wa * src[(size_t)t.i00 * C + c] + t.wb * src[(size_t)t.i01 * C + c]) +
+               t.wc * src[(size_t)t.i10 * C + c]) + t.wd * src[(size_t)t.i11 * C + c];
+    if (MODE == 1) o = fabsf(o - ref[(size_t)pix * C + c]) * t.valid;
+    out[obase + c] = o;
+  }
+  if (mask_out && c == 0) mask_out[(size_t)d * npix + pix] = t.valid;
+}
+
+extern "C" int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
+                                const float* depth_start, const float* depth_interval, float* out, float* mask_out,
+                                int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep,
+                                atvs_stream_t stream) {
+  if (!src || !homographies || !out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0 || C <= 0 || ld_out < C || c_off < 0) return ATVS_ERR_SHAPE;
+  if (mode == 1 && !ref) return ATVS_ERR_NULL;
+  if (mode == 2 && (C != 1 || !depth_start || !depth_interval || rep < 1 || c_off + rep > ld_out)) return ATVS_ERR_SHAPE;
+  if (mode != 2 && c_off + C > ld_out) return ATVS_ERR_SHAPE;
+  bool vec = (C % 4 == 0) && (ld_out % 4 == 0) && (c_off % 4 == 0) && mode != 2;
+  long lanes = (long)h * w * (mode == 2 ? 1 : (vec ? C / 4 : C));
+  dim3 grid(cdiv(lanes, 256), D), block(256);
+  hipStream_t s = as_stream(stream);
+#define LAUNCH(M, V)                                                                                            \
+  hipLaunchKernelGGL((warp_planes_kernel<M, V>), grid, block, 0, s, src, homographies, ref, depth_start,        \
+                     depth_interval, out, mask_out, D, h, w, C, ld_out, c_off, rep)
+  if (mode == 0) { if (vec) LAUNCH(0, 4); else LAUNCH(0, 1); }
+  else if (mode == 1) { if (vec) LAUNCH(1, 4); else LAUNCH(1, 1); }
+  else if (mode == 2) LAUNCH(2, 1);
+  else return ATVS_ERR_ARG;
+#undef LAUNCH
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Cost volume (model.py:157-200): out[d, y, x, :] = concat(ref[y, x, :], warp_d(view)[y, x, :]).
+// One lane per float4 of the 2C-wide row; a wavefront writes 1 KiB contiguous.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cost_volume_kernel(const float* __restrict__ ref_f, const float* __restrict__ view_f,
+                                                          const float* __restrict__ Hmats, float* __restrict__ out,
+                                                          int D, int h, int w, int C) {
+  const int d = blockIdx.y;
+  const int cg = (2 * C) / 4;
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long npix = (long)h * w;
+  if (gid >= npix * cg) return;
+  int pix = (int)(gid / cg);
+  int c = (int)(gid % cg) * 4;
+  float4 o;
+  if (c < C) {
+    o = ld4(ref_f + (size_t)pix * C + c);
+  } else {
+    int cv = c - C;
+    int y = pix / w, x = pix % w;
+    float Hm[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Hm[i] = Hmats[d * 9 + i];
+    float xw, yw;
+    homography_apply(Hm, x, y, &xw, &yw);
+    Tap4 t = bilinear_taps(xw, yw, h, w);
+    o = blend4(t, ld4(view_f + (size_t)t.i00 * C + cv), ld4(view_f + (size_t)t.i01 * C + cv),
+               ld4(view_f + (size_t)t.i10 * C + cv), ld4(view_f + (size_t)t.i11 * C + cv));
+  }
+  st4(out + ((size_t)d * npix + pix) * (size_t)(2 * C) + c, o);
+}
+
+extern "C" int atvs_build_cost_volume(const float* ref_feature, const float* view_feature, const float* homographies,
+                                      float* cost_volume, int D, int h, int w, int C, atvs_stream_t stream) {
+  if (!ref_feature || !view_feature || !homographies || !cost_volume) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0 || C <= 0 || (C % 4) != 0) return ATVS_ERR_SHAPE;
+  long lanes = (long)h * w * (2 * C / 4);
+  hipLaunchKernelGGL(cost_volume_kernel, dim3(cdiv(lanes, 256), D), dim3(256), 0, as_stream(stream), ref_feature,
+                     view_feature, homographies, cost_volume, D, h, w, C);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Broadcast an (h, w, C) map along D into out (D, h, w, ld) at c_off
+// (tf.tile call sites model.py:311,316,329-330).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tile_planes_kernel(const float* __restrict__ src, float* __restrict__ out, int D,
+                                                          long npix, int C, int ld, int c_off) {
+  const int d = blockIdx.y;
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= npix * C) return;
+  long pix = gid / C;
+  int c = (int)(gid % C);
+  out[((size_t)d * npix + pix) * (size_t)ld + c_off + c] = src[gid];
+}
+
+extern "C" int atvs_tile_planes(const float* src, float* out, int D, int h, int w, int C, int ld_out, int c_off,
+                                atvs_stream_t stream) {
+  if (!src || !out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0 || C <= 0 || c_off < 0 || c_off + C > ld_out) return ATVS_ERR_SHAPE;
+  long n = (long)h * w * C;
+  hipLaunchKernelGGL(tile_planes_kernel, dim3(cdiv(n, 256), D), dim3(256), 0, as_stream(stream), src, out, D,
+                     (long)h * w, C, ld_out, c_off);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// geo reference volume (model.py:289-290): out[d,pix] = |depth_ref[pix] - delta_d| / interval / D
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void geo_ref_kernel(const float* __restrict__ depth_ref, const float* __restrict__ depth_start,
+                                                      const float* __restrict__ depth_interval, float* __restrict__ out,
+                                                      int D, long npix, int ld, int c_off) {
+  const int d = blockIdx.y;
+  long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (pix >= npix) return;
+  float val = depth_start[0] + (float)d * depth_interval[0];
+  out[((size_t)d * npix + pix) * (size_t)ld + c_off] = fabsf(depth_ref[pix] - val) / depth_interval[0] / (float)D;
+}
+
+extern "C" int atvs_geo_ref_planes(const float* depth_ref, const float* depth_start, const float* depth_interval,
+                                   float* out, int D, int h, int w, int ld_out, int c_off, atvs_stream_t stream) {
+  if (!depth_ref || !depth_start || !depth_interval || !out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0 || c_off < 0 || c_off >= ld_out) return ATVS_ERR_SHAPE;
+  long npix = (long)h * w;
+  hipLaunchKernelGGL(geo_ref_kernel, dim3(cdiv(npix, 256), D), dim3(256), 0, as_stream(stream), depth_ref,
+                     depth_start, depth_interval, out, D, npix, ld_out, c_off);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Visual hull for two depth maps (homography_warping.py:329-387 with view_num = 2,
+// the only configuration the path uses: model.py:323-324 via :436 / :373):
+//   hull[d] = ([ref>0][ref>delta_d] + [wd>0][wd>delta_d]) / 2,  wd = nearest-warp_d(view_depth_in_ref)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void visual_hull_kernel(const float* __restrict__ ref_depth, const float* __restrict__ view_depth_trans,
+                                                          const float* __restrict__ Hmats, const float* __restrict__ depth_start,
+                                                          const float* __restrict__ depth_interval, float* __restrict__ out,
+                                                          int D, int h, int w, int inverse_depth, float view_num) {
+  const int d = blockIdx.y;
+  long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long npix = (long)h * w;
+  if (pix >= npix) return;
+  int y = (int)(pix / w), x = (int)(pix % w);
+  float cur = depth_start[0] + depth_interval[0] * (float)d;
+  float rd = ref_depth[pix];
+  float s = ((rd > 0.f) ? 1.f : 0.f) * (inverse_depth ? ((rd > cur) ? 1.f : 0.f) : ((cur > rd) ? 1.f : 0.f));
+  float Hm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Hm[i] = Hmats[d * 9 + i];
+  float xw, yw, valid;
+  homography_apply(Hm, x, y, &xw, &yw);
+  int idx = nearest_tap(xw, yw, h, w, &valid);
+  float wd = view_depth_trans[idx];
+  s = s + ((wd > 0.f) ? 1.f : 0.f) * (inverse_depth ? ((wd > cur) ? 1.f : 0.f) : ((cur > wd) ? 1.f : 0.f));
+  out[(size_t)d * npix + pix] = s / view_num;
+}
+
+extern "C" int atvs_visual_hull(const float* ref_depth, const float* view_depth_in_ref, const float* homographies,
+                                const float* depth_start, const float* depth_interval, float* out, int D, int h,
+                                int w, int inverse_depth, atvs_stream_t stream) {
+  if (!ref_depth || !view_depth_in_ref || !homographies || !depth_start || !depth_interval || !out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
+  long npix = (long)h * w;
+  hipLaunchKernelGGL(visual_hull_kernel, dim3(cdiv(npix, 256), D), dim3(256), 0, as_stream(stream), ref_depth,
+                     view_depth_in_ref, homographies, depth_start, depth_interval, out, D, h, w, inverse_depth, 2.0f);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Relative pose  mat = K_r R_r R_l^T K_l^-1,  vec = K_r R_r c_l + K_r t_r
+// (homography_warping.py:123-146, 290-313), recomputed per thread: 12 floats.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void relative_pose(const float* left_cam, const float* right_cam, M3* mat, float* vec) {
+  M3 Rl, Kl, Rr, Kr;
+  float tl[3], tr[3];
+  split_cam(left_cam, &Rl, tl, &Kl);
+  split_cam(right_cam, &Rr, tr, &Kr);
+  M3 Kli = inv3(Kl);
+  M3 RlT = transpose3(Rl);
+  float cl[3];
+  mv3(RlT, tl, cl);
+  for (int i = 0; i < 3; ++i) cl[i] = -cl[i];
+  *mat = mm3(Kr, mm3(Rr, mm3(RlT, Kli)));
+  float v0[3], v1[3], v2[3];
+  mv3(Rr, cl, v0);
+  mv3(Kr, v0, v1);
+  mv3(Kr, tr, v2);
+  for (int i = 0; i < 3; ++i) vec[i] = v1[i] + v2[i];
+}
+
+// pose (12 floats: mat row-major, vec) computed once by a 1-thread kernel
+__global__ void relative_pose_kernel(const float* left_cam, const float* right_cam, float* pose) {
+  M3 mat;
+  float vec[3];
+  relative_pose(left_cam, right_cam, &mat, vec);
+  for (int i = 0; i < 9; ++i) pose[i] = mat.m[i];
+  for (int i = 0; i < 3; ++i) pose[9 + i] = vec[i];
+}
+
+// ---------------------------------------------------------------------------
+// Per-pixel-depth warp (homography_warping.py:108-176): p' ~ M p + v * delta(p).
+// method 0 bilinear / 1 nearest; mask written when mask_out != nullptr.
+// ---------------------------------------------------------------------------
+template <int NEAREST>
+__global__ __launch_bounds__(256) void warp_by_depth_kernel(const float* __restrict__ src, const float* __restrict__ pose,
+                                                            const float* __restrict__ depth, float* __restrict__ out,
+                                                            float* __restrict__ mask_out, int h, int w, int C,
+                                                            int inverse_depth) {
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long npix = (long)h * w;
+  if (gid >= npix * C) return;
+  int pix = (int)(gid / C), c = (int)(gid % C);
+  int y = pix / w, x = pix % w;
+  float px = (float)x + 0.5f, py = (float)y + 0.5f;
+  float dd = depth[pix];
+  float r[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    float v = inverse_depth ? (pose[9 + i] * dd) : (pose[9 + i] / dd);
+    r[i] = ((pose[i * 3 + 0] * px + pose[i * 3 + 1] * py) + pose[i * 3 + 2]) + v;
+  }
+  float xw = r[0] / r[2], yw = r[1] / r[2];
+  float o, valid;
+  if (NEAREST) {
+    int idx = nearest_tap(xw, yw, h, w, &valid);
+    o = src[(size_t)idx * C + c];
+  } else {
+    Tap4 t = bilinear_taps(xw, yw, h, w);
+    valid = t.valid;
+    o = ((t.wa * src[(size_t)t.i00 * C + c] + t.wb * src[(size_t)t.i01 * C + c]) + t.wc * src[(size_t)t.i10 * C + c]) +
+        t.wd * src[(size_t)t.i11 * C + c];
+  }
+  out[gid] = o;
+  if (mask_out && c == 0) mask_out[pix] = valid;
+}
+
+extern "C" int atvs_warp_by_depth(const float* src, const float* left_cam, const float* right_cam, const float* depth,
+                                  float* out, float* mask_out, float* pose_ws, int h, int w, int C, int method,
+                                  int inverse_depth, atvs_stream_t stream) {
+  if (!src || !left_cam || !right_cam || !depth || !out || !pose_ws) return ATVS_ERR_NULL;
+  if (h <= 0 || w <= 0 || C <= 0) return ATVS_ERR_SHAPE;
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(relative_pose_kernel, dim3(1), dim3(1), 0, s, left_cam, right_cam, pose_ws);
+  long n = (long)h * w * C;
+  if (method == 0)
+    hipLaunchKernelGGL((warp_by_depth_kernel<0>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, pose_ws, depth, out, mask_out, h, w, C, inverse_depth);
+  else if (method == 1)
+    hipLaunchKernelGGL((warp_by_depth_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, pose_ws, depth, out, mask_out, h, w, C, inverse_depth);
+  else
+    return ATVS_ERR_ARG;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// transform_depth (homography_warping.py:275-326): two global maxima (quirk C15)
+// -> three tiny passes.  ws: 2 floats (max of input, max of transformed z).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float block_max_256(float v) {
+  __shared__ float sm[4];
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  __syncthreads();
+  return v;
+}
+
+// fmaxf drops NaNs, like tf.reduce_max on finite data; order-independent, so atomics are exact.
+__device__ __forceinline__ void atomic_max_float(float* addr, float v) {
+  // monotone int mapping of finite floats
+  if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+  else atomicMin(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+}
+
+__global__ void fill_neg_inf_kernel(float* ws) {
+  ws[0] = -INFINITY;
+  ws[1] = -INFINITY;
+}
+
+__global__ __launch_bounds__(256) void max_kernel(const float* __restrict__ x, long n, float* __restrict__ ws) {
+  float v = -INFINITY;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) v = fmaxf(v, x[i]);
+  v = block_max_256(v);
+  if (threadIdx.x == 0) atomic_max_float(ws, v);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void transform_depth_kernel(const float* __restrict__ depth, const float* __restrict__ pose,
+                                                              float* __restrict__ out, float* __restrict__ ws, int h, int w,
+                                                              int inverse_depth) {
+  long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long npix = (long)h * w;
+  float z = -INFINITY;
+  bool in = pix < npix;
+  float valid = 0.f;
+  if (in) {
+    float d = depth[pix];
+    if (inverse_depth) {
+      valid = (d > 1e-10f) ? 1.f : 0.f;
+      d = fminf(fmaxf(d, 1e-10f), ws[0]);
+      d = 1.0f / d;
+      d = d * valid;
+    }
+    int y = (int)(pix / w), x = (int)(pix % w);
+    float gx = ((float)x + 0.5f) * d, gy = ((float)y + 0.5f) * d;
+    z = ((pose[6] * gx + pose[7] * gy) + pose[8] * d) + pose[11];
+  }
+  if (PASS == 0) {
+    float m = block_max_256(z);
+    if (threadIdx.x == 0) atomic_max_float(ws + 1, m);
+  } else if (in) {
+    if (inverse_depth) {
+      z = fminf(fmaxf(z, 1e-10f), ws[1]);
+      z = 1.0f / z;
+      z = z * valid;
+    }
+    out[pix] = z;
+  }
+}
+
+extern "C" int atvs_transform_depth(const float* depth, const float* left_cam, const float* right_cam, float* out,
+                                    float* ws14, int h, int w, int inverse_depth, atvs_stream_t stream) {
+  if (!depth || !left_cam || !right_cam || !out || !ws14) return ATVS_ERR_NULL;
+  if (h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
+  hipStream_t s = as_stream(stream);
+  long npix = (long)h * w;
+  float* pose = ws14 + 2;
+  hipLaunchKernelGGL(fill_neg_inf_kernel, dim3(1), dim3(1), 0, s, ws14);
+  hipLaunchKernelGGL(relative_pose_kernel, dim3(1), dim3(1), 0, s, left_cam, right_cam, pose);
+  hipLaunchKernelGGL(max_kernel, dim3(min(cdiv(npix, 256), 1024)), dim3(256), 0, s, depth, npix, ws14);
+  hipLaunchKernelGGL((transform_depth_kernel<0>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, pose, out, ws14, h, w, inverse_depth);
+  hipLaunchKernelGGL((transform_depth_kernel<1>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, pose, out, ws14, h, w, inverse_depth);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
+// |a - b| * mask[pixel]  (photo_err / geo_err, model.py:310,315)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void absdiff_mask_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ mask, float* __restrict__ out,
+                                                           long n, int C) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = fabsf(a[i] - b[i]) * mask[i / C];
+}
+
+extern "C" int atvs_absdiff_mask(const float* a, const float* b, const float* mask, float* out, int npix, int C,
+                                 atvs_stream_t stream) {
+  if (!a || !b || !mask || !out) return ATVS_ERR_NULL;
+  if (npix <= 0 || C <= 0) return ATVS_ERR_SHAPE;
+  long n = (long)npix * C;
+  hipLaunchKernelGGL(absdiff_mask_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), a, b, mask, out, n, C);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

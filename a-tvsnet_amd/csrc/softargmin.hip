@@ -1,0 +1,127 @@
+// Soft-argmin depth regression (gfx950).
+//
+// Reference: /root/reference/atvsnet/model.py:80-109 (prob2depth: softmax(-cost)
+// over D, expectation of tf.linspace(start, end, D)) and :68-76,113-129
+// (prob2depth_upsample: bilinear x4, align_corners, of the PRE-softmax cost per
+// depth plane, then the same soft-argmin at full resolution; quirk C10).
+//
+// HBM-bound: the (D, h, w) cost volume is read once.  Lanes run along w (the
+// contiguous axis) so every plane read is coalesced; the depth axis is split
+// over the four wavefronts of a workgroup and the online-softmax partials
+// (max, sum, weighted sum) are merged through LDS.  The x4 variant never
+// materialises the (D, 4h, 4w) volume the reference builds.
+#include "common.h"
+
+struct Osm {  // online softmax state over x = -cost
+  float m, s, t;
+};
+
+__device__ __forceinline__ void osm_push(Osm& a, float x, float val) {
+  if (x > a.m) {
+    float r = expf(a.m - x);
+    a.s = a.s * r + 1.f;
+    a.t = a.t * r + val;
+    a.m = x;
+  } else {
+    float e = expf(x - a.m);
+    a.s += e;
+    a.t += e * val;
+  }
+}
+
+__device__ __forceinline__ float linspace_step(float start, float interval, int D, float* end_out) {
+  float end = start + ((float)D - 1.0f) * interval;
+  *end_out = end;
+  return (D > 1) ? (end - start) / (float)(D - 1) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict__ cost, const float* __restrict__ depth_start,
+                                                         const float* __restrict__ depth_interval, float* __restrict__ depth_out,
+                                                         int D, long npix) {
+  __shared__ float sm[3][4][64];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  long pix = (long)blockIdx.x * 64 + lane;
+  float start = depth_start[0], end;
+  float step = linspace_step(start, depth_interval[0], D, &end);
+  Osm a = {-INFINITY, 0.f, 0.f};
+  int d0 = (int)(((long)D * wv) / 4), d1 = (int)(((long)D * (wv + 1)) / 4);
+  if (pix < npix) {
+    const float* p = cost + pix;
+    for (int d = d0; d < d1; ++d) {
+      float c = p[(size_t)d * npix];
+      osm_push(a, -1.0f * c, start + step * (float)d);
+    }
+  }
+  sm[0][wv][lane] = a.m;
+  sm[1][wv][lane] = a.s;
+  sm[2][wv][lane] = a.t;
+  __syncthreads();
+  if (wv == 0 && pix < npix) {
+    float m = fmaxf(fmaxf(sm[0][0][lane], sm[0][1][lane]), fmaxf(sm[0][2][lane], sm[0][3][lane]));
+    float s = 0.f, t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float mk = sm[0][k][lane];
+      float r = (mk == -INFINITY) ? 0.f : expf(mk - m);
+      s += sm[1][k][lane] * r;
+      t += sm[2][k][lane] * r;
+    }
+    depth_out[pix] = t / s;
+  }
+}
+
+extern "C" int atvs_softargmin(const float* cost, const float* depth_start, const float* depth_interval, float* depth_out,
+                               int D, int h, int w, atvs_stream_t stream) {
+  if (!cost || !depth_start || !depth_interval || !depth_out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
+  long npix = (long)h * w;
+  hipLaunchKernelGGL(softargmin_kernel, dim3(cdiv(npix, 64)), dim3(256), 0, as_stream(stream), cost, depth_start,
+                     depth_interval, depth_out, D, npix);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// One thread per full-resolution pixel; its four low-resolution taps are shared with
+// its neighbours and stay in L1/L2 (the whole (D,h,w) volume is a few MB).
+__global__ __launch_bounds__(256) void upsample_softargmin_kernel(const float* __restrict__ cost, const float* __restrict__ depth_start,
+                                                                  const float* __restrict__ depth_interval, float* __restrict__ depth_out,
+                                                                  int D, int h, int w, int H, int W, float sy, float sx) {
+  int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+  int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox >= W || oy >= H) return;
+  float fy = (float)oy * sy, fx = (float)ox * sx;
+  int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+  int y1 = min((int)ceilf(fy), h - 1), x1 = min((int)ceilf(fx), w - 1);
+  float ly = fy - (float)y0, lx = fx - (float)x0;
+  float start = depth_start[0], end;
+  float step = linspace_step(start, depth_interval[0], D, &end);
+  long npix = (long)h * w;
+  const float* p00 = cost + (size_t)y0 * w + x0;
+  const float* p01 = cost + (size_t)y0 * w + x1;
+  const float* p10 = cost + (size_t)y1 * w + x0;
+  const float* p11 = cost + (size_t)y1 * w + x1;
+  Osm a = {-INFINITY, 0.f, 0.f};
+  for (int d = 0; d < D; ++d) {
+    size_t o = (size_t)d * npix;
+    float tl = p00[o], tr = p01[o], bl = p10[o], br = p11[o];
+    float t = tl + (tr - tl) * lx;
+    float b = bl + (br - bl) * lx;
+    float c = t + (b - t) * ly;
+    osm_push(a, -1.0f * c, start + step * (float)d);
+  }
+  depth_out[(size_t)oy * W + ox] = a.t / a.s;
+}
+
+extern "C" int atvs_upsample_softargmin(const float* cost, const float* depth_start, const float* depth_interval,
+                                        float* depth_up_out, int D, int h, int w, int up_scale, atvs_stream_t stream) {
+  if (!cost || !depth_start || !depth_interval || !depth_up_out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0 || up_scale <= 0) return ATVS_ERR_SHAPE;
+  int H = h * up_scale, W = w * up_scale;
+  // tf.image.resize_images(align_corners=True): scale = (in-1)/(out-1), computed in double then rounded
+  float sy = (H > 1) ? (float)((double)(h - 1) / (double)(H - 1)) : 0.f;
+  float sx = (W > 1) ? (float)((double)(w - 1) / (double)(W - 1)) : 0.f;
+  hipLaunchKernelGGL(upsample_softargmin_kernel, dim3(cdiv(W, 64), cdiv(H, 4)), dim3(256), 0, as_stream(stream), cost,
+                     depth_start, depth_interval, depth_up_out, D, h, w, H, W, sy, sx);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

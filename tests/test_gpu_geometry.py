@@ -1,0 +1,162 @@
+"""-m gpu: geometry + soft-argmin HIP kernels (through the C-ABI) vs the CPU oracle.
+
+Geometry is integer/index work plus fixed-order fp32 arithmetic -> BIT-EXACT bar
+(built with -ffp-contract=off; oracle uses the same operation order).
+Soft-argmin uses expf -> tolerance 2e-6 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import homography_warping as G
+from oracle import model as OM
+
+pytestmark = pytest.mark.gpu
+
+
+def _example_cams(views=2):
+    from atvsnet_amd import synthetic
+    cams = synthetic.make_cams(views, 128, 160, 32)
+    return torch.from_numpy(cams)[None]          # (1,N,2,4,4)
+
+
+def _golden_cams():
+    import os
+    d = os.path.join(os.path.dirname(__file__), 'golden')
+    c = np.stack([np.load(os.path.join(d, 'example2_%d_cam.npy' % i)) for i in range(2)]).astype(np.float32)
+    return torch.from_numpy(c)[None]
+
+
+@pytest.mark.parametrize('which', ['synthetic', 'example2'])
+@pytest.mark.parametrize('D', [1, 32, 192])
+def test_homographies_bit_exact(cuda, which, D):
+    from atvsnet_amd import ops
+    cams = _example_cams() if which == 'synthetic' else _golden_cams()
+    ds, di = OM.depth_start_interval(cams)
+    for a, b in ((0, 1), (1, 0)):
+        want = G.get_homographies(cams[:, a], cams[:, b], D, ds, di)[0]
+        got = ops.get_homographies(cams[0, a].to(cuda).contiguous(), cams[0, b].to(cuda).contiguous(),
+                                   ds.to(cuda), di.to(cuda), D).cpu()
+        assert torch.equal(got, want)
+
+
+def _feat(h, w, C, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(1, h, w, C, generator=g)
+
+
+@pytest.mark.parametrize('h,w,C,D', [(32, 40, 32, 32), (30, 36, 16, 8), (17, 23, 4, 5), (32, 40, 1, 16), (9, 11, 3, 4)])
+def test_warp_planes_bit_exact(cuda, h, w, C, D):
+    from atvsnet_amd import ops
+    cams = _example_cams()
+    # intrinsics are for 32x40; other sizes simply sample more out-of-range pixels (exercises the masks)
+    ds, di = OM.depth_start_interval(cams)
+    H = G.get_homographies(cams[:, 0], cams[:, 1], D, ds, di)
+    src = _feat(h, w, C, 1)
+    want = torch.stack([G.homography_warping(src, H[:, d])[0] for d in range(D)])
+    wm = torch.stack([G.homography_warping(src, H[:, d], output_mask=True)[1][0, ..., 0] for d in range(D)])
+    got, mask = ops.warp_planes(src[0].to(cuda), H[0].to(cuda), want_mask=True)
+    assert torch.equal(got.cpu(), want)
+    assert torch.equal(mask.cpu(), wm.to(torch.float32))
+    assert 0.05 < wm.float().mean() < 1.0          # both valid and invalid samples are present
+
+
+def test_cost_volume_bit_exact(cuda):
+    from atvsnet_amd import ops
+    cams = _example_cams()
+    ds, di = OM.depth_start_interval(cams)
+    D, h, w, C = 32, 32, 40, 32
+    rf, vf = _feat(h, w, C, 2), _feat(h, w, C, 3)
+    want = OM.build_cost_volume(rf, vf, cams, D, ds, di, 0, 1)[0]
+    H = ops.get_homographies(cams[0, 0].to(cuda), cams[0, 1].to(cuda), ds.to(cuda), di.to(cuda), D)
+    got = ops.build_cost_volume(rf[0].to(cuda), vf[0].to(cuda), H)
+    assert torch.equal(got.cpu(), want)
+    # reverse direction (model.py:413, quirk C11)
+    want = OM.build_cost_volume(vf, rf, cams, D, ds, di, 1, 0)[0]
+    H = ops.get_homographies(cams[0, 1].to(cuda), cams[0, 0].to(cuda), ds.to(cuda), di.to(cuda), D)
+    got = ops.build_cost_volume(vf[0].to(cuda), rf[0].to(cuda), H)
+    assert torch.equal(got.cpu(), want)
+
+
+def test_identity_camera_warp(cuda):
+    """Known answer: identity pose -> identity away from the last row/col, which go to 0."""
+    from atvsnet_amd import ops
+    cams = _example_cams()
+    ds, di = OM.depth_start_interval(cams)
+    src = _feat(12, 20, 8, 5)[0]
+    H = ops.get_homographies(cams[0, 0].to(cuda), cams[0, 0].to(cuda), ds.to(cuda), di.to(cuda), 3)
+    out = ops.warp_planes(src.to(cuda), H).cpu()
+    for d in range(3):
+        assert torch.allclose(out[d, :-1, :-1], src[:-1, :-1], atol=1e-5)
+        assert torch.all(out[d, -1] == 0) and torch.all(out[d, :, -1] == 0)
+
+
+def test_refinement_volumes_bit_exact(cuda):
+    """photo / geo / visual-hull volumes and the D-constant maps of model.py:270-336."""
+    from atvsnet_amd import ops
+    cams = _example_cams()
+    ds, di = OM.depth_start_interval(cams)
+    D, h, w = 16, 32, 40
+    g = torch.Generator().manual_seed(7)
+    ref_f, view_f = _feat(h, w, 16, 11), _feat(h, w, 16, 12)
+    d_ref = 0.05 + 0.3 * torch.rand(1, h, w, 1, generator=g)
+    d_view = 0.05 + 0.3 * torch.rand(1, h, w, 1, generator=g)
+    d_view[0, :3, :5] = 0.0                       # invalid depths exercise the 1e-10 clip / mask
+    init = torch.stack([d_ref, d_view], 1)
+    prob = torch.randn(1, D, h, w, generator=g)
+    want = OM.refinement_inputs(init, cams, D, ds, di, None, prob, None, 0, 1, shallow=(ref_f, view_f))
+
+    c = lambda t: t.to(cuda).contiguous()
+    ref_cam, view_cam = c(cams[0, 0]), c(cams[0, 1])
+    dsg, dig = c(ds), c(di)
+    H = ops.get_homographies(ref_cam, view_cam, dsg, dig, D)
+    vtrans = ops.transform_depth(c(d_view[0, ..., 0]), view_cam, ref_cam)
+    assert torch.equal(vtrans.cpu(), G.transform_depth(d_view, cams[:, 1], cams[:, 0])[0, ..., 0])
+
+    photo = torch.empty(D, h, w, 48, device=cuda)
+    ops.warp_planes(c(view_f[0]), H, out=photo, c_off=0, mode=1, ref=c(ref_f[0]))
+    wf, mp = ops.warp_by_depth(c(view_f[0]), ref_cam, view_cam, c(d_ref[0, ..., 0]))
+    from atvsnet_amd import ops as O
+    perr = O.absdiff_mask(wf, c(ref_f[0]), mp)
+    ops.tile_planes(perr, photo, 16)
+    ops.tile_planes(c(ref_f[0]), photo, 32)
+    assert torch.equal(photo.cpu(), want['photo_group'][0])
+
+    geo = torch.empty(D, h, w, 19, device=cuda)
+    ops.geo_ref_planes(c(d_ref[0, ..., 0]), dsg, dig, geo, 0)
+    ops.warp_planes(vtrans.reshape(h, w, 1), H, out=geo, c_off=1, mode=2, depth_start=dsg, depth_interval=dig, rep=16)
+    wd, mg = ops.warp_by_depth(vtrans.reshape(h, w, 1), ref_cam, view_cam, c(d_ref[0, ..., 0]), method='nearest')
+    gerr = O.absdiff_mask(wd, c(d_ref[0]), mg)
+    ops.tile_planes(gerr, geo, 17)
+    ops.tile_planes(c(d_ref[0]), geo, 18)
+    assert torch.equal(geo.cpu(), want['geo_group'][0])
+
+    hull = ops.visual_hull(c(d_ref[0, ..., 0]), vtrans, H, dsg, dig)
+    assert torch.equal(hull.cpu(), want['vis_hull'][0, ..., 0])
+
+
+@pytest.mark.parametrize('D,h,w', [(32, 32, 40), (192, 16, 24), (1, 5, 7), (7, 3, 130)])
+def test_softargmin(cuda, D, h, w):
+    from atvsnet_amd import ops
+    g = torch.Generator().manual_seed(D)
+    cost = 6.0 * torch.randn(1, D, h, w, generator=g)
+    ds, di = torch.tensor([0.05]), torch.tensor([0.31 / max(D, 1)])
+    want = OM.prob2depth(cost, D, ds, di)[0, ..., 0]
+    got = ops.softargmin(cost[0].to(cuda), ds.to(cuda), di.to(cuda)).cpu()
+    assert torch.allclose(got, want, rtol=2e-6, atol=1e-8)
+    _, want_up = OM.prob2depth_upsample(cost, D, ds, di)
+    got_up = ops.upsample_softargmin(cost[0].to(cuda), ds.to(cuda), di.to(cuda)).cpu()
+    assert got_up.shape == (4 * h, 4 * w)
+    assert torch.allclose(got_up, want_up[0, ..., 0], rtol=2e-6, atol=1e-8)
+
+
+def test_softargmin_known_answers(cuda):
+    """one-hot minimum -> that plane's delta; constant cost -> mid-range."""
+    from atvsnet_amd import ops
+    D, h, w = 16, 4, 6
+    ds, di = torch.tensor([0.1], device=cuda), torch.tensor([0.02], device=cuda)
+    cost = torch.full((D, h, w), 50.0, device=cuda)
+    cost[5] = -50.0
+    assert torch.allclose(ops.softargmin(cost, ds, di).cpu(), torch.full((h, w), 0.1 + 5 * 0.02), rtol=1e-6)
+    flat = torch.zeros(D, h, w, device=cuda)
+    assert torch.allclose(ops.softargmin(flat, ds, di).cpu(), torch.full((h, w), 0.1 + 7.5 * 0.02), rtol=1e-6)
