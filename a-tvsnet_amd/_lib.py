@@ -83,4 +83,6 @@ def lib():
             fn = getattr(_lib, name)          # AttributeError if the library lacks a declared symbol
             fn.restype = ctypes.c_int
         _lib.atvs_target_arch.restype = ctypes.c_char_p
+        _lib.atvs_conv_num_blocks.restype = ctypes.c_long
+        _lib.atvs_channel_stats_num_blocks.restype = ctypes.c_long
     return _lib

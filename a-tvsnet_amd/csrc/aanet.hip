@@ -1,0 +1,165 @@
+// Attention aggregation over source views (AANet) -- the cross-view softmax and
+// weighted sum (gfx950).  The two 3x3x3 8->8 convolutions per view run in conv.hip as
+// ONE 8->16 convolution with a ReLU epilogue (shared | unique weights side by side),
+// giving SR_n = [S_n | R_n] (V,16) per view.
+//
+// Reference: Network.attention_activation / attention_aggregation,
+// /root/reference/cnn_wrapper/network.py:282-351, 378-408 with second_weight=True,
+// relu=True, biased=False (call sites cnn_wrapper/atvsnet.py:202,234):
+//   S_sum = sum_n S_n ;  U_n = R_n - S_n + S_sum ;  score = softmax_n(U) ;
+//   out   = sum_n score_n * X_n
+// HBM-bound element-wise work over V*C values: every SR_n and X_n is read once.
+//
+// The *_partial kernels split the same arithmetic at its three reductions over views
+// so that views sharded across GPUs combine with three all-reduces (SUM, MAX, SUM).
+#include "common.h"
+
+#define AANET_MAX_VIEWS 16
+
+struct ViewPtrs {
+  const float* sr[AANET_MAX_VIEWS];
+  const float* x[AANET_MAX_VIEWS];
+};
+
+// one lane per float4 of the (V, 8) output
+__global__ __launch_bounds__(256) void aanet_combine_kernel(ViewPtrs p, int nv, float* __restrict__ out, long n4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  long v = i >> 1;
+  int half = (int)(i & 1) * 4;
+  size_t so = (size_t)v * 16 + half, xo = (size_t)v * 8 + half;
+  float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < nv; ++n) {
+    float4 s = ld4(p.sr[n] + so);
+    ssum.x += s.x; ssum.y += s.y; ssum.z += s.z; ssum.w += s.w;
+  }
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  for (int n = 0; n < nv; ++n) {
+    float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8);
+    m.x = fmaxf(m.x, (r.x - s.x) + ssum.x);
+    m.y = fmaxf(m.y, (r.y - s.y) + ssum.y);
+    m.z = fmaxf(m.z, (r.z - s.z) + ssum.z);
+    m.w = fmaxf(m.w, (r.w - s.w) + ssum.w);
+  }
+  float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < nv; ++n) {
+    float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8);
+    den.x += expf(((r.x - s.x) + ssum.x) - m.x);
+    den.y += expf(((r.y - s.y) + ssum.y) - m.y);
+    den.z += expf(((r.z - s.z) + ssum.z) - m.z);
+    den.w += expf(((r.w - s.w) + ssum.w) - m.w);
+  }
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < nv; ++n) {
+    float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8), x = ld4(p.x[n] + xo);
+    o.x += (expf(((r.x - s.x) + ssum.x) - m.x) / den.x) * x.x;
+    o.y += (expf(((r.y - s.y) + ssum.y) - m.y) / den.y) * x.y;
+    o.z += (expf(((r.z - s.z) + ssum.z) - m.z) / den.z) * x.z;
+    o.w += (expf(((r.w - s.w) + ssum.w) - m.w) / den.w) * x.w;
+  }
+  st4(out + xo, o);
+}
+
+static int fill_ptrs(ViewPtrs* p, const float* const* sr, const float* const* x, int nv) {
+  if (!sr || nv <= 0 || nv > AANET_MAX_VIEWS) return ATVS_ERR_SHAPE;
+  for (int n = 0; n < AANET_MAX_VIEWS; ++n) {
+    p->sr[n] = n < nv ? sr[n] : nullptr;
+    p->x[n] = (x && n < nv) ? x[n] : nullptr;
+    if (n < nv && (!p->sr[n] || (x && !p->x[n]))) return ATVS_ERR_NULL;
+  }
+  return ATVS_OK;
+}
+
+// sr_ptrs / x_ptrs: HOST arrays of nv device pointers: SR_n (V,16), X_n (V,8).  out (V,8).
+extern "C" int atvs_aanet_combine(const float* const* sr_ptrs, const float* const* x_ptrs, int nv, float* out,
+                                  long V, atvs_stream_t stream) {
+  if (!out || !x_ptrs) return ATVS_ERR_NULL;
+  if (V <= 0) return ATVS_ERR_SHAPE;
+  ViewPtrs p;
+  int rc = fill_ptrs(&p, sr_ptrs, x_ptrs, nv);
+  if (rc) return rc;
+  long n4 = V * 2;
+  hipLaunchKernelGGL(aanet_combine_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, as_stream(stream), p, nv, out, n4);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---- view-sharded form -----------------------------------------------------
+// stage 0: ssum_local[v,c] = sum over local views of S_n[v,c]            -> all-reduce SUM
+// stage 1: umax_local[v,c] = max over local views of U_n[v,c]            -> all-reduce MAX
+// stage 2: acc_local[0][v,c] = sum e_n, acc_local[1][v,c] = sum e_n X_n   -> all-reduce SUM
+// stage 3: out = acc[1] / acc[0]
+__global__ __launch_bounds__(256) void aanet_partial_kernel(ViewPtrs p, int nv, int stage, const float* __restrict__ ssum,
+                                                            const float* __restrict__ umax, float* __restrict__ out,
+                                                            long n4, long V8) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  long v = i >> 1;
+  int half = (int)(i & 1) * 4;
+  size_t so = (size_t)v * 16 + half, xo = (size_t)v * 8 + half;
+  if (stage == 0) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int n = 0; n < nv; ++n) {
+      float4 s = ld4(p.sr[n] + so);
+      a.x += s.x; a.y += s.y; a.z += s.z; a.w += s.w;
+    }
+    st4(out + xo, a);
+    return;
+  }
+  float4 ss = ld4(ssum + xo);
+  if (stage == 1) {
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (int n = 0; n < nv; ++n) {
+      float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8);
+      m.x = fmaxf(m.x, (r.x - s.x) + ss.x);
+      m.y = fmaxf(m.y, (r.y - s.y) + ss.y);
+      m.z = fmaxf(m.z, (r.z - s.z) + ss.z);
+      m.w = fmaxf(m.w, (r.w - s.w) + ss.w);
+    }
+    st4(out + xo, m);
+    return;
+  }
+  float4 m = ld4(umax + xo);
+  float4 den = make_float4(0.f, 0.f, 0.f, 0.f), num = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int n = 0; n < nv; ++n) {
+    float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8), x = ld4(p.x[n] + xo);
+    float ex = expf(((r.x - s.x) + ss.x) - m.x), ey = expf(((r.y - s.y) + ss.y) - m.y);
+    float ez = expf(((r.z - s.z) + ss.z) - m.z), ew = expf(((r.w - s.w) + ss.w) - m.w);
+    den.x += ex; den.y += ey; den.z += ez; den.w += ew;
+    num.x += ex * x.x; num.y += ey * x.y; num.z += ez * x.z; num.w += ew * x.w;
+  }
+  st4(out + xo, den);
+  st4(out + V8 + xo, num);
+}
+
+extern "C" int atvs_aanet_partial(const float* const* sr_ptrs, const float* const* x_ptrs, int nv, int stage,
+                                  const float* ssum, const float* umax, float* out, long V, atvs_stream_t stream) {
+  if (!out) return ATVS_ERR_NULL;
+  if (V <= 0 || stage < 0 || stage > 2) return ATVS_ERR_SHAPE;
+  if ((stage >= 1 && !ssum) || (stage == 2 && (!umax || !x_ptrs))) return ATVS_ERR_NULL;
+  ViewPtrs p;
+  int rc = fill_ptrs(&p, sr_ptrs, stage == 2 ? x_ptrs : nullptr, nv);
+  if (rc) return rc;
+  long n4 = V * 2;
+  hipLaunchKernelGGL(aanet_partial_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, as_stream(stream), p, nv, stage, ssum, umax,
+                     out, n4, V * 8);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+__global__ __launch_bounds__(256) void divide_kernel(const float* __restrict__ num, const float* __restrict__ den,
+                                                     float* __restrict__ out, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  float4 a = ld4(num + i), b = ld4(den + i);
+  st4(out + i, make_float4(a.x / b.x, a.y / b.y, a.z / b.z, a.w / b.w));
+}
+
+// out = num / den over n floats (n % 4 == 0)
+extern "C" int atvs_divide(const float* num, const float* den, float* out, long n, atvs_stream_t stream) {
+  if (!num || !den || !out) return ATVS_ERR_NULL;
+  if (n <= 0 || (n % 4) != 0) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL(divide_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), num, den, out, n);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

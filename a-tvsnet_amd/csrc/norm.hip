@@ -1,0 +1,168 @@
+// Training-mode batch normalisation (batch statistics at inference, reference
+// quirk C1) and the element-wise glue around the convolutions (gfx950).
+//
+// Reference: tf.layers.batch_normalization(center=False, scale=False, training=True)
+// at /root/reference/cnn_wrapper/network.py:206-212, 541-547; slim.batch_norm
+// (center=True) at :570-571; tf.add_n at :695-697.  y = (x - mean) * rsqrt(var + 1e-3)
+// [+ beta], biased variance over every axis but the channel.
+//
+// Statistics are deterministic: fixed-shape per-workgroup partial sums (written by
+// the convolution epilogue or by channel_stats below) are tree-reduced in double.
+#include "common.h"
+
+// partials: [nblocks][2][cpad] doubles (sum, sum of squares).  params out: [3][C]
+// floats = mean, rsqrt(var+eps), beta.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, long nblocks, int cpad,
+                                                          double count, const float* __restrict__ beta, float eps,
+                                                          float* __restrict__ params, int C) {
+  __shared__ double sm[2][256];
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  for (long b = threadIdx.x; b < nblocks; b += 256) {
+    s += partials[(b * 2 + 0) * cpad + c];
+    q += partials[(b * 2 + 1) * cpad + c];
+  }
+  sm[0][threadIdx.x] = s;
+  sm[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      sm[0][threadIdx.x] += sm[0][threadIdx.x + o];
+      sm[1][threadIdx.x] += sm[1][threadIdx.x + o];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    double mean = sm[0][0] / count;
+    double var = sm[1][0] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    params[c] = (float)mean;
+    params[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+    params[2 * C + c] = beta ? beta[c] : 0.f;
+  }
+}
+
+extern "C" int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, long count, const float* beta,
+                                float eps, float* params, int C, atvs_stream_t stream) {
+  if (!stats_partial || !params) return ATVS_ERR_NULL;
+  if (num_blocks <= 0 || C <= 0 || cpad < C || count <= 0) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats_partial, num_blocks, cpad,
+                     (double)count, beta, eps, params, C);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// per-channel partial sums of an arbitrary (rows, C) tensor, C <= 256
+#define STATS_ROWS_PER_BLOCK 4096
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long rows, int C,
+                                                            double* __restrict__ partials) {
+  __shared__ double sm[2][256];
+  const int tpb = (256 / C) * C;        // active threads, multiple of C
+  const int rstride = tpb / C;
+  const int t = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  if (t < tpb) {
+    const int c = t % C;
+    long r0 = (long)blockIdx.x * STATS_ROWS_PER_BLOCK;
+    long r1 = min(rows, r0 + STATS_ROWS_PER_BLOCK);
+    float fs = 0.f, fq = 0.f;
+    int k = 0;
+    for (long r = r0 + t / C; r < r1; r += rstride) {
+      float v = x[(size_t)r * C + c];
+      fs += v;
+      fq += v * v;
+      if (++k == 32) {   // bound the fp32 chains
+        s += fs; q += fq; fs = fq = 0.f; k = 0;
+      }
+    }
+    s += fs;
+    q += fq;
+  }
+  sm[0][t] = s;
+  sm[1][t] = q;
+  __syncthreads();
+  if (t < C) {
+    double a = 0.0, b = 0.0;
+    for (int k = t; k < tpb; k += C) {
+      a += sm[0][k];
+      b += sm[1][k];
+    }
+    partials[((size_t)blockIdx.x * 2 + 0) * C + t] = a;
+    partials[((size_t)blockIdx.x * 2 + 1) * C + t] = b;
+  }
+}
+
+extern "C" long atvs_channel_stats_num_blocks(long rows) { return (rows + STATS_ROWS_PER_BLOCK - 1) / STATS_ROWS_PER_BLOCK; }
+
+extern "C" int atvs_channel_stats(const float* x, long rows, int C, double* stats_partial, atvs_stream_t stream) {
+  if (!x || !stats_partial) return ATVS_ERR_NULL;
+  if (rows <= 0 || C <= 0 || C > 256) return ATVS_ERR_SHAPE;
+  long nb = atvs_channel_stats_num_blocks(rows);
+  hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), x, rows, C, stats_partial);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ params,
+                                                       float* __restrict__ y, long n, int C, int relu) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
+  if (i >= n) return;
+  int c = (int)(i % C);
+  if (VEC == 4) {
+    float4 v = ld4(x + i), m = ld4(params + c), s = ld4(params + C + c), b = ld4(params + 2 * C + c);
+    v.x = (v.x - m.x) * s.x + b.x;
+    v.y = (v.y - m.y) * s.y + b.y;
+    v.z = (v.z - m.z) * s.z + b.z;
+    v.w = (v.w - m.w) * s.w + b.w;
+    if (relu) {
+      v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    st4(y + i, v);
+  } else {
+    float v = (x[i] - params[c]) * params[C + c] + params[2 * C + c];
+    y[i] = relu ? fmaxf(v, 0.f) : v;
+  }
+}
+
+extern "C" int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int relu,
+                             atvs_stream_t stream) {
+  if (!x || !params || !y) return ATVS_ERR_NULL;
+  if (rows <= 0 || C <= 0) return ATVS_ERR_SHAPE;
+  long n = rows * C;
+  if (C % 4 == 0)
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, relu);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, relu);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// tf.add_n of 2 or 3 tensors: (a + b) + c
+__global__ __launch_bounds__(256) void add_n_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                    const float* __restrict__ c, float* __restrict__ y, long n) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i + 3 < n) {
+    float4 u = ld4(a + i), v = ld4(b + i);
+    u.x += v.x; u.y += v.y; u.z += v.z; u.w += v.w;
+    if (c) {
+      float4 w = ld4(c + i);
+      u.x += w.x; u.y += w.y; u.z += w.z; u.w += w.w;
+    }
+    st4(y + i, u);
+  } else {
+    for (; i < n; ++i) {
+      float u = a[i] + b[i];
+      if (c) u += c[i];
+      y[i] = u;
+    }
+  }
+}
+
+extern "C" int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream) {
+  if (!a || !b || !y) return ATVS_ERR_NULL;
+  if (n <= 0) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL(add_n_kernel, dim3(cdiv((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), a, b, c, y, n);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

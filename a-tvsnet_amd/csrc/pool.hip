@@ -1,0 +1,109 @@
+// Spatial-pyramid-pooling helpers of the 2-D feature tower (gfx950): SAME average
+// pooling, align_corners bilinear resize, channel-slice copy (tf.concat).
+//
+// Reference: tf.layers.average_pooling2d at /root/reference/cnn_wrapper/network.py:665-671
+// (SAME: mean over the VALID window elements only), tf.image.resize_images(BILINEAR,
+// align_corners=True) at :649-655, tf.concat at :691-693; used by ResNetDS2SPP,
+// /root/reference/cnn_wrapper/atvsnet.py:269-290.  All trivially small next to the volumes.
+#include "common.h"
+
+// one workgroup per output pixel; threads = (window slices) x channels
+__global__ __launch_bounds__(256) void avg_pool_same_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
+                                                            int W, int C, int Ho, int Wo, int k, int s, int pad_t,
+                                                            int pad_l) {
+  __shared__ float sm[256];
+  const int oy = blockIdx.y, ox = blockIdx.x;
+  const int y0 = max(oy * s - pad_t, 0), y1 = min(oy * s - pad_t + k, H);
+  const int x0 = max(ox * s - pad_l, 0), x1 = min(ox * s - pad_l + k, W);
+  const int ww = x1 - x0, n = (y1 - y0) * ww;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int cw = min(C - cb, 256);         // channels in this pass
+    const int slices = 256 / cw;
+    const int t = threadIdx.x;
+    float acc = 0.f;
+    if (t < slices * cw) {
+      const int c = cb + t % cw;
+      for (int i = t / cw; i < n; i += slices) {
+        int yy = y0 + i / ww, xx = x0 + i % ww;
+        acc += x[((size_t)yy * W + xx) * C + c];
+      }
+    }
+    sm[t] = acc;
+    __syncthreads();
+    if (t < cw) {
+      float v = 0.f;
+      for (int j = 0; j < slices; ++j) v += sm[j * cw + t];
+      y[((size_t)oy * Wo + ox) * C + cb + t] = v / (float)n;
+    }
+    __syncthreads();
+  }
+}
+
+extern "C" int atvs_avg_pool_same(const float* x, float* y, int H, int W, int C, int pool, int stride,
+                                  atvs_stream_t stream) {
+  if (!x || !y) return ATVS_ERR_NULL;
+  if (H <= 0 || W <= 0 || C <= 0 || pool <= 0 || stride <= 0) return ATVS_ERR_SHAPE;
+  int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  int ph = max((Ho - 1) * stride + pool - H, 0), pw = max((Wo - 1) * stride + pool - W, 0);
+  hipLaunchKernelGGL(avg_pool_same_kernel, dim3(Wo, Ho), dim3(256), 0, as_stream(stream), x, y, H, W, C, Ho, Wo, pool,
+                     stride, ph / 2, pw / 2);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// out written into a channel slice [c_off, c_off+C) of rows of width ld
+__global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
+                                                              int W, int C, int Ho, int Wo, float sy, float sx, int ld,
+                                                              int c_off) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long n = (long)Ho * Wo * C;
+  if (i >= n) return;
+  int c = (int)(i % C);
+  long pix = i / C;
+  int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+  float fy = (float)oy * sy, fx = (float)ox * sx;
+  int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+  int y1 = min((int)ceilf(fy), H - 1), x1 = min((int)ceilf(fx), W - 1);
+  float ly = fy - (float)y0, lx = fx - (float)x0;
+  float tl = x[((size_t)y0 * W + x0) * C + c], tr = x[((size_t)y0 * W + x1) * C + c];
+  float bl = x[((size_t)y1 * W + x0) * C + c], br = x[((size_t)y1 * W + x1) * C + c];
+  float t = tl + (tr - tl) * lx;
+  float b = bl + (br - bl) * lx;
+  y[(size_t)pix * ld + c_off + c] = t + (b - t) * ly;
+}
+
+extern "C" int atvs_resize_bilinear(const float* x, float* y, int H, int W, int C, int Ho, int Wo, int ld_out, int c_off,
+                                    atvs_stream_t stream) {
+  if (!x || !y) return ATVS_ERR_NULL;
+  if (H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || c_off < 0 || c_off + C > ld_out) return ATVS_ERR_SHAPE;
+  float sy = (Ho > 1) ? (float)((double)(H - 1) / (double)(Ho - 1)) : 0.f;
+  float sx = (Wo > 1) ? (float)((double)(W - 1) / (double)(Wo - 1)) : 0.f;
+  long n = (long)Ho * Wo * C;
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, y, H, W, C, Ho, Wo,
+                     sy, sx, ld_out, c_off);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// dst[r, dst_off + c] = src[r, src_off + c], c < C  (tf.concat / un-stacking a trailing axis)
+__global__ __launch_bounds__(256) void copy_channels_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            long rows, int C, int ld_src, int src_off, int ld_dst,
+                                                            int dst_off) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * C) return;
+  long r = i / C;
+  int c = (int)(i % C);
+  dst[(size_t)r * ld_dst + dst_off + c] = src[(size_t)r * ld_src + src_off + c];
+}
+
+extern "C" int atvs_copy_channels(const float* src, float* dst, long rows, int C, int ld_src, int src_off, int ld_dst,
+                                  int dst_off, atvs_stream_t stream) {
+  if (!src || !dst) return ATVS_ERR_NULL;
+  if (rows <= 0 || C <= 0 || src_off < 0 || dst_off < 0 || src_off + C > ld_src || dst_off + C > ld_dst)
+    return ATVS_ERR_SHAPE;
+  long n = rows * C;
+  hipLaunchKernelGGL(copy_channels_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), src, dst, rows, C,
+                     ld_src, src_off, ld_dst, dst_off);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

@@ -175,3 +175,329 @@ def upsample_softargmin(cost, depth_start, depth_interval, up_scale=4):
         _call('atvs_upsample_softargmin', _p(cost), _p(depth_start), _p(depth_interval), _p(out), D, h, w,
               int(up_scale), _stream())
     return out
+
+
+# --------------------------------------------------------------------------- convolutions
+
+def same_pad(in_size, k, s, d=1):
+    """TF padding='SAME' -> (pad_before, out_size); end-heavy when the total is odd."""
+    out = -(-in_size // s)
+    total = max((out - 1) * s + (k - 1) * d + 1 - in_size, 0)
+    return total // 2, out
+
+
+def conv_taps(ksize, dilation, pad_before):
+    """Tap list (index in the TF kernel, dz, dy, dx) of a forward convolution."""
+    kd, kh, kw = ksize
+    taps = []
+    for a in range(kd):
+        for b in range(kh):
+            for c in range(kw):
+                taps.append(((a * kh + b) * kw + c, a * dilation - pad_before[0], b * dilation - pad_before[1],
+                             c * dilation - pad_before[2]))
+    return tuple(taps)
+
+
+def deconv_s2_class_taps(parity):
+    """Taps of one output-parity class of conv3d_transpose(k=3, stride=2, SAME):
+    out[2i+k] += in[i] W[k]  =>  even outputs 2j take (k=0, i=j), (k=2, i=j-1); odd 2j+1 take (k=1, i=j)."""
+    per_axis = [((0, 0), (2, -1)) if p == 0 else ((1, 0),) for p in parity]
+    taps = []
+    for ka, oa in per_axis[0]:
+        for kb, ob in per_axis[1]:
+            for kc, oc in per_axis[2]:
+                taps.append(((ka * 3 + kb) * 3 + kc, oa, ob, oc))
+    return tuple(taps)
+
+
+_pack_cache = {}
+
+
+class _Packed(object):
+    __slots__ = ('wp', 'tab', 'ntaps', 'vec', 'ksteps', 'ntiles', 'cin', 'cout')
+
+
+def pack_conv_weights(key, w_host, taps, transposed, device):
+    """Packed weights + group table on `device` for (variable, tap list); cached."""
+    import numpy as np
+    ck = (key, taps, bool(transposed), str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)
+    cin, cout = (w.shape[-1], w.shape[-2]) if transposed else (w.shape[-2], w.shape[-1])
+    ntaps = len(taps)
+    L = _lib.lib()
+    vec, ks, nt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    pf, ti = ctypes.c_long(), ctypes.c_long()
+    rc = L.atvs_conv_pack_size(ntaps, cin, cout, ctypes.byref(vec), ctypes.byref(ks), ctypes.byref(nt),
+                               ctypes.byref(pf), ctypes.byref(ti))
+    if rc:
+        raise RuntimeError('atvs_conv_pack_size failed (%d) for Cin=%d Cout=%d' % (rc, cin, cout))
+    packed = np.empty(pf.value, np.float32)
+    table = np.empty(ti.value, np.int32)
+    tp = np.ascontiguousarray(np.array(taps, dtype=np.int32).reshape(-1, 4))
+    rc = L.atvs_conv_pack(w.ctypes.data_as(ctypes.c_void_p), int(bool(transposed)), tp.ctypes.data_as(ctypes.c_void_p),
+                          ntaps, cin, cout, packed.ctypes.data_as(ctypes.c_void_p),
+                          table.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = ntaps, vec.value, ks.value, nt.value, cin, cout
+    if torch.device(device).type == 'meta':
+        pk.wp = pk.tab = None
+    else:
+        pk.wp = torch.from_numpy(packed).to(device)
+        pk.tab = torch.from_numpy(table).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+def _pick_tile_m(M, ntiles):
+    """Largest voxel-tile count per wavefront that still leaves >= 1024 workgroups (4 per CU)."""
+    for tm in (8, 4, 2):
+        if tm * ntiles <= 16 and -(-M // (64 * tm)) >= 1024:
+            return tm
+    return 1
+
+
+class Stats(object):
+    """Per-workgroup partial sums of a tensor: feeds bn_finalize."""
+    __slots__ = ('partial', 'blocks', 'cpad', 'count')
+
+
+def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bias=None, residual=None, relu=False,
+                stats_buf=None, tile_m=None):
+    """One atvs_conv_mfma_f32 launch.  x4: (Di,Hi,Wi,Cin); y: full output (Dy,Hy,Wy,ldy)."""
+    Di, Hi, Wi, Cin = x4.shape
+    Dy, Hy, Wy, ldy = y.shape
+    Do, Ho, Wo = out_grid
+    M = Do * Ho * Wo
+    tm = tile_m or _pick_tile_m(M, pk.ntiles)
+    if _dev_ok(x4, y, bias, residual):
+        args = [_p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual), _p(y),
+                ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0),
+                Di, Hi, Wi, Cin, Do, Ho, Wo, int(in_stride), Dy, Hy, Wy, int(out_stride), int(out_off[0]),
+                int(out_off[1]), int(out_off[2]), ldy, int(y_coff), pk.cout, pk.ntaps, tm, int(bool(relu)), _stream()]
+        _call('atvs_conv_mfma_f32', *args)
+    return tm
+
+
+def conv_blocks(M, ntiles, tile_m=None):
+    tm = tile_m or _pick_tile_m(M, ntiles)
+    return -(-M // (64 * tm)), tm
+
+
+def _stats_buffer(ref, blocks, cpad):
+    return torch.empty((blocks, 2, cpad), dtype=torch.float64, device=ref.device)
+
+
+def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None, bias=None, residual=None,
+         relu=False, want_stats=False, out=None, y_coff=0):
+    """Forward convolution of a channel-last tensor x: (H,W,C) or (D,H,W,C).
+
+    w_host: TF-layout numpy kernel [k.., Cin, Cout]; `key` names it for the pack cache.
+    padding: 'SAME' | 'VALID'; explicit_pad = (before, after) per spatial axis overrides it
+    (bottleneck conv2, network.py:589-595).  Returns y or (y, Stats).
+    """
+    nsp = x.dim() - 1
+    x4 = x if nsp == 3 else x.reshape((1,) + tuple(x.shape))
+    ks = (1,) * (3 - nsp) + tuple(int(k) for k in w_host.shape[:nsp])
+    ins = x4.shape[:3]
+    pads, outs = [], []
+    for i in range(3):
+        if ks[i] == 1 and i < 3 - nsp:
+            pads.append(0)
+            outs.append(1)
+            continue
+        ax = i - (3 - nsp)
+        if explicit_pad is not None:
+            pb, pe = explicit_pad[ax]
+            pads.append(pb)
+            outs.append((ins[i] + pb + pe - ((ks[i] - 1) * dilation + 1)) // stride + 1)
+        elif padding == 'SAME':
+            pb, o = same_pad(ins[i], ks[i], stride, dilation)
+            pads.append(pb)
+            outs.append(o)
+        else:
+            pads.append(0)
+            outs.append((ins[i] - ((ks[i] - 1) * dilation + 1)) // stride + 1)
+    taps = conv_taps(ks, dilation, pads)
+    pk = pack_conv_weights(key, w_host, taps, False, x.device)
+    if pk.cin != x4.shape[3]:
+        raise ValueError('conv %s: input has %d channels, kernel wants %d' % (key, x4.shape[3], pk.cin))
+    if out is None:
+        y4 = _new(x, tuple(outs) + (pk.cout,))
+    else:
+        y4 = out if out.dim() == 4 else out.reshape((1,) + tuple(out.shape))
+        if tuple(y4.shape[:3]) != tuple(outs):
+            raise ValueError('conv %s: output buffer %s does not match %s' % (key, tuple(y4.shape), outs))
+    res4 = None
+    if residual is not None:
+        res4 = residual if residual.dim() == 4 else residual.reshape((1,) + tuple(residual.shape))
+    M = outs[0] * outs[1] * outs[2]
+    blocks, tm = conv_blocks(M, pk.ntiles)
+    st = None
+    sbuf = None
+    if want_stats:
+        sbuf = _stats_buffer(x, blocks, pk.ntiles * 16)
+        st = Stats()
+        st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
+    conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm)
+    y = out if out is not None else (y4 if nsp == 3 else y4.reshape(tuple(y4.shape[1:])))
+    return (y, st) if want_stats else y
+
+
+def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
+    """tf.layers.conv3d_transpose(3, stride 2, SAME): (D,H,W,Cin) -> (2D,2H,2W,Cout) as 8 parity classes.
+
+    w_host: TF layout [3,3,3,Cout,Cin].
+    """
+    D, H, W, Cin = x.shape
+    cout = int(w_host.shape[-2])
+    y = _new(x, (2 * D, 2 * H, 2 * W, cout))
+    M = D * H * W
+    classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
+    pks = [pack_conv_weights(key, w_host, deconv_s2_class_taps(par), True, x.device) for par in classes]
+    blocks, tm = conv_blocks(M, pks[0].ntiles)
+    cpad = pks[0].ntiles * 16
+    st = None
+    sbuf = None
+    if want_stats:
+        sbuf = _stats_buffer(x, blocks * 8, cpad)
+        st = Stats()
+        st.partial, st.blocks, st.cpad, st.count = sbuf, blocks * 8, cpad, 8 * M
+    for i, (par, pk) in enumerate(zip(classes, pks)):
+        sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
+        conv_launch(x, pk, y, (D, H, W), 1, 2, par, 0, None, None, relu, sb, tm)
+    return (y, st) if want_stats else y
+
+
+# --------------------------------------------------------------------------- batch norm / glue
+
+def channel_stats(x):
+    """Partial sums of x viewed as (rows, C)."""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    blocks = -(-rows // 4096)
+    st = Stats()
+    st.partial, st.blocks, st.cpad, st.count = _stats_buffer(x, blocks, C), blocks, C, rows
+    if _dev_ok(x):
+        _call('atvs_channel_stats', _p(x), ctypes.c_long(rows), C, ctypes.c_void_p(st.partial.data_ptr()), _stream())
+    return st
+
+
+def bn_params(st, C, ref, beta=None, eps=1e-3):
+    """Stats -> params (3,C) = (mean, rstd, beta)."""
+    params = _new(ref, (3, C))
+    if _dev_ok(ref, beta):
+        _call('atvs_bn_finalize', ctypes.c_void_p(st.partial.data_ptr()), ctypes.c_long(st.blocks), st.cpad,
+              ctypes.c_long(st.count), _p(beta), ctypes.c_float(eps), _p(params), C, _stream())
+    return params
+
+
+def bn_apply(x, params, relu=False, out=None):
+    C = x.shape[-1]
+    y = x if out is None else out
+    if _dev_ok(x, params, y):
+        _call('atvs_bn_apply', _p(x), _p(params), _p(y), ctypes.c_long(x.numel() // C), C, int(bool(relu)), _stream())
+    return y
+
+
+def batch_norm(x, st=None, beta=None, relu=False, inplace=False, eps=1e-3):
+    """Training-mode BN of x with its own batch statistics (st = Stats from the producer, else computed)."""
+    if st is None:
+        st = channel_stats(x)
+    params = bn_params(st, x.shape[-1], x, beta, eps)
+    return bn_apply(x, params, relu, out=(x if inplace else _new(x, x.shape)))
+
+
+def add_n(tensors):
+    """tf.add_n: ((a + b) + c) + ..."""
+    acc = tensors[0]
+    i = 1
+    first = True
+    while i < len(tensors):
+        b = tensors[i]
+        c = tensors[i + 1] if (first and i + 1 < len(tensors)) else None
+        out = _new(acc, acc.shape)
+        if _dev_ok(acc, b, c):
+            _call('atvs_add_n', _p(acc), _p(b), _p(c), _p(out), ctypes.c_long(acc.numel()), _stream())
+        acc = out
+        i += 2 if c is not None else 1
+        first = False
+    return acc
+
+
+def avg_pool_same(x, pool, stride):
+    H, W, C = x.shape
+    y = _new(x, (-(-H // stride), -(-W // stride), C))
+    if _dev_ok(x):
+        _call('atvs_avg_pool_same', _p(x), _p(y), H, W, C, int(pool), int(stride), _stream())
+    return y
+
+
+def resize_bilinear(x, size, out=None, c_off=0):
+    H, W, C = x.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = _new(x, (Ho, Wo, C)) if out is None else out
+    if _dev_ok(x, y):
+        _call('atvs_resize_bilinear', _p(x), _p(y), H, W, C, Ho, Wo, y.shape[-1], int(c_off), _stream())
+    return y
+
+
+def copy_channels(src, dst, C, src_off=0, dst_off=0):
+    rows = src.numel() // src.shape[-1]
+    if _dev_ok(src, dst):
+        _call('atvs_copy_channels', _p(src), _p(dst), ctypes.c_long(rows), int(C), src.shape[-1], int(src_off),
+              dst.shape[-1], int(dst_off), _stream())
+    return dst
+
+
+def concat_channels(tensors):
+    """tf.concat(axis=-1) of tensors sharing their leading dims."""
+    total = sum(t.shape[-1] for t in tensors)
+    out = _new(tensors[0], tuple(tensors[0].shape[:-1]) + (total,))
+    off = 0
+    for t in tensors:
+        copy_channels(t, out, t.shape[-1], 0, off)
+        off += t.shape[-1]
+    return out
+
+
+# --------------------------------------------------------------------------- AANet
+
+def _ptr_array(ts):
+    arr = (ctypes.c_void_p * len(ts))()
+    for i, t in enumerate(ts):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def aanet_combine(srs, xs):
+    """srs: list of (V..,16) [S|R] tensors, xs: list of (V..,8) -> sum_n softmax_n(U) X_n, shape of xs[0]."""
+    out = _new(xs[0], xs[0].shape)
+    if _dev_ok(*(list(srs) + list(xs))):
+        _call('atvs_aanet_combine', _ptr_array(srs), _ptr_array(xs), len(xs), _p(out),
+              ctypes.c_long(out.numel() // 8), _stream())
+    return out
+
+
+def aanet_partial(srs, xs, stage, ssum=None, umax=None):
+    V8 = tuple(xs[0].shape)
+    out = _new(xs[0], ((2,) + V8) if stage == 2 else V8)
+    if _dev_ok(*(list(srs) + list(xs))):
+        _call('atvs_aanet_partial', _ptr_array(srs), _ptr_array(xs), len(srs), int(stage), _p(ssum), _p(umax), _p(out),
+              ctypes.c_long(xs[0].numel() // 8), _stream())
+    return out
+
+
+def divide(num, den):
+    out = _new(num, num.shape)
+    if _dev_ok(num, den):
+        _call('atvs_divide', _p(num), _p(den), _p(out), ctypes.c_long(num.numel()), _stream())
+    return out

@@ -110,6 +110,109 @@ int atvs_softargmin(const float* cost, const float* depth_start, const float* de
 int atvs_upsample_softargmin(const float* cost, const float* depth_start, const float* depth_interval,
                              float* depth_up_out, int D, int h, int w, int up_scale, atvs_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ * Convolutions  (cnn_wrapper/network.py)
+ * ------------------------------------------------------------------------- */
+
+/* Sizes of the packed weights / group table for `ntaps` taps (see atvs_conv_pack).
+ * vec = 4 when Cin % 4 == 0 else 1; ksteps = ceil(ntaps*Cin/vec / 4); ntiles = Cout
+ * rounded up to 16, 32, 64 or 128, over 16.  Host function, no GPU work. */
+int atvs_conv_pack_size(int ntaps, int Cin, int Cout, int* vec, int* ksteps, int* ntiles,
+                        long* packed_floats, long* table_ints);
+
+/* HOST function (plain CPU loops, host pointers): arrange a TF-layout kernel for
+ * atvs_conv_mfma_f32.  w: [n_w_taps][Cin][Cout] (w_transposed = 0, tf.layers.conv2d/3d
+ * kernels [k.., Cin, Cout]) or [n_w_taps][Cout][Cin] (w_transposed = 1,
+ * conv3d_transpose kernels [k.., Cout, Cin]).  taps: ntaps x 4 int32 =
+ * (index of the tap in w, dz, dy, dx), (dz,dy,dx) = input offset relative to
+ * output_index * in_stride (SAME / explicit padding and dilation folded in; the 8
+ * parity classes of a stride-2 transposed convolution are 8 tap lists).
+ * The caller uploads `packed` and `table` to the device. */
+int atvs_conv_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
+                   float* packed, int32_t* table);
+
+/* Workgroups a launch with M = Do*Ho*Wo output voxels and `tile_m` uses
+ * (= rows of stats_partial): ceil(M / (64 * tile_m)). */
+long atvs_conv_num_blocks(long M, int tile_m);
+
+/* tf.layers.conv2d / conv3d / conv3d_transpose (one parity class per call),
+ * slim.conv2d, tf.nn.conv3d + bias_add + residual add + relu, on the fp32 matrix
+ * cores: network.py:141-215, 282-351, 510-602.
+ *   x (Di,Hi,Wi,Cin) (2-D: Di = 1); y rows of width ldy, channels [y_coff, y_coff+Cout)
+ *   of the full output tensor (Dy,Hy,Wy); this launch writes output voxels
+ *   o*out_stride + off for o in the logical grid (Do,Ho,Wo) and reads inputs at
+ *   o*in_stride + tap offset.  bias (Cout) / residual (same addressing as y,
+ *   y_coff must be 0) may be NULL.  relu != 0 applies max(.,0) last.
+ *   stats_partial: NULL, or [atvs_conv_num_blocks][2][16*ntiles] doubles receiving
+ *   per-workgroup (sum, sum of squares) of the values written, per channel, for
+ *   training-mode batch norm (network.py:206-212).  tile_m in {1,2,4,8},
+ *   tile_m * ntiles <= 16. */
+int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* group_table, const float* bias,
+                       const float* residual, float* y, double* stats_partial, int Di, int Hi, int Wi,
+                       int Cin, int Do, int Ho, int Wo, int in_stride, int Dy, int Hy, int Wy,
+                       int out_stride, int off_z, int off_y, int off_x, int ldy, int y_coff, int Cout,
+                       int ntaps, int tile_m, int relu, atvs_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Batch norm with batch statistics, element-wise glue  (cnn_wrapper/network.py)
+ * ------------------------------------------------------------------------- */
+
+/* Reduce per-workgroup partial sums [num_blocks][2][cpad] (double) to
+ * params [3][C] = (mean, rsqrt(var+eps), beta): the moments of
+ * tf.layers.batch_normalization(training=True) / slim.batch_norm, network.py:206-212,
+ * 541-547, 570-571.  count = elements per channel.  beta (C) or NULL. */
+int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, long count, const float* beta,
+                     float eps, float* params, int C, atvs_stream_t stream);
+
+/* Partial sums of an arbitrary (rows, C) tensor, C <= 256, in the layout above with
+ * cpad = C and atvs_channel_stats_num_blocks(rows) blocks. */
+long atvs_channel_stats_num_blocks(long rows);
+int atvs_channel_stats(const float* x, long rows, int C, double* stats_partial, atvs_stream_t stream);
+
+/* y = (x - mean) * rstd + beta [, relu]; y may alias x. */
+int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int relu,
+                  atvs_stream_t stream);
+
+/* tf.add_n of two or three tensors (c may be NULL), network.py:695-697. */
+int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream);
+
+/* tf.layers.average_pooling2d(padding='SAME'), network.py:665-671: x (H,W,C) ->
+ * y (ceil(H/stride), ceil(W/stride), C), mean over the valid window elements. */
+int atvs_avg_pool_same(const float* x, float* y, int H, int W, int C, int pool, int stride,
+                       atvs_stream_t stream);
+
+/* tf.image.resize_images(BILINEAR, align_corners=True), network.py:649-655:
+ * x (H,W,C) -> y (Ho,Wo,ld_out)[..., c_off:c_off+C]. */
+int atvs_resize_bilinear(const float* x, float* y, int H, int W, int C, int Ho, int Wo, int ld_out, int c_off,
+                         atvs_stream_t stream);
+
+/* tf.concat along channels / un-stacking a trailing axis, network.py:691-693:
+ * dst[r, dst_off + c] = src[r, src_off + c], c < C. */
+int atvs_copy_channels(const float* src, float* dst, long rows, int C, int ld_src, int src_off, int ld_dst,
+                       int dst_off, atvs_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * AANet aggregation over views  (cnn_wrapper/network.py:282-351, 378-408)
+ * ------------------------------------------------------------------------- */
+
+/* sr_ptrs / x_ptrs: HOST arrays of nv (<= 16) device pointers.  SR_n (V,16) =
+ * [relu(conv(X_n, W_shared)) | relu(conv(X_n, W_unique))], X_n (V,8).
+ * out (V,8) = sum_n softmax_n(R_n - S_n + sum_m S_m) * X_n. */
+int atvs_aanet_combine(const float* const* sr_ptrs, const float* const* x_ptrs, int nv, float* out, long V,
+                       atvs_stream_t stream);
+
+/* The same arithmetic split at its three reductions over views, for views sharded
+ * across GPUs (all-reduce SUM / MAX / SUM between stages):
+ *   stage 0: out (V,8) = sum_local S_n
+ *   stage 1: out (V,8) = max_local U_n                (needs ssum)
+ *   stage 2: out (2,V,8) = [sum e_n ; sum e_n * X_n]   (needs ssum, umax, x_ptrs) */
+int atvs_aanet_partial(const float* const* sr_ptrs, const float* const* x_ptrs, int nv, int stage,
+                       const float* ssum, const float* umax, float* out, long V, atvs_stream_t stream);
+
+/* out = num / den, n % 4 == 0 (last step of the sharded AANet). */
+int atvs_divide(const float* num, const float* den, float* out, long n, atvs_stream_t stream);
+
+
 #ifdef __cplusplus
 }
 #endif

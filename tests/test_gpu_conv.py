@@ -1,0 +1,207 @@
+"""-m gpu: MFMA convolution / batch-norm / pooling kernels (through the C-ABI) vs the CPU oracle.
+
+Floating point: fp32 MFMA products are exact fp32 FMAs, only the summation order
+differs from the oracle's (oneDNN) -> tolerance 2e-5 * max|ref| (stated per test).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import tf_ops as T
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return scale * torch.randn(*shape, generator=g)
+
+
+def _close(got, want, tol=2e-5):
+    scale = float(want.abs().max()) + 1e-30
+    err = float((got - want).abs().max())
+    assert err <= tol * scale, 'max err %.3e vs scale %.3e' % (err, scale)
+
+
+CONV3D = [
+    # D, H, W, Cin, Cout, stride
+    (8, 8, 16, 64, 8, 1),
+    (8, 8, 16, 64, 16, 2),
+    (6, 10, 12, 8, 8, 1),
+    (4, 6, 10, 16, 32, 2),
+    (4, 4, 5, 64, 64, 1),
+    (5, 7, 9, 48, 8, 1),
+    (5, 7, 9, 19, 8, 1),
+    (5, 7, 9, 1, 8, 1),
+    (6, 6, 6, 8, 1, 1),
+    (3, 5, 33, 32, 16, 2),
+]
+
+
+@pytest.mark.parametrize('D,H,W,Cin,Cout,stride', CONV3D)
+def test_conv3d_same(cuda, D, H, W, Cin, Cout, stride):
+    from atvsnet_amd import ops
+    x = _rand((1, D, H, W, Cin), 1)
+    w = _rand((3, 3, 3, Cin, Cout), 2, 0.2)
+    want = T.conv(x, w, stride, 'SAME')[0]
+    got, st = ops.conv(x[0].to(cuda), ('t', D, H, W, Cin, Cout, stride), w.numpy(), stride=stride, want_stats=True)
+    assert tuple(got.shape) == tuple(want.shape)
+    _close(got.cpu(), want)
+    # statistics epilogue: per-channel sum / sum of squares of what was written
+    s = st.partial.sum(0).cpu()
+    _close(s[0, :Cout].float(), want.reshape(-1, Cout).double().sum(0).float(), 1e-5)
+    _close(s[1, :Cout].float(), (want.reshape(-1, Cout).double() ** 2).sum(0).float(), 1e-5)
+
+
+@pytest.mark.parametrize('tile_m', [1, 2, 4, 8])
+def test_conv3d_tile_variants(cuda, tile_m):
+    from atvsnet_amd import ops
+    x = _rand((1, 6, 9, 21, 16), 3)
+    w = _rand((3, 3, 3, 16, 16), 4, 0.2)
+    want = T.conv(x, w, 1, 'SAME')[0]
+    taps = ops.conv_taps((3, 3, 3), 1, (1, 1, 1))
+    pk = ops.pack_conv_weights(('tv', tile_m), w.numpy(), taps, False, cuda)
+    y = torch.empty(6, 9, 21, 16, device=cuda)
+    ops.conv_launch(x[0].to(cuda), pk, y, (6, 9, 21), 1, 1, (0, 0, 0), 0, tile_m=tile_m)
+    _close(y.cpu(), want)
+
+
+CONV2D = [
+    # H, W, Cin, Cout, k, stride, rate
+    (32, 40, 3, 32, 3, 2, 1),
+    (16, 20, 32, 32, 3, 1, 1),
+    (16, 20, 64, 64, 3, 1, 2),
+    (16, 20, 128, 128, 3, 1, 4),
+    (16, 20, 32, 64, 1, 2, 1),
+    (9, 13, 320, 128, 3, 1, 1),
+    (9, 13, 128, 32, 1, 1, 1),
+    (33, 41, 3, 16, 1, 4, 1),
+    (2, 3, 128, 32, 3, 1, 1),
+    (1, 1, 128, 32, 3, 1, 1),
+]
+
+
+@pytest.mark.parametrize('H,W,Cin,Cout,k,stride,rate', CONV2D)
+def test_conv2d_same_bias_relu(cuda, H, W, Cin, Cout, k, stride, rate):
+    from atvsnet_amd import ops
+    x = _rand((1, H, W, Cin), 5)
+    w = _rand((k, k, Cin, Cout), 6, 0.2)
+    b = _rand((Cout,), 7)
+    want = torch.clamp(T.conv(x, w, stride, 'SAME', rate, bias=b), min=0)[0]
+    got = ops.conv(x[0].to(cuda), ('c2', H, W, Cin, Cout, k, stride, rate), w.numpy(), stride=stride, dilation=rate,
+                   bias=b.to(cuda), relu=True)
+    assert tuple(got.shape) == tuple(want.shape)
+    _close(got.cpu(), want)
+
+
+@pytest.mark.parametrize('stride', [2, 4])
+def test_conv2d_explicit_pad_valid_with_residual(cuda, stride):
+    """bottleneck conv2 with stride (network.py:589-595) and the fused shortcut add of conv3."""
+    from atvsnet_amd import ops
+    x = _rand((1, 32, 40, 16), 8)
+    w = _rand((3, 3, 16, 16), 9, 0.2)
+    b = _rand((16,), 10)
+    want = T.conv(x, w, stride, 'VALID', 1, bias=b, explicit_pad=[(1, 1), (1, 1)])[0]
+    res = _rand(tuple(want.shape), 11)
+    got = ops.conv(x[0].to(cuda), ('c2e', stride), w.numpy(), stride=stride, explicit_pad=[(1, 1), (1, 1)],
+                   bias=b.to(cuda), residual=res.to(cuda))
+    _close(got.cpu(), want + res)
+
+
+@pytest.mark.parametrize('D,H,W,Cin,Cout', [(3, 4, 5, 64, 32), (4, 4, 4, 32, 16), (6, 5, 7, 16, 8)])
+def test_conv3d_transpose(cuda, D, H, W, Cin, Cout):
+    from atvsnet_amd import ops
+    x = _rand((1, D, H, W, Cin), 12)
+    w = _rand((3, 3, 3, Cout, Cin), 13, 0.2)
+    want = T.conv3d_transpose_same(x, w, 2)[0]
+    got, st = ops.conv3d_transpose_s2(x[0].to(cuda), ('dc', D, H, W, Cin, Cout), w.numpy(), want_stats=True)
+    assert tuple(got.shape) == (2 * D, 2 * H, 2 * W, Cout)
+    _close(got.cpu(), want)
+    s = st.partial.sum(0).cpu()
+    _close(s[0, :Cout].float(), want.reshape(-1, Cout).double().sum(0).float(), 1e-5)
+
+
+def test_conv_writes_channel_slice(cuda):
+    from atvsnet_amd import ops
+    x = _rand((1, 4, 6, 7, 8), 14)
+    w = _rand((3, 3, 3, 8, 8), 15, 0.2)
+    want = T.conv(x, w, 1, 'SAME')[0]
+    buf = torch.full((4, 6, 7, 32), -7.0, device=cuda)
+    ops.conv(x[0].to(cuda), 'slice', w.numpy(), out=buf, y_coff=16)
+    out = buf.cpu()
+    _close(out[..., 16:24], want)
+    assert torch.all(out[..., :16] == -7.0) and torch.all(out[..., 24:] == -7.0)
+
+
+@pytest.mark.parametrize('shape,beta', [((6, 7, 9, 8), False), ((33, 41, 3), True), ((10, 12, 128), True), ((2, 3, 32), False)])
+def test_batch_norm_train(cuda, shape, beta):
+    """training-mode BN, eps 1e-3, biased variance; tolerance 1e-5 absolute (outputs are O(1))."""
+    from atvsnet_amd import ops
+    x = _rand((1,) + shape, 16, 3.0) + 5.0
+    b = _rand((shape[-1],), 17) if beta else None
+    want = torch.clamp(T.batch_norm_train(x, beta=b), min=0)[0]
+    got = ops.batch_norm(x[0].to(cuda), beta=(b.to(cuda) if beta else None), relu=True)
+    assert float((got.cpu() - want).abs().max()) < 1e-5
+    # known answer: mean 0, variance s^2/(s^2+eps) before relu
+    raw = ops.batch_norm(x[0].to(cuda), relu=False).cpu().reshape(-1, shape[-1]).double()
+    v = x.reshape(-1, shape[-1]).double().var(0, unbiased=False)
+    assert float(raw.mean(0).abs().max()) < 1e-5
+    assert torch.allclose(raw.var(0, unbiased=False), v / (v + 1e-3), rtol=1e-4)
+
+
+def test_conv_bn_matches_oracle_layer(cuda):
+    from atvsnet_amd import ops
+    x = _rand((1, 6, 8, 10, 16), 18)
+    W = {'l/conv3d/kernel': _rand((3, 3, 3, 16, 32), 19, 0.1)}
+    want = nets.conv_bn(x, W, 'l', 32, 2)[0]
+    y, st = ops.conv(x[0].to(cuda), 'l', W['l/conv3d/kernel'].numpy(), stride=2, want_stats=True)
+    got = ops.batch_norm(y, st, relu=True, inplace=True)
+    assert float((got.cpu() - want).abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize('H,W,pool', [(32, 40, 64), (32, 40, 32), (32, 40, 16), (32, 40, 8), (30, 45, 8), (128, 160, 64)])
+def test_avg_pool_same_and_resize(cuda, H, W, pool):
+    from atvsnet_amd import ops
+    x = _rand((1, H, W, 128), 20)
+    want = T.avg_pool2d_same(x, pool, pool)[0]
+    got = ops.avg_pool_same(x[0].to(cuda), pool, pool)
+    assert tuple(got.shape) == tuple(want.shape)
+    _close(got.cpu(), want, 1e-5)
+    up = T.resize_bilinear_align_corners(want[None], (H, W))[0]
+    got_up = ops.resize_bilinear(got, (H, W))
+    _close(got_up.cpu(), up, 1e-5)
+
+
+def test_add_n_and_concat(cuda):
+    from atvsnet_amd import ops
+    a, b, c = _rand((5, 6, 7, 8), 21), _rand((5, 6, 7, 8), 22), _rand((5, 6, 7, 8), 23)
+    assert torch.equal(ops.add_n([a.to(cuda), b.to(cuda)]).cpu(), a + b)
+    assert torch.equal(ops.add_n([a.to(cuda), b.to(cuda), c.to(cuda)]).cpu(), (a + b) + c)
+    d = _rand((5, 6, 7, 3), 24)
+    assert torch.equal(ops.concat_channels([a.to(cuda), d.to(cuda), b.to(cuda)]).cpu(), torch.cat([a, d, b], -1))
+
+
+@pytest.mark.parametrize('nv', [1, 2, 4])
+def test_aanet(cuda, nv):
+    """AANet through the fused 8->16 conv + combine kernel vs the oracle; tolerance 1e-5 absolute."""
+    from atvsnet_amd import ops
+    D, h, w = 6, 8, 10
+    X = _rand((1, D, h, w, 8, nv), 25)
+    W = {'a/attention_activation/weight_unique': _rand((3, 3, 3, 8, 8), 26, 0.3),
+         'a/attention_activation/weight_shared': _rand((3, 3, 3, 8, 8), 27, 0.3)}
+    want = nets.attention_aggregation(X, W, 'a')[0]
+    w16 = np.concatenate([W['a/attention_activation/weight_shared'].numpy(),
+                          W['a/attention_activation/weight_unique'].numpy()], axis=-1)
+    xs = [X[0, ..., n].contiguous().to(cuda) for n in range(nv)]
+    srs = [ops.conv(x, ('aan', nv), w16, relu=True) for x in xs]
+    got = ops.aanet_combine(srs, xs)
+    assert float((got.cpu() - want).abs().max()) < 1e-5
+    if nv == 1:
+        assert float((got.cpu() - X[0, ..., 0]).abs().max()) < 1e-6
+    # the view-sharded form (three reductions) gives the same answer
+    ssum = ops.aanet_partial(srs, xs, 0)
+    umax = ops.aanet_partial(srs, xs, 1, ssum=ssum)
+    acc = ops.aanet_partial(srs, xs, 2, ssum=ssum, umax=umax)
+    got2 = ops.divide(acc[1], acc[0])
+    assert float((got2.cpu() - want).abs().max()) < 1e-5
