@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Entry point mirroring the reference's ``atvsnet/example.py`` (CLI, data layout, outputs).
+
+    python -m atvsnet_amd.atvsnet.example --root_path ../example/ --example_index 2 \
+        --pretrained_model_ckpt_path weights.npz --view_num 2
+
+* data: ``<root>/<idx>/{i.jpg, i_cam.npy, 0_gt.npy}`` (reference example.py:307-342);
+* flags: the reference's (``FLAGS``: max_d, view_num, ..., example.py:25-48);
+* outputs: ``result/pred.npy`` (H,W float32 depth), ``pred.jpg`` (viridis of the inverse depth),
+  ``error.xlsx`` (sheet ``<view_num>_view``), reference example.py:183-213, 269-299.
+
+What differs: there is no graph/session.  ``infer_twoview`` / ``infer_multiview`` run the whole
+pipeline on one MI355X without leaving the device -- the reference bounces every per-view
+(D,h,w,8) volume through host numpy between ``sess.run`` calls (example.py:144-181).  The
+reference feature tower is computed once per depth map instead of once per source view.
+
+Weights: the reference restores a TF-1.5 checkpoint that is not distributed with it.  Here
+``--pretrained_model_ckpt_path`` takes an ``.npz`` of ``{tf_variable_name: array}`` (see
+variables.variable_specs()); ``--synthetic_weights`` uses the seeded random initialisation.
+"""
+from __future__ import print_function
+
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+from .. import variables
+from ..flags import FLAGS
+from ..tools.common import Notify
+from ..tools import xlsx
+from .eval_errors import acc_metrics_namelist, calc_error, err_metrics_namelist
+from .model import (TVSNet, TVSNet_base_siamese, TVSNet_feature_extraction, TVSNet_refine,           # noqa: F401
+                    cost_volume_aggregation, cost_volume_aggregation_refine, extract_feature_shallow, output_conv,
+                    output_conv_refine, prob2depth, prob2depth_upsample)
+from ..cnn_wrapper.atvsnet import ResNetDS2SPP_shallow_f16
+
+
+def depth_range(cams):
+    """depth_start = cams[0,0,1,3,0], depth_interval = cams[0,0,1,3,1] as 1-element device tensors
+    (reference example.py:66-69)."""
+    return cams[0, 0, 1, 3, 0:1].contiguous(), cams[0, 0, 1, 3, 1:2].contiguous()
+
+
+def infer_twoview(images, cams, max_d=None):
+    """The graph of run_test_twoview (reference example.py:239-240, 267): images (1,2,H,W,3) float32
+    BGR 0..255, cams (1,2,2,4,4), both on the device -> inverse-depth map (1,H,W,1) on the device."""
+    max_d = FLAGS.max_d if max_d is None else max_d
+    depth_start, depth_interval = depth_range(cams)
+    refined_prob_volume = TVSNet(images, cams, max_d, depth_start, depth_interval, view_i=1, ref_i=0)
+    _, depth_refined = prob2depth_upsample(refined_prob_volume, max_d, depth_start, depth_interval, out_prob_map=False)
+    return depth_refined
+
+
+def infer_multiview(images, cams, max_d=None, stages=None):
+    """The run loop of run_test_multiview (reference example.py:140-181), on the device:
+    base (per source) -> AAM1 -> refinement (per source) -> AAM2 -> x4 upsample + soft-argmin."""
+    max_d = FLAGS.max_d if max_d is None else max_d
+    n = images.shape[1]
+    assert n > 2
+    depth_start, depth_interval = depth_range(cams)
+    ref_feature = TVSNet_feature_extraction(images, 0)
+    filtered_cost_volumes, depth_views = [], []
+    for view_i in range(1, n):
+        _, _prob_b2, filtered, depth_view = TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval,
+                                                                view_i=view_i, ref_i=0, ref_feature=ref_feature)
+        filtered_cost_volumes.append(filtered)      # prob volumes are fed but unused by the reference (quirk C12)
+        depth_views.append(depth_view)
+    # AAM1
+    cost_volume_agg = cost_volume_aggregation(filtered_cost_volumes, reuse=False, keepchannel=True)
+    prob_volume_agg = output_conv(cost_volume_agg, reuse=False)
+    depth_agg_init = prob2depth(prob_volume_agg, max_d, depth_start, depth_interval, out_prob_map=False)
+    del filtered_cost_volumes
+    # refinement against the aggregated estimate
+    ref_shallow = ResNetDS2SPP_shallow_f16({'data': images[:, 0]}, is_training=True).get_output()
+    refined_cost_volumes = []
+    for view_i in range(1, n):
+        shallow = extract_feature_shallow(images, 0, view_i, ref_feature=ref_shallow)
+        _, refined_cost = TVSNet_refine(depth_agg_init, depth_views[view_i - 1], prob_volume_agg, cost_volume_agg,
+                                        images, cams, max_d, depth_start, depth_interval, view_i=view_i, ref_i=0,
+                                        shallow_features=shallow)
+        refined_cost_volumes.append(refined_cost)
+    # AAM2
+    refined_cost_volume_agg = cost_volume_aggregation_refine(refined_cost_volumes, reuse=False, keepchannel=True)
+    refined_prob_volume_agg = output_conv_refine(refined_cost_volume_agg, reuse=False)
+    _, depth_agg_refined = prob2depth_upsample(refined_prob_volume_agg, max_d, depth_start, depth_interval,
+                                               out_prob_map=False)
+    if stages is not None:
+        stages.update(depth_views=depth_views, cost_volume_agg=cost_volume_agg, prob_volume_agg=prob_volume_agg,
+                      depth_agg_init=depth_agg_init, refined_cost_volume_agg=refined_cost_volume_agg,
+                      refined_prob_volume_agg=refined_prob_volume_agg)
+    return depth_agg_refined
+
+
+def _load_weights():
+    path = FLAGS.pretrained_model_ckpt_path
+    store = variables.default_store()
+    if getattr(FLAGS, 'synthetic_weights', False):
+        store.init_synthetic(1234)
+        print(Notify.INFO, 'using seeded synthetic weights (no checkpoint)', Notify.ENDC)
+        return
+    if path is None:
+        print('FLAGS.pretrained_model_ckpt_path is None !!')
+        sys.exit()
+    if not path.endswith('.npz'):
+        raise RuntimeError('%s: TF-1.5 checkpoints are not read here; convert to an .npz of '
+                           '{tf_variable_name: array} or pass --synthetic_weights' % path)
+    store.load_npz(path)
+    print(Notify.INFO, 'pre-trained model restored from %s' % path, Notify.ENDC)
+
+
+def _save_results(savepath, out_depth_map, out_disp_map, depth_gt):
+    import matplotlib
+    matplotlib.use('Agg')
+    import matplotlib.pyplot as plt
+    if not os.path.exists(savepath):
+        os.makedirs(savepath)
+    np.save(os.path.join(savepath, 'pred.npy'), np.squeeze(np.array(out_depth_map)))
+    plt.imsave(os.path.join(savepath, 'pred.jpg'), np.squeeze(np.array(out_disp_map)), cmap='viridis')
+    if depth_gt is not None:
+        print(Notify.INFO, 'calulating error......', Notify.ENDC)
+        error, _ = calc_error(np.squeeze(out_depth_map), np.squeeze(depth_gt))
+        write_error_xlsx(os.path.join(savepath, 'error.xlsx'), error, FLAGS.view_num)
+    print(Notify.INFO, "result save to {}.".format(savepath), Notify.ENDC)
+
+
+def write_error_xlsx(path, error, view_num):
+    """The sheet layout of reference example.py:199-213."""
+    workbook = xlsx.Workbook(path)
+    worksheet = workbook.add_worksheet(str(view_num) + '_view')
+    n_err = len(err_metrics_namelist)
+    for i, name in enumerate(err_metrics_namelist):
+        worksheet.write(i + 1, 0, name)
+    for i, name in enumerate(acc_metrics_namelist):
+        worksheet.write(i + n_err + 2, 0, name)
+    values = error.tolist()
+    worksheet.write(0, 1, 'err')
+    worksheet.write(n_err + 1, 1, 'acc')
+    for i in range(n_err):
+        worksheet.write(i + 1, 1, values[i])
+    for i in range(n_err, len(values)):
+        worksheet.write(i + 2, 1, values[i])
+    workbook.close()
+
+
+def _to_device(images_data, cams_data):
+    dev = torch.device('cuda:%d' % FLAGS.gpu_id)
+    images = torch.from_numpy(np.ascontiguousarray(images_data, dtype=np.float32))[None].to(dev)
+    cams = torch.from_numpy(np.ascontiguousarray(cams_data, dtype=np.float32))[None].to(dev)
+    return images, cams
+
+
+def run_test_multiview(savepath, images_data, cams_data, depth_gt=None):
+    """reference example.py:51-216."""
+    assert FLAGS.view_num > 2
+    print(Notify.INFO, 'loading checkpoint......', Notify.ENDC)
+    _load_weights()
+    images, cams = _to_device(images_data, cams_data)
+    print(Notify.INFO, 'running test......', Notify.ENDC)
+    out_depth_map = infer_multiview(images, cams, FLAGS.max_d).cpu().numpy()
+    out_disp_map = out_depth_map.copy()
+    if FLAGS.inverse_depth:
+        out_depth_map[out_depth_map < 1e-10] = float("inf")
+        out_depth_map = 1.0 / out_depth_map
+    _save_results(savepath, out_depth_map, out_disp_map, depth_gt)
+
+
+def run_test_twoview(savepath, images_data, cams_data, depth_gt=None):
+    """reference example.py:219-302."""
+    assert FLAGS.view_num == 2
+    print(Notify.INFO, 'loading checkpoint......', Notify.ENDC)
+    _load_weights()
+    images, cams = _to_device(images_data, cams_data)
+    print(Notify.INFO, 'running test......', Notify.ENDC)
+    out_depth_map = infer_twoview(images, cams, FLAGS.max_d).cpu().numpy()
+    out_disp_map = out_depth_map.copy()
+    if FLAGS.inverse_depth:
+        out_depth_map[out_depth_map <= 0] = float("inf")
+        out_depth_map = 1.0 / out_depth_map
+    _save_results(savepath, out_depth_map, out_disp_map, depth_gt)
+
+
+def _imread_bgr(path):
+    """cv2.imread equivalent (BGR uint8); the image has no OpenCV, PIL decodes the JPEG."""
+    from PIL import Image
+    return np.asarray(Image.open(path).convert('RGB'))[:, :, ::-1].copy()
+
+
+def load_example(data_root, view_num):
+    """-> (images (N,H,W,3) uint8 BGR, cams (N,2,4,4), depth_gt or None, views found) (reference :312-342)."""
+    valid = 0
+    for view_i in range(view_num):
+        img_path = os.path.join(data_root, str(view_i) + '.jpg')
+        cam_path = os.path.join(data_root, str(view_i) + '_cam.npy')
+        if os.path.exists(img_path) and os.path.exists(cam_path):
+            valid += 1
+        else:
+            print("{} or {} not exist. check view_num".format(img_path, cam_path))
+    images = np.stack([_imread_bgr(os.path.join(data_root, '%d.jpg' % i)) for i in range(valid)], axis=0)
+    cams = np.stack([np.load(os.path.join(data_root, '%d_cam.npy' % i)) for i in range(valid)], axis=0)
+    gt_path = os.path.join(data_root, '0_gt.npy')
+    depth_gt = np.load(gt_path) if os.path.exists(gt_path) else None
+    return images, cams, depth_gt, valid
+
+
+def main(argv=None):
+    data_root = os.path.join(FLAGS.root_path, str(FLAGS.example_index))
+    savepath = os.path.join(data_root, 'result')
+    if not os.path.exists(savepath):
+        os.makedirs(savepath)
+    images, cams, depth_gt, valid = load_example(data_root, FLAGS.view_num)
+    if valid != FLAGS.view_num:
+        print(Notify.INFO, 'only %d views found (FLAGS.view_num = %d), continue with %d views' %
+              (valid, FLAGS.view_num, valid), Notify.ENDC)
+        FLAGS.view_num = valid
+    if FLAGS.view_num == 2:
+        run_test_twoview(savepath, images, cams, depth_gt)
+    else:
+        run_test_multiview(savepath, images, cams, depth_gt)
+
+
+def cli(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument('--root_path', type=str, default=FLAGS.root_path)
+    parser.add_argument('--example_index', type=int, default=FLAGS.example_index)
+    parser.add_argument('--pretrained_model_ckpt_path', type=str, default=FLAGS.pretrained_model_ckpt_path)
+    parser.add_argument('--view_num', type=int, default=FLAGS.view_num)
+    parser.add_argument('--max_d', type=int, default=FLAGS.max_d)
+    parser.add_argument('--gpu_id', type=int, default=FLAGS.gpu_id)
+    parser.add_argument('--synthetic_weights', action='store_true')
+    args = parser.parse_args(argv)
+    for k, v in vars(args).items():
+        setattr(FLAGS, k, v)
+    assert FLAGS.view_num > 1
+    print(Notify.INFO, 'Testing A-TVSNet with %d views' % (FLAGS.view_num), Notify.ENDC)
+    main()
+
+
+if __name__ == '__main__':
+    cli()

@@ -1,0 +1,95 @@
+"""Plane-sweep geometry of the reference's ``atvsnet/homography_warping.py`` on the HIP kernels.
+
+Same function names, argument order and tensor layouts (batch-first, channel-last,
+B = 1) as /root/reference/atvsnet/homography_warping.py; each function is one or a few
+launches through ``ops`` (include/atvsnet_hip.h).  ``FLAGS.inverse_depth`` is read
+where the reference reads it (:149,215,301,321,369,378).
+
+Beyond the reference API, ``homography_warping`` accepts a whole (B,D,3,3) stack of
+homographies and returns the (B,D,H,W,C) stack of warps in one launch -- the form
+model.py's D-unrolled loops need.
+"""
+import torch
+
+from .. import ops
+from ..flags import FLAGS
+
+
+def _cam(c):
+    """(B,2,4,4) -> contiguous (2,4,4)."""
+    if c.shape[0] != 1:
+        raise ValueError('batch size must be 1 (FLAGS.batch_size)')
+    return c[0].contiguous()
+
+
+def _scalar(t):
+    return t.reshape(-1)[:1].contiguous()
+
+
+def get_homographies(left_cam, right_cam, depth_num, depth_start, depth_interval):
+    """(B,2,4,4) x2 -> (B,D,3,3) (reference :179-227)."""
+    H = ops.get_homographies(_cam(left_cam), _cam(right_cam), _scalar(depth_start), _scalar(depth_interval),
+                             int(depth_num), FLAGS.inverse_depth)
+    return H.unsqueeze(0)
+
+
+def homography_warping(input_image, homography, method='bilinear', output_mask=False):
+    """Warp (B,H,W,C) by (B,3,3) -> (B,H,W,C) [, bool mask (B,H,W,1)] (reference :230-271).
+
+    With a (B,D,3,3) stack: -> (B,D,H,W,C) [, mask (B,D,H,W,1)].  Bilinear only here; the nearest
+    mode is used by get_visual_hull alone and is fused into its kernel.
+    """
+    if method != 'bilinear':
+        raise NotImplementedError('homography_warping(method=%r): nearest sampling is built into '
+                                  'get_visual_hull only' % method)
+    stack = homography.dim() == 4
+    Hm = (homography[0] if stack else homography).contiguous()
+    res = ops.warp_planes(input_image[0].contiguous(), Hm, want_mask=output_mask)
+    out, mask = res if output_mask else (res, None)
+    if not stack:
+        out = out[0]
+        mask = mask[0] if mask is not None else None
+    if output_mask:
+        return out.unsqueeze(0), (mask.unsqueeze(0).unsqueeze(-1) > 0)
+    return out.unsqueeze(0)
+
+
+def homography_warping_by_depth(input_image, left_cam, right_cam, depth_image, output_mask=False, method='bilinear'):
+    """Per-pixel-depth warp (reference :108-176): (B,H,W,C), depth (B,H,W,1) -> (B,H,W,C) [, mask (B,H,W,1)]."""
+    h, w = input_image.shape[1:3]
+    out, mask = ops.warp_by_depth(input_image[0].contiguous(), _cam(left_cam), _cam(right_cam),
+                                  depth_image.reshape(h, w).contiguous(), method, FLAGS.inverse_depth)
+    if output_mask:
+        return out.unsqueeze(0), (mask.reshape(1, h, w, 1) > 0)
+    return out.unsqueeze(0)
+
+
+def transform_depth(left_depth, left_cam, right_cam):
+    """Express a view's (inverse-)depth map in another camera's frame (reference :275-326).
+    (B,H,W[,1]) -> same shape."""
+    shape = left_depth.shape
+    h, w = shape[1], shape[2]
+    out = ops.transform_depth(left_depth.reshape(h, w).contiguous(), _cam(left_cam), _cam(right_cam),
+                              FLAGS.inverse_depth)
+    return out.reshape(shape)
+
+
+def get_visual_hull(depth_images, cams, depth_num, depth_start, depth_interval, ref_id=0, view_num=None):
+    """(B,N,H,W) depths -> (B,D,H,W,1) (reference :329-387).  Only view_num == 2 (every call site:
+    model.py:323-324 with num_depths=2) is built.  Quirk C6: the second map is paired with
+    cams[:, id_reorder[1]], whatever the current source view is."""
+    if view_num is None:
+        view_num = FLAGS.view_num
+    if view_num != 2:
+        raise NotImplementedError('get_visual_hull: view_num=2 is the only form the path uses')
+    ids = list(range(view_num))
+    ids[0] = ref_id
+    ids[ref_id] = 0
+    vi = ids[1]
+    ref_cam, view_cam = cams[:, ref_id], cams[:, vi]
+    H = get_homographies(ref_cam, view_cam, depth_num, depth_start, depth_interval)
+    h, w = depth_images.shape[2:4]
+    vtrans = transform_depth(depth_images[:, vi], view_cam, ref_cam)
+    hull = ops.visual_hull(depth_images[0, ref_id].contiguous(), vtrans.reshape(h, w), H[0], _scalar(depth_start),
+                           _scalar(depth_interval), FLAGS.inverse_depth)
+    return hull.reshape(1, depth_num, h, w, 1)

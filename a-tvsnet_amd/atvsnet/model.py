@@ -1,0 +1,255 @@
+"""Model assembly of the reference's ``atvsnet/model.py`` on the HIP kernels.
+
+Same function names, positional arguments, tensor layouts and return values as
+/root/reference/atvsnet/model.py (cited per function).  Tensors are batch-first,
+channel-last float32 device tensors with B = 1; ``cams`` is (B,N,2,4,4);
+``depth_start`` / ``depth_interval`` are 1-element device tensors (example.py:66-69) and
+are never read back to the host.
+
+Differences from the reference, none of which changes a value:
+* the D-unrolled Python loops of warps become one launch per volume;
+* D-constant tensors (tf.tile of reference features, photo/geo errors) are written
+  straight into their channel slice of the network input;
+* optional keyword arguments let the caller pass feature-tower outputs it already has
+  (the reference recomputes the reference tower for every source view).
+"""
+import torch
+
+from .. import ops
+from ..cnn_wrapper.atvsnet import (AttAggregation, AttAggregation_keepchannel, AttAggregation_refine,
+                                    AttAggregation_refine_keepchannel, CostVolRefineNet, OutputConv,
+                                    OutputConv_refine, ResNetDS2SPP, ResNetDS2SPP_shallow_f16, StackedUNet,
+                                    StackedUNet_prob)
+from ..flags import AUTO_REUSE, FLAGS
+from .homography_warping import (get_homographies, get_visual_hull, homography_warping,          # noqa: F401
+                                 homography_warping_by_depth, transform_depth)
+
+
+def _scalar(t):
+    return t.reshape(-1)[:1].contiguous()
+
+
+def get_propability_map(cv, depth_map, depth_start, depth_interval):
+    """Confidence from the 4 nearest hypotheses (reference :13-65).  Used by eval_pointcloud.py only
+    (next, not part of the example.py path)."""
+    raise NotImplementedError('get_propability_map belongs to the eval_pointcloud.py driver (SURVEY.md 8f-2)')
+
+
+def upsample_prob_vol(prob_vol, up_scale=4):
+    """Bilinear x4 (align_corners) of every depth plane (reference :68-76): (B,D,h,w) -> (B,D,4h,4w).
+    prob2depth_upsample does NOT call this: it regresses depth without materialising the volume."""
+    B, D, h, w = prob_vol.shape
+    # (D,h,w) viewed as (h,w,D) rows would need a transpose; resize plane by plane through channel slices
+    out = torch.empty((D, h * up_scale, w * up_scale), dtype=torch.float32, device=prob_vol.device)
+    for d in range(D):
+        ops.resize_bilinear(prob_vol[0, d].reshape(h, w, 1), (h * up_scale, w * up_scale),
+                            out=out[d].reshape(h * up_scale, w * up_scale, 1))
+    return out.unsqueeze(0)
+
+
+def prob2depth(prob_volume, depth_num, depth_start, depth_interval, out_prob_map=False):
+    """Soft-argmin over the (inverse) depth hypotheses (reference :80-109): (B,D,H,W) -> (B,H,W,1)."""
+    if out_prob_map:
+        return get_propability_map(None, None, None, None)
+    if prob_volume.shape[1] != depth_num:
+        raise ValueError('prob2depth: volume has %d planes, depth_num is %d' % (prob_volume.shape[1], depth_num))
+    d = ops.softargmin(prob_volume[0].contiguous(), _scalar(depth_start), _scalar(depth_interval))
+    return d.reshape(1, d.shape[0], d.shape[1], 1)
+
+
+def prob2depth_upsample(prob_volume, depth_num, depth_start, depth_interval, out_prob_map=False):
+    """(B,D,h,w) -> (depth (B,h,w,1), depth_up (B,4h,4w,1)) (reference :113-129): the x4 bilinear
+    upsampling of the pre-softmax cost and the soft-argmin are one kernel."""
+    if out_prob_map:
+        return get_propability_map(None, None, None, None)
+    ds, di = _scalar(depth_start), _scalar(depth_interval)
+    up = ops.upsample_softargmin(prob_volume[0].contiguous(), ds, di, 4)
+    lo = ops.softargmin(prob_volume[0].contiguous(), ds, di)
+    return lo.reshape(1, lo.shape[0], lo.shape[1], 1), up.reshape(1, up.shape[0], up.shape[1], 1)
+
+
+def output_conv(cost_volume, reuse=AUTO_REUSE):
+    """(B,D,H,W,C) -> (B,D,H,W) (reference :132-135)."""
+    tower = OutputConv({'data': cost_volume}, is_training=True, reuse=reuse)
+    return tower.get_output().squeeze(-1)
+
+
+def output_conv_refine(cost_volume, reuse=AUTO_REUSE):
+    """(reference :137-140)."""
+    tower = OutputConv_refine({'data': cost_volume}, is_training=True, reuse=reuse)
+    return tower.get_output().squeeze(-1)
+
+
+def extract_feature_shallow(images, ref_id=0, view_id=1, ref_feature=None):
+    """Low-level features of the reference and the source image (reference :144-154)."""
+    if ref_feature is None:
+        ref_feature = ResNetDS2SPP_shallow_f16({'data': images[:, ref_id]}, is_training=True, reuse=AUTO_REUSE).get_output()
+    view_feature = ResNetDS2SPP_shallow_f16({'data': images[:, view_id]}, is_training=True, reuse=AUTO_REUSE).get_output()
+    return ref_feature, view_feature
+
+
+def build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id, view_id,
+                      output_homo=False, warp_ref=False):
+    """concat([tile(ref), stack_d warp_d(view)], channel) -> (B,D,H,W,2F) (reference :157-200)."""
+    if warp_ref:
+        raise NotImplementedError('build_cost_volume(warp_ref=True) is an unused branch of the reference (:175-184)')
+    H = get_homographies(cams[:, ref_id], cams[:, view_id], depth_num=depth_num, depth_start=depth_start,
+                         depth_interval=depth_interval)
+    cv = ops.build_cost_volume(ref_feature[0].contiguous(), view_feature[0].contiguous(), H[0]).unsqueeze(0)
+    return (cv, H) if output_homo else cv
+
+
+def cost_volume_reasoning(cost_volume, output_prob=True, output_filtered_cost=False, reuse=AUTO_REUSE):
+    """Cost-volume regularisation (reference :204-223)."""
+    if output_prob:
+        tower = StackedUNet_prob({'data': cost_volume}, is_training=True, reuse=reuse)
+        prob = tower.get_output().squeeze(-1)
+        if output_filtered_cost:
+            return prob, tower.get_output_by_name('conv_b2_6_1')
+        return prob
+    tower = StackedUNet({'data': cost_volume}, is_training=True, reuse=reuse)
+    return tower.get_output_by_name('conv_b2_6_1')
+
+
+def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, images, prob_vol, ref_id, view_id,
+               view_homographies=None, num_depths=None, depth_ref_id=None, depth_view_id=None,
+               shallow_features=None):
+    """Refinement network on photometric / geometric / visual-hull volumes (reference :227-339).
+
+    init_depth_images (B,2,h,w,1), prob_vol (B,D,h,w) -> (cost residual (B,D,h,w,8), prob residual (B,D,h,w)).
+    """
+    if depth_ref_id is None:
+        depth_ref_id = ref_id
+    if depth_view_id is None:
+        depth_view_id = view_id
+    if num_depths is None:
+        num_depths = FLAGS.view_num
+    D = int(depth_num)
+    ds, di = _scalar(depth_start), _scalar(depth_interval)
+    init_ref = init_depth_images[:, depth_ref_id]             # (B,h,w,1)
+    init_view = init_depth_images[:, depth_view_id]
+    h, w = init_ref.shape[1:3]
+    ref_cam, view_cam = cams[:, ref_id], cams[:, view_id]
+    init_view_trans = transform_depth(init_view, view_cam, ref_cam)
+    if view_homographies is None:
+        view_homographies = get_homographies(ref_cam, view_cam, depth_num=D, depth_start=depth_start,
+                                             depth_interval=depth_interval)
+    Hm = view_homographies[0].contiguous()
+    if shallow_features is None:
+        ref_f, view_f = extract_feature_shallow(images, ref_id, view_id)
+    else:
+        ref_f, view_f = shallow_features
+    chan = ref_f.shape[3]
+    rf, vf = ref_f[0].contiguous(), view_f[0].contiguous()
+    dref = init_ref.reshape(h, w).contiguous()
+    dvt = init_view_trans.reshape(h, w, 1).contiguous()
+    rc, vc = ref_cam[0].contiguous(), view_cam[0].contiguous()
+
+    # photo_group = [ |warp_d(view_f) - ref_f| * mask , tile(photo_err) , tile(ref_f) ]   (:270-280, 309-311, 329, 333)
+    photo = torch.empty((D, h, w, 3 * chan), dtype=torch.float32, device=rf.device)
+    ops.warp_planes(vf, Hm, out=photo, c_off=0, mode=1, ref=rf)
+    wfeat, mphoto = ops.warp_by_depth(vf, rc, vc, dref, 'bilinear', FLAGS.inverse_depth)
+    ops.tile_planes(ops.absdiff_mask(wfeat, rf, mphoto), photo, chan)
+    ops.tile_planes(rf, photo, 2 * chan)
+
+    # geo_group = [ geo_ref(1) , geo_view (mask tiled to `chan` identical channels, quirk C7) , tile(geo_err) ,
+    #               tile(init_ref) ]                                                      (:285-300, 313-316, 330, 334)
+    geo = torch.empty((D, h, w, 1 + chan + 2), dtype=torch.float32, device=rf.device)
+    ops.geo_ref_planes(dref, ds, di, geo, 0)
+    ops.warp_planes(dvt, Hm, out=geo, c_off=1, mode=2, depth_start=ds, depth_interval=di, rep=chan)
+    wdep, mgeo = ops.warp_by_depth(dvt, rc, vc, dref, 'nearest', FLAGS.inverse_depth)
+    ops.tile_planes(ops.absdiff_mask(wdep, dref.reshape(h, w, 1), mgeo), geo, 1 + chan)
+    ops.tile_planes(dref.reshape(h, w, 1), geo, 2 + chan)
+
+    vis_hull = get_visual_hull(init_depth_images.squeeze(-1), cams, D, depth_start, depth_interval, ref_id=ref_id,
+                               view_num=num_depths)
+    tower = CostVolRefineNet({'photo_group': photo.unsqueeze(0), 'geo_group': geo.unsqueeze(0),
+                              'prob_vol': prob_vol.unsqueeze(-1), 'vis_hull': vis_hull},
+                             is_training=True, reuse=AUTO_REUSE)
+    return tower.get_output_by_name('global_refine_3dconv6_1'), tower.get_output().squeeze(-1)
+
+
+def TVSNet_feature_extraction(images, view_i):
+    """2-D feature tower of one image (reference :420-425): (B,N,H,W,3) -> (B,H/4,W/4,32)."""
+    return ResNetDS2SPP({'data': images[:, view_i]}, is_training=True, reuse=AUTO_REUSE).get_output()
+
+
+def TVSNet(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0):
+    """Two-view network (reference :346-377) -> refined_prob_vol (B,D,h,w)."""
+    ref_feature = TVSNet_feature_extraction(images, ref_i)
+    view_feature = TVSNet_feature_extraction(images, view_i)
+    cost_vol_view = build_cost_volume(view_feature, ref_feature, cams, depth_num, depth_start, depth_interval,
+                                      ref_id=view_i, view_id=0)
+    prob_vol_view = cost_volume_reasoning(cost_vol_view, output_filtered_cost=False)
+    del cost_vol_view
+    depth_view = prob2depth(prob_vol_view, depth_num, depth_start, depth_interval)
+    cost_vol = build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id=0,
+                                 view_id=view_i)
+    prob_vol_b2, _ = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
+    del cost_vol
+    depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
+    init_depth_images = torch.stack([depth_b2, depth_view], dim=1)
+    _, prob_residual = refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, images, prob_vol_b2,
+                                  ref_id=ref_i, view_id=view_i, view_homographies=None, num_depths=2, depth_ref_id=0,
+                                  depth_view_id=1)
+    return ops.add_n([prob_vol_b2[0], prob_residual[0]]).unsqueeze(0)
+
+
+def TVSNet_base(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0, ref_feature=None):
+    """(reference :380-395) -> (depth_b2, prob_vol_b2, filtered_cost_volume)."""
+    if ref_feature is None:
+        ref_feature = TVSNet_feature_extraction(images, ref_i)
+    view_feature = TVSNet_feature_extraction(images, view_i)
+    cost_vol = build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id=0,
+                                 view_id=view_i)
+    prob_vol_b2, filtered = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
+    depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
+    return depth_b2, prob_vol_b2, filtered
+
+
+def TVSNet_base_siamese(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0, ref_feature=None):
+    """Both directions of one (reference, source) pair (reference :398-417) ->
+    (depth_b2, prob_vol_b2, filtered_cost_volume, depth_view).  Quirk C11: the reverse
+    direction sweeps the reference camera's depth range."""
+    if ref_feature is None:
+        ref_feature = TVSNet_feature_extraction(images, ref_i)
+    view_feature = TVSNet_feature_extraction(images, view_i)
+    cost_vol = build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id=0,
+                                 view_id=view_i)
+    prob_vol_b2, filtered = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
+    del cost_vol
+    depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
+    cost_vol_view = build_cost_volume(view_feature, ref_feature, cams, depth_num, depth_start, depth_interval,
+                                      ref_id=view_i, view_id=0)
+    prob_vol_view = cost_volume_reasoning(cost_vol_view, output_filtered_cost=False, reuse=AUTO_REUSE)
+    del cost_vol_view
+    depth_view = prob2depth(prob_vol_view, depth_num, depth_start, depth_interval)
+    return depth_b2, prob_vol_b2, filtered, depth_view
+
+
+def TVSNet_refine(depth_b2, depth_view, prob_vol_b2, filtered_cost_volume, images, cams, depth_num, depth_start,
+                  depth_interval, view_i, ref_i=0, shallow_features=None):
+    """Refinement of one source view against the aggregated estimate (reference :428-441) ->
+    (refined_prob_vol (B,D,h,w), refined_cost_volume (B,D,h,w,8))."""
+    init_depth_images = torch.stack([depth_b2, depth_view], dim=1)
+    cost_residual, prob_residual = refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, images,
+                                              prob_vol_b2, ref_id=ref_i, view_id=view_i, view_homographies=None,
+                                              num_depths=2, depth_ref_id=0, depth_view_id=1,
+                                              shallow_features=shallow_features)
+    refined_cost_volume = ops.add_n([filtered_cost_volume[0], cost_residual[0]]).unsqueeze(0)
+    refined_prob_vol = ops.add_n([prob_vol_b2[0], prob_residual[0]]).unsqueeze(0)
+    return refined_prob_vol, refined_cost_volume
+
+
+def cost_volume_aggregation(cost_volumes, reuse=AUTO_REUSE, keepchannel=False):
+    """AAM1 (reference :445-456).  cost_volumes: (B,D,H,W,C,N-1), or a list of N-1 tensors (B,D,H,W,C)."""
+    if keepchannel:
+        return AttAggregation_keepchannel({'data': cost_volumes}, is_training=True, reuse=reuse).get_output()
+    return AttAggregation({'data': cost_volumes}, is_training=True, reuse=reuse).get_output().squeeze(-1)
+
+
+def cost_volume_aggregation_refine(cost_volumes, reuse=AUTO_REUSE, keepchannel=False):
+    """AAM2 (reference :460-468)."""
+    if keepchannel:
+        return AttAggregation_refine_keepchannel({'data': cost_volumes}, is_training=True, reuse=reuse).get_output()
+    return AttAggregation_refine({'data': cost_volumes}, is_training=True, reuse=reuse).get_output().squeeze(-1)

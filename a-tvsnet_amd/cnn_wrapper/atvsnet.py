@@ -1,0 +1,181 @@
+"""Layer graphs of A-TVSNet on the Network operator API.
+
+Same class names, layer names (hence variable names) and wiring as
+/root/reference/cnn_wrapper/atvsnet.py; the three stacked U-Nets are written as a
+loop over the stack index instead of being spelled out three times.
+Exact graphs: SURVEY.md Appendix A.
+"""
+from .network import Network
+
+
+def _stacked_unet(net, with_prob_head):
+    """Three 3-level 3-D U-Nets with cross-stack skip adds (reference atvsnet.py:5-96 / :100-192).
+
+    Stack b reads I_b (I_0 = 'data'; I_b = conv_b{b-1}_6_0 + conv_b{b-1}_0_1).  Layer
+    conv_b{b}_{level}_{0|1}: level 1-3 stride-2 encoders (_0) and same-resolution convs (_1),
+    level 4-6 stride-2 transposed-conv decoders.
+    """
+    f = 8
+    for b in range(3):
+        n = lambda s: 'conv_b%d_%s' % (b, s)          # noqa: E731
+        p = lambda s: 'conv_b%d_%s' % (b - 1, s)      # noqa: E731
+        if b == 0:
+            src = 'data'
+        else:
+            src = n('0_0')
+            net.feed(p('6_0'), p('0_1')).add(name=src)
+        (net.feed(src)
+            .conv_bn(3, f * 2, 2, name=n('1_0'))
+            .conv_bn(3, f * 4, 2, name=n('2_0'))
+            .conv_bn(3, f * 8, 2, name=n('3_0')))
+        net.feed(src).conv_bn(3, f, 1, name=n('0_1'))
+        if b == 0:
+            net.feed(n('1_0')).conv_bn(3, f * 2, 1, name=n('1_1'))
+            net.feed(n('2_0')).conv_bn(3, f * 4, 1, name=n('2_1'))
+        else:
+            net.feed(n('1_0'), p('5_0')).add(name=n('1_1_concat')).conv_bn(3, f * 2, 1, name=n('1_1'))
+            net.feed(n('2_0'), p('4_0')).add(name=n('2_1_concat')).conv_bn(3, f * 4, 1, name=n('2_1'))
+        (net.feed(n('3_0'))
+            .conv_bn(3, f * 8, 1, name=n('3_1'))
+            .deconv_bn(3, f * 4, 2, name=n('4_0')))
+        skip2 = [n('4_0'), n('2_1')] + ([] if b == 0 else ['conv_b0_2_1'])
+        net.feed(*skip2).add(name=n('4_1')).deconv_bn(3, f * 2, 2, name=n('5_0'))
+        skip1 = [n('5_0'), n('1_1')] + ([] if b == 0 else ['conv_b0_1_1'])
+        net.feed(*skip1).add(name=n('5_1')).deconv_bn(3, f, 2, name=n('6_0'))
+    net.feed('conv_b2_6_0', 'conv_b2_0_1').add(name='conv_b2_6_1')
+    if with_prob_head:
+        net.conv(3, 1, 1, relu=False, name='conv_b2_6_2')
+
+
+class StackedUNet(Network):
+    """Cost-volume regulariser without the probability head (reference atvsnet.py:5-96)."""
+
+    def setup(self):
+        _stacked_unet(self, with_prob_head=False)
+
+
+class StackedUNet_prob(Network):
+    """Regulariser with the 8->1 head: outputs conv_b2_6_1 (filtered cost) and conv_b2_6_2
+    (reference atvsnet.py:100-192)."""
+
+    def setup(self):
+        _stacked_unet(self, with_prob_head=True)
+
+
+def _attention(net, scope, head):
+    # 'data': (B,D,H,W,C,N) or a list of N (B,D,H,W,C) tensors, N = number of source views
+    shape_in = net.get_shape_by_name('data')
+    net.feed('data').attention_aggregation(kernel_size=3, name=scope, second_weight=True, relu=True, biased=False,
+                                           n_view=shape_in[-1])
+    if head:
+        net.conv(3, 1, 1, relu=False, name=head)
+
+
+class AttAggregation_keepchannel(Network):
+    """AAM1 attention (reference atvsnet.py:196-203)."""
+
+    def setup(self):
+        _attention(self, 'attention_aggregate', None)
+
+
+class AttAggregation(Network):
+    """AAM1 attention + 8->1 head (reference atvsnet.py:206-213)."""
+
+    def setup(self):
+        _attention(self, 'attention_aggregate', 'attention_prob_vol')
+
+
+class OutputConv(Network):
+    """8->1 convolution after AAM1 (reference atvsnet.py:216-220)."""
+
+    def setup(self):
+        self.feed('data').conv(3, 1, 1, relu=False, name='attention_prob_vol')
+
+
+class OutputConv_refine(Network):
+    """8->1 convolution after AAM2 (reference atvsnet.py:222-226)."""
+
+    def setup(self):
+        self.feed('data').conv(3, 1, 1, relu=False, name='attention_prob_vol_refine')
+
+
+class AttAggregation_refine_keepchannel(Network):
+    """AAM2 attention (reference atvsnet.py:229-234)."""
+
+    def setup(self):
+        _attention(self, 'attention_aggregate_refine', None)
+
+
+class AttAggregation_refine(Network):
+    """AAM2 attention + head (reference atvsnet.py:236-242)."""
+
+    def setup(self):
+        _attention(self, 'attention_aggregate_refine', 'attention_prob_vol_refine')
+
+
+class ResNetDS2SPP_shallow_f16(Network):
+    """Low-level 16-channel features at 1/4 resolution for the refinement (reference atvsnet.py:245-251)."""
+
+    def setup(self):
+        (self.feed('data')
+             .res_block(3, 16, num_block=3, stride=4, rate=1, name='global_refine_conv0_x')
+             .conv(1, 16, 1, relu=False, name='global_refine_shallow_feature'))
+
+
+class ResNetDS2SPP(Network):
+    """2-D feature tower: dilated ResNet, 1/4 resolution, spatial pyramid pooling, 32 channels
+    (reference atvsnet.py:254-292)."""
+
+    def setup(self):
+        f = 32
+        (self.feed('data')
+             .conv_bn(3, f, 2, name='conv0_0')
+             .conv_bn(3, f, 1, name='conv0_1')
+             .conv_bn(3, f, 1, name='conv0_2')
+             .res_block(3, f, num_block=3, stride=1, rate=1, name='conv0_x')
+             .res_block(3, f * 2, num_block=8, stride=2, rate=1, name='conv1_x')
+             .res_block(3, f * 4, num_block=3, stride=1, rate=2, name='conv2_x')
+             .res_block(3, f * 4, num_block=3, stride=1, rate=4, name='conv3_x'))
+        size = self.get_shape_by_name('conv3_x')[1:3]
+        for i, pool in enumerate((64, 32, 16, 8)):
+            (self.feed('conv3_x')
+                 .avg_pool(pool, pool, name='branch_%d_pool' % i)
+                 .conv_bn(3, f, 1, relu=True, name='branch_%d_conv' % i)
+                 .image_resize(size=size, method='bilinear', name='branch_%d' % i, align_corners=True))
+        (self.feed('conv1_x', 'conv3_x', 'branch_0', 'branch_1', 'branch_2', 'branch_3')
+             .concat(axis=-1, name='concat_feature')
+             .conv_bn(3, f * 4, 1, relu=True, name='fusion0')
+             .conv(1, f, 1, relu=False, name='fusion1'))
+
+
+class CostVolRefineNet(Network):
+    """Refinement network over the photo / geo / probability / visual-hull volumes
+    (reference atvsnet.py:295-336)."""
+
+    def setup(self):
+        f = 8
+        g = 'global_refine_'
+        stems = []
+        for src, tag in (('photo_group', 'photo'), ('geo_group', 'geo'), ('prob_vol', 'prob'), ('vis_hull', 'vishull')):
+            self.feed(src).conv_bn(3, f, 1, name=g + tag + '_3dconv')
+            stems.append(g + tag + '_3dconv')
+        (self.feed(*stems)
+             .concat(axis=-1, name=g + 'concat')
+             .conv_bn(3, f * 2, 2, name=g + '3dconv1_0')
+             .conv_bn(3, f * 4, 2, name=g + '3dconv2_0')
+             .conv_bn(3, f * 8, 2, name=g + '3dconv3_0'))
+        self.feed(g + 'concat').conv_bn(3, f, 1, name=g + '3dconv0_1')
+        self.feed(g + '3dconv1_0').conv_bn(3, f * 2, 1, name=g + '3dconv1_1')
+        self.feed(g + '3dconv2_0').conv_bn(3, f * 4, 1, name=g + '3dconv2_1')
+        (self.feed(g + '3dconv3_0')
+             .conv_bn(3, f * 8, 1, name=g + '3dconv3_1')
+             .deconv_bn(3, f * 4, 2, name=g + '3dconv4_0'))
+        (self.feed(g + '3dconv4_0', g + '3dconv2_1')
+             .add(name=g + '3dconv4_1')
+             .deconv_bn(3, f * 2, 2, name=g + '3dconv5_0'))
+        (self.feed(g + '3dconv5_0', g + '3dconv1_1')
+             .add(name=g + '3dconv5_1')
+             .deconv_bn(3, f, 2, name=g + '3dconv6_0'))
+        (self.feed(g + '3dconv6_0', g + '3dconv0_1')
+             .add(name=g + '3dconv6_1')
+             .conv(3, 1, 1, relu=False, name='global_refined_cost_vol'))

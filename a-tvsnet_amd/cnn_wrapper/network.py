@@ -1,0 +1,361 @@
+"""Operator API of the reference's ``cnn_wrapper/network.py`` on the HIP kernels.
+
+Same class, method names, keyword arguments, chaining (`feed(...).op(...).op(...)`),
+name-based layer lookup and error behaviour as /root/reference/cnn_wrapper/network.py
+(cited per method).  Differences that follow from leaving TensorFlow-1.5 graph mode:
+
+* execution is eager: ``setup()`` runs the layers on the device as it builds them;
+* tensors are channel-last float32 torch tensors (device memory only; every op is a
+  gfx950 kernel behind ``include/atvsnet_hip.h`` reached through ``ops``); ``meta``
+  tensors run the same host code without launching anything (shape / memory planning);
+* variables live in ``variables.default_store()`` under the TF variable names and are
+  always shared by name (the reference passes reuse=tf.AUTO_REUSE or builds once);
+* batch size is 1 (FLAGS.batch_size; the kernels take no batch axis).
+"""
+import numpy as np
+import torch
+
+from .. import ops
+from .. import variables
+
+DEFAULT_PADDING = 'SAME'
+BN_EPS = 1e-3      # tf.layers.batch_normalization / slim.batch_norm default epsilon
+
+string_types = (str,)
+
+
+def layer(op):
+    """Decorator for composable network layers (reference network.py:11-34)."""
+
+    def layer_decorated(self, *args, **kwargs):
+        # Automatically set a name if not provided.
+        name = kwargs.setdefault('name', self.get_unique_name(op.__name__))
+        # Figure out the layer inputs.
+        if not self.terminals:
+            raise RuntimeError('No input variables found for layer %s.' % name)
+        elif len(self.terminals) == 1:
+            layer_input = self.terminals[0]
+        else:
+            layer_input = list(self.terminals)
+        layer_output = op(self, layer_input, *args, **kwargs)
+        self.layers[name] = layer_output
+        self.feed(layer_output)
+        return self
+
+    layer_decorated.__name__ = op.__name__
+    layer_decorated.__doc__ = op.__doc__
+    return layer_decorated
+
+
+def _b1(x, what):
+    if x.shape[0] != 1:
+        raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d' % (what, x.shape[0]))
+    return x[0]
+
+
+class Network(object):
+    """Class NetWork (reference network.py:37-139)."""
+
+    def __init__(self, inputs, is_training, dropout_rate=0.9, seed=None, reuse=False, scope_name=None):
+        self.inputs = inputs
+        self.terminals = []
+        self.layers = dict(inputs)
+        self.trainable = is_training
+        self.reuse = reuse
+        self.scope_name = scope_name
+        self.training = is_training
+        self.seed = seed
+        self.dropout_rate = dropout_rate
+        self.store = variables.default_store()
+        self.setup()
+
+    def setup(self):
+        '''Construct the network. '''
+        raise NotImplementedError('Must be implemented by the subclass.')
+
+    def load(self, data_path, session=None, ignore_missing=False):
+        '''Load network weights from a numpy-serialized {op_name: {param_name: array}} dict
+        (reference network.py:67-82); `session` is accepted and ignored.'''
+        data_dict = np.load(data_path, allow_pickle=True).item()
+        for op_name in data_dict:
+            for param_name, data in data_dict[op_name].items():
+                self.store.set('%s/%s' % (op_name, param_name), data)
+
+    def feed(self, *args):
+        '''Set the input(s) for the next operation by replacing the terminal nodes.
+        The arguments can be either layer names or the actual layers (reference :84-107).'''
+        assert args
+        self.terminals = []
+        for fed_layer in args:
+            if isinstance(fed_layer, string_types):
+                try:
+                    fed_layer = self.layers[fed_layer]
+                except KeyError:
+                    raise KeyError('Unknown layer name fed: %s' % fed_layer)
+            elif isinstance(fed_layer, list):
+                if len(fed_layer) == 2 and isinstance(fed_layer[0], Network) and isinstance(fed_layer[1], string_types):
+                    try:
+                        fed_layer = fed_layer[0].get_output_by_name(fed_layer[1])
+                    except KeyError:
+                        raise KeyError('Unknown layer name fed: %s' % fed_layer[1])
+            self.terminals.append(fed_layer)
+        return self
+
+    def get_output(self):
+        '''Returns the current network output.'''
+        return self.terminals[-1]
+
+    def get_output_by_name(self, layer_name):
+        return self.layers[layer_name]
+
+    def get_shape_by_name(self, layer_name):
+        '''Shape of a layer (a tuple here; tf.shape in the reference :121-127).
+        A list of per-view tensors (attention input) reports the stacked shape.'''
+        t = self.layers[layer_name]
+        if isinstance(t, (list, tuple)):
+            return tuple(t[0].shape) + (len(t),)
+        return tuple(t.shape)
+
+    def get_unique_name(self, prefix):
+        '''Returns an index-suffixed unique name for the given prefix (reference :129-134).'''
+        ident = sum(t.startswith(prefix) for t, _ in self.layers.items()) + 1
+        return '%s_%d' % (prefix, ident)
+
+    def change_inputs(self, inputs):
+        assert len(inputs) == 1
+        for key in inputs:
+            self.layers[key] = inputs[key]
+
+    def make_var(self, name, shape, initializer=None, device=None):
+        '''A variable by (scoped) name (reference :275-279): created on first use.'''
+        return self.store.get(name, shape, device if device is not None else 'meta')
+
+    def validate_padding(self, padding):
+        assert padding in ('SAME', 'VALID')
+
+    # ------------------------------------------------------------------ helpers
+    def _kernel(self, name, shape):
+        """Host copy of a kernel variable (the pack cache uploads the arranged form)."""
+        return self.store.get_host(name, shape)
+
+    def _vec(self, name, n, like):
+        return self.store.get(name, (n,), like.device)
+
+    def _bn(self, y, st, scope, center, relu):
+        """tf.layers.batch_normalization(center, scale=False, training=self.training) [+ relu]."""
+        C = y.shape[-1]
+        beta = self._vec('%s/batch_normalization/beta' % scope, C, y) if center else None
+        if self.training:
+            return ops.batch_norm(y, st, beta=beta, relu=relu, inplace=True, eps=BN_EPS)
+        return self._bn_inference(y, '%s/batch_normalization' % scope, beta, relu)
+
+    def _bn_inference(self, y, scope, beta, relu):
+        """Moving-average BN (never used by the reference's inference code, which passes is_training=True)."""
+        C = y.shape[-1]
+        mean = self.store.get_host('%s/moving_mean' % scope, (C,))
+        var = self.store.get_host('%s/moving_variance' % scope, (C,))
+        b = self.store.get_host(scope + '/beta', (C,)) if beta is not None else np.zeros(C, np.float32)
+        p = np.stack([mean, 1.0 / np.sqrt(var + BN_EPS), b]).astype(np.float32)
+        params = torch.empty((3, C), dtype=torch.float32, device='meta') if y.is_meta else torch.from_numpy(p).to(y.device)
+        return ops.bn_apply(y, params, relu)
+
+    # ------------------------------------------------------------------ layers on the hot path
+    @layer
+    def conv(self, input, kernel_size, filters, strides, name, relu=True, padding=DEFAULT_PADDING, biased=False,
+             rate=1):
+        '''tf.layers.conv2d / conv3d (reference network.py:141-169): variables name/kernel [, name/bias].'''
+        rank = input.dim()
+        if rank not in (4, 5):
+            raise ValueError('Improper input rank for layer: ' + name)
+        x = _b1(input, name)
+        cin = x.shape[-1]
+        w = self._kernel('%s/kernel' % name, (kernel_size,) * (rank - 2) + (cin, filters))
+        bias = self._vec('%s/bias' % name, filters, x) if biased else None
+        y = ops.conv(x, name + '/kernel', w, stride=strides, dilation=rate, padding=padding, bias=bias, relu=relu)
+        return y.unsqueeze(0)
+
+    @layer
+    def conv_bn(self, input, kernel_size, filters, strides, name, relu=True, center=False, padding=DEFAULT_PADDING,
+                biased=False, rate=1):
+        '''conv (no activation) -> batch norm with batch statistics -> relu (reference network.py:172-215):
+        variables name/conv{2,3}d/kernel.  The statistics come from the convolution's epilogue.'''
+        rank = input.dim()
+        if rank not in (4, 5):
+            raise ValueError('Improper input rank for layer: ' + name)
+        x = _b1(input, name)
+        cin = x.shape[-1]
+        kind = 'conv2d' if rank == 4 else 'conv3d'
+        vname = '%s/%s/kernel' % (name, kind)
+        w = self._kernel(vname, (kernel_size,) * (rank - 2) + (cin, filters))
+        bias = self._vec('%s/%s/bias' % (name, kind), filters, x) if biased else None
+        if self.training:
+            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True)
+        else:
+            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias), None
+        return self._bn(y, st, name, center, relu).unsqueeze(0)
+
+    @layer
+    def deconv_bn(self, input, kernel_size, filters, strides, name, relu=True, center=False, padding=DEFAULT_PADDING,
+                  biased=False):
+        '''conv3d_transpose -> batch norm -> relu (reference network.py:510-550): variables
+        name/conv3d_transpose/kernel [k,k,k,Cout,Cin].  The path only uses k=3, stride 2, SAME, rank 5.'''
+        rank = input.dim()
+        if rank not in (4, 5):
+            raise ValueError('Improper input rank for layer: ' + name + ', input_shape: ' + str(rank))
+        if rank != 5 or kernel_size != 3 or strides != 2 or padding != 'SAME' or biased:
+            raise NotImplementedError('deconv_bn: only the 3-D k=3, stride-2, SAME, unbiased form used by '
+                                      'cnn_wrapper/atvsnet.py is built')
+        x = _b1(input, name)
+        vname = '%s/conv3d_transpose/kernel' % name
+        w = self._kernel(vname, (3, 3, 3, filters, x.shape[-1]))
+        if self.training:
+            y, st = ops.conv3d_transpose_s2(x, vname, w, want_stats=True)
+        else:
+            y, st = ops.conv3d_transpose_s2(x, vname, w), None
+        return self._bn(y, st, name, center, relu).unsqueeze(0)
+
+    def bottleneck(self, inputs, kernel_size, depth, stride=1, rate=1, name=None):
+        """Bottleneck residual unit variant with BN before convolutions (reference network.py:552-602).
+
+        slim.batch_norm (beta, batch statistics) + relu -> [1x1 shortcut on the pre-activation] ->
+        1x1 (bias, relu) -> 3x3 (dilated | strided with explicit symmetric pad) (bias, relu) ->
+        1x1 (bias) + shortcut (added in the last convolution's epilogue).
+        """
+        scope = name
+        x = _b1(inputs, scope)
+        depth_in = x.shape[-1]
+        beta = self._vec('%s/preact/beta' % scope, depth_in, x)
+        if self.training:
+            preact = ops.batch_norm(x, None, beta=beta, relu=True, eps=BN_EPS)
+        else:
+            preact = self._bn_inference(x.clone(), '%s/preact' % scope, beta, True)
+        if depth == depth_in:
+            if stride == 1:
+                shortcut = x
+            else:
+                raise NotImplementedError('bottleneck: max_pool shortcut (same depth, stride != 1) is never '
+                                          'reached by cnn_wrapper/atvsnet.py and is not built')
+        else:
+            shortcut = ops.conv(preact, scope + '/shortcut/weights',
+                                self._kernel('%s/shortcut/weights' % scope, (1, 1, depth_in, depth)), stride=stride,
+                                bias=self._vec('%s/shortcut/biases' % scope, depth, x))
+        r = ops.conv(preact, scope + '/conv1/weights', self._kernel('%s/conv1/weights' % scope, (1, 1, depth_in, depth)),
+                     bias=self._vec('%s/conv1/biases' % scope, depth, x), relu=True)
+        w2 = self._kernel('%s/conv2/weights' % scope, (kernel_size, kernel_size, depth, depth))
+        b2 = self._vec('%s/conv2/biases' % scope, depth, x)
+        if stride == 1:
+            r = ops.conv(r, scope + '/conv2/weights', w2, dilation=rate, bias=b2, relu=True)
+        else:
+            k_eff = kernel_size + (kernel_size - 1) * (rate - 1)
+            pb = (k_eff - 1) // 2
+            pe = (k_eff - 1) - pb
+            r = ops.conv(r, scope + '/conv2/weights', w2, stride=stride, dilation=rate,
+                         explicit_pad=[(pb, pe), (pb, pe)], bias=b2, relu=True)
+        out = ops.conv(r, scope + '/conv3/weights', self._kernel('%s/conv3/weights' % scope, (1, 1, depth, depth)),
+                       bias=self._vec('%s/conv3/biases' % scope, depth, x), residual=shortcut)
+        return out.unsqueeze(0)
+
+    @layer
+    def res_block(self, inputs, kernel_size, depth, num_block=1, stride=1, rate=1, name=None):
+        '''num_block bottlenecks, scopes name_0 .. name_{n-2}, name (reference network.py:604-616).'''
+        if num_block == 1:
+            return self.bottleneck(inputs=inputs, kernel_size=kernel_size, depth=depth, stride=stride, rate=rate,
+                                   name=name)
+        output = self.bottleneck(inputs=inputs, kernel_size=kernel_size, depth=depth, stride=stride, rate=rate,
+                                 name=name + '_' + str(0))
+        for i in range(1, num_block):
+            scope_name = name + '_' + str(i) if i != num_block - 1 else name
+            output = self.bottleneck(inputs=output, kernel_size=kernel_size, depth=depth, stride=1, rate=rate,
+                                     name=scope_name)
+        return output
+
+    @layer
+    def avg_pool(self, input, pool_size, strides, name, padding=DEFAULT_PADDING):
+        '''tf.layers.average_pooling2d (reference network.py:665-671); SAME only.'''
+        if padding != 'SAME':
+            raise NotImplementedError('avg_pool: only SAME padding is built')
+        return ops.avg_pool_same(_b1(input, name), pool_size, strides).unsqueeze(0)
+
+    @layer
+    def image_resize(self, input, size, name, align_corners=True, method='bilinear'):
+        '''tf.image.resize_images: always bilinear (reference network.py:649-655, quirk C14).'''
+        if not align_corners:
+            raise NotImplementedError('image_resize: only align_corners=True is built')
+        return ops.resize_bilinear(_b1(input, name), (int(size[0]), int(size[1]))).unsqueeze(0)
+
+    @layer
+    def concat(self, inputs, axis, name):
+        '''tf.concat (reference network.py:691-693); channel axis only.'''
+        if axis not in (-1, inputs[0].dim() - 1):
+            raise NotImplementedError('concat: only the channel axis is built')
+        return ops.concat_channels([_b1(t, name) for t in inputs]).unsqueeze(0)
+
+    @layer
+    def add(self, inputs, name):
+        '''tf.add_n (reference network.py:695-697).'''
+        return ops.add_n([_b1(t, name) for t in inputs]).unsqueeze(0)
+
+    def attention_activation(self, input, kernel_size, name, filters=None, second_weight=False, relu=True,
+                             padding=DEFAULT_PADDING, biased=False, n_view=None):
+        raise NotImplementedError('attention_activation is fused into attention_aggregation on this backend')
+
+    @layer
+    def attention_aggregation(self, input, kernel_size, name, filters=None, second_weight=False, relu=True,
+                              padding=DEFAULT_PADDING, biased=False, n_view=None):
+        '''AANet aggregation over views (reference network.py:378-408 -> :282-351).
+
+        input: (B,D,H,W,C,N) like the reference, or a list of N tensors (B,D,H,W,C) (no stacking
+        copy).  Variables name/attention_activation/{weight_unique,weight_shared}.  The shared and
+        unique 3x3x3 convolutions run as one C->2C convolution; the cross-view softmax and the
+        weighted sum are one kernel.  Only the form the path uses is built.
+        '''
+        if not (second_weight and relu and not biased and padding == 'SAME' and kernel_size == 3):
+            raise NotImplementedError('attention_aggregation: only second_weight=True, relu=True, biased=False, '
+                                      'kernel 3, SAME (cnn_wrapper/atvsnet.py:202,234) is built')
+        if isinstance(input, (list, tuple)):
+            xs = [_b1(t, name) for t in input]
+        else:
+            if input.dim() != 6:
+                raise ValueError('Improper input rank for layer: ' + name)
+            st = _b1(input, name)
+            nv = st.shape[-1]
+            xs = []
+            for n in range(nv):
+                xn = torch.empty(tuple(st.shape[:-1]), dtype=torch.float32, device=st.device)
+                ops.copy_channels(st, xn.reshape(-1, 1), 1, n, 0)
+                xs.append(xn)
+        c_in = xs[0].shape[-1]
+        if c_in != 8 or (filters not in (None, c_in)):
+            raise NotImplementedError('attention_aggregation: C = filters = 8 is built')
+        scope = '%s/attention_activation' % name
+        wu = self.store.get_host('%s/weight_unique' % scope, (3, 3, 3, c_in, c_in))
+        ws = self.store.get_host('%s/weight_shared' % scope, (3, 3, 3, c_in, c_in))
+        key = scope + '/shared|unique'
+        w16 = np.concatenate([ws, wu], axis=-1)
+        srs = [ops.conv(x, key, w16, relu=True) for x in xs]
+        return ops.aanet_combine(srs, xs).unsqueeze(0)
+
+    # ------------------------------------------------------------------ API surface off the hot path
+    # The remaining reference layers (deconv, split_separable_conv2d, attention_activation_layer,
+    # attention_activation_2d, max_pool, l2_pool, lrn, fc, softmax, dropout, ...; reference
+    # network.py:218-268, 354-376, 411-508, 619-647, 657-689, 699-775) are not used by
+    # cnn_wrapper/atvsnet.py.  The cheap tensor-shape ones are provided; the rest raise.
+    @layer
+    def squeeze(self, input, axis=None, name=None):
+        return input.squeeze(axis) if axis is not None else input.squeeze()
+
+    @layer
+    def expand_dims(self, input, axis, name=None):
+        return input.unsqueeze(axis)
+
+    def __getattr__(self, item):
+        if item in _OFF_PATH_LAYERS:
+            raise NotImplementedError('Network.%s: reference layer that cnn_wrapper/atvsnet.py never uses; '
+                                      'not built on the MI355X backend' % item)
+        raise AttributeError(item)
+
+
+_OFF_PATH_LAYERS = frozenset([
+    'relu', 'split_separable_conv2d', 'attention_activation_layer', 'attention_activation_2d', 'deconv', 'transpose', 'divide',
+    'reduce_mean', 'reduce_sum', 'tile', 'squeeze_and_transpose', 'max_pool', 'l2_pool', 'lrn', 'multiply',
+    'multiply_channel_wise', 'fc', 'sigmoid', 'softmax', 'nn_softmax', 'batch_normalization', 'dropout', 'l2norm'])

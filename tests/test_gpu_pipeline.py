@@ -1,0 +1,103 @@
+"""-m gpu: whole networks and the example.py pipelines on the MI355X vs the CPU oracle,
+same seeded inputs and weights (config 1 of BASELINE.json: 160x128 image, D=32).
+
+Bar (BASELINE.json north_star): rel-L1 of the final depth map <= 1e-3.  The fp32 path is
+expected to sit orders of magnitude below it; intermediate volumes are checked at 1e-3 of
+their max (31 BN-normalised layers amplify summation-order noise by < 100x).
+"""
+import pytest
+import torch
+
+from oracle import model as OM
+from oracle import nets
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_l1(got, want):
+    return float(((got - want).abs() / want.abs().clamp(min=1e-12)).mean())
+
+
+def _inputs(views, H=128, W=160, D=32):
+    from atvsnet_amd import synthetic
+    imgs, cams = synthetic.make_inputs(views, H, W, D)
+    return torch.from_numpy(imgs), torch.from_numpy(cams)
+
+
+def test_feature_tower(cuda, weights):
+    from atvsnet_amd.cnn_wrapper.atvsnet import ResNetDS2SPP, ResNetDS2SPP_shallow_f16
+    imgs, _ = _inputs(2)
+    L = {}
+    want = nets.resnet_ds2_spp(imgs[:, 0], weights, L)
+    net = ResNetDS2SPP({'data': imgs[:, 0].to(cuda)}, is_training=True)
+    for name in ('conv1_x', 'conv3_x', 'branch_0', 'branch_1', 'branch_2', 'branch_3', 'fusion0', 'fusion1'):
+        g, w = net.get_output_by_name(name).cpu(), L[name]
+        assert g.shape == w.shape, name
+        assert float((g - w).abs().max()) <= 2e-4 * float(w.abs().max()) + 1e-6, name
+    assert float((net.get_output().cpu() - want).abs().max()) <= 2e-4 * float(want.abs().max())
+    want16 = nets.resnet_ds2_spp_shallow_f16(imgs[:, 1], weights)
+    got16 = ResNetDS2SPP_shallow_f16({'data': imgs[:, 1].to(cuda)}, is_training=True).get_output().cpu()
+    assert got16.shape == want16.shape
+    assert float((got16 - want16).abs().max()) <= 2e-4 * float(want16.abs().max())
+
+
+def test_stacked_unet(cuda, weights):
+    from atvsnet_amd.cnn_wrapper.atvsnet import StackedUNet_prob
+    g = torch.Generator().manual_seed(3)
+    data = torch.randn(1, 32, 32, 40, 64, generator=g)
+    L = {}
+    want_p, want_f = nets.stacked_unet_prob(data, weights, L)
+    net = StackedUNet_prob({'data': data.to(cuda)}, is_training=True)
+    for name, w in L.items():
+        if name == 'data':
+            continue
+        gt = net.get_output_by_name(name).cpu()
+        assert gt.shape == w.shape, name
+        assert float((gt - w).abs().max()) <= 1e-3 * float(w.abs().max()) + 1e-6, name
+    assert float((net.get_output().cpu() - want_p).abs().max()) <= 1e-3 * float(want_p.abs().max())
+
+
+def test_twoview_end_to_end(cuda, weights):
+    from atvsnet_amd.atvsnet import example as ex
+    imgs, cams = _inputs(2)
+    S = {}
+    want = OM.run_twoview(imgs, cams, weights, 32, S)
+    got = ex.infer_twoview(imgs.to(cuda), cams.to(cuda), 32).cpu()
+    assert got.shape == want.shape == (1, 128, 160, 1)
+    err = rel_l1(got, want)
+    err_depth = rel_l1(OM.invert_depth(got, True), OM.invert_depth(want, True))
+    print('two-view rel-L1 inverse depth %.3e, depth %.3e' % (err, err_depth))
+    assert err <= 1e-3 and err_depth <= 1e-3
+    assert float(want.std()) > 0.02            # not a degenerate (flat) answer
+
+
+def test_multiview_end_to_end(cuda, weights):
+    from atvsnet_amd.atvsnet import example as ex
+    imgs, cams = _inputs(4)
+    S, G = {}, {}
+    want = OM.run_multiview(imgs, cams, weights, 32, S)
+    got = ex.infer_multiview(imgs.to(cuda), cams.to(cuda), 32, G).cpu()
+    for k in ('depth_agg_init', 'cost_volume_agg', 'prob_volume_agg', 'refined_cost_volume_agg',
+              'refined_prob_volume_agg'):
+        g, w = G[k].cpu(), S[k]
+        assert g.shape == w.shape, k
+        assert float((g - w).abs().max()) <= 2e-3 * float(w.abs().max()), k
+    err = rel_l1(got, want)
+    print('multi-view (N=4) rel-L1 inverse depth %.3e' % err)
+    assert err <= 1e-3
+    assert rel_l1(OM.invert_depth(got, False), OM.invert_depth(want, False)) <= 1e-3
+
+
+def test_stacked_attention_input_matches_list(cuda, weights):
+    """cost_volume_aggregation accepts the reference's (B,D,H,W,C,N) layout as well as a list."""
+    from atvsnet_amd.atvsnet import model
+    g = torch.Generator().manual_seed(9)
+    X = torch.randn(1, 8, 8, 12, 8, 3, generator=g)
+    want = OM.cost_volume_aggregation(X, weights)
+    a = model.cost_volume_aggregation(X.to(cuda), keepchannel=True).cpu()
+    b = model.cost_volume_aggregation([X[..., n].contiguous().to(cuda) for n in range(3)], keepchannel=True).cpu()
+    assert torch.equal(a, b)
+    assert float((a - want).abs().max()) < 1e-5
+    p = model.cost_volume_aggregation(X.to(cuda), keepchannel=False).cpu()
+    want_p = nets.output_conv(want, weights, 'attention_prob_vol')
+    assert float((p - want_p).abs().max()) < 1e-4 * float(want_p.abs().max()) + 1e-5
