@@ -214,7 +214,7 @@ _pack_cache = {}
 
 
 class _Packed(object):
-    __slots__ = ('wp', 'tab', 'ntaps', 'vec', 'ksteps', 'ntiles', 'cin', 'cout')
+    __slots__ = ('wp', 'tab', 'ntaps', 'vec', 'ksteps', 'ntiles', 'cin', 'cout', 'key')
 
 
 def pack_conv_weights(key, w_host, taps, transposed, device):
@@ -244,6 +244,7 @@ def pack_conv_weights(key, w_host, taps, transposed, device):
         raise RuntimeError('atvs_conv_pack failed (%d)' % rc)
     pk = _Packed()
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = ntaps, vec.value, ks.value, nt.value, cin, cout
+    pk.key = key
     if torch.device(device).type == 'meta':
         pk.wp = pk.tab = None
     else:
@@ -279,12 +280,34 @@ def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bia
     M = Do * Ho * Wo
     tm = tile_m or _pick_tile_m(M, pk.ntiles)
     if _dev_ok(x4, y, bias, residual):
+        timed = _watch['tag'] is not None and pk.key == _watch['tag']
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         args = [_p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual), _p(y),
                 ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0),
                 Di, Hi, Wi, Cin, Do, Ho, Wo, int(in_stride), Dy, Hy, Wy, int(out_stride), int(out_off[0]),
                 int(out_off[1]), int(out_off[2]), ldy, int(y_coff), pk.cout, pk.ntaps, tm, int(bool(relu)), _stream()]
         _call('atvs_conv_mfma_f32', *args)
+        if timed:
+            e1.record()
+            _watch['events'].append((e0, e1))
     return tm
+
+
+_watch = {'tag': None, 'events': []}
+
+
+def watch(tag):
+    """Time every convolution launch whose weight key is `tag` with HIP events on the launch stream.
+    watch(None) stops and returns the list of durations in ms."""
+    out = None
+    if tag is None:
+        torch.cuda.synchronize()
+        out = [a.elapsed_time(b) for a, b in _watch['events']]
+    _watch['tag'] = tag
+    _watch['events'] = []
+    return out
 
 
 def conv_blocks(M, ntiles, tile_m=None):

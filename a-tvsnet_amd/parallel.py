@@ -1,0 +1,114 @@
+"""Source views sharded across the GPUs of one node.
+
+One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The base stage
+(towers, warp, 2x U-Net, soft-argmin) and the refinement stage are independent per source
+view (reference example.py:144-149, 163-172): view v runs on rank (v-1) mod G with
+replicated weights and reference features; training-mode BN statistics are per view call,
+so no BN collective exists.  The only exchange is inside the two AANet modules
+(reference network.py:282-351, 378-408), split at their three reductions over views:
+
+    S_sum  = all_reduce_SUM( sum_local S_n )
+    U_max  = all_reduce_MAX( max_local (R_n - S_n + S_sum) )
+    [den, num] = all_reduce_SUM( [sum_local e_n, sum_local e_n * X_n] ),  e_n = exp(U_n - U_max)
+    out = num / den            (then the 8->1 output conv and soft-argmin, replicated)
+
+so every rank ends each AAM with the aggregated volume its refinement needs.  Messages are
+V*8 fp32 (126 MB at 160x128x192) -- large enough that RCCL's ring runs at link rate.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from . import variables
+from .flags import FLAGS
+
+
+class HipAttentionOps(object):
+    """The local pieces of the sharded AANet on the HIP kernels."""
+
+    def scores(self, xs, scope):
+        st = variables.default_store()
+        wu = st.get_host('%s/attention_activation/weight_unique' % scope, (3, 3, 3, 8, 8))
+        ws = st.get_host('%s/attention_activation/weight_shared' % scope, (3, 3, 3, 8, 8))
+        w16 = np.concatenate([ws, wu], axis=-1)
+        return [ops.conv(x, scope + '/attention_activation/shared|unique', w16, relu=True) for x in xs]
+
+    def partial(self, srs, xs, stage, ssum=None, umax=None):
+        return ops.aanet_partial(srs, xs, stage, ssum=ssum, umax=umax)
+
+    def divide(self, num, den):
+        return ops.divide(num, den)
+
+
+def sharded_attention(local_xs, scope, like, impl=None, group=None):
+    """AANet over views that live on different ranks.
+
+    local_xs: this rank's list of (D,h,w,8) tensors (may be empty); `like`: a tensor giving the
+    (D,h,w,8) shape / device for ranks that own no view.  Returns the aggregated (D,h,w,8) volume,
+    identical on every rank.
+    """
+    impl = impl or HipAttentionOps()
+    shape = tuple(like.shape)
+    if local_xs:
+        srs = impl.scores(local_xs, scope)
+        ssum = impl.partial(srs, local_xs, 0)
+    else:
+        ssum = torch.zeros(shape, dtype=torch.float32, device=like.device)
+    dist.all_reduce(ssum, op=dist.ReduceOp.SUM, group=group)
+    if local_xs:
+        umax = impl.partial(srs, local_xs, 1, ssum=ssum)
+    else:
+        umax = torch.full(shape, float('-inf'), dtype=torch.float32, device=like.device)
+    dist.all_reduce(umax, op=dist.ReduceOp.MAX, group=group)
+    if local_xs:
+        acc = impl.partial(srs, local_xs, 2, ssum=ssum, umax=umax)
+    else:
+        acc = torch.zeros((2,) + shape, dtype=torch.float32, device=like.device)
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    return impl.divide(acc[1], acc[0])
+
+
+def local_views(num_views, rank, world):
+    """Source views (1..N-1) owned by `rank`: round-robin."""
+    return [v for v in range(1, num_views) if (v - 1) % world == rank]
+
+
+def infer_multiview_sharded(images, cams, max_d=None, group=None):
+    """example.infer_multiview with the source views sharded over the process group.
+    Every rank returns the same full-resolution inverse-depth map (1,H,W,1)."""
+    from .atvsnet import example as ex
+    from .atvsnet import model
+    from .cnn_wrapper.atvsnet import ResNetDS2SPP_shallow_f16
+    max_d = FLAGS.max_d if max_d is None else max_d
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    n = images.shape[1]
+    mine = local_views(n, rank, world)
+    depth_start, depth_interval = ex.depth_range(cams)
+    ref_feature = model.TVSNet_feature_extraction(images, 0)
+    h, w = ref_feature.shape[1:3]
+    like = torch.empty((max_d, h, w, 8), dtype=torch.float32, device=images.device) if not mine else None
+    filtered, depth_views = [], []
+    for v in mine:
+        _, _, f, dv = model.TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval, view_i=v, ref_i=0,
+                                                ref_feature=ref_feature)
+        filtered.append(f[0])
+        depth_views.append(dv)
+    cost_agg = sharded_attention(filtered, 'attention_aggregate', filtered[0] if mine else like, group=group)
+    cost_agg = cost_agg.unsqueeze(0)
+    prob_agg = model.output_conv(cost_agg, reuse=False)
+    depth_init = model.prob2depth(prob_agg, max_d, depth_start, depth_interval)
+    del filtered
+    refined = []
+    if mine:
+        ref_shallow = ResNetDS2SPP_shallow_f16({'data': images[:, 0]}, is_training=True).get_output()
+    for i, v in enumerate(mine):
+        shallow = model.extract_feature_shallow(images, 0, v, ref_feature=ref_shallow)
+        _, rc = model.TVSNet_refine(depth_init, depth_views[i], prob_agg, cost_agg, images, cams, max_d, depth_start,
+                                    depth_interval, view_i=v, ref_i=0, shallow_features=shallow)
+        refined.append(rc[0])
+    rcost_agg = sharded_attention(refined, 'attention_aggregate_refine', refined[0] if mine else like, group=group)
+    rprob_agg = model.output_conv_refine(rcost_agg.unsqueeze(0), reuse=False)
+    _, depth_refined = model.prob2depth_upsample(rprob_agg, max_d, depth_start, depth_interval)
+    return depth_refined

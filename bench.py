@@ -1,0 +1,188 @@
+#!/usr/bin/env python
+"""Headline benchmark: depth-maps/sec of the A-TVSNet multi-view inference path.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step = one depth map: N=5 views (1 reference + 4 sources) of 640x512 images, D=192
+hypotheses (BASELINE.json configs[2], the configuration the metric is quoted on), through the
+whole example.py multi-view pipeline (towers -> 2x stacked 3-D U-Net per source -> AAM1 ->
+refinement per source -> AAM2 -> x4 upsample + soft-argmin), inputs resident in HBM, synthetic
+seeded data and weights.  Arithmetic: fp32 (fp32 MFMA for every convolution).
+
+--gpus N > 1 (one process per GPU, launched by torch.distributed.run): the source views of
+the SAME depth map are sharded over the ranks and aggregated with RCCL all-reduces inside both
+AANet modules (a-tvsnet_amd/parallel.py); total work is fixed -> "scaling": "strong".
+
+One JSON line on rank 0; `roofline` is for the dominant kernel (the 64->8 3x3x3 convolution
+at full resolution, conv_b0_0_1), timed with HIP events on the launch stream inside the timed
+region; `cpu_baseline` is the CPU oracle on the host cores over a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+WIDTH, HEIGHT, DEPTHS, VIEWS = 640, 512, 192, 5
+DOMINANT = 'conv_b0_0_1/conv3d/kernel'
+PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, Peak FP32 (matrix)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument('--gpus', type=int, default=1)
+    p.add_argument('--steps', type=int, default=5)
+    p.add_argument('--warmup', type=int, default=2)
+    p.add_argument('--width', type=int, default=WIDTH)
+    p.add_argument('--height', type=int, default=HEIGHT)
+    p.add_argument('--depths', type=int, default=DEPTHS)
+    p.add_argument('--views', type=int, default=VIEWS)
+    p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--cpu-baseline-seconds', type=float, default=25.0)
+    return p.parse_args()
+
+
+def cpu_baseline(args, budget_s):
+    """Time the CPU oracle (our restatement of the reference's TF-CPU path; TF-1.5 cannot be
+    installed) on the host cores: each stage of one depth map once at full size while the budget
+    lasts, composed as the pipeline composes them."""
+    from atvsnet_amd import synthetic, variables
+    from oracle import model as OM, nets
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    W = {k: torch.from_numpy(v) for k, v in variables.default_store().host.items()}
+    imgs, cams = synthetic.make_inputs(2, args.height, args.width, args.depths)
+    imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
+    ds, di = OM.depth_start_interval(cams)
+    D, n_src = args.depths, args.views - 1
+    t0 = time.time()
+    with torch.no_grad():
+        t = time.time()
+        ref_f = nets.resnet_ds2_spp(imgs[:, 0], W)
+        t_tower = time.time() - t
+        view_f = ref_f.flip(2).contiguous()
+        t = time.time()
+        cv = OM.build_cost_volume(ref_f, view_f, cams, D, ds, di, 0, 1)
+        t_warp = time.time() - t
+        t = time.time()
+        pv, filt = OM.cost_volume_reasoning(cv, W)
+        depth = OM.prob2depth(pv, D, ds, di)
+        t_unet = time.time() - t
+        del cv
+        sample = 'tower x1 + warp x1 + StackedUNet_prob x1'
+        t_refine = None
+        if time.time() - t0 < budget_s:
+            t = time.time()
+            OM.TVSNet_refine(depth, depth, pv, filt, imgs, cams, D, ds, di, W, view_i=1)
+            t_refine = time.time() - t
+            sample += ' + refinement x1'
+        t_aam = None
+        if time.time() - t0 < budget_s:
+            t = time.time()
+            agg = nets.attention_aggregation(torch.stack([filt] * n_src, -1), W, 'attention_aggregate')
+            OM.prob2depth(nets.output_conv(agg, W), D, ds, di)
+            t_aam = time.time() - t
+            sample += ' + AAM x1'
+    if t_refine is None:
+        t_refine = t_unet * 0.9      # FLOP ratio 207/233
+    if t_aam is None:
+        t_aam = t_unet * 0.5
+    per_map = args.views * t_tower + n_src * (2 * (t_warp + t_unet) + t_refine) + 2 * t_aam
+    return {'value': 1.0 / per_map, 'unit': 'depth-maps/sec', 'cores': cores, 'kind': 'port',
+            'sample': '%s at %dx%dxD%d, composed as %d towers + %d x (2 U-Nets + refinement) + 2 AAM; %.1f s measured'
+                      % (sample, args.width, args.height, D, args.views, n_src, time.time() - t0)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', device_id=dev)
+
+    import atvsnet_amd                                       # noqa: F401
+    from atvsnet_amd import ops, synthetic, variables
+    from atvsnet_amd.atvsnet import example as ex
+    from atvsnet_amd import parallel
+
+    variables.default_store().init_synthetic(1234)
+    imgs, cams = synthetic.make_inputs(args.views, args.height, args.width, args.depths, seed=0)
+    imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
+
+    def step():
+        if world > 1:
+            return parallel.infer_multiview_sharded(imgs, cams, args.depths)
+        if args.views == 2:
+            return ex.infer_twoview(imgs, cams, args.depths)
+        return ex.infer_multiview(imgs, cams, args.depths)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    ops.watch(DOMINANT)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    watched = ops.watch(None)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+
+    if rank == 0:
+        h, w = args.height // 4, args.width // 4
+        vox = args.depths * h * w
+        flops = 2.0 * 27 * 64 * 8 * vox                       # conv_b0_0_1: 3x3x3, 64 -> 8, stride 1, SAME
+        roof = None
+        if watched:
+            avg_ms = float(np.mean(watched))
+            ach = flops / (avg_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'kernel': 'conv_mfma_f32_kernel<NT=1,TM=8,V=4> (conv_b0_0_1, 64->8 3x3x3)',
+                    'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched),
+                    'algorithmic_flops_per_launch': flops}
+        line = {
+            'metric': 'depth-maps/sec at 640x512xD=192, N=5 views', 'value': round(args.steps / dt, 4),
+            'unit': 'depth-maps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
+            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '1 depth map: %d views (1 ref + %d src) %dx%d, D=%d, example.py multi-view pipeline'
+                                   % (args.views, args.views - 1, args.width, args.height, args.depths),
+                       'feature_hw': [h, w], 'voxels': vox,
+                       'parallelism': 'views sharded over %d GPUs, RCCL all-reduce in AAM1/AAM2' % world if world > 1 else 'single GPU'},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line['cpu_baseline'] = cpu_baseline(args, args.cpu_baseline_seconds)
+            except Exception as e:                        # the baseline must never hide the GPU number
+                line['cpu_baseline'] = {'error': repr(e)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()
