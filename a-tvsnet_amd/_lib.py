@@ -85,4 +85,5 @@ def lib():
         _lib.atvs_target_arch.restype = ctypes.c_char_p
         _lib.atvs_conv_num_blocks.restype = ctypes.c_long
         _lib.atvs_channel_stats_num_blocks.restype = ctypes.c_long
+        _lib.atvs_avg_pool_ws_floats.restype = ctypes.c_long
     return _lib

@@ -226,7 +226,9 @@ class Network(object):
         depth_in = x.shape[-1]
         beta = self._vec('%s/preact/beta' % scope, depth_in, x)
         if self.training:
-            preact = ops.batch_norm(x, None, beta=beta, relu=True, eps=BN_EPS)
+            # statistics of `inputs` come from the epilogue of the convolution that produced it, when
+            # that was the previous bottleneck's conv3 (+shortcut); otherwise from a channel_stats pass
+            preact = ops.batch_norm(x, getattr(inputs, '_atvs_stats', None), beta=beta, relu=True, eps=BN_EPS)
         else:
             preact = self._bn_inference(x.clone(), '%s/preact' % scope, beta, True)
         if depth == depth_in:
@@ -251,9 +253,11 @@ class Network(object):
             pe = (k_eff - 1) - pb
             r = ops.conv(r, scope + '/conv2/weights', w2, stride=stride, dilation=rate,
                          explicit_pad=[(pb, pe), (pb, pe)], bias=b2, relu=True)
-        out = ops.conv(r, scope + '/conv3/weights', self._kernel('%s/conv3/weights' % scope, (1, 1, depth, depth)),
-                       bias=self._vec('%s/conv3/biases' % scope, depth, x), residual=shortcut)
-        return out.unsqueeze(0)
+        out, st = ops.conv(r, scope + '/conv3/weights', self._kernel('%s/conv3/weights' % scope, (1, 1, depth, depth)),
+                           bias=self._vec('%s/conv3/biases' % scope, depth, x), residual=shortcut, want_stats=True)
+        out = out.unsqueeze(0)
+        out._atvs_stats = st          # consumed by the next bottleneck's pre-activation batch norm
+        return out
 
     @layer
     def res_block(self, inputs, kernel_size, depth, num_block=1, stride=1, rate=1, name=None):

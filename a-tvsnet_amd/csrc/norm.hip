@@ -53,7 +53,7 @@ extern "C" int atvs_bn_finalize(const double* stats_partial, long num_blocks, in
 }
 
 // per-channel partial sums of an arbitrary (rows, C) tensor, C <= 256
-#define STATS_ROWS_PER_BLOCK 4096
+#define STATS_ROWS_PER_BLOCK 512
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long rows, int C,
                                                             double* __restrict__ partials) {
   __shared__ double sm[2][256];

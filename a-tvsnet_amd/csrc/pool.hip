@@ -7,24 +7,27 @@
 // /root/reference/cnn_wrapper/atvsnet.py:269-290.  All trivially small next to the volumes.
 #include "common.h"
 
-// one workgroup per output pixel; threads = (window slices) x channels
-__global__ __launch_bounds__(256) void avg_pool_same_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
-                                                            int W, int C, int Ho, int Wo, int k, int s, int pad_t,
-                                                            int pad_l) {
+// Stage 1: one workgroup per (output pixel, slice of the window rows): partial sums -> ws
+// (Ho, Wo, POOL_SLICES, C).  Stage 2: fixed-order sum of the slices / valid count.  Deterministic.
+#define POOL_SLICES 16
+__global__ __launch_bounds__(256) void avg_pool_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, int H,
+                                                               int W, int C, int Wo, int k, int s, int pad_t, int pad_l) {
   __shared__ float sm[256];
-  const int oy = blockIdx.y, ox = blockIdx.x;
+  const int oy = blockIdx.y, ox = blockIdx.x, sl = blockIdx.z;
   const int y0 = max(oy * s - pad_t, 0), y1 = min(oy * s - pad_t + k, H);
   const int x0 = max(ox * s - pad_l, 0), x1 = min(ox * s - pad_l + k, W);
-  const int ww = x1 - x0, n = (y1 - y0) * ww;
+  const int rows = y1 - y0;
+  const int ra = y0 + (rows * sl) / POOL_SLICES, rb = y0 + (rows * (sl + 1)) / POOL_SLICES;
+  const int ww = x1 - x0, n = (rb - ra) * ww;
   for (int cb = 0; cb < C; cb += 256) {
-    const int cw = min(C - cb, 256);         // channels in this pass
-    const int slices = 256 / cw;
+    const int cw = min(C - cb, 256);
+    const int lanes = 256 / cw;
     const int t = threadIdx.x;
     float acc = 0.f;
-    if (t < slices * cw) {
+    if (t < lanes * cw) {
       const int c = cb + t % cw;
-      for (int i = t / cw; i < n; i += slices) {
-        int yy = y0 + i / ww, xx = x0 + i % ww;
+      for (int i = t / cw; i < n; i += lanes) {
+        int yy = ra + i / ww, xx = x0 + i % ww;
         acc += x[((size_t)yy * W + xx) * C + c];
       }
     }
@@ -32,21 +35,43 @@ __global__ __launch_bounds__(256) void avg_pool_same_kernel(const float* __restr
     __syncthreads();
     if (t < cw) {
       float v = 0.f;
-      for (int j = 0; j < slices; ++j) v += sm[j * cw + t];
-      y[((size_t)oy * Wo + ox) * C + cb + t] = v / (float)n;
+      for (int j = 0; j < lanes; ++j) v += sm[j * cw + t];
+      ws[(((size_t)oy * Wo + ox) * POOL_SLICES + sl) * C + cb + t] = v;
     }
     __syncthreads();
   }
 }
 
-extern "C" int atvs_avg_pool_same(const float* x, float* y, int H, int W, int C, int pool, int stride,
+__global__ __launch_bounds__(256) void avg_pool_finish_kernel(const float* __restrict__ ws, float* __restrict__ y, int H, int W,
+                                                              int C, int Ho, int Wo, int k, int s, int pad_t, int pad_l) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (long)Ho * Wo * C) return;
+  int c = (int)(i % C);
+  long pix = i / C;
+  int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+  const int y0 = max(oy * s - pad_t, 0), y1 = min(oy * s - pad_t + k, H);
+  const int x0 = max(ox * s - pad_l, 0), x1 = min(ox * s - pad_l + k, W);
+  float v = 0.f;
+  for (int sl = 0; sl < POOL_SLICES; ++sl) v += ws[((size_t)pix * POOL_SLICES + sl) * C + c];
+  y[i] = v / (float)((y1 - y0) * (x1 - x0));
+}
+
+extern "C" long atvs_avg_pool_ws_floats(int H, int W, int C, int stride) {
+  long Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  return Ho * Wo * POOL_SLICES * C;
+}
+
+extern "C" int atvs_avg_pool_same(const float* x, float* y, float* ws, int H, int W, int C, int pool, int stride,
                                   atvs_stream_t stream) {
-  if (!x || !y) return ATVS_ERR_NULL;
+  if (!x || !y || !ws) return ATVS_ERR_NULL;
   if (H <= 0 || W <= 0 || C <= 0 || pool <= 0 || stride <= 0) return ATVS_ERR_SHAPE;
   int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
   int ph = max((Ho - 1) * stride + pool - H, 0), pw = max((Wo - 1) * stride + pool - W, 0);
-  hipLaunchKernelGGL(avg_pool_same_kernel, dim3(Wo, Ho), dim3(256), 0, as_stream(stream), x, y, H, W, C, Ho, Wo, pool,
+  hipStream_t s = as_stream(stream);
+  hipLaunchKernelGGL(avg_pool_partial_kernel, dim3(Wo, Ho, POOL_SLICES), dim3(256), 0, s, x, ws, H, W, C, Wo, pool,
                      stride, ph / 2, pw / 2);
+  hipLaunchKernelGGL(avg_pool_finish_kernel, dim3(cdiv((long)Ho * Wo * C, 256)), dim3(256), 0, s, ws, y, H, W, C, Ho, Wo,
+                     pool, stride, ph / 2, pw / 2);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -406,7 +406,7 @@ def channel_stats(x):
     """Partial sums of x viewed as (rows, C)."""
     C = x.shape[-1]
     rows = x.numel() // C
-    blocks = -(-rows // 4096)
+    blocks = int(_lib.lib().atvs_channel_stats_num_blocks(ctypes.c_long(rows)))
     st = Stats()
     st.partial, st.blocks, st.cpad, st.count = _stats_buffer(x, blocks, C), blocks, C, rows
     if _dev_ok(x):
@@ -458,9 +458,11 @@ def add_n(tensors):
 
 def avg_pool_same(x, pool, stride):
     H, W, C = x.shape
-    y = _new(x, (-(-H // stride), -(-W // stride), C))
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    y = _new(x, (Ho, Wo, C))
+    ws = _new(x, (Ho, Wo, 16, C))
     if _dev_ok(x):
-        _call('atvs_avg_pool_same', _p(x), _p(y), H, W, C, int(pool), int(stride), _stream())
+        _call('atvs_avg_pool_same', _p(x), _p(y), _p(ws), H, W, C, int(pool), int(stride), _stream())
     return y
 
 

@@ -51,53 +51,59 @@ def parse():
 
 def cpu_baseline(args, budget_s):
     """Time the CPU oracle (our restatement of the reference's TF-CPU path; TF-1.5 cannot be
-    installed) on the host cores: each stage of one depth map once at full size while the budget
-    lasts, composed as the pipeline composes them."""
+    installed) on the host cores over a BOUNDED sample of the same workload: every stage of the
+    pipeline once on a (W/2 x H/2 image, D/2 hypotheses) crop, i.e. 1/4 of the pixels of a tower
+    pass and 1/8 of the voxels of a volume pass, scaled back linearly (all stages are
+    convolutions / gathers, linear in pixels resp. voxels) and composed as the pipeline composes
+    them."""
     from atvsnet_amd import synthetic, variables
     from oracle import model as OM, nets
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    threads = min(os.cpu_count() or 1, 32)      # oneDNN scales badly past a few dozen threads on these sizes
+    torch.set_num_threads(threads)
     W = {k: torch.from_numpy(v) for k, v in variables.default_store().host.items()}
-    imgs, cams = synthetic.make_inputs(2, args.height, args.width, args.depths)
-    imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
-    ds, di = OM.depth_start_interval(cams)
-    D, n_src = args.depths, args.views - 1
+    Hs, Ws, Ds = args.height // 2, args.width // 2, max(args.depths // 2, 8)
+    pix_ratio = (args.height * args.width) / float(Hs * Ws)
+    vox_ratio = pix_ratio * args.depths / float(Ds)
+    n_src = args.views - 1
     t0 = time.time()
-    with torch.no_grad():
-        t = time.time()
-        ref_f = nets.resnet_ds2_spp(imgs[:, 0], W)
-        t_tower = time.time() - t
-        view_f = ref_f.flip(2).contiguous()
-        t = time.time()
-        cv = OM.build_cost_volume(ref_f, view_f, cams, D, ds, di, 0, 1)
-        t_warp = time.time() - t
-        t = time.time()
-        pv, filt = OM.cost_volume_reasoning(cv, W)
-        depth = OM.prob2depth(pv, D, ds, di)
-        t_unet = time.time() - t
-        del cv
-        sample = 'tower x1 + warp x1 + StackedUNet_prob x1'
-        t_refine = None
-        if time.time() - t0 < budget_s:
+
+    def stages(H, Wd, D, timed):
+        imgs, cams = synthetic.make_inputs(2, H, Wd, D)
+        imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
+        ds, di = OM.depth_start_interval(cams)
+        T = {}
+        with torch.no_grad():
+            t = time.time()
+            ref_f = nets.resnet_ds2_spp(imgs[:, 0], W)
+            T['tower'] = time.time() - t
+            view_f = nets.resnet_ds2_spp(imgs[:, 1], W) if not timed else ref_f.flip(2).contiguous()
+            t = time.time()
+            cv = OM.build_cost_volume(ref_f, view_f, cams, D, ds, di, 0, 1)
+            T['warp'] = time.time() - t
+            t = time.time()
+            pv, filt = OM.cost_volume_reasoning(cv, W)
+            depth = OM.prob2depth(pv, D, ds, di)
+            T['unet'] = time.time() - t
+            del cv
             t = time.time()
             OM.TVSNet_refine(depth, depth, pv, filt, imgs, cams, D, ds, di, W, view_i=1)
-            t_refine = time.time() - t
-            sample += ' + refinement x1'
-        t_aam = None
-        if time.time() - t0 < budget_s:
+            T['refine'] = time.time() - t
             t = time.time()
             agg = nets.attention_aggregation(torch.stack([filt] * n_src, -1), W, 'attention_aggregate')
-            OM.prob2depth(nets.output_conv(agg, W), D, ds, di)
-            t_aam = time.time() - t
-            sample += ' + AAM x1'
-    if t_refine is None:
-        t_refine = t_unet * 0.9      # FLOP ratio 207/233 (SURVEY.md Appendix D)
-    if t_aam is None:
-        t_aam = t_unet * 0.5
-    per_map = args.views * t_tower + n_src * (2 * (t_warp + t_unet) + t_refine) + 2 * t_aam
-    return {'value': 1.0 / per_map, 'unit': 'depth-maps/sec', 'cores': cores, 'kind': 'port',
-            'sample': '%s at %dx%dxD%d, composed as %d towers + %d x (2 U-Nets + refinement) + 2 AAM; %.1f s measured'
-                      % (sample, args.width, args.height, D, args.views, n_src, time.time() - t0)}
+            OM.prob2depth_upsample(nets.output_conv(agg, W), D, ds, di)
+            T['aam'] = time.time() - t
+        return T
+
+    stages(128, 160, 8, False)                   # warm-up: oneDNN primitive creation, allocator
+    T = stages(Hs, Ws, Ds, True)
+    per_map = (args.views * T['tower'] * pix_ratio +
+               n_src * (2 * (T['warp'] + T['unet']) + T['refine']) * vox_ratio + 2 * T['aam'] * vox_ratio)
+    return {'value': 1.0 / per_map, 'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'port',
+            'sample': 'each stage once on a %dx%d, D=%d crop (tower %.2fs, warp %.2fs, U-Net %.2fs, refinement %.2fs, '
+                      'AAM %.2fs), scaled x%.0f (pixels) / x%.0f (voxels) and composed as %d towers + %d x (2 warps + '
+                      '2 U-Nets + refinement) + 2 AAM; %.1f s of CPU work measured'
+                      % (Ws, Hs, Ds, T['tower'], T['warp'], T['unet'], T['refine'], T['aam'], pix_ratio, vox_ratio,
+                         args.views, n_src, time.time() - t0)}
 
 
 def main():

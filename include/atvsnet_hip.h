@@ -177,8 +177,10 @@ int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int 
 int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream);
 
 /* tf.layers.average_pooling2d(padding='SAME'), network.py:665-671: x (H,W,C) ->
- * y (ceil(H/stride), ceil(W/stride), C), mean over the valid window elements. */
-int atvs_avg_pool_same(const float* x, float* y, int H, int W, int C, int pool, int stride,
+ * y (ceil(H/stride), ceil(W/stride), C), mean over the valid window elements.
+ * ws: atvs_avg_pool_ws_floats(H, W, C, stride) floats of scratch. */
+long atvs_avg_pool_ws_floats(int H, int W, int C, int stride);
+int atvs_avg_pool_same(const float* x, float* y, float* ws, int H, int W, int C, int pool, int stride,
                        atvs_stream_t stream);
 
 /* tf.image.resize_images(BILINEAR, align_corners=True), network.py:649-655:
