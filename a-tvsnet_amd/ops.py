@@ -254,6 +254,91 @@ def pack_conv_weights(key, w_host, taps, transposed, device):
     return pk
 
 
+def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y):
+    """Packed weights + LDS-offset table for the LDS-tiled kernel; cached."""
+    import numpy as np
+    ck = ('tiled', key, taps, bool(transposed), str(device), tile_y)
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)
+    cin, cout = (w.shape[-1], w.shape[-2]) if transposed else (w.shape[-2], w.shape[-1])
+    ntaps = len(taps)
+    L = _lib.lib()
+    nch, ccp, jc, nt = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    pf, ti = ctypes.c_long(), ctypes.c_long()
+    rc = L.atvs_conv_tiled_pack_size(ntaps, cin, cout, ctypes.byref(nch), ctypes.byref(ccp), ctypes.byref(jc),
+                                     ctypes.byref(nt), ctypes.byref(pf), ctypes.byref(ti))
+    if rc:
+        raise RuntimeError('atvs_conv_tiled_pack_size failed (%d)' % rc)
+    packed = np.empty(pf.value, np.float32)
+    table = np.empty(ti.value, np.int32)
+    tp = np.ascontiguousarray(np.array(taps, dtype=np.int32).reshape(-1, 4))
+    rc = L.atvs_conv_tiled_pack(w.ctypes.data_as(ctypes.c_void_p), int(bool(transposed)),
+                                tp.ctypes.data_as(ctypes.c_void_p), ntaps, cin, cout, int(tile_y),
+                                packed.ctypes.data_as(ctypes.c_void_p), table.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv_tiled_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = ntaps, 4, jc.value * nch.value, nt.value, cin, cout
+    pk.key = key
+    if torch.device(device).type == 'meta':
+        pk.wp = pk.tab = None
+    else:
+        pk.wp = torch.from_numpy(packed).to(device)
+        pk.tab = torch.from_numpy(table).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+def tiled_tile_y(H, W, cout):
+    """tile_y for the LDS-tiled kernel, or 0 when the gather kernel should be used."""
+    if _FORCE_IMPL == 'gather':
+        return 0
+    nt = 1
+    while nt * 16 < cout:
+        nt *= 2
+    if W < 12 and _FORCE_IMPL != 'tiled':
+        return 0
+    if nt <= 2 and H >= 16:
+        return 8
+    if nt <= 4:
+        return 4
+    return 0
+
+
+_FORCE_IMPL = None
+
+
+def force_conv_impl(impl):
+    """Testing hook: 'tiled' | 'gather' | None (automatic)."""
+    global _FORCE_IMPL
+    _FORCE_IMPL = impl
+
+
+def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None, residual=None, relu=False,
+                      stats_buf=None):
+    """One atvs_conv_tiled_f32 launch: logical output grid = input grid of x4 (D,H,W,Cin)."""
+    D, H, W, Cin = x4.shape
+    Dy, Hy, Wy, ldy = y.shape
+    if _dev_ok(x4, y, bias, residual):
+        timed = _watch['tag'] is not None and pk.key == _watch['tag']
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _call('atvs_conv_tiled_f32', _p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
+              _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
+              Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
+              pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), _stream())
+        if timed:
+            e1.record()
+            _watch['events'].append((e0, e1))
+
+
+def tiled_blocks(D, H, W, tile_y):
+    return (-(-D // 4)) * (-(-H // tile_y)) * (-(-W // 16))
+
+
 def clear_pack_cache():
     _pack_cache.clear()
 
@@ -350,7 +435,15 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             pads.append(0)
             outs.append((ins[i] - ((ks[i] - 1) * dilation + 1)) // stride + 1)
     taps = conv_taps(ks, dilation, pads)
-    pk = pack_conv_weights(key, w_host, taps, False, x.device)
+    cout = int(w_host.shape[-1])
+    tile_y = 0
+    if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
+            and tuple(outs) == tuple(ins):
+        tile_y = tiled_tile_y(ins[1], ins[2], cout)
+    if tile_y:
+        pk = pack_conv_weights_tiled(key, w_host, taps, False, x.device, tile_y)
+    else:
+        pk = pack_conv_weights(key, w_host, taps, False, x.device)
     if pk.cin != x4.shape[3]:
         raise ValueError('conv %s: input has %d channels, kernel wants %d' % (key, x4.shape[3], pk.cin))
     if out is None:
@@ -363,14 +456,20 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     if residual is not None:
         res4 = residual if residual.dim() == 4 else residual.reshape((1,) + tuple(residual.shape))
     M = outs[0] * outs[1] * outs[2]
-    blocks, tm = conv_blocks(M, pk.ntiles)
+    if tile_y:
+        blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y), 0
+    else:
+        blocks, tm = conv_blocks(M, pk.ntiles)
     st = None
     sbuf = None
     if want_stats:
         sbuf = _stats_buffer(x, blocks, pk.ntiles * 16)
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
-    conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm)
+    if tile_y:
+        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf)
+    else:
+        conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm)
     y = out if out is not None else (y4 if nsp == 3 else y4.reshape(tuple(y4.shape[1:])))
     return (y, st) if want_stats else y
 
@@ -385,8 +484,14 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
     y = _new(x, (2 * D, 2 * H, 2 * W, cout))
     M = D * H * W
     classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
-    pks = [pack_conv_weights(key, w_host, deconv_s2_class_taps(par), True, x.device) for par in classes]
-    blocks, tm = conv_blocks(M, pks[0].ntiles)
+    tile_y = tiled_tile_y(H, W, cout)
+    if tile_y:
+        pks = [pack_conv_weights_tiled(key, w_host, deconv_s2_class_taps(par), True, x.device, tile_y)
+               for par in classes]
+        blocks, tm = tiled_blocks(D, H, W, tile_y), 0
+    else:
+        pks = [pack_conv_weights(key, w_host, deconv_s2_class_taps(par), True, x.device) for par in classes]
+        blocks, tm = conv_blocks(M, pks[0].ntiles)
     cpad = pks[0].ntiles * 16
     st = None
     sbuf = None
@@ -396,7 +501,10 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks * 8, cpad, 8 * M
     for i, (par, pk) in enumerate(zip(classes, pks)):
         sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
-        conv_launch(x, pk, y, (D, H, W), 1, 2, par, 0, None, None, relu, sb, tm)
+        if tile_y:
+            conv_tiled_launch(x, pk, y, 2, par, 0, tile_y, None, None, relu, sb)
+        else:
+            conv_launch(x, pk, y, (D, H, W), 1, 2, par, 0, None, None, relu, sb, tm)
     return (y, st) if want_stats else y
 
 

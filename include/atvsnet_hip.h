@@ -153,6 +153,23 @@ int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* gro
                        int out_stride, int off_z, int off_y, int off_x, int ldy, int y_coff, int Cout,
                        int ntaps, int tile_m, int relu, atvs_stream_t stream);
 
+/* LDS-tiled variant of the same convolution for halo-1 stencils: 3-D, input step 1, every
+ * tap offset in [-1,1]^3 (3x3x3 stride-1 SAME convolutions; each parity class of the
+ * stride-2 transposed convolution).  A workgroup computes a 4 x tile_y x 16 block of the
+ * logical output grid (= the input grid D,H,W) from an input halo tile staged once in LDS.
+ * atvs_conv_tiled_pack_size / _pack are the HOST packing functions for it (same inputs
+ * as atvs_conv_pack; the table depends on tile_y in {4, 8}); stats_partial has
+ * atvs_conv_tiled_num_blocks rows of 16*ntiles doubles x 2. */
+int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* chunk_pad, int* ksteps_per_chunk,
+                              int* ntiles, long* packed_floats, long* table_ints);
+int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
+                         int tile_y, float* packed, int32_t* table);
+long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y);
+int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
+                        const float* residual, float* y, double* stats_partial, int D, int H, int W, int Cin,
+                        int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
+                        int y_coff, int Cout, int ntaps, int tile_y, int relu, atvs_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Batch norm with batch statistics, element-wise glue  (cnn_wrapper/network.py)
  * ------------------------------------------------------------------------- */

@@ -39,8 +39,19 @@ CONV3D = [
 ]
 
 
-@pytest.mark.parametrize('D,H,W,Cin,Cout,stride', CONV3D)
-def test_conv3d_same(cuda, D, H, W, Cin, Cout, stride):
+@pytest.fixture(params=['gather', 'tiled', None])
+def impl(request):
+    from atvsnet_amd import ops
+    ops.force_conv_impl(request.param)
+    ops.clear_pack_cache()
+    yield request.param
+    ops.force_conv_impl(None)
+    ops.clear_pack_cache()
+
+
+@pytest.mark.parametrize('D,H,W,Cin,Cout,stride', CONV3D + [(9, 17, 35, 64, 8, 1), (5, 20, 40, 48, 8, 1),
+                                                              (4, 16, 32, 32, 32, 1), (7, 33, 18, 8, 16, 1)])
+def test_conv3d_same(cuda, impl, D, H, W, Cin, Cout, stride):
     from atvsnet_amd import ops
     x = _rand((1, D, H, W, Cin), 1)
     w = _rand((3, 3, 3, Cin, Cout), 2, 0.2)
@@ -109,8 +120,8 @@ def test_conv2d_explicit_pad_valid_with_residual(cuda, stride):
     _close(got.cpu(), want + res)
 
 
-@pytest.mark.parametrize('D,H,W,Cin,Cout', [(3, 4, 5, 64, 32), (4, 4, 4, 32, 16), (6, 5, 7, 16, 8)])
-def test_conv3d_transpose(cuda, D, H, W, Cin, Cout):
+@pytest.mark.parametrize('D,H,W,Cin,Cout', [(3, 4, 5, 64, 32), (4, 4, 4, 32, 16), (6, 5, 7, 16, 8), (5, 18, 20, 16, 8)])
+def test_conv3d_transpose(cuda, impl, D, H, W, Cin, Cout):
     from atvsnet_amd import ops
     x = _rand((1, D, H, W, Cin), 12)
     w = _rand((3, 3, 3, Cout, Cin), 13, 0.2)
