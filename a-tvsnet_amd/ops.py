@@ -322,7 +322,7 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
     D, H, W, Cin = x4.shape
     Dy, Hy, Wy, ldy = y.shape
     if _dev_ok(x4, y, bias, residual):
-        timed = _watch['tag'] is not None and pk.key == _watch['tag']
+        timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -332,7 +332,7 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
               pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), _stream())
         if timed:
             e1.record()
-            _watch['events'].append((e0, e1))
+            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
 
 
 def tiled_blocks(D, H, W, tile_y):
@@ -365,7 +365,7 @@ def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bia
     M = Do * Ho * Wo
     tm = tile_m or _pick_tile_m(M, pk.ntiles)
     if _dev_ok(x4, y, bias, residual):
-        timed = _watch['tag'] is not None and pk.key == _watch['tag']
+        timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -376,7 +376,7 @@ def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bia
         _call('atvs_conv_mfma_f32', *args)
         if timed:
             e1.record()
-            _watch['events'].append((e0, e1))
+            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
     return tm
 
 
@@ -385,11 +385,15 @@ _watch = {'tag': None, 'events': []}
 
 def watch(tag):
     """Time every convolution launch whose weight key is `tag` with HIP events on the launch stream.
-    watch(None) stops and returns the list of durations in ms."""
+    tag '*' times every convolution launch.  watch(None) stops and returns the list of durations in ms
+    (for '*': a list of (key, input shape, Cout, ms))."""
     out = None
     if tag is None:
         torch.cuda.synchronize()
-        out = [a.elapsed_time(b) for a, b in _watch['events']]
+        if _watch['tag'] == '*':
+            out = [(e[2], e[3], e[4], e[0].elapsed_time(e[1])) for e in _watch['events']]
+        else:
+            out = [e[0].elapsed_time(e[1]) for e in _watch['events']]
     _watch['tag'] = tag
     _watch['events'] = []
     return out

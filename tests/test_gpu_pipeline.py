@@ -71,6 +71,22 @@ def test_twoview_end_to_end(cuda, weights):
     assert float(want.std()) > 0.02            # not a degenerate (flat) answer
 
 
+def test_against_committed_oracle_fixture(cuda, weights):
+    """The same pipelines against tests/golden/oracle_cfg1.npz (made by tests/golden/make_oracle_golden.py)."""
+    import os
+    import numpy as np
+    from atvsnet_amd.atvsnet import example as ex
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'oracle_cfg1.npz'))
+    imgs, cams = _inputs(2)
+    got = ex.infer_twoview(imgs.to(cuda), cams.to(cuda), 32).cpu()[0, ..., 0]
+    assert rel_l1(got, torch.from_numpy(gold['twoview_depth'])) <= 1e-3
+    imgs, cams = _inputs(3)
+    G = {}
+    got = ex.infer_multiview(imgs.to(cuda), cams.to(cuda), 32, G).cpu()[0, ..., 0]
+    assert rel_l1(got, torch.from_numpy(gold['multiview3_depth'])) <= 1e-3
+    assert rel_l1(G['depth_agg_init'].cpu()[0, ..., 0], torch.from_numpy(gold['multiview3_depth_agg_init'])) <= 1e-3
+
+
 def test_multiview_end_to_end(cuda, weights):
     from atvsnet_amd.atvsnet import example as ex
     imgs, cams = _inputs(4)
