@@ -89,13 +89,22 @@ def extract_feature_shallow(images, ref_id=0, view_id=1, ref_feature=None):
 
 
 def build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id, view_id,
-                      output_homo=False, warp_ref=False):
-    """concat([tile(ref), stack_d warp_d(view)], channel) -> (B,D,H,W,2F) (reference :157-200)."""
+                      output_homo=False, warp_ref=False, lazy=False):
+    """concat([tile(ref), stack_d warp_d(view)], channel) -> (B,D,H,W,2F) (reference :157-200).
+
+    lazy=True returns an ops.SplitVolume (warped half (D,h,w,F) + the un-tiled reference features) that
+    the networks consume without ever building the tiled half."""
     if warp_ref:
         raise NotImplementedError('build_cost_volume(warp_ref=True) is an unused branch of the reference (:175-184)')
     H = get_homographies(cams[:, ref_id], cams[:, view_id], depth_num=depth_num, depth_start=depth_start,
                          depth_interval=depth_interval)
-    cv = ops.build_cost_volume(ref_feature[0].contiguous(), view_feature[0].contiguous(), H[0]).unsqueeze(0)
+    rf, vf = ref_feature[0].contiguous(), view_feature[0].contiguous()
+    if lazy:
+        F = rf.shape[-1]
+        cv = ops.SplitVolume(ops.warp_planes(vf, H[0].contiguous()), rf,
+                             [('c', i) for i in range(F)] + [('v', i) for i in range(F)])
+    else:
+        cv = ops.build_cost_volume(rf, vf, H[0]).unsqueeze(0)
     return (cv, H) if output_homo else cv
 
 
@@ -146,24 +155,25 @@ def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, 
     rc, vc = ref_cam[0].contiguous(), view_cam[0].contiguous()
 
     # photo_group = [ |warp_d(view_f) - ref_f| * mask , tile(photo_err) , tile(ref_f) ]   (:270-280, 309-311, 329, 333)
-    photo = torch.empty((D, h, w, 3 * chan), dtype=torch.float32, device=rf.device)
-    ops.warp_planes(vf, Hm, out=photo, c_off=0, mode=1, ref=rf)
+    # geo_group   = [ geo_ref(1) , geo_view (mask tiled to `chan` identical channels, quirk C7) , tile(geo_err) ,
+    #                 tile(init_ref) ]                                                    (:285-300, 313-316, 330, 334)
+    # Only the D-varying channels are built as volumes; the tiled maps stay (h,w,C) (ops.SplitVolume).
     wfeat, mphoto = ops.warp_by_depth(vf, rc, vc, dref, 'bilinear', FLAGS.inverse_depth)
-    ops.tile_planes(ops.absdiff_mask(wfeat, rf, mphoto), photo, chan)
-    ops.tile_planes(rf, photo, 2 * chan)
-
-    # geo_group = [ geo_ref(1) , geo_view (mask tiled to `chan` identical channels, quirk C7) , tile(geo_err) ,
-    #               tile(init_ref) ]                                                      (:285-300, 313-316, 330, 334)
-    geo = torch.empty((D, h, w, 1 + chan + 2), dtype=torch.float32, device=rf.device)
-    ops.geo_ref_planes(dref, ds, di, geo, 0)
-    ops.warp_planes(dvt, Hm, out=geo, c_off=1, mode=2, depth_start=ds, depth_interval=di, rep=chan)
+    photo_err = ops.absdiff_mask(wfeat, rf, mphoto)
     wdep, mgeo = ops.warp_by_depth(dvt, rc, vc, dref, 'nearest', FLAGS.inverse_depth)
-    ops.tile_planes(ops.absdiff_mask(wdep, dref.reshape(h, w, 1), mgeo), geo, 1 + chan)
-    ops.tile_planes(dref.reshape(h, w, 1), geo, 2 + chan)
+    geo_err = ops.absdiff_mask(wdep, dref.reshape(h, w, 1), mgeo)
+    photo_var = ops.warp_planes(vf, Hm, mode=1, ref=rf)                              # (D,h,w,chan)
+    photo = ops.SplitVolume(photo_var, ops.concat_channels([photo_err, rf]),
+                            [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
+    geo_var = torch.empty((D, h, w, 2), dtype=torch.float32, device=rf.device)
+    ops.geo_ref_planes(dref, ds, di, geo_var, 0)
+    ops.warp_planes(dvt, Hm, out=geo_var, c_off=1, mode=2, depth_start=ds, depth_interval=di, rep=1)
+    geo = ops.SplitVolume(geo_var, ops.concat_channels([geo_err, dref.reshape(h, w, 1)]),
+                          [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
 
     vis_hull = get_visual_hull(init_depth_images.squeeze(-1), cams, D, depth_start, depth_interval, ref_id=ref_id,
                                view_num=num_depths)
-    tower = CostVolRefineNet({'photo_group': photo.unsqueeze(0), 'geo_group': geo.unsqueeze(0),
+    tower = CostVolRefineNet({'photo_group': photo, 'geo_group': geo,
                               'prob_vol': prob_vol.unsqueeze(-1), 'vis_hull': vis_hull},
                              is_training=True, reuse=AUTO_REUSE)
     return tower.get_output_by_name('global_refine_3dconv6_1'), tower.get_output().squeeze(-1)
@@ -179,12 +189,12 @@ def TVSNet(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0
     ref_feature = TVSNet_feature_extraction(images, ref_i)
     view_feature = TVSNet_feature_extraction(images, view_i)
     cost_vol_view = build_cost_volume(view_feature, ref_feature, cams, depth_num, depth_start, depth_interval,
-                                      ref_id=view_i, view_id=0)
+                                      ref_id=view_i, view_id=0, lazy=True)
     prob_vol_view = cost_volume_reasoning(cost_vol_view, output_filtered_cost=False)
     del cost_vol_view
     depth_view = prob2depth(prob_vol_view, depth_num, depth_start, depth_interval)
     cost_vol = build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id=0,
-                                 view_id=view_i)
+                                 view_id=view_i, lazy=True)
     prob_vol_b2, _ = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
     del cost_vol
     depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
@@ -201,7 +211,7 @@ def TVSNet_base(images, cams, depth_num, depth_start, depth_interval, view_i, re
         ref_feature = TVSNet_feature_extraction(images, ref_i)
     view_feature = TVSNet_feature_extraction(images, view_i)
     cost_vol = build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id=0,
-                                 view_id=view_i)
+                                 view_id=view_i, lazy=True)
     prob_vol_b2, filtered = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
     depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
     return depth_b2, prob_vol_b2, filtered
@@ -215,12 +225,12 @@ def TVSNet_base_siamese(images, cams, depth_num, depth_start, depth_interval, vi
         ref_feature = TVSNet_feature_extraction(images, ref_i)
     view_feature = TVSNet_feature_extraction(images, view_i)
     cost_vol = build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id=0,
-                                 view_id=view_i)
+                                 view_id=view_i, lazy=True)
     prob_vol_b2, filtered = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
     del cost_vol
     depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
     cost_vol_view = build_cost_volume(view_feature, ref_feature, cams, depth_num, depth_start, depth_interval,
-                                      ref_id=view_i, view_id=0)
+                                      ref_id=view_i, view_id=0, lazy=True)
     prob_vol_view = cost_volume_reasoning(cost_vol_view, output_filtered_cost=False, reuse=AUTO_REUSE)
     del cost_vol_view
     depth_view = prob2depth(prob_vol_view, depth_num, depth_start, depth_interval)

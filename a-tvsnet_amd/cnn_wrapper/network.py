@@ -48,6 +48,8 @@ def layer(op):
 
 
 def _b1(x, what):
+    if isinstance(x, ops.SplitVolume):
+        x = x.materialize()
     if x.shape[0] != 1:
         raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d' % (what, x.shape[0]))
     return x[0]
@@ -182,6 +184,13 @@ class Network(object):
         rank = input.dim()
         if rank not in (4, 5):
             raise ValueError('Improper input rank for layer: ' + name)
+        if isinstance(input, ops.SplitVolume):
+            if kernel_size == 3 and rate == 1 and padding == 'SAME' and not biased and self.training:
+                vname = '%s/conv3d/kernel' % name
+                w = self._kernel(vname, (3, 3, 3, input.shape[-1], filters))
+                y, st = ops.conv_split(input, vname, w, stride=strides, want_stats=True)
+                return self._bn(y, st, name, center, relu).unsqueeze(0)
+            input = input.materialize()
         x = _b1(input, name)
         cin = x.shape[-1]
         kind = 'conv2d' if rank == 4 else 'conv3d'

@@ -39,7 +39,17 @@ struct ConvArgs {
   int J;                   // K steps (4 groups each)
   int relu;
   int vec_out;
+  const float* pbias;      // (Ho, Wo, 3*Cout) depth-plane bias variants or nullptr (see plane_variant)
+  int pb_pz;               // z padding before, to pick the variant
 };
+
+// Contribution of input channels that are CONSTANT along depth (tf.tile'd reference features,
+// model.py:186,311,316,329-330): it equals a 2-D convolution with the kd-summed kernel, computed once
+// per (y, x) for the three sets of kd taps that fall inside the volume, and is added here like a bias.
+//   variant 0: kd = 0 falls before the first plane;  1: all three planes exist;  2: kd = 2 falls past the end.
+__device__ __forceinline__ int plane_variant(int z_in_first, int Di) {
+  return (z_in_first < 0) ? 0 : ((z_in_first + 2 >= Di) ? 2 : 1);
+}
 
 template <int V>
 struct AVal;
@@ -156,11 +166,19 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs p) {
     int zo = (int)(rest / p.Ho);
     size_t vox = ((size_t)(zo * p.oS + p.offz) * p.Hy + (yo * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx);
     size_t base = vox * (size_t)p.ldy + p.ycoff;
+    const float* pb = nullptr;
+    if (p.pbias)
+      pb = p.pbias + ((size_t)yo * p.Wo + xo) * (size_t)(3 * p.Cout) + plane_variant(zo * p.sI - p.pb_pz, p.Di) * p.Cout;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       int co = n * 16 + 4 * q;
       if (co >= p.Cout) continue;
       float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
+      if (pb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (co + k < p.Cout) v[k] += pb[co + k];
+      }
       if (p.vec_out) {
         if (p.bias) {
           float4 b = ld4(p.bias + co);
@@ -322,7 +340,8 @@ static int launch_nt(const ConvArgs& a, int NT, int TM, hipStream_t s) {
 }
 
 extern "C" int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* group_table, const float* bias,
-                                  const float* residual, float* y, double* stats_partial, int Di, int Hi, int Wi,
+                                  const float* residual, const float* plane_bias, int pad_z, float* y,
+                                  double* stats_partial, int Di, int Hi, int Wi,
                                   int Cin, int Do, int Ho, int Wo, int in_stride, int Dy, int Hy, int Wy,
                                   int out_stride, int off_z, int off_y, int off_x, int ldy, int y_coff, int Cout,
                                   int ntaps, int tile_m, int relu, atvs_stream_t stream) {
@@ -343,6 +362,8 @@ extern "C" int atvs_conv_mfma_f32(const float* x, const float* packed_w, const i
   a.sI = in_stride; a.Hy = Hy; a.Wy = Wy; a.oS = out_stride; a.offz = off_z; a.offy = off_y; a.offx = off_x;
   a.ldy = ldy; a.ycoff = y_coff; a.Cout = Cout; a.J = J; a.relu = relu;
   a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
+  a.pbias = plane_bias; a.pb_pz = pad_z;
+  if (plane_bias && (out_stride != 1 || Di < 2)) return ATVS_ERR_ARG;
   if (residual && y_coff != 0) return ATVS_ERR_ARG;   // residual shares y's addressing
   hipStream_t s = as_stream(stream);
   rc = (V == 4) ? launch_nt<4>(a, NT, tile_m, s) : launch_nt<1>(a, NT, tile_m, s);
@@ -380,6 +401,7 @@ struct TiledArgs {
   int nchunk, Cc, Ccp, Jc;   // chunks, real / padded channels per chunk, K steps per chunk
   int tiles_y, tiles_x;      // grid decomposition
   int relu, vec_out, vec_in;
+  const float* pbias;        // (H, W, 3*Cout) or nullptr
 };
 
 template <int NT, int TY>
@@ -494,11 +516,19 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_f32_kernel(TiledArgs p) {
     if (zo >= p.Di || yo >= p.Hi || xo >= p.Wi) continue;
     size_t vox = ((size_t)(zo * p.oS + p.offz) * p.Hy + (yo * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx);
     size_t base = vox * (size_t)p.ldy + p.ycoff;
+    const float* pb = nullptr;
+    if (p.pbias)
+      pb = p.pbias + ((size_t)yo * p.Wi + xo) * (size_t)(3 * p.Cout) + plane_variant(zo - 1, p.Di) * p.Cout;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       int co = n * 16 + 4 * q;
       if (co >= p.Cout) continue;
       float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
+      if (pb) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (co + k < p.Cout) v[k] += pb[co + k];
+      }
       if (p.vec_out) {
         if (p.bias) {
           float4 b = ld4(p.bias + co);
@@ -654,7 +684,8 @@ static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
 // the input grid (D,H,W); output voxel = o*out_stride + off inside the full tensor (Dy,Hy,Wy,ldy).
 // stats_partial rows = atvs_conv_tiled_num_blocks(D,H,W,tile_y), width 16*ntiles.  tile_y in {4, 8}.
 extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
-                                   const float* residual, float* y, double* stats_partial, int D, int H, int W, int Cin,
+                                   const float* residual, const float* plane_bias, float* y, double* stats_partial,
+                                   int D, int H, int W, int Cin,
                                    int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
                                    int y_coff, int Cout, int ntaps, int tile_y, int relu, atvs_stream_t stream) {
   if (!x || !packed_w || !table || !y) return ATVS_ERR_NULL;
@@ -675,6 +706,8 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   a.relu = relu;
   a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
   a.vec_in = (Cin % 4 == 0);
+  a.pbias = plane_bias;
+  if (plane_bias && (out_stride != 1 || D < 2)) return ATVS_ERR_ARG;
   long blocks = atvs_conv_tiled_num_blocks(D, H, W, tile_y);
   hipStream_t s = as_stream(stream);
   if (tile_y == 8) {

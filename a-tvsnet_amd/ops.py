@@ -317,17 +317,17 @@ def force_conv_impl(impl):
 
 
 def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None, residual=None, relu=False,
-                      stats_buf=None):
+                      stats_buf=None, plane_bias=None):
     """One atvs_conv_tiled_f32 launch: logical output grid = input grid of x4 (D,H,W,Cin)."""
     D, H, W, Cin = x4.shape
     Dy, Hy, Wy, ldy = y.shape
-    if _dev_ok(x4, y, bias, residual):
+    if _dev_ok(x4, y, bias, residual, plane_bias):
         timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
         _call('atvs_conv_tiled_f32', _p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
-              _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
+              _p(plane_bias), _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
               Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
               pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), _stream())
         if timed:
@@ -357,19 +357,20 @@ class Stats(object):
 
 
 def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bias=None, residual=None, relu=False,
-                stats_buf=None, tile_m=None):
+                stats_buf=None, tile_m=None, plane_bias=None, pad_z=0):
     """One atvs_conv_mfma_f32 launch.  x4: (Di,Hi,Wi,Cin); y: full output (Dy,Hy,Wy,ldy)."""
     Di, Hi, Wi, Cin = x4.shape
     Dy, Hy, Wy, ldy = y.shape
     Do, Ho, Wo = out_grid
     M = Do * Ho * Wo
     tm = tile_m or _pick_tile_m(M, pk.ntiles)
-    if _dev_ok(x4, y, bias, residual):
+    if _dev_ok(x4, y, bias, residual, plane_bias):
         timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        args = [_p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual), _p(y),
+        args = [_p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual), _p(plane_bias),
+                int(pad_z), _p(y),
                 ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0),
                 Di, Hi, Wi, Cin, Do, Ho, Wo, int(in_stride), Dy, Hy, Wy, int(out_stride), int(out_off[0]),
                 int(out_off[1]), int(out_off[2]), ldy, int(y_coff), pk.cout, pk.ntaps, tm, int(bool(relu)), _stream()]
@@ -409,7 +410,7 @@ def _stats_buffer(ref, blocks, cpad):
 
 
 def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None, bias=None, residual=None,
-         relu=False, want_stats=False, out=None, y_coff=0):
+         relu=False, want_stats=False, out=None, y_coff=0, plane_bias=None):
     """Forward convolution of a channel-last tensor x: (H,W,C) or (D,H,W,C).
 
     w_host: TF-layout numpy kernel [k.., Cin, Cout]; `key` names it for the pack cache.
@@ -470,12 +471,85 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         sbuf = _stats_buffer(x, blocks, pk.ntiles * 16)
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
+    if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
+        raise ValueError('conv %s: plane_bias %s, expected %s' % (key, tuple(plane_bias.shape), (outs[1], outs[2], 3 * pk.cout)))
     if tile_y:
-        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf)
+        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf, plane_bias)
     else:
-        conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm)
+        conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm, plane_bias, pads[0])
     y = out if out is not None else (y4 if nsp == 3 else y4.reshape(tuple(y4.shape[1:])))
     return (y, st) if want_stats else y
+
+
+class SplitVolume(object):
+    """A (1,D,h,w,C) network input whose channels are a concat of D-varying and D-constant parts.
+
+    Stands for tf.concat([...tf.tile(x, [1,D,1,1,1])...], -1) of model.py:186-195, 329-336 without
+    materialising the tiled parts.  var: (D,h,w,Cv); const: (h,w,Cc); chan_map: for each channel of
+    the reference's concat, ('v', i) or ('c', i) -- several channels may map to the same source
+    (the 16 identical geo-view channels, quirk C7)."""
+
+    def __init__(self, var, const, chan_map):
+        self.var, self.const, self.chan_map = var, const, list(chan_map)
+        self.device = var.device
+
+    @property
+    def shape(self):
+        D, h, w, _ = self.var.shape
+        return (1, D, h, w, len(self.chan_map))
+
+    def dim(self):
+        return 5
+
+    @property
+    def is_meta(self):
+        return self.var.is_meta
+
+    def materialize(self):
+        """The dense (1,D,h,w,C) tensor the reference would build."""
+        D, h, w, _ = self.var.shape
+        C = len(self.chan_map)
+        out = _new(self.var, (D, h, w, C))
+        for ch, (kind, i) in enumerate(self.chan_map):
+            if kind == 'v':
+                copy_channels(self.var, out, 1, i, ch)
+            else:
+                src = _new(self.const, (h, w, 1))
+                copy_channels(self.const, src, 1, i, 0)
+                tile_planes(src, out, ch)
+        return out.unsqueeze(0)
+
+
+_fold_cache = {}
+
+
+def _fold_split_weights(key, w_host, chan_map, cv, cc):
+    """W (3,3,3,C,Cout) -> (W_var (3,3,3,Cv,Cout), W_planes (3,3,Cc,3*Cout)); cached per key."""
+    import numpy as np
+    ck = (key, tuple(chan_map))
+    hit = _fold_cache.get(ck)
+    if hit is not None:
+        return hit
+    w = np.asarray(w_host, np.float32)
+    cout = w.shape[-1]
+    wv = np.zeros((3, 3, 3, cv, cout), np.float32)
+    wc = np.zeros((3, 3, 3, cc, cout), np.float32)
+    for ch, (kind, i) in enumerate(chan_map):
+        (wv if kind == 'v' else wc)[:, :, :, i, :] += w[:, :, :, ch, :]
+    # the three sets of in-range kd taps: [kd=0 missing | all | kd=2 missing]
+    planes = np.concatenate([wc[1] + wc[2], (wc[0] + wc[1]) + wc[2], wc[0] + wc[1]], axis=-1)
+    hit = (wv, np.ascontiguousarray(planes))
+    _fold_cache[ck] = hit
+    return hit
+
+
+def conv_split(sv, key, w_host, stride=1, want_stats=False):
+    """3x3x3 SAME convolution of a SplitVolume: conv3d over the D-varying channels plus the 2-D convolution
+    of the D-constant channels (kd-summed kernel) added per depth plane in the epilogue."""
+    cv, cc = sv.var.shape[-1], sv.const.shape[-1]
+    wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
+    pb = conv(sv.const, key + '#planes', planes, stride=stride)            # (ho, wo, 3*Cout)
+    return conv(sv.var, key + '#var', wv, stride=stride, want_stats=want_stats, plane_bias=pb)
 
 
 def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):

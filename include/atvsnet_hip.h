@@ -143,12 +143,18 @@ long atvs_conv_num_blocks(long M, int tile_m);
  *   o*out_stride + off for o in the logical grid (Do,Ho,Wo) and reads inputs at
  *   o*in_stride + tap offset.  bias (Cout) / residual (same addressing as y,
  *   y_coff must be 0) may be NULL.  relu != 0 applies max(.,0) last.
+ *   plane_bias: NULL, or (Ho,Wo,3*Cout): the contribution of input channels that are
+ *   constant along depth (the tf.tile'd halves of model.py:186,311,316,329-330), i.e. the
+ *   2-D convolution of those channels with the kd-summed kernel, for the three sets of
+ *   in-range kd taps [kd=0 missing | all | kd=2 missing]; added per output voxel according
+ *   to its plane (pad_z = z padding before).  3x3x3 kernels, out_stride 1 only.
  *   stats_partial: NULL, or [atvs_conv_num_blocks][2][16*ntiles] doubles receiving
  *   per-workgroup (sum, sum of squares) of the values written, per channel, for
  *   training-mode batch norm (network.py:206-212).  tile_m in {1,2,4,8},
  *   tile_m * ntiles <= 16. */
 int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* group_table, const float* bias,
-                       const float* residual, float* y, double* stats_partial, int Di, int Hi, int Wi,
+                       const float* residual, const float* plane_bias, int pad_z, float* y,
+                       double* stats_partial, int Di, int Hi, int Wi,
                        int Cin, int Do, int Ho, int Wo, int in_stride, int Dy, int Hy, int Wy,
                        int out_stride, int off_z, int off_y, int off_x, int ldy, int y_coff, int Cout,
                        int ntaps, int tile_m, int relu, atvs_stream_t stream);
@@ -166,7 +172,8 @@ int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, 
                          int tile_y, float* packed, int32_t* table);
 long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y);
 int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
-                        const float* residual, float* y, double* stats_partial, int D, int H, int W, int Cin,
+                        const float* residual, const float* plane_bias, float* y, double* stats_partial,
+                        int D, int H, int W, int Cin,
                         int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
                         int y_coff, int Cout, int ntaps, int tile_y, int relu, atvs_stream_t stream);
 

@@ -216,3 +216,25 @@ def test_aanet(cuda, nv):
     acc = ops.aanet_partial(srs, xs, 2, ssum=ssum, umax=umax)
     got2 = ops.divide(acc[1], acc[0])
     assert float((got2.cpu() - want).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_split_volume_conv_matches_dense(cuda, impl, stride):
+    """conv over concat([var, tile(const)]) == conv3d(var) + per-plane 2-D conv of the constant channels,
+    including replicated channels (geo_group, quirk C7) and first/last depth planes."""
+    from atvsnet_amd import ops
+    D, h, w = 6, 16, 20
+    var = _rand((D, h, w, 2), 30)
+    const = _rand((h, w, 3), 31)
+    cmap = [('v', 0)] + [('v', 1)] * 4 + [('c', 2), ('c', 0), ('c', 1)]
+    dense = torch.cat([var[..., :1]] + [var[..., 1:2]] * 4 +
+                      [const[None, ..., 2:3].expand(D, -1, -1, -1), const[None, ..., :2].expand(D, -1, -1, -1)], -1)
+    wgt = _rand((3, 3, 3, 8, 8), 32, 0.3)
+    want = T.conv(dense[None], wgt, stride, 'SAME')[0]
+    sv = ops.SplitVolume(var.to(cuda), const.to(cuda), cmap)
+    assert sv.shape == (1, D, h, w, 8)
+    assert torch.equal(sv.materialize().cpu()[0], dense)
+    got, st = ops.conv_split(sv, ('split', stride), wgt.numpy(), stride=stride, want_stats=True)
+    _close(got.cpu(), want)
+    s = st.partial.sum(0).cpu()
+    _close(s[0, :8].float(), want.reshape(-1, 8).double().sum(0).float(), 1e-5)

@@ -55,7 +55,7 @@ def _worker(rank, world, port, nviews, q):
         X = torch.randn(nviews, 6, 8, 10, 8, generator=g)
         mine = [X[v - 1] for v in parallel.local_views(nviews + 1, rank, world)]
         out = parallel.sharded_attention(mine, 'attention_aggregate', X[0], impl=OracleAttentionOps(W))
-        q.put((rank, out))
+        q.put((rank, out.numpy().copy()))     # plain bytes: the worker may exit before the parent reads
     finally:
         dist.destroy_process_group()
 
@@ -69,7 +69,7 @@ def test_sharded_attention_equals_single_process(weights, nviews):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, nviews, q)) for r in range(2)]
     for p in procs:
         p.start()
-    outs = dict(q.get(timeout=120) for _ in range(2))
+    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(2))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
