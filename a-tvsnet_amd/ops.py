@@ -548,8 +548,8 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False):
     of the D-constant channels (kd-summed kernel) added per depth plane in the epilogue."""
     cv, cc = sv.var.shape[-1], sv.const.shape[-1]
     wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
-    pb = conv(sv.const, key + '#planes', planes, stride=stride)            # (ho, wo, 3*Cout)
-    return conv(sv.var, key + '#var', wv, stride=stride, want_stats=want_stats, plane_bias=pb)
+    pb = conv(sv.const, (key, 'planes'), planes, stride=stride)            # (ho, wo, 3*Cout)
+    return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb)
 
 
 def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
