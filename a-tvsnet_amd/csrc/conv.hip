@@ -402,6 +402,9 @@ struct TiledArgs {
   int tiles_y, tiles_x;      // grid decomposition
   int relu, vec_out, vec_in;
   const float* pbias;        // (H, W, 3*Cout) or nullptr
+  // fused stride-2 transposed convolution: the GEMM's N axis is (parity class, output channel);
+  // cls_cout = real Cout (0 = ordinary convolution), cls_base = first class of this launch
+  int cls_cout, cls_base;
 };
 
 template <int NT, int TY>
@@ -524,6 +527,22 @@ __global__ __launch_bounds__(256, 2) void conv_tiled_f32_kernel(TiledArgs p) {
       int co = n * 16 + 4 * q;
       if (co >= p.Cout) continue;
       float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
+      if (p.cls_cout) {
+        // virtual channel -> (parity class, real channel); output voxel (2z+pz, 2y+py, 2x+px)
+        int cls = p.cls_base + co / p.cls_cout, cr = co % p.cls_cout;
+        size_t ov = ((size_t)(zo * 2 + (cls >> 2)) * p.Hy + (yo * 2 + ((cls >> 1) & 1))) * p.Wy + (xo * 2 + (cls & 1));
+        if (p.relu) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        st4(p.y + ov * (size_t)p.ldy + p.ycoff + cr, make_float4(v[0], v[1], v[2], v[3]));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          ssum[n][k] += v[k];
+          ssq[n][k] += v[k] * v[k];
+        }
+        continue;
+      }
       if (pb) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -687,12 +706,20 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
                                    const float* residual, const float* plane_bias, float* y, double* stats_partial,
                                    int D, int H, int W, int Cin,
                                    int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
-                                   int y_coff, int Cout, int ntaps, int tile_y, int relu, atvs_stream_t stream) {
+                                   int y_coff, int Cout, int ntaps, int tile_y, int relu, int class_cout, int class_base,
+                                   atvs_stream_t stream) {
   if (!x || !packed_w || !table || !y) return ATVS_ERR_NULL;
   if (D <= 0 || H <= 0 || W <= 0 || out_stride <= 0) return ATVS_ERR_SHAPE;
-  if (y_coff < 0 || y_coff + Cout > ldy) return ATVS_ERR_SHAPE;
-  if ((D - 1) * out_stride + off_z >= Dy || (H - 1) * out_stride + off_y >= Hy || (W - 1) * out_stride + off_x >= Wy)
-    return ATVS_ERR_SHAPE;
+  if (class_cout) {
+    // fused transposed convolution: Cout = classes_in_this_launch * class_cout virtual channels
+    if (class_cout % 4 || Cout % class_cout || class_base < 0 || class_base + Cout / class_cout > 8) return ATVS_ERR_SHAPE;
+    if (y_coff < 0 || y_coff + class_cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+    if (2 * D > Dy || 2 * H > Hy || 2 * W > Wy || bias || residual || plane_bias) return ATVS_ERR_ARG;
+  } else {
+    if (y_coff < 0 || y_coff + Cout > ldy) return ATVS_ERR_SHAPE;
+    if ((D - 1) * out_stride + off_z >= Dy || (H - 1) * out_stride + off_y >= Hy || (W - 1) * out_stride + off_x >= Wy)
+      return ATVS_ERR_SHAPE;
+  }
   if (residual && y_coff != 0) return ATVS_ERR_ARG;
   int nch, Ccp, Jc, NT;
   int rc = atvs_conv_tiled_pack_size(ntaps, Cin, Cout, &nch, &Ccp, &Jc, &NT, nullptr, nullptr);
@@ -707,6 +734,7 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
   a.vec_in = (Cin % 4 == 0);
   a.pbias = plane_bias;
+  a.cls_cout = class_cout; a.cls_base = class_base;
   if (plane_bias && (out_stride != 1 || D < 2)) return ATVS_ERR_ARG;
   long blocks = atvs_conv_tiled_num_blocks(D, H, W, tile_y);
   hipStream_t s = as_stream(stream);
@@ -718,6 +746,7 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
     if (NT == 1) rc = launch_tiled<1, 4>(a, blocks, s);
     else if (NT == 2) rc = launch_tiled<2, 4>(a, blocks, s);
     else if (NT == 4) rc = launch_tiled<4, 4>(a, blocks, s);
+    else if (NT == 8) rc = launch_tiled<8, 4>(a, blocks, s);
     else return ATVS_ERR_ARG;
   } else {
     return ATVS_ERR_ARG;

@@ -14,14 +14,15 @@
 // floats = mean, rsqrt(var+eps), beta.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, long nblocks, int cpad,
                                                           double count, const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ params, int C) {
+                                                          float* __restrict__ params, int C, int fold) {
   __shared__ double sm[2][256];
   const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
-  for (long b = threadIdx.x; b < nblocks; b += 256) {
-    s += partials[(b * 2 + 0) * cpad + c];
-    q += partials[(b * 2 + 1) * cpad + c];
-  }
+  for (long b = threadIdx.x; b < nblocks; b += 256)
+    for (int f = 0; f < fold; ++f) {      // columns c, c+C, ... hold the same channel (fused transposed conv)
+      s += partials[(b * 2 + 0) * cpad + c + f * C];
+      q += partials[(b * 2 + 1) * cpad + c + f * C];
+    }
   sm[0][threadIdx.x] = s;
   sm[1][threadIdx.x] = q;
   __syncthreads();
@@ -42,12 +43,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
-extern "C" int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, long count, const float* beta,
-                                float eps, float* params, int C, atvs_stream_t stream) {
+extern "C" int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, int fold, long count,
+                                const float* beta, float eps, float* params, int C, atvs_stream_t stream) {
   if (!stats_partial || !params) return ATVS_ERR_NULL;
-  if (num_blocks <= 0 || C <= 0 || cpad < C || count <= 0) return ATVS_ERR_SHAPE;
+  if (num_blocks <= 0 || C <= 0 || fold < 1 || cpad < C * fold || count <= 0) return ATVS_ERR_SHAPE;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats_partial, num_blocks, cpad,
-                     (double)count, beta, eps, params, C);
+                     (double)count, beta, eps, params, C, fold);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

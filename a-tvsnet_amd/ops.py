@@ -317,7 +317,7 @@ def force_conv_impl(impl):
 
 
 def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None, residual=None, relu=False,
-                      stats_buf=None, plane_bias=None):
+                      stats_buf=None, plane_bias=None, class_cout=0, class_base=0):
     """One atvs_conv_tiled_f32 launch: logical output grid = input grid of x4 (D,H,W,Cin)."""
     D, H, W, Cin = x4.shape
     Dy, Hy, Wy, ldy = y.shape
@@ -329,7 +329,7 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
         _call('atvs_conv_tiled_f32', _p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
               _p(plane_bias), _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
               Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
-              pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), _stream())
+              pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), int(class_cout), int(class_base), _stream())
         if timed:
             e1.record()
             _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
@@ -353,7 +353,10 @@ def _pick_tile_m(M, ntiles):
 
 class Stats(object):
     """Per-workgroup partial sums of a tensor: feeds bn_finalize."""
-    __slots__ = ('partial', 'blocks', 'cpad', 'count')
+    __slots__ = ('partial', 'blocks', 'cpad', 'count', 'fold')
+
+    def __init__(self):
+        self.fold = 1
 
 
 def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bias=None, residual=None, relu=False,
@@ -552,24 +555,68 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False):
     return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb)
 
 
-def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
-    """tf.layers.conv3d_transpose(3, stride 2, SAME): (D,H,W,Cin) -> (2D,2H,2W,Cout) as 8 parity classes.
+_DECONV_OFFSETS = [(a, b, c) for a in (0, -1) for b in (0, -1) for c in (0, -1)]
+_virt_cache = {}
 
-    w_host: TF layout [3,3,3,Cout,Cin].
+
+def _deconv_virtual_kernel(key, w_host):
+    """Dense virtual kernel of the fused transposed convolution: (8 offsets, Cin, 8 classes * Cout).
+    Per axis: even outputs 2j take (k=0, i=j) and (k=2, i=j-1); odd outputs 2j+1 take (k=1, i=j)."""
+    import numpy as np
+    hit = _virt_cache.get(key)
+    if hit is not None:
+        return hit
+    w = np.asarray(w_host, np.float32)               # [3,3,3,Cout,Cin]
+    cout, cin = w.shape[3], w.shape[4]
+    wv = np.zeros((8, cin, 8, cout), np.float32)
+    kof = {(0, 0): 0, (0, -1): 2, (1, 0): 1}          # (parity, offset) -> k
+    for oi, off in enumerate(_DECONV_OFFSETS):
+        for cls in range(8):
+            par = ((cls >> 2) & 1, (cls >> 1) & 1, cls & 1)
+            ks = [kof.get((par[a], off[a])) for a in range(3)]
+            if None in ks:
+                continue
+            wv[oi, :, cls, :] = w[ks[0], ks[1], ks[2]].T
+    hit = wv.reshape(8, cin, 8 * cout)
+    _virt_cache[key] = hit
+    return hit
+
+
+def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
+    """tf.layers.conv3d_transpose(3, stride 2, SAME): (D,H,W,Cin) -> (2D,2H,2W,Cout).
+
+    w_host: TF layout [3,3,3,Cout,Cin].  LDS-tiled path: all 8 output parity classes from one staged
+    input tile per workgroup (N axis = class x channel); fallback: one gather launch per class.
     """
     D, H, W, Cin = x.shape
     cout = int(w_host.shape[-2])
     y = _new(x, (2 * D, 2 * H, 2 * W, cout))
     M = D * H * W
     classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
-    tile_y = tiled_tile_y(H, W, cout)
-    if tile_y:
-        pks = [pack_conv_weights_tiled(key, w_host, deconv_s2_class_taps(par), True, x.device, tile_y)
-               for par in classes]
-        blocks, tm = tiled_blocks(D, H, W, tile_y), 0
-    else:
-        pks = [pack_conv_weights(key, w_host, deconv_s2_class_taps(par), True, x.device) for par in classes]
-        blocks, tm = conv_blocks(M, pks[0].ntiles)
+    fused = _FORCE_IMPL != 'gather' and cout % 4 == 0 and cout <= 64 and (W >= 12 or _FORCE_IMPL == 'tiled')
+    if fused:
+        per = min(8, 128 // cout)                     # classes per launch (N <= 128 virtual channels)
+        wv = _deconv_virtual_kernel(key, w_host)
+        taps = tuple((i,) + off for i, off in enumerate(_DECONV_OFFSETS))
+        nt = 1
+        while nt * 16 < per * cout:
+            nt *= 2
+        tile_y = 8 if (nt <= 2 and H >= 16) else 4
+        blocks = tiled_blocks(D, H, W, tile_y)
+        nl = 8 // per
+        st, sbuf = None, None
+        if want_stats:
+            sbuf = _stats_buffer(x, blocks * nl, nt * 16)
+            st = Stats()
+            st.partial, st.blocks, st.cpad, st.count, st.fold = sbuf, blocks * nl, nt * 16, 8 * M, per
+        for i in range(nl):
+            wpart = wv[:, :, i * per * cout:(i + 1) * per * cout]
+            pk = pack_conv_weights_tiled((key, 'cls', i), wpart, taps, False, x.device, tile_y)
+            sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
+            conv_tiled_launch(x, pk, y, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per)
+        return (y, st) if want_stats else y
+    pks = [pack_conv_weights(key, w_host, deconv_s2_class_taps(par), True, x.device) for par in classes]
+    blocks, tm = conv_blocks(M, pks[0].ntiles)
     cpad = pks[0].ntiles * 16
     st = None
     sbuf = None
@@ -579,10 +626,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks * 8, cpad, 8 * M
     for i, (par, pk) in enumerate(zip(classes, pks)):
         sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
-        if tile_y:
-            conv_tiled_launch(x, pk, y, 2, par, 0, tile_y, None, None, relu, sb)
-        else:
-            conv_launch(x, pk, y, (D, H, W), 1, 2, par, 0, None, None, relu, sb, tm)
+        conv_launch(x, pk, y, (D, H, W), 1, 2, par, 0, None, None, relu, sb, tm)
     return (y, st) if want_stats else y
 
 
@@ -605,7 +649,7 @@ def bn_params(st, C, ref, beta=None, eps=1e-3):
     params = _new(ref, (3, C))
     if _dev_ok(ref, beta):
         _call('atvs_bn_finalize', ctypes.c_void_p(st.partial.data_ptr()), ctypes.c_long(st.blocks), st.cpad,
-              ctypes.c_long(st.count), _p(beta), ctypes.c_float(eps), _p(params), C, _stream())
+              int(st.fold), ctypes.c_long(st.count), _p(beta), ctypes.c_float(eps), _p(params), C, _stream())
     return params
 
 

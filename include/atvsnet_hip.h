@@ -165,7 +165,13 @@ int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* gro
  * logical output grid (= the input grid D,H,W) from an input halo tile staged once in LDS.
  * atvs_conv_tiled_pack_size / _pack are the HOST packing functions for it (same inputs
  * as atvs_conv_pack; the table depends on tile_y in {4, 8}); stats_partial has
- * atvs_conv_tiled_num_blocks rows of 16*ntiles doubles x 2. */
+ * atvs_conv_tiled_num_blocks rows of 16*ntiles doubles x 2.
+ * Fused stride-2 transposed convolution (class_cout != 0): the 8 output parity classes of
+ * conv3d_transpose(3, stride 2, SAME) are computed from ONE staged tile -- the GEMM's N axis is
+ * (class, channel): Cout = n_classes * class_cout "virtual" channels over the 8 taps
+ * {-1,0}^3 with the dense virtual kernel Wv[off][ci][(class, co)] = W[k(off, class)] or 0; virtual
+ * channel (c, co) of grid voxel j is written to output voxel 2j + parity(class_base + c); the
+ * statistics columns (c, co) fold onto co in atvs_bn_finalize(fold = n_classes). */
 int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* chunk_pad, int* ksteps_per_chunk,
                               int* ntiles, long* packed_floats, long* table_ints);
 int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
@@ -175,7 +181,8 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
                         const float* residual, const float* plane_bias, float* y, double* stats_partial,
                         int D, int H, int W, int Cin,
                         int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
-                        int y_coff, int Cout, int ntaps, int tile_y, int relu, atvs_stream_t stream);
+                        int y_coff, int Cout, int ntaps, int tile_y, int relu, int class_cout, int class_base,
+                        atvs_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Batch norm with batch statistics, element-wise glue  (cnn_wrapper/network.py)
@@ -184,9 +191,10 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
 /* Reduce per-workgroup partial sums [num_blocks][2][cpad] (double) to
  * params [3][C] = (mean, rsqrt(var+eps), beta): the moments of
  * tf.layers.batch_normalization(training=True) / slim.batch_norm, network.py:206-212,
- * 541-547, 570-571.  count = elements per channel.  beta (C) or NULL. */
-int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, long count, const float* beta,
-                     float eps, float* params, int C, atvs_stream_t stream);
+ * 541-547, 570-571.  count = elements per channel.  beta (C) or NULL.  fold >= 1: channel c
+ * also sums columns c + C, c + 2C, ... (fold of them). */
+int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, int fold, long count,
+                     const float* beta, float eps, float* params, int C, atvs_stream_t stream);
 
 /* Partial sums of an arbitrary (rows, C) tensor, C <= 256, in the layout above with
  * cpad = C and atvs_channel_stats_num_blocks(rows) blocks. */

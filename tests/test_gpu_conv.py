@@ -130,7 +130,11 @@ def test_conv3d_transpose(cuda, impl, D, H, W, Cin, Cout):
     assert tuple(got.shape) == (2 * D, 2 * H, 2 * W, Cout)
     _close(got.cpu(), want)
     s = st.partial.sum(0).cpu()
-    _close(s[0, :Cout].float(), want.reshape(-1, Cout).double().sum(0).float(), 1e-5)
+    folded = s[:, :st.fold * Cout].reshape(2, st.fold, Cout).sum(1)     # (class, channel) columns fold onto the channel
+    _close(folded[0].float(), want.reshape(-1, Cout).double().sum(0).float(), 1e-5)
+    _close(folded[1].float(), (want.reshape(-1, Cout).double() ** 2).sum(0).float(), 1e-5)
+    bn = ops.batch_norm(got, st, relu=True).cpu()
+    assert float((bn - torch.clamp(T.batch_norm_train(want[None]), min=0)[0]).abs().max()) < 2e-5
 
 
 def test_conv_writes_channel_slice(cuda):
