@@ -17,9 +17,7 @@
 // K ordering trick: with Cin % 4 == 0 a lane loads one float4 = 4 consecutive input
 // channels of its tap and feeds element s to MFMA s; the packed weight for MFMA s is
 // arranged to match, so one 16-byte load per lane feeds four MFMAs.
-#include "common.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+#include "conv_common.h"
 
 struct ConvArgs {
   const float* x;
@@ -42,14 +40,6 @@ struct ConvArgs {
   const float* pbias;      // (Ho, Wo, 3*Cout) depth-plane bias variants or nullptr (see plane_variant)
   int pb_pz;               // z padding before, to pick the variant
 };
-
-// Contribution of input channels that are CONSTANT along depth (tf.tile'd reference features,
-// model.py:186,311,316,329-330): it equals a 2-D convolution with the kd-summed kernel, computed once
-// per (y, x) for the three sets of kd taps that fall inside the volume, and is added here like a bias.
-//   variant 0: kd = 0 falls before the first plane;  1: all three planes exist;  2: kd = 2 falls past the end.
-__device__ __forceinline__ int plane_variant(int z_in_first, int Di) {
-  return (z_in_first < 0) ? 0 : ((z_in_first + 2 >= Di) ? 2 : 1);
-}
 
 template <int V>
 struct AVal;
@@ -242,13 +232,6 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs p) {
   }
 }
 
-static int pow2_tiles(int cout) {
-  int nt = (cout + 15) / 16;
-  int p = 1;
-  while (p < nt) p <<= 1;
-  return p;
-}
-
 extern "C" int atvs_conv_pack_size(int ntaps, int Cin, int Cout, int* vec, int* ksteps, int* ntiles,
                                    long* packed_floats, long* table_ints) {
   if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || Cout > 128) return ATVS_ERR_SHAPE;
@@ -367,390 +350,6 @@ extern "C" int atvs_conv_mfma_f32(const float* x, const float* packed_w, const i
   if (residual && y_coff != 0) return ATVS_ERR_ARG;   // residual shares y's addressing
   hipStream_t s = as_stream(stream);
   rc = (V == 4) ? launch_nt<4>(a, NT, tile_m, s) : launch_nt<1>(a, NT, tile_m, s);
-  if (rc) return rc;
-  ATVS_LAUNCH_CHECK();
-  return ATVS_OK;
-}
-
-// ===========================================================================
-// LDS-tiled variant for halo-1 stencils (3x3x3 stride-1 convolutions and the parity
-// classes of the stride-2 transposed convolution): the workgroup stages the
-// (4+2) x (TY+2) x (16+2) input halo tile of one 16-channel chunk in LDS once and every
-// tap reads it from there, instead of gathering each tap from global memory.
-//   workgroup = 4 wavefronts, output tile 4(z) x TY(y) x 16(x) voxels; wavefront w owns
-//   plane z = w of the tile = TY MFMA tiles of 16 x-consecutive voxels.
-//   LDS image: [z][y][x][Ccp] floats (Ccp = chunk channels, multiple of 4): a wavefront's
-//   ds_read_b128 of one tap covers 16 voxels x 64 B = 1 KiB contiguous (conflict-free at Ccp=16).
-//   K order: (chunk, tap, 4-channel group); weights stream from L2 in the packed order.
-// ===========================================================================
-#define TILE_TZ 4
-#define TILE_TX 16
-
-struct TiledArgs {
-  const float* x;
-  const float* wp;
-  const int* tab;      // per K group: LDS byte offset of (tap, channel group) relative to the voxel's base
-  const float* bias;
-  const float* res;
-  float* y;
-  double* stats;
-  int Di, Hi, Wi, Cin;
-  int Hy, Wy;
-  int oS, offz, offy, offx;
-  int ldy, ycoff, Cout;
-  int nchunk, Cc, Ccp, Jc;   // chunks, real / padded channels per chunk, K steps per chunk
-  int tiles_y, tiles_x;      // grid decomposition
-  int relu, vec_out, vec_in;
-  const float* pbias;        // (H, W, 3*Cout) or nullptr
-  // fused stride-2 transposed convolution: the GEMM's N axis is (parity class, output channel);
-  // cls_cout = real Cout (0 = ordinary convolution), cls_base = first class of this launch
-  int cls_cout, cls_base;
-};
-
-template <int NT, int TY>
-__global__ __launch_bounds__(256, 2) void conv_tiled_f32_kernel(TiledArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* tile = reinterpret_cast<float*>(smem);
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 15, q = lane >> 4;
-  constexpr int HZ = TILE_TZ + 2, HY = TY + 2, HX = TILE_TX + 2;
-  const int tile_floats = HZ * HY * HX * p.Ccp;
-  int* s_tab = reinterpret_cast<int*>(tile + tile_floats);
-  for (int i = tid; i < p.Jc * 4; i += 256) s_tab[i] = p.tab[i];
-
-  // tile origin
-  int bx = blockIdx.x % p.tiles_x;
-  int rest = blockIdx.x / p.tiles_x;
-  int by = rest % p.tiles_y;
-  int bz = rest / p.tiles_y;
-  const int z0 = bz * TILE_TZ, y0 = by * TY, x0 = bx * TILE_TX;
-
-  f32x4 acc[TY][NT];
-#pragma unroll
-  for (int t = 0; t < TY; ++t)
-#pragma unroll
-    for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  // byte offset of this lane's voxel (tile plane z = wave, row t, column r) in the LDS image
-  int vbase[TY];
-#pragma unroll
-  for (int t = 0; t < TY; ++t) vbase[t] = ((wave * HY + t) * HX + r) * p.Ccp * 4;
-
-  const int c4n = p.Ccp / 4;                     // float4 groups per voxel in LDS
-  const int slots = HZ * HY * HX * c4n;
-  const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wp);
-  const unsigned char* lds = smem;
-
-  for (int ch = 0; ch < p.nchunk; ++ch) {
-    __syncthreads();
-    // ---- stage the halo tile of chunk ch (zero outside the volume / beyond Cin)
-    const int cbase = ch * p.Cc;
-    for (int s = tid; s < slots; s += 256) {
-      int c4 = s % c4n;
-      int v = s / c4n;
-      int xx = v % HX;
-      int v2 = v / HX;
-      int yy = v2 % HY;
-      int zz = v2 / HY;
-      int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
-      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)gz < (unsigned)p.Di && (unsigned)gy < (unsigned)p.Hi && (unsigned)gx < (unsigned)p.Wi) {
-        const float* src = p.x + (((size_t)gz * p.Hi + gy) * p.Wi + gx) * (size_t)p.Cin + cbase + c4 * 4;
-        int left = min(p.Cc, p.Cin - cbase) - c4 * 4;       // real channels from here
-        if (p.vec_in && left >= 4) {
-          val = ld4(src);
-        } else {
-          if (left > 0) val.x = src[0];
-          if (left > 1) val.y = src[1];
-          if (left > 2) val.z = src[2];
-          if (left > 3) val.w = src[3];
-        }
-      }
-      reinterpret_cast<float4*>(tile)[s] = val;
-    }
-    __syncthreads();
-
-    // ---- K steps of this chunk
-    const float4* wch = wp + (size_t)ch * p.Jc * NT * 64;
-    float4 w_cur[NT], b_cur[TY];
-    {
-      int off = s_tab[q];
-#pragma unroll
-      for (int n = 0; n < NT; ++n) w_cur[n] = wch[n * 64 + lane];
-#pragma unroll
-      for (int t = 0; t < TY; ++t) b_cur[t] = *reinterpret_cast<const float4*>(lds + vbase[t] + off);
-    }
-    for (int j = 0; j < p.Jc; ++j) {
-      float4 w_nxt[NT], b_nxt[TY];
-      if (j + 1 < p.Jc) {
-        int off = s_tab[(j + 1) * 4 + q];
-#pragma unroll
-        for (int n = 0; n < NT; ++n) w_nxt[n] = wch[((size_t)(j + 1) * NT + n) * 64 + lane];
-#pragma unroll
-        for (int t = 0; t < TY; ++t) b_nxt[t] = *reinterpret_cast<const float4*>(lds + vbase[t] + off);
-      }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-          for (int t = 0; t < TY; ++t)
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aget<4>(w_cur[n], s), aget<4>(b_cur[t], s), acc[t][n], 0, 0, 0);
-      if (j + 1 < p.Jc) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n) w_cur[n] = w_nxt[n];
-#pragma unroll
-        for (int t = 0; t < TY; ++t) b_cur[t] = b_nxt[t];
-      }
-    }
-  }
-
-  // ---- epilogue (same contract as conv_mfma_f32_kernel)
-  float ssum[NT][4], ssq[NT][4];
-#pragma unroll
-  for (int n = 0; n < NT; ++n)
-#pragma unroll
-    for (int k = 0; k < 4; ++k) ssum[n][k] = ssq[n][k] = 0.f;
-  const int zo = z0 + wave, xo = x0 + r;
-#pragma unroll
-  for (int t = 0; t < TY; ++t) {
-    const int yo = y0 + t;
-    if (zo >= p.Di || yo >= p.Hi || xo >= p.Wi) continue;
-    size_t vox = ((size_t)(zo * p.oS + p.offz) * p.Hy + (yo * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx);
-    size_t base = vox * (size_t)p.ldy + p.ycoff;
-    const float* pb = nullptr;
-    if (p.pbias)
-      pb = p.pbias + ((size_t)yo * p.Wi + xo) * (size_t)(3 * p.Cout) + plane_variant(zo - 1, p.Di) * p.Cout;
-#pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      int co = n * 16 + 4 * q;
-      if (co >= p.Cout) continue;
-      float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
-      if (p.cls_cout) {
-        // virtual channel -> (parity class, real channel); output voxel (2z+pz, 2y+py, 2x+px)
-        int cls = p.cls_base + co / p.cls_cout, cr = co % p.cls_cout;
-        size_t ov = ((size_t)(zo * 2 + (cls >> 2)) * p.Hy + (yo * 2 + ((cls >> 1) & 1))) * p.Wy + (xo * 2 + (cls & 1));
-        if (p.relu) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        st4(p.y + ov * (size_t)p.ldy + p.ycoff + cr, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ssum[n][k] += v[k];
-          ssq[n][k] += v[k] * v[k];
-        }
-        continue;
-      }
-      if (pb) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (co + k < p.Cout) v[k] += pb[co + k];
-      }
-      if (p.vec_out) {
-        if (p.bias) {
-          float4 b = ld4(p.bias + co);
-          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-        }
-        if (p.res) {
-          float4 rr = ld4(p.res + base + co);
-          v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
-        }
-        if (p.relu) {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        st4(p.y + base + co, make_float4(v[0], v[1], v[2], v[3]));
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          ssum[n][k] += v[k];
-          ssq[n][k] += v[k] * v[k];
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          if (co + k < p.Cout) {
-            float u = v[k];
-            if (p.bias) u += p.bias[co + k];
-            if (p.res) u += p.res[base + co + k];
-            if (p.relu) u = fmaxf(u, 0.f);
-            p.y[base + co + k] = u;
-            ssum[n][k] += u;
-            ssq[n][k] += u * u;
-          }
-        }
-      }
-    }
-  }
-  if (p.stats) {
-    __syncthreads();     // the tile is dead: reuse LDS for the cross-wave reduction
-    double* s_red = reinterpret_cast<double*>(smem);   // [4][2][NT*16]
-#pragma unroll
-    for (int n = 0; n < NT; ++n)
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        double a = (double)ssum[n][k], b = (double)ssq[n][k];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o);
-          b += __shfl_xor(b, o);
-        }
-        if (r == 0) {
-          s_red[(wave * 2 + 0) * (NT * 16) + n * 16 + 4 * q + k] = a;
-          s_red[(wave * 2 + 1) * (NT * 16) + n * 16 + 4 * q + k] = b;
-        }
-      }
-    __syncthreads();
-    if (tid < 2 * NT * 16) {
-      int which = tid / (NT * 16), c = tid % (NT * 16);
-      double v = (s_red[(0 * 2 + which) * (NT * 16) + c] + s_red[(1 * 2 + which) * (NT * 16) + c]) +
-                 (s_red[(2 * 2 + which) * (NT * 16) + c] + s_red[(3 * 2 + which) * (NT * 16) + c]);
-      p.stats[((size_t)blockIdx.x * 2 + which) * (NT * 16) + c] = v;
-    }
-  }
-}
-
-// chunks of <= 16 input channels, balanced, each padded to a multiple of 4
-static void tiled_chunks(int Cin, int* nch, int* Cc) {
-  *nch = (Cin + 15) / 16;
-  int per = (Cin + *nch - 1) / *nch;
-  *Cc = (per + 3) / 4 * 4;
-}
-
-extern "C" int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* chunk_pad, int* ksteps_per_chunk,
-                                         int* ntiles, long* packed_floats, long* table_ints) {
-  if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || Cout > 128) return ATVS_ERR_SHAPE;
-  int nch, Ccp;
-  tiled_chunks(Cin, &nch, &Ccp);
-  int Jc = (ntaps * (Ccp / 4) + 3) / 4;
-  int NT = pow2_tiles(Cout);
-  if (nchunk) *nchunk = nch;
-  if (chunk_pad) *chunk_pad = Ccp;
-  if (ksteps_per_chunk) *ksteps_per_chunk = Jc;
-  if (ntiles) *ntiles = NT;
-  if (packed_floats) *packed_floats = (long)nch * Jc * NT * 64 * 4;
-  if (table_ints) *table_ints = (long)Jc * 4;
-  return ATVS_OK;
-}
-
-// HOST function.  Same inputs as atvs_conv_pack, taps restricted to offsets in [-1, 1]^3; `tile_y` is the
-// TY the launch will use (the table holds LDS byte offsets of the (4+2) x (tile_y+2) x 18 x Ccp image).
-extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
-                                    int tile_y, float* packed, int32_t* table) {
-  if (!w || !taps || !packed || !table) return ATVS_ERR_NULL;
-  int nch, Ccp, Jc, NT;
-  long pf, ti;
-  int rc = atvs_conv_tiled_pack_size(ntaps, Cin, Cout, &nch, &Ccp, &Jc, &NT, &pf, &ti);
-  if (rc) return rc;
-  const int Cc = Ccp;
-  const int c4n = Ccp / 4;
-  const int G = ntaps * c4n;
-  const int HY = tile_y + 2, HX = TILE_TX + 2;
-  for (int t = 0; t < ntaps; ++t)
-    for (int a = 1; a < 4; ++a)
-      if (taps[t * 4 + a] < -1 || taps[t * 4 + a] > 1) return ATVS_ERR_ARG;
-  for (long i = 0; i < pf; ++i) packed[i] = 0.f;
-  for (int j = 0; j < Jc; ++j)
-    for (int q = 0; q < 4; ++q) {
-      int g = j * 4 + q;
-      if (g >= G) {
-        table[g] = 0;
-        continue;
-      }
-      int t = g / c4n, c4 = g % c4n;
-      int dz = taps[t * 4 + 1], dy = taps[t * 4 + 2], dx = taps[t * 4 + 3];
-      table[g] = ((((dz + 1) * HY + (dy + 1)) * HX + (dx + 1)) * Ccp + c4 * 4) * 4;
-      int wt = taps[t * 4 + 0];
-      for (int ch = 0; ch < nch; ++ch)
-        for (int n = 0; n < NT; ++n)
-          for (int co16 = 0; co16 < 16; ++co16) {
-            int co = n * 16 + co16;
-            if (co >= Cout) continue;
-            for (int s = 0; s < 4; ++s) {
-              int cl = c4 * 4 + s;                 // channel within the chunk
-              int ci = ch * Cc + cl;
-              if (cl >= Cc || ci >= Cin) continue;
-              float val = w_transposed ? w[((size_t)wt * Cout + co) * Cin + ci] : w[((size_t)wt * Cin + ci) * Cout + co];
-              packed[(((((size_t)ch * Jc + j) * NT + n) * 64) + q * 16 + co16) * 4 + s] = val;
-            }
-          }
-    }
-  return ATVS_OK;
-}
-
-extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y) {
-  return (long)((Do + TILE_TZ - 1) / TILE_TZ) * ((Ho + tile_y - 1) / tile_y) * ((Wo + TILE_TX - 1) / TILE_TX);
-}
-
-template <int NT, int TY>
-static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
-  size_t lds = (size_t)(TILE_TZ + 2) * (TY + 2) * (TILE_TX + 2) * a.Ccp * 4 + (size_t)a.Jc * 4 * sizeof(int);
-  size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double);
-  if (lds < red) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tiled_f32_kernel<NT, TY>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY>), dim3((unsigned)blocks), dim3(256), lds, s, a);
-  return ATVS_OK;
-}
-
-// 3-D stride-1 halo-1 stencil on the LDS-tiled kernel.  x (D,H,W,Cin); the logical output grid equals
-// the input grid (D,H,W); output voxel = o*out_stride + off inside the full tensor (Dy,Hy,Wy,ldy).
-// stats_partial rows = atvs_conv_tiled_num_blocks(D,H,W,tile_y), width 16*ntiles.  tile_y in {4, 8}.
-extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
-                                   const float* residual, const float* plane_bias, float* y, double* stats_partial,
-                                   int D, int H, int W, int Cin,
-                                   int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
-                                   int y_coff, int Cout, int ntaps, int tile_y, int relu, int class_cout, int class_base,
-                                   atvs_stream_t stream) {
-  if (!x || !packed_w || !table || !y) return ATVS_ERR_NULL;
-  if (D <= 0 || H <= 0 || W <= 0 || out_stride <= 0) return ATVS_ERR_SHAPE;
-  if (class_cout) {
-    // fused transposed convolution: Cout = classes_in_this_launch * class_cout virtual channels
-    if (class_cout % 4 || Cout % class_cout || class_base < 0 || class_base + Cout / class_cout > 8) return ATVS_ERR_SHAPE;
-    if (y_coff < 0 || y_coff + class_cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
-    if (2 * D > Dy || 2 * H > Hy || 2 * W > Wy || bias || residual || plane_bias) return ATVS_ERR_ARG;
-  } else {
-    if (y_coff < 0 || y_coff + Cout > ldy) return ATVS_ERR_SHAPE;
-    if ((D - 1) * out_stride + off_z >= Dy || (H - 1) * out_stride + off_y >= Hy || (W - 1) * out_stride + off_x >= Wy)
-      return ATVS_ERR_SHAPE;
-  }
-  if (residual && y_coff != 0) return ATVS_ERR_ARG;
-  int nch, Ccp, Jc, NT;
-  int rc = atvs_conv_tiled_pack_size(ntaps, Cin, Cout, &nch, &Ccp, &Jc, &NT, nullptr, nullptr);
-  if (rc) return rc;
-  TiledArgs a;
-  a.x = x; a.wp = packed_w; a.tab = table; a.bias = bias; a.res = residual; a.y = y; a.stats = stats_partial;
-  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.Hy = Hy; a.Wy = Wy;
-  a.oS = out_stride; a.offz = off_z; a.offy = off_y; a.offx = off_x; a.ldy = ldy; a.ycoff = y_coff; a.Cout = Cout;
-  a.nchunk = nch; a.Cc = Ccp; a.Ccp = Ccp; a.Jc = Jc;
-  a.tiles_y = (H + tile_y - 1) / tile_y; a.tiles_x = (W + TILE_TX - 1) / TILE_TX;
-  a.relu = relu;
-  a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
-  a.vec_in = (Cin % 4 == 0);
-  a.pbias = plane_bias;
-  a.cls_cout = class_cout; a.cls_base = class_base;
-  if (plane_bias && (out_stride != 1 || D < 2)) return ATVS_ERR_ARG;
-  long blocks = atvs_conv_tiled_num_blocks(D, H, W, tile_y);
-  hipStream_t s = as_stream(stream);
-  if (tile_y == 8) {
-    if (NT == 1) rc = launch_tiled<1, 8>(a, blocks, s);
-    else if (NT == 2) rc = launch_tiled<2, 8>(a, blocks, s);
-    else return ATVS_ERR_ARG;
-  } else if (tile_y == 4) {
-    if (NT == 1) rc = launch_tiled<1, 4>(a, blocks, s);
-    else if (NT == 2) rc = launch_tiled<2, 4>(a, blocks, s);
-    else if (NT == 4) rc = launch_tiled<4, 4>(a, blocks, s);
-    else if (NT == 8) rc = launch_tiled<8, 4>(a, blocks, s);
-    else return ATVS_ERR_ARG;
-  } else {
-    return ATVS_ERR_ARG;
-  }
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

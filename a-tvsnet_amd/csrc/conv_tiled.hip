@@ -1,0 +1,500 @@
+// LDS-tiled fp32-MFMA convolution for halo-1 stencils (gfx950): the 3x3x3 stride-1 SAME
+// convolutions of the stacked U-Nets / refinement net / AANet and the stride-2 transposed
+// convolution (all 8 output parity classes from one staged tile).
+//
+// Replaces tf.layers.conv3d / tf.nn.conv3d / tf.layers.conv3d_transpose (+ bias-free batch-norm
+// statistics) at /root/reference/cnn_wrapper/network.py:165-167,198-200,304,331,534-536.
+//
+// Structure (one workgroup = 4 wavefronts, persistent over output tiles):
+//   tile     4(z) x TY(y) x 16(x) output voxels; wavefront w owns plane z = w = TY MFMA tiles of 16
+//            x-consecutive voxels (GEMM: M = output channels, N = 16 voxels, K = (tap, channel)).
+//   stage    = (tile, <=16-channel chunk).  The (4+2) x (TY+2) x 18 input halo of the stage is
+//            PREFETCHED into registers (global_load_dwordx4, issued before the previous stage's MFMAs
+//            so HBM/L2 latency hides under them), then written to LDS as [z][y][x][chunk].
+//   LDS      a wavefront's tap read covers 16 voxels x 64 B; bit 5 of the byte address is XOR-ed with
+//            bit 8 so that each 16-lane group of ds_read_b128 hits 16 distinct 16-byte slots
+//            (conflict-free for every tap alignment; the plain image is 2-way conflicted).
+//   K loop   27 taps x chunk/4 channel groups; a lane's float4 (4 consecutive input channels of its
+//            tap) feeds 4 MFMAs; packed weights stream from L2; operands of step j+1 are loaded
+//            before the MFMAs of step j.
+//   epilogue bias / depth-plane bias / residual / ReLU, 16-byte channel-last stores, per-channel
+//            (sum, sum of squares) accumulated over the workgroup's tiles -> one partial row per
+//            workgroup for the deterministic batch-norm reduction.
+#include "conv_common.h"
+
+#define TILE_TZ 4
+#define TILE_TX 16
+#define TILED_MAX_WG 512     // persistent grid: 2 workgroups per CU
+
+struct TiledArgs {
+  const float* x;
+  const float* wp;
+  const int* tab;      // per K group: LDS byte offset of (tap, channel group) relative to the voxel's base
+  const float* bias;
+  const float* res;
+  float* y;
+  double* stats;
+  int Di, Hi, Wi, Cin;
+  int Hy, Wy;
+  int oS, offz, offy, offx;
+  int ldy, ycoff, Cout;
+  int nchunk, Jc;            // chunks; K steps per chunk
+  int tiles_z, tiles_y, tiles_x, ntiles;
+  int relu, vec_out;
+  const float* pbias;        // (H, W, 3*Cout) or nullptr
+  // fused stride-2 transposed convolution: the GEMM's M axis is (parity class, output channel);
+  // cls_cout = real Cout (0 = ordinary convolution), cls_base = first class of this launch
+  int cls_cout, cls_base;
+};
+
+__device__ __forceinline__ int lds_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
+
+// Wavefronts per SIMD the register budget of an instantiation allows (accumulators + prefetch
+// registers + operands): 2 workgroups per CU when it fits in 256 VGPRs, else 1 (512).
+__host__ __device__ constexpr int tiled_wps(int NT, int TY, int C4) {
+  return (NT * TY * 4 + ((TILE_TZ + 2) * (TY + 2) * (TILE_TX + 2) * C4 + 255) / 256 * 4 + TY * 4 + NT * 16 + 40 <= 200) ? 2 : 1;
+}
+// statistics in the epilogue cost 8*NT registers; the widest variant leaves them to a separate pass
+__host__ __device__ constexpr bool tiled_has_stats(int NT) { return NT < 8; }
+
+// C4 = channel groups (float4) per voxel of a chunk in LDS: 4 (16 channels), 2 (8), 1 (<= 4).
+// FULL = every chunk has exactly 4*C4 real channels and Cin % 4 == 0 (vector loads, no tail).
+template <int NT, int TY, int C4, bool FULL>
+__global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_kernel(TiledArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int HZ = TILE_TZ + 2, HY = TY + 2, HX = TILE_TX + 2;
+  constexpr int SLOTS = HZ * HY * HX * C4;
+  constexpr int MAXS = (SLOTS + 255) / 256;
+  constexpr int VB = C4 * 16;                     // bytes per voxel in LDS
+  constexpr bool SWZ = (C4 == 4);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  int* s_tab = reinterpret_cast<int*>(smem + SLOTS * 16);
+  for (int i = tid; i < p.Jc * 4; i += 256) s_tab[i] = p.tab[i];
+
+  // persistent tile list of this workgroup; tiles are dealt so that workgroups sharing an XCD
+  // (blockIdx % 8) sweep one contiguous eighth of the tile range (halo re-use in that XCD's L2)
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int wg_per_xcd = (G + 7 - xcd) >> 3;      // workgroups with this blockIdx % 8
+  int my_tiles = 0;
+  if (local < per_xcd) {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);   // tiles in this XCD's range
+    if (local < last) my_tiles = (last - local + wg_per_xcd - 1) / wg_per_xcd;
+  }
+  const int nstage = my_tiles * p.nchunk;
+
+  constexpr bool STATS = tiled_has_stats(NT);
+  constexpr int SN = STATS ? NT : 1;
+  f32x4 acc[TY][NT];
+  float ssum[SN][4], ssq[SN][4];
+#pragma unroll
+  for (int n = 0; n < SN; ++n)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ssum[n][k] = ssq[n][k] = 0.f;
+
+  int vbase[TY];
+#pragma unroll
+  for (int t = 0; t < TY; ++t) vbase[t] = ((wave * HY + t) * HX + r) * VB;
+
+  const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wp);
+  const unsigned char* lds = smem;
+  const int Cc = C4 * 4;
+
+  auto tile_origin = [&](int k, int* z0, int* y0, int* x0) {
+    int tl = xcd * per_xcd + local + k * wg_per_xcd;
+    int bx = tl % p.tiles_x;
+    int rest = tl / p.tiles_x;
+    *x0 = bx * TILE_TX;
+    *y0 = (rest % p.tiles_y) * TY;
+    *z0 = (rest / p.tiles_y) * TILE_TZ;
+  };
+
+  float4 pf[MAXS];
+  auto prefetch = [&](int stage) {
+    int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int cbase = ch * Cc;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      int s = tid + i * 256;
+      int c4 = s % C4;
+      int v = s / C4;
+      int xx = v % HX;
+      int v2 = v / HX;
+      int yy = v2 % HY;
+      int zz = v2 / HY;
+      int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool ok = (s < SLOTS) && ((unsigned)gz < (unsigned)p.Di) && ((unsigned)gy < (unsigned)p.Hi) &&
+                ((unsigned)gx < (unsigned)p.Wi);
+      if (ok) {
+        const float* src = p.x + (((size_t)gz * p.Hi + gy) * p.Wi + gx) * (size_t)p.Cin + cbase + c4 * 4;
+        if (FULL) {
+          val = ld4(src);
+        } else {
+          int left = p.Cin - cbase - c4 * 4;        // real channels from here
+          if (left > 0) val.x = src[0];
+          if (left > 1) val.y = src[1];
+          if (left > 2) val.z = src[2];
+          if (left > 3) val.w = src[3];
+        }
+      }
+      pf[i] = val;
+    }
+  };
+
+  if (nstage > 0) prefetch(0);
+  __syncthreads();   // s_tab
+
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    if (ch == 0) {
+#pragma unroll
+      for (int t = 0; t < TY; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                       // every wave is done reading the previous stage's image
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      int s = tid + i * 256;
+      if (s < SLOTS) {
+        int a = s * 16;
+        if (SWZ) a = lds_swz(a);
+        *reinterpret_cast<float4*>(smem + a) = pf[i];
+      }
+    }
+    __syncthreads();
+    if (stage + 1 < nstage) prefetch(stage + 1);   // in flight during this stage's MFMAs
+
+    // ---- K steps of this chunk.  Weights (L2, long latency) are double-buffered one step ahead;
+    // the LDS operand of tile t is refreshed in place right after its last MFMA of the step, which
+    // leaves >= 7 MFMAs (224+ cycles) before it is consumed again.
+    const float4* wch = wp + (size_t)ch * p.Jc * NT * 64;
+    float4 w_cur[NT], b_cur[TY];
+    {
+      int off = s_tab[q];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) w_cur[n] = wch[n * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        int a = vbase[t] + off;
+        if (SWZ) a = lds_swz(a);
+        b_cur[t] = *reinterpret_cast<const float4*>(lds + a);
+      }
+    }
+    for (int j = 0; j < p.Jc; ++j) {
+      float4 w_nxt[NT];
+      const bool more = (j + 1 < p.Jc);
+      int off_n = 0;
+      if (more) {
+        off_n = s_tab[(j + 1) * 4 + q];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) w_nxt[n] = wch[((size_t)(j + 1) * NT + n) * 64 + lane];
+      }
+#pragma unroll
+      for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int t = 0; t < TY; ++t)
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[n].w, b_cur[t].w, acc[t][n], 0, 0, 0);
+        if (more) {
+          int a = vbase[t] + off_n;
+          if (SWZ) a = lds_swz(a);
+          b_cur[t] = *reinterpret_cast<const float4*>(lds + a);
+        }
+      }
+      if (more) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) w_cur[n] = w_nxt[n];
+      }
+    }
+    if (ch != p.nchunk - 1) continue;
+
+    // ---- epilogue of this tile: lane holds channels n*16 + 4q .. +3 of voxel (z0+wave, y0+t, x0+r)
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int zo = z0 + wave, xo = x0 + r;
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+      const int yo = y0 + t;
+      if (zo >= p.Di || yo >= p.Hi || xo >= p.Wi) continue;
+      size_t vox = ((size_t)(zo * p.oS + p.offz) * p.Hy + (yo * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx);
+      size_t base = vox * (size_t)p.ldy + p.ycoff;
+      const float* pb = nullptr;
+      if (p.pbias)
+        pb = p.pbias + ((size_t)yo * p.Wi + xo) * (size_t)(3 * p.Cout) + plane_variant(zo - 1, p.Di) * p.Cout;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        int co = n * 16 + 4 * q;
+        if (co >= p.Cout) continue;
+        float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
+        if (p.cls_cout) {
+          // virtual channel -> (parity class, real channel); output voxel (2z+pz, 2y+py, 2x+px)
+          int cls = p.cls_base + co / p.cls_cout, cr = co % p.cls_cout;
+          size_t ov = ((size_t)(zo * 2 + (cls >> 2)) * p.Hy + (yo * 2 + ((cls >> 1) & 1))) * p.Wy + (xo * 2 + (cls & 1));
+          if (p.relu) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v[kk] = fmaxf(v[kk], 0.f);
+          }
+          st4(p.y + ov * (size_t)p.ldy + p.ycoff + cr, make_float4(v[0], v[1], v[2], v[3]));
+          if (STATS) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              ssum[n % SN][kk] += v[kk];
+              ssq[n % SN][kk] += v[kk] * v[kk];
+            }
+          }
+          continue;
+        }
+        if (pb) {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk)
+            if (co + kk < p.Cout) v[kk] += pb[co + kk];
+        }
+        if (p.vec_out) {
+          if (p.bias) {
+            float4 b = ld4(p.bias + co);
+            v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+          }
+          if (p.res) {
+            float4 rr = ld4(p.res + base + co);
+            v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
+          }
+          if (p.relu) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) v[kk] = fmaxf(v[kk], 0.f);
+          }
+          st4(p.y + base + co, make_float4(v[0], v[1], v[2], v[3]));
+          if (STATS) {
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+              ssum[n % SN][kk] += v[kk];
+              ssq[n % SN][kk] += v[kk] * v[kk];
+            }
+          }
+        } else {
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            if (co + kk < p.Cout) {
+              float u = v[kk];
+              if (p.bias) u += p.bias[co + kk];
+              if (p.res) u += p.res[base + co + kk];
+              if (p.relu) u = fmaxf(u, 0.f);
+              p.y[base + co + kk] = u;
+              if (STATS) {
+                ssum[n % SN][kk] += u;
+                ssq[n % SN][kk] += u * u;
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+
+  if (STATS && p.stats) {
+    __syncthreads();     // the tile image is dead: reuse LDS for the cross-wave reduction
+    double* s_red = reinterpret_cast<double*>(smem);   // [4][2][NT*16]
+#pragma unroll
+    for (int n = 0; n < SN; ++n)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double a = (double)ssum[n][k], b = (double)ssq[n][k];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o);
+          b += __shfl_xor(b, o);
+        }
+        if (r == 0) {
+          s_red[(wave * 2 + 0) * (NT * 16) + n * 16 + 4 * q + k] = a;
+          s_red[(wave * 2 + 1) * (NT * 16) + n * 16 + 4 * q + k] = b;
+        }
+      }
+    __syncthreads();
+    if (tid < 2 * NT * 16) {
+      int which = tid / (NT * 16), c = tid % (NT * 16);
+      double v = (s_red[(0 * 2 + which) * (NT * 16) + c] + s_red[(1 * 2 + which) * (NT * 16) + c]) +
+                 (s_red[(2 * 2 + which) * (NT * 16) + c] + s_red[(3 * 2 + which) * (NT * 16) + c]);
+      p.stats[((size_t)blockIdx.x * 2 + which) * (NT * 16) + c] = v;
+    }
+  }
+}
+
+// chunks of <= 16 input channels: 16 when Cin > 8 (last chunk zero-padded), else 8 or 4
+static void tiled_chunks(int Cin, int* nch, int* Cc) {
+  if (Cin > 8) {
+    *Cc = 16;
+    *nch = (Cin + 15) / 16;
+  } else {
+    *Cc = (Cin > 4) ? 8 : 4;
+    *nch = 1;
+  }
+}
+
+extern "C" int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* chunk_pad, int* ksteps_per_chunk,
+                                         int* ntiles, long* packed_floats, long* table_ints) {
+  if (ntaps <= 0 || Cin <= 0 || Cout <= 0 || Cout > 128) return ATVS_ERR_SHAPE;
+  int nch, Ccp;
+  tiled_chunks(Cin, &nch, &Ccp);
+  int Jc = (ntaps * (Ccp / 4) + 3) / 4;
+  int NT = pow2_tiles(Cout);
+  if (nchunk) *nchunk = nch;
+  if (chunk_pad) *chunk_pad = Ccp;
+  if (ksteps_per_chunk) *ksteps_per_chunk = Jc;
+  if (ntiles) *ntiles = NT;
+  if (packed_floats) *packed_floats = (long)nch * Jc * NT * 64 * 4;
+  if (table_ints) *table_ints = (long)Jc * 4;
+  return ATVS_OK;
+}
+
+// HOST function.  Same inputs as atvs_conv_pack, taps restricted to offsets in [-1, 1]^3; `tile_y` is the
+// TY the launch will use (the table holds LDS byte offsets of the (4+2) x (tile_y+2) x 18 x chunk image).
+extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
+                                    int tile_y, float* packed, int32_t* table) {
+  if (!w || !taps || !packed || !table) return ATVS_ERR_NULL;
+  int nch, Ccp, Jc, NT;
+  long pf, ti;
+  int rc = atvs_conv_tiled_pack_size(ntaps, Cin, Cout, &nch, &Ccp, &Jc, &NT, &pf, &ti);
+  if (rc) return rc;
+  const int c4n = Ccp / 4;
+  const int G = ntaps * c4n;
+  const int HY = tile_y + 2, HX = TILE_TX + 2;
+  for (int t = 0; t < ntaps; ++t)
+    for (int a = 1; a < 4; ++a)
+      if (taps[t * 4 + a] < -1 || taps[t * 4 + a] > 1) return ATVS_ERR_ARG;
+  for (long i = 0; i < pf; ++i) packed[i] = 0.f;
+  for (int j = 0; j < Jc; ++j)
+    for (int q = 0; q < 4; ++q) {
+      int g = j * 4 + q;
+      if (g >= G) {
+        table[g] = 0;
+        continue;
+      }
+      int t = g / c4n, c4 = g % c4n;
+      int dz = taps[t * 4 + 1], dy = taps[t * 4 + 2], dx = taps[t * 4 + 3];
+      table[g] = ((((dz + 1) * HY + (dy + 1)) * HX + (dx + 1)) * Ccp + c4 * 4) * 4;
+      int wt = taps[t * 4 + 0];
+      for (int ch = 0; ch < nch; ++ch)
+        for (int n = 0; n < NT; ++n)
+          for (int co16 = 0; co16 < 16; ++co16) {
+            int co = n * 16 + co16;
+            if (co >= Cout) continue;
+            for (int s = 0; s < 4; ++s) {
+              int ci = ch * Ccp + c4 * 4 + s;
+              if (ci >= Cin) continue;
+              float val = w_transposed ? w[((size_t)wt * Cout + co) * Cin + ci] : w[((size_t)wt * Cin + ci) * Cout + co];
+              packed[(((((size_t)ch * Jc + j) * NT + n) * 64) + q * 16 + co16) * 4 + s] = val;
+            }
+          }
+    }
+  return ATVS_OK;
+}
+
+static long tiled_ntiles(int Do, int Ho, int Wo, int tile_y) {
+  return (long)((Do + TILE_TZ - 1) / TILE_TZ) * ((Ho + tile_y - 1) / tile_y) * ((Wo + TILE_TX - 1) / TILE_TX);
+}
+
+// workgroups of a launch (= rows of stats_partial): the persistent grid, 256 CUs x resident workgroups.
+// Returns 0 when the variant does not produce statistics in its epilogue (Cout > 64: use atvs_channel_stats).
+extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
+  int nch, Ccp;
+  tiled_chunks(Cin, &nch, &Ccp);
+  long nt = tiled_ntiles(Do, Ho, Wo, tile_y);
+  long cap = 256L * tiled_wps(pow2_tiles(Cout), tile_y, Ccp / 4);
+  return nt < cap ? nt : cap;
+}
+extern "C" int atvs_conv_tiled_has_stats(int Cout) { return tiled_has_stats(pow2_tiles(Cout)) ? 1 : 0; }
+
+template <int NT, int TY, int C4, bool FULL>
+static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
+  size_t lds = (size_t)(TILE_TZ + 2) * (TY + 2) * (TILE_TX + 2) * C4 * 16 + (size_t)a.Jc * 4 * sizeof(int);
+  size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double);
+  if (lds < red) lds = red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tiled_f32_kernel<NT, TY, C4, FULL>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return ATVS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY, C4, FULL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  return ATVS_OK;
+}
+
+template <int NT, int TY>
+static int launch_c4(const TiledArgs& a, int C4, bool full, long blocks, hipStream_t s) {
+  if (C4 == 4) return full ? launch_tiled<NT, TY, 4, true>(a, blocks, s) : launch_tiled<NT, TY, 4, false>(a, blocks, s);
+  if (C4 == 2) return full ? launch_tiled<NT, TY, 2, true>(a, blocks, s) : launch_tiled<NT, TY, 2, false>(a, blocks, s);
+  if (C4 == 1) return full ? launch_tiled<NT, TY, 1, true>(a, blocks, s) : launch_tiled<NT, TY, 1, false>(a, blocks, s);
+  return ATVS_ERR_ARG;
+}
+
+// 3-D stride-1 halo-1 stencil on the LDS-tiled kernel.  x (D,H,W,Cin); the logical output grid equals
+// the input grid (D,H,W); output voxel = o*out_stride + off inside the full tensor (Dy,Hy,Wy,ldy).
+// stats_partial rows = atvs_conv_tiled_num_blocks(D,H,W,tile_y), width 16*ntiles.  tile_y in {4, 8}.
+extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
+                                   const float* residual, const float* plane_bias, float* y, double* stats_partial,
+                                   int D, int H, int W, int Cin, int Dy, int Hy, int Wy, int out_stride, int off_z,
+                                   int off_y, int off_x, int ldy, int y_coff, int Cout, int ntaps, int tile_y, int relu,
+                                   int class_cout, int class_base, atvs_stream_t stream) {
+  if (!x || !packed_w || !table || !y) return ATVS_ERR_NULL;
+  if (D <= 0 || H <= 0 || W <= 0 || out_stride <= 0) return ATVS_ERR_SHAPE;
+  if (class_cout) {
+    // fused transposed convolution: Cout = classes_in_this_launch * class_cout virtual channels
+    if (class_cout % 4 || Cout % class_cout || class_base < 0 || class_base + Cout / class_cout > 8) return ATVS_ERR_SHAPE;
+    if (y_coff < 0 || y_coff + class_cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+    if (2 * D > Dy || 2 * H > Hy || 2 * W > Wy || bias || residual || plane_bias) return ATVS_ERR_ARG;
+  } else {
+    if (y_coff < 0 || y_coff + Cout > ldy) return ATVS_ERR_SHAPE;
+    if ((D - 1) * out_stride + off_z >= Dy || (H - 1) * out_stride + off_y >= Hy || (W - 1) * out_stride + off_x >= Wy)
+      return ATVS_ERR_SHAPE;
+  }
+  if (residual && y_coff != 0) return ATVS_ERR_ARG;
+  if (plane_bias && (out_stride != 1 || D < 2)) return ATVS_ERR_ARG;
+  int nch, Ccp, Jc, NT;
+  int rc = atvs_conv_tiled_pack_size(ntaps, Cin, Cout, &nch, &Ccp, &Jc, &NT, nullptr, nullptr);
+  if (rc) return rc;
+  TiledArgs a;
+  a.x = x; a.wp = packed_w; a.tab = table; a.bias = bias; a.res = residual; a.y = y; a.stats = stats_partial;
+  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.Hy = Hy; a.Wy = Wy;
+  a.oS = out_stride; a.offz = off_z; a.offy = off_y; a.offx = off_x; a.ldy = ldy; a.ycoff = y_coff; a.Cout = Cout;
+  a.nchunk = nch; a.Jc = Jc;
+  a.tiles_z = (D + TILE_TZ - 1) / TILE_TZ; a.tiles_y = (H + tile_y - 1) / tile_y; a.tiles_x = (W + TILE_TX - 1) / TILE_TX;
+  a.ntiles = a.tiles_z * a.tiles_y * a.tiles_x;
+  a.relu = relu;
+  a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
+  a.pbias = plane_bias;
+  a.cls_cout = class_cout; a.cls_base = class_base;
+  const int C4 = Ccp / 4;
+  const bool full = (Cin % Ccp == 0);
+  long blocks = atvs_conv_tiled_num_blocks(D, H, W, tile_y, Cin, Cout);
+  if (stats_partial && !tiled_has_stats(NT)) return ATVS_ERR_ARG;
+  hipStream_t s = as_stream(stream);
+  if (tile_y == 8) {
+    if (NT == 1) rc = launch_c4<1, 8>(a, C4, full, blocks, s);
+    else if (NT == 2) rc = launch_c4<2, 8>(a, C4, full, blocks, s);
+    else return ATVS_ERR_ARG;
+  } else if (tile_y == 4) {
+    if (NT == 1) rc = launch_c4<1, 4>(a, C4, full, blocks, s);
+    else if (NT == 2) rc = launch_c4<2, 4>(a, C4, full, blocks, s);
+    else if (NT == 4) rc = launch_c4<4, 4>(a, C4, full, blocks, s);
+    else if (NT == 8) rc = launch_c4<8, 4>(a, C4, full, blocks, s);
+    else return ATVS_ERR_ARG;
+  } else {
+    return ATVS_ERR_ARG;
+  }
+  if (rc) return rc;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

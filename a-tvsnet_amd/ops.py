@@ -335,8 +335,9 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
             _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
 
 
-def tiled_blocks(D, H, W, tile_y):
-    return (-(-D // 4)) * (-(-H // tile_y)) * (-(-W // 16))
+def tiled_blocks(D, H, W, tile_y, cin, cout):
+    """Workgroups (= statistics rows) of a tiled launch: the persistent grid size."""
+    return int(_lib.lib().atvs_conv_tiled_num_blocks(int(D), int(H), int(W), int(tile_y), int(cin), int(cout)))
 
 
 def clear_pack_cache():
@@ -465,7 +466,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         res4 = residual if residual.dim() == 4 else residual.reshape((1,) + tuple(residual.shape))
     M = outs[0] * outs[1] * outs[2]
     if tile_y:
-        blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y), 0
+        blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout), 0
     else:
         blocks, tm = conv_blocks(M, pk.ntiles)
     st = None
@@ -602,10 +603,11 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
         while nt * 16 < per * cout:
             nt *= 2
         tile_y = 8 if (nt <= 2 and H >= 16) else 4
-        blocks = tiled_blocks(D, H, W, tile_y)
+        blocks = tiled_blocks(D, H, W, tile_y, Cin, per * cout)
         nl = 8 // per
+        in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(per * cout))
         st, sbuf = None, None
-        if want_stats:
+        if want_stats and in_kernel:
             sbuf = _stats_buffer(x, blocks * nl, nt * 16)
             st = Stats()
             st.partial, st.blocks, st.cpad, st.count, st.fold = sbuf, blocks * nl, nt * 16, 8 * M, per
@@ -614,6 +616,8 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
             pk = pack_conv_weights_tiled((key, 'cls', i), wpart, taps, False, x.device, tile_y)
             sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
             conv_tiled_launch(x, pk, y, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per)
+        if want_stats and not in_kernel:
+            st = channel_stats(y)
         return (y, st) if want_stats else y
     pks = [pack_conv_weights(key, w_host, deconv_s2_class_taps(par), True, x.device) for par in classes]
     blocks, tm = conv_blocks(M, pks[0].ntiles)
