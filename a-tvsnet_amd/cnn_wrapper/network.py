@@ -171,6 +171,11 @@ class Network(object):
             raise ValueError('Improper input rank for layer: ' + name)
         x = _b1(input, name)
         cin = x.shape[-1]
+        if rank == 5 and kernel_size == 3 and filters == 1 and cin == 8 and strides == 1 and rate == 1 \
+                and padding == 'SAME' and not biased and not relu:
+            # the 8 -> 1 probability heads: HBM-bound, dedicated FMA kernel
+            wd = self.store.get('%s/kernel' % name, (3, 3, 3, 8, 1), x.device)
+            return ops.conv3d_8to1(x, wd).unsqueeze(0)
         w = self._kernel('%s/kernel' % name, (kernel_size,) * (rank - 2) + (cin, filters))
         bias = self._vec('%s/bias' % name, filters, x) if biased else None
         y = ops.conv(x, name + '/kernel', w, stride=strides, dilation=rate, padding=padding, bias=bias, relu=relu)

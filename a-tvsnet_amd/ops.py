@@ -485,6 +485,17 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     return (y, st) if want_stats else y
 
 
+def conv3d_8to1(x, w_dev):
+    """3x3x3 SAME convolution (D,H,W,8) -> (D,H,W,1); w_dev: device tensor of the TF kernel [3,3,3,8,1]."""
+    D, H, W, C = x.shape
+    if C != 8 or w_dev.numel() != 216:
+        raise ValueError('conv3d_8to1: 8 input channels and a [3,3,3,8,1] kernel')
+    y = _new(x, (D, H, W, 1))
+    if _dev_ok(x, w_dev):
+        _call('atvs_conv3d_8to1', _p(x), _p(w_dev), _p(y), D, H, W, _stream())
+    return y
+
+
 class SplitVolume(object):
     """A (1,D,h,w,C) network input whose channels are a concat of D-varying and D-constant parts.
 

@@ -187,6 +187,12 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
                         int y_coff, int Cout, int ntaps, int tile_y, int relu, int class_cout, int class_base,
                         atvs_stream_t stream);
 
+/* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
+ * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,
+ * 242,336).  x (D,H,W,8); w = the TF kernel [3,3,3,8,1] (216 floats, device); y (D,H,W).
+ * HBM-bound (one output channel): FMA kernel, not MFMA. */
+int atvs_conv3d_8to1(const float* x, const float* w, float* y, int D, int H, int W, atvs_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Batch norm with batch statistics, element-wise glue  (cnn_wrapper/network.py)
  * ------------------------------------------------------------------------- */

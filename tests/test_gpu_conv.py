@@ -242,3 +242,14 @@ def test_split_volume_conv_matches_dense(cuda, impl, stride):
     _close(got.cpu(), want)
     s = st.partial.sum(0).cpu()
     _close(s[0, :8].float(), want.reshape(-1, 8).double().sum(0).float(), 1e-5)
+
+
+@pytest.mark.parametrize('D,H,W', [(6, 8, 16), (5, 9, 21), (2, 3, 4), (16, 32, 40)])
+def test_conv3d_8to1_head(cuda, D, H, W):
+    from atvsnet_amd import ops
+    x = _rand((1, D, H, W, 8), 40)
+    w = _rand((3, 3, 3, 8, 1), 41, 0.3)
+    want = T.conv(x, w, 1, 'SAME')[0]
+    got = ops.conv3d_8to1(x[0].to(cuda), w.to(cuda))
+    assert tuple(got.shape) == (D, H, W, 1)
+    _close(got.cpu(), want)
