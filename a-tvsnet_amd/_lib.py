@@ -87,4 +87,5 @@ def lib():
         _lib.atvs_channel_stats_num_blocks.restype = ctypes.c_long
         _lib.atvs_avg_pool_ws_floats.restype = ctypes.c_long
         _lib.atvs_conv_tiled_num_blocks.restype = ctypes.c_long
+        _lib.atvs_conv_tiled_grid.restype = ctypes.c_long
     return _lib

@@ -45,6 +45,9 @@ struct TiledArgs {
   // fused stride-2 transposed convolution: the GEMM's M axis is (parity class, output channel);
   // cls_cout = real Cout (0 = ordinary convolution), cls_base = first class of this launch
   int cls_cout, cls_base;
+  // N-split: the 16-channel MFMA tiles of the output are dealt to `nsplit` workgroups per spatial tile
+  // (more workgroups for small volumes); nt_total = tiles in the packed weights, this kernel's NT = nt_total / nsplit
+  int nsplit, nt_total;
 };
 
 __device__ __forceinline__ int lds_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
@@ -74,15 +77,18 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
   for (int i = tid; i < p.Jc * 4; i += 256) s_tab[i] = p.tab[i];
 
   // persistent tile list of this workgroup; tiles are dealt so that workgroups sharing an XCD
-  // (blockIdx % 8) sweep one contiguous eighth of the tile range (halo re-use in that XCD's L2)
+  // (blockIdx % 8) sweep one contiguous eighth of the tile range (halo re-use in that XCD's L2).
+  // With N-split, workgroup (xcd, local) owns output-channel tiles nsi = local % nsplit of every
+  // spatial tile it visits (gridDim.x is a multiple of 8 * nsplit).
   const int G = gridDim.x;
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int per_xcd = (p.ntiles + 7) >> 3;
-  const int wg_per_xcd = (G + 7 - xcd) >> 3;      // workgroups with this blockIdx % 8
+  const int per_xcd = (p.ntiles + 7) >> 3;                 // spatial tiles per XCD range
+  const int nsi = local % p.nsplit, tslot = local / p.nsplit;
+  const int slots_per_xcd = (G >> 3) / p.nsplit;           // workgroups per (XCD, nsi)
   int my_tiles = 0;
-  if (local < per_xcd) {
-    int last = min(per_xcd, p.ntiles - xcd * per_xcd);   // tiles in this XCD's range
-    if (local < last) my_tiles = (last - local + wg_per_xcd - 1) / wg_per_xcd;
+  {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);     // tiles in this XCD's range
+    if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
   }
   const int nstage = my_tiles * p.nchunk;
 
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
   const int Cc = C4 * 4;
 
   auto tile_origin = [&](int k, int* z0, int* y0, int* x0) {
-    int tl = xcd * per_xcd + local + k * wg_per_xcd;
+    int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
     int bx = tl % p.tiles_x;
     int rest = tl / p.tiles_x;
     *x0 = bx * TILE_TX;
@@ -174,7 +180,8 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
     // ---- K steps of this chunk.  Weights (L2, long latency) are double-buffered one step ahead;
     // the LDS operand of tile t is refreshed in place right after its last MFMA of the step, which
     // leaves >= 7 MFMAs (224+ cycles) before it is consumed again.
-    const float4* wch = wp + (size_t)ch * p.Jc * NT * 64;
+    const float4* wch = wp + ((size_t)ch * p.Jc * p.nt_total + nsi * NT) * 64;
+    const int wstep = p.nt_total * 64;                                          // float4 per K step
     float4 w_cur[NT], b_cur[TY];
     {
       int off = s_tab[q];
@@ -194,7 +201,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
       if (more) {
         off_n = s_tab[(j + 1) * 4 + q];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) w_nxt[n] = wch[((size_t)(j + 1) * NT + n) * 64 + lane];
+        for (int n = 0; n < NT; ++n) w_nxt[n] = wch[(size_t)(j + 1) * wstep + n * 64 + lane];
       }
 #pragma unroll
       for (int s = 0; s < 3; ++s)
@@ -236,7 +243,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
         pb = p.pbias + ((size_t)yo * p.Wi + xo) * (size_t)(3 * p.Cout) + plane_variant(zo - 1, p.Di) * p.Cout;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        int co = n * 16 + 4 * q;
+        int co = (nsi * NT + n) * 16 + 4 * q;
         if (co >= p.Cout) continue;
         float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
         if (p.cls_cout) {
@@ -326,7 +333,8 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
       int which = tid / (NT * 16), c = tid % (NT * 16);
       double v = (s_red[(0 * 2 + which) * (NT * 16) + c] + s_red[(1 * 2 + which) * (NT * 16) + c]) +
                  (s_red[(2 * 2 + which) * (NT * 16) + c] + s_red[(3 * 2 + which) * (NT * 16) + c]);
-      p.stats[((size_t)blockIdx.x * 2 + which) * (NT * 16) + c] = v;
+      // row of width nt_total*16; with N-split the other columns are zero (caller zero-fills the buffer)
+      p.stats[((size_t)blockIdx.x * 2 + which) * (p.nt_total * 16) + nsi * NT * 16 + c] = v;
     }
   }
 }
@@ -405,16 +413,37 @@ static long tiled_ntiles(int Do, int Ho, int Wo, int tile_y) {
   return (long)((Do + TILE_TZ - 1) / TILE_TZ) * ((Ho + tile_y - 1) / tile_y) * ((Wo + TILE_TX - 1) / TILE_TX);
 }
 
-// workgroups of a launch (= rows of stats_partial): the persistent grid, 256 CUs x resident workgroups.
-// Returns 0 when the variant does not produce statistics in its epilogue (Cout > 64: use atvs_channel_stats).
-extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
+// N-split factor: small volumes deal the 16-channel output tiles of a spatial tile to several workgroups
+static int tiled_nsplit(long ntiles, int NT) {
+  int ns = 1;
+  while (ns < NT && ntiles * ns < 256) ns <<= 1;
+  return ns;
+}
+
+// workgroups of a launch (= rows of stats_partial): the persistent grid, 256 CUs x resident workgroups,
+// a multiple of 8 * nsplit.  With nsplit > 1 (returned through *nsplit_out when non-NULL) the statistics
+// buffer must be zero-filled by the caller.
+extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int* nsplit_out) {
   int nch, Ccp;
   tiled_chunks(Cin, &nch, &Ccp);
   long nt = tiled_ntiles(Do, Ho, Wo, tile_y);
-  long cap = 256L * tiled_wps(pow2_tiles(Cout), tile_y, Ccp / 4);
-  return nt < cap ? nt : cap;
+  int NT = pow2_tiles(Cout);
+  int ns = tiled_nsplit(nt, NT);
+  long cap = 256L * tiled_wps(NT / ns, tile_y, Ccp / 4);
+  long want = nt * ns;
+  long g = want < cap ? want : cap;
+  long unit = 8L * ns;
+  g = (g + unit - 1) / unit * unit;
+  if (nsplit_out) *nsplit_out = ns;
+  return g;
 }
-extern "C" int atvs_conv_tiled_has_stats(int Cout) { return tiled_has_stats(pow2_tiles(Cout)) ? 1 : 0; }
+extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
+  return atvs_conv_tiled_grid(Do, Ho, Wo, tile_y, Cin, Cout, nullptr);
+}
+extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cout) {
+  int NT = pow2_tiles(Cout);
+  return tiled_has_stats(NT / tiled_nsplit(tiled_ntiles(Do, Ho, Wo, tile_y), NT)) ? 1 : 0;
+}
 
 template <int NT, int TY, int C4, bool FULL>
 static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
@@ -478,18 +507,21 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   a.cls_cout = class_cout; a.cls_base = class_base;
   const int C4 = Ccp / 4;
   const bool full = (Cin % Ccp == 0);
-  long blocks = atvs_conv_tiled_num_blocks(D, H, W, tile_y, Cin, Cout);
-  if (stats_partial && !tiled_has_stats(NT)) return ATVS_ERR_ARG;
+  int ns = 1;
+  long blocks = atvs_conv_tiled_grid(D, H, W, tile_y, Cin, Cout, &ns);
+  a.nsplit = ns; a.nt_total = NT;
+  const int NTg = NT / ns;
+  if (stats_partial && !tiled_has_stats(NTg)) return ATVS_ERR_ARG;
   hipStream_t s = as_stream(stream);
   if (tile_y == 8) {
-    if (NT == 1) rc = launch_c4<1, 8>(a, C4, full, blocks, s);
-    else if (NT == 2) rc = launch_c4<2, 8>(a, C4, full, blocks, s);
+    if (NTg == 1) rc = launch_c4<1, 8>(a, C4, full, blocks, s);
+    else if (NTg == 2) rc = launch_c4<2, 8>(a, C4, full, blocks, s);
     else return ATVS_ERR_ARG;
   } else if (tile_y == 4) {
-    if (NT == 1) rc = launch_c4<1, 4>(a, C4, full, blocks, s);
-    else if (NT == 2) rc = launch_c4<2, 4>(a, C4, full, blocks, s);
-    else if (NT == 4) rc = launch_c4<4, 4>(a, C4, full, blocks, s);
-    else if (NT == 8) rc = launch_c4<8, 4>(a, C4, full, blocks, s);
+    if (NTg == 1) rc = launch_c4<1, 4>(a, C4, full, blocks, s);
+    else if (NTg == 2) rc = launch_c4<2, 4>(a, C4, full, blocks, s);
+    else if (NTg == 4) rc = launch_c4<4, 4>(a, C4, full, blocks, s);
+    else if (NTg == 8) rc = launch_c4<8, 4>(a, C4, full, blocks, s);
     else return ATVS_ERR_ARG;
   } else {
     return ATVS_ERR_ARG;

@@ -340,6 +340,12 @@ def tiled_blocks(D, H, W, tile_y, cin, cout):
     return int(_lib.lib().atvs_conv_tiled_num_blocks(int(D), int(H), int(W), int(tile_y), int(cin), int(cout)))
 
 
+def tiled_nsplit(D, H, W, tile_y, cin, cout):
+    ns = ctypes.c_int()
+    _lib.lib().atvs_conv_tiled_grid(int(D), int(H), int(W), int(tile_y), int(cin), int(cout), ctypes.byref(ns))
+    return ns.value
+
+
 def clear_pack_cache():
     _pack_cache.clear()
 
@@ -409,8 +415,9 @@ def conv_blocks(M, ntiles, tile_m=None):
     return -(-M // (64 * tm)), tm
 
 
-def _stats_buffer(ref, blocks, cpad):
-    return torch.empty((blocks, 2, cpad), dtype=torch.float64, device=ref.device)
+def _stats_buffer(ref, blocks, cpad, zero=False):
+    f = torch.zeros if zero else torch.empty
+    return f((blocks, 2, cpad), dtype=torch.float64, device=ref.device)
 
 
 def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None, bias=None, residual=None,
@@ -472,7 +479,8 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     st = None
     sbuf = None
     if want_stats:
-        sbuf = _stats_buffer(x, blocks, pk.ntiles * 16)
+        zero = bool(tile_y) and tiled_nsplit(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout) > 1
+        sbuf = _stats_buffer(x, blocks, pk.ntiles * 16, zero)
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
     if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
@@ -616,10 +624,10 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
         tile_y = 8 if (nt <= 2 and H >= 16) else 4
         blocks = tiled_blocks(D, H, W, tile_y, Cin, per * cout)
         nl = 8 // per
-        in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(per * cout))
+        in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(D, H, W, tile_y, per * cout))
         st, sbuf = None, None
         if want_stats and in_kernel:
-            sbuf = _stats_buffer(x, blocks * nl, nt * 16)
+            sbuf = _stats_buffer(x, blocks * nl, nt * 16, tiled_nsplit(D, H, W, tile_y, Cin, per * cout) > 1)
             st = Stats()
             st.partial, st.blocks, st.cpad, st.count, st.fold = sbuf, blocks * nl, nt * 16, 8 * M, per
         for i in range(nl):

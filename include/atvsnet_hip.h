@@ -166,8 +166,11 @@ int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* gro
  * atvs_conv_tiled_pack_size / _pack are the HOST packing functions for it (same inputs
  * as atvs_conv_pack; the table depends on tile_y in {4, 8}).  The grid is persistent
  * (atvs_conv_tiled_num_blocks workgroups sweep the tiles); stats_partial has that many rows of
- * 16*ntiles doubles x 2 (one per workgroup); variants with Cout > 64 produce no statistics
- * (atvs_conv_tiled_has_stats == 0: pass NULL and use atvs_channel_stats on the output).
+ * 16*ntiles doubles x 2 (one per workgroup).  Small volumes deal the 16-channel output tiles of a
+ * spatial tile to several workgroups (atvs_conv_tiled_grid reports nsplit): each then fills only its
+ * own columns, so the caller zero-fills stats_partial when nsplit > 1.  Launches whose per-workgroup
+ * width is 128 channels produce no statistics (atvs_conv_tiled_has_stats == 0: pass NULL and
+ * use atvs_channel_stats on the output).
  * Fused stride-2 transposed convolution (class_cout != 0): the 8 output parity classes of
  * conv3d_transpose(3, stride 2, SAME) are computed from ONE staged tile -- the GEMM's N axis is
  * (class, channel): Cout = n_classes * class_cout "virtual" channels over the 8 taps
@@ -179,7 +182,8 @@ int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* ch
 int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
                          int tile_y, float* packed, int32_t* table);
 long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout);
-int atvs_conv_tiled_has_stats(int Cout);
+long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int* nsplit_out);
+int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cout);
 int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
                         const float* residual, const float* plane_bias, float* y, double* stats_partial,
                         int D, int H, int W, int Cin,
