@@ -413,11 +413,22 @@ static long tiled_ntiles(int Do, int Ho, int Wo, int tile_y) {
   return (long)((Do + TILE_TZ - 1) / TILE_TZ) * ((Ho + tile_y - 1) / tile_y) * ((Wo + TILE_TX - 1) / TILE_TX);
 }
 
-// N-split factor: small volumes deal the 16-channel output tiles of a spatial tile to several workgroups
-static int tiled_nsplit(long ntiles, int NT) {
-  int ns = 1;
-  while (ns < NT && ntiles * ns < 256) ns <<= 1;
-  return ns;
+// N-split factor: deal the 16-channel output tiles of a spatial tile to `ns` workgroups when that
+// shortens the launch: estimated time = rounds of the persistent grid x cost of one work item
+// (MFMA work ~ tiles per item, plus a fixed staging / epilogue share).
+static int tiled_nsplit(long ntiles, int NT, int tile_y, int C4) {
+  int best = 1;
+  double best_t = 1e30;
+  for (int ns = 1; ns <= NT; ns <<= 1) {
+    long cap = 256L * tiled_wps(NT / ns, tile_y, C4);
+    long rounds = (ntiles * ns + cap - 1) / cap;
+    double t = (double)rounds * ((double)(NT / ns) + 0.5);
+    if (t < best_t - 1e-9) {
+      best_t = t;
+      best = ns;
+    }
+  }
+  return best;
 }
 
 // workgroups of a launch (= rows of stats_partial): the persistent grid, 256 CUs x resident workgroups,
@@ -428,7 +439,7 @@ extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin
   tiled_chunks(Cin, &nch, &Ccp);
   long nt = tiled_ntiles(Do, Ho, Wo, tile_y);
   int NT = pow2_tiles(Cout);
-  int ns = tiled_nsplit(nt, NT);
+  int ns = tiled_nsplit(nt, NT, tile_y, Ccp / 4);
   long cap = 256L * tiled_wps(NT / ns, tile_y, Ccp / 4);
   long want = nt * ns;
   long g = want < cap ? want : cap;
@@ -440,9 +451,11 @@ extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin
 extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
   return atvs_conv_tiled_grid(Do, Ho, Wo, tile_y, Cin, Cout, nullptr);
 }
-extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cout) {
+extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
+  int nch, Ccp;
+  tiled_chunks(Cin, &nch, &Ccp);
   int NT = pow2_tiles(Cout);
-  return tiled_has_stats(NT / tiled_nsplit(tiled_ntiles(Do, Ho, Wo, tile_y), NT)) ? 1 : 0;
+  return tiled_has_stats(NT / tiled_nsplit(tiled_ntiles(Do, Ho, Wo, tile_y), NT, tile_y, Ccp / 4)) ? 1 : 0;
 }
 
 template <int NT, int TY, int C4, bool FULL>

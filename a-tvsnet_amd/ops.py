@@ -624,7 +624,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
         tile_y = 8 if (nt <= 2 and H >= 16) else 4
         blocks = tiled_blocks(D, H, W, tile_y, Cin, per * cout)
         nl = 8 // per
-        in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(D, H, W, tile_y, per * cout))
+        in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(D, H, W, tile_y, Cin, per * cout))
         st, sbuf = None, None
         if want_stats and in_kernel:
             sbuf = _stats_buffer(x, blocks * nl, nt * 16, tiled_nsplit(D, H, W, tile_y, Cin, per * cout) > 1)

@@ -183,7 +183,7 @@ int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, 
                          int tile_y, float* packed, int32_t* table);
 long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout);
 long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int* nsplit_out);
-int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cout);
+int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout);
 int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
                         const float* residual, const float* plane_bias, float* y, double* stats_partial,
                         int D, int H, int W, int Cin,
