@@ -20,6 +20,12 @@
 //   epilogue bias / depth-plane bias / residual / ReLU, 16-byte channel-last stores, per-channel
 //            (sum, sum of squares) accumulated over the workgroup's tiles -> one partial row per
 //            workgroup for the deterministic batch-norm reduction.
+//   x-pair   (XP, Cout == 8 only) 8 output channels would fill half of the 16-row MFMA tile.  The rows
+//            become (x parity, channel): lane column i holds the voxel PAIR (2i, 2i+1), the K axis runs
+//            over the 4 x-offsets -1..2 that the pair touches with the kernel zero-padded accordingly
+//            (36 virtual taps instead of 27): 3/4 of the MFMA work is useful instead of 1/2, a third fewer
+//            MFMAs per voxel.  The LDS image keeps even and odd x in separate runs so a tap read is
+//            still 16 voxels x 64 B contiguous.
 #include "conv_common.h"
 
 #define TILE_TZ 4
@@ -54,18 +60,19 @@ __device__ __forceinline__ int lds_swz(int a) { return a ^ (((a >> 8) & 1) << 5)
 
 // Wavefronts per SIMD the register budget of an instantiation allows (accumulators + prefetch
 // registers + operands): 2 workgroups per CU when it fits in 256 VGPRs, else 1 (512).
-__host__ __device__ constexpr int tiled_wps(int NT, int TY, int C4) {
-  return (NT * TY * 4 + ((TILE_TZ + 2) * (TY + 2) * (TILE_TX + 2) * C4 + 255) / 256 * 4 + TY * 4 + NT * 16 + 40 <= 200) ? 2 : 1;
+__host__ __device__ constexpr int tiled_wps(int NT, int TY, int C4, bool XP = false) {
+  return (NT * TY * 4 + ((TILE_TZ + 2) * (TY + 2) * ((XP ? 2 : 1) * TILE_TX + 2) * C4 + 255) / 256 * 4 + TY * 4 + NT * 16 + 40 <= 200) ? 2 : 1;
 }
 // statistics in the epilogue cost 8*NT registers; the widest variant leaves them to a separate pass
 __host__ __device__ constexpr bool tiled_has_stats(int NT) { return NT < 8; }
 
 // C4 = channel groups (float4) per voxel of a chunk in LDS: 4 (16 channels), 2 (8), 1 (<= 4).
 // FULL = every chunk has exactly 4*C4 real channels and Cin % 4 == 0 (vector loads, no tail).
-template <int NT, int TY, int C4, bool FULL>
-__global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_kernel(TiledArgs p) {
+template <int NT, int TY, int C4, bool FULL, bool XP>
+__global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32_kernel(TiledArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int HZ = TILE_TZ + 2, HY = TY + 2, HX = TILE_TX + 2;
+  constexpr int TXV = XP ? 2 * TILE_TX : TILE_TX;          // voxels per tile row
+  constexpr int HZ = TILE_TZ + 2, HY = TY + 2, HX = TXV + 2;
   constexpr int SLOTS = HZ * HY * HX * C4;
   constexpr int MAXS = (SLOTS + 255) / 256;
   constexpr int VB = C4 * 16;                     // bytes per voxel in LDS
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
 
   int vbase[TY];
 #pragma unroll
-  for (int t = 0; t < TY; ++t) vbase[t] = ((wave * HY + t) * HX + r) * VB;
+  for (int t = 0; t < TY; ++t) vbase[t] = ((wave * HY + t) * HX + r) * VB;   // XP: r = pair index within the even/odd run
 
   const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wp);
   const unsigned char* lds = smem;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
     int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
     int bx = tl % p.tiles_x;
     int rest = tl / p.tiles_x;
-    *x0 = bx * TILE_TX;
+    *x0 = bx * TXV;
     *y0 = (rest % p.tiles_y) * TY;
     *z0 = (rest / p.tiles_y) * TILE_TZ;
   };
@@ -170,6 +177,12 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
       int s = tid + i * 256;
       if (s < SLOTS) {
         int a = s * 16;
+        if (XP) {
+          // even / odd x in separate runs of 17 voxels: (row, xl) -> row*34 + (xl&1)*17 + (xl>>1)
+          int c4 = s % C4, v = s / C4;
+          int xl = v % HX, row = v / HX;
+          a = ((row * HX + (xl & 1) * (HX / 2) + (xl >> 1)) * C4 + c4) * 16;
+        }
         if (SWZ) a = lds_swz(a);
         *reinterpret_cast<float4*>(smem + a) = pf[i];
       }
@@ -231,7 +244,38 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
     // ---- epilogue of this tile: lane holds channels n*16 + 4q .. +3 of voxel (z0+wave, y0+t, x0+r)
     int z0, y0, x0;
     tile_origin(k, &z0, &y0, &x0);
-    const int zo = z0 + wave, xo = x0 + r;
+    const int zo = z0 + wave;
+    if (XP) {
+      // rows of the accumulator = (x parity, channel): this lane holds channels (q&1)*4..+3 of voxel 2r + (q>>1)
+      const int xo = x0 + 2 * r + (q >> 1), co = (q & 1) * 4;
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        const int yo = y0 + t;
+        if (zo >= p.Di || yo >= p.Hi || xo >= p.Wi) continue;
+        size_t base = (((size_t)zo * p.Hy + yo) * p.Wy + xo) * (size_t)p.ldy + p.ycoff + co;
+        float4 v = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
+        if (p.pbias) {
+          float4 b = ld4(p.pbias + ((size_t)yo * p.Wi + xo) * 24 + plane_variant(zo - 1, p.Di) * 8 + co);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (p.bias) {
+          float4 b = ld4(p.bias + co);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (p.res) {
+          float4 b = ld4(p.res + base);
+          v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        st4(p.y + base, v);
+        ssum[0][0] += v.x; ssum[0][1] += v.y; ssum[0][2] += v.z; ssum[0][3] += v.w;
+        ssq[0][0] += v.x * v.x; ssq[0][1] += v.y * v.y; ssq[0][2] += v.z * v.z; ssq[0][3] += v.w * v.w;
+      }
+      continue;
+    }
+    const int xo = x0 + r;
 #pragma unroll
     for (int t = 0; t < TY; ++t) {
       const int yo = y0 + t;
@@ -323,6 +367,11 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4)) void conv_tiled_f32_ker
           a += __shfl_xor(a, o);
           b += __shfl_xor(b, o);
         }
+        if (XP) {   // lanes q and q^2 hold the same channels (the two x parities)
+          a += __shfl_xor(a, 32);
+          b += __shfl_xor(b, 32);
+          if (q >= 2) a = b = 0.0;
+        }
         if (r == 0) {
           s_red[(wave * 2 + 0) * (NT * 16) + n * 16 + 4 * q + k] = a;
           s_red[(wave * 2 + 1) * (NT * 16) + n * 16 + 4 * q + k] = b;
@@ -369,7 +418,7 @@ extern "C" int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchu
 // HOST function.  Same inputs as atvs_conv_pack, taps restricted to offsets in [-1, 1]^3; `tile_y` is the
 // TY the launch will use (the table holds LDS byte offsets of the (4+2) x (tile_y+2) x 18 x chunk image).
 extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
-                                    int tile_y, float* packed, int32_t* table) {
+                                    int tile_y, int xpair, float* packed, int32_t* table) {
   if (!w || !taps || !packed || !table) return ATVS_ERR_NULL;
   int nch, Ccp, Jc, NT;
   long pf, ti;
@@ -377,10 +426,10 @@ extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int3
   if (rc) return rc;
   const int c4n = Ccp / 4;
   const int G = ntaps * c4n;
-  const int HY = tile_y + 2, HX = TILE_TX + 2;
+  const int HY = tile_y + 2, HX = (xpair ? 2 : 1) * TILE_TX + 2;
   for (int t = 0; t < ntaps; ++t)
     for (int a = 1; a < 4; ++a)
-      if (taps[t * 4 + a] < -1 || taps[t * 4 + a] > 1) return ATVS_ERR_ARG;
+      if (taps[t * 4 + a] < -1 || taps[t * 4 + a] > ((xpair && a == 3) ? 2 : 1)) return ATVS_ERR_ARG;
   for (long i = 0; i < pf; ++i) packed[i] = 0.f;
   for (int j = 0; j < Jc; ++j)
     for (int q = 0; q < 4; ++q) {
@@ -391,7 +440,9 @@ extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int3
       }
       int t = g / c4n, c4 = g % c4n;
       int dz = taps[t * 4 + 1], dy = taps[t * 4 + 2], dx = taps[t * 4 + 3];
-      table[g] = ((((dz + 1) * HY + (dy + 1)) * HX + (dx + 1)) * Ccp + c4 * 4) * 4;
+      int xl = dx + 1;          // x position in the halo row for column 0 of the tile
+      int xcol = xpair ? ((xl & 1) * (HX / 2) + (xl >> 1)) : xl;
+      table[g] = ((((dz + 1) * HY + (dy + 1)) * HX + xcol) * Ccp + c4 * 4) * 4;
       int wt = taps[t * 4 + 0];
       for (int ch = 0; ch < nch; ++ch)
         for (int n = 0; n < NT; ++n)
@@ -409,18 +460,19 @@ extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int3
   return ATVS_OK;
 }
 
-static long tiled_ntiles(int Do, int Ho, int Wo, int tile_y) {
-  return (long)((Do + TILE_TZ - 1) / TILE_TZ) * ((Ho + tile_y - 1) / tile_y) * ((Wo + TILE_TX - 1) / TILE_TX);
+static long tiled_ntiles(int Do, int Ho, int Wo, int tile_y, int xpair = 0) {
+  int tx = (xpair ? 2 : 1) * TILE_TX;
+  return (long)((Do + TILE_TZ - 1) / TILE_TZ) * ((Ho + tile_y - 1) / tile_y) * ((Wo + tx - 1) / tx);
 }
 
 // N-split factor: deal the 16-channel output tiles of a spatial tile to `ns` workgroups when that
 // shortens the launch: estimated time = rounds of the persistent grid x cost of one work item
 // (MFMA work ~ tiles per item, plus a fixed staging / epilogue share).
-static int tiled_nsplit(long ntiles, int NT, int tile_y, int C4) {
+static int tiled_nsplit(long ntiles, int NT, int tile_y, int C4, bool xp = false) {
   int best = 1;
   double best_t = 1e30;
   for (int ns = 1; ns <= NT; ns <<= 1) {
-    long cap = 256L * tiled_wps(NT / ns, tile_y, C4);
+    long cap = 256L * tiled_wps(NT / ns, tile_y, C4, xp);
     long rounds = (ntiles * ns + cap - 1) / cap;
     double t = (double)rounds * ((double)(NT / ns) + 0.5);
     if (t < best_t - 1e-9) {
@@ -434,13 +486,13 @@ static int tiled_nsplit(long ntiles, int NT, int tile_y, int C4) {
 // workgroups of a launch (= rows of stats_partial): the persistent grid, 256 CUs x resident workgroups,
 // a multiple of 8 * nsplit.  With nsplit > 1 (returned through *nsplit_out when non-NULL) the statistics
 // buffer must be zero-filled by the caller.
-extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int* nsplit_out) {
+extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int* nsplit_out) {
   int nch, Ccp;
   tiled_chunks(Cin, &nch, &Ccp);
-  long nt = tiled_ntiles(Do, Ho, Wo, tile_y);
-  int NT = pow2_tiles(Cout);
-  int ns = tiled_nsplit(nt, NT, tile_y, Ccp / 4);
-  long cap = 256L * tiled_wps(NT / ns, tile_y, Ccp / 4);
+  long nt = tiled_ntiles(Do, Ho, Wo, tile_y, xpair);
+  int NT = xpair ? 1 : pow2_tiles(Cout);
+  int ns = tiled_nsplit(nt, NT, tile_y, Ccp / 4, xpair != 0);
+  long cap = 256L * tiled_wps(NT / ns, tile_y, Ccp / 4, xpair != 0);
   long want = nt * ns;
   long g = want < cap ? want : cap;
   long unit = 8L * ns;
@@ -448,8 +500,8 @@ extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin
   if (nsplit_out) *nsplit_out = ns;
   return g;
 }
-extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
-  return atvs_conv_tiled_grid(Do, Ho, Wo, tile_y, Cin, Cout, nullptr);
+extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair) {
+  return atvs_conv_tiled_grid(Do, Ho, Wo, tile_y, Cin, Cout, xpair, nullptr);
 }
 extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
   int nch, Ccp;
@@ -458,20 +510,28 @@ extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int
   return tiled_has_stats(NT / tiled_nsplit(tiled_ntiles(Do, Ho, Wo, tile_y), NT, tile_y, Ccp / 4)) ? 1 : 0;
 }
 
-template <int NT, int TY, int C4, bool FULL>
+template <int NT, int TY, int C4, bool FULL, bool XP = false>
 static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
-  size_t lds = (size_t)(TILE_TZ + 2) * (TY + 2) * (TILE_TX + 2) * C4 * 16 + (size_t)a.Jc * 4 * sizeof(int);
+  size_t lds = (size_t)(TILE_TZ + 2) * (TY + 2) * ((XP ? 2 : 1) * TILE_TX + 2) * C4 * 16 + (size_t)a.Jc * 4 * sizeof(int);
   size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double);
   if (lds < red) lds = red;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tiled_f32_kernel<NT, TY, C4, FULL>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY, C4, FULL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;
+}
+
+template <int TY>
+static int launch_xp(const TiledArgs& a, int C4, bool full, long blocks, hipStream_t s) {
+  if (C4 == 4) return full ? launch_tiled<1, TY, 4, true, true>(a, blocks, s) : launch_tiled<1, TY, 4, false, true>(a, blocks, s);
+  if (C4 == 2) return full ? launch_tiled<1, TY, 2, true, true>(a, blocks, s) : launch_tiled<1, TY, 2, false, true>(a, blocks, s);
+  if (C4 == 1) return full ? launch_tiled<1, TY, 1, true, true>(a, blocks, s) : launch_tiled<1, TY, 1, false, true>(a, blocks, s);
+  return ATVS_ERR_ARG;
 }
 
 template <int NT, int TY>
@@ -489,7 +549,7 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
                                    const float* residual, const float* plane_bias, float* y, double* stats_partial,
                                    int D, int H, int W, int Cin, int Dy, int Hy, int Wy, int out_stride, int off_z,
                                    int off_y, int off_x, int ldy, int y_coff, int Cout, int ntaps, int tile_y, int relu,
-                                   int class_cout, int class_base, atvs_stream_t stream) {
+                                   int class_cout, int class_base, int xpair, atvs_stream_t stream) {
   if (!x || !packed_w || !table || !y) return ATVS_ERR_NULL;
   if (D <= 0 || H <= 0 || W <= 0 || out_stride <= 0) return ATVS_ERR_SHAPE;
   if (class_cout) {
@@ -504,15 +564,17 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   }
   if (residual && y_coff != 0) return ATVS_ERR_ARG;
   if (plane_bias && (out_stride != 1 || D < 2)) return ATVS_ERR_ARG;
+  if (xpair && (Cout != 8 || class_cout || out_stride != 1 || (ldy % 4) || (y_coff % 4) || ntaps != 36)) return ATVS_ERR_ARG;
   int nch, Ccp, Jc, NT;
-  int rc = atvs_conv_tiled_pack_size(ntaps, Cin, Cout, &nch, &Ccp, &Jc, &NT, nullptr, nullptr);
+  int rc = atvs_conv_tiled_pack_size(ntaps, Cin, xpair ? 16 : Cout, &nch, &Ccp, &Jc, &NT, nullptr, nullptr);
   if (rc) return rc;
   TiledArgs a;
   a.x = x; a.wp = packed_w; a.tab = table; a.bias = bias; a.res = residual; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.Hy = Hy; a.Wy = Wy;
   a.oS = out_stride; a.offz = off_z; a.offy = off_y; a.offx = off_x; a.ldy = ldy; a.ycoff = y_coff; a.Cout = Cout;
   a.nchunk = nch; a.Jc = Jc;
-  a.tiles_z = (D + TILE_TZ - 1) / TILE_TZ; a.tiles_y = (H + tile_y - 1) / tile_y; a.tiles_x = (W + TILE_TX - 1) / TILE_TX;
+  const int txv = (xpair ? 2 : 1) * TILE_TX;
+  a.tiles_z = (D + TILE_TZ - 1) / TILE_TZ; a.tiles_y = (H + tile_y - 1) / tile_y; a.tiles_x = (W + txv - 1) / txv;
   a.ntiles = a.tiles_z * a.tiles_y * a.tiles_x;
   a.relu = relu;
   a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
@@ -521,12 +583,16 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   const int C4 = Ccp / 4;
   const bool full = (Cin % Ccp == 0);
   int ns = 1;
-  long blocks = atvs_conv_tiled_grid(D, H, W, tile_y, Cin, Cout, &ns);
+  long blocks = atvs_conv_tiled_grid(D, H, W, tile_y, Cin, Cout, xpair, &ns);
   a.nsplit = ns; a.nt_total = NT;
   const int NTg = NT / ns;
   if (stats_partial && !tiled_has_stats(NTg)) return ATVS_ERR_ARG;
   hipStream_t s = as_stream(stream);
-  if (tile_y == 8) {
+  if (xpair) {
+    if (tile_y == 8 && C4 < 4) rc = launch_xp<8>(a, C4, full, blocks, s);
+    else if (tile_y == 4) rc = launch_xp<4>(a, C4, full, blocks, s);
+    else return ATVS_ERR_ARG;
+  } else if (tile_y == 8) {
     if (NTg == 1) rc = launch_c4<1, 8>(a, C4, full, blocks, s);
     else if (NTg == 2) rc = launch_c4<2, 8>(a, C4, full, blocks, s);
     else return ATVS_ERR_ARG;

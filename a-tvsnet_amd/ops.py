@@ -254,10 +254,10 @@ def pack_conv_weights(key, w_host, taps, transposed, device):
     return pk
 
 
-def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y):
+def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y, xpair=False):
     """Packed weights + LDS-offset table for the LDS-tiled kernel; cached."""
     import numpy as np
-    ck = ('tiled', key, taps, bool(transposed), str(device), tile_y)
+    ck = ('tiled', key, taps, bool(transposed), str(device), tile_y, bool(xpair))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
@@ -275,7 +275,7 @@ def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y):
     table = np.empty(ti.value, np.int32)
     tp = np.ascontiguousarray(np.array(taps, dtype=np.int32).reshape(-1, 4))
     rc = L.atvs_conv_tiled_pack(w.ctypes.data_as(ctypes.c_void_p), int(bool(transposed)),
-                                tp.ctypes.data_as(ctypes.c_void_p), ntaps, cin, cout, int(tile_y),
+                                tp.ctypes.data_as(ctypes.c_void_p), ntaps, cin, cout, int(tile_y), int(bool(xpair)),
                                 packed.ctypes.data_as(ctypes.c_void_p), table.ctypes.data_as(ctypes.c_void_p))
     if rc:
         raise RuntimeError('atvs_conv_tiled_pack failed (%d)' % rc)
@@ -317,7 +317,7 @@ def force_conv_impl(impl):
 
 
 def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None, residual=None, relu=False,
-                      stats_buf=None, plane_bias=None, class_cout=0, class_base=0):
+                      stats_buf=None, plane_bias=None, class_cout=0, class_base=0, xpair=False):
     """One atvs_conv_tiled_f32 launch: logical output grid = input grid of x4 (D,H,W,Cin)."""
     D, H, W, Cin = x4.shape
     Dy, Hy, Wy, ldy = y.shape
@@ -329,21 +329,58 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
         _call('atvs_conv_tiled_f32', _p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
               _p(plane_bias), _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
               Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
-              pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), int(class_cout), int(class_base), _stream())
+              8 if xpair else pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), int(class_cout), int(class_base),
+              int(bool(xpair)), _stream())
         if timed:
             e1.record()
             _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
 
 
-def tiled_blocks(D, H, W, tile_y, cin, cout):
+def tiled_blocks(D, H, W, tile_y, cin, cout, xpair=False):
     """Workgroups (= statistics rows) of a tiled launch: the persistent grid size."""
-    return int(_lib.lib().atvs_conv_tiled_num_blocks(int(D), int(H), int(W), int(tile_y), int(cin), int(cout)))
+    return int(_lib.lib().atvs_conv_tiled_num_blocks(int(D), int(H), int(W), int(tile_y), int(cin), int(cout),
+                                                     int(bool(xpair))))
 
 
-def tiled_nsplit(D, H, W, tile_y, cin, cout):
+def tiled_nsplit(D, H, W, tile_y, cin, cout, xpair=False):
     ns = ctypes.c_int()
-    _lib.lib().atvs_conv_tiled_grid(int(D), int(H), int(W), int(tile_y), int(cin), int(cout), ctypes.byref(ns))
+    _lib.lib().atvs_conv_tiled_grid(int(D), int(H), int(W), int(tile_y), int(cin), int(cout), int(bool(xpair)),
+                                    ctypes.byref(ns))
     return ns.value
+
+
+_xp_cache = {}
+
+
+def _xpair_virtual_kernel(key, w_host):
+    """Dense virtual kernel of the x-pair form: (36 taps (kd,kh,ox in -1..2), Cin, (jx, co)) with
+    Wv[(kd,kh,ox)][ci][jx*8+co] = W[kd][kh][kw = ox - jx + 1][ci][co] (0 when kw is outside 0..2)."""
+    import numpy as np
+    hit = _xp_cache.get(key)
+    if hit is not None:
+        return hit
+    w = np.asarray(w_host, np.float32)               # [3,3,3,Cin,8]
+    cin = w.shape[3]
+    wv = np.zeros((3, 3, 4, cin, 2, 8), np.float32)
+    for oi in range(4):
+        for jx in range(2):
+            kw = (oi - 1) - jx + 1
+            if 0 <= kw <= 2:
+                wv[:, :, oi, :, jx, :] = w[:, :, kw]
+    hit = wv.reshape(36, cin, 16)
+    _xp_cache[key] = hit
+    return hit
+
+
+XPAIR_TAPS = tuple(((kd * 3 + kh) * 4 + oi, kd - 1, kh - 1, oi - 1) for kd in range(3) for kh in range(3)
+                   for oi in range(4))
+_USE_XPAIR = True
+
+
+def use_xpair(flag):
+    """Testing / A-B hook for the x-pair form of the Cout == 8 convolutions."""
+    global _USE_XPAIR
+    _USE_XPAIR = bool(flag)
 
 
 def clear_pack_cache():
@@ -456,7 +493,13 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
             and tuple(outs) == tuple(ins):
         tile_y = tiled_tile_y(ins[1], ins[2], cout)
-    if tile_y:
+    xpair = bool(tile_y) and _USE_XPAIR and cout == 8 and (ins[2] >= 24 or _FORCE_IMPL == 'tiled') \
+        and (out is None or (out.shape[-1] % 4 == 0 and y_coff % 4 == 0))
+    if xpair:
+        tile_y = 4 if w_host.shape[-2] > 8 else tile_y
+        pk = pack_conv_weights_tiled(key, _xpair_virtual_kernel(key, w_host), XPAIR_TAPS, False, x.device, tile_y, True)
+        pk.cout = 8
+    elif tile_y:
         pk = pack_conv_weights_tiled(key, w_host, taps, False, x.device, tile_y)
     else:
         pk = pack_conv_weights(key, w_host, taps, False, x.device)
@@ -473,20 +516,20 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         res4 = residual if residual.dim() == 4 else residual.reshape((1,) + tuple(residual.shape))
     M = outs[0] * outs[1] * outs[2]
     if tile_y:
-        blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout), 0
+        blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout, xpair), 0
     else:
         blocks, tm = conv_blocks(M, pk.ntiles)
     st = None
     sbuf = None
     if want_stats:
-        zero = bool(tile_y) and tiled_nsplit(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout) > 1
+        zero = bool(tile_y) and tiled_nsplit(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout, xpair) > 1
         sbuf = _stats_buffer(x, blocks, pk.ntiles * 16, zero)
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
     if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
         raise ValueError('conv %s: plane_bias %s, expected %s' % (key, tuple(plane_bias.shape), (outs[1], outs[2], 3 * pk.cout)))
     if tile_y:
-        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf, plane_bias)
+        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf, plane_bias, xpair=xpair)
     else:
         conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm, plane_bias, pads[0])
     y = out if out is not None else (y4 if nsp == 3 else y4.reshape(tuple(y4.shape[1:])))

@@ -176,20 +176,24 @@ int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* gro
  * (class, channel): Cout = n_classes * class_cout "virtual" channels over the 8 taps
  * {-1,0}^3 with the dense virtual kernel Wv[off][ci][(class, co)] = W[k(off, class)] or 0; virtual
  * channel (c, co) of grid voxel j is written to output voxel 2j + parity(class_base + c); the
- * statistics columns (c, co) fold onto co in atvs_bn_finalize(fold = n_classes). */
+ * statistics columns (c, co) fold onto co in atvs_bn_finalize(fold = n_classes).
+ * x-pair form (xpair != 0, Cout == 8 only): the 16 GEMM rows are (x parity, channel) and a tile column
+ * is the voxel pair (2i, 2i+1), so no row of the MFMA tile is padding; the packed kernel is the dense
+ * virtual kernel Wv[(kd,kh,ox)][ci][(jx,co)] = W[kd][kh][ox-jx+1] (or 0) over the 36 taps
+ * ox in -1..2 (pack with xpair = 1 and 16 output channels); tile_y = 4 for 16-channel chunks. */
 int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* chunk_pad, int* ksteps_per_chunk,
                               int* ntiles, long* packed_floats, long* table_ints);
 int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
-                         int tile_y, float* packed, int32_t* table);
-long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout);
-long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int* nsplit_out);
+                         int tile_y, int xpair, float* packed, int32_t* table);
+long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair);
+long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int* nsplit_out);
 int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout);
 int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
                         const float* residual, const float* plane_bias, float* y, double* stats_partial,
                         int D, int H, int W, int Cin,
                         int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
                         int y_coff, int Cout, int ntaps, int tile_y, int relu, int class_cout, int class_base,
-                        atvs_stream_t stream);
+                        int xpair, atvs_stream_t stream);
 
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,
