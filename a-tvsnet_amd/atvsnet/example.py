@@ -54,20 +54,61 @@ def infer_twoview(images, cams, max_d=None):
     return depth_refined
 
 
-def infer_multiview(images, cams, max_d=None, stages=None):
+class _ViewStreams(object):
+    """One HIP stream per source view (plus the caller's stream).
+
+    The per-view base and refinement stages are independent (reference example.py:144-149,163-172), and
+    many of their kernels (1/4- and 1/8-resolution layers, 2-D towers) cannot fill 256 CUs on their own:
+    issuing the views on separate streams lets the GPU overlap them.  Every tensor a view stream produces
+    is handed to the main stream with an event wait + record_stream (caching-allocator safety)."""
+
+    def __init__(self, n, device, enabled):
+        self.main = torch.cuda.current_stream(device) if device.type == 'cuda' else None
+        self.enabled = bool(enabled) and device.type == 'cuda' and n > 1
+        self.streams = [torch.cuda.Stream(device) for _ in range(n)] if self.enabled else []
+
+    def run(self, i, fn):
+        """fn() on stream i (after everything queued so far on the main stream); returns fn's result."""
+        if not self.enabled:
+            return fn()
+        st = self.streams[i]
+        st.wait_stream(self.main)
+        with torch.cuda.stream(st):
+            return fn()
+
+    def join(self, tensors):
+        """Main stream waits for every view stream; `tensors` (nested lists ok) become usable on it."""
+        if not self.enabled:
+            return
+        for st in self.streams:
+            self.main.wait_stream(st)
+
+        def rec(t):
+            if isinstance(t, (list, tuple)):
+                for u in t:
+                    rec(u)
+            elif isinstance(t, torch.Tensor):
+                t.record_stream(self.main)
+        rec(tensors)
+
+
+def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True):
     """The run loop of run_test_multiview (reference example.py:140-181), on the device:
-    base (per source) -> AAM1 -> refinement (per source) -> AAM2 -> x4 upsample + soft-argmin."""
+    base (per source) -> AAM1 -> refinement (per source) -> AAM2 -> x4 upsample + soft-argmin.
+    view_streams: issue the independent per-view stages on separate HIP streams."""
     max_d = FLAGS.max_d if max_d is None else max_d
     n = images.shape[1]
     assert n > 2
     depth_start, depth_interval = depth_range(cams)
+    vs = _ViewStreams(n - 1, images.device, view_streams)
     ref_feature = TVSNet_feature_extraction(images, 0)
-    filtered_cost_volumes, depth_views = [], []
-    for view_i in range(1, n):
-        _, _prob_b2, filtered, depth_view = TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval,
-                                                                view_i=view_i, ref_i=0, ref_feature=ref_feature)
-        filtered_cost_volumes.append(filtered)      # prob volumes are fed but unused by the reference (quirk C12)
-        depth_views.append(depth_view)
+    base = [vs.run(v - 1, lambda v=v: TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval, view_i=v,
+                                                          ref_i=0, ref_feature=ref_feature))
+            for v in range(1, n)]
+    vs.join(base)
+    filtered_cost_volumes = [b[2] for b in base]    # prob volumes are fed but unused by the reference (quirk C12)
+    depth_views = [b[3] for b in base]
+    del base
     # AAM1
     cost_volume_agg = cost_volume_aggregation(filtered_cost_volumes, reuse=False, keepchannel=True)
     prob_volume_agg = output_conv(cost_volume_agg, reuse=False)
@@ -75,13 +116,13 @@ def infer_multiview(images, cams, max_d=None, stages=None):
     del filtered_cost_volumes
     # refinement against the aggregated estimate
     ref_shallow = ResNetDS2SPP_shallow_f16({'data': images[:, 0]}, is_training=True).get_output()
-    refined_cost_volumes = []
-    for view_i in range(1, n):
+
+    def refine(view_i):
         shallow = extract_feature_shallow(images, 0, view_i, ref_feature=ref_shallow)
-        _, refined_cost = TVSNet_refine(depth_agg_init, depth_views[view_i - 1], prob_volume_agg, cost_volume_agg,
-                                        images, cams, max_d, depth_start, depth_interval, view_i=view_i, ref_i=0,
-                                        shallow_features=shallow)
-        refined_cost_volumes.append(refined_cost)
+        return TVSNet_refine(depth_agg_init, depth_views[view_i - 1], prob_volume_agg, cost_volume_agg, images, cams,
+                             max_d, depth_start, depth_interval, view_i=view_i, ref_i=0, shallow_features=shallow)[1]
+    refined_cost_volumes = [vs.run(v - 1, lambda v=v: refine(v)) for v in range(1, n)]
+    vs.join(refined_cost_volumes)
     # AAM2
     refined_cost_volume_agg = cost_volume_aggregation_refine(refined_cost_volumes, reuse=False, keepchannel=True)
     refined_prob_volume_agg = output_conv_refine(refined_cost_volume_agg, reuse=False)
