@@ -117,3 +117,20 @@ def test_stacked_attention_input_matches_list(cuda, weights):
     p = model.cost_volume_aggregation(X.to(cuda), keepchannel=False).cpu()
     want_p = nets.output_conv(want, weights, 'attention_prob_vol')
     assert float((p - want_p).abs().max()) < 1e-4 * float(want_p.abs().max()) + 1e-5
+
+
+def test_graph_replay_equals_eager(cuda, weights):
+    """The pipeline captured in a HIP graph (per-view streams included) gives the eager result, also
+    after the static input buffers are overwritten with another scene."""
+    from atvsnet_amd.atvsnet import example as ex
+    imgs, cams = _inputs(4)
+    imgs, cams = imgs.to(cuda), cams.to(cuda)
+    eager = ex.infer_multiview(imgs, cams, 32).clone()
+    g = ex.GraphedInference(imgs, cams, 32)
+    assert torch.equal(g(), eager)
+    imgs2 = imgs.flip(1).contiguous()
+    cams2 = cams.flip(1).contiguous()
+    eager2 = ex.infer_multiview(imgs2, cams2, 32).clone()
+    assert not torch.equal(eager2, eager)
+    assert torch.equal(g(imgs2, cams2), eager2)
+    assert torch.equal(g(imgs, cams), eager)
