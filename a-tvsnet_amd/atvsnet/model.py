@@ -217,23 +217,42 @@ def TVSNet_base(images, cams, depth_num, depth_start, depth_interval, view_i, re
     return depth_b2, prob_vol_b2, filtered
 
 
-def TVSNet_base_siamese(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0, ref_feature=None):
+def TVSNet_base_siamese(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0, ref_feature=None,
+                        side_stream=None):
     """Both directions of one (reference, source) pair (reference :398-417) ->
     (depth_b2, prob_vol_b2, filtered_cost_volume, depth_view).  Quirk C11: the reverse
-    direction sweeps the reference camera's depth range."""
+    direction sweeps the reference camera's depth range.  The two directions only share the feature
+    towers; with `side_stream` (a torch.cuda.Stream) the reverse one is issued there and joined before
+    returning."""
     if ref_feature is None:
         ref_feature = TVSNet_feature_extraction(images, ref_i)
     view_feature = TVSNet_feature_extraction(images, view_i)
+
+    def reverse():
+        cost_vol_view = build_cost_volume(view_feature, ref_feature, cams, depth_num, depth_start, depth_interval,
+                                          ref_id=view_i, view_id=0, lazy=True)
+        prob_vol_view = cost_volume_reasoning(cost_vol_view, output_filtered_cost=False, reuse=AUTO_REUSE)
+        del cost_vol_view
+        return prob2depth(prob_vol_view, depth_num, depth_start, depth_interval)
+
+    cur = None
+    if side_stream is not None and view_feature.is_cuda:
+        cur = torch.cuda.current_stream(view_feature.device)
+        side_stream.wait_stream(cur)
+        with torch.cuda.stream(side_stream):
+            depth_view = reverse()
     cost_vol = build_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id=0,
                                  view_id=view_i, lazy=True)
     prob_vol_b2, filtered = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
     del cost_vol
     depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
-    cost_vol_view = build_cost_volume(view_feature, ref_feature, cams, depth_num, depth_start, depth_interval,
-                                      ref_id=view_i, view_id=0, lazy=True)
-    prob_vol_view = cost_volume_reasoning(cost_vol_view, output_filtered_cost=False, reuse=AUTO_REUSE)
-    del cost_vol_view
-    depth_view = prob2depth(prob_vol_view, depth_num, depth_start, depth_interval)
+    if cur is not None:
+        cur.wait_stream(side_stream)
+        depth_view.record_stream(cur)
+        view_feature.record_stream(side_stream)
+        ref_feature.record_stream(side_stream)
+    else:
+        depth_view = reverse()
     return depth_b2, prob_vol_b2, filtered, depth_view
 
 
