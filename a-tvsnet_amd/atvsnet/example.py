@@ -83,6 +83,8 @@ class _ViewStreams(object):
             return
         for st in self.streams:
             self.main.wait_stream(st)
+        if torch.cuda.is_current_stream_capturing():        # a capturing graph owns its pool's lifetimes
+            return
 
         def rec(t):
             if isinstance(t, (list, tuple)):

@@ -248,9 +248,10 @@ def TVSNet_base_siamese(images, cams, depth_num, depth_start, depth_interval, vi
     depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
     if cur is not None:
         cur.wait_stream(side_stream)
-        depth_view.record_stream(cur)
-        view_feature.record_stream(side_stream)
-        ref_feature.record_stream(side_stream)
+        if not torch.cuda.is_current_stream_capturing():     # a capturing graph owns its pool's lifetimes
+            depth_view.record_stream(cur)
+            view_feature.record_stream(side_stream)
+            ref_feature.record_stream(side_stream)
     else:
         depth_view = reverse()
     return depth_b2, prob_vol_b2, filtered, depth_view
