@@ -66,7 +66,6 @@ class _ViewStreams(object):
         self.main = torch.cuda.current_stream(device) if device.type == 'cuda' else None
         self.enabled = bool(enabled) and device.type == 'cuda' and n > 1
         self.streams = [torch.cuda.Stream(device) for _ in range(n)] if self.enabled else []
-        self.side = [torch.cuda.Stream(device) for _ in range(n)] if self.enabled else [None] * n
 
     def run(self, i, fn):
         """fn() on stream i (after everything queued so far on the main stream); returns fn's result."""
@@ -106,7 +105,7 @@ def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True):
     vs = _ViewStreams(n - 1, images.device, view_streams)
     ref_feature = TVSNet_feature_extraction(images, 0)
     base = [vs.run(v - 1, lambda v=v: TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval, view_i=v,
-                                                          ref_i=0, ref_feature=ref_feature, side_stream=vs.side[v - 1]))
+                                                          ref_i=0, ref_feature=ref_feature))
             for v in range(1, n)]
     vs.join(base)
     filtered_cost_volumes = [b[2] for b in base]    # prob volumes are fed but unused by the reference (quirk C12)
