@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    import torch
+    # the CPU oracle (oneDNN) slows down badly with hundreds of threads on these small convolutions
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
 
 
 @pytest.fixture(scope='session')

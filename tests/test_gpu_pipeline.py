@@ -134,3 +134,18 @@ def test_graph_replay_equals_eager(cuda, weights):
     assert not torch.equal(eager2, eager)
     assert torch.equal(g(imgs2, cams2), eager2)
     assert torch.equal(g(imgs, cams), eager)
+
+
+def test_midsize_pipelines(cuda, weights):
+    """320x256 images, D=64 (feature grid 64x80): exercises full tiles, the x-pair form, N-split and the
+    fused transposed convolution at sizes between config 1 and the benchmark configuration."""
+    from atvsnet_amd.atvsnet import example as ex
+    imgs, cams = _inputs(3, 256, 320, 64)
+    want2 = OM.run_twoview(imgs[:, :2], cams[:, :2], weights, 64)
+    got2 = ex.infer_twoview(imgs[:, :2].contiguous().to(cuda), cams[:, :2].contiguous().to(cuda), 64).cpu()
+    e2 = rel_l1(got2, want2)
+    want3 = OM.run_multiview(imgs, cams, weights, 64)
+    got3 = ex.infer_multiview(imgs.to(cuda), cams.to(cuda), 64).cpu()
+    e3 = rel_l1(got3, want3)
+    print('mid-size rel-L1: two-view %.3e, 3-view %.3e' % (e2, e3))
+    assert e2 <= 1e-3 and e3 <= 1e-3
