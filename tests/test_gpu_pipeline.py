@@ -149,3 +149,22 @@ def test_midsize_pipelines(cuda, weights):
     e3 = rel_l1(got3, want3)
     print('mid-size rel-L1: two-view %.3e, 3-view %.3e' % (e2, e3))
     assert e2 <= 1e-3 and e3 <= 1e-3
+
+
+def test_midsize_against_float64_networks(cuda, weights):
+    """tests/golden/truth64_mid.npz (tests/golden/make_truth64_golden.py): the same two-view case with the
+    oracle's networks in float64.  With these weights float32 rounding alone moves the final depth by
+    ~1e-3 (31 batch-normalised layers + a peaked soft-argmin amplify it); the HIP path must be no further
+    from the float64 value than the float32 oracle is (x1.5 slack), and within 1e-3 of the float32 oracle."""
+    import os
+    import numpy as np
+    from atvsnet_amd.atvsnet import example as ex
+    gold = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'truth64_mid.npz'))
+    imgs, cams = _inputs(2, 256, 320, 64)
+    got = ex.infer_twoview(imgs.to(cuda), cams.to(cuda), 64).cpu()[0, ..., 0]
+    e64 = rel_l1(got, torch.from_numpy(gold['depth64']))
+    e32 = rel_l1(got, torch.from_numpy(gold['depth32']))
+    print('HIP vs float64 networks %.3e (float32 oracle: %.3e); HIP vs float32 oracle %.3e'
+          % (e64, float(gold['oracle32_rel_l1']), e32))
+    assert e64 <= 1.5 * float(gold['oracle32_rel_l1'])
+    assert e32 <= 1e-3
