@@ -131,6 +131,22 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
     int z0, y0, x0;
     tile_origin(k, &z0, &y0, &x0);
     const int cbase = ch * Cc;
+    // tiles whose halo lies inside the volume (the vast majority) skip every bounds test;
+    // element offsets fit 32 bits (the launcher refuses larger inputs)
+    const bool interior = FULL && z0 >= 1 && y0 >= 1 && x0 >= 1 && z0 + TILE_TZ < p.Di && y0 + TY < p.Hi && x0 + TXV < p.Wi;
+    if (interior) {
+      const float* org = p.x + (((size_t)(z0 - 1) * p.Hi + (y0 - 1)) * p.Wi + (x0 - 1)) * (size_t)p.Cin + cbase;
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        int s = tid + i * 256;
+        int c4 = s % C4, v = s / C4;
+        int xx = v % HX, v2 = v / HX;
+        int yy = v2 % HY, zz = v2 / HY;
+        unsigned off = (unsigned)(((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4);
+        if (s < SLOTS) pf[i] = ld4(org + off);
+      }
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       int s = tid + i * 256;
@@ -564,6 +580,7 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   }
   if (residual && y_coff != 0) return ATVS_ERR_ARG;
   if (plane_bias && (out_stride != 1 || D < 2)) return ATVS_ERR_ARG;
+  if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;   // 31-bit tile-relative element offsets
   if (xpair && (Cout != 8 || class_cout || out_stride != 1 || (ldy % 4) || (y_coff % 4) || ntaps != 36)) return ATVS_ERR_ARG;
   int nch, Ccp, Jc, NT;
   int rc = atvs_conv_tiled_pack_size(ntaps, Cin, xpair ? 16 : Cout, &nch, &Ccp, &Jc, &NT, nullptr, nullptr);
