@@ -131,37 +131,37 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
     int z0, y0, x0;
     tile_origin(k, &z0, &y0, &x0);
     const int cbase = ch * Cc;
-    // tiles whose halo lies inside the volume (the vast majority) skip every bounds test;
-    // element offsets fit 32 bits (the launcher refuses larger inputs)
+    // one uniform base pointer + 32-bit per-lane element offsets (the launcher refuses inputs of 2^31
+    // elements or more).  Tiles whose halo lies inside the volume skip every bounds test.
     const bool interior = FULL && z0 >= 1 && y0 >= 1 && x0 >= 1 && z0 + TILE_TZ < p.Di && y0 + TY < p.Hi && x0 + TXV < p.Wi;
+    const float* xb = p.x + cbase;
+    const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
     if (interior) {
-      const float* org = p.x + (((size_t)(z0 - 1) * p.Hi + (y0 - 1)) * p.Wi + (x0 - 1)) * (size_t)p.Cin + cbase;
+      const unsigned org = (unsigned)(((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin);
 #pragma unroll
       for (int i = 0; i < MAXS; ++i) {
         int s = tid + i * 256;
         int c4 = s % C4, v = s / C4;
         int xx = v % HX, v2 = v / HX;
         int yy = v2 % HY, zz = v2 / HY;
-        unsigned off = (unsigned)(((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4);
-        if (s < SLOTS) pf[i] = ld4(org + off);
+        unsigned off = org + (unsigned)(((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4);
+        if (s < SLOTS) pf[i] = ld4(xb + off);
       }
       return;
     }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       int s = tid + i * 256;
-      int c4 = s % C4;
-      int v = s / C4;
-      int xx = v % HX;
-      int v2 = v / HX;
-      int yy = v2 % HY;
-      int zz = v2 / HY;
-      int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      int c4 = s % C4, v = s / C4;
+      int xx = v % HX, v2 = v / HX;
+      int yy = v2 % HY, zz = v2 / HY;
+      int gz = gz0 + zz, gy = gy0 + yy, gx = gx0 + xx;
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
       bool ok = (s < SLOTS) && ((unsigned)gz < (unsigned)p.Di) && ((unsigned)gy < (unsigned)p.Hi) &&
                 ((unsigned)gx < (unsigned)p.Wi);
       if (ok) {
-        const float* src = p.x + (((size_t)gz * p.Hi + gy) * p.Wi + gx) * (size_t)p.Cin + cbase + c4 * 4;
+        unsigned off = (unsigned)(((gz * p.Hi + gy) * p.Wi + gx) * p.Cin + c4 * 4);
+        const float* src = xb + off;
         if (FULL) {
           val = ld4(src);
         } else {
@@ -206,16 +206,22 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
     __syncthreads();
     if (stage + 1 < nstage) prefetch(stage + 1);   // in flight during this stage's MFMAs
 
-    // ---- K steps of this chunk.  Weights (L2, long latency) are double-buffered one step ahead;
-    // the LDS operand of tile t is refreshed in place right after its last MFMA of the step, which
-    // leaves >= 7 MFMAs (224+ cycles) before it is consumed again.
+    // ---- K steps of this chunk.  Operands are software-pipelined by hand: the LDS fragments of step
+    // j+1 and the packed weights of step j+2 (L2, ~600+ cycles) are requested at the top of step j,
+    // so that neither latency sits between two MFMAs.  Indices past the end are clamped (harmless re-reads)
+    // to keep the body straight-line.
     const float4* wch = wp + ((size_t)ch * p.Jc * p.nt_total + nsi * NT) * 64;
     const int wstep = p.nt_total * 64;                                          // float4 per K step
-    float4 w_cur[NT], b_cur[TY];
+    const int jlast = p.Jc - 1;
+    float4 w_cur[NT], w_nx1[NT], b_cur[TY];
     {
       int off = s_tab[q];
+      const int j1 = min(1, jlast);
 #pragma unroll
-      for (int n = 0; n < NT; ++n) w_cur[n] = wch[n * 64 + lane];
+      for (int n = 0; n < NT; ++n) {
+        w_cur[n] = wch[n * 64 + lane];
+        w_nx1[n] = wch[(size_t)j1 * wstep + n * 64 + lane];
+      }
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
         int a = vbase[t] + off;
@@ -224,36 +230,31 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
       }
     }
     for (int j = 0; j < p.Jc; ++j) {
-      float4 w_nxt[NT];
-      const bool more = (j + 1 < p.Jc);
-      int off_n = 0;
-      if (more) {
-        off_n = s_tab[(j + 1) * 4 + q];
+      float4 w_nx2[NT], b_nxt[TY];
+      const int off_n = s_tab[min(j + 1, jlast) * 4 + q];
+      const int j2 = min(j + 2, jlast);
 #pragma unroll
-        for (int n = 0; n < NT; ++n) w_nxt[n] = wch[(size_t)(j + 1) * wstep + n * 64 + lane];
+      for (int n = 0; n < NT; ++n) w_nx2[n] = wch[(size_t)j2 * wstep + n * 64 + lane];
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        int a = vbase[t] + off_n;
+        if (SWZ) a = lds_swz(a);
+        b_nxt[t] = *reinterpret_cast<const float4*>(lds + a);
       }
 #pragma unroll
-      for (int s = 0; s < 3; ++s)
+      for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int n = 0; n < NT; ++n)
 #pragma unroll
           for (int t = 0; t < TY; ++t)
             acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < TY; ++t) {
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-          acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(w_cur[n].w, b_cur[t].w, acc[t][n], 0, 0, 0);
-        if (more) {
-          int a = vbase[t] + off_n;
-          if (SWZ) a = lds_swz(a);
-          b_cur[t] = *reinterpret_cast<const float4*>(lds + a);
-        }
+      for (int n = 0; n < NT; ++n) {
+        w_cur[n] = w_nx1[n];
+        w_nx1[n] = w_nx2[n];
       }
-      if (more) {
 #pragma unroll
-        for (int n = 0; n < NT; ++n) w_cur[n] = w_nxt[n];
-      }
+      for (int t = 0; t < TY; ++t) b_cur[t] = b_nxt[t];
     }
     if (ch != p.nchunk - 1) continue;
 
