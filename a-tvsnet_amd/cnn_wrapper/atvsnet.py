@@ -156,8 +156,11 @@ class CostVolRefineNet(Network):
         f = 8
         g = 'global_refine_'
         stems = []
-        for src, tag in (('photo_group', 'photo'), ('geo_group', 'geo'), ('prob_vol', 'prob'), ('vis_hull', 'vishull')):
-            self.feed(src).conv_bn(3, f, 1, name=g + tag + '_3dconv')
+        # the four stems write straight into their 8-channel slice of the 32-channel concat
+        self.concat_buffer(g + 'concat', self.layers['prob_vol'], 4 * f)
+        for i, (src, tag) in enumerate((('photo_group', 'photo'), ('geo_group', 'geo'), ('prob_vol', 'prob'),
+                                        ('vis_hull', 'vishull'))):
+            self.feed(src).conv_bn(3, f, 1, name=g + tag + '_3dconv', out_slice=(g + 'concat', i * f))
             stems.append(g + tag + '_3dconv')
         (self.feed(*stems)
              .concat(axis=-1, name=g + 'concat')

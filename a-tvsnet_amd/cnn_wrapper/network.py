@@ -52,7 +52,8 @@ def _b1(x, what):
         x = x.materialize()
     if x.shape[0] != 1:
         raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d' % (what, x.shape[0]))
-    return x[0]
+    x = x[0]
+    return x if x.is_contiguous() else x.contiguous()      # e.g. a concat-buffer slice consumed on its own
 
 
 class Network(object):
@@ -143,13 +144,25 @@ class Network(object):
     def _vec(self, name, n, like):
         return self.store.get(name, (n,), like.device)
 
-    def _bn(self, y, st, scope, center, relu):
-        """tf.layers.batch_normalization(center, scale=False, training=self.training) [+ relu]."""
-        C = y.shape[-1]
-        beta = self._vec('%s/batch_normalization/beta' % scope, C, y) if center else None
+    def _bn(self, y, st, scope, center, relu, C=None, c_off=0):
+        """tf.layers.batch_normalization(center, scale=False, training=self.training) [+ relu].
+        C / c_off: y is a wider concat buffer and only that channel slice is this layer's output."""
+        Cn = y.shape[-1] if C is None else C
+        beta = self._vec('%s/batch_normalization/beta' % scope, Cn, y) if center else None
         if self.training:
-            return ops.batch_norm(y, st, beta=beta, relu=relu, inplace=True, eps=BN_EPS)
+            return ops.batch_norm(y, st, beta=beta, relu=relu, inplace=True, eps=BN_EPS, C=C, c_off=c_off)
+        if C is not None:
+            raise NotImplementedError('moving-average batch norm into a concat slice')
         return self._bn_inference(y, '%s/batch_normalization' % scope, beta, relu)
+
+    def concat_buffer(self, name, like, channels):
+        """Pre-allocate the output of a later `concat(name=...)` so that the layers feeding it can write their
+        channel slice directly (conv_bn(..., out_slice=(name, c_off))) instead of being copied."""
+        shape = tuple(like.shape[:-1]) + (channels,)
+        buf = torch.empty(shape, dtype=torch.float32, device=like.device)
+        self._concat_bufs = getattr(self, '_concat_bufs', {})
+        self._concat_bufs[name] = buf
+        return buf
 
     def _bn_inference(self, y, scope, beta, relu):
         """Moving-average BN (never used by the reference's inference code, which passes is_training=True)."""
@@ -183,18 +196,22 @@ class Network(object):
 
     @layer
     def conv_bn(self, input, kernel_size, filters, strides, name, relu=True, center=False, padding=DEFAULT_PADDING,
-                biased=False, rate=1):
+                biased=False, rate=1, out_slice=None):
         '''conv (no activation) -> batch norm with batch statistics -> relu (reference network.py:172-215):
         variables name/conv{2,3}d/kernel.  The statistics come from the convolution's epilogue.'''
         rank = input.dim()
         if rank not in (4, 5):
             raise ValueError('Improper input rank for layer: ' + name)
+        buf, c_off = None, 0
+        if out_slice is not None:          # extension: write into a channel slice of a pre-allocated concat buffer
+            buf, c_off = self._concat_bufs[out_slice[0]][0], int(out_slice[1])
         if isinstance(input, ops.SplitVolume):
             if kernel_size == 3 and rate == 1 and padding == 'SAME' and not biased and self.training:
                 vname = '%s/conv3d/kernel' % name
                 w = self._kernel(vname, (3, 3, 3, input.shape[-1], filters))
-                y, st = ops.conv_split(input, vname, w, stride=strides, want_stats=True)
-                return self._bn(y, st, name, center, relu).unsqueeze(0)
+                y, st = ops.conv_split(input, vname, w, stride=strides, want_stats=True, out=buf, y_coff=c_off)
+                return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None),
+                                                c_off=c_off), out_slice, filters)
             input = input.materialize()
         x = _b1(input, name)
         cin = x.shape[-1]
@@ -203,10 +220,22 @@ class Network(object):
         w = self._kernel(vname, (kernel_size,) * (rank - 2) + (cin, filters))
         bias = self._vec('%s/%s/bias' % (name, kind), filters, x) if biased else None
         if self.training:
-            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True)
+            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
+                             out=buf, y_coff=c_off)
         else:
-            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias), None
-        return self._bn(y, st, name, center, relu).unsqueeze(0)
+            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, out=buf,
+                             y_coff=c_off), None
+        return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None), c_off=c_off),
+                               out_slice, filters)
+
+    def _slice_out(self, y, out_slice, filters):
+        """Layer result: the dense tensor, or (for out_slice) a view of the concat buffer tagged for concat()."""
+        if out_slice is None:
+            return y.unsqueeze(0)
+        full = self._concat_bufs[out_slice[0]]
+        view = full[..., int(out_slice[1]):int(out_slice[1]) + filters]
+        view._atvs_slice = (out_slice[0], int(out_slice[1]))
+        return view
 
     @layer
     def deconv_bn(self, input, kernel_size, filters, strides, name, relu=True, center=False, padding=DEFAULT_PADDING,
@@ -306,6 +335,17 @@ class Network(object):
         '''tf.concat (reference network.py:691-693); channel axis only.'''
         if axis not in (-1, inputs[0].dim() - 1):
             raise NotImplementedError('concat: only the channel axis is built')
+        # inputs already written into their slices of a pre-allocated buffer (concat_buffer): nothing to copy
+        tags = [getattr(t, '_atvs_slice', None) for t in inputs]
+        if all(tg is not None and tg[0] == name for tg in tags):
+            off = 0
+            ok = True
+            for t, tg in zip(inputs, tags):
+                ok = ok and tg[1] == off
+                off += t.shape[-1]
+            buf = self._concat_bufs[name]
+            if ok and off == buf.shape[-1]:
+                return buf
         return ops.concat_channels([_b1(t, name) for t in inputs]).unsqueeze(0)
 
     @layer

@@ -104,14 +104,16 @@ extern "C" int atvs_channel_stats(const float* x, long rows, int C, double* stat
   return ATVS_OK;
 }
 
+// rows of width ld; the C channels starting at c_off are normalised (a channel slice of a concat buffer)
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ params,
-                                                       float* __restrict__ y, long n, int C, int relu) {
+                                                       float* __restrict__ y, long n, int C, int ld, int c_off, int relu) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (i >= n) return;
   int c = (int)(i % C);
+  long a = (ld == C) ? i : (i / C) * ld + c_off + c;
   if (VEC == 4) {
-    float4 v = ld4(x + i), m = ld4(params + c), s = ld4(params + C + c), b = ld4(params + 2 * C + c);
+    float4 v = ld4(x + a), m = ld4(params + c), s = ld4(params + C + c), b = ld4(params + 2 * C + c);
     v.x = (v.x - m.x) * s.x + b.x;
     v.y = (v.y - m.y) * s.y + b.y;
     v.z = (v.z - m.z) * s.z + b.z;
@@ -119,22 +121,22 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     if (relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
-    st4(y + i, v);
+    st4(y + a, v);
   } else {
-    float v = (x[i] - params[c]) * params[C + c] + params[2 * C + c];
-    y[i] = relu ? fmaxf(v, 0.f) : v;
+    float v = (x[a] - params[c]) * params[C + c] + params[2 * C + c];
+    y[a] = relu ? fmaxf(v, 0.f) : v;
   }
 }
 
-extern "C" int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int relu,
-                             atvs_stream_t stream) {
+extern "C" int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int ld, int c_off,
+                             int relu, atvs_stream_t stream) {
   if (!x || !params || !y) return ATVS_ERR_NULL;
-  if (rows <= 0 || C <= 0) return ATVS_ERR_SHAPE;
+  if (rows <= 0 || C <= 0 || ld < C || c_off < 0 || c_off + C > ld) return ATVS_ERR_SHAPE;
   long n = rows * C;
-  if (C % 4 == 0)
-    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, relu);
+  if (C % 4 == 0 && ld % 4 == 0 && c_off % 4 == 0)
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, ld, c_off, relu);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, ld, c_off, relu);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -609,13 +609,13 @@ def _fold_split_weights(key, w_host, chan_map, cv, cc):
     return hit
 
 
-def conv_split(sv, key, w_host, stride=1, want_stats=False):
+def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
     """3x3x3 SAME convolution of a SplitVolume: conv3d over the D-varying channels plus the 2-D convolution
     of the D-constant channels (kd-summed kernel) added per depth plane in the epilogue."""
     cv, cc = sv.var.shape[-1], sv.const.shape[-1]
     wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
     pb = conv(sv.const, (key, 'planes'), planes, stride=stride)            # (ho, wo, 3*Cout)
-    return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb)
+    return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb, out=out, y_coff=y_coff)
 
 
 _DECONV_OFFSETS = [(a, b, c) for a in (0, -1) for b in (0, -1) for c in (0, -1)]
@@ -719,19 +719,27 @@ def bn_params(st, C, ref, beta=None, eps=1e-3):
     return params
 
 
-def bn_apply(x, params, relu=False, out=None):
-    C = x.shape[-1]
+def bn_apply(x, params, relu=False, out=None, C=None, c_off=0):
+    """y = relu((x - mean) * rstd + beta).  With C / c_off: only that channel slice of the rows of x (in place)."""
+    ld = x.shape[-1]
+    C = ld if C is None else C
     y = x if out is None else out
     if _dev_ok(x, params, y):
-        _call('atvs_bn_apply', _p(x), _p(params), _p(y), ctypes.c_long(x.numel() // C), C, int(bool(relu)), _stream())
+        _call('atvs_bn_apply', _p(x), _p(params), _p(y), ctypes.c_long(x.numel() // ld), int(C), int(ld), int(c_off),
+              int(bool(relu)), _stream())
     return y
 
 
-def batch_norm(x, st=None, beta=None, relu=False, inplace=False, eps=1e-3):
-    """Training-mode BN of x with its own batch statistics (st = Stats from the producer, else computed)."""
+def batch_norm(x, st=None, beta=None, relu=False, inplace=False, eps=1e-3, C=None, c_off=0):
+    """Training-mode BN of x with its own batch statistics (st = Stats from the producer, else computed).
+    C / c_off select a channel slice of a wider buffer (statistics must then come from the producer)."""
     if st is None:
+        if C is not None:
+            raise ValueError('batch_norm on a channel slice needs the producer\'s statistics')
         st = channel_stats(x)
-    params = bn_params(st, x.shape[-1], x, beta, eps)
+    params = bn_params(st, x.shape[-1] if C is None else C, x, beta, eps)
+    if C is not None:
+        return bn_apply(x, params, relu, C=C, c_off=c_off)
     return bn_apply(x, params, relu, out=(x if inplace else _new(x, x.shape)))
 
 

@@ -218,9 +218,10 @@ int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, int
 long atvs_channel_stats_num_blocks(long rows);
 int atvs_channel_stats(const float* x, long rows, int C, double* stats_partial, atvs_stream_t stream);
 
-/* y = (x - mean) * rstd + beta [, relu]; y may alias x. */
-int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int relu,
-                  atvs_stream_t stream);
+/* y = (x - mean) * rstd + beta [, relu]; y may alias x.  x and y are rows of width ld of which the C
+ * channels starting at c_off are touched (ld = C, c_off = 0 for a dense tensor). */
+int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int ld, int c_off,
+                  int relu, atvs_stream_t stream);
 
 /* tf.add_n of two or three tensors (c may be NULL), network.py:695-697. */
 int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream);
