@@ -149,6 +149,12 @@ class Network(object):
         C / c_off: y is a wider concat buffer and only that channel slice is this layer's output."""
         Cn = y.shape[-1] if C is None else C
         beta = self._vec('%s/batch_normalization/beta' % scope, Cn, y) if center else None
+        if self.training and C is not None:
+            # slice of a concat buffer: only the moments now; one dense normalisation pass over the whole
+            # buffer happens in concat() (a strided pass per slice would touch 32-byte fragments of each row)
+            self._pending_bn = getattr(self, '_pending_bn', {})
+            self._pending_bn.setdefault(id(y), []).append((c_off, C, ops.bn_params(st, C, y, beta, BN_EPS), relu))
+            return y
         if self.training:
             return ops.batch_norm(y, st, beta=beta, relu=relu, inplace=True, eps=BN_EPS, C=C, c_off=c_off)
         if C is not None:
@@ -162,7 +168,12 @@ class Network(object):
         buf = torch.empty(shape, dtype=torch.float32, device=like.device)
         self._concat_bufs = getattr(self, '_concat_bufs', {})
         self._concat_bufs[name] = buf
+        self._concat_views = getattr(self, '_concat_views', {})
+        self._concat_views[name] = buf[0]        # the 4-D view handed to the kernels (stable identity)
         return buf
+
+    def _buf_id(self, name):
+        return id(self._concat_views[name])
 
     def _bn_inference(self, y, scope, beta, relu):
         """Moving-average BN (never used by the reference's inference code, which passes is_training=True)."""
@@ -204,7 +215,7 @@ class Network(object):
             raise ValueError('Improper input rank for layer: ' + name)
         buf, c_off = None, 0
         if out_slice is not None:          # extension: write into a channel slice of a pre-allocated concat buffer
-            buf, c_off = self._concat_bufs[out_slice[0]][0], int(out_slice[1])
+            buf, c_off = self._concat_views[out_slice[0]], int(out_slice[1])
         if isinstance(input, ops.SplitVolume):
             if kernel_size == 3 and rate == 1 and padding == 'SAME' and not biased and self.training:
                 vname = '%s/conv3d/kernel' % name
@@ -345,6 +356,15 @@ class Network(object):
                 off += t.shape[-1]
             buf = self._concat_bufs[name]
             if ok and off == buf.shape[-1]:
+                pend = getattr(self, '_pending_bn', {}).pop(self._buf_id(name), [])
+                if pend:
+                    params = torch.empty((3, off), dtype=torch.float32, device=buf.device)
+                    relus = set()
+                    for c_off, C, p, relu in pend:
+                        ops.copy_channels(p, params, C, 0, c_off)
+                        relus.add(bool(relu))
+                    assert len(relus) == 1 and sum(pc[1] for pc in pend) == off
+                    ops.bn_apply(buf[0], params, relus.pop())
                 return buf
         return ops.concat_channels([_b1(t, name) for t in inputs]).unsqueeze(0)
 
