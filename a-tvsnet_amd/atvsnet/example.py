@@ -33,7 +33,7 @@ from ..tools.common import Notify
 from ..tools import xlsx
 from .eval_errors import acc_metrics_namelist, calc_error, err_metrics_namelist
 from .model import (TVSNet, TVSNet_base_siamese, TVSNet_feature_extraction, TVSNet_refine,           # noqa: F401
-                    build_cost_volume, cost_volume_reasoning, cost_volume_aggregation, cost_volume_aggregation_refine, extract_feature_shallow, output_conv,
+                    cost_volume_aggregation, cost_volume_aggregation_refine, extract_feature_shallow, output_conv,
                     output_conv_refine, prob2depth, prob2depth_upsample)
 from ..cnn_wrapper.atvsnet import ResNetDS2SPP_shallow_f16
 
@@ -102,28 +102,15 @@ def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True):
     n = images.shape[1]
     assert n > 2
     depth_start, depth_interval = depth_range(cams)
-    vs = _ViewStreams(2 * (n - 1), images.device, view_streams)
-    # feature towers: the reference image on the caller's stream, every source image on its own
-    view_features = [vs.run(v - 1, lambda v=v: TVSNet_feature_extraction(images, v)) for v in range(1, n)]
+    vs = _ViewStreams(n - 1, images.device, view_streams)
     ref_feature = TVSNet_feature_extraction(images, 0)
-    vs.join(view_features)
-
-    # base stage = TVSNet_base_siamese (reference model.py:398-417) per source, its two directions being
-    # independent once the towers exist: 2(N-1) concurrent cost-volume + stacked-U-Net passes
-    def forward(v):
-        cost_vol = build_cost_volume(ref_feature, view_features[v - 1], cams, max_d, depth_start, depth_interval,
-                                     ref_id=0, view_id=v, lazy=True)
-        _prob_b2, filtered = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
-        return filtered             # prob volumes are fed but unused by the reference (quirk C12)
-
-    def reverse(v):                 # quirk C11: sweeps the reference camera's depth range
-        cost_vol = build_cost_volume(view_features[v - 1], ref_feature, cams, max_d, depth_start, depth_interval,
-                                     ref_id=v, view_id=0, lazy=True)
-        return prob2depth(cost_volume_reasoning(cost_vol, output_filtered_cost=False), max_d, depth_start,
-                          depth_interval)
-    filtered_cost_volumes = [vs.run(2 * (v - 1), lambda v=v: forward(v)) for v in range(1, n)]
-    depth_views = [vs.run(2 * (v - 1) + 1, lambda v=v: reverse(v)) for v in range(1, n)]
-    vs.join([filtered_cost_volumes, depth_views])
+    base = [vs.run(v - 1, lambda v=v: TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval, view_i=v,
+                                                          ref_i=0, ref_feature=ref_feature))
+            for v in range(1, n)]
+    vs.join(base)
+    filtered_cost_volumes = [b[2] for b in base]    # prob volumes are fed but unused by the reference (quirk C12)
+    depth_views = [b[3] for b in base]
+    del base
     # AAM1
     cost_volume_agg = cost_volume_aggregation(filtered_cost_volumes, reuse=False, keepchannel=True)
     prob_volume_agg = output_conv(cost_volume_agg, reuse=False)
