@@ -3,8 +3,9 @@
 One process per GPU (torch.distributed, backend "nccl" = RCCL over xGMI).  The base stage
 (towers, warp, 2x U-Net, soft-argmin) and the refinement stage are independent per source
 view (reference example.py:144-149, 163-172): view v runs on rank (v-1) mod G with
-replicated weights and reference features; training-mode BN statistics are per view call,
-so no BN collective exists.  The only exchange is inside the two AANet modules
+replicated weights and reference features (with >= 2 ranks per source the two siamese directions of a
+pair split over two ranks, see plan()); training-mode BN statistics are per view call, so no BN
+collective exists.  The only exchange is inside the two AANet modules
 (reference network.py:282-351, 378-408), split at their three reductions over views:
 
     S_sum  = all_reduce_SUM( sum_local S_n )
@@ -70,8 +71,29 @@ def sharded_attention(local_xs, scope, like, impl=None, group=None):
 
 
 def local_views(num_views, rank, world):
-    """Source views (1..N-1) owned by `rank`: round-robin."""
-    return [v for v in range(1, num_views) if (v - 1) % world == rank]
+    """Source views (1..N-1) whose refinement (and forward direction) `rank` owns."""
+    return [v for (kind, v) in plan(num_views, world)[rank] if kind == 'fwd']
+
+
+def plan(num_views, world):
+    """Work of every rank: a list of ('fwd', v) / ('rev', v) tasks per rank.
+
+    'fwd' = reference->source direction of the base stage (filtered cost volume) AND the later refinement
+    of source v; 'rev' = source->reference direction (depth_view only).  With at least two ranks per source
+    the two directions of a pair run on different ranks (the (h,w) depth_view map travels in one tiny
+    all-reduce); otherwise sources are dealt round-robin with both directions on the owner.
+    """
+    nsrc = num_views - 1
+    tasks = [[] for _ in range(world)]
+    if world >= 2 * nsrc:
+        for v in range(1, num_views):
+            tasks[2 * (v - 1)].append(('fwd', v))
+            tasks[2 * (v - 1) + 1].append(('rev', v))
+    else:
+        g = min(world, nsrc)
+        for v in range(1, num_views):
+            tasks[(v - 1) % g] += [('fwd', v), ('rev', v)]
+    return tasks
 
 
 def infer_multiview_sharded(images, cams, max_d=None, group=None):
@@ -84,31 +106,50 @@ def infer_multiview_sharded(images, cams, max_d=None, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     n = images.shape[1]
-    mine = local_views(n, rank, world)
+    mine = plan(n, world)[rank]
+    fwd = [v for kind, v in mine if kind == 'fwd']
+    rev = [v for kind, v in mine if kind == 'rev']
     depth_start, depth_interval = ex.depth_range(cams)
-    ref_feature = model.TVSNet_feature_extraction(images, 0)
-    h, w = ref_feature.shape[1:3]
-    like = torch.empty((max_d, h, w, 8), dtype=torch.float32, device=images.device) if not mine else None
-    filtered, depth_views = [], []
-    for v in mine:
-        _, _, f, dv = model.TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval, view_i=v, ref_i=0,
-                                                ref_feature=ref_feature)
+    dev = images.device
+    h, w = images.shape[2] // 4, images.shape[3] // 4
+    ref_feature = model.TVSNet_feature_extraction(images, 0) if mine else None
+    feats = {v: model.TVSNet_feature_extraction(images, v) for v in sorted(set(fwd + rev))}
+
+    # ---- base stage (reference model.py:398-417), one direction per task
+    filtered = []
+    for v in fwd:
+        cv = model.build_cost_volume(ref_feature, feats[v], cams, max_d, depth_start, depth_interval, ref_id=0, view_id=v,
+                                     lazy=True)
+        _, f = model.cost_volume_reasoning(cv, output_filtered_cost=True)
         filtered.append(f[0])
-        depth_views.append(dv)
-    cost_agg = sharded_attention(filtered, 'attention_aggregate', filtered[0] if mine else like, group=group)
-    cost_agg = cost_agg.unsqueeze(0)
+    dv_all = torch.zeros((n - 1, h, w), dtype=torch.float32, device=dev)
+    for v in rev:      # quirk C11: sweeps the reference camera's depth range
+        cv = model.build_cost_volume(feats[v], ref_feature, cams, max_d, depth_start, depth_interval, ref_id=v, view_id=0,
+                                     lazy=True)
+        dv = model.prob2depth(model.cost_volume_reasoning(cv, output_filtered_cost=False), max_d, depth_start,
+                              depth_interval)
+        dv_all[v - 1].copy_(dv.reshape(h, w))
+    dist.all_reduce(dv_all, op=dist.ReduceOp.SUM, group=group)       # every view has exactly one contributor
+
+    # ---- AAM1 across ranks
+    like = torch.empty((max_d, h, w, 8), dtype=torch.float32, device=dev) if not filtered else filtered[0]
+    cost_agg = sharded_attention(filtered, 'attention_aggregate', like, group=group).unsqueeze(0)
     prob_agg = model.output_conv(cost_agg, reuse=False)
     depth_init = model.prob2depth(prob_agg, max_d, depth_start, depth_interval)
     del filtered
+
+    # ---- refinement of the owned sources
     refined = []
-    if mine:
+    if fwd:
         ref_shallow = ResNetDS2SPP_shallow_f16({'data': images[:, 0]}, is_training=True).get_output()
-    for i, v in enumerate(mine):
+    for v in fwd:
         shallow = model.extract_feature_shallow(images, 0, v, ref_feature=ref_shallow)
-        _, rc = model.TVSNet_refine(depth_init, depth_views[i], prob_agg, cost_agg, images, cams, max_d, depth_start,
-                                    depth_interval, view_i=v, ref_i=0, shallow_features=shallow)
+        _, rc = model.TVSNet_refine(depth_init, dv_all[v - 1].reshape(1, h, w, 1), prob_agg, cost_agg, images, cams,
+                                    max_d, depth_start, depth_interval, view_i=v, ref_i=0, shallow_features=shallow)
         refined.append(rc[0])
-    rcost_agg = sharded_attention(refined, 'attention_aggregate_refine', refined[0] if mine else like, group=group)
+
+    # ---- AAM2 across ranks, head, x4 upsample + soft-argmin (replicated)
+    rcost_agg = sharded_attention(refined, 'attention_aggregate_refine', like, group=group)
     rprob_agg = model.output_conv_refine(rcost_agg.unsqueeze(0), reuse=False)
     _, depth_refined = model.prob2depth_upsample(rprob_agg, max_d, depth_start, depth_interval)
     return depth_refined

@@ -82,8 +82,15 @@ def test_sharded_attention_equals_single_process(weights, nviews):
 
 def test_view_partition():
     from atvsnet_amd import parallel
-    for n, world in ((5, 1), (5, 2), (5, 4), (5, 8), (9, 8), (3, 2)):
+    for n, world in ((5, 1), (5, 2), (5, 4), (5, 8), (9, 8), (3, 2), (3, 8), (5, 6)):
+        tasks = parallel.plan(n, world)
+        assert len(tasks) == world
+        for kind in ('fwd', 'rev'):                           # every direction of every source exactly once
+            assert sorted(v for t in tasks for (k, v) in t if k == kind) == list(range(1, n))
         owned = [parallel.local_views(n, r, world) for r in range(world)]
-        flat = sorted(v for o in owned for v in o)
-        assert flat == list(range(1, n))                     # every source view exactly once
-        assert max(len(o) for o in owned) - min(len(o) for o in owned) <= 1
+        assert sorted(v for o in owned for v in o) == list(range(1, n))
+        if world >= 2 * (n - 1):                              # directions of a pair on two ranks
+            assert all(len(t) <= 1 for t in tasks)
+        else:
+            busy = [len(o) for o in owned if o]
+            assert max(busy) - min(busy) <= 1
