@@ -54,6 +54,16 @@ struct TiledArgs {
   // N-split: the 16-channel MFMA tiles of the output are dealt to `nsplit` workgroups per spatial tile
   // (more workgroups for small volumes); nt_total = tiles in the packed weights, this kernel's NT = nt_total / nsplit
   int nsplit, nt_total;
+  // batch-norm moments finished in-launch by the last workgroup to arrive (no separate finalize launch):
+  // fin_counter = one zero-initialised device word (left at zero again), fin_params = (3, fin_c) floats
+  // (mean, rstd, 0), fin_rows = rows of `stats` to reduce (all launches of the layer), fin_arrivals =
+  // workgroups of all those launches, fin_fold = columns per channel, fin_count = elements per channel.
+  unsigned* fin_counter;
+  float* fin_params;
+  int fin_rows, fin_arrivals, fin_c, fin_fold;
+  double fin_count;
+  float fin_eps;
+  double* fin_stats;     // first row of the layer's statistics buffer
 };
 
 __device__ __forceinline__ int lds_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
@@ -402,6 +412,54 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
       // row of width nt_total*16; with N-split the other columns are zero (caller zero-fills the buffer)
       p.stats[((size_t)blockIdx.x * 2 + which) * (p.nt_total * 16) + nsi * NT * 16 + c] = v;
     }
+    if (p.fin_counter) {
+      // ---- last-arriver finalize (agent-scope release / acquire around one atomic ticket)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      int* s_flag = reinterpret_cast<int*>(smem + 4 * 2 * NT * 16 * sizeof(double));
+      if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned prev = __hip_atomic_fetch_add(p.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int last = (prev == (unsigned)(p.fin_arrivals - 1)) ? 1 : 0;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        *s_flag = last;
+      }
+      __syncthreads();
+      if (*s_flag) {
+        const int C = p.fin_c, cpad = p.nt_total * 16;
+        const int pairs = 2 * C;                 // (which, channel)
+        const int lanes = 256 / pairs;           // row lanes per pair (C <= 64 -> >= 2)
+        double* red = reinterpret_cast<double*>(smem);
+        double a = 0.0;
+        if (tid < lanes * pairs) {
+          const int pc = tid % pairs, rl = tid / pairs;
+          const int which = pc / C, c = pc % C;
+          for (int r = rl; r < p.fin_rows; r += lanes)
+            for (int f = 0; f < p.fin_fold; ++f) a += p.fin_stats[((size_t)r * 2 + which) * cpad + c + f * C];
+        }
+        __syncthreads();
+        red[tid] = a;
+        __syncthreads();
+        if (tid < C) {
+          double sm = 0.0, sq = 0.0;
+          for (int l = 0; l < lanes; ++l) {
+            sm += red[l * pairs + tid];
+            sq += red[l * pairs + C + tid];
+          }
+          double mean = sm / p.fin_count;
+          double var = sq / p.fin_count - mean * mean;
+          if (var < 0.0) var = 0.0;
+          p.fin_params[tid] = (float)mean;
+          p.fin_params[C + tid] = (float)(1.0 / sqrt(var + (double)p.fin_eps));
+          p.fin_params[2 * C + tid] = 0.f;
+        }
+        if (tid == 0) __hip_atomic_store(p.fin_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -530,7 +588,8 @@ extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int
 template <int NT, int TY, int C4, bool FULL, bool XP = false>
 static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
   size_t lds = (size_t)(TILE_TZ + 2) * (TY + 2) * ((XP ? 2 : 1) * TILE_TX + 2) * C4 * 16 + (size_t)a.Jc * 4 * sizeof(int);
-  size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double);
+  size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double) + 16;
+  if (red < 256 * sizeof(double)) red = 256 * sizeof(double);
   if (lds < red) lds = red;
   static bool attr_set = false;
   if (!attr_set) {
@@ -566,7 +625,9 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
                                    const float* residual, const float* plane_bias, float* y, double* stats_partial,
                                    int D, int H, int W, int Cin, int Dy, int Hy, int Wy, int out_stride, int off_z,
                                    int off_y, int off_x, int ldy, int y_coff, int Cout, int ntaps, int tile_y, int relu,
-                                   int class_cout, int class_base, int xpair, atvs_stream_t stream) {
+                                   int class_cout, int class_base, int xpair, uint32_t* fin_counter, float* fin_params,
+                                   double* fin_stats, int fin_rows, int fin_arrivals, int fin_channels, int fin_fold,
+                                   long fin_count, float fin_eps, atvs_stream_t stream) {
   if (!x || !packed_w || !table || !y) return ATVS_ERR_NULL;
   if (D <= 0 || H <= 0 || W <= 0 || out_stride <= 0) return ATVS_ERR_SHAPE;
   if (class_cout) {
@@ -598,6 +659,12 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
   a.pbias = plane_bias;
   a.cls_cout = class_cout; a.cls_base = class_base;
+  a.fin_counter = fin_counter; a.fin_params = fin_params; a.fin_stats = fin_stats; a.fin_rows = fin_rows;
+  a.fin_arrivals = fin_arrivals; a.fin_c = fin_channels; a.fin_fold = fin_fold; a.fin_count = (double)fin_count;
+  a.fin_eps = fin_eps;
+  if (fin_counter && (!stats_partial || !fin_params || !fin_stats || fin_rows <= 0 || fin_arrivals <= 0 ||
+                      fin_channels <= 0 || fin_channels > 64 || fin_fold < 1 || fin_count <= 0))
+    return ATVS_ERR_ARG;
   const int C4 = Ccp / 4;
   const bool full = (Cin % Ccp == 0);
   int ns = 1;

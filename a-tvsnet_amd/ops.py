@@ -316,8 +316,34 @@ def force_conv_impl(impl):
     _FORCE_IMPL = impl
 
 
+_fin_pool = {}
+_FUSED_FINALIZE = True
+
+
+def fused_finalize(flag):
+    """Testing / A-B hook: finish the batch-norm moments inside the convolution launch."""
+    global _FUSED_FINALIZE
+    _FUSED_FINALIZE = bool(flag)
+
+
+def _fin_counter(device):
+    """A zero device word for one layer's arrival ticket (the kernel leaves it at zero again)."""
+    key = str(device)
+    ent = _fin_pool.get(key)
+    if ent is None:
+        ent = [torch.zeros(8192, dtype=torch.int32, device=device), 0]
+        _fin_pool[key] = ent
+    ent[1] = (ent[1] + 1) % 8192
+    return ent[0][ent[1]:ent[1] + 1]
+
+
+class Fin(object):
+    """In-launch finalize request for one layer (all its launches share it)."""
+    __slots__ = ('counter', 'params', 'stats', 'rows', 'arrivals', 'channels', 'fold', 'count')
+
+
 def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None, residual=None, relu=False,
-                      stats_buf=None, plane_bias=None, class_cout=0, class_base=0, xpair=False):
+                      stats_buf=None, plane_bias=None, class_cout=0, class_base=0, xpair=False, fin=None):
     """One atvs_conv_tiled_f32 launch: logical output grid = input grid of x4 (D,H,W,Cin)."""
     D, H, W, Cin = x4.shape
     Dy, Hy, Wy, ldy = y.shape
@@ -330,7 +356,13 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
               _p(plane_bias), _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
               Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
               8 if xpair else pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), int(class_cout), int(class_base),
-              int(bool(xpair)), _stream())
+              int(bool(xpair)),
+              ctypes.c_void_p(fin.counter.data_ptr()) if fin is not None else ctypes.c_void_p(0),
+              _p(fin.params) if fin is not None else ctypes.c_void_p(0),
+              ctypes.c_void_p(fin.stats.data_ptr()) if fin is not None else ctypes.c_void_p(0),
+              fin.rows if fin is not None else 0, fin.arrivals if fin is not None else 0,
+              fin.channels if fin is not None else 0, fin.fold if fin is not None else 0,
+              ctypes.c_long(fin.count if fin is not None else 0), ctypes.c_float(1e-3), _stream())
         if timed:
             e1.record()
             _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
@@ -397,10 +429,11 @@ def _pick_tile_m(M, ntiles):
 
 class Stats(object):
     """Per-workgroup partial sums of a tensor: feeds bn_finalize."""
-    __slots__ = ('partial', 'blocks', 'cpad', 'count', 'fold')
+    __slots__ = ('partial', 'blocks', 'cpad', 'count', 'fold', 'params')
 
     def __init__(self):
         self.fold = 1
+        self.params = None      # (3,C) moments already finished inside the producing launch
 
 
 def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bias=None, residual=None, relu=False,
@@ -529,7 +562,14 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
         raise ValueError('conv %s: plane_bias %s, expected %s' % (key, tuple(plane_bias.shape), (outs[1], outs[2], 3 * pk.cout)))
     if tile_y:
-        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf, plane_bias, xpair=xpair)
+        fin = None
+        if want_stats and _FUSED_FINALIZE and pk.cout <= 64 and not x.is_meta:
+            fin = Fin()
+            fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, pk.cout)), sbuf
+            fin.rows, fin.arrivals, fin.channels, fin.fold, fin.count = blocks, blocks, pk.cout, 1, M
+            st.params = fin.params
+        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf, plane_bias, xpair=xpair,
+                          fin=fin)
     else:
         conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm, plane_bias, pads[0])
     y = out if out is not None else (y4 if nsp == 3 else y4.reshape(tuple(y4.shape[1:])))
@@ -673,11 +713,17 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
             sbuf = _stats_buffer(x, blocks * nl, nt * 16, tiled_nsplit(D, H, W, tile_y, Cin, per * cout) > 1)
             st = Stats()
             st.partial, st.blocks, st.cpad, st.count, st.fold = sbuf, blocks * nl, nt * 16, 8 * M, per
+        fin = None
+        if st is not None and _FUSED_FINALIZE and cout <= 64 and not x.is_meta:
+            fin = Fin()
+            fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, cout)), sbuf
+            fin.rows, fin.arrivals, fin.channels, fin.fold, fin.count = blocks * nl, blocks * nl, cout, per, 8 * M
+            st.params = fin.params
         for i in range(nl):
             wpart = wv[:, :, i * per * cout:(i + 1) * per * cout]
             pk = pack_conv_weights_tiled((key, 'cls', i), wpart, taps, False, x.device, tile_y)
             sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
-            conv_tiled_launch(x, pk, y, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per)
+            conv_tiled_launch(x, pk, y, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per, fin=fin)
         if want_stats and not in_kernel:
             st = channel_stats(y)
         return (y, st) if want_stats else y
@@ -712,6 +758,8 @@ def channel_stats(x):
 
 def bn_params(st, C, ref, beta=None, eps=1e-3):
     """Stats -> params (3,C) = (mean, rstd, beta)."""
+    if st.params is not None and beta is None and abs(eps - 1e-3) < 1e-12:
+        return st.params
     params = _new(ref, (3, C))
     if _dev_ok(ref, beta):
         _call('atvs_bn_finalize', ctypes.c_void_p(st.partial.data_ptr()), ctypes.c_long(st.blocks), st.cpad,

@@ -180,7 +180,12 @@ int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* gro
  * x-pair form (xpair != 0, Cout == 8 only): the 16 GEMM rows are (x parity, channel) and a tile column
  * is the voxel pair (2i, 2i+1), so no row of the MFMA tile is padding; the packed kernel is the dense
  * virtual kernel Wv[(kd,kh,ox)][ci][(jx,co)] = W[kd][kh][ox-jx+1] (or 0) over the 36 taps
- * ox in -1..2 (pack with xpair = 1 and 16 output channels); tile_y = 4 for 16-channel chunks. */
+ * ox in -1..2 (pack with xpair = 1 and 16 output channels); tile_y = 4 for 16-channel chunks.
+ * In-launch finalize (fin_counter != NULL): the last workgroup to arrive (one agent-scope atomic ticket on
+ * *fin_counter, which must be zero before the layer's first launch and is left at zero) reduces the
+ * fin_rows rows of fin_stats (the layer's whole statistics buffer; fin_arrivals = workgroups of all the
+ * layer's launches) into fin_params = (3, fin_channels) floats (mean, rsqrt(var + fin_eps), 0), exactly
+ * what atvs_bn_finalize(beta = NULL) would write -- no separate finalize launch.  fin_channels <= 64. */
 int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* chunk_pad, int* ksteps_per_chunk,
                               int* ntiles, long* packed_floats, long* table_ints);
 int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
@@ -193,7 +198,9 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
                         int D, int H, int W, int Cin,
                         int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
                         int y_coff, int Cout, int ntaps, int tile_y, int relu, int class_cout, int class_base,
-                        int xpair, atvs_stream_t stream);
+                        int xpair, uint32_t* fin_counter, float* fin_params, double* fin_stats, int fin_rows,
+                        int fin_arrivals, int fin_channels, int fin_fold, long fin_count, float fin_eps,
+                        atvs_stream_t stream);
 
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,

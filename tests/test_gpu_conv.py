@@ -253,3 +253,30 @@ def test_conv3d_8to1_head(cuda, D, H, W):
     got = ops.conv3d_8to1(x[0].to(cuda), w.to(cuda))
     assert tuple(got.shape) == (D, H, W, 1)
     _close(got.cpu(), want)
+
+
+@pytest.mark.parametrize('shape,cin,cout', [((48, 64, 80), 16, 8), ((24, 32, 40), 32, 32), ((96, 128, 160), 8, 8)])
+def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
+    """The batch-norm moments finished by the last-arriving workgroup of the convolution equal the ones the
+    separate atvs_bn_finalize launch computes from the same partial sums -- on every one of many launches
+    (inter-workgroup hand-off: stale data would show up as run-to-run differences)."""
+    from atvsnet_amd import ops
+    D, H, W = shape
+    x = _rand((D, H, W, cin), 50).to(cuda)
+    w = _rand((3, 3, 3, cin, cout), 51, 0.2).numpy()
+    ops.fused_finalize(True)
+    ref = None
+    for it in range(12):
+        y, st = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
+        assert st.params is not None
+        fused = st.params.clone()
+        st.params = None
+        sep = ops.bn_params(st, cout, y)
+        assert torch.allclose(fused[:2], sep[:2], rtol=1e-6, atol=1e-7) and torch.all(fused[2] == 0)
+        if ref is None:
+            ref = fused
+        assert torch.equal(fused, ref)
+    ops.fused_finalize(False)
+    y2, st2 = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
+    ops.fused_finalize(True)
+    assert st2.params is None and torch.equal(y2, y)
