@@ -409,17 +409,19 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
       int which = tid / (NT * 16), c = tid % (NT * 16);
       double v = (s_red[(0 * 2 + which) * (NT * 16) + c] + s_red[(1 * 2 + which) * (NT * 16) + c]) +
                  (s_red[(2 * 2 + which) * (NT * 16) + c] + s_red[(3 * 2 + which) * (NT * 16) + c]);
-      // row of width nt_total*16; with N-split the other columns are zero (caller zero-fills the buffer)
-      p.stats[((size_t)blockIdx.x * 2 + which) * (p.nt_total * 16) + nsi * NT * 16 + c] = v;
+      // row of width nt_total*16; with N-split the other columns are zero (caller zero-fills the buffer).
+      // Written through to memory (relaxed agent-scope store = global_store sc1): the finalizing workgroup on
+      // another CU / XCD reads it without this workgroup paying an L2 write-back of its whole output tile.
+      __hip_atomic_store(p.stats + ((size_t)blockIdx.x * 2 + which) * (p.nt_total * 16) + nsi * NT * 16 + c, v,
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (p.fin_counter) {
-      // ---- last-arriver finalize (agent-scope release / acquire around one atomic ticket)
+      // ---- last-arriver finalize: write-through partial rows, every storing wave drains its stores, one
+      // relaxed agent-scope ticket; only the last arriver pays an acquire (L1 invalidate) before reading
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       int* s_flag = reinterpret_cast<int*>(smem + 4 * 2 * NT * 16 * sizeof(double));
       if (tid == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned prev = __hip_atomic_fetch_add(p.fin_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int last = (prev == (unsigned)(p.fin_arrivals - 1)) ? 1 : 0;
         if (last) {
