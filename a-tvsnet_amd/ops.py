@@ -317,7 +317,10 @@ def force_conv_impl(impl):
 
 
 _fin_pool = {}
-_FUSED_FINALIZE = True
+# Measured on MI355X (cfg3 pipeline, HIP-graph replay): 51.4 ms/depth-map with the separate 5-us finalize
+# launches, 54.5 ms with the in-launch last-arriver finalize (the arrival drains every workgroup's output
+# stores and the reducing workgroup runs alone at the tail) -> off by default, kept and tested.
+_FUSED_FINALIZE = False
 
 
 def fused_finalize(flag):

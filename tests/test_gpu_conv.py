@@ -278,5 +278,4 @@ def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
         assert torch.equal(fused, ref)
     ops.fused_finalize(False)
     y2, st2 = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
-    ops.fused_finalize(True)
     assert st2.params is None and torch.equal(y2, y)
