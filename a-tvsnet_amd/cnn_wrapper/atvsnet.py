@@ -28,20 +28,21 @@ def _stacked_unet(net, with_prob_head):
             .conv_bn(3, f * 2, 2, name=n('1_0'))
             .conv_bn(3, f * 4, 2, name=n('2_0'))
             .conv_bn(3, f * 8, 2, name=n('3_0')))
-        net.feed(src).conv_bn(3, f, 1, name=n('0_1'))
+        # defer_bn: these layers are consumed by `add`s only, which normalise them on the fly
+        net.feed(src).conv_bn(3, f, 1, name=n('0_1'), defer_bn=True)
         if b == 0:
-            net.feed(n('1_0')).conv_bn(3, f * 2, 1, name=n('1_1'))
-            net.feed(n('2_0')).conv_bn(3, f * 4, 1, name=n('2_1'))
+            net.feed(n('1_0')).conv_bn(3, f * 2, 1, name=n('1_1'), defer_bn=True)
+            net.feed(n('2_0')).conv_bn(3, f * 4, 1, name=n('2_1'), defer_bn=True)
         else:
-            net.feed(n('1_0'), p('5_0')).add(name=n('1_1_concat')).conv_bn(3, f * 2, 1, name=n('1_1'))
-            net.feed(n('2_0'), p('4_0')).add(name=n('2_1_concat')).conv_bn(3, f * 4, 1, name=n('2_1'))
+            net.feed(n('1_0'), p('5_0')).add(name=n('1_1_concat')).conv_bn(3, f * 2, 1, name=n('1_1'), defer_bn=True)
+            net.feed(n('2_0'), p('4_0')).add(name=n('2_1_concat')).conv_bn(3, f * 4, 1, name=n('2_1'), defer_bn=True)
         (net.feed(n('3_0'))
             .conv_bn(3, f * 8, 1, name=n('3_1'))
-            .deconv_bn(3, f * 4, 2, name=n('4_0')))
+            .deconv_bn(3, f * 4, 2, name=n('4_0'), defer_bn=True))
         skip2 = [n('4_0'), n('2_1')] + ([] if b == 0 else ['conv_b0_2_1'])
-        net.feed(*skip2).add(name=n('4_1')).deconv_bn(3, f * 2, 2, name=n('5_0'))
+        net.feed(*skip2).add(name=n('4_1')).deconv_bn(3, f * 2, 2, name=n('5_0'), defer_bn=True)
         skip1 = [n('5_0'), n('1_1')] + ([] if b == 0 else ['conv_b0_1_1'])
-        net.feed(*skip1).add(name=n('5_1')).deconv_bn(3, f, 2, name=n('6_0'))
+        net.feed(*skip1).add(name=n('5_1')).deconv_bn(3, f, 2, name=n('6_0'), defer_bn=True)
     net.feed('conv_b2_6_0', 'conv_b2_0_1').add(name='conv_b2_6_1')
     if with_prob_head:
         net.conv(3, 1, 1, relu=False, name='conv_b2_6_2')
@@ -167,18 +168,18 @@ class CostVolRefineNet(Network):
              .conv_bn(3, f * 2, 2, name=g + '3dconv1_0')
              .conv_bn(3, f * 4, 2, name=g + '3dconv2_0')
              .conv_bn(3, f * 8, 2, name=g + '3dconv3_0'))
-        self.feed(g + 'concat').conv_bn(3, f, 1, name=g + '3dconv0_1')
-        self.feed(g + '3dconv1_0').conv_bn(3, f * 2, 1, name=g + '3dconv1_1')
-        self.feed(g + '3dconv2_0').conv_bn(3, f * 4, 1, name=g + '3dconv2_1')
+        self.feed(g + 'concat').conv_bn(3, f, 1, name=g + '3dconv0_1', defer_bn=True)
+        self.feed(g + '3dconv1_0').conv_bn(3, f * 2, 1, name=g + '3dconv1_1', defer_bn=True)
+        self.feed(g + '3dconv2_0').conv_bn(3, f * 4, 1, name=g + '3dconv2_1', defer_bn=True)
         (self.feed(g + '3dconv3_0')
              .conv_bn(3, f * 8, 1, name=g + '3dconv3_1')
-             .deconv_bn(3, f * 4, 2, name=g + '3dconv4_0'))
+             .deconv_bn(3, f * 4, 2, name=g + '3dconv4_0', defer_bn=True))
         (self.feed(g + '3dconv4_0', g + '3dconv2_1')
              .add(name=g + '3dconv4_1')
-             .deconv_bn(3, f * 2, 2, name=g + '3dconv5_0'))
+             .deconv_bn(3, f * 2, 2, name=g + '3dconv5_0', defer_bn=True))
         (self.feed(g + '3dconv5_0', g + '3dconv1_1')
              .add(name=g + '3dconv5_1')
-             .deconv_bn(3, f, 2, name=g + '3dconv6_0'))
+             .deconv_bn(3, f, 2, name=g + '3dconv6_0', defer_bn=True))
         (self.feed(g + '3dconv6_0', g + '3dconv0_1')
              .add(name=g + '3dconv6_1')
              .conv(3, 1, 1, relu=False, name='global_refined_cost_vol'))

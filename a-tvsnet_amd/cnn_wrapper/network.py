@@ -48,7 +48,7 @@ def layer(op):
 
 
 def _b1(x, what):
-    if isinstance(x, ops.SplitVolume):
+    if isinstance(x, (ops.SplitVolume, ops.PendingBN)):
         x = x.materialize()
     if x.shape[0] != 1:
         raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d' % (what, x.shape[0]))
@@ -106,10 +106,12 @@ class Network(object):
 
     def get_output(self):
         '''Returns the current network output.'''
-        return self.terminals[-1]
+        t = self.terminals[-1]
+        return t.materialize() if isinstance(t, ops.PendingBN) else t
 
     def get_output_by_name(self, layer_name):
-        return self.layers[layer_name]
+        t = self.layers[layer_name]
+        return t.materialize() if isinstance(t, ops.PendingBN) else t
 
     def get_shape_by_name(self, layer_name):
         '''Shape of a layer (a tuple here; tf.shape in the reference :121-127).
@@ -207,7 +209,7 @@ class Network(object):
 
     @layer
     def conv_bn(self, input, kernel_size, filters, strides, name, relu=True, center=False, padding=DEFAULT_PADDING,
-                biased=False, rate=1, out_slice=None):
+                biased=False, rate=1, out_slice=None, defer_bn=False):
         '''conv (no activation) -> batch norm with batch statistics -> relu (reference network.py:172-215):
         variables name/conv{2,3}d/kernel.  The statistics come from the convolution's epilogue.'''
         rank = input.dim()
@@ -221,6 +223,8 @@ class Network(object):
                 vname = '%s/conv3d/kernel' % name
                 w = self._kernel(vname, (3, 3, 3, input.shape[-1], filters))
                 y, st = ops.conv_split(input, vname, w, stride=strides, want_stats=True, out=buf, y_coff=c_off)
+                if defer_bn and buf is None and not center and filters % 4 == 0:
+                    return ops.PendingBN(y, ops.bn_params(st, filters, y, None, BN_EPS), relu)
                 return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None),
                                                 c_off=c_off), out_slice, filters)
             input = input.materialize()
@@ -230,6 +234,10 @@ class Network(object):
         vname = '%s/%s/kernel' % (name, kind)
         w = self._kernel(vname, (kernel_size,) * (rank - 2) + (cin, filters))
         bias = self._vec('%s/%s/bias' % (name, kind), filters, x) if biased else None
+        if self.training and defer_bn and buf is None and not center and filters % 4 == 0:
+            # extension: the layer's consumers are adds only -> hand them the raw output + the moments
+            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True)
+            return ops.PendingBN(y, ops.bn_params(st, filters, y, None, BN_EPS), relu)
         if self.training:
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
                              out=buf, y_coff=c_off)
@@ -250,7 +258,7 @@ class Network(object):
 
     @layer
     def deconv_bn(self, input, kernel_size, filters, strides, name, relu=True, center=False, padding=DEFAULT_PADDING,
-                  biased=False):
+                  biased=False, defer_bn=False):
         '''conv3d_transpose -> batch norm -> relu (reference network.py:510-550): variables
         name/conv3d_transpose/kernel [k,k,k,Cout,Cin].  The path only uses k=3, stride 2, SAME, rank 5.'''
         rank = input.dim()
@@ -262,6 +270,9 @@ class Network(object):
         x = _b1(input, name)
         vname = '%s/conv3d_transpose/kernel' % name
         w = self._kernel(vname, (3, 3, 3, filters, x.shape[-1]))
+        if self.training and defer_bn and not center and filters % 4 == 0:
+            y, st = ops.conv3d_transpose_s2(x, vname, w, want_stats=True)
+            return ops.PendingBN(y, ops.bn_params(st, filters, y, None, BN_EPS), relu)
         if self.training:
             y, st = ops.conv3d_transpose_s2(x, vname, w, want_stats=True)
         else:
@@ -370,7 +381,12 @@ class Network(object):
 
     @layer
     def add(self, inputs, name):
-        '''tf.add_n (reference network.py:695-697).'''
+        '''tf.add_n (reference network.py:695-697).  Inputs whose batch norm is still pending (conv_bn /
+        deconv_bn with defer_bn=True) are normalised inside the add kernel.'''
+        if len(inputs) in (2, 3) and any(isinstance(t, ops.PendingBN) for t in inputs) \
+                and inputs[0].shape[-1] % 4 == 0:
+            items = [t if isinstance(t, ops.PendingBN) else _b1(t, name) for t in inputs]
+            return ops.bn_add(items).unsqueeze(0)
         return ops.add_n([_b1(t, name) for t in inputs]).unsqueeze(0)
 
     def attention_activation(self, input, kernel_size, name, filters=None, second_weight=False, relu=True,

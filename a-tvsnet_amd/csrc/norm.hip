@@ -169,3 +169,48 @@ extern "C" int atvs_add_n(const float* a, const float* b, const float* c, float*
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
+
+// Sum of up to three tensors, each optionally a raw convolution output with pending batch norm + ReLU:
+//   y = sum_i  (p_i ? relu?((x_i - mean_i) * rstd_i + beta_i) : x_i)
+// One pass for conv_bn -> conv_bn -> add chains (cnn_wrapper/atvsnet.py U-Net skip adds) instead of a
+// normalisation pass per tensor plus the add.  relu_mask bit i = ReLU after input i's batch norm.
+__global__ __launch_bounds__(256) void bn_add_kernel(const float* __restrict__ x0, const float* __restrict__ p0,
+                                                     const float* __restrict__ x1, const float* __restrict__ p1,
+                                                     const float* __restrict__ x2, const float* __restrict__ p2,
+                                                     float* __restrict__ y, long n, int C, int relu_mask) {
+  long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  int c = (int)(i % C);
+  auto term = [&](const float* x, const float* p, int relu) {
+    float4 v = ld4(x + i);
+    if (p) {
+      float4 m = ld4(p + c), s = ld4(p + C + c), b = ld4(p + 2 * C + c);
+      v.x = (v.x - m.x) * s.x + b.x;
+      v.y = (v.y - m.y) * s.y + b.y;
+      v.z = (v.z - m.z) * s.z + b.z;
+      v.w = (v.w - m.w) * s.w + b.w;
+      if (relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+    }
+    return v;
+  };
+  float4 a = term(x0, p0, relu_mask & 1), b = term(x1, p1, relu_mask & 2);
+  a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+  if (x2) {
+    float4 d = term(x2, p2, relu_mask & 4);
+    a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+  }
+  st4(y + i, a);
+}
+
+extern "C" int atvs_bn_add(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
+                           const float* params2, float* y, long rows, int C, int relu_mask, atvs_stream_t stream) {
+  if (!x0 || !x1 || !y) return ATVS_ERR_NULL;
+  if (rows <= 0 || C <= 0 || (C % 4) != 0) return ATVS_ERR_SHAPE;
+  long n = rows * C;
+  hipLaunchKernelGGL(bn_add_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x0, params0, x1, params1, x2,
+                     params2, y, n, C, relu_mask);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

@@ -794,6 +794,56 @@ def batch_norm(x, st=None, beta=None, relu=False, inplace=False, eps=1e-3, C=Non
     return bn_apply(x, params, relu, out=(x if inplace else _new(x, x.shape)))
 
 
+class PendingBN(object):
+    """A raw convolution output whose training-mode batch norm (+ ReLU) has not been applied yet.
+
+    Layers whose only consumers are `add`s never need the normalised tensor on its own: the add kernel
+    normalises on the fly (ops.bn_add).  Any other consumer calls materialize()."""
+
+    def __init__(self, raw, params, relu):
+        self.raw, self.params, self.relu = raw, params, bool(relu)
+        self._final = None
+        self.device = raw.device
+
+    @property
+    def shape(self):
+        return (1,) + tuple(self.raw.shape)
+
+    def dim(self):
+        return self.raw.dim() + 1
+
+    @property
+    def is_meta(self):
+        return self.raw.is_meta
+
+    def materialize(self):
+        """The (1, ...) normalised tensor (computed once, in place on the raw buffer)."""
+        if self._final is None:
+            self._final = bn_apply(self.raw, self.params, self.relu).unsqueeze(0)
+        return self._final
+
+
+def bn_add(items):
+    """Sum of 2 or 3 items, each a dense tensor or a PendingBN (normalised on the fly); dims without batch."""
+    xs, ps, mask = [], [], 0
+    for i, it in enumerate(items):
+        if isinstance(it, PendingBN) and it._final is None:
+            xs.append(it.raw)
+            ps.append(it.params)
+            mask |= (1 << i) if it.relu else 0
+        else:
+            t = it.materialize()[0] if isinstance(it, PendingBN) else it
+            xs.append(t)
+            ps.append(None)
+    C = xs[0].shape[-1]
+    out = _new(xs[0], xs[0].shape)
+    if _dev_ok(*(xs + [p for p in ps if p is not None])):
+        x2, p2 = (xs[2], ps[2]) if len(xs) > 2 else (None, None)
+        _call('atvs_bn_add', _p(xs[0]), _p(ps[0]), _p(xs[1]), _p(ps[1]), _p(x2), _p(p2), _p(out),
+              ctypes.c_long(out.numel() // C), C, int(mask), _stream())
+    return out
+
+
 def add_n(tensors):
     """tf.add_n: ((a + b) + c) + ..."""
     acc = tensors[0]

@@ -230,6 +230,12 @@ int atvs_channel_stats(const float* x, long rows, int C, double* stats_partial, 
 int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int ld, int c_off,
                   int relu, atvs_stream_t stream);
 
+/* tf.add_n of two or three tensors of which any may still be a raw convolution output whose
+ * batch norm (+ ReLU, relu_mask bit i) is pending: y = sum_i bn_relu_i(x_i), params_i (3,C) or NULL
+ * for an already-final tensor; x2 may be NULL.  C % 4 == 0.  (network.py:172-215 + :695-697 fused.) */
+int atvs_bn_add(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
+                const float* params2, float* y, long rows, int C, int relu_mask, atvs_stream_t stream);
+
 /* tf.add_n of two or three tensors (c may be NULL), network.py:695-697. */
 int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream);
 
