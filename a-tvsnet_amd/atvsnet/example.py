@@ -67,14 +67,22 @@ class _ViewStreams(object):
         self.enabled = bool(enabled) and device.type == 'cuda' and n > 1
         self.streams = [torch.cuda.Stream(device) for _ in range(n)] if self.enabled else []
 
-    def run(self, i, fn):
-        """fn() on stream i (after everything queued so far on the main stream); returns fn's result."""
+    def run(self, i, fn, after=None):
+        """fn() on stream i, after everything queued so far on the main stream (or after the event `after`
+        recorded earlier on it); returns fn's result."""
         if not self.enabled:
             return fn()
         st = self.streams[i]
-        st.wait_stream(self.main)
+        if after is not None:
+            st.wait_event(after)
+        else:
+            st.wait_stream(self.main)
         with torch.cuda.stream(st):
             return fn()
+
+    def mark(self):
+        """An event on the main stream at this point of the issue order (None when streams are off)."""
+        return self.main.record_event() if self.enabled else None
 
     def join(self, tensors):
         """Main stream waits for every view stream; `tensors` (nested lists ok) become usable on it."""
@@ -103,9 +111,12 @@ def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True):
     assert n > 2
     depth_start, depth_interval = depth_range(cams)
     vs = _ViewStreams(n - 1, images.device, view_streams)
+    start = vs.mark()                       # the source towers need not wait for the reference tower ...
     ref_feature = TVSNet_feature_extraction(images, 0)
+    ref_ready = vs.mark()                   # ... only their cost volumes do
     base = [vs.run(v - 1, lambda v=v: TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval, view_i=v,
-                                                          ref_i=0, ref_feature=ref_feature))
+                                                          ref_i=0, ref_feature=ref_feature, ref_ready=ref_ready),
+                   after=start)
             for v in range(1, n)]
     vs.join(base)
     filtered_cost_volumes = [b[2] for b in base]    # prob volumes are fed but unused by the reference (quirk C12)

@@ -218,7 +218,7 @@ def TVSNet_base(images, cams, depth_num, depth_start, depth_interval, view_i, re
 
 
 def TVSNet_base_siamese(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0, ref_feature=None,
-                        side_stream=None):
+                        side_stream=None, ref_ready=None):
     """Both directions of one (reference, source) pair (reference :398-417) ->
     (depth_b2, prob_vol_b2, filtered_cost_volume, depth_view).  Quirk C11: the reverse
     direction sweeps the reference camera's depth range.  The two directions only share the feature
@@ -227,6 +227,8 @@ def TVSNet_base_siamese(images, cams, depth_num, depth_start, depth_interval, vi
     if ref_feature is None:
         ref_feature = TVSNet_feature_extraction(images, ref_i)
     view_feature = TVSNet_feature_extraction(images, view_i)
+    if ref_ready is not None:        # ref_feature is being produced on another stream: needed from here on
+        torch.cuda.current_stream(view_feature.device).wait_event(ref_ready)
 
     def reverse():
         cost_vol_view = build_cost_volume(view_feature, ref_feature, cams, depth_num, depth_start, depth_interval,
