@@ -54,6 +54,9 @@ def infer_twoview(images, cams, max_d=None):
     return depth_refined
 
 
+OVERLAP_REF_TOWER = True
+
+
 class _ViewStreams(object):
     """One HIP stream per source view (plus the caller's stream).
 
@@ -111,9 +114,9 @@ def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True):
     assert n > 2
     depth_start, depth_interval = depth_range(cams)
     vs = _ViewStreams(n - 1, images.device, view_streams)
-    start = vs.mark()                       # the source towers need not wait for the reference tower ...
+    start = vs.mark() if OVERLAP_REF_TOWER else None     # the source towers need not wait for the reference tower ...
     ref_feature = TVSNet_feature_extraction(images, 0)
-    ref_ready = vs.mark()                   # ... only their cost volumes do
+    ref_ready = vs.mark() if OVERLAP_REF_TOWER else None  # ... only their cost volumes do
     base = [vs.run(v - 1, lambda v=v: TVSNet_base_siamese(images, cams, max_d, depth_start, depth_interval, view_i=v,
                                                           ref_i=0, ref_feature=ref_feature, ref_ready=ref_ready),
                    after=start)
