@@ -54,7 +54,9 @@ def infer_twoview(images, cams, max_d=None):
     return depth_refined
 
 
-OVERLAP_REF_TOWER = True
+# A-B on MI355X (tools_dev/ab.py): 49.3 ms without, 52.5 ms with (five concurrent towers delay the reference
+# tower every stream then waits for)
+OVERLAP_REF_TOWER = False
 
 
 class _ViewStreams(object):
