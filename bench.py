@@ -8,14 +8,18 @@ hypotheses (BASELINE.json configs[2], the configuration the metric is quoted on)
 whole example.py multi-view pipeline (towers -> 2x stacked 3-D U-Net per source -> AAM1 ->
 refinement per source -> AAM2 -> x4 upsample + soft-argmin), inputs resident in HBM, synthetic
 seeded data and weights.  Arithmetic: fp32 (fp32 MFMA for every convolution).
+On one GPU the step is ONE replay of a HIP graph captured from the pipeline (per-view streams
+forked and joined inside it); --eager issues every launch from Python instead.
 
 --gpus N > 1 (one process per GPU, launched by torch.distributed.run): the source views of
 the SAME depth map are sharded over the ranks and aggregated with RCCL all-reduces inside both
 AANet modules (a-tvsnet_amd/parallel.py); total work is fixed -> "scaling": "strong".
 
-One JSON line on rank 0; `roofline` is for the dominant kernel (the 64->8 3x3x3 convolution
-at full resolution, conv_b0_0_1), timed with HIP events on the launch stream inside the timed
-region; `cpu_baseline` is the CPU oracle on the host cores over a bounded sample.
+One JSON line on rank 0; `roofline` is for the dominant kernel (the 3x3x3 convolution of the 32
+warped channels of conv_b0_0_1 at full resolution), timed with HIP events on its launch stream;
+`roofline.traffic` is the HBM traffic of that launch from rocprofv3 PMC passes recorded in
+profiles/round1_pmc_dominant_kernel.json (WRITE_SIZE + FETCH_SIZE, see the note there);
+`cpu_baseline` is the CPU oracle on the host cores over a bounded sample.
 """
 import argparse
 import json
@@ -107,6 +111,22 @@ def cpu_baseline(args, budget_s):
                          args.views, n_src, time.time() - t0)}
 
 
+def pmc_traffic(args):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (only valid for
+    the default workload they were taken on): WRITE_SIZE + raw FETCH_SIZE."""
+    if (args.width, args.height, args.depths) != (WIDTH, HEIGHT, DEPTHS):
+        return None
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'round1_pmc_dominant_kernel.json')) as f:
+            d = json.load(f)['derived']
+        return {'hbm_bytes': d['write_bytes_pmc'] + d['fetch_bytes_pmc_raw'], 'unit': 'B per launch',
+                'fetch_bytes_if_wide_stream_correction_applies': d['fetch_bytes_pmc_x2_gfx950_wide_stream_correction'],
+                'algorithmic_bytes': d['algorithmic_read_bytes'] + d['algorithmic_write_bytes'],
+                'source': 'profiles/round1_pmc_dominant_kernel.json'}
+    except Exception:
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -186,11 +206,12 @@ def main():
             ach = flops / (avg_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'kernel': 'conv_tiled_f32_kernel<NT=1,TY=4,C4=4,x-pair> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full resolution)',
                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': None,
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(args),
                     'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched),
                     'algorithmic_flops_per_launch': flops}
         line = {
-            'metric': 'depth-maps/sec at 640x512xD=192, N=5 views', 'value': round(args.steps / dt, 4),
+            'metric': 'depth-maps/sec at %dx%dxD=%d, N=%d views' % (args.width, args.height, args.depths, args.views),
+            'value': round(args.steps / dt, 4),
             'unit': 'depth-maps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
