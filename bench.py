@@ -119,10 +119,7 @@ def pmc_traffic(args):
     try:
         with open(os.path.join(ROOT, 'profiles', 'round1_pmc_dominant_kernel.json')) as f:
             d = json.load(f)['derived']
-        return {'hbm_bytes': d['write_bytes_pmc'] + d['fetch_bytes_pmc_raw'], 'unit': 'B per launch',
-                'fetch_bytes_if_wide_stream_correction_applies': d['fetch_bytes_pmc_x2_gfx950_wide_stream_correction'],
-                'algorithmic_bytes': d['algorithmic_read_bytes'] + d['algorithmic_write_bytes'],
-                'source': 'profiles/round1_pmc_dominant_kernel.json'}
+        return d['write_bytes_pmc'] + d['fetch_bytes_pmc_raw']      # bytes per launch
     except Exception:
         return None
 
@@ -207,6 +204,8 @@ def main():
             roof = {'bound': 'mfma', 'kernel': 'conv_tiled_f32_kernel<NT=1,TY=4,C4=4,x-pair> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full resolution)',
                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(args),
+                    'traffic_note': 'HBM bytes per launch, WRITE_SIZE + FETCH_SIZE (rocprofv3 --pmc, profiles/'
+                                    'round1_pmc_dominant_kernel.json); algorithmic bytes 629145600',
                     'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched),
                     'algorithmic_flops_per_launch': flops}
         line = {
