@@ -21,8 +21,48 @@ struct ViewPtrs {
   const float* x[AANET_MAX_VIEWS];
 };
 
-// one lane per float4 of the (V, 8) output
-__global__ __launch_bounds__(256) void aanet_combine_kernel(ViewPtrs p, int nv, float* __restrict__ out, long n4) {
+// one lane per float4 of the (V, 8) output; every S_n, R_n, X_n is read once and kept in registers
+template <int NV>
+__global__ __launch_bounds__(256) void aanet_combine_kernel(ViewPtrs p, int nv_rt, float* __restrict__ out, long n4) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  long v = i >> 1;
+  int half = (int)(i & 1) * 4;
+  size_t so = (size_t)v * 16 + half, xo = (size_t)v * 8 + half;
+  float4 u[NV], x[NV];
+  float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8);
+    x[n] = ld4(p.x[n] + xo);
+    ssum.x += s.x; ssum.y += s.y; ssum.z += s.z; ssum.w += s.w;
+    u[n] = make_float4(r.x - s.x, r.y - s.y, r.z - s.z, r.w - s.w);
+  }
+  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    u[n].x += ssum.x; u[n].y += ssum.y; u[n].z += ssum.z; u[n].w += ssum.w;      // (R - S) + S_sum
+    m.x = fmaxf(m.x, u[n].x); m.y = fmaxf(m.y, u[n].y); m.z = fmaxf(m.z, u[n].z); m.w = fmaxf(m.w, u[n].w);
+  }
+  float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    u[n].x = expf(u[n].x - m.x); u[n].y = expf(u[n].y - m.y); u[n].z = expf(u[n].z - m.z); u[n].w = expf(u[n].w - m.w);
+    den.x += u[n].x; den.y += u[n].y; den.z += u[n].z; den.w += u[n].w;
+  }
+  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    o.x += (u[n].x / den.x) * x[n].x;
+    o.y += (u[n].y / den.y) * x[n].y;
+    o.z += (u[n].z / den.z) * x[n].z;
+    o.w += (u[n].w / den.w) * x[n].w;
+  }
+  st4(out + xo, o);
+}
+
+// any number of views: re-reads the operands per pass
+__global__ __launch_bounds__(256) void aanet_combine_generic_kernel(ViewPtrs p, int nv, float* __restrict__ out, long n4) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   long v = i >> 1;
@@ -79,7 +119,19 @@ extern "C" int atvs_aanet_combine(const float* const* sr_ptrs, const float* cons
   int rc = fill_ptrs(&p, sr_ptrs, x_ptrs, nv);
   if (rc) return rc;
   long n4 = V * 2;
-  hipLaunchKernelGGL(aanet_combine_kernel, dim3(cdiv(n4, 256)), dim3(256), 0, as_stream(stream), p, nv, out, n4);
+  dim3 grid(cdiv(n4, 256)), block(256);
+  hipStream_t s = as_stream(stream);
+  switch (nv) {
+    case 1: hipLaunchKernelGGL((aanet_combine_kernel<1>), grid, block, 0, s, p, nv, out, n4); break;
+    case 2: hipLaunchKernelGGL((aanet_combine_kernel<2>), grid, block, 0, s, p, nv, out, n4); break;
+    case 3: hipLaunchKernelGGL((aanet_combine_kernel<3>), grid, block, 0, s, p, nv, out, n4); break;
+    case 4: hipLaunchKernelGGL((aanet_combine_kernel<4>), grid, block, 0, s, p, nv, out, n4); break;
+    case 5: hipLaunchKernelGGL((aanet_combine_kernel<5>), grid, block, 0, s, p, nv, out, n4); break;
+    case 6: hipLaunchKernelGGL((aanet_combine_kernel<6>), grid, block, 0, s, p, nv, out, n4); break;
+    case 7: hipLaunchKernelGGL((aanet_combine_kernel<7>), grid, block, 0, s, p, nv, out, n4); break;
+    case 8: hipLaunchKernelGGL((aanet_combine_kernel<8>), grid, block, 0, s, p, nv, out, n4); break;
+    default: hipLaunchKernelGGL(aanet_combine_generic_kernel, grid, block, 0, s, p, nv, out, n4); break;
+  }
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -405,15 +405,18 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
         }
       }
     __syncthreads();
-    if (tid < 2 * NT * 16) {
-      int which = tid / (NT * 16), c = tid % (NT * 16);
-      double v = (s_red[(0 * 2 + which) * (NT * 16) + c] + s_red[(1 * 2 + which) * (NT * 16) + c]) +
-                 (s_red[(2 * 2 + which) * (NT * 16) + c] + s_red[(3 * 2 + which) * (NT * 16) + c]);
-      // row of width nt_total*16; with N-split the other columns are zero (caller zero-fills the buffer).
-      // Written through to memory (relaxed agent-scope store = global_store sc1): the finalizing workgroup on
-      // another CU / XCD reads it without this workgroup paying an L2 write-back of its whole output tile.
-      __hip_atomic_store(p.stats + ((size_t)blockIdx.x * 2 + which) * (p.nt_total * 16) + nsi * NT * 16 + c, v,
-                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // this workgroup's row of the statistics buffer: width nt_total*16; columns of the output-channel
+    // tiles it does not own (N-split) are written as zeros, so the buffer needs no pre-clearing.
+    // Written through to memory (relaxed agent-scope store = global_store sc1) for the in-launch finalize.
+    for (int i = tid; i < 2 * p.nt_total * 16; i += 256) {
+      int which = i / (p.nt_total * 16), col = i % (p.nt_total * 16);
+      int c = col - nsi * NT * 16;
+      double v = 0.0;
+      if (c >= 0 && c < NT * 16)
+        v = (s_red[(0 * 2 + which) * (NT * 16) + c] + s_red[(1 * 2 + which) * (NT * 16) + c]) +
+            (s_red[(2 * 2 + which) * (NT * 16) + c] + s_red[(3 * 2 + which) * (NT * 16) + c]);
+      __hip_atomic_store(p.stats + ((size_t)blockIdx.x * 2 + which) * (p.nt_total * 16) + col, v, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
     }
     if (p.fin_counter) {
       // ---- last-arriver finalize: write-through partial rows, every storing wave drains its stores, one

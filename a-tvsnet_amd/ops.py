@@ -558,8 +558,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     st = None
     sbuf = None
     if want_stats:
-        zero = bool(tile_y) and tiled_nsplit(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout, xpair) > 1
-        sbuf = _stats_buffer(x, blocks, pk.ntiles * 16, zero)
+        sbuf = _stats_buffer(x, blocks, pk.ntiles * 16)
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
     if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
@@ -713,7 +712,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
         in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(D, H, W, tile_y, Cin, per * cout))
         st, sbuf = None, None
         if want_stats and in_kernel:
-            sbuf = _stats_buffer(x, blocks * nl, nt * 16, tiled_nsplit(D, H, W, tile_y, Cin, per * cout) > 1)
+            sbuf = _stats_buffer(x, blocks * nl, nt * 16)
             st = Stats()
             st.partial, st.blocks, st.cpad, st.count, st.fold = sbuf, blocks * nl, nt * 16, 8 * M, per
         fin = None

@@ -167,8 +167,8 @@ int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* gro
  * as atvs_conv_pack; the table depends on tile_y in {4, 8}).  The grid is persistent
  * (atvs_conv_tiled_num_blocks workgroups sweep the tiles); stats_partial has that many rows of
  * 16*ntiles doubles x 2 (one per workgroup).  Small volumes deal the 16-channel output tiles of a
- * spatial tile to several workgroups (atvs_conv_tiled_grid reports nsplit): each then fills only its
- * own columns, so the caller zero-fills stats_partial when nsplit > 1.  Launches whose per-workgroup
+ * spatial tile to several workgroups (atvs_conv_tiled_grid reports nsplit): each then fills its own
+ * columns of its row and zeros in the others.  Launches whose per-workgroup
  * width is 128 channels produce no statistics (atvs_conv_tiled_has_stats == 0: pass NULL and
  * use atvs_channel_stats on the output).
  * Fused stride-2 transposed convolution (class_cout != 0): the 8 output parity classes of
