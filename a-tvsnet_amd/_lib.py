@@ -12,7 +12,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(_HERE, 'libatvsnet_hip.so')
+LIB_PATH = os.environ.get('ATVS_LIB') or os.path.join(_HERE, 'libatvsnet_hip.so')   # ATVS_LIB: A/B a development build
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'atvsnet_hip.h')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
@@ -88,4 +88,5 @@ def lib():
         _lib.atvs_avg_pool_ws_floats.restype = ctypes.c_long
         _lib.atvs_conv_tiled_num_blocks.restype = ctypes.c_long
         _lib.atvs_conv_tiled_grid.restype = ctypes.c_long
+        _lib.atvs_conv_xp_grid.restype = ctypes.c_long
     return _lib

@@ -1,0 +1,378 @@
+// 3x3x3 SAME stride-1 convolution to EIGHT output channels in x-pair form, one wavefront per SIMD (gfx950).
+//
+// These are the widest layers of the stacked U-Nets / refinement net (conv_b*_0_1, global_refine_3dconv0_1,
+// the refinement stems: cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, layer code
+// /root/reference/cnn_wrapper/network.py:165-215): full-resolution volumes, 8 output channels.  They are
+// MFMA-bound and dominate the depth-map time, so this kernel is built around what measurements on MI355X
+// showed about keeping the fp32 MFMA pipe busy:
+//   * a second wavefront on the SIMD does not help (its non-MFMA instructions issue about once per MFMA of
+//     the first) -- what counts is the number of non-MFMA instructions the MFMA-issuing wavefront itself
+//     executes per MFMA, and that it never waits for a load younger than ~2000 cycles;
+//   * so: ONE workgroup of 4 wavefronts per CU with the whole 512-entry register file and 160 KB of LDS,
+//     a fully unrolled K loop whose LDS reads are base register + immediate (no address arithmetic),
+//     weights requested 4 steps ahead, and the next tile's halo loads (one 16-byte slot per K step, address
+//     = per-slot register + tile origin) issued between the MFMAs instead of as a burst in front of them.
+//
+// x-pair: 8 output channels fill half of a 16-row MFMA tile, so the rows are (x parity, channel): lane column
+// i holds the voxel PAIR (2i, 2i+1) and the K axis runs over the 4 x-offsets -1..2 the pair touches, the kernel
+// zero-padded accordingly (36 virtual taps instead of 27: 3/4 of the MFMA work is useful instead of 1/2).
+//
+// Tile: 4(z) x 8(y) x 32(x) output voxels per workgroup step, wavefront w owns plane z = w (8 accumulator
+// tiles of 16 voxel pairs).  LDS image [6][10][40 voxels][chunk]: even x in columns 0..19, odd x in columns
+// 20..39 (17 used each) so that a tap read is 16 consecutive voxels; the row pitch (40 voxels) is a multiple
+// of 512 bytes, which makes every (dz, dy, row) displacement an immediate offset that commutes with the bank
+// swizzle (bit 5 ^= bit 8).
+#include "conv_common.h"
+
+namespace {
+
+constexpr int XP_TZ = 4, XP_TY = 8, XP_TXV = 32;
+constexpr int XP_HZ = XP_TZ + 2, XP_HY = XP_TY + 2, XP_HX = XP_TXV + 2;
+constexpr int XP_RUN = 20, XP_HXP = 2 * XP_RUN;      // padded row: two runs of 20 voxels
+constexpr int XP_LOOK = 4;                           // weight look-ahead in K steps
+
+struct XpArgs {
+  const float* x;
+  const float* wp;       // packed weights, see atvs_conv_xp_pack
+  const float* zeros;    // 16 bytes of zeros (tail of the packed weights): source of the zero padding
+  const float* bias;
+  const float* res;
+  const float* pbias;    // (H, W, 24) or nullptr
+  float* y;
+  double* stats;
+  int Di, Hi, Wi, Cin;
+  int ldy, ycoff;
+  int nchunk;
+  int tiles_y, tiles_x, ntiles;
+  int relu;
+};
+
+__device__ __forceinline__ int xp_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
+
+// C4 = float4 channel groups per voxel of a chunk: 4 (16-channel chunks) or 2 (8-channel chunks).
+// K step j of a chunk:  C4 == 4: one virtual tap (dz,dy,xl) = (j/12, j/4%3, j%4), lane group q = channel group;
+//                       C4 == 2: two taps (dz,dy) = (j/6, j/2%3), xl = 2*(j%2) + (q>>1), channel group q&1.
+template <int C4>
+__global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int VB = C4 * 16;                      // bytes per voxel in LDS
+  constexpr int ROWB = XP_HXP * VB;                // bytes per image row
+  constexpr int SLOTS = XP_HZ * XP_HY * XP_HX * C4;
+  constexpr int MAXS = (SLOTS + 255) / 256;        // 16-byte halo slots per thread
+  constexpr int TPS = 4 / C4;                      // taps per K step
+  constexpr int JC = 36 / TPS;                     // K steps per chunk
+  constexpr int NB = 4 / TPS;                      // distinct x displacements per lane group
+  constexpr bool SWZ = (C4 == 4);
+  constexpr int CC = C4 * 4;                       // channels per chunk
+  static_assert(MAXS <= JC, "one halo slot per K step");
+  static_assert(((2 * XP_HY + 2) + 3) * ROWB < 65536, "ds_read immediate offset");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+
+  // ---- LDS read bases: (x displacement set, row group of 4) -> byte address of this lane's fragment for
+  // (dz, dy, row) = (-1, -1, 0); everything else is an immediate.
+  int base[NB][2];
+#pragma unroll
+  for (int xs = 0; xs < NB; ++xs) {
+    const int xl = (TPS == 1) ? xs : 2 * xs + (q >> 1);
+    const int cg = (TPS == 1) ? q : (q & 1);
+    const int xcol = (xl & 1) * XP_RUN + (xl >> 1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      int a = ((wave * XP_HY + 4 * g) * XP_HXP + xcol + r) * VB + cg * 16;
+      base[xs][g] = SWZ ? xp_swz(a) : a;
+    }
+  }
+
+  // ---- per-slot constants of this thread: global element offset from the halo origin, LDS byte address,
+  // and the packed halo coordinate (zz | yy<<8 | xx<<16, each byte with its top bit set) for the bounds test
+  int goff[MAXS], laddr[MAXS];
+  unsigned pg[MAXS];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < SLOTS;
+    s = min(s, SLOTS - 1);
+    const int c4 = s % C4, v = s / C4;
+    const int xx = v % XP_HX, v2 = v / XP_HX;
+    const int yy = v2 % XP_HY, zz = v2 / XP_HY;
+    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
+    int a = ((zz * XP_HY + yy) * XP_HXP + (xx & 1) * XP_RUN + (xx >> 1)) * VB + c4 * 16;
+    laddr[i] = SWZ ? xp_swz(a) : a;
+    pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+  }
+
+  // persistent tile list, dealt so that the workgroups of one XCD (blockIdx % 8) sweep one contiguous eighth
+  // of the tile range (halo re-use in that XCD's L2)
+  const int G = gridDim.x;
+  const int xcd = blockIdx.x & 7, tslot = blockIdx.x >> 3;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int slots_per_xcd = G >> 3;
+  int my_tiles = 0;
+  {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);
+    if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
+  }
+  const int nstage = my_tiles * p.nchunk;
+
+  auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
+    int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
+    int bx = tl % p.tiles_x;
+    int rest = tl / p.tiles_x;
+    *x0 = bx * XP_TXV;
+    *y0 = (rest % p.tiles_y) * XP_TY;
+    *z0 = (rest / p.tiles_y) * XP_TZ;
+  };
+
+  // uniform description of the (tile, chunk) whose halo is being fetched
+  struct PfTile {
+    const float* xb;      // p.x + first channel of the chunk
+    int org;              // element offset of the halo origin (may be negative: first layer of the halo is outside)
+    unsigned lo, hi1;     // packed bounds: valid iff lo_f <= f <= hi_f in every field (hi1 = hi + 1 per byte)
+  };
+  auto pf_tile = [&](int stage) __attribute__((always_inline)) {
+    PfTile T;
+    int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
+    T.xb = p.x + ch * CC;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
+    T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+    T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+            ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+    return T;
+  };
+  float4 pf[MAXS];
+  // slot i of the halo: lanes outside the volume (or past the last slot) read the 16 zero bytes instead
+  auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
+    const unsigned t1 = pg[i] - T.lo;          // byte f keeps its top bit iff f >= lo_f
+    const unsigned t2 = T.hi1 + ~pg[i];        // byte f has its top bit iff f <= hi_f
+    const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
+    const float* src = ok ? (T.xb + (T.org + goff[i])) : p.zeros;
+    pf[i] = ld4(src);
+  };
+
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[XP_TY];
+  const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wp);
+
+  if (nstage > 0) {
+    const PfTile T = pf_tile(0);
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) pf_slot(T, i);
+  }
+
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    if (ch == 0) {
+#pragma unroll
+      for (int t = 0; t < XP_TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // weights of the first steps: on their way while the image is written
+    const float4* wch = wp + (size_t)ch * JC * 64 + lane;
+    float4 w[JC];
+#pragma unroll
+    for (int jj = 0; jj < XP_LOOK; ++jj) w[jj] = wch[jj * 64];
+
+    __syncthreads();                       // every wave is done reading the previous stage's image
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i)
+      if (i < MAXS - 1 || tid + i * 256 < SLOTS) *reinterpret_cast<float4*>(smem + laddr[i]) = pf[i];
+    __syncthreads();
+
+    // ---- K loop, fully unrolled
+    const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
+    float4 b[2][XP_TY];
+    auto request_b = [&](int j) __attribute__((always_inline)) {
+      const int dzdy = j / NB, xs = j % NB;
+      const int rowoff = (dzdy / 3) * XP_HY + (dzdy % 3);
+#pragma unroll
+      for (int t = 0; t < XP_TY; ++t)
+        b[j & 1][t] = *reinterpret_cast<const float4*>(smem + base[xs][t >> 2] + (rowoff + (t & 3)) * ROWB);
+    };
+    request_b(0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int j = 0; j < JC; ++j) {
+      if (j + XP_LOOK < JC) w[j + XP_LOOK] = wch[(j + XP_LOOK) * 64];
+      if (j + 1 < JC) request_b(j + 1);
+      if (j < MAXS) pf_slot(T, j);
+      // compiler barrier (keeps InstCombine / the scheduler from sinking the requests to their uses) +
+      // scheduling barrier (keeps them in front of the MFMAs that cover their latency)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < XP_TY; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w[j], s), f4get(b[j & 1][t], s), acc[t], 0, 0, 0);
+    }
+    if (ch != p.nchunk - 1) continue;
+
+    // ---- epilogue: rows of the accumulator = (x parity, channel): this lane holds channels (q&1)*4..+3 of
+    // voxel x0 + 2r + (q>>1) for the 8 rows y0..y0+7 of plane z0 + wave
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int zo = z0 + wave;
+    const int xo = x0 + 2 * r + (q >> 1), co = (q & 1) * 4;
+    if (zo < p.Di && xo < p.Wi) {
+      const int pv = plane_variant(zo - 1, p.Di) * 8 + co;
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.bias) bv = ld4(p.bias + co);
+#pragma unroll
+      for (int t = 0; t < XP_TY; ++t) {
+        const int yo = y0 + t;
+        if (yo >= p.Hi) break;
+        const size_t vox = ((size_t)zo * p.Hi + yo) * p.Wi + xo;
+        const size_t o = vox * (size_t)p.ldy + p.ycoff + co;
+        float4 v = make_float4(acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w);
+        if (p.pbias) {
+          float4 pb = ld4(p.pbias + ((size_t)yo * p.Wi + xo) * 24 + pv);
+          v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
+        }
+        if (p.res) {
+          float4 rr = ld4(p.res + o);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+        if (p.relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+        st4(p.y + o, v);
+        ssum[0] += v.x; ssum[1] += v.y; ssum[2] += v.z; ssum[3] += v.w;
+        ssq[0] += v.x * v.x; ssq[1] += v.y * v.y; ssq[2] += v.z * v.z; ssq[3] += v.w * v.w;
+      }
+    }
+  }
+
+  // ---- per-workgroup partial moments (sum, sum of squares) per output channel -> row blockIdx of stats:
+  // [2][16] doubles, columns 0..7 = channels, 8..15 = 0 (the layout of the tiled kernel's x-pair form)
+  if (p.stats) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][8]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a = (double)ssum[kk], bq = (double)ssq[kk];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        bq += __shfl_xor(bq, o);
+      }
+      a += __shfl_xor(a, 32);      // lanes q and q^2 hold the same channels (the two x parities)
+      bq += __shfl_xor(bq, 32);
+      if (r == 0 && q < 2) {
+        s_red[(wave * 2 + 0) * 8 + q * 4 + kk] = a;
+        s_red[(wave * 2 + 1) * 8 + q * 4 + kk] = bq;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, col = tid & 15;
+      double v = 0.0;
+      if (col < 8)
+        v = (s_red[(0 * 2 + which) * 8 + col] + s_red[(1 * 2 + which) * 8 + col]) +
+            (s_red[(2 * 2 + which) * 8 + col] + s_red[(3 * 2 + which) * 8 + col]);
+      p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] = v;
+    }
+  }
+}
+
+int xp_c4(int Cin) { return (Cin % 16 == 0) ? 4 : ((Cin % 8 == 0) ? 2 : 0); }
+
+long xp_ntiles(int D, int H, int W) {
+  return (long)((D + XP_TZ - 1) / XP_TZ) * ((H + XP_TY - 1) / XP_TY) * ((W + XP_TXV - 1) / XP_TXV);
+}
+
+}  // namespace
+
+// Floats of the packed form of a [3,3,3,Cin,8] kernel (Cin % 8 == 0), including 4 trailing zeros.
+extern "C" int atvs_conv_xp_pack_size(int Cin, long* packed_floats) {
+  const int C4 = xp_c4(Cin);
+  if (Cin <= 0 || !C4 || !packed_floats) return ATVS_ERR_SHAPE;
+  const int nch = Cin / (4 * C4), JC = 36 * C4 / 4;
+  *packed_floats = (long)nch * JC * 64 * 4 + 4;
+  return ATVS_OK;
+}
+
+// HOST function.  w: TF kernel [3,3,3,Cin,8].  packed[chunk][K step][lane = q*16 + (jx*8 + co)][s]:
+// the x-pair virtual kernel Wv[(kd,kh,xl)][ci][jx][co] = W[kd][kh][kw = xl - jx][ci][co] (0 outside 0..2),
+// ordered as the kernel's K steps consume it.
+extern "C" int atvs_conv_xp_pack(const float* w, int Cin, float* packed) {
+  if (!w || !packed) return ATVS_ERR_NULL;
+  long pf;
+  int rc = atvs_conv_xp_pack_size(Cin, &pf);
+  if (rc) return rc;
+  const int C4 = xp_c4(Cin), TPS = 4 / C4, NB = 4 / TPS, JC = 36 / TPS, CC = 4 * C4, nch = Cin / CC;
+  for (long i = 0; i < pf; ++i) packed[i] = 0.f;
+  for (int ch = 0; ch < nch; ++ch)
+    for (int j = 0; j < JC; ++j)
+      for (int q = 0; q < 4; ++q) {
+        const int dzdy = j / NB, xs = j % NB;
+        const int kd = dzdy / 3, kh = dzdy % 3;
+        const int xl = (TPS == 1) ? xs : 2 * xs + (q >> 1);
+        const int cg = (TPS == 1) ? q : (q & 1);
+        for (int jx = 0; jx < 2; ++jx) {
+          const int kw = xl - jx;
+          if (kw < 0 || kw > 2) continue;
+          for (int co = 0; co < 8; ++co)
+            for (int s = 0; s < 4; ++s) {
+              const int ci = ch * CC + cg * 4 + s;
+              packed[((((size_t)ch * JC + j) * 64) + q * 16 + jx * 8 + co) * 4 + s] =
+                  w[((((size_t)kd * 3 + kh) * 3 + kw) * Cin + ci) * 8 + co];
+            }
+        }
+      }
+  return ATVS_OK;
+}
+
+// workgroups of a launch (= rows of the statistics buffer): one per CU, a multiple of 8
+extern "C" long atvs_conv_xp_grid(int D, int H, int W) {
+  long nt = xp_ntiles(D, H, W);
+  long g = nt < 256 ? nt : 256;
+  return (g + 7) / 8 * 8;
+}
+
+template <int C4>
+static int launch_xp1(const XpArgs& a, long blocks, hipStream_t s) {
+  size_t lds = (size_t)XP_HZ * XP_HY * XP_HXP * C4 * 16;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xp_kernel<C4>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return ATVS_ERR_LAUNCH;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((conv_xp_kernel<C4>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  return ATVS_OK;
+}
+
+// y[z,y,x, y_coff + co] = sum_taps W * x (+ bias, + plane_bias, + residual, ReLU), co < 8; x (D,H,W,Cin) with
+// Cin % 8 == 0; y (D,H,W,ldy).  stats_partial: atvs_conv_xp_grid rows of [2][16] doubles (or NULL).
+extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
+                                const float* plane_bias, float* y, double* stats_partial, int D, int H, int W, int Cin,
+                                int ldy, int y_coff, int relu, atvs_stream_t stream) {
+  if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  const int C4 = xp_c4(Cin);
+  if (D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || !C4) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if (residual && y_coff != 0) return ATVS_ERR_ARG;
+  if (plane_bias && D < 2) return ATVS_ERR_ARG;
+  if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;   // 31-bit element offsets
+  long pf;
+  atvs_conv_xp_pack_size(Cin, &pf);
+  XpArgs a;
+  a.x = x; a.wp = packed_w; a.zeros = packed_w + (pf - 4); a.bias = bias; a.res = residual; a.pbias = plane_bias;
+  a.y = y; a.stats = stats_partial;
+  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff;
+  a.nchunk = Cin / (4 * C4);
+  a.tiles_y = (H + XP_TY - 1) / XP_TY; a.tiles_x = (W + XP_TXV - 1) / XP_TXV;
+  a.ntiles = (int)xp_ntiles(D, H, W);
+  a.relu = relu;
+  const long blocks = atvs_conv_xp_grid(D, H, W);
+  int rc = (C4 == 4) ? launch_xp1<4>(a, blocks, as_stream(stream)) : launch_xp1<2>(a, blocks, as_stream(stream));
+  if (rc) return rc;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

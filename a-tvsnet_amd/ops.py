@@ -291,6 +291,63 @@ def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y, xpair
     return pk
 
 
+def pack_conv_xp(key, w_host, device):
+    """Packed weights of the one-workgroup-per-CU x-pair kernel (atvs_conv_xp_f32); cached."""
+    import numpy as np
+    ck = ('xp', key, str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)           # [3,3,3,Cin,8]
+    cin = w.shape[-2]
+    L = _lib.lib()
+    pf = ctypes.c_long()
+    rc = L.atvs_conv_xp_pack_size(cin, ctypes.byref(pf))
+    if rc:
+        raise RuntimeError('atvs_conv_xp_pack_size failed (%d) for Cin=%d' % (rc, cin))
+    packed = np.empty(pf.value, np.float32)
+    rc = L.atvs_conv_xp_pack(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv_xp_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 36, 4, 0, 1, cin, 8
+    pk.key = key
+    pk.tab = None
+    pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+def conv_xp_launch(x4, pk, y, y_coff, bias=None, residual=None, relu=False, stats_buf=None, plane_bias=None):
+    """One atvs_conv_xp_f32 launch: x4 (D,H,W,Cin) -> y (D,H,W,ldy)[..., y_coff:y_coff+8]."""
+    D, H, W, Cin = x4.shape
+    ldy = y.shape[-1]
+    if _dev_ok(x4, y, bias, residual, plane_bias):
+        timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _call('atvs_conv_xp_f32', _p(x4), _p(pk.wp), _p(bias), _p(residual), _p(plane_bias), _p(y),
+              ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W, Cin, ldy,
+              int(y_coff), int(bool(relu)), _stream())
+        if timed:
+            e1.record()
+            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
+
+
+def xp_blocks(D, H, W):
+    return int(_lib.lib().atvs_conv_xp_grid(int(D), int(H), int(W)))
+
+
+_USE_XP1W = True
+
+
+def use_xp1w(flag):
+    """Testing / A-B hook: the one-workgroup-per-CU x-pair kernel for Cout == 8, Cin % 8 == 0."""
+    global _USE_XP1W
+    _USE_XP1W = bool(flag)
+
+
 def tiled_tile_y(H, W, cout):
     """tile_y for the LDS-tiled kernel, or 0 when the gather kernel should be used."""
     if _FORCE_IMPL == 'gather':
@@ -531,7 +588,10 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         tile_y = tiled_tile_y(ins[1], ins[2], cout)
     xpair = bool(tile_y) and _USE_XPAIR and cout == 8 and (ins[2] >= 24 or _FORCE_IMPL == 'tiled') \
         and (out is None or (out.shape[-1] % 4 == 0 and y_coff % 4 == 0))
-    if xpair:
+    xp1w = xpair and _USE_XP1W and w_host.shape[-2] % 8 == 0
+    if xp1w:
+        pk = pack_conv_xp(key, w_host, x.device)
+    elif xpair:
         tile_y = 4 if w_host.shape[-2] > 8 else tile_y
         pk = pack_conv_weights_tiled(key, _xpair_virtual_kernel(key, w_host), XPAIR_TAPS, False, x.device, tile_y, True)
         pk.cout = 8
@@ -551,7 +611,9 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     if residual is not None:
         res4 = residual if residual.dim() == 4 else residual.reshape((1,) + tuple(residual.shape))
     M = outs[0] * outs[1] * outs[2]
-    if tile_y:
+    if xp1w:
+        blocks, tm = xp_blocks(outs[0], outs[1], outs[2]), 0
+    elif tile_y:
         blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout, xpair), 0
     else:
         blocks, tm = conv_blocks(M, pk.ntiles)
@@ -563,7 +625,9 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
     if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
         raise ValueError('conv %s: plane_bias %s, expected %s' % (key, tuple(plane_bias.shape), (outs[1], outs[2], 3 * pk.cout)))
-    if tile_y:
+    if xp1w:
+        conv_xp_launch(x4, pk, y4, y_coff, bias, res4, relu, sbuf, plane_bias)
+    elif tile_y:
         fin = None
         if want_stats and _FUSED_FINALIZE and pk.cout <= 64 and not x.is_meta:
             fin = Fin()

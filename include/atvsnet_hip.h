@@ -202,6 +202,22 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
                         int fin_arrivals, int fin_channels, int fin_fold, long fin_count, float fin_eps,
                         atvs_stream_t stream);
 
+/* conv / conv_bn(3, 8, 1) on a full-resolution volume -- 3x3x3 SAME stride-1 convolution to EIGHT output
+ * channels (conv_b*_0_1, global_refine_3dconv0_1, the refinement stems; cnn_wrapper/atvsnet.py, layer code
+ * cnn_wrapper/network.py:165-215), Cin % 8 == 0.  x-pair form (two x-adjacent voxels fill the 16 MFMA rows),
+ * ONE workgroup per CU with the whole register file and LDS, fully unrolled K loop (conv_xp.hip).
+ *   atvs_conv_xp_pack_size / _pack   HOST: pack the TF kernel [3,3,3,Cin,8] (upload the result)
+ *   atvs_conv_xp_grid                workgroups of a launch = rows of stats_partial ([2][16] doubles each,
+ *                                    columns 0..7 = channels, the layout atvs_bn_finalize takes with cpad 16)
+ *   atvs_conv_xp_f32                 y (D,H,W,ldy)[..., y_coff + co] = conv(x) (+ bias, + plane_bias (H,W,24),
+ *                                    + residual (only with y_coff 0), ReLU) */
+int atvs_conv_xp_pack_size(int Cin, long* packed_floats);
+int atvs_conv_xp_pack(const float* w, int Cin, float* packed);
+long atvs_conv_xp_grid(int D, int H, int W);
+int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
+                     const float* plane_bias, float* y, double* stats_partial, int D, int H, int W, int Cin,
+                     int ldy, int y_coff, int relu, atvs_stream_t stream);
+
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,
  * 242,336).  x (D,H,W,8); w = the TF kernel [3,3,3,8,1] (216 floats, device); y (D,H,W).

@@ -244,6 +244,45 @@ def test_split_volume_conv_matches_dense(cuda, impl, stride):
     _close(s[0, :8].float(), want.reshape(-1, 8).double().sum(0).float(), 1e-5)
 
 
+@pytest.mark.parametrize('xp1w', [True, False])
+@pytest.mark.parametrize('D,H,W,Cin', [(9, 19, 70, 32), (4, 8, 32, 16), (6, 21, 45, 8), (13, 9, 33, 24), (2, 3, 24, 16)])
+def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
+    """Both x-pair kernels for the 8-output-channel layers (one workgroup per CU / the tiled kernel's x-pair form):
+    ragged sizes, 16- and 8-channel chunks, with depth-plane bias + bias + residual + ReLU, written into a
+    channel slice of a wider (concat) buffer, statistics of what was written."""
+    from atvsnet_amd import ops
+    ops.use_xp1w(xp1w)
+    ops.clear_pack_cache()
+    try:
+        x = _rand((1, D, H, W, Cin), 50)
+        w = _rand((3, 3, 3, Cin, 8), 51, 0.2)
+        b = _rand((8,), 52)
+        pb = _rand((H, W, 24), 53)
+        want = T.conv(x, w, 1, 'SAME', bias=b)[0]
+        var = torch.ones(D, dtype=torch.long)
+        var[0], var[-1] = 0, 2
+        for z in range(D):
+            want[z] += pb[..., int(var[z]) * 8:int(var[z]) * 8 + 8]
+        # 1. plane bias + bias + ReLU into channels 4..11 of a 16-channel buffer
+        out = torch.full((D, H, W, 16), -7.0, device=cuda)
+        got, st = ops.conv(x[0].to(cuda), ('xp', D, H, W, Cin), w.numpy(), bias=b.to(cuda), relu=True, want_stats=True,
+                           out=out, y_coff=4, plane_bias=pb.to(cuda))
+        w1 = torch.clamp(want, min=0)
+        _close(out.cpu()[..., 4:12], w1)
+        assert float((out.cpu()[..., :4] + 7.0).abs().max()) == 0.0 and float((out.cpu()[..., 12:] + 7.0).abs().max()) == 0.0
+        s = st.partial.sum(0).cpu()
+        _close(s[0, :8].float(), w1.reshape(-1, 8).double().sum(0).float(), 1e-5)
+        _close(s[1, :8].float(), (w1.reshape(-1, 8).double() ** 2).sum(0).float(), 1e-5)
+        # 2. residual, no ReLU, dense output
+        res = _rand((D, H, W, 8), 54)
+        got2 = ops.conv(x[0].to(cuda), ('xp', D, H, W, Cin), w.numpy(), bias=b.to(cuda), residual=res.to(cuda),
+                        plane_bias=pb.to(cuda))
+        _close(got2.cpu(), want + res)
+    finally:
+        ops.use_xp1w(True)
+        ops.clear_pack_cache()
+
+
 @pytest.mark.parametrize('D,H,W', [(6, 8, 16), (5, 9, 21), (2, 3, 4), (16, 32, 40)])
 def test_conv3d_8to1_head(cuda, D, H, W):
     from atvsnet_amd import ops
@@ -265,6 +304,7 @@ def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
     x = _rand((D, H, W, cin), 50).to(cuda)
     w = _rand((3, 3, 3, cin, cout), 51, 0.2).numpy()
     ops.fused_finalize(True)
+    ops.use_xp1w(False)           # the in-launch finalize lives in the tiled kernel
     ref = None
     for it in range(12):
         y, st = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
@@ -278,4 +318,5 @@ def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
         assert torch.equal(fused, ref)
     ops.fused_finalize(False)
     y2, st2 = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
+    ops.use_xp1w(True)
     assert st2.params is None and torch.equal(y2, y)
