@@ -18,17 +18,33 @@
 // zero-padded accordingly (36 virtual taps instead of 27: 3/4 of the MFMA work is useful instead of 1/2).
 //
 // Tile: 4(z) x 8(y) x 32(x) output voxels per workgroup step, wavefront w owns plane z = w (8 accumulator
-// tiles of 16 voxel pairs).  LDS image [6][10][40 voxels][chunk]: even x in columns 0..19, odd x in columns
-// 20..39 (17 used each) so that a tap read is 16 consecutive voxels; the row pitch (40 voxels) is a multiple
+// tiles of 16 voxel pairs).  LDS image [6][10][40 voxels][chunk]: even x in columns 0..16, odd x in columns
+// 18..34 so that a tap read is 16 consecutive voxels; the row pitch (40 voxels) is a multiple
 // of 512 bytes, which makes every (dz, dy, row) displacement an immediate offset that commutes with the bank
 // swizzle (bit 5 ^= bit 8).
+#include <type_traits>
+
 #include "conv_common.h"
+
+// Development build (-DATVS_XP_DEBUG): per-wavefront cycle counts of the phases, read back with atvs_debug_read
+// (tools_dev/phase_times.py).
+#ifdef ATVS_XP_DEBUG
+__device__ unsigned long long atvs_dbg[4096 * 8];
+extern "C" int atvs_debug_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(atvs_dbg), sizeof(atvs_dbg));
+}
+#define DBG_T(i) { unsigned long long t_ = clock64(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; }
+#else
+#define DBG_T(i)
+#endif
 
 namespace {
 
 constexpr int XP_TZ = 4, XP_TY = 8, XP_TXV = 32;
 constexpr int XP_HZ = XP_TZ + 2, XP_HY = XP_TY + 2, XP_HX = XP_TXV + 2;
-constexpr int XP_RUN = 20, XP_HXP = 2 * XP_RUN;      // padded row: two runs of 20 voxels
+constexpr int XP_HXP = 40;       // voxels per image row: even x in columns 0..16, odd x in columns XP_ODD..XP_ODD+16
+constexpr int XP_ODD = 18;       // 18 * 64 B = 128 (mod 256): the even and the odd voxels that one 16-lane group
+                                 // of a halo write touches fall into different bank halves
 constexpr int XP_LOOK = 4;                           // weight look-ahead in K steps
 
 struct XpArgs {
@@ -78,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   for (int xs = 0; xs < NB; ++xs) {
     const int xl = (TPS == 1) ? xs : 2 * xs + (q >> 1);
     const int cg = (TPS == 1) ? q : (q & 1);
-    const int xcol = (xl & 1) * XP_RUN + (xl >> 1);
+    const int xcol = (xl & 1) * XP_ODD + (xl >> 1);
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
       int a = ((wave * XP_HY + 4 * g) * XP_HXP + xcol + r) * VB + cg * 16;
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     const int xx = v % XP_HX, v2 = v / XP_HX;
     const int yy = v2 % XP_HY, zz = v2 / XP_HY;
     goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
-    int a = ((zz * XP_HY + yy) * XP_HXP + (xx & 1) * XP_RUN + (xx >> 1)) * VB + c4 * 16;
+    int a = ((zz * XP_HY + yy) * XP_HXP + (xx & 1) * XP_ODD + (xx >> 1)) * VB + c4 * 16;
     laddr[i] = SWZ ? xp_swz(a) : a;
     pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
   }
@@ -156,6 +172,8 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   };
 
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);        // bias of this lane's 4 output channels
+  if (p.bias) bv = ld4(p.bias + (q & 1) * 4);
   f32x4 acc[XP_TY];
   const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wp);
 
@@ -165,8 +183,13 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     for (int i = 0; i < MAXS; ++i) pf_slot(T, i);
   }
 
+#ifdef ATVS_XP_DEBUG
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
   for (int stage = 0; stage < nstage; ++stage) {
     const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    DBG_T(6)
     if (ch == 0) {
 #pragma unroll
       for (int t = 0; t < XP_TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -178,13 +201,30 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     for (int jj = 0; jj < XP_LOOK; ++jj) w[jj] = wch[jj * 64];
 
     __syncthreads();                       // every wave is done reading the previous stage's image
+    DBG_T(0)
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < SLOTS) *reinterpret_cast<float4*>(smem + laddr[i]) = pf[i];
+    DBG_T(1)
     __syncthreads();
+    DBG_T(2)
 
     // ---- K loop, fully unrolled
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
+    // output addressing of this tile: this lane holds channels (q&1)*4..+3 of voxel x0 + 2r + (q>>1) for the
+    // 8 rows y0..y0+7 of plane z0 + wave (accumulator rows = (x parity, channel))
+    const bool last_chunk = (ch == p.nchunk - 1);
+    int tz0, ty0, tx0;
+    tile_origin(k, &tz0, &ty0, &tx0);
+    const int zo = tz0 + wave, xo = tx0 + 2 * r + (q >> 1), co = (q & 1) * 4;
+    const bool evox_ok = zo < p.Di && xo < p.Wi;
+    const size_t erow = (size_t)p.Wi * p.ldy;                                          // floats per output row
+    const size_t eo = (((size_t)zo * p.Hi + ty0) * p.Wi + xo) * (size_t)p.ldy + p.ycoff + co;
+    const size_t epb_off = ((size_t)ty0 * p.Wi + xo) * 24 + plane_variant(zo - 1, p.Di) * 8 + co;
+    auto erow_ok = [&](int t) __attribute__((always_inline)) { return evox_ok && ty0 + t < p.Hi; };
+    float4 epb[XP_TY], ers[XP_TY];
+#pragma unroll
+    for (int t = 0; t < XP_TY; ++t) epb[t] = ers[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     float4 b[2][XP_TY];
     auto request_b = [&](int j) __attribute__((always_inline)) {
       const int dzdy = j / NB, xs = j % NB;
@@ -200,6 +240,16 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
       if (j + XP_LOOK < JC) w[j + XP_LOOK] = wch[(j + XP_LOOK) * 64];
       if (j + 1 < JC) request_b(j + 1);
       if (j < MAXS) pf_slot(T, j);
+      // operands of the epilogue (depth-plane bias, residual) of the tile's last chunk: requested a few steps
+      // before the end of the K loop, so the epilogue never waits for them
+      if (j == JC - 4 && last_chunk && p.pbias) {
+#pragma unroll
+        for (int t = 0; t < XP_TY; ++t) epb[t] = ld4(erow_ok(t) ? p.pbias + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
+      }
+      if (j == JC - 3 && last_chunk && p.res) {
+#pragma unroll
+        for (int t = 0; t < XP_TY; ++t) ers[t] = ld4(erow_ok(t) ? p.res + (eo + (size_t)t * erow) : p.zeros);
+      }
       // compiler barrier (keeps InstCombine / the scheduler from sinking the requests to their uses) +
       // scheduling barrier (keeps them in front of the MFMAs that cover their latency)
       asm volatile("" ::: "memory");
@@ -210,43 +260,40 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
         for (int t = 0; t < XP_TY; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w[j], s), f4get(b[j & 1][t], s), acc[t], 0, 0, 0);
     }
+    DBG_T(4)
     if (ch != p.nchunk - 1) continue;
 
-    // ---- epilogue: rows of the accumulator = (x parity, channel): this lane holds channels (q&1)*4..+3 of
-    // voxel x0 + 2r + (q>>1) for the 8 rows y0..y0+7 of plane z0 + wave
-    int z0, y0, x0;
-    tile_origin(k, &z0, &y0, &x0);
-    const int zo = z0 + wave;
-    const int xo = x0 + 2 * r + (q >> 1), co = (q & 1) * 4;
-    if (zo < p.Di && xo < p.Wi) {
-      const int pv = plane_variant(zo - 1, p.Di) * 8 + co;
-      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.bias) bv = ld4(p.bias + co);
+    // ---- epilogue (no loads, no branches per row besides the bounds test)
+    auto store_rows = [&](auto relu_tag) __attribute__((always_inline)) {
 #pragma unroll
       for (int t = 0; t < XP_TY; ++t) {
-        const int yo = y0 + t;
-        if (yo >= p.Hi) break;
-        const size_t vox = ((size_t)zo * p.Hi + yo) * p.Wi + xo;
-        const size_t o = vox * (size_t)p.ldy + p.ycoff + co;
-        float4 v = make_float4(acc[t][0] + bv.x, acc[t][1] + bv.y, acc[t][2] + bv.z, acc[t][3] + bv.w);
-        if (p.pbias) {
-          float4 pb = ld4(p.pbias + ((size_t)yo * p.Wi + xo) * 24 + pv);
-          v.x += pb.x; v.y += pb.y; v.z += pb.z; v.w += pb.w;
+        if (!erow_ok(t)) continue;
+        float4 v;
+        v.x = ((acc[t][0] + bv.x) + epb[t].x) + ers[t].x;
+        v.y = ((acc[t][1] + bv.y) + epb[t].y) + ers[t].y;
+        v.z = ((acc[t][2] + bv.z) + epb[t].z) + ers[t].z;
+        v.w = ((acc[t][3] + bv.w) + epb[t].w) + ers[t].w;
+        if (decltype(relu_tag)::value) {          // NaN passes through, as in tf.nn.relu
+          v.x = (v.x < 0.f) ? 0.f : v.x;
+          v.y = (v.y < 0.f) ? 0.f : v.y;
+          v.z = (v.z < 0.f) ? 0.f : v.z;
+          v.w = (v.w < 0.f) ? 0.f : v.w;
         }
-        if (p.res) {
-          float4 rr = ld4(p.res + o);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        if (p.relu) {
-          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-        }
-        st4(p.y + o, v);
+        st4(p.y + (eo + (size_t)t * erow), v);
         ssum[0] += v.x; ssum[1] += v.y; ssum[2] += v.z; ssum[3] += v.w;
         ssq[0] += v.x * v.x; ssq[1] += v.y * v.y; ssq[2] += v.z * v.z; ssq[3] += v.w * v.w;
       }
-    }
+    };
+    if (p.relu) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
+    DBG_T(7)
   }
 
+#ifdef ATVS_XP_DEBUG
+  DBG_T(5)
+  if (lane == 0 && blockIdx.x < 1024)
+    for (int i = 0; i < 8; ++i) atvs_dbg[(blockIdx.x * 4 + wave) * 8 + i] = dbg_acc[i];
+#endif
   // ---- per-workgroup partial moments (sum, sum of squares) per output channel -> row blockIdx of stats:
   // [2][16] doubles, columns 0..7 = channels, 8..15 = 0 (the layout of the tiled kernel's x-pair form)
   if (p.stats) {

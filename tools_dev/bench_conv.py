@@ -7,18 +7,20 @@ import atvsnet_amd
 from atvsnet_amd import ops
 D, H, W, cin, cout = [int(v) for v in sys.argv[1:6]]
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+with_pb = len(sys.argv) > 7 and sys.argv[7] == 'pb'        # depth-plane bias (H, W, 3*cout), as the cost-volume layers have
 dev = torch.device('cuda:0')
 x = torch.randn(D, H, W, cin, device=dev)
 w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, cout)) * 0.1).astype(np.float32)
+pb = torch.randn(H, W, 3 * cout, device=dev) if with_pb else None
 for _ in range(2):
-    y, st = ops.conv(x, 'bench', w, want_stats=True)
+    y, st = ops.conv(x, 'bench', w, want_stats=True, plane_bias=pb)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(reps):
-    y, st = ops.conv(x, 'bench', w, want_stats=True)
+    y, st = ops.conv(x, 'bench', w, want_stats=True, plane_bias=pb)
 e1.record()
 torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / reps
 gf = 2.0 * 27 * cin * cout * D * H * W / 1e9
-print('conv %dx%dx%d %d->%d: %.3f ms  %.1f TF/s useful' % (D, H, W, cin, cout, ms, gf / ms))
+print('conv %dx%dx%d %d->%d%s: %.3f ms  %.1f TF/s useful' % (D, H, W, cin, cout, ' +plane bias' if with_pb else '', ms, gf / ms))

@@ -22,5 +22,5 @@ tot = b.sum(1).mean()
 print('waves %d  mean total cycles %.0f' % (len(b), tot))
 for i, n in enumerate(names):
     col = b[:, [0, 1, 2, 3, 4, 6, 5][i]] if False else b[:, i]
-for i, n in zip([6, 0, 1, 2, 3, 4, 5], ['loop top + acc zero', 'barrier1 (others finish K loop)', 'LDS write (+wait prefetch)', 'barrier2', 'prefetch issue', 'K loop', 'epilogue (incl. continue)']):
+for i, n in zip([7, 6, 0, 1, 2, 3, 4, 5], ['epilogue of a tile (conv_xp only)', 'loop top + acc zero', 'barrier1 (others finish K loop)', 'LDS write (+wait prefetch)', 'barrier2', 'prefetch issue', 'K loop', 'epilogue (incl. continue)']):
     print('%-36s mean %9.0f  (%.1f%%)  min %9.0f max %9.0f' % (n, b[:, i].mean(), 100 * b[:, i].mean() / tot, b[:, i].min(), b[:, i].max()))
