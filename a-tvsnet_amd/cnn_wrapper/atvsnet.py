@@ -24,12 +24,13 @@ def _stacked_unet(net, with_prob_head):
         else:
             src = n('0_0')
             net.feed(p('6_0'), p('0_1')).add(name=src)
+        # defer_bn: these layers are consumed by `add`s only, which normalise them on the fly.
+        # conv_b*_0_1 and the encoder branch conv_b*_1_0 read the same tensor: issued as siblings (one launch)
         (net.feed(src)
-            .conv_bn(3, f * 2, 2, name=n('1_0'))
+            .conv_bn_siblings(dict(kernel_size=3, filters=f, strides=1, name=n('0_1'), defer_bn=True),
+                              dict(kernel_size=3, filters=f * 2, strides=2, name=n('1_0')))
             .conv_bn(3, f * 4, 2, name=n('2_0'))
             .conv_bn(3, f * 8, 2, name=n('3_0')))
-        # defer_bn: these layers are consumed by `add`s only, which normalise them on the fly
-        net.feed(src).conv_bn(3, f, 1, name=n('0_1'), defer_bn=True)
         if b == 0:
             net.feed(n('1_0')).conv_bn(3, f * 2, 1, name=n('1_1'), defer_bn=True)
             net.feed(n('2_0')).conv_bn(3, f * 4, 1, name=n('2_1'), defer_bn=True)
@@ -165,10 +166,10 @@ class CostVolRefineNet(Network):
             stems.append(g + tag + '_3dconv')
         (self.feed(*stems)
              .concat(axis=-1, name=g + 'concat')
-             .conv_bn(3, f * 2, 2, name=g + '3dconv1_0')
+             .conv_bn_siblings(dict(kernel_size=3, filters=f, strides=1, name=g + '3dconv0_1', defer_bn=True),
+                               dict(kernel_size=3, filters=f * 2, strides=2, name=g + '3dconv1_0'))
              .conv_bn(3, f * 4, 2, name=g + '3dconv2_0')
              .conv_bn(3, f * 8, 2, name=g + '3dconv3_0'))
-        self.feed(g + 'concat').conv_bn(3, f, 1, name=g + '3dconv0_1', defer_bn=True)
         self.feed(g + '3dconv1_0').conv_bn(3, f * 2, 1, name=g + '3dconv1_1', defer_bn=True)
         self.feed(g + '3dconv2_0').conv_bn(3, f * 4, 1, name=g + '3dconv2_1', defer_bn=True)
         (self.feed(g + '3dconv3_0')

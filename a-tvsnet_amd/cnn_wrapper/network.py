@@ -247,6 +247,52 @@ class Network(object):
         return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None), c_off=c_off),
                                out_slice, filters)
 
+    def conv_bn_siblings(self, first, second):
+        """Extension: two conv_bn layers of the SAME input (the current terminal), e.g. the U-Net's conv_b*_0_1
+        (8 channels, stride 1) and its encoder branch conv_b*_1_0 (16 channels, stride 2) -- reference
+        cnn_wrapper/atvsnet.py feeds one tensor to both.  `first` / `second` are the keyword arguments of the two
+        conv_bn calls (kernel_size, filters, strides, name [, relu, defer_bn]).  When the kernels allow it both run
+        as ONE launch that stages the input once; otherwise this is exactly the two conv_bn calls.  Both outputs
+        are registered under their names; the terminal becomes `second` (so the encoder chain can continue)."""
+        if len(self.terminals) != 1:
+            raise RuntimeError('conv_bn_siblings takes one input')
+        src = self.terminals[0]
+        a, b = dict(first), dict(second)
+        plain = lambda d: (d.get('kernel_size', 3) == 3 and not d.get('center', False) and not d.get('biased', False)   # noqa: E731
+                           and d.get('padding', DEFAULT_PADDING) == 'SAME' and d.get('rate', 1) == 1
+                           and d.get('out_slice') is None)
+        shape = tuple(src.shape)
+        fusable = (self.training and len(shape) == 5 and shape[0] == 1 and plain(a) and plain(b)
+                   and a['strides'] == 1 and b['strides'] == 2 and not b.get('defer_bn', False)
+                   and not isinstance(src, ops.PendingBN))
+        if fusable:
+            if isinstance(src, ops.SplitVolume):
+                cin_var = src.var.shape[-1]
+                fusable = ops.siblings_ok(shape[1:4], cin_var, a['filters'], b['filters'])
+            else:
+                fusable = ops.siblings_ok(shape[1:4], shape[4], a['filters'], b['filters'])
+        if not fusable:
+            self.feed(src).conv_bn(**a)
+            self.feed(src).conv_bn(**b)
+            return self
+        cin = shape[4]
+        va, vb = '%s/conv3d/kernel' % a['name'], '%s/conv3d/kernel' % b['name']
+        wa = self._kernel(va, (3, 3, 3, cin, a['filters']))
+        wb = self._kernel(vb, (3, 3, 3, cin, b['filters']))
+        if isinstance(src, ops.SplitVolume):
+            (ya, sa), (yb, sb) = ops.conv_split_siblings(src, va, wa, vb, wb)
+        else:
+            (ya, sa), (yb, sb) = ops.conv_siblings(_b1(src, a['name']), va, wa, vb, wb)
+        if a.get('defer_bn', False):
+            out_a = ops.PendingBN(ya, ops.bn_params(sa, a['filters'], ya, None, BN_EPS), a.get('relu', True))
+        else:
+            out_a = self._bn(ya, sa, a['name'], False, a.get('relu', True)).unsqueeze(0)
+        out_b = self._bn(yb, sb, b['name'], False, b.get('relu', True)).unsqueeze(0)
+        self.layers[a['name']] = out_a
+        self.layers[b['name']] = out_b
+        self.feed(out_b)
+        return self
+
     def _slice_out(self, y, out_slice, filters):
         """Layer result: the dense tensor, or (for out_slice) a view of the concat buffer tagged for concat()."""
         if out_slice is None:

@@ -52,7 +52,6 @@ struct XpArgs {
   const float* wp;       // packed weights, see atvs_conv_xp_pack
   const float* zeros;    // 16 bytes of zeros (tail of the packed weights): source of the zero padding
   const float* bias;
-  const float* res;
   const float* pbias;    // (H, W, 24) or nullptr
   float* y;
   double* stats;
@@ -61,6 +60,14 @@ struct XpArgs {
   int nchunk;
   int tiles_y, tiles_x, ntiles;
   int relu;
+  // sibling: a second 3x3x3 convolution of the SAME input, stride 2, 16 output channels (the U-Net's encoder
+  // branch conv_b*_1_0 next to conv_b*_0_1), computed from the staged image after the main K loop
+  const float* wp2;      // packed sibling weights (atvs_conv_xp_pack_sibling) or nullptr
+  const float* pbias2;   // (Ho2, Wo2, 48) or nullptr
+  float* y2;
+  double* stats2;
+  int Do2, Ho2, Wo2, ldy2, ycoff2;
+  int pbz, pby, pbx;     // SAME padding in front of each axis (0 or 1)
 };
 
 __device__ __forceinline__ int xp_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
@@ -68,7 +75,12 @@ __device__ __forceinline__ int xp_swz(int a) { return a ^ (((a >> 8) & 1) << 5);
 // C4 = float4 channel groups per voxel of a chunk: 4 (16-channel chunks) or 2 (8-channel chunks).
 // K step j of a chunk:  C4 == 4: one virtual tap (dz,dy,xl) = (j/12, j/4%3, j%4), lane group q = channel group;
 //                       C4 == 2: two taps (dz,dy) = (j/6, j/2%3), xl = 2*(j%2) + (q>>1), channel group q&1.
-template <int C4>
+//
+// SIB: additionally the stride-2 sibling.  Its 2(z) x 4(y) x 16(x) outputs per tile read the same image (the
+// even / odd x runs make a stride-2 tap read 16 consecutive voxels as well); wavefront w owns output plane
+// w>>1, rows 2(w&1), 2(w&1)+1.  K steps:  C4 == 4: tap (kd,kh,kw) = (i/9, i/3%3, i%3), q = channel group;
+//                                        C4 == 2: (kd,kh) = (i/6, i/2%3), kw = 2*(i%2) + (q>>1) (kw 3 = zero), q&1.
+template <int C4, bool SIB>
 __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VB = C4 * 16;                      // bytes per voxel in LDS
@@ -80,6 +92,8 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   constexpr int NB = 4 / TPS;                      // distinct x displacements per lane group
   constexpr bool SWZ = (C4 == 4);
   constexpr int CC = C4 * 4;                       // channels per chunk
+  constexpr int J2 = SIB ? ((C4 == 4) ? 27 : 18) : 0;   // sibling K steps per chunk
+  constexpr int NB2 = (C4 == 4) ? 3 : 2;
   static_assert(MAXS <= JC, "one halo slot per K step");
   static_assert(((2 * XP_HY + 2) + 3) * ROWB < 65536, "ds_read immediate offset");
 
@@ -99,6 +113,21 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     for (int g = 0; g < 2; ++g) {
       int a = ((wave * XP_HY + 4 * g) * XP_HXP + xcol + r) * VB + cg * 16;
       base[xs][g] = SWZ ? xp_swz(a) : a;
+    }
+  }
+
+  // sibling read bases: this lane's fragment for tap (kd, kh) = (0, 0), output row 0 of the wavefront
+  int base2[NB2];
+  if (SIB) {
+#pragma unroll
+    for (int xs = 0; xs < NB2; ++xs) {
+      const int kw = (C4 == 4) ? xs : min(2 * xs + (q >> 1), 2);
+      const int cg = (C4 == 4) ? q : (q & 1);
+      const int xh = kw + 1 - p.pbx;                                  // halo x of output column 0
+      const int col = (xh & 1) * XP_ODD + (xh >> 1) + r;
+      const int row0 = (2 * (wave >> 1) + 1 - p.pbz) * XP_HY + (4 * (wave & 1) + 1 - p.pby);
+      int a = (row0 * XP_HXP + col) * VB + cg * 16;
+      base2[xs] = SWZ ? xp_swz(a) : a;
     }
   }
 
@@ -175,7 +204,10 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);        // bias of this lane's 4 output channels
   if (p.bias) bv = ld4(p.bias + (q & 1) * 4);
   f32x4 acc[XP_TY];
+  f32x4 acc2[2];
+  float ssum2[4] = {0.f, 0.f, 0.f, 0.f}, ssq2[4] = {0.f, 0.f, 0.f, 0.f};
   const float4* __restrict__ wp = reinterpret_cast<const float4*>(p.wp);
+  const float4* __restrict__ wp2 = reinterpret_cast<const float4*>(p.wp2);
 
   if (nstage > 0) {
     const PfTile T = pf_tile(0);
@@ -193,9 +225,11 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     if (ch == 0) {
 #pragma unroll
       for (int t = 0; t < XP_TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[0] = acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // weights of the first steps: on their way while the image is written
     const float4* wch = wp + (size_t)ch * JC * 64 + lane;
+    const float4* wch2 = wp2 + (size_t)ch * J2 * 64 + lane;
     float4 w[JC];
 #pragma unroll
     for (int jj = 0; jj < XP_LOOK; ++jj) w[jj] = wch[jj * 64];
@@ -222,10 +256,17 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     const size_t eo = (((size_t)zo * p.Hi + ty0) * p.Wi + xo) * (size_t)p.ldy + p.ycoff + co;
     const size_t epb_off = ((size_t)ty0 * p.Wi + xo) * 24 + plane_variant(zo - 1, p.Di) * 8 + co;
     auto erow_ok = [&](int t) __attribute__((always_inline)) { return evox_ok && ty0 + t < p.Hi; };
-    float4 epb[XP_TY], ers[XP_TY];
+    float4 epb[XP_TY], epb2[2];
 #pragma unroll
-    for (int t = 0; t < XP_TY; ++t) epb[t] = ers[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 b[2][XP_TY];
+    for (int t = 0; t < XP_TY; ++t) epb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    epb2[0] = epb2[1] = make_float4(0.f, 0.f, 0.f, 0.f);
+    // sibling outputs of this lane: channels 4q..4q+3 of voxel (tz0/2 + (wave>>1), ty0/2 + 2(wave&1) + t, tx0/2 + r)
+    const int zo2 = (tz0 >> 1) + (wave >> 1), yo2 = (ty0 >> 1) + 2 * (wave & 1), xo2 = (tx0 >> 1) + r;
+    const bool evox2_ok = SIB && zo2 < p.Do2 && xo2 < p.Wo2;
+    auto erow2_ok = [&](int t) __attribute__((always_inline)) { return evox2_ok && yo2 + t < p.Ho2; };
+    const size_t erow2 = (size_t)p.Wo2 * p.ldy2;
+    const size_t eo2 = (((size_t)zo2 * p.Ho2 + yo2) * p.Wo2 + xo2) * (size_t)p.ldy2 + p.ycoff2 + 4 * q;
+    float4 b[2][XP_TY], b2[2][2];
     auto request_b = [&](int j) __attribute__((always_inline)) {
       const int dzdy = j / NB, xs = j % NB;
       const int rowoff = (dzdy / 3) * XP_HY + (dzdy % 3);
@@ -233,22 +274,33 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
       for (int t = 0; t < XP_TY; ++t)
         b[j & 1][t] = *reinterpret_cast<const float4*>(smem + base[xs][t >> 2] + (rowoff + (t & 3)) * ROWB);
     };
+    auto request_b2 = [&](int i) __attribute__((always_inline)) {
+      const int kdkh = i / NB2, xs = i % NB2;
+      const int rowoff = (kdkh / 3) * XP_HY + (kdkh % 3);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        b2[i & 1][t] = *reinterpret_cast<const float4*>(smem + base2[xs] + (rowoff + 2 * t) * ROWB);
+    };
+    float4 w2[SIB ? J2 : 1];
     request_b(0);
     asm volatile("" ::: "memory");
 #pragma unroll
     for (int j = 0; j < JC; ++j) {
       if (j + XP_LOOK < JC) w[j + XP_LOOK] = wch[(j + XP_LOOK) * 64];
+      else if (SIB) w2[j + XP_LOOK - JC] = wch2[(j + XP_LOOK - JC) * 64];
       if (j + 1 < JC) request_b(j + 1);
+      else if (SIB) request_b2(0);
       if (j < MAXS) pf_slot(T, j);
-      // operands of the epilogue (depth-plane bias, residual) of the tile's last chunk: requested a few steps
-      // before the end of the K loop, so the epilogue never waits for them
+      // operands of the epilogues (depth-plane biases) of the tile's last chunk: requested a few steps before
+      // the end of the main K loop, so the epilogue never waits for them
       if (j == JC - 4 && last_chunk && p.pbias) {
 #pragma unroll
         for (int t = 0; t < XP_TY; ++t) epb[t] = ld4(erow_ok(t) ? p.pbias + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
       }
-      if (j == JC - 3 && last_chunk && p.res) {
+      if (SIB && j == JC - 3 && last_chunk && p.pbias2) {
+        const size_t o = ((size_t)yo2 * p.Wo2 + xo2) * 48 + plane_variant(2 * zo2 - p.pbz, p.Di) * 16 + 4 * q;
 #pragma unroll
-        for (int t = 0; t < XP_TY; ++t) ers[t] = ld4(erow_ok(t) ? p.res + (eo + (size_t)t * erow) : p.zeros);
+        for (int t = 0; t < 2; ++t) epb2[t] = ld4(erow2_ok(t) ? p.pbias2 + (o + (size_t)t * p.Wo2 * 48) : p.zeros);
       }
       // compiler barrier (keeps InstCombine / the scheduler from sinking the requests to their uses) +
       // scheduling barrier (keeps them in front of the MFMAs that cover their latency)
@@ -260,6 +312,21 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
         for (int t = 0; t < XP_TY; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w[j], s), f4get(b[j & 1][t], s), acc[t], 0, 0, 0);
     }
+    if (SIB) {
+      // ---- the sibling's K steps on the same image (weights and the first fragments are already on their way)
+#pragma unroll
+      for (int i = 0; i < J2; ++i) {
+        if (i + XP_LOOK < J2) w2[i + XP_LOOK] = wch2[(i + XP_LOOK) * 64];
+        if (i + 1 < J2) request_b2(i + 1);
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w2[i], s), f4get(b2[i & 1][t], s), acc2[t], 0, 0, 0);
+      }
+    }
     DBG_T(4)
     if (ch != p.nchunk - 1) continue;
 
@@ -269,10 +336,10 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
       for (int t = 0; t < XP_TY; ++t) {
         if (!erow_ok(t)) continue;
         float4 v;
-        v.x = ((acc[t][0] + bv.x) + epb[t].x) + ers[t].x;
-        v.y = ((acc[t][1] + bv.y) + epb[t].y) + ers[t].y;
-        v.z = ((acc[t][2] + bv.z) + epb[t].z) + ers[t].z;
-        v.w = ((acc[t][3] + bv.w) + epb[t].w) + ers[t].w;
+        v.x = (acc[t][0] + bv.x) + epb[t].x;
+        v.y = (acc[t][1] + bv.y) + epb[t].y;
+        v.z = (acc[t][2] + bv.z) + epb[t].z;
+        v.w = (acc[t][3] + bv.w) + epb[t].w;
         if (decltype(relu_tag)::value) {          // NaN passes through, as in tf.nn.relu
           v.x = (v.x < 0.f) ? 0.f : v.x;
           v.y = (v.y < 0.f) ? 0.f : v.y;
@@ -286,6 +353,16 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     };
     if (p.relu) store_rows(std::true_type{});
     else store_rows(std::false_type{});
+    if (SIB) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (!erow2_ok(t)) continue;
+        float4 v = make_float4(acc2[t][0] + epb2[t].x, acc2[t][1] + epb2[t].y, acc2[t][2] + epb2[t].z, acc2[t][3] + epb2[t].w);
+        st4(p.y2 + (eo2 + (size_t)t * erow2), v);
+        ssum2[0] += v.x; ssum2[1] += v.y; ssum2[2] += v.z; ssum2[3] += v.w;
+        ssq2[0] += v.x * v.x; ssq2[1] += v.y * v.y; ssq2[2] += v.z * v.z; ssq2[3] += v.w * v.w;
+      }
+    }
     DBG_T(7)
   }
 
@@ -322,6 +399,30 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
         v = (s_red[(0 * 2 + which) * 8 + col] + s_red[(1 * 2 + which) * 8 + col]) +
             (s_red[(2 * 2 + which) * 8 + col] + s_red[(3 * 2 + which) * 8 + col]);
       p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] = v;
+    }
+  }
+  if (SIB && p.stats2) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a = (double)ssum2[kk], bq = (double)ssq2[kk];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        bq += __shfl_xor(bq, o);
+      }
+      if (r == 0) {
+        s_red[(wave * 2 + 0) * 16 + q * 4 + kk] = a;
+        s_red[(wave * 2 + 1) * 16 + q * 4 + kk] = bq;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, col = tid & 15;
+      p.stats2[((size_t)blockIdx.x * 2 + which) * 16 + col] =
+          (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
+          (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
     }
   }
 }
@@ -381,44 +482,94 @@ extern "C" long atvs_conv_xp_grid(int D, int H, int W) {
   return (g + 7) / 8 * 8;
 }
 
-template <int C4>
+// Floats of the packed sibling kernel [3,3,3,Cin,16].
+extern "C" int atvs_conv_xp_pack_sibling_size(int Cin, long* packed_floats) {
+  const int C4 = xp_c4(Cin);
+  if (Cin <= 0 || !C4 || !packed_floats) return ATVS_ERR_SHAPE;
+  const int nch = Cin / (4 * C4), J2 = (C4 == 4) ? 27 : 18;
+  *packed_floats = (long)nch * J2 * 64 * 4;
+  return ATVS_OK;
+}
+
+// HOST function.  w2: TF kernel [3,3,3,Cin,16] of the stride-2 sibling.  packed[chunk][K step][lane = q*16 + co][s].
+extern "C" int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed) {
+  if (!w2 || !packed) return ATVS_ERR_NULL;
+  long pf;
+  int rc = atvs_conv_xp_pack_sibling_size(Cin, &pf);
+  if (rc) return rc;
+  const int C4 = xp_c4(Cin), NB2 = (C4 == 4) ? 3 : 2, J2 = (C4 == 4) ? 27 : 18, CC = 4 * C4, nch = Cin / CC;
+  for (long i = 0; i < pf; ++i) packed[i] = 0.f;
+  for (int ch = 0; ch < nch; ++ch)
+    for (int j = 0; j < J2; ++j)
+      for (int q = 0; q < 4; ++q) {
+        const int kdkh = j / NB2, xs = j % NB2;
+        const int kd = kdkh / 3, kh = kdkh % 3;
+        const int kw = (C4 == 4) ? xs : 2 * xs + (q >> 1);
+        const int cg = (C4 == 4) ? q : (q & 1);
+        if (kw > 2) continue;
+        for (int co = 0; co < 16; ++co)
+          for (int s = 0; s < 4; ++s) {
+            const int ci = ch * CC + cg * 4 + s;
+            packed[((((size_t)ch * J2 + j) * 64) + q * 16 + co) * 4 + s] =
+                w2[((((size_t)kd * 3 + kh) * 3 + kw) * Cin + ci) * 16 + co];
+          }
+      }
+  return ATVS_OK;
+}
+
+template <int C4, bool SIB>
 static int launch_xp1(const XpArgs& a, long blocks, hipStream_t s) {
   size_t lds = (size_t)XP_HZ * XP_HY * XP_HXP * C4 * 16;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xp_kernel<C4>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xp_kernel<C4, SIB>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((conv_xp_kernel<C4>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_xp_kernel<C4, SIB>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
-// y[z,y,x, y_coff + co] = sum_taps W * x (+ bias, + plane_bias, + residual, ReLU), co < 8; x (D,H,W,Cin) with
-// Cin % 8 == 0; y (D,H,W,ldy).  stats_partial: atvs_conv_xp_grid rows of [2][16] doubles (or NULL).
-extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
-                                const float* plane_bias, float* y, double* stats_partial, int D, int H, int W, int Cin,
-                                int ldy, int y_coff, int relu, atvs_stream_t stream) {
+// y[z,y,x, y_coff + co] = sum_taps W * x (+ bias, + plane_bias, ReLU), co < 8; x (D,H,W,Cin) with Cin % 8 == 0;
+// y (D,H,W,ldy).  stats_partial: atvs_conv_xp_grid rows of [2][16] doubles (or NULL).
+// Sibling (packed_w2 != NULL): y2 (ceil(D/2), ceil(H/2), ceil(W/2), ldy2)[..., y_coff2 + co] = the 3x3x3 SAME
+// stride-2 convolution of the same x with a [3,3,3,Cin,16] kernel (+ plane_bias2 (Ho2, Wo2, 48)), its partial
+// moments in stats_partial2 (same rows, 16 channels).
+extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias,
+                                float* y, double* stats_partial, int D, int H, int W, int Cin, int ldy, int y_coff,
+                                int relu, const float* packed_w2, const float* plane_bias2, float* y2,
+                                double* stats_partial2, int ldy2, int y_coff2, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   const int C4 = xp_c4(Cin);
   if (D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || !C4) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
-  if (residual && y_coff != 0) return ATVS_ERR_ARG;
   if (plane_bias && D < 2) return ATVS_ERR_ARG;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;   // 31-bit element offsets
+  if (packed_w2) {
+    if (!y2) return ATVS_ERR_NULL;
+    if (y_coff2 < 0 || y_coff2 + 16 > ldy2 || (ldy2 % 4) || (y_coff2 % 4)) return ATVS_ERR_SHAPE;
+  } else if (plane_bias2 || y2 || stats_partial2) {
+    return ATVS_ERR_ARG;
+  }
   long pf;
   atvs_conv_xp_pack_size(Cin, &pf);
   XpArgs a;
-  a.x = x; a.wp = packed_w; a.zeros = packed_w + (pf - 4); a.bias = bias; a.res = residual; a.pbias = plane_bias;
+  a.x = x; a.wp = packed_w; a.zeros = packed_w + (pf - 4); a.bias = bias; a.pbias = plane_bias;
   a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff;
   a.nchunk = Cin / (4 * C4);
   a.tiles_y = (H + XP_TY - 1) / XP_TY; a.tiles_x = (W + XP_TXV - 1) / XP_TXV;
   a.ntiles = (int)xp_ntiles(D, H, W);
   a.relu = relu;
+  a.wp2 = packed_w2; a.pbias2 = plane_bias2; a.y2 = y2; a.stats2 = stats_partial2;
+  a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
+  a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;      // tf SAME, kernel 3, stride 2: one leading pad iff the size is odd
   const long blocks = atvs_conv_xp_grid(D, H, W);
-  int rc = (C4 == 4) ? launch_xp1<4>(a, blocks, as_stream(stream)) : launch_xp1<2>(a, blocks, as_stream(stream));
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (packed_w2) rc = (C4 == 4) ? launch_xp1<4, true>(a, blocks, st) : launch_xp1<2, true>(a, blocks, st);
+  else rc = (C4 == 4) ? launch_xp1<4, false>(a, blocks, st) : launch_xp1<2, false>(a, blocks, st);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

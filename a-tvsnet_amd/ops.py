@@ -318,21 +318,54 @@ def pack_conv_xp(key, w_host, device):
     return pk
 
 
-def conv_xp_launch(x4, pk, y, y_coff, bias=None, residual=None, relu=False, stats_buf=None, plane_bias=None):
-    """One atvs_conv_xp_f32 launch: x4 (D,H,W,Cin) -> y (D,H,W,ldy)[..., y_coff:y_coff+8]."""
+def pack_conv_xp_sibling(key, w_host, device):
+    """Packed weights of the stride-2 sibling [3,3,3,Cin,16] of an x-pair launch; cached."""
+    import numpy as np
+    ck = ('xp2', key, str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)
+    cin = w.shape[-2]
+    if w.shape[-1] != 16:
+        raise ValueError('x-pair sibling: 16 output channels, got %d' % w.shape[-1])
+    L = _lib.lib()
+    pf = ctypes.c_long()
+    rc = L.atvs_conv_xp_pack_sibling_size(cin, ctypes.byref(pf))
+    if rc:
+        raise RuntimeError('atvs_conv_xp_pack_sibling_size failed (%d) for Cin=%d' % (rc, cin))
+    packed = np.empty(pf.value, np.float32)
+    rc = L.atvs_conv_xp_pack_sibling(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv_xp_pack_sibling failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, 16
+    pk.key = key
+    pk.tab = None
+    pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+def conv_xp_launch(x4, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None):
+    """One atvs_conv_xp_f32 launch: x4 (D,H,W,Cin) -> y (D,H,W,ldy)[..., y_coff:y_coff+8].
+    sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x4."""
     D, H, W, Cin = x4.shape
     ldy = y.shape[-1]
-    if _dev_ok(x4, y, bias, residual, plane_bias):
+    null = ctypes.c_void_p(0)
+    sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null     # noqa: E731
+    pk2, y2, y_coff2, sbuf2, pb2 = sibling if sibling is not None else (None, None, 0, None, None)
+    if _dev_ok(x4, y, bias, plane_bias, y2, pb2):
         timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
         if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _call('atvs_conv_xp_f32', _p(x4), _p(pk.wp), _p(bias), _p(residual), _p(plane_bias), _p(y),
-              ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W, Cin, ldy,
-              int(y_coff), int(bool(relu)), _stream())
+        _call('atvs_conv_xp_f32', _p(x4), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), D, H, W, Cin, ldy,
+              int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2), sp(sbuf2),
+              int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _stream())
         if timed:
             e1.record()
-            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
+            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout + (16 if pk2 is not None else 0)))
 
 
 def xp_blocks(D, H, W):
@@ -588,7 +621,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         tile_y = tiled_tile_y(ins[1], ins[2], cout)
     xpair = bool(tile_y) and _USE_XPAIR and cout == 8 and (ins[2] >= 24 or _FORCE_IMPL == 'tiled') \
         and (out is None or (out.shape[-1] % 4 == 0 and y_coff % 4 == 0))
-    xp1w = xpair and _USE_XP1W and w_host.shape[-2] % 8 == 0
+    xp1w = xpair and _USE_XP1W and w_host.shape[-2] % 8 == 0 and residual is None
     if xp1w:
         pk = pack_conv_xp(key, w_host, x.device)
     elif xpair:
@@ -626,7 +659,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
         raise ValueError('conv %s: plane_bias %s, expected %s' % (key, tuple(plane_bias.shape), (outs[1], outs[2], 3 * pk.cout)))
     if xp1w:
-        conv_xp_launch(x4, pk, y4, y_coff, bias, res4, relu, sbuf, plane_bias)
+        conv_xp_launch(x4, pk, y4, y_coff, bias, relu, sbuf, plane_bias)
     elif tile_y:
         fin = None
         if want_stats and _FUSED_FINALIZE and pk.cout <= 64 and not x.is_meta:
@@ -722,6 +755,57 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
     wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
     pb = conv(sv.const, (key, 'planes'), planes, stride=stride)            # (ho, wo, 3*Cout)
     return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb, out=out, y_coff=y_coff)
+
+
+def siblings_ok(shape, cin, cout, cout2):
+    """Can conv(8 channels, stride 1) and conv(16 channels, stride 2) of one (D,H,W,cin) input share a launch?"""
+    return (_USE_XP1W and _USE_XPAIR and _USE_SIBLINGS and _FORCE_IMPL != 'gather' and len(shape) == 3 and cout == 8
+            and cout2 == 16 and cin % 8 == 0 and (shape[2] >= 24 or _FORCE_IMPL == 'tiled'))
+
+
+_USE_SIBLINGS = True
+
+
+def use_siblings(flag):
+    """Testing / A-B hook for the fused stride-2 sibling of the x-pair kernel."""
+    global _USE_SIBLINGS
+    _USE_SIBLINGS = bool(flag)
+
+
+def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None):
+    """The U-Net's two convolutions of one input in ONE launch: y = conv3x3x3(x, w) (8 channels, stride 1) and
+    y2 = conv3x3x3(x, w2) (16 channels, stride 2, SAME), each with the partial moments of its output.
+    x (D,H,W,Cin), Cin % 8 == 0.  Returns (y, Stats), (y2, Stats)."""
+    D, H, W, cin = x.shape
+    if not siblings_ok((D, H, W), cin, int(w_host.shape[-1]), int(w2_host.shape[-1])):
+        raise ValueError('conv_siblings: unsupported shapes')
+    pk = pack_conv_xp(key, w_host, x.device)
+    pk2 = pack_conv_xp_sibling(key2, w2_host, x.device)
+    if pk.cin != cin or pk2.cin != cin:
+        raise ValueError('conv_siblings %s: input has %d channels' % (key, cin))
+    D2, H2, W2 = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    y, y2 = _new(x, (D, H, W, 8)), _new(x, (D2, H2, W2, 16))
+    blocks = xp_blocks(D, H, W)
+    sbuf, sbuf2 = _stats_buffer(x, blocks, 16), _stats_buffer(x, blocks, 16)
+    st, st2 = Stats(), Stats()
+    st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, 16, D * H * W
+    st2.partial, st2.blocks, st2.cpad, st2.count = sbuf2, blocks, 16, D2 * H2 * W2
+    if plane_bias is not None and tuple(plane_bias.shape) != (H, W, 24):
+        raise ValueError('conv_siblings %s: plane_bias %s' % (key, tuple(plane_bias.shape)))
+    if plane_bias2 is not None and tuple(plane_bias2.shape) != (H2, W2, 48):
+        raise ValueError('conv_siblings %s: plane_bias2 %s' % (key2, tuple(plane_bias2.shape)))
+    conv_xp_launch(x, pk, y, 0, None, False, sbuf, plane_bias, sibling=(pk2, y2, 0, sbuf2, plane_bias2))
+    return (y, st), (y2, st2)
+
+
+def conv_split_siblings(sv, key, w_host, key2, w2_host):
+    """conv_siblings over a SplitVolume: the D-constant channels enter both outputs as depth-plane biases."""
+    cv, cc = sv.var.shape[-1], sv.const.shape[-1]
+    wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
+    wv2, planes2 = _fold_split_weights(key2, w2_host, sv.chan_map, cv, cc)
+    pb = conv(sv.const, (key, 'planes'), planes, stride=1)
+    pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2)
+    return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2)
 
 
 _DECONV_OFFSETS = [(a, b, c) for a in (0, -1) for b in (0, -1) for c in (0, -1)]

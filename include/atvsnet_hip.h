@@ -209,14 +209,21 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
  *   atvs_conv_xp_pack_size / _pack   HOST: pack the TF kernel [3,3,3,Cin,8] (upload the result)
  *   atvs_conv_xp_grid                workgroups of a launch = rows of stats_partial ([2][16] doubles each,
  *                                    columns 0..7 = channels, the layout atvs_bn_finalize takes with cpad 16)
- *   atvs_conv_xp_f32                 y (D,H,W,ldy)[..., y_coff + co] = conv(x) (+ bias, + plane_bias (H,W,24),
- *                                    + residual (only with y_coff 0), ReLU) */
+ *   atvs_conv_xp_f32                 y (D,H,W,ldy)[..., y_coff + co] = conv(x) (+ bias, + plane_bias (H,W,24), ReLU)
+ * Sibling: the U-Nets feed the same tensor to conv_b*_0_1 (8 channels, stride 1) and to the encoder branch
+ * conv_b*_1_0 (16 channels, stride 2; cnn_wrapper/atvsnet.py StackedUNet, CostVolRefineNet 0_1 / 1_0).  With
+ * packed_w2 != NULL (atvs_conv_xp_pack_sibling of the TF kernel [3,3,3,Cin,16]) the launch also writes
+ * y2 (ceil(D/2), ceil(H/2), ceil(W/2), ldy2)[..., y_coff2 + co] = that stride-2 SAME convolution (+ plane_bias2
+ * (Ho2, Wo2, 48)) from the tile already staged in LDS, and its moments into stats_partial2 (same rows). */
 int atvs_conv_xp_pack_size(int Cin, long* packed_floats);
 int atvs_conv_xp_pack(const float* w, int Cin, float* packed);
+int atvs_conv_xp_pack_sibling_size(int Cin, long* packed_floats);
+int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed);
 long atvs_conv_xp_grid(int D, int H, int W);
-int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
-                     const float* plane_bias, float* y, double* stats_partial, int D, int H, int W, int Cin,
-                     int ldy, int y_coff, int relu, atvs_stream_t stream);
+int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias, float* y,
+                     double* stats_partial, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                     const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
+                     int y_coff2, atvs_stream_t stream);
 
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,

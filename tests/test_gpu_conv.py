@@ -283,6 +283,59 @@ def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
         ops.clear_pack_cache()
 
 
+@pytest.mark.parametrize('D,H,W,Cin', [(8, 16, 64, 32), (9, 19, 70, 16), (6, 21, 45, 8), (5, 8, 33, 24), (4, 7, 32, 8)])
+def test_conv_siblings_one_launch(cuda, D, H, W, Cin):
+    """conv(8 channels, stride 1) and conv(16 channels, stride 2, SAME) of one input from ONE launch equal the two
+    separate convolutions (even and odd sizes: the stride-2 SAME padding moves), with plane biases and statistics."""
+    from atvsnet_amd import ops
+    ops.clear_pack_cache()
+    x = _rand((1, D, H, W, Cin), 60)
+    w = _rand((3, 3, 3, Cin, 8), 61, 0.2)
+    w2 = _rand((3, 3, 3, Cin, 16), 62, 0.2)
+    D2, H2, W2 = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
+    pb, pb2 = _rand((H, W, 24), 63), _rand((H2, W2, 48), 64)
+    want = T.conv(x, w, 1, 'SAME')[0]
+    want2 = T.conv(x, w2, 2, 'SAME')[0]
+    assert tuple(want2.shape) == (D2, H2, W2, 16)
+    for z in range(D):
+        v = 0 if z == 0 else (2 if z == D - 1 else 1)
+        want[z] += pb[..., v * 8:v * 8 + 8]
+    pz = D % 2
+    for z in range(D2):
+        first = 2 * z - pz
+        v = 0 if first < 0 else (2 if first + 2 >= D else 1)
+        want2[z] += pb2[..., v * 16:v * 16 + 16]
+    (y, st), (y2, st2) = ops.conv_siblings(x[0].to(cuda), ('sib', D, H, W, Cin), w.numpy(), ('sib2', D, H, W, Cin), w2.numpy(),
+                                           plane_bias=pb.to(cuda), plane_bias2=pb2.to(cuda))
+    _close(y.cpu(), want)
+    _close(y2.cpu(), want2)
+    for got_st, ref, C in ((st, want, 8), (st2, want2, 16)):
+        s = got_st.partial.sum(0).cpu()
+        _close(s[0, :C].float(), ref.reshape(-1, C).double().sum(0).float(), 1e-5)
+        _close(s[1, :C].float(), (ref.reshape(-1, C).double() ** 2).sum(0).float(), 1e-5)
+        assert got_st.count == ref.shape[0] * ref.shape[1] * ref.shape[2]
+    # without plane biases
+    (y, _), (y2, _) = ops.conv_siblings(x[0].to(cuda), ('sib', D, H, W, Cin), w.numpy(), ('sib2', D, H, W, Cin), w2.numpy())
+    _close(y2.cpu(), T.conv(x, w2, 2, 'SAME')[0])
+    _close(y.cpu(), T.conv(x, w, 1, 'SAME')[0])
+
+
+def test_conv_split_siblings_match_dense(cuda):
+    from atvsnet_amd import ops
+    ops.clear_pack_cache()
+    D, h, w = 6, 16, 40
+    var = _rand((D, h, w, 8), 70)
+    const = _rand((h, w, 5), 71)
+    cmap = [('c', i) for i in range(5)] + [('v', i) for i in range(8)] + [('v', 3), ('c', 1)]
+    dense = torch.cat([const[None].expand(D, -1, -1, -1), var, var[..., 3:4], const[None, ..., 1:2].expand(D, -1, -1, -1)], -1)
+    w1 = _rand((3, 3, 3, 15, 8), 72, 0.3)
+    w2 = _rand((3, 3, 3, 15, 16), 73, 0.3)
+    sv = ops.SplitVolume(var.to(cuda), const.to(cuda), cmap)
+    (y, st), (y2, st2) = ops.conv_split_siblings(sv, 'ss1', w1.numpy(), 'ss2', w2.numpy())
+    _close(y.cpu(), T.conv(dense[None], w1, 1, 'SAME')[0])
+    _close(y2.cpu(), T.conv(dense[None], w2, 2, 'SAME')[0])
+
+
 @pytest.mark.parametrize('D,H,W', [(6, 8, 16), (5, 9, 21), (2, 3, 4), (16, 32, 40)])
 def test_conv3d_8to1_head(cuda, D, H, W):
     from atvsnet_amd import ops
