@@ -15,10 +15,11 @@ forked and joined inside it); --eager issues every launch from Python instead.
 the SAME depth map are sharded over the ranks and aggregated with RCCL all-reduces inside both
 AANet modules (a-tvsnet_amd/parallel.py); total work is fixed -> "scaling": "strong".
 
-One JSON line on rank 0; `roofline` is for the dominant kernel (the 3x3x3 convolution of the 32
-warped channels of conv_b0_0_1 at full resolution), timed with HIP events on its launch stream;
-`roofline.traffic` is the HBM traffic of that launch from rocprofv3 PMC passes recorded in
-profiles/round1_pmc_dominant_kernel.json (WRITE_SIZE + FETCH_SIZE, see the note there);
+One JSON line on rank 0; `roofline` is for the dominant kernel (conv_xp.hip: the 3x3x3 convolution of
+the 32 warped channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0,
+one launch), timed with HIP events on its launch stream; `roofline.traffic` is the HBM traffic of that
+launch from rocprofv3 PMC passes recorded in profiles/round1_pmc_dominant_kernel_v2.json (WRITE_SIZE +
+FETCH_SIZE, see the note there);
 `cpu_baseline` is the CPU oracle on the host cores over a bounded sample.
 """
 import argparse
@@ -117,7 +118,7 @@ def pmc_traffic(args):
     if (args.width, args.height, args.depths) != (WIDTH, HEIGHT, DEPTHS):
         return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'round1_pmc_dominant_kernel.json')) as f:
+        with open(os.path.join(ROOT, 'profiles', 'round1_pmc_dominant_kernel_v2.json')) as f:
             d = json.load(f)['derived']
         return d['write_bytes_pmc'] + d['fetch_bytes_pmc_raw']      # bytes per launch
     except Exception:
@@ -194,18 +195,25 @@ def main():
     if rank == 0:
         h, w = args.height // 4, args.width // 4
         vox = args.depths * h * w
-        # conv_b0_0_1 (3x3x3, 64 -> 8, stride 1, SAME): its 32 D-constant input channels (the tiled reference
-        # features) are a per-plane bias, so the launch convolves the 32 warped channels: 2*27*32*8 FLOP per voxel
-        flops = 2.0 * 27 * 32 * 8 * vox
+        # conv_b0_0_1 (3x3x3, 64 -> 8, stride 1, SAME) and conv_b0_1_0 (3x3x3, 64 -> 16, stride 2, SAME) read the same
+        # cost volume and run as ONE launch.  Their 32 D-constant input channels (the tiled reference features) are
+        # per-plane biases, so the launch convolves the 32 warped channels: 2*27*32*8 FLOP per voxel + 2*27*32*16 FLOP
+        # per half-resolution voxel.  Without the sibling (ops.use_siblings(False)) only the first term applies.
+        from atvsnet_amd import ops as _ops
+        vox2 = ((args.depths + 1) // 2) * ((h + 1) // 2) * ((w + 1) // 2)
+        sib = _ops.siblings_ok((args.depths, h, w), 32, 8, 16)
+        flops = 2.0 * 27 * 32 * 8 * vox + (2.0 * 27 * 32 * 16 * vox2 if sib else 0.0)
+        alg_bytes = 4 * (32 * vox + 8 * vox + (16 * vox2 if sib else 0))
         roof = None
         if watched:
             avg_ms = float(np.mean(watched))
             ach = flops / (avg_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'conv_tiled_f32_kernel<NT=1,TY=4,C4=4,x-pair> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full resolution)',
+            roof = {'bound': 'mfma', 'kernel': 'conv_xp_kernel<C4=4,SIB> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full resolution, + sibling '
+                                              'conv_b0_1_0: -> 16, stride 2)',
                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(args),
                     'traffic_note': 'HBM bytes per launch, WRITE_SIZE + FETCH_SIZE (rocprofv3 --pmc, profiles/'
-                                    'round1_pmc_dominant_kernel.json); algorithmic bytes 629145600',
+                                    'round1_pmc_dominant_kernel_v2.json); algorithmic bytes %d' % alg_bytes,
                     'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched),
                     'algorithmic_flops_per_launch': flops}
         line = {
