@@ -91,7 +91,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   int* s_tab = reinterpret_cast<int*>(smem + SLOTS * 16);
-  for (int i = tid; i < p.Jc * 4; i += 256) s_tab[i] = p.tab[i];
+  for (int i = tid; i < p.Jc * 5; i += 256) s_tab[i] = p.tab[i];   // Jc*4 offsets, then Jc tile masks
 
   // persistent tile list of this workgroup; tiles are dealt so that workgroups sharing an XCD
   // (blockIdx % 8) sweep one contiguous eighth of the tile range (halo re-use in that XCD's L2).
@@ -251,13 +251,29 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
         if (SWZ) a = lds_swz(a);
         b_nxt[t] = *reinterpret_cast<const float4*>(lds + a);
       }
+      // output-channel tiles whose weights of this K step are all zero are skipped (the fused transposed
+      // convolution's (offset, parity class) blocks: 42-56 % of its tile-steps are non-zero); the mask is uniform
+      // (only instantiations with >= 2 tiles test it: the narrow ones have no structural zeros and no registers to spare)
+      if constexpr (NT >= 2) {
+        const unsigned msk = (unsigned)__builtin_amdgcn_readfirstlane(s_tab[p.Jc * 4 + j]) >> (nsi * NT);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+        for (int n = 0; n < NT; ++n) {
+          if (!((msk >> n) & 1u)) continue;
 #pragma unroll
-        for (int n = 0; n < NT; ++n)
+          for (int s = 0; s < 4; ++s)
 #pragma unroll
-          for (int t = 0; t < TY; ++t)
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
+            for (int t = 0; t < TY; ++t)
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int t = 0; t < TY; ++t)
+              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
+      }
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         w_cur[n] = w_nx1[n];
@@ -491,7 +507,7 @@ extern "C" int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchu
   if (ksteps_per_chunk) *ksteps_per_chunk = Jc;
   if (ntiles) *ntiles = NT;
   if (packed_floats) *packed_floats = (long)nch * Jc * NT * 64 * 4;
-  if (table_ints) *table_ints = (long)Jc * 4;
+  if (table_ints) *table_ints = (long)Jc * 5;      // Jc*4 LDS offsets + Jc masks of the non-zero output tiles
   return ATVS_OK;
 }
 
@@ -511,6 +527,7 @@ extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int3
     for (int a = 1; a < 4; ++a)
       if (taps[t * 4 + a] < -1 || taps[t * 4 + a] > ((xpair && a == 3) ? 2 : 1)) return ATVS_ERR_ARG;
   for (long i = 0; i < pf; ++i) packed[i] = 0.f;
+  for (int j = 0; j < Jc; ++j) table[Jc * 4 + j] = 0;
   for (int j = 0; j < Jc; ++j)
     for (int q = 0; q < 4; ++q) {
       int g = j * 4 + q;
@@ -534,6 +551,7 @@ extern "C" int atvs_conv_tiled_pack(const float* w, int w_transposed, const int3
               if (ci >= Cin) continue;
               float val = w_transposed ? w[((size_t)wt * Cout + co) * Cin + ci] : w[((size_t)wt * Cin + ci) * Cout + co];
               packed[(((((size_t)ch * Jc + j) * NT + n) * 64) + q * 16 + co16) * 4 + s] = val;
+              if (val != 0.f) table[Jc * 4 + j] |= 1 << n;
             }
           }
     }
@@ -592,7 +610,7 @@ extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int
 
 template <int NT, int TY, int C4, bool FULL, bool XP = false>
 static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
-  size_t lds = (size_t)(TILE_TZ + 2) * (TY + 2) * ((XP ? 2 : 1) * TILE_TX + 2) * C4 * 16 + (size_t)a.Jc * 4 * sizeof(int);
+  size_t lds = (size_t)(TILE_TZ + 2) * (TY + 2) * ((XP ? 2 : 1) * TILE_TX + 2) * C4 * 16 + (size_t)a.Jc * 5 * sizeof(int);
   size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double) + 16;
   if (red < 256 * sizeof(double)) red = 256 * sizeof(double);
   if (lds < red) lds = red;

@@ -185,7 +185,10 @@ int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* gro
  * *fin_counter, which must be zero before the layer's first launch and is left at zero) reduces the
  * fin_rows rows of fin_stats (the layer's whole statistics buffer; fin_arrivals = workgroups of all the
  * layer's launches) into fin_params = (3, fin_channels) floats (mean, rsqrt(var + fin_eps), 0), exactly
- * what atvs_bn_finalize(beta = NULL) would write -- no separate finalize launch.  fin_channels <= 64. */
+ * what atvs_bn_finalize(beta = NULL) would write -- no separate finalize launch.  fin_channels <= 64.
+ * `table` (atvs_conv_tiled_pack): per K step the 4 LDS offsets of its (tap, channel group) entries, then per
+ * K step a bit mask of the 16-channel output tiles whose packed weights are not all zero -- the kernel skips
+ * the others (the structural zeros of the fused transposed convolution: 44-58 % of its tile-steps). */
 int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* chunk_pad, int* ksteps_per_chunk,
                               int* ntiles, long* packed_floats, long* table_ints);
 int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
