@@ -107,10 +107,12 @@ class _ViewStreams(object):
         rec(tensors)
 
 
-def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True):
+def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True, out_prob_map=False):
     """The run loop of run_test_multiview (reference example.py:140-181), on the device:
     base (per source) -> AAM1 -> refinement (per source) -> AAM2 -> x4 upsample + soft-argmin.
-    view_streams: issue the independent per-view stages on separate HIP streams."""
+    view_streams: issue the independent per-view stages on separate HIP streams.
+    out_prob_map: return (depth, depth_up, prob_map, prob_map_up) as the ETH3D driver's last stage does
+    (reference eval_pointcloud.py:268-272) instead of depth_up alone."""
     max_d = FLAGS.max_d if max_d is None else max_d
     n = images.shape[1]
     assert n > 2
@@ -144,13 +146,13 @@ def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True):
     # AAM2
     refined_cost_volume_agg = cost_volume_aggregation_refine(refined_cost_volumes, reuse=False, keepchannel=True)
     refined_prob_volume_agg = output_conv_refine(refined_cost_volume_agg, reuse=False)
-    _, depth_agg_refined = prob2depth_upsample(refined_prob_volume_agg, max_d, depth_start, depth_interval,
-                                               out_prob_map=False)
+    final = prob2depth_upsample(refined_prob_volume_agg, max_d, depth_start, depth_interval, out_prob_map=out_prob_map)
+    depth_agg_refined = final[1]
     if stages is not None:
         stages.update(depth_views=depth_views, cost_volume_agg=cost_volume_agg, prob_volume_agg=prob_volume_agg,
                       depth_agg_init=depth_agg_init, refined_cost_volume_agg=refined_cost_volume_agg,
                       refined_prob_volume_agg=refined_prob_volume_agg)
-    return depth_agg_refined
+    return final if out_prob_map else depth_agg_refined
 
 
 class GraphedInference(object):
@@ -162,8 +164,9 @@ class GraphedInference(object):
     Inputs live in static device buffers: pass new images / cams to __call__ to overwrite them.
     """
 
-    def __init__(self, images, cams, max_d=None, view_streams=True):
+    def __init__(self, images, cams, max_d=None, view_streams=True, out_prob_map=False):
         self.max_d = FLAGS.max_d if max_d is None else max_d
+        self.out_prob_map = out_prob_map
         self.images = images.clone()
         self.cams = cams.clone()
         self.twoview = images.shape[1] == 2
@@ -181,7 +184,8 @@ class GraphedInference(object):
     def _run(self):
         if self.twoview:
             return infer_twoview(self.images, self.cams, self.max_d)
-        return infer_multiview(self.images, self.cams, self.max_d, view_streams=self.view_streams)
+        return infer_multiview(self.images, self.cams, self.max_d, view_streams=self.view_streams,
+                               out_prob_map=self.out_prob_map)
 
     def __call__(self, images=None, cams=None):
         if images is not None:

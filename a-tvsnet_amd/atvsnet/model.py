@@ -30,9 +30,15 @@ def _scalar(t):
 
 
 def get_propability_map(cv, depth_map, depth_start, depth_interval):
-    """Confidence from the 4 nearest hypotheses (reference :13-65).  Used by eval_pointcloud.py only
-    (next, not part of the example.py path)."""
-    raise NotImplementedError('get_propability_map belongs to the eval_pointcloud.py driver (SURVEY.md 8f-2)')
+    """Confidence of a depth estimate (reference :13-65): the sum of the probabilities of the 4 hypotheses around
+    it.  cv (B,D,H,W) probability volume (already soft-maxed, as the reference passes it), depth_map (B,H,W,1)
+    -> (B,H,W,1).  prob2depth(out_prob_map=True) uses the fused form (soft-max evaluated on the fly)."""
+    if cv.shape[0] != 1:
+        raise ValueError('get_propability_map: batch size must be 1 (FLAGS.batch_size)')
+    D, H, W = cv.shape[1:4]
+    p = ops.probability_map(cv[0].contiguous(), depth_map.reshape(H, W).contiguous(), _scalar(depth_start),
+                            _scalar(depth_interval), up_scale=1, softmax=False)
+    return p.reshape(1, H, W, 1)
 
 
 def upsample_prob_vol(prob_vol, up_scale=4):
@@ -48,24 +54,34 @@ def upsample_prob_vol(prob_vol, up_scale=4):
 
 
 def prob2depth(prob_volume, depth_num, depth_start, depth_interval, out_prob_map=False):
-    """Soft-argmin over the (inverse) depth hypotheses (reference :80-109): (B,D,H,W) -> (B,H,W,1)."""
-    if out_prob_map:
-        return get_propability_map(None, None, None, None)
+    """Soft-argmin over the (inverse) depth hypotheses (reference :80-109): (B,D,H,W) -> (B,H,W,1)
+    [, probability map (B,H,W,1) with out_prob_map=True: get_propability_map of softmax(-volume), :104-107]."""
     if prob_volume.shape[1] != depth_num:
         raise ValueError('prob2depth: volume has %d planes, depth_num is %d' % (prob_volume.shape[1], depth_num))
-    d = ops.softargmin(prob_volume[0].contiguous(), _scalar(depth_start), _scalar(depth_interval))
-    return d.reshape(1, d.shape[0], d.shape[1], 1)
+    vol = prob_volume[0].contiguous()
+    ds, di = _scalar(depth_start), _scalar(depth_interval)
+    d = ops.softargmin(vol, ds, di)
+    depth = d.reshape(1, d.shape[0], d.shape[1], 1)
+    if not out_prob_map:
+        return depth
+    p = ops.probability_map(vol, d, ds, di, up_scale=1, softmax=True)
+    return depth, p.reshape(1, p.shape[0], p.shape[1], 1)
 
 
 def prob2depth_upsample(prob_volume, depth_num, depth_start, depth_interval, out_prob_map=False):
-    """(B,D,h,w) -> (depth (B,h,w,1), depth_up (B,4h,4w,1)) (reference :113-129): the x4 bilinear
-    upsampling of the pre-softmax cost and the soft-argmin are one kernel."""
-    if out_prob_map:
-        return get_propability_map(None, None, None, None)
+    """(B,D,h,w) -> (depth (B,h,w,1), depth_up (B,4h,4w,1)) [, prob_map, prob_map_up] (reference :113-129): the x4
+    bilinear upsampling of the pre-softmax cost, the soft-argmin and the probability gather never materialise
+    the (D,4h,4w) volume."""
     ds, di = _scalar(depth_start), _scalar(depth_interval)
-    up = ops.upsample_softargmin(prob_volume[0].contiguous(), ds, di, 4)
-    lo = ops.softargmin(prob_volume[0].contiguous(), ds, di)
-    return lo.reshape(1, lo.shape[0], lo.shape[1], 1), up.reshape(1, up.shape[0], up.shape[1], 1)
+    vol = prob_volume[0].contiguous()
+    up = ops.upsample_softargmin(vol, ds, di, 4)
+    lo = ops.softargmin(vol, ds, di)
+    depth, depth_up = lo.reshape(1, lo.shape[0], lo.shape[1], 1), up.reshape(1, up.shape[0], up.shape[1], 1)
+    if not out_prob_map:
+        return depth, depth_up
+    p = ops.probability_map(vol, lo, ds, di, up_scale=1, softmax=True)
+    p_up = ops.probability_map(vol, up, ds, di, up_scale=4, softmax=True)
+    return depth, depth_up, p.reshape(1, p.shape[0], p.shape[1], 1), p_up.reshape(1, p_up.shape[0], p_up.shape[1], 1)
 
 
 def output_conv(cost_volume, reuse=AUTO_REUSE):

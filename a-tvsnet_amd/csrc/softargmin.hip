@@ -125,3 +125,84 @@ extern "C" int atvs_upsample_softargmin(const float* cost, const float* depth_st
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
+
+// ---------------------------------------------------------------------------
+// Probability (confidence) map: get_propability_map, /root/reference/atvsnet/model.py:13-65, as used by
+// prob2depth(out_prob_map=True) :104-107 and prob2depth_upsample(out_prob_map=True) :122-125 (the ETH3D batch
+// driver eval_pointcloud.py:232,269).  Per pixel, with d = (depth - depth_start) / depth_interval:
+//   l0 = clip(floor(d)), l1 = clip(l0 - 1), r0 = clip(ceil(d)), r1 = clip(r0 + 1)   (clip to [0, D-1])
+//   prob = P[l0] + P[l1] + P[r0] + P[r1]        (an integral d counts its plane twice, as the reference does)
+// SOFTMAX: P = softmax(-cost) over D computed on the fly (max, then sum, then the four terms) instead of the
+// reference's materialised probability volume; otherwise P is the given volume.  UP: the volume is read through
+// the x4 align_corners bilinear interpolation of upsample_prob_vol (:66-75) instead of being materialised.
+// One thread per output pixel; the (D,h,w) volume is a few MB and stays in L2.
+template <bool SOFTMAX, bool UP>
+__global__ __launch_bounds__(256) void probability_map_kernel(const float* __restrict__ vol, const float* __restrict__ depth_map,
+                                                              const float* __restrict__ depth_start,
+                                                              const float* __restrict__ depth_interval, float* __restrict__ prob_out,
+                                                              int D, int h, int w, int H, int W, float sy, float sx) {
+  int ox = blockIdx.x * 64 + (threadIdx.x & 63);
+  int oy = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (ox >= W || oy >= H) return;
+  const long npix = (long)h * w;
+  const float *p00, *p01 = nullptr, *p10 = nullptr, *p11 = nullptr;
+  float lx = 0.f, ly = 0.f;
+  if (UP) {
+    float fy = (float)oy * sy, fx = (float)ox * sx;
+    int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
+    int y1 = min((int)ceilf(fy), h - 1), x1 = min((int)ceilf(fx), w - 1);
+    ly = fy - (float)y0;
+    lx = fx - (float)x0;
+    p00 = vol + (size_t)y0 * w + x0;
+    p01 = vol + (size_t)y0 * w + x1;
+    p10 = vol + (size_t)y1 * w + x0;
+    p11 = vol + (size_t)y1 * w + x1;
+  } else {
+    p00 = vol + (size_t)oy * w + ox;
+  }
+  auto fetch = [&](int d) {
+    size_t o = (size_t)d * npix;
+    if (!UP) return p00[o];
+    float tl = p00[o], tr = p01[o], bl = p10[o], br = p11[o];
+    float t = tl + (tr - tl) * lx;
+    float b = bl + (br - bl) * lx;
+    return t + (b - t) * ly;
+  };
+  float m = 0.f, ssum = 1.f;
+  if (SOFTMAX) {
+    m = -INFINITY;
+    for (int d = 0; d < D; ++d) m = fmaxf(m, -1.0f * fetch(d));
+    ssum = 0.f;
+    for (int d = 0; d < D; ++d) ssum += expf(-1.0f * fetch(d) - m);
+  }
+  const float dc = (depth_map[(size_t)oy * W + ox] - depth_start[0]) / depth_interval[0];
+  const int l0 = min(max((int)floorf(dc), 0), D - 1);
+  const int l1 = min(max(l0 - 1, 0), D - 1);
+  const int r0 = min(max((int)ceilf(dc), 0), D - 1);
+  const int r1 = min(max(r0 + 1, 0), D - 1);
+  auto prob = [&](int d) { return SOFTMAX ? expf(-1.0f * fetch(d) - m) / ssum : fetch(d); };
+  prob_out[(size_t)oy * W + ox] = ((prob(l0) + prob(l1)) + prob(r0)) + prob(r1);
+}
+
+// vol (D,h,w); depth_map / prob_out (h*up, w*up) (up_scale 1 = same resolution).  softmax != 0: vol is the
+// pre-softmax cost (P = softmax(-vol)); softmax == 0: vol is the probability volume itself.
+extern "C" int atvs_probability_map(const float* vol, const float* depth_map, const float* depth_start,
+                                    const float* depth_interval, float* prob_out, int D, int h, int w, int up_scale,
+                                    int softmax, atvs_stream_t stream) {
+  if (!vol || !depth_map || !depth_start || !depth_interval || !prob_out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0 || up_scale <= 0) return ATVS_ERR_SHAPE;
+  int H = h * up_scale, W = w * up_scale;
+  float sy = (H > 1) ? (float)((double)(h - 1) / (double)(H - 1)) : 0.f;
+  float sx = (W > 1) ? (float)((double)(w - 1) / (double)(W - 1)) : 0.f;
+  dim3 grid(cdiv(W, 64), cdiv(H, 4)), block(256);
+  hipStream_t s = as_stream(stream);
+  if (up_scale == 1) {
+    if (softmax) hipLaunchKernelGGL((probability_map_kernel<true, false>), grid, block, 0, s, vol, depth_map, depth_start, depth_interval, prob_out, D, h, w, H, W, sy, sx);
+    else hipLaunchKernelGGL((probability_map_kernel<false, false>), grid, block, 0, s, vol, depth_map, depth_start, depth_interval, prob_out, D, h, w, H, W, sy, sx);
+  } else {
+    if (softmax) hipLaunchKernelGGL((probability_map_kernel<true, true>), grid, block, 0, s, vol, depth_map, depth_start, depth_interval, prob_out, D, h, w, H, W, sy, sx);
+    else hipLaunchKernelGGL((probability_map_kernel<false, true>), grid, block, 0, s, vol, depth_map, depth_start, depth_interval, prob_out, D, h, w, H, W, sy, sx);
+  }
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

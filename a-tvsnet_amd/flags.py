@@ -22,6 +22,12 @@ class _Flags(object):
         self.sample_scale = 0.25
         self.batch_size = 1
         self.inverse_depth = True
+        # eval_pointcloud.py (reference :31-57; its own defaults for view_num / max_d are set by its cli)
+        self.data_root = '../data/'
+        self.savepath = '../eval/pointcloud/'
+        self.max_w = 896
+        self.max_h = 480
+        self.adaptive_scaling = True
 
 
 FLAGS = _Flags()

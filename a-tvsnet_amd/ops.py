@@ -177,6 +177,18 @@ def upsample_softargmin(cost, depth_start, depth_interval, up_scale=4):
     return out
 
 
+def probability_map(vol, depth_map, depth_start, depth_interval, up_scale=1, softmax=True):
+    """vol (D,h,w) + depth_map (h*up, w*up) -> (h*up, w*up): sum of the four plane probabilities around the depth."""
+    D, h, w = vol.shape
+    if tuple(depth_map.shape) != (h * up_scale, w * up_scale):
+        raise ValueError('probability_map: depth map %s for a (%d,%d) volume x%d' % (tuple(depth_map.shape), h, w, up_scale))
+    out = _new(vol, (h * up_scale, w * up_scale))
+    if _dev_ok(vol, depth_map, depth_start, depth_interval):
+        _call('atvs_probability_map', _p(vol), _p(depth_map), _p(depth_start), _p(depth_interval), _p(out), D, h, w,
+              int(up_scale), int(bool(softmax)), _stream())
+    return out
+
+
 # --------------------------------------------------------------------------- convolutions
 
 def same_pad(in_size, k, s, d=1):

@@ -110,6 +110,17 @@ int atvs_softargmin(const float* cost, const float* depth_start, const float* de
 int atvs_upsample_softargmin(const float* cost, const float* depth_start, const float* depth_interval,
                              float* depth_up_out, int D, int h, int w, int up_scale, atvs_stream_t stream);
 
+/* get_propability_map (model.py:13-65) as used by prob2depth / prob2depth_upsample(out_prob_map=True)
+ * (:104-107, :122-125; the ETH3D driver eval_pointcloud.py:232,269): per pixel the sum of the probabilities of
+ * the four depth planes around the estimated depth, l0 = clip(floor(d)), l1 = clip(l0-1), r0 = clip(ceil(d)),
+ * r1 = clip(r0+1), d = (depth - depth_start) / depth_interval.  vol (D,h,w); depth_map, prob_out
+ * (h*up_scale, w*up_scale).  softmax != 0: vol is the pre-softmax cost and P = softmax(-vol) is evaluated on
+ * the fly; up_scale > 1: vol is read through the align_corners bilinear interpolation of upsample_prob_vol
+ * (:66-75) -- neither the probability volume nor its upsampled copy is materialised. */
+int atvs_probability_map(const float* vol, const float* depth_map, const float* depth_start,
+                         const float* depth_interval, float* prob_out, int D, int h, int w, int up_scale, int softmax,
+                         atvs_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  * Convolutions  (cnn_wrapper/network.py)
  * ------------------------------------------------------------------------- */

@@ -19,19 +19,43 @@ def upsample_prob_vol(prob_vol, up_scale=4):
     return x.permute(0, 3, 1, 2).contiguous()
 
 
-def prob2depth(prob_volume, depth_num, depth_start, depth_interval):
-    """model.py:80-109 soft-argmin over (inverse) depth: (B,D,H,W) -> (B,H,W,1)."""
+def get_propability_map(cv, depth_map, depth_start, depth_interval):
+    """model.py:13-65: cv (B,D,H,W) probability volume, depth_map (B,H,W,1) -> (B,H,W,1) = the sum of the
+    probabilities at clip(floor(d)), clip(floor(d))-1, clip(ceil(d)), clip(ceil(d))+1 (each clipped to [0, D-1];
+    an integral d counts its plane twice), d = (depth - depth_start) / depth_interval.  Batch 1 (the
+    reference's _repeat_ / meshgrid bookkeeping is the identity for FLAGS.batch_size = 1)."""
+    B, D, H, W = cv.shape
+    assert B == 1
+    d = ((depth_map.reshape(-1) - depth_start[0]) / depth_interval[0])
+    l0 = torch.clamp(torch.floor(d).to(torch.int64), 0, D - 1)
+    l1 = torch.clamp(l0 - 1, 0, D - 1)
+    r0 = torch.clamp(torch.ceil(d).to(torch.int64), 0, D - 1)
+    r1 = torch.clamp(r0 + 1, 0, D - 1)
+    flat = cv[0].reshape(D, H * W)
+    pix = torch.arange(H * W)
+    g = lambda idx: flat[idx, pix]          # noqa: E731
+    return (g(l0) + g(l1) + g(r0) + g(r1)).reshape(1, H, W, 1)
+
+
+def prob2depth(prob_volume, depth_num, depth_start, depth_interval, out_prob_map=False):
+    """model.py:80-109 soft-argmin over (inverse) depth: (B,D,H,W) -> (B,H,W,1) [, probability map :104-107]."""
     B = prob_volume.shape[0]
     depth_end = depth_start + (float(depth_num) - 1.0) * depth_interval
     p = T.softmax(-1.0 * prob_volume, axis=1)
     soft = torch.stack([T.linspace(depth_start[i], depth_end[i], depth_num) for i in range(B)], 0)
-    est = (soft.reshape(B, depth_num, 1, 1) * p).sum(dim=1)
-    return est.unsqueeze(3)
+    est = (soft.reshape(B, depth_num, 1, 1) * p).sum(dim=1).unsqueeze(3)
+    if out_prob_map:
+        return est, get_propability_map(p, est, depth_start, depth_interval)
+    return est
 
 
-def prob2depth_upsample(prob_volume, depth_num, depth_start, depth_interval):
-    """model.py:113-129 -> (depth (B,h,w,1), depth_up (B,4h,4w,1))."""
+def prob2depth_upsample(prob_volume, depth_num, depth_start, depth_interval, out_prob_map=False):
+    """model.py:113-129 -> (depth (B,h,w,1), depth_up (B,4h,4w,1)) [, prob_map, prob_map_up]."""
     up = upsample_prob_vol(prob_volume)
+    if out_prob_map:
+        d_up, p_up = prob2depth(up, depth_num, depth_start, depth_interval, True)
+        d, p = prob2depth(prob_volume, depth_num, depth_start, depth_interval, True)
+        return d, d_up, p, p_up
     d_up = prob2depth(up, depth_num, depth_start, depth_interval)
     d = prob2depth(prob_volume, depth_num, depth_start, depth_interval)
     return d, d_up
