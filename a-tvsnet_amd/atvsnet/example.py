@@ -206,10 +206,13 @@ def _load_weights():
     if path is None:
         print('FLAGS.pretrained_model_ckpt_path is None !!')
         sys.exit()
-    if not path.endswith('.npz'):
-        raise RuntimeError('%s: TF-1.5 checkpoints are not read here; convert to an .npz of '
-                           '{tf_variable_name: array} or pass --synthetic_weights' % path)
-    store.load_npz(path)
+    if path.endswith('.npz'):
+        store.load_npz(path)             # {tf_variable_name: array}
+    elif os.path.exists(path + '.index'):
+        store.load_checkpoint(path)      # the TensorFlow checkpoint the reference restores (tools/tf_checkpoint.py)
+    else:
+        raise RuntimeError('%s: neither an .npz of {tf_variable_name: array} nor a TensorFlow checkpoint prefix '
+                           '(%s.index not found); pass --synthetic_weights to run without weights' % (path, path))
     print(Notify.INFO, 'pre-trained model restored from %s' % path, Notify.ENDC)
 
 

@@ -138,6 +138,16 @@ class VariableStore(object):
                 self.set(k, f[k])
         self.strict = True
 
+    def load_checkpoint(self, prefix):
+        """A TensorFlow tensor-bundle checkpoint `<prefix>.index` / `<prefix>.data-*` (what the reference's
+        tf.train.Saver restores, example.py:122-124): every float tensor becomes a variable under its TF name
+        (optimizer slots and counters in the file are simply never asked for)."""
+        from .tools import tf_checkpoint
+        for k, v in tf_checkpoint.read_checkpoint(prefix).items():
+            if v.dtype == np.float32:
+                self.set(k, v)
+        self.strict = True
+
     def save_npz(self, path):
         np.savez(path, **self.host)
 
