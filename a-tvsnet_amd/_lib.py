@@ -78,6 +78,11 @@ def lib():
             raise RuntimeError(
                 'libatvsnet_hip.so is not built (%s). Run `python -c "import __graft_entry__ as g; g.build()"`; '
                 'there is no CPU fallback for the HIP path.' % LIB_PATH)
+        # torch first: its wheel carries its own HIP runtime, and the streams / device pointers handed to this
+        # library belong to THAT runtime.  Loaded after torch, the library's hip* symbols bind to the runtime
+        # already in the process; loaded before it, they would bind to /opt/rocm's copy and every launch on a
+        # torch stream would fail.
+        import torch  # noqa: F401
         _lib = ctypes.CDLL(LIB_PATH)
         for name in declared_symbols():
             fn = getattr(_lib, name)          # AttributeError if the library lacks a declared symbol

@@ -168,3 +168,17 @@ def test_midsize_against_float64_networks(cuda, weights):
           % (e64, float(gold['oracle32_rel_l1']), e32))
     assert e64 <= 1.5 * float(gold['oracle32_rel_l1'])
     assert e32 <= 1e-3
+
+
+def test_graft_entry_build_then_smoke_in_one_process(cuda):
+    """build() loads the HIP library before anything touched the GPU; smoke() then runs the pipeline.  (The library
+    must bind to the HIP runtime torch carries -- loaded before torch it once bound to /opt/rocm's and every launch
+    on a torch stream failed.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-c', 'import __graft_entry__ as g; g.build(); g.smoke()'], cwd=root,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode('utf-8', 'replace')
+    assert r.returncode == 0 and 'smoke ok' in out, out[-2000:]
