@@ -24,3 +24,58 @@ def test_sharded_path_world1_equals_single_gpu(cuda, weights):
         assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
     finally:
         dist.destroy_process_group()
+
+
+def _sharded_worker(rank, world, port, n_views, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import atvsnet_amd                                 # noqa: F401
+        from atvsnet_amd import parallel, synthetic, variables
+        from atvsnet_amd.atvsnet import example as ex
+        variables.default_store().init_synthetic(1234)
+        dev = torch.device('cuda:0')
+        imgs, cams = synthetic.make_inputs(n_views, 128, 160, 32)
+        imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
+        got = parallel.infer_multiview_sharded(imgs, cams, 32)
+        torch.cuda.synchronize()
+        diff = scale = tasks = None
+        if rank == 0:
+            want = ex.infer_multiview(imgs, cams, 32, view_streams=False)
+            diff, scale = float((got - want).abs().max()), float(want.abs().max())
+        tasks = parallel.plan(n_views, world)[rank]
+        q.put((rank, diff, scale, tasks, got.cpu().numpy().copy()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world,n_views', [(2, 4), (2, 3), (4, 3)])
+def test_sharded_path_multi_rank_on_one_gpu(cuda, world, n_views):
+    """The COMPLETE view-sharded pipeline on the HIP kernels with several ranks (all on this one GPU, gloo carrying the
+    collectives -- RCCL refuses two ranks per device): sources dealt round-robin (world 2) and the two siamese
+    directions of a source on different ranks with the depth_view exchange (world 4, 2 sources).  Every rank must
+    end with the single-process depth map."""
+    import numpy as np
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29750 + world * 10 + n_views
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, n_views, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    res.sort(key=lambda t: t[0])
+    diff, scale = res[0][1], res[0][2]
+    assert diff <= 1e-5 * scale, (diff, scale)
+    for r in res[1:]:
+        assert np.array_equal(r[4], res[0][4])               # every rank holds the same map
+    kinds = [sorted(k for k, _ in r[3]) for r in res]
+    if world >= 2 * (n_views - 1):
+        assert all(len(k) == 1 for k in kinds)               # one direction per rank
+    else:
+        assert all(k.count('fwd') == k.count('rev') for k in kinds)
