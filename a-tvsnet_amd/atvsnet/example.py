@@ -57,6 +57,10 @@ def infer_twoview(images, cams, max_d=None):
 # A-B on MI355X (tools_dev/ab.py): 49.3 ms without, 52.5 ms with (five concurrent towers delay the reference
 # tower every stream then waits for)
 OVERLAP_REF_TOWER = False
+# Upper bound on concurrently issued views (views are dealt round-robin to the streams).  A-B at config 3 (4 sources):
+# 1 stream 55.3 ms, 2 streams 45.7, 3 streams 47.4, 4 streams 43.5; one stream per (source, direction) = 8 streams
+# 50.1 ms -- more concurrency than one stream per source makes the GPU-filling kernels of different streams collide.
+MAX_VIEW_STREAMS = 16
 
 
 class _ViewStreams(object):
@@ -70,14 +74,14 @@ class _ViewStreams(object):
     def __init__(self, n, device, enabled):
         self.main = torch.cuda.current_stream(device) if device.type == 'cuda' else None
         self.enabled = bool(enabled) and device.type == 'cuda' and n > 1
-        self.streams = [torch.cuda.Stream(device) for _ in range(n)] if self.enabled else []
+        self.streams = [torch.cuda.Stream(device) for _ in range(min(n, MAX_VIEW_STREAMS))] if self.enabled else []
 
     def run(self, i, fn, after=None):
         """fn() on stream i, after everything queued so far on the main stream (or after the event `after`
         recorded earlier on it); returns fn's result."""
         if not self.enabled:
             return fn()
-        st = self.streams[i]
+        st = self.streams[i % len(self.streams)]
         if after is not None:
             st.wait_event(after)
         else:

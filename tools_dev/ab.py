@@ -7,12 +7,13 @@ from atvsnet_amd import ops, synthetic, variables
 from atvsnet_amd.atvsnet import example as ex, model
 dev = torch.device('cuda:0')
 variables.default_store().init_synthetic(1234)
-imgs, cams = synthetic.make_inputs(5, 512, 640, 192)
+views, H, W, D = [int(v) for v in os.environ.get('ATVS_AB_CFG', '5,512,640,192').split(',')]      # views,H,W,D
+imgs, cams = synthetic.make_inputs(views, H, W, D)
 imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
 variants = []
 for code in sys.argv[1:]:
     exec(code)
-    variants.append((code, ex.GraphedInference(imgs, cams, 192)))
+    variants.append((code, ex.GraphedInference(imgs, cams, D)))
 res = {c: [] for c, _ in variants}
 for rnd in range(6):
     for code, g in variants:
