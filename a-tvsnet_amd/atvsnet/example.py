@@ -72,9 +72,14 @@ class _ViewStreams(object):
     is handed to the main stream with an event wait + record_stream (caching-allocator safety)."""
 
     def __init__(self, n, device, enabled):
-        self.main = torch.cuda.current_stream(device) if device.type == 'cuda' else None
+        self.device = device
         self.enabled = bool(enabled) and device.type == 'cuda' and n > 1
         self.streams = [torch.cuda.Stream(device) for _ in range(min(n, MAX_VIEW_STREAMS))] if self.enabled else []
+
+    @property
+    def main(self):
+        """The caller's stream NOW (a pipeline captured as several graphs re-enters with a new capture stream)."""
+        return torch.cuda.current_stream(self.device) if self.device.type == 'cuda' else None
 
     def run(self, i, fn, after=None):
         """fn() on stream i, after everything queued so far on the main stream (or after the event `after`
@@ -97,8 +102,9 @@ class _ViewStreams(object):
         """Main stream waits for every view stream; `tensors` (nested lists ok) become usable on it."""
         if not self.enabled:
             return
+        main = self.main
         for st in self.streams:
-            self.main.wait_stream(st)
+            main.wait_stream(st)
         if torch.cuda.is_current_stream_capturing():        # a capturing graph owns its pool's lifetimes
             return
 
@@ -107,7 +113,7 @@ class _ViewStreams(object):
                 for u in t:
                     rec(u)
             elif isinstance(t, torch.Tensor):
-                t.record_stream(self.main)
+                t.record_stream(main)
         rec(tensors)
 
 

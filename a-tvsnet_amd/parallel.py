@@ -42,13 +42,9 @@ class HipAttentionOps(object):
         return ops.divide(num, den)
 
 
-def sharded_attention(local_xs, scope, like, impl=None, group=None):
-    """AANet over views that live on different ranks.
-
-    local_xs: this rank's list of (D,h,w,8) tensors (may be empty); `like`: a tensor giving the
-    (D,h,w,8) shape / device for ranks that own no view.  Returns the aggregated (D,h,w,8) volume,
-    identical on every rank.
-    """
+def _attention_steps(local_xs, scope, like, impl=None):
+    """Generator form of the sharded AANet: yields (tensor, reduce op) wherever the ranks must all-reduce that
+    tensor in place, and returns the aggregated (D,h,w,8) volume (identical on every rank)."""
     impl = impl or HipAttentionOps()
     shape = tuple(like.shape)
     if local_xs:
@@ -56,18 +52,38 @@ def sharded_attention(local_xs, scope, like, impl=None, group=None):
         ssum = impl.partial(srs, local_xs, 0)
     else:
         ssum = torch.zeros(shape, dtype=torch.float32, device=like.device)
-    dist.all_reduce(ssum, op=dist.ReduceOp.SUM, group=group)
+    yield ssum, dist.ReduceOp.SUM
     if local_xs:
         umax = impl.partial(srs, local_xs, 1, ssum=ssum)
     else:
         umax = torch.full(shape, float('-inf'), dtype=torch.float32, device=like.device)
-    dist.all_reduce(umax, op=dist.ReduceOp.MAX, group=group)
+    yield umax, dist.ReduceOp.MAX
     if local_xs:
         acc = impl.partial(srs, local_xs, 2, ssum=ssum, umax=umax)
     else:
         acc = torch.zeros((2,) + shape, dtype=torch.float32, device=like.device)
-    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    yield acc, dist.ReduceOp.SUM
     return impl.divide(acc[1], acc[0])
+
+
+def _drive(gen, group=None):
+    """Run a step generator eagerly: perform every yielded all-reduce, return the generator's result."""
+    try:
+        while True:
+            tensor, op = next(gen)
+            dist.all_reduce(tensor, op=op, group=group)
+    except StopIteration as e:
+        return e.value
+
+
+def sharded_attention(local_xs, scope, like, impl=None, group=None):
+    """AANet over views that live on different ranks.
+
+    local_xs: this rank's list of (D,h,w,8) tensors (may be empty); `like`: a tensor giving the
+    (D,h,w,8) shape / device for ranks that own no view.  Returns the aggregated (D,h,w,8) volume,
+    identical on every rank.
+    """
+    return _drive(_attention_steps(local_xs, scope, like, impl), group)
 
 
 def local_views(num_views, rank, world):
@@ -96,60 +112,128 @@ def plan(num_views, world):
     return tasks
 
 
-def infer_multiview_sharded(images, cams, max_d=None, group=None):
-    """example.infer_multiview with the source views sharded over the process group.
-    Every rank returns the same full-resolution inverse-depth map (1,H,W,1)."""
+def _sharded_steps(images, cams, max_d, world, rank, view_streams=True):
+    """example.infer_multiview for this rank's share of the source views, as a generator: local compute runs
+    between the yields, every yield is (tensor, reduce op) = an in-place all-reduce all ranks must perform.
+    Returns the full-resolution inverse-depth map (1,H,W,1), identical on every rank."""
     from .atvsnet import example as ex
     from .atvsnet import model
     from .cnn_wrapper.atvsnet import ResNetDS2SPP_shallow_f16
-    max_d = FLAGS.max_d if max_d is None else max_d
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
     n = images.shape[1]
     mine = plan(n, world)[rank]
     fwd = [v for kind, v in mine if kind == 'fwd']
     rev = [v for kind, v in mine if kind == 'rev']
+    views = sorted(set(fwd + rev))
     depth_start, depth_interval = ex.depth_range(cams)
     dev = images.device
     h, w = images.shape[2] // 4, images.shape[3] // 4
+    vs = ex._ViewStreams(len(views), dev, view_streams)          # one stream per owned source view
+    slot = {v: i for i, v in enumerate(views)}
     ref_feature = model.TVSNet_feature_extraction(images, 0) if mine else None
-    feats = {v: model.TVSNet_feature_extraction(images, v) for v in sorted(set(fwd + rev))}
-
-    # ---- base stage (reference model.py:398-417), one direction per task
-    filtered = []
-    for v in fwd:
-        cv = model.build_cost_volume(ref_feature, feats[v], cams, max_d, depth_start, depth_interval, ref_id=0, view_id=v,
-                                     lazy=True)
-        _, f = model.cost_volume_reasoning(cv, output_filtered_cost=True)
-        filtered.append(f[0])
     dv_all = torch.zeros((n - 1, h, w), dtype=torch.float32, device=dev)
-    for v in rev:      # quirk C11: sweeps the reference camera's depth range
-        cv = model.build_cost_volume(feats[v], ref_feature, cams, max_d, depth_start, depth_interval, ref_id=v, view_id=0,
-                                     lazy=True)
-        dv = model.prob2depth(model.cost_volume_reasoning(cv, output_filtered_cost=False), max_d, depth_start,
-                              depth_interval)
-        dv_all[v - 1].copy_(dv.reshape(h, w))
-    dist.all_reduce(dv_all, op=dist.ReduceOp.SUM, group=group)       # every view has exactly one contributor
+
+    # ---- base stage (reference model.py:398-417): the owned directions of every owned view
+    def base(v):
+        feat = model.TVSNet_feature_extraction(images, v)
+        f = None
+        if v in fwd:
+            cv = model.build_cost_volume(ref_feature, feat, cams, max_d, depth_start, depth_interval, ref_id=0,
+                                         view_id=v, lazy=True)
+            f = model.cost_volume_reasoning(cv, output_filtered_cost=True)[1][0]
+        if v in rev:      # quirk C11: sweeps the reference camera's depth range
+            cv = model.build_cost_volume(feat, ref_feature, cams, max_d, depth_start, depth_interval, ref_id=v,
+                                         view_id=0, lazy=True)
+            dv = model.prob2depth(model.cost_volume_reasoning(cv, output_filtered_cost=False), max_d, depth_start,
+                                  depth_interval)
+            dv_all[v - 1].copy_(dv.reshape(h, w))
+        return f
+    outs = [vs.run(slot[v], lambda v=v: base(v)) for v in views]
+    vs.join(outs)
+    filtered = [o for o in outs if o is not None]
+    del outs
+    yield dv_all, dist.ReduceOp.SUM                 # every view has exactly one contributor
 
     # ---- AAM1 across ranks
     like = torch.empty((max_d, h, w, 8), dtype=torch.float32, device=dev) if not filtered else filtered[0]
-    cost_agg = sharded_attention(filtered, 'attention_aggregate', like, group=group).unsqueeze(0)
+    cost_agg = (yield from _attention_steps(filtered, 'attention_aggregate', like)).unsqueeze(0)
     prob_agg = model.output_conv(cost_agg, reuse=False)
     depth_init = model.prob2depth(prob_agg, max_d, depth_start, depth_interval)
     del filtered
 
     # ---- refinement of the owned sources
-    refined = []
-    if fwd:
-        ref_shallow = ResNetDS2SPP_shallow_f16({'data': images[:, 0]}, is_training=True).get_output()
-    for v in fwd:
+    ref_shallow = ResNetDS2SPP_shallow_f16({'data': images[:, 0]}, is_training=True).get_output() if fwd else None
+
+    def refine(v):
         shallow = model.extract_feature_shallow(images, 0, v, ref_feature=ref_shallow)
-        _, rc = model.TVSNet_refine(depth_init, dv_all[v - 1].reshape(1, h, w, 1), prob_agg, cost_agg, images, cams,
-                                    max_d, depth_start, depth_interval, view_i=v, ref_i=0, shallow_features=shallow)
-        refined.append(rc[0])
+        return model.TVSNet_refine(depth_init, dv_all[v - 1].reshape(1, h, w, 1), prob_agg, cost_agg, images, cams,
+                                   max_d, depth_start, depth_interval, view_i=v, ref_i=0, shallow_features=shallow)[1][0]
+    refined = [vs.run(slot[v], lambda v=v: refine(v)) for v in fwd]
+    vs.join(refined)
 
     # ---- AAM2 across ranks, head, x4 upsample + soft-argmin (replicated)
-    rcost_agg = sharded_attention(refined, 'attention_aggregate_refine', like, group=group)
+    rcost_agg = yield from _attention_steps(refined, 'attention_aggregate_refine', like)
     rprob_agg = model.output_conv_refine(rcost_agg.unsqueeze(0), reuse=False)
     _, depth_refined = model.prob2depth_upsample(rprob_agg, max_d, depth_start, depth_interval)
     return depth_refined
+
+
+def infer_multiview_sharded(images, cams, max_d=None, group=None, view_streams=True):
+    """example.infer_multiview with the source views sharded over the process group (every launch issued from
+    Python).  Every rank returns the same full-resolution inverse-depth map (1,H,W,1)."""
+    max_d = FLAGS.max_d if max_d is None else max_d
+    return _drive(_sharded_steps(images, cams, max_d, dist.get_world_size(group), dist.get_rank(group), view_streams),
+                  group)
+
+
+class ShardedGraphedInference(object):
+    """The sharded pipeline as a chain of HIP graphs with the collectives between them.
+
+    The local compute between two all-reduces is captured once into a HIP graph (per-view streams forked and
+    joined inside it); the all-reduces themselves stay ordinary RCCL calls on the tensors the graphs own.  One
+    step = replay, all-reduce, replay, ... (7 all-reduces, 8 graphs) instead of ~500-1000 launches issued from
+    Python per rank, which is what bounds the eager sharded path.  All graphs share one memory pool and are
+    replayed in capture order.  Inputs live in static buffers: pass new images / cams to __call__."""
+
+    def __init__(self, images, cams, max_d=None, group=None, view_streams=True):
+        self.max_d = FLAGS.max_d if max_d is None else max_d
+        self.group = group
+        self.images, self.cams = images.clone(), cams.clone()
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        dev = images.device
+        # warm-up on a side stream: weight packing / uploads, function attributes, communicator set-up
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            _drive(_sharded_steps(self.images, self.cams, self.max_d, world, rank, view_streams), group)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graphs, self.colls = [], []
+        pool = torch.cuda.graph_pool_handle()
+        gen = _sharded_steps(self.images, self.cams, self.max_d, world, rank, view_streams)
+        done = False
+        while not done:
+            g = torch.cuda.CUDAGraph()
+            item = None
+            with torch.cuda.graph(g, pool=pool):
+                try:
+                    item = next(gen)
+                except StopIteration as e:
+                    self.out, done = e.value, True
+            self.graphs.append(g)
+            if not done:
+                # during capture nothing ran: the tensor holds whatever the pool had; the all-reduce keeps the ranks'
+                # collective sequences aligned and is repeated, on real data, in every step
+                dist.all_reduce(item[0], op=item[1], group=group)
+                self.colls.append(item)
+        torch.cuda.synchronize(dev)
+
+    def __call__(self, images=None, cams=None):
+        if images is not None:
+            self.images.copy_(images)
+        if cams is not None:
+            self.cams.copy_(cams)
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.colls):
+                dist.all_reduce(self.colls[i][0], op=self.colls[i][1], group=self.group)
+        return self.out

@@ -13,7 +13,8 @@ forked and joined inside it); --eager issues every launch from Python instead.
 
 --gpus N > 1 (one process per GPU, launched by torch.distributed.run): the source views of
 the SAME depth map are sharded over the ranks and aggregated with RCCL all-reduces inside both
-AANet modules (a-tvsnet_amd/parallel.py); total work is fixed -> "scaling": "strong".
+AANet modules (a-tvsnet_amd/parallel.py); per rank the local compute between two all-reduces is one
+HIP graph; total work is fixed -> "scaling": "strong".
 
 One JSON line on rank 0; `roofline` is for the dominant kernel (conv_xp.hip: the 3x3x3 convolution of
 the 32 warped channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0,
@@ -147,8 +148,12 @@ def main():
     imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
 
     graphed = None
-    if world == 1 and not args.eager:
-        graphed = ex.GraphedInference(imgs, cams, args.depths)      # one HIP graph per depth map
+    if not args.eager:
+        if world == 1:
+            graphed = ex.GraphedInference(imgs, cams, args.depths)      # one HIP graph per depth map
+        else:
+            # per rank: a chain of HIP graphs (the local compute between two all-reduces) with the RCCL calls between
+            graphed = parallel.ShardedGraphedInference(imgs, cams, args.depths)
 
     def eager_step():
         if world > 1:
@@ -184,7 +189,12 @@ def main():
         # shares the GPU with it), right after the timed region
         ops.watch(DOMINANT)
         for _ in range(2):
-            ex.infer_multiview(imgs, cams, args.depths, view_streams=False) if args.views > 2 else eager_step()
+            if world > 1:
+                parallel.infer_multiview_sharded(imgs, cams, args.depths, view_streams=False)
+            elif args.views > 2:
+                ex.infer_multiview(imgs, cams, args.depths, view_streams=False)
+            else:
+                eager_step()
         watched = ops.watch(None)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -226,7 +236,8 @@ def main():
                                    % (args.views, args.views - 1, args.width, args.height, args.depths),
                        'feature_hw': [h, w], 'voxels': vox,
                        'parallelism': 'views sharded over %d GPUs, RCCL all-reduce in AAM1/AAM2' % world if world > 1 else 'single GPU',
-                       'launch': 'eager' if graphed is None else 'HIP graph replay, per-view streams'},
+                       'launch': 'eager' if graphed is None else ('HIP graph replay, per-view streams' if world == 1 else
+                                                                   'HIP graphs between the all-reduces, per-view streams')},
             'roofline': roof,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -22,6 +22,13 @@ def test_sharded_path_world1_equals_single_gpu(cuda, weights):
         got = parallel.infer_multiview_sharded(imgs, cams, 32)
         # the sharded AANet computes num/den instead of sum(score*X): same value up to rounding
         assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+        # the same as a chain of HIP graphs with the RCCL all-reduces between them, replayed twice
+        g = parallel.ShardedGraphedInference(imgs, cams, 32)
+        assert len(g.graphs) == 8 and len(g.colls) == 7
+        for _ in range(2):
+            assert torch.equal(g(), got)
+        other = imgs.flip(1).contiguous()                       # new inputs through the static buffers
+        assert torch.equal(g(other), parallel.infer_multiview_sharded(other, cams, 32))
     finally:
         dist.destroy_process_group()
 
@@ -41,6 +48,11 @@ def _sharded_worker(rank, world, port, n_views, q):
         imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
         got = parallel.infer_multiview_sharded(imgs, cams, 32)
         torch.cuda.synchronize()
+        graphed = parallel.ShardedGraphedInference(imgs, cams, 32)
+        for _ in range(2):
+            rep = graphed()
+        torch.cuda.synchronize()
+        assert torch.equal(rep, got), 'graph-segment replay differs from the eager sharded path'
         diff = scale = tasks = None
         if rank == 0:
             want = ex.infer_multiview(imgs, cams, 32, view_streams=False)
