@@ -63,6 +63,15 @@ def build(force=False, verbose=False):
     return LIB_PATH
 
 
+def header_abi_version():
+    """ATVS_ABI_VERSION of include/atvsnet_hip.h."""
+    with open(HEADER) as f:
+        m = re.search(r'#define\s+ATVS_ABI_VERSION\s+(\d+)', f.read())
+    if not m:
+        raise RuntimeError('%s defines no ATVS_ABI_VERSION' % HEADER)
+    return int(m.group(1))
+
+
 def declared_symbols():
     """Every function name declared in include/atvsnet_hip.h."""
     with open(HEADER) as f:
@@ -87,6 +96,11 @@ def lib():
         for name in declared_symbols():
             fn = getattr(_lib, name)          # AttributeError if the library lacks a declared symbol
             fn.restype = ctypes.c_int
+        have, want = _lib.atvs_abi_version(), header_abi_version()
+        if have != want:          # a stale prebuilt library next to newer sources
+            _lib = None
+            raise RuntimeError('%s has ABI version %d, include/atvsnet_hip.h declares %d: rebuild it '
+                               '(`python -c "import __graft_entry__ as g; g.build()"`)' % (LIB_PATH, have, want))
         _lib.atvs_target_arch.restype = ctypes.c_char_p
         _lib.atvs_conv_num_blocks.restype = ctypes.c_long
         _lib.atvs_channel_stats_num_blocks.restype = ctypes.c_long

@@ -111,6 +111,7 @@ def run_eval_pc(savepath, image_infos, use_graph=True):
     from PIL import Image
     assert FLAGS.view_num > 2, 'the ETH3D driver runs the multi-view (AANet) pipeline'
     example._load_weights()
+    torch.cuda.set_device(FLAGS.gpu_id)          # every kernel launches on the current device's stream
     run = _Pipelines(torch.device('cuda:%d' % FLAGS.gpu_id), use_graph)
     for image_info, _fmt in image_infos:
         mvs_list = gen_data_list(image_info[0])

@@ -190,6 +190,10 @@ class GraphedInference(object):
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = self._run()
+        # the graph holds raw pointers to the weights it was captured with: keep those copies alive even if the
+        # variable store is reloaded afterwards (the graph then goes on computing with the captured weights)
+        from .. import ops
+        self._weights = (ops.cache_snapshot(), variables.default_store().device_snapshot())
 
     def _run(self):
         if self.twoview:
@@ -261,6 +265,7 @@ def write_error_xlsx(path, error, view_num):
 
 
 def _to_device(images_data, cams_data):
+    torch.cuda.set_device(FLAGS.gpu_id)          # every kernel launches on the current device's stream
     dev = torch.device('cuda:%d' % FLAGS.gpu_id)
     images = torch.from_numpy(np.ascontiguousarray(images_data, dtype=np.float32))[None].to(dev)
     cams = torch.from_numpy(np.ascontiguousarray(cams_data, dtype=np.float32))[None].to(dev)

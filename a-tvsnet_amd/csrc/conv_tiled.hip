@@ -614,12 +614,15 @@ static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
   size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double) + 16;
   if (red < 256 * sizeof(double)) red = 256 * sizeof(double);
   if (lds < red) lds = red;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: one flag per device ordinal of this process
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;

@@ -520,12 +520,15 @@ extern "C" int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed
 template <int C4, bool SIB>
 static int launch_xp1(const XpArgs& a, long blocks, hipStream_t s) {
   size_t lds = (size_t)XP_HZ * XP_HY * XP_HXP * C4 * 16;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: one flag per device ordinal of this process
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  if (!attr_set[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xp_kernel<C4, SIB>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
-    attr_set = true;
+    attr_set[dev] = true;
   }
   hipLaunchKernelGGL((conv_xp_kernel<C4, SIB>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;

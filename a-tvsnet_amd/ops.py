@@ -17,11 +17,16 @@ _ERR = {-1: 'null pointer', -2: 'bad shape', -3: 'bad argument', -4: 'launch fai
 
 
 def _dev_ok(*ts):
-    """True if the kernels must be launched, False for meta tensors."""
+    """True if the kernels must be launched, False for meta tensors.  Device tensors must live on the CURRENT
+    device (torch.cuda.set_device / FLAGS.gpu_id): the launch goes to that device's current stream."""
     meta = None
     for t in ts:
         if t is None:
             continue
+        if t.device.type == 'cuda' and t.device.index != torch.cuda.current_device():
+            raise RuntimeError('atvsnet ops launch on the current device (cuda:%d) but got a tensor on %s: call '
+                               'torch.cuda.set_device first (example.py --gpu_id does)' %
+                               (torch.cuda.current_device(), t.device))
         if t.dtype != torch.float32:
             raise TypeError('atvsnet ops take float32 tensors, got %s' % t.dtype)
         if not t.is_contiguous():
@@ -78,8 +83,9 @@ def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=N
         ld_out = out.shape[-1]
     mask = _new(src, (D, h, w)) if want_mask else None
     if _dev_ok(src, homographies, out, ref, depth_start, depth_interval):
-        _call('atvs_warp_planes', _p(src), _p(homographies), _p(ref), _p(depth_start), _p(depth_interval), _p(out),
-              _p(mask), D, h, w, C, int(ld_out), int(c_off), int(mode), int(rep), _stream())
+        with _Timed(('warp', int(mode)), (D, h, w, C), width):
+            _call('atvs_warp_planes', _p(src), _p(homographies), _p(ref), _p(depth_start), _p(depth_interval),
+                  _p(out), _p(mask), D, h, w, C, int(ld_out), int(c_off), int(mode), int(rep), _stream())
     return (out, mask) if want_mask else out
 
 
@@ -368,16 +374,10 @@ def conv_xp_launch(x4, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
     sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null     # noqa: E731
     pk2, y2, y_coff2, sbuf2, pb2 = sibling if sibling is not None else (None, None, 0, None, None)
     if _dev_ok(x4, y, bias, plane_bias, y2, pb2):
-        timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _call('atvs_conv_xp_f32', _p(x4), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), D, H, W, Cin, ldy,
-              int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2), sp(sbuf2),
-              int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _stream())
-        if timed:
-            e1.record()
-            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout + (16 if pk2 is not None else 0)))
+        with _Timed(pk.key, x4.shape, pk.cout + (16 if pk2 is not None else 0)):
+            _call('atvs_conv_xp_f32', _p(x4), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), D, H, W, Cin,
+                  ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
+                  sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _stream())
 
 
 def xp_blocks(D, H, W):
@@ -453,11 +453,8 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
     D, H, W, Cin = x4.shape
     Dy, Hy, Wy, ldy = y.shape
     if _dev_ok(x4, y, bias, residual, plane_bias):
-        timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        _call('atvs_conv_tiled_f32', _p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
+        with _Timed(pk.key, x4.shape, pk.cout):
+          _call('atvs_conv_tiled_f32', _p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
               _p(plane_bias), _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
               Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
               8 if xpair else pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), int(class_cout), int(class_base),
@@ -468,9 +465,6 @@ def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
               fin.rows if fin is not None else 0, fin.arrivals if fin is not None else 0,
               fin.channels if fin is not None else 0, fin.fold if fin is not None else 0,
               ctypes.c_long(fin.count if fin is not None else 0), ctypes.c_float(1e-3), _stream())
-        if timed:
-            e1.record()
-            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
 
 
 def tiled_blocks(D, H, W, tile_y, cin, cout, xpair=False):
@@ -521,7 +515,22 @@ def use_xpair(flag):
 
 
 def clear_pack_cache():
+    """Forget every arranged form of the weights (packed device copies, folded split kernels, virtual x-pair and
+    transposed-convolution kernels).  They are keyed by variable NAME, so the variable store calls this whenever a
+    value changes (VariableStore.set / clear / load_*).  A captured HIP graph keeps the copies it was captured
+    with alive (GraphedInference holds references) and goes on using them."""
     _pack_cache.clear()
+    _fold_cache.clear()
+    _xp_cache.clear()
+    _virt_cache.clear()
+
+
+invalidate_weights = clear_pack_cache
+
+
+def cache_snapshot():
+    """References to every cached device tensor (for owners of captured graphs)."""
+    return [pk for pk in _pack_cache.values()]
 
 
 def _pick_tile_m(M, ntiles):
@@ -550,36 +559,58 @@ def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bia
     M = Do * Ho * Wo
     tm = tile_m or _pick_tile_m(M, pk.ntiles)
     if _dev_ok(x4, y, bias, residual, plane_bias):
-        timed = _watch['tag'] is not None and (_watch['tag'] == '*' or pk.key == _watch['tag'])
-        if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
         args = [_p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual), _p(plane_bias),
                 int(pad_z), _p(y),
                 ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0),
                 Di, Hi, Wi, Cin, Do, Ho, Wo, int(in_stride), Dy, Hy, Wy, int(out_stride), int(out_off[0]),
                 int(out_off[1]), int(out_off[2]), ldy, int(y_coff), pk.cout, pk.ntaps, tm, int(bool(relu)), _stream()]
-        _call('atvs_conv_mfma_f32', *args)
-        if timed:
-            e1.record()
-            _watch['events'].append((e0, e1, pk.key, tuple(x4.shape), pk.cout))
+        with _Timed(pk.key, x4.shape, pk.cout):
+            _call('atvs_conv_mfma_f32', *args)
     return tm
 
 
 _watch = {'tag': None, 'events': []}
 
 
+def _watched(key):
+    tag = _watch['tag']
+    return tag is not None and (tag == '*' or key == tag or (isinstance(tag, list) and key in tag))
+
+
+class _Timed(object):
+    """HIP events around one launch on the launch stream (= torch's current stream), when `key` is watched."""
+
+    def __init__(self, key, shape, cout):
+        self.on = _watched(key)
+        self.info = (key, tuple(shape), cout)
+
+    def __enter__(self):
+        if self.on:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            self.e1.record()
+            _watch['events'].append((self.e0, self.e1) + self.info)
+        return False
+
+
 def watch(tag):
-    """Time every convolution launch whose weight key is `tag` with HIP events on the launch stream.
-    tag '*' times every convolution launch.  watch(None) stops and returns the list of durations in ms
-    (for '*': a list of (key, input shape, Cout, ms))."""
+    """Time launches with HIP events on the launch stream.  tag: a convolution's weight key, ('warp', mode) for
+    atvs_warp_planes, a LIST of such keys, or '*' (every convolution launch).  watch(None) stops and returns the
+    durations in ms: a list for one key, {key: list} for a list of keys, [(key, input shape, Cout, ms)] for '*'."""
     out = None
     if tag is None:
         torch.cuda.synchronize()
-        if _watch['tag'] == '*':
-            out = [(e[2], e[3], e[4], e[0].elapsed_time(e[1])) for e in _watch['events']]
+        ev, old = _watch['events'], _watch['tag']
+        if old == '*':
+            out = [(e[2], e[3], e[4], e[0].elapsed_time(e[1])) for e in ev]
+        elif isinstance(old, list):
+            out = {k: [e[0].elapsed_time(e[1]) for e in ev if e[2] == k] for k in old}
         else:
-            out = [e[0].elapsed_time(e[1]) for e in _watch['events']]
+            out = [e[0].elapsed_time(e[1]) for e in ev]
     _watch['tag'] = tag
     _watch['events'] = []
     return out

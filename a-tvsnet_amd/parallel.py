@@ -86,6 +86,24 @@ def sharded_attention(local_xs, scope, like, impl=None, group=None):
     return _drive(_attention_steps(local_xs, scope, like, impl), group)
 
 
+EXCHANGE = 'three all-reduces per AANet: SUM S, MAX U, SUM [e, e*X]'
+
+
+def rank_groups(num_views, world, split_directions=False):
+    """Ranks -> groups; every group computes its own depth map with that map's source views sharded over its ranks.
+
+    A group never has more ranks than the depth map has source views (one source per GPU is the finest useful
+    partition: both siamese directions, the refinement and the AANet share of a source stay on its owner, so no rank
+    idles through a stage); ranks beyond that form further groups that work on further depth maps (the other
+    reference views of a scene are independent, reference eval_pointcloud.py:399-424).  split_directions=True keeps
+    ONE group and deals the two directions of a pair to two ranks instead (plan()).
+    """
+    nsrc = max(num_views - 1, 1)
+    if split_directions or world <= nsrc:
+        return [list(range(world))]
+    return [list(range(a, min(a + nsrc, world))) for a in range(0, world, nsrc)]
+
+
 def local_views(num_views, rank, world):
     """Source views (1..N-1) whose refinement (and forward direction) `rank` owns."""
     return [v for (kind, v) in plan(num_views, world)[rank] if kind == 'fwd']
@@ -226,6 +244,7 @@ class ShardedGraphedInference(object):
                 dist.all_reduce(item[0], op=item[1], group=group)
                 self.colls.append(item)
         torch.cuda.synchronize(dev)
+        self._weights = (ops.cache_snapshot(), variables.default_store().device_snapshot())
 
     def __call__(self, images=None, cams=None):
         if images is not None:

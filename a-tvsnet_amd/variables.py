@@ -116,9 +116,15 @@ class VariableStore(object):
         self._dev = {}
         self.strict = False      # True: unknown names raise instead of being synthesised
 
+    def _invalidate(self):
+        """Arranged copies of the weights (ops' pack caches) are keyed by name: drop them when a value changes."""
+        from . import ops
+        ops.invalidate_weights()
+
     def clear(self):
         self.host.clear()
         self._dev.clear()
+        self._invalidate()
 
     def init_synthetic(self, seed=1234):
         self.clear()
@@ -131,6 +137,7 @@ class VariableStore(object):
         self.host[name] = np.ascontiguousarray(value, dtype=np.float32)
         for k in [k for k in self._dev if k[0] == name]:
             del self._dev[k]
+        self._invalidate()
 
     def load_npz(self, path):
         with np.load(path) as f:
@@ -147,6 +154,10 @@ class VariableStore(object):
             if v.dtype == np.float32:
                 self.set(k, v)
         self.strict = True
+
+    def device_snapshot(self):
+        """References to every device copy handed out so far (owners of captured HIP graphs keep them alive)."""
+        return list(self._dev.values())
 
     def save_npz(self, path):
         np.savez(path, **self.host)

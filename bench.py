@@ -1,31 +1,39 @@
 #!/usr/bin/env python
 """Headline benchmark: depth-maps/sec of the A-TVSNet multi-view inference path.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg2|cfg3|cfg4|cfg5]
 
-A step = one depth map: N=5 views (1 reference + 4 sources) of 640x512 images, D=192
-hypotheses (BASELINE.json configs[2], the configuration the metric is quoted on), through the
-whole example.py multi-view pipeline (towers -> 2x stacked 3-D U-Net per source -> AAM1 ->
-refinement per source -> AAM2 -> x4 upsample + soft-argmin), inputs resident in HBM, synthetic
-seeded data and weights.  Arithmetic: fp32 (fp32 MFMA for every convolution).
-On one GPU the step is ONE replay of a HIP graph captured from the pipeline (per-view streams
-forked and joined inside it); --eager issues every launch from Python instead.
+A step = one depth map through the whole example.py pipeline (towers -> 2x stacked 3-D U-Net per source ->
+AAM1 -> refinement per source -> AAM2 -> x4 upsample + soft-argmin), inputs resident in HBM, synthetic
+seeded images / cameras / weights, fp32 arithmetic (fp32 MFMA for every convolution).
+Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: 5 views
+(1 reference + 4 sources) of 640x512, D=192.  cfg2 = two-view 640x512x192, cfg4 = 9 views 928x480x256 (the
+8-source configuration quoted for 8 GPUs), cfg5 = two-view 1600x1184x256.
+On one GPU the step is ONE replay of a HIP graph captured from the pipeline (per-view streams forked and
+joined inside it); --eager issues every launch from Python instead.
 
---gpus N > 1 (one process per GPU, launched by torch.distributed.run): the source views of
-the SAME depth map are sharded over the ranks and aggregated with RCCL all-reduces inside both
-AANet modules (a-tvsnet_amd/parallel.py); per rank the local compute between two all-reduces is one
-HIP graph; total work is fixed -> "scaling": "strong".
+--gpus N > 1: this process touches no GPU; it starts N ranks (one process per GPU, RANK / LOCAL_RANK /
+WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), relays rank 0's JSON line and exits non-zero if any rank
+fails or if fewer than N devices are visible.  (Launched under torch.distributed.run -- WORLD_SIZE already in
+the environment -- it is a rank itself.)  The ranks form groups of at most one rank per source view
+(a-tvsnet_amd/parallel.py): inside a group the source views of ONE depth map are sharded over the ranks and
+exchanged inside both AANet modules over RCCL; when there are more ranks than sources, the extra ranks form
+further groups that work on further depth maps (other reference views of the scene).  value = depth maps
+completed by all groups per second.
 
-One JSON line on rank 0; `roofline` is for the dominant kernel (conv_xp.hip: the 3x3x3 convolution of
-the 32 warped channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0,
-one launch), timed with HIP events on its launch stream; `roofline.traffic` is the HBM traffic of that
-launch from rocprofv3 PMC passes recorded in profiles/round1_pmc_dominant_kernel_v2.json (WRITE_SIZE +
-FETCH_SIZE, see the note there);
-`cpu_baseline` is the CPU oracle on the host cores over a bounded sample.
+One JSON line on rank 0.  `roofline` = the dominant kernel (conv_xp.hip: the 3x3x3 convolution of the 32 warped
+channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch) against
+the fp32 MFMA peak, timed with HIP events on its launch stream; `roofline_hbm` = the plane-sweep warp
+(warp_planes_kernel) against the HBM peak, timed the same way; `kernels` = the top kernels of the committed
+rocprofv3 kernel trace of this command; `parity` = the output of the timed path against the oracle-generated
+fixture of this workload (tests/golden/fullsize_*.npz) and graph replay == eager bit for bit;
+`cpu_baseline` = the CPU oracle on the host cores.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,108 +41,273 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np          # noqa: E402
-import torch                # noqa: E402
-
-WIDTH, HEIGHT, DEPTHS, VIEWS = 640, 512, 192, 5
+WORKLOADS = {          # name: (views, width, height, depths)
+    'cfg2': (2, 640, 512, 192),
+    'cfg3': (5, 640, 512, 192),
+    'cfg4': (9, 928, 480, 256),
+    'cfg5': (2, 1600, 1184, 256),
+}
 DOMINANT = ('conv_b0_0_1/conv3d/kernel', 'var')   # the D-varying half of conv_b0_0_1 (see ops.conv_split)
+WARP = ('warp', 0)                                 # atvs_warp_planes, bilinear (the cost-volume build)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md, HBM3E peak (6.29 TB/s achievable by a float4 copy)
+PMC_FILE = os.path.join('profiles', 'round1_pmc_dominant_kernel_v2.json')
+KERNEL_STATS_FILE = os.path.join('profiles', 'round2_bench_kernel_stats.csv')
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument('--gpus', type=int, default=1)
     p.add_argument('--steps', type=int, default=5)
     p.add_argument('--warmup', type=int, default=2)
-    p.add_argument('--width', type=int, default=WIDTH)
-    p.add_argument('--height', type=int, default=HEIGHT)
-    p.add_argument('--depths', type=int, default=DEPTHS)
-    p.add_argument('--views', type=int, default=VIEWS)
+    p.add_argument('--workload', choices=sorted(WORKLOADS), default='cfg3')
+    p.add_argument('--width', type=int, default=None)
+    p.add_argument('--height', type=int, default=None)
+    p.add_argument('--depths', type=int, default=None)
+    p.add_argument('--views', type=int, default=None)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-parity', action='store_true')
     p.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
-    p.add_argument('--cpu-baseline-seconds', type=float, default=25.0)
-    return p.parse_args()
+    p.add_argument('--split-directions', action='store_true',
+                   help='with >= 2 ranks per source: one siamese direction per rank instead of further depth-map groups')
+    p.add_argument('--dry', action='store_true',
+                   help='no GPU: the ranks rendezvous over gloo, agree on the plan and print the line (launcher test)')
+    a = p.parse_args(argv)
+    v, w, h, d = WORKLOADS[a.workload]
+    a.custom = any(x is not None for x in (a.width, a.height, a.depths, a.views))
+    a.views = a.views or v
+    a.width = a.width or w
+    a.height = a.height or h
+    a.depths = a.depths or d
+    return a
 
 
-def cpu_baseline(args, budget_s):
-    """Time the CPU oracle (our restatement of the reference's TF-CPU path; TF-1.5 cannot be
-    installed) on the host cores over a BOUNDED sample of the same workload: every stage of the
-    pipeline once on a (W/2 x H/2 image, D/2 hypotheses) crop, i.e. 1/4 of the pixels of a tower
-    pass and 1/8 of the voxels of a volume pass, scaled back linearly (all stages are
-    convolutions / gathers, linear in pixels resp. voxels) and composed as the pipeline composes
-    them."""
+# --------------------------------------------------------------------------------------------- launcher
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch(args, argv):
+    """Start args.gpus ranks of this script as child processes; no GPU call happens in this process."""
+    n = args.gpus
+    if not args.dry:
+        import torch
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to run a smaller world\n' % (n, have))
+            return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            p.wait(timeout=max(1.0, deadline - time.time()))
+        except subprocess.TimeoutExpired:
+            p.kill()          # the exact child we started
+            p.wait()
+        rcs.append(p.returncode)
+    text = out0.decode('utf-8', 'replace') if out0 else ''
+    sys.stdout.write(text)
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write('bench.py: rank(s) failed: %s\n' % bad)
+        return 1
+    return 0
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+
+def cpu_baseline(args):
+    """The CPU oracle (our restatement of the reference's TF-CPU path; TensorFlow 1.5 cannot be installed) timed
+    on the host cores at FULL size: BASELINE configs[0] (two-view 160x128, D=32) 1 warm-up + 3 runs, median;
+    the stages of the two-view pipeline at the benchmark's image size and depth count once each (one full
+    configs[1] pipeline), the AANet over the benchmark's source views once; `value` composes those full-size
+    stage times the way the benchmarked pipeline composes them."""
+    import numpy as np
+    import torch
     from atvsnet_amd import synthetic, variables
     from oracle import model as OM, nets
-    threads = min(os.cpu_count() or 1, 32)      # oneDNN scales badly past a few dozen threads on these sizes
+    ncpu = os.cpu_count() or 1
+    threads = min(ncpu, 32)      # oneDNN scales badly past a few dozen threads on these sizes
     torch.set_num_threads(threads)
     W = {k: torch.from_numpy(v) for k, v in variables.default_store().host.items()}
-    Hs, Ws, Ds = args.height // 2, args.width // 2, max(args.depths // 2, 8)
-    pix_ratio = (args.height * args.width) / float(Hs * Ws)
-    vox_ratio = pix_ratio * args.depths / float(Ds)
+    model_name = ''
+    try:
+        with open('/proc/cpuinfo') as f:
+            for ln in f:
+                if ln.startswith('model name'):
+                    model_name = ln.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    t_all = time.time()
+    # configs[0]: full pipeline, 1 warm-up + 3 runs
+    imgs, cams = synthetic.make_inputs(2, 128, 160, 32)
+    imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
+    runs = []
+    with torch.no_grad():
+        for i in range(4):
+            t = time.time()
+            OM.run_twoview(imgs, cams, W, 32)
+            runs.append(time.time() - t)
+    cfg1 = float(np.median(runs[1:]))
+    # the benchmark's size, stage by stage (= one two-view pipeline), each stage once
+    D = args.depths
+    imgs, cams = synthetic.make_inputs(2, args.height, args.width, D)
+    imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
+    ds, di = OM.depth_start_interval(cams)
     n_src = args.views - 1
-    t0 = time.time()
-
-    def stages(H, Wd, D, timed):
-        imgs, cams = synthetic.make_inputs(2, H, Wd, D)
-        imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
-        ds, di = OM.depth_start_interval(cams)
-        T = {}
-        with torch.no_grad():
-            t = time.time()
-            ref_f = nets.resnet_ds2_spp(imgs[:, 0], W)
-            T['tower'] = time.time() - t
-            view_f = nets.resnet_ds2_spp(imgs[:, 1], W) if not timed else ref_f.flip(2).contiguous()
-            t = time.time()
-            cv = OM.build_cost_volume(ref_f, view_f, cams, D, ds, di, 0, 1)
-            T['warp'] = time.time() - t
-            t = time.time()
-            pv, filt = OM.cost_volume_reasoning(cv, W)
-            depth = OM.prob2depth(pv, D, ds, di)
-            T['unet'] = time.time() - t
-            del cv
-            t = time.time()
-            OM.TVSNet_refine(depth, depth, pv, filt, imgs, cams, D, ds, di, W, view_i=1)
-            T['refine'] = time.time() - t
+    T = {}
+    with torch.no_grad():
+        t = time.time()
+        ref_f = nets.resnet_ds2_spp(imgs[:, 0], W)
+        T['tower'] = time.time() - t
+        view_f = nets.resnet_ds2_spp(imgs[:, 1], W)
+        t = time.time()
+        cv = OM.build_cost_volume(ref_f, view_f, cams, D, ds, di, 0, 1)
+        T['warp'] = time.time() - t
+        t = time.time()
+        pv, filt = OM.cost_volume_reasoning(cv, W)
+        depth = OM.prob2depth(pv, D, ds, di)
+        T['unet'] = time.time() - t
+        del cv
+        t = time.time()
+        OM.TVSNet_refine(depth, depth, pv, filt, imgs, cams, D, ds, di, W, view_i=1)
+        T['refine'] = time.time() - t
+        T['aam'] = 0.0
+        if n_src > 1:
             t = time.time()
             agg = nets.attention_aggregation(torch.stack([filt] * n_src, -1), W, 'attention_aggregate')
             OM.prob2depth_upsample(nets.output_conv(agg, W), D, ds, di)
             T['aam'] = time.time() - t
-        return T
-
-    stages(128, 160, 8, False)                   # warm-up: oneDNN primitive creation, allocator
-    T = stages(Hs, Ws, Ds, True)
-    per_map = (args.views * T['tower'] * pix_ratio +
-               n_src * (2 * (T['warp'] + T['unet']) + T['refine']) * vox_ratio + 2 * T['aam'] * vox_ratio)
+    twoview = 2 * T['tower'] + 2 * (T['warp'] + T['unet']) + T['refine']
+    if n_src > 1:
+        per_map = args.views * T['tower'] + n_src * (2 * (T['warp'] + T['unet']) + T['refine']) + 2 * T['aam']
+    else:
+        per_map = twoview
     return {'value': 1.0 / per_map, 'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'port',
-            'sample': 'each stage once on a %dx%d, D=%d crop (tower %.2fs, warp %.2fs, U-Net %.2fs, refinement %.2fs, '
-                      'AAM %.2fs), scaled x%.0f (pixels) / x%.0f (voxels) and composed as %d towers + %d x (2 warps + '
-                      '2 U-Nets + refinement) + 2 AAM; %.1f s of CPU work measured'
-                      % (Ws, Hs, Ds, T['tower'], T['warp'], T['unet'], T['refine'], T['aam'], pix_ratio, vox_ratio,
-                         args.views, n_src, time.time() - t0)}
+            'host_cpus': ncpu, 'cpu_model': model_name,
+            'configs0_s': round(cfg1, 3), 'configs0_runs_s': [round(r, 3) for r in runs],
+            'twoview_fullsize_s': round(twoview, 2), 'stage_s': {k: round(v, 2) for k, v in T.items()},
+            'sample': 'CPU restatement (not TensorFlow): configs[0] (160x128, D=32 two-view) 1 warm-up + 3 runs, median '
+                      '%.2f s; every stage of the pipeline once at FULL size %dx%d, D=%d (tower %.1f s, warp %.1f s, '
+                      'U-Net %.1f s, refinement %.1f s, AANet over %d views + head + upsample %.1f s); value = 1 / (%d '
+                      'towers + %d x (2 warps + 2 U-Nets + refinement) + 2 AAM) = 1 / %.1f s; %.0f s of CPU work in all'
+                      % (cfg1, args.width, args.height, D, T['tower'], T['warp'], T['unet'], T['refine'], n_src,
+                         T['aam'], args.views if n_src > 1 else 2, n_src, per_map, time.time() - t_all)}
 
+
+# --------------------------------------------------------------------------------------------- reporting helpers
 
 def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (only valid for
-    the default workload they were taken on): WRITE_SIZE + raw FETCH_SIZE."""
-    if (args.width, args.height, args.depths) != (WIDTH, HEIGHT, DEPTHS):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (only valid for the
+    640x512x192 volume they were taken on).  FETCH_SIZE on gfx950 counts wide coalesced reads at half their
+    bytes (MI355X_MICROARCH.md, HBM): both the raw and the doubled figure are given."""
+    if (args.width, args.height, args.depths) != (640, 512, 192):
         return None
     try:
-        with open(os.path.join(ROOT, 'profiles', 'round1_pmc_dominant_kernel_v2.json')) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             d = json.load(f)['derived']
-        return d['write_bytes_pmc'] + d['fetch_bytes_pmc_raw']      # bytes per launch
+        return {'write': d['write_bytes_pmc'], 'fetch_raw': d['fetch_bytes_pmc_raw'],
+                'fetch_x2': 2 * d['fetch_bytes_pmc_raw'], 'source': PMC_FILE}
     except Exception:
         return None
 
 
-def main():
-    args = parse()
+def top_kernels(k=5):
+    """Top kernels of the committed rocprofv3 --kernel-trace --stats summary of this command."""
+    import csv
+    path = os.path.join(ROOT, KERNEL_STATS_FILE)
+    if not os.path.exists(path):
+        return None
+    rows = []
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            rows.append((r['Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', ''),
+                         int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['Percentage'])))
+    rows.sort(key=lambda t: -t[3])
+    return {'source': KERNEL_STATS_FILE,
+            'top': [{'kernel': n, 'calls': c, 'avg_us': round(a, 1), 'pct': round(p, 2)} for n, c, a, p in rows[:k]]}
+
+
+def parity_check(args, out, eager_out):
+    """rel-L1 of the timed path's depth map against the oracle fixture of this workload (when the run is one of
+    BASELINE's configurations) + graph replay == eager launch, bit for bit."""
+    import numpy as np
+    import torch
+    res = {'bar': 1e-3}
+    if eager_out is not None:
+        res['graph_equals_eager_bitwise'] = bool(torch.equal(out, eager_out))
+    path = os.path.join(ROOT, 'tests', 'golden', 'fullsize_%s.npz' % args.workload)
+    if args.custom or not os.path.exists(path):
+        res['fixture'] = None
+        return res
+    want = torch.from_numpy(np.load(path)['depth'])
+    got = out.reshape(want.shape).cpu()
+    res['fixture'] = os.path.relpath(path, ROOT)
+    res['rel_l1'] = float(((got - want).abs() / want.abs()).mean())
+    res['rel_l1_inverse'] = float(((1.0 / got - 1.0 / want).abs() / (1.0 / want).abs()).mean())
+    res['max_abs'] = float((got - want).abs().max())
+    res['ok'] = bool(res['rel_l1'] <= res['bar'] and res['rel_l1_inverse'] <= res['bar'])
+    return res
+
+
+# --------------------------------------------------------------------------------------------- one rank
+
+def dry_rank(args):
+    """Launcher / rendezvous check without a GPU: gloo process group, the plan, one all-reduce."""
+    import torch
+    import torch.distributed as dist
+    import atvsnet_amd                                       # noqa: F401
+    from atvsnet_amd import parallel
+    world, rank = int(os.environ.get('WORLD_SIZE', '1')), int(os.environ.get('RANK', '0'))
+    assert world == args.gpus, 'WORLD_SIZE %d != --gpus %d' % (world, args.gpus)
+    if world > 1:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    groups = parallel.rank_groups(args.views, world, args.split_directions)
+    t = torch.ones(1)
+    if world > 1:
+        dist.all_reduce(t)
+        dist.destroy_process_group()
+    assert int(t.item()) == world
+    if rank == 0:
+        print(json.dumps({'metric': 'depth-maps/sec at %dx%dxD=%d, N=%d views' % (args.width, args.height, args.depths, args.views),
+                          'value': 0.0, 'unit': 'depth-maps/sec', 'n_gpus': world, 'steps': args.steps,
+                          'warmup': args.warmup, 'dry': True,
+                          'config': {'workload': args.workload, 'world_size': world, 'groups': groups,
+                                     'plan': parallel.plan(args.views, len(groups[0]))}}))
+    return 0
+
+
+def rank_main(args):
+    import numpy as np
+    import torch
+    import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: WORLD_SIZE=%d but --gpus %d\n' % (world, args.gpus))
+        return 2
     assert torch.cuda.is_available(), 'bench.py needs an MI355X'
+    assert torch.cuda.device_count() > local_rank, 'rank %d: no device %d' % (rank, local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    import torch.distributed as dist
     if world > 1:
         dist.init_process_group('nccl', device_id=dev)
 
@@ -146,21 +319,32 @@ def main():
     variables.default_store().init_synthetic(1234)
     imgs, cams = synthetic.make_inputs(args.views, args.height, args.width, args.depths, seed=0)
     imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
+    twoview = args.views == 2
+
+    # ranks -> groups of at most one rank per source (each group computes its own depth map)
+    groups = parallel.rank_groups(args.views, world, args.split_directions) if world > 1 else [[0]]
+    group, gsize, n_groups = None, 1, len(groups)
+    if world > 1:
+        for g in groups:
+            h = dist.new_group(g) if len(groups) > 1 else None       # every rank creates every group
+            if rank in g:
+                group, gsize = h, len(g)
+    sharded = gsize > 1
 
     graphed = None
     if not args.eager:
-        if world == 1:
-            graphed = ex.GraphedInference(imgs, cams, args.depths)      # one HIP graph per depth map
+        if sharded:
+            # per rank: a chain of HIP graphs (the local compute between two exchanges) with the RCCL calls between
+            graphed = parallel.ShardedGraphedInference(imgs, cams, args.depths, group=group)
         else:
-            # per rank: a chain of HIP graphs (the local compute between two all-reduces) with the RCCL calls between
-            graphed = parallel.ShardedGraphedInference(imgs, cams, args.depths)
+            graphed = ex.GraphedInference(imgs, cams, args.depths)      # one HIP graph per depth map
 
-    def eager_step():
-        if world > 1:
-            return parallel.infer_multiview_sharded(imgs, cams, args.depths)
-        if args.views == 2:
+    def eager_step(view_streams=True):
+        if sharded:
+            return parallel.infer_multiview_sharded(imgs, cams, args.depths, group=group, view_streams=view_streams)
+        if twoview:
             return ex.infer_twoview(imgs, cams, args.depths)
-        return ex.infer_multiview(imgs, cams, args.depths)
+        return ex.infer_multiview(imgs, cams, args.depths, view_streams=view_streams)
 
     def step():
         return graphed() if graphed is not None else eager_step()
@@ -174,33 +358,30 @@ def main():
     for _ in range(args.warmup):
         out = step()
     barrier()
-    if graphed is None:
-        ops.watch(DOMINANT)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
-    if graphed is None:
-        watched = ops.watch(None)
-    else:
-        # kernels inside a replayed graph cannot be bracketed by events: the dominant kernel is timed by
-        # HIP events on its launch stream in two eager single-stream passes of the same step (no other kernel
-        # shares the GPU with it), right after the timed region
-        ops.watch(DOMINANT)
-        for _ in range(2):
-            if world > 1:
-                parallel.infer_multiview_sharded(imgs, cams, args.depths, view_streams=False)
-            elif args.views > 2:
-                ex.infer_multiview(imgs, cams, args.depths, view_streams=False)
-            else:
-                eager_step()
-        watched = ops.watch(None)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    out = out.clone()
+
+    # the dominant kernel and the warp, timed by HIP events on their launch stream in two eager single-stream passes
+    # of the same step right after the timed region (kernels inside a replayed graph cannot be bracketed by events;
+    # single stream: no other kernel shares the GPU with the one being timed)
+    ops.watch([DOMINANT, WARP])
+    for _ in range(2):
+        eager_out = eager_step(view_streams=False)
+    watched = ops.watch(None)
     assert torch.isfinite(out).all()
+    comm = None
+    if sharded and graphed is not None and hasattr(graphed, 'timed_call'):
+        comm = graphed.timed_call()              # ms of local graphs vs ms of the exchanges, this rank
+    if world > 1:
+        dist.barrier()
 
     if rank == 0:
         h, w = args.height // 4, args.width // 4
@@ -209,46 +390,92 @@ def main():
         # cost volume and run as ONE launch.  Their 32 D-constant input channels (the tiled reference features) are
         # per-plane biases, so the launch convolves the 32 warped channels: 2*27*32*8 FLOP per voxel + 2*27*32*16 FLOP
         # per half-resolution voxel.  Without the sibling (ops.use_siblings(False)) only the first term applies.
-        from atvsnet_amd import ops as _ops
         vox2 = ((args.depths + 1) // 2) * ((h + 1) // 2) * ((w + 1) // 2)
-        sib = _ops.siblings_ok((args.depths, h, w), 32, 8, 16)
+        sib = ops.siblings_ok((args.depths, h, w), 32, 8, 16)
         flops = 2.0 * 27 * 32 * 8 * vox + (2.0 * 27 * 32 * 16 * vox2 if sib else 0.0)
         alg_bytes = 4 * (32 * vox + 8 * vox + (16 * vox2 if sib else 0))
-        roof = None
-        if watched:
-            avg_ms = float(np.mean(watched))
+        roof = roof_hbm = None
+        if watched.get(DOMINANT):
+            avg_ms = float(np.mean(watched[DOMINANT]))
             ach = flops / (avg_ms * 1e-3) / 1e12
-            roof = {'bound': 'mfma', 'kernel': 'conv_xp_kernel<C4=4,SIB> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full resolution, + sibling '
-                                              'conv_b0_1_0: -> 16, stride 2)',
+            tr = pmc_traffic(args)
+            roof = {'bound': 'mfma', 'kernel': 'conv_xp_kernel<C4=4,SIB> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full '
+                                              'resolution, + sibling conv_b0_1_0: -> 16, stride 2)',
                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(args),
-                    'traffic_note': 'HBM bytes per launch, WRITE_SIZE + FETCH_SIZE (rocprofv3 --pmc, profiles/'
-                                    'round1_pmc_dominant_kernel_v2.json); algorithmic bytes %d' % alg_bytes,
-                    'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched),
-                    'algorithmic_flops_per_launch': flops}
+                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                    'traffic': (tr['write'] + tr['fetch_x2']) if tr else None,
+                    'traffic_detail': dict(tr, algorithmic=alg_bytes,
+                                           ratio_raw=round((tr['write'] + tr['fetch_raw']) / alg_bytes, 3),
+                                           ratio_x2=round((tr['write'] + tr['fetch_x2']) / alg_bytes, 3),
+                                           note='HBM bytes per launch from rocprofv3 --pmc passes; FETCH_SIZE on gfx950 '
+                                                'reports half the bytes of wide coalesced reads, so the true read traffic '
+                                                'lies between fetch_raw and fetch_x2; `traffic` uses write + fetch_x2')
+                    if tr else None,
+                    'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[DOMINANT]),
+                    'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg_bytes}
+        if watched.get(WARP):
+            # plane-sweep warp of the 32-channel source features into the D-varying half of the cost volume:
+            # algorithmic bytes = write D*h*w*32*4 + read h*w*32*4
+            wb = 4.0 * 32 * vox + 4.0 * 32 * h * w
+            avg_ms = float(np.mean(watched[WARP]))
+            gbs = wb / (avg_ms * 1e-3) / 1e9
+            roof_hbm = {'bound': 'hbm', 'kernel': 'warp_planes_kernel<bilinear, float4> (cost-volume build, 32 channels)',
+                        'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                        'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[WARP]),
+                        'algorithmic_bytes_per_launch': wb, 'traffic': None}
+        par = 'single GPU'
+        if world > 1:
+            par = ('%d group(s) of %d rank(s); inside a group the source views of one depth map are sharded over the ranks, '
+                   'exchange inside AAM1/AAM2 over RCCL (%s)' % (n_groups, len(groups[0]), parallel.EXCHANGE))
         line = {
             'metric': 'depth-maps/sec at %dx%dxD=%d, N=%d views' % (args.width, args.height, args.depths, args.views),
-            'value': round(args.steps / dt, 4),
+            'value': round(n_groups * args.steps / dt, 4),
             'unit': 'depth-maps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'strong' if world > 1 else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': '1 depth map: %d views (1 ref + %d src) %dx%d, D=%d, example.py multi-view pipeline'
-                                   % (args.views, args.views - 1, args.width, args.height, args.depths),
-                       'feature_hw': [h, w], 'voxels': vox,
-                       'parallelism': 'views sharded over %d GPUs, RCCL all-reduce in AAM1/AAM2' % world if world > 1 else 'single GPU',
-                       'launch': 'eager' if graphed is None else ('HIP graph replay, per-view streams' if world == 1 else
-                                                                   'HIP graphs between the all-reduces, per-view streams')},
-            'roofline': roof,
+            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': '%d depth map(s) per step: %d views (1 ref + %d src) %dx%d, D=%d, example.py %s pipeline'
+                                   % (n_groups, args.views, args.views - 1, args.width, args.height, args.depths,
+                                      'two-view' if twoview else 'multi-view'),
+                       'name': args.workload if not args.custom else 'custom',
+                       'feature_hw': [h, w], 'voxels': vox, 'parallelism': par, 'world_size': world,
+                       'groups': groups if world > 1 else None,
+                       'rccl': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+                       'launch': 'eager' if graphed is None else ('HIP graph replay, per-view streams' if not sharded else
+                                                                   'HIP graphs between the exchanges, per-view streams')},
+            'source_views_per_sec': round(n_groups * args.steps * (args.views - 1) / dt, 3),
+            'roofline': roof, 'roofline_hbm': roof_hbm, 'kernels': top_kernels(),
         }
+        if comm is not None:
+            line['exchange'] = comm
+        if not args.no_parity:
+            try:
+                line['parity'] = parity_check(args, out, eager_out if (graphed is not None and not sharded) else None)
+            except Exception as e:
+                line['parity'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line['cpu_baseline'] = cpu_baseline(args, args.cpu_baseline_seconds)
+                line['cpu_baseline'] = cpu_baseline(args)
             except Exception as e:                        # the baseline must never hide the GPU number
                 line['cpu_baseline'] = {'error': repr(e)}
         print(json.dumps(line))
+        sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    return 0
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        sys.stderr.write('bench.py: --gpus must be >= 1\n')
+        return 2
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch(args, argv)
+    if args.dry:
+        return dry_rank(args)
+    return rank_main(args)
 
 
 if __name__ == '__main__':
-    main()
+    sys.exit(main())

@@ -34,7 +34,9 @@ enum {
   ATVS_ERR_LAUNCH = -4  /* the HIP runtime rejected the launch */
 };
 
-/* ABI version of this header (bumped on any signature change). */
+/* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
+ * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
+#define ATVS_ABI_VERSION 2
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);

@@ -1,0 +1,125 @@
+"""Generates tests/golden/fullsize_<cfg>.npz: outputs of the CPU oracle (oracle/) at BASELINE.json's FULL
+configurations on the seeded synthetic inputs and weights (the same ones bench.py uses), so that the
+-m gpu tests can check the HIP path at the sizes the throughput is quoted on:
+
+    cfg2    two-view 640x512, D=192                (BASELINE configs[1])   float32 oracle
+    cfg2f64 the same with the oracle's NETWORKS evaluated in float64 (geometry stays float32 so the same
+            pixels are sampled): the value both float32 pipelines approximate = the noise floor
+    cfg3    5 views 640x512, D=192, multi-view     (BASELINE configs[2], the metric's configuration)
+    cfg4    9 views 928x480, D=256, multi-view     (BASELINE configs[3]: 8 sources)
+    cfg5    two-view 1600x1184, D=256              (BASELINE configs[4])
+
+Each fixture holds the final full-resolution inverse-depth map plus a few intermediate maps / single depth
+planes of stage volumes (a few MB).  Run from the repository root in the BUILD container (CPU only):
+
+    python tests/golden/make_fullsize_golden.py cfg2 cfg2f64 cfg3 cfg4 cfg5
+
+Measured here (8 cores): see the `seconds` entry each fixture records.
+"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import atvsnet_amd                                     # noqa: E402,F401
+from atvsnet_amd import synthetic, variables           # noqa: E402
+from oracle import homography_warping as G             # noqa: E402
+from oracle import model as OM                         # noqa: E402
+from oracle import tf_ops as T                         # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CONFIGS = {            # name: (views, H, W, D)
+    'cfg2': (2, 512, 640, 192),
+    'cfg3': (5, 512, 640, 192),
+    'cfg4': (9, 480, 928, 256),
+    'cfg5': (2, 1184, 1600, 256),
+}
+
+
+def weights():
+    store = variables.VariableStore().init_synthetic(1234)
+    return {k: torch.from_numpy(v) for k, v in store.host.items()}
+
+
+def inputs(name):
+    n, H, Wd, D = CONFIGS[name]
+    imgs, cams = synthetic.make_inputs(n, H, Wd, D, seed=0)
+    return torch.from_numpy(imgs), torch.from_numpy(cams), D
+
+
+def twoview(name):
+    imgs, cams, D = inputs(name)
+    S = {}
+    d = OM.run_twoview(imgs, cams, weights(), D, S)
+    mid = D // 2
+    return {'depth': d[0, ..., 0].numpy(), 'depth_b2': S['depth_b2'][0, ..., 0].numpy(),
+            'depth_view': S['depth_view'][0, ..., 0].numpy(),
+            'refined_prob_mid': S['refined_prob_vol'][0, mid].numpy(),
+            'filtered_cost_mid': S['filtered_cost_volume'][0, mid].numpy()}
+
+
+def twoview_f64(name):
+    """The float64-network evaluation (see tests/golden/make_truth64_golden.py for the idea)."""
+    imgs, cams, D = inputs(name)
+    W64 = {k: v.double() for k, v in weights().items()}
+
+    def f32_boundary(fn):
+        def wrapped(*args, **kw):
+            args = [a.float() if isinstance(a, torch.Tensor) and a.dtype == torch.float64 else a for a in args]
+            out = fn(*args, **kw)
+            if isinstance(out, tuple):
+                return tuple(o.double() if o.dtype == torch.float32 else o for o in out)
+            return out.double() if out.dtype == torch.float32 else out
+        return wrapped
+    saved = {}
+    for fn in ('homography_warping', 'homography_warping_by_depth', 'transform_depth', 'get_visual_hull'):
+        saved[fn] = getattr(G, fn)
+        setattr(G, fn, f32_boundary(saved[fn]))
+    orig_linspace = T.linspace
+    T.linspace = lambda a, b, n: orig_linspace(float(a), float(b), n).double()
+    try:
+        d64 = OM.run_twoview(imgs.double(), cams, W64, D)
+    finally:
+        for fn, f in saved.items():
+            setattr(G, fn, f)
+        T.linspace = orig_linspace
+    return {'depth64': d64[0, ..., 0].numpy().astype(np.float32)}
+
+
+def multiview(name):
+    imgs, cams, D = inputs(name)
+    S = {}
+    d = OM.run_multiview(imgs, cams, weights(), D, S)
+    mid = D // 2
+    return {'depth': d[0, ..., 0].numpy(), 'depth_agg_init': S['depth_agg_init'][0, ..., 0].numpy(),
+            'depth_views': torch.stack([v[0, ..., 0] for v in S['depth_views']], 0).numpy(),
+            'cost_agg_mid': S['cost_volume_agg'][0, mid].numpy(),
+            'refined_cost_agg_mid': S['refined_cost_volume_agg'][0, mid].numpy()}
+
+
+def main(argv):
+    torch.set_num_threads(int(os.environ.get('ORACLE_THREADS', min(os.cpu_count() or 1, 8))))
+    for name in argv:
+        t0 = time.time()
+        with torch.no_grad():
+            if name == 'cfg2f64':
+                out = twoview_f64('cfg2')
+            elif CONFIGS[name][0] == 2:
+                out = twoview(name)
+            else:
+                out = multiview(name)
+        out['seconds'] = np.float64(time.time() - t0)
+        out['threads'] = np.int64(torch.get_num_threads())
+        path = os.path.join(HERE, 'fullsize_%s.npz' % name)
+        np.savez_compressed(path, **out)
+        print('%s: %.0f s, %.2f MB, depth mean %.6f' % (name, out['seconds'], os.path.getsize(path) / 1e6,
+                                                       float(np.abs(out.get('depth', out.get('depth64'))).mean())),
+              flush=True)
+
+
+if __name__ == '__main__':
+    main(sys.argv[1:] or ['cfg2', 'cfg2f64', 'cfg3'])

@@ -1,0 +1,40 @@
+"""bench.py --gpus N must start N ranks itself (the driver's command line is `python bench.py --gpus N ...`)."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*argv):
+    env = dict(os.environ)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=600)
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith('{')]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr.decode()
+
+
+def test_launcher_starts_n_ranks_dry():
+    rc, line, err = _run('--gpus', '2', '--dry')
+    assert rc == 0, err
+    assert line['n_gpus'] == 2 and line['config']['world_size'] == 2 and line['dry'] is True
+    assert line['config']['groups'] == [[0, 1]]
+    # every direction of every source of the default workload (4 sources) is planned exactly once
+    tasks = [tuple(t) for rank_tasks in line['config']['plan'] for t in rank_tasks]
+    assert sorted(tasks) == sorted((k, v) for k in ('fwd', 'rev') for v in (1, 2, 3, 4))
+
+
+def test_launcher_groups_beyond_one_rank_per_source():
+    rc, line, err = _run('--gpus', '4', '--dry', '--views', '3')
+    assert rc == 0, err
+    assert line['n_gpus'] == 4 and line['config']['groups'] == [[0, 1], [2, 3]]
+
+
+def test_launcher_refuses_a_smaller_world():
+    """Fewer visible devices than --gpus: non-zero exit and a message, never a silent world of 1."""
+    rc, line, err = _run('--gpus', '64')
+    assert rc != 0 and line is None
+    assert 'device' in err

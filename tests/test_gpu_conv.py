@@ -373,3 +373,37 @@ def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
     y2, st2 = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
     ops.use_xp1w(True)
     assert st2.params is None and torch.equal(y2, y)
+
+
+def test_weight_reload_changes_the_result(cuda):
+    """Run a convolution, replace its kernel in the variable store, run it again: the new kernel must be used (the
+    arranged copies are cached by variable name -- ADVICE r1) and the other device must not be touched."""
+    import numpy as np
+    from atvsnet_amd import variables
+    from atvsnet_amd.cnn_wrapper.network import Network
+
+    class One(Network):
+        def setup(self):
+            self.feed('data').conv(3, 16, 1, relu=False, name='reload_probe')
+
+    store = variables.default_store()
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(1, 8, 16, 24, 16, generator=g).to(cuda)
+    w1 = torch.randn(3, 3, 3, 16, 16, generator=g).numpy()
+    store.set('reload_probe/kernel', w1)
+    y1 = One({'data': x}, is_training=True).get_output().clone()
+    store.set('reload_probe/kernel', 2.0 * w1)
+    y2 = One({'data': x}, is_training=True).get_output()
+    assert float((y2 - 2.0 * y1).abs().max()) <= 1e-5 * float(y1.abs().max())
+    assert float(y1.abs().max()) > 0
+    del store.host['reload_probe/kernel']
+
+
+def test_tensor_on_another_device_is_refused(cuda):
+    """Kernels launch on the CURRENT device's stream: a tensor that lives elsewhere must raise, not fault."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip('one device')
+    from atvsnet_amd import ops
+    x = torch.zeros(4, 8, 8, device='cuda:1')
+    with pytest.raises(RuntimeError):
+        ops.channel_stats(x)

@@ -1,0 +1,191 @@
+"""-m gpu: the HIP path at EVERY BASELINE.json configuration, at full size.
+
+Fixtures tests/golden/fullsize_<cfg>.npz are outputs of the CPU oracle on the seeded inputs / weights
+(tests/golden/make_fullsize_golden.py, run in the build container).  Bar (BASELINE.json): rel-L1 of the final
+inverse-depth map <= 1e-3, on the inverse depth and on the depth; the tolerance is written here and is not
+loosened per size.  configs[1] additionally has the float64-network evaluation (the noise floor: what both
+float32 implementations approximate).  Size-independent properties checked at every configuration: HIP-graph replay ==
+eager launch bit for bit, the output lies inside the swept inverse-depth range, peak device memory.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), 'golden')
+BAR = 1e-3
+CONFIGS = {            # name: (views, H, W, D)
+    'cfg2': (2, 512, 640, 192),
+    'cfg3': (5, 512, 640, 192),
+    'cfg4': (9, 480, 928, 256),
+    'cfg5': (2, 1184, 1600, 256),
+}
+
+
+def rel_l1(got, want):
+    return float(((got - want).abs() / want.abs().clamp(min=1e-12)).mean())
+
+
+def _gold(name):
+    path = os.path.join(GOLD, 'fullsize_%s.npz' % name)
+    if not os.path.exists(path):
+        pytest.fail('fixture %s is missing: run tests/golden/make_fullsize_golden.py %s' % (path, name))
+    return {k: v for k, v in np.load(path).items()}
+
+
+def _inputs(name, cuda):
+    from atvsnet_amd import synthetic
+    n, H, W, D = CONFIGS[name]
+    imgs, cams = synthetic.make_inputs(n, H, W, D, seed=0)
+    return torch.from_numpy(imgs).to(cuda), torch.from_numpy(cams).to(cuda), D
+
+
+def _check_depth(name, got, gold, cams, D):
+    """Final map vs the oracle: rel-L1 on the inverse depth and on the depth, range, degeneracy."""
+    want = torch.from_numpy(gold['depth'])
+    got = got.reshape(want.shape).cpu()
+    e_inv = rel_l1(got, want)
+    e_dep = rel_l1(1.0 / got, 1.0 / want)
+    print('%s: rel-L1 inverse depth %.3e, depth %.3e (bar %.0e)' % (name, e_inv, e_dep, BAR))
+    ds, di = float(cams[0, 0, 1, 3, 0]), float(cams[0, 0, 1, 3, 1])
+    assert float(got.min()) >= ds - 1e-6 and float(got.max()) <= ds + (D - 1) * di + 1e-6      # soft-argmin is a convex combination
+    assert float(want.std()) > 0.02                                                            # not a flat answer
+    assert e_inv <= BAR and e_dep <= BAR
+    return e_inv
+
+
+def test_cfg2_twoview_fullsize(cuda, weights):
+    """BASELINE configs[1]: two-view 640x512, D=192 -- final map, both base-stage maps, one plane of two stage volumes,
+    and the float64 noise floor."""
+    from atvsnet_amd.atvsnet import example as ex
+    from atvsnet_amd.atvsnet import model
+    gold, g64 = _gold('cfg2'), _gold('cfg2f64')
+    imgs, cams, D = _inputs('cfg2', cuda)
+    got = ex.infer_twoview(imgs, cams, D)
+    _check_depth('cfg2', got, gold, cams, D)
+    # stage outputs of the base network (both siamese directions)
+    ds, di = ex.depth_range(cams)
+    depth_b2, prob_b2, filt, depth_view = model.TVSNet_base_siamese(imgs, cams, D, ds, di, view_i=1, ref_i=0)
+    for k, t in (('depth_b2', depth_b2), ('depth_view', depth_view)):
+        e = rel_l1(t.cpu()[0, ..., 0], torch.from_numpy(gold[k]))
+        print('cfg2 %s rel-L1 %.3e' % (k, e))
+        assert e <= BAR, k
+    w = torch.from_numpy(gold['filtered_cost_mid'])
+    assert float((filt.cpu()[0, D // 2] - w).abs().max()) <= 5e-3 * float(w.abs().max())
+    # noise floor: the HIP path is as close to the float64-network value as the float32 oracle is
+    d64 = torch.from_numpy(g64['depth64'])
+    g = got.cpu()[0, ..., 0]
+    e_hip64, e_orc64 = rel_l1(g, d64), rel_l1(torch.from_numpy(gold['depth']), d64)
+    print('cfg2: HIP vs float64 networks %.3e, float32 oracle vs float64 networks %.3e' % (e_hip64, e_orc64))
+    assert e_hip64 <= 1.5 * e_orc64 + 1e-6
+    # graph replay == eager, bit for bit
+    gr = ex.GraphedInference(imgs, cams, D)
+    assert torch.equal(gr(), got)
+
+
+def test_cfg3_multiview_fullsize(cuda, weights):
+    """BASELINE configs[2], the configuration the throughput is quoted on: 5 views 640x512, D=192.  Eager, per-view
+    streams and the HIP-graph replay that bench.py times all against the oracle fixture."""
+    from atvsnet_amd.atvsnet import example as ex
+    gold = _gold('cfg3')
+    imgs, cams, D = _inputs('cfg3', cuda)
+    G = {}
+    got = ex.infer_multiview(imgs, cams, D, G, view_streams=False)
+    _check_depth('cfg3', got, gold, cams, D)
+    e = rel_l1(G['depth_agg_init'].cpu()[0, ..., 0], torch.from_numpy(gold['depth_agg_init']))
+    print('cfg3 depth_agg_init rel-L1 %.3e' % e)
+    assert e <= BAR
+    dv = torch.stack([v[0, ..., 0] for v in G['depth_views']], 0).cpu()
+    assert rel_l1(dv, torch.from_numpy(gold['depth_views'])) <= BAR
+    for k, gk in (('cost_volume_agg', 'cost_agg_mid'), ('refined_cost_volume_agg', 'refined_cost_agg_mid')):
+        w = torch.from_numpy(gold[gk])
+        d = float((G[k].cpu()[0, D // 2] - w).abs().max())
+        print('cfg3 %s plane %d: max abs diff %.3e of max %.3e' % (k, D // 2, d, float(w.abs().max())))
+        assert d <= 5e-3 * float(w.abs().max()), k
+    del G
+    torch.cuda.reset_peak_memory_stats()
+    gr = ex.GraphedInference(imgs, cams, D)          # what bench.py replays
+    rep = gr()
+    assert torch.equal(rep, ex.infer_multiview(imgs, cams, D))          # per-view streams, eager
+    assert torch.equal(rep, got)
+    print('cfg3 peak device memory %.1f GB of 288' % (torch.cuda.max_memory_allocated() / 1e9))
+
+
+def test_cfg4_eight_sources_fullsize(cuda, weights):
+    """BASELINE configs[3]'s shape on one GPU: 9 views (8 sources) 928x480, D=256."""
+    from atvsnet_amd.atvsnet import example as ex
+    gold = _gold('cfg4')
+    imgs, cams, D = _inputs('cfg4', cuda)
+    torch.cuda.reset_peak_memory_stats()
+    G = {}
+    got = ex.infer_multiview(imgs, cams, D, G)
+    _check_depth('cfg4', got, gold, cams, D)
+    assert rel_l1(G['depth_agg_init'].cpu()[0, ..., 0], torch.from_numpy(gold['depth_agg_init'])) <= BAR
+    del G
+    gr = ex.GraphedInference(imgs, cams, D)
+    assert torch.equal(gr(), got)
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    print('cfg4 peak device memory %.1f GB of 288' % peak)
+    assert peak < 288
+
+
+def test_cfg5_highres_twoview_fullsize(cuda, weights):
+    """BASELINE configs[4]: two-view 1600x1184, D=256 (feature grid 296x400, 30.3 M voxels)."""
+    from atvsnet_amd.atvsnet import example as ex
+    gold = _gold('cfg5')
+    imgs, cams, D = _inputs('cfg5', cuda)
+    torch.cuda.reset_peak_memory_stats()
+    got = ex.infer_twoview(imgs, cams, D)
+    _check_depth('cfg5', got, gold, cams, D)
+    gr = ex.GraphedInference(imgs, cams, D)
+    assert torch.equal(gr(), got)
+    peak = torch.cuda.max_memory_allocated() / 1e9
+    print('cfg5 peak device memory %.1f GB of 288' % peak)
+    assert peak < 288
+
+
+def test_dominant_layer_fullsize_vs_oracle(cuda, weights):
+    """The launch bench.py's roofline is quoted on, at its full size: conv_b0_0_1 (3x3x3, 32 warped channels -> 8)
+    with its stride-2 sibling conv_b0_1_0 (-> 16) over a 192x128x160 volume, against the oracle's convolutions."""
+    from atvsnet_amd import ops
+    from oracle import tf_ops as T
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(192, 128, 160, 32, generator=g)
+    w8 = weights['conv_b0_0_1/conv3d/kernel'][:, :, :, 32:, :].contiguous()       # the D-varying (warped) half
+    w16 = weights['conv_b0_1_0/conv3d/kernel'][:, :, :, 32:, :].contiguous()
+    (y, st), (y2, st2) = ops.conv_siblings(x.to(cuda), 'fs/w8', w8.numpy(), 'fs/w16', w16.numpy())
+    want = T.conv(x[None], w8, 1, 'SAME')[0]
+    want2 = T.conv(x[None], w16, 2, 'SAME')[0]
+    assert y.shape == want.shape and y2.shape == want2.shape
+    assert float((y.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float((y2.cpu() - want2).abs().max()) <= 2e-5 * float(want2.abs().max())
+    # the moments the epilogue hands to batch norm
+    p = ops.bn_params(st, 8, y).cpu()
+    assert float((p[0] - want.reshape(-1, 8).mean(0)).abs().max()) <= 1e-5
+    var = want.reshape(-1, 8).double().var(0, unbiased=False)
+    assert float((p[1].double() - 1.0 / torch.sqrt(var + 1e-3)).abs().max()) <= 1e-4
+
+
+def test_warp_fullsize_bit_exact(cuda, weights):
+    """The plane-sweep warp at configs[1..2]'s size (192 planes of 128x160x32) and at configs[4]'s feature grid (a slab of
+    16 planes of 296x400x32): bit-exact against the oracle's per-plane warp."""
+    from atvsnet_amd import ops, synthetic
+    from oracle import homography_warping as G
+    for (H, W, D, planes) in ((512, 640, 192, range(0, 192, 37)), (1184, 1600, 256, (0, 100, 255))):
+        _, cams = synthetic.make_inputs(2, H, W, D)
+        cams = torch.from_numpy(cams)
+        h, w = H // 4, W // 4
+        g = torch.Generator().manual_seed(5)
+        feat = torch.randn(1, h, w, 32, generator=g)
+        ds, di = cams[:1, 0, 1, 3, 0].clone(), cams[:1, 0, 1, 3, 1].clone()
+        Hm = G.get_homographies(cams[:, 0], cams[:, 1], D, ds, di)
+        Hd = ops.get_homographies(cams[0, 0].contiguous().to(cuda), cams[0, 1].contiguous().to(cuda), ds.to(cuda),
+                                  di.to(cuda), D)
+        assert torch.equal(Hd.cpu(), Hm[0])
+        sel = torch.tensor(list(planes))
+        got = ops.warp_planes(feat[0].to(cuda), Hd[sel.to(cuda)].contiguous()).cpu()
+        for i, d in enumerate(planes):
+            assert torch.equal(got[i], G.homography_warping(feat, Hm[:, d])[0]), (H, W, d)

@@ -198,3 +198,26 @@ def test_flags_defaults_match_the_reference():
     FLAGS.reset()
     assert (FLAGS.view_num, FLAGS.max_d, FLAGS.batch_size, FLAGS.inverse_depth, FLAGS.sample_scale) == (5, 128, 1, True, 0.25)
     assert FLAGS.example_index == 2 and FLAGS.num_gpus == 1
+
+
+def test_library_abi_version_matches_header():
+    from atvsnet_amd import _lib
+    assert _lib.lib().atvs_abi_version() == _lib.header_abi_version() >= 2
+
+
+def test_weight_reload_drops_arranged_copies():
+    """The pack caches are keyed by variable NAME: setting a variable must drop every arranged copy."""
+    import numpy as np
+    import torch
+    from atvsnet_amd import ops, variables
+    store = variables.default_store()
+    w = store.get_host('conv_b1_1_1/conv3d/kernel', (3, 3, 3, 16, 16)).copy()
+    x = torch.empty((8, 16, 24, 16), dtype=torch.float32, device='meta')
+    ops.conv(x, 'conv_b1_1_1/conv3d/kernel', w)
+    ops._fold_cache[('k', ())] = 1
+    ops._xp_cache['k'] = 1
+    ops._virt_cache['k'] = 1
+    assert ops._pack_cache
+    store.set('conv_b1_1_1/conv3d/kernel', np.zeros_like(w))
+    assert not ops._pack_cache and not ops._fold_cache and not ops._xp_cache and not ops._virt_cache
+    store.set('conv_b1_1_1/conv3d/kernel', w)
