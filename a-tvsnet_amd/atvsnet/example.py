@@ -188,7 +188,8 @@ class GraphedInference(object):
         torch.cuda.current_stream(images.device).wait_stream(side)
         torch.cuda.synchronize(images.device)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # thread_local: other threads (e.g. the RCCL watchdog of a multi-GPU run) may issue HIP calls meanwhile
+        with torch.cuda.graph(self.graph, capture_error_mode='thread_local'):
             self.out = self._run()
         # the graph holds raw pointers to the weights it was captured with: keep those copies alive even if the
         # variable store is reloaded afterwards (the graph then goes on computing with the captured weights)

@@ -17,6 +17,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                           float* __restrict__ params, int C, int fold) {
   __shared__ double sm[2][256];
   const int c = blockIdx.x;
+  // blockIdx.y = independent sample (group): its own rows of partial sums, its own (3, C) parameter block
+  partials += (size_t)blockIdx.y * nblocks * 2 * cpad;
+  params += (size_t)blockIdx.y * 3 * C;
   double s = 0.0, q = 0.0;
   for (long b = threadIdx.x; b < nblocks; b += 256)
     for (int f = 0; f < fold; ++f) {      // columns c, c+C, ... hold the same channel (fused transposed conv)
@@ -43,11 +46,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
   }
 }
 
-extern "C" int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, int fold, long count,
+extern "C" int atvs_bn_finalize(const double* stats_partial, int groups, long num_blocks, int cpad, int fold, long count,
                                 const float* beta, float eps, float* params, int C, atvs_stream_t stream) {
   if (!stats_partial || !params) return ATVS_ERR_NULL;
-  if (num_blocks <= 0 || C <= 0 || fold < 1 || cpad < C * fold || count <= 0) return ATVS_ERR_SHAPE;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, as_stream(stream), stats_partial, num_blocks, cpad,
+  if (groups <= 0 || groups > 65535 || num_blocks <= 0 || C <= 0 || fold < 1 || cpad < C * fold || count <= 0)
+    return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C, groups), dim3(256), 0, as_stream(stream), stats_partial, num_blocks, cpad,
                      (double)count, beta, eps, params, C, fold);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
@@ -58,6 +62,8 @@ extern "C" int atvs_bn_finalize(const double* stats_partial, long num_blocks, in
 __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long rows, int C,
                                                             double* __restrict__ partials) {
   __shared__ double sm[2][256];
+  x += (size_t)blockIdx.y * rows * C;                        // blockIdx.y = independent sample (group)
+  partials += (size_t)blockIdx.y * gridDim.x * 2 * C;
   const int tpb = (256 / C) * C;        // active threads, multiple of C
   const int rstride = tpb / C;
   const int t = threadIdx.x;
@@ -95,11 +101,11 @@ __global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restr
 
 extern "C" long atvs_channel_stats_num_blocks(long rows) { return (rows + STATS_ROWS_PER_BLOCK - 1) / STATS_ROWS_PER_BLOCK; }
 
-extern "C" int atvs_channel_stats(const float* x, long rows, int C, double* stats_partial, atvs_stream_t stream) {
+extern "C" int atvs_channel_stats(const float* x, int groups, long rows, int C, double* stats_partial, atvs_stream_t stream) {
   if (!x || !stats_partial) return ATVS_ERR_NULL;
-  if (rows <= 0 || C <= 0 || C > 256) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || groups > 65535 || rows <= 0 || C <= 0 || C > 256) return ATVS_ERR_SHAPE;
   long nb = atvs_channel_stats_num_blocks(rows);
-  hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)nb), dim3(256), 0, as_stream(stream), x, rows, C, stats_partial);
+  hipLaunchKernelGGL(channel_stats_kernel, dim3((unsigned)nb, groups), dim3(256), 0, as_stream(stream), x, rows, C, stats_partial);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
@@ -107,10 +113,12 @@ extern "C" int atvs_channel_stats(const float* x, long rows, int C, double* stat
 // rows of width ld; the C channels starting at c_off are normalised (a channel slice of a concat buffer)
 template <int VEC>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ params,
-                                                       float* __restrict__ y, long n, int C, int ld, int c_off, int relu) {
+                                                       float* __restrict__ y, long n, int C, int ld, int c_off, int relu,
+                                                       long group_n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * VEC;
   if (i >= n) return;
   int c = (int)(i % C);
+  params += (i / group_n) * (3 * C);                          // group_n = elements per independent sample
   long a = (ld == C) ? i : (i / C) * ld + c_off + c;
   if (VEC == 4) {
     float4 v = ld4(x + a), m = ld4(params + c), s = ld4(params + C + c), b = ld4(params + 2 * C + c);
@@ -128,15 +136,16 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-extern "C" int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int ld, int c_off,
+extern "C" int atvs_bn_apply(const float* x, const float* params, float* y, int groups, long rows, int C, int ld, int c_off,
                              int relu, atvs_stream_t stream) {
   if (!x || !params || !y) return ATVS_ERR_NULL;
-  if (rows <= 0 || C <= 0 || ld < C || c_off < 0 || c_off + C > ld) return ATVS_ERR_SHAPE;
-  long n = rows * C;
+  if (groups <= 0 || rows <= 0 || C <= 0 || ld < C || c_off < 0 || c_off + C > ld) return ATVS_ERR_SHAPE;
+  long n = (long)groups * rows * C;          // rows = rows per independent sample; params (groups, 3, C)
+  const long gn = rows * C;
   if (C % 4 == 0 && ld % 4 == 0 && c_off % 4 == 0)
-    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, ld, c_off, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, ld, c_off, relu, gn);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, ld, c_off, relu);
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, params, y, n, C, ld, c_off, relu, gn);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
@@ -177,13 +186,16 @@ extern "C" int atvs_add_n(const float* a, const float* b, const float* c, float*
 __global__ __launch_bounds__(256) void bn_add_kernel(const float* __restrict__ x0, const float* __restrict__ p0,
                                                      const float* __restrict__ x1, const float* __restrict__ p1,
                                                      const float* __restrict__ x2, const float* __restrict__ p2,
-                                                     float* __restrict__ y, long n, int C, int relu_mask) {
+                                                     float* __restrict__ y, long n, int C, int relu_mask,
+                                                     long group_n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   int c = (int)(i % C);
+  const long pg = (i / group_n) * (3 * C);                    // parameter block of this element's sample
   auto term = [&](const float* x, const float* p, int relu) {
     float4 v = ld4(x + i);
     if (p) {
+      p += pg;
       float4 m = ld4(p + c), s = ld4(p + C + c), b = ld4(p + 2 * C + c);
       v.x = (v.x - m.x) * s.x + b.x;
       v.y = (v.y - m.y) * s.y + b.y;
@@ -205,12 +217,13 @@ __global__ __launch_bounds__(256) void bn_add_kernel(const float* __restrict__ x
 }
 
 extern "C" int atvs_bn_add(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
-                           const float* params2, float* y, long rows, int C, int relu_mask, atvs_stream_t stream) {
+                           const float* params2, float* y, int groups, long rows, int C, int relu_mask,
+                           atvs_stream_t stream) {
   if (!x0 || !x1 || !y) return ATVS_ERR_NULL;
-  if (rows <= 0 || C <= 0 || (C % 4) != 0) return ATVS_ERR_SHAPE;
-  long n = rows * C;
+  if (groups <= 0 || rows <= 0 || C <= 0 || (C % 4) != 0) return ATVS_ERR_SHAPE;
+  long n = (long)groups * rows * C;          // rows per independent sample; params_i (groups, 3, C)
   hipLaunchKernelGGL(bn_add_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x0, params0, x1, params1, x2,
-                     params2, y, n, C, relu_mask);
+                     params2, y, n, C, relu_mask, rows * C);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -365,6 +365,74 @@ def pack_conv_xp_sibling(key, w_host, device):
     return pk
 
 
+def conv2d_lds_ok(cin, cout, dilation, H, W):
+    """Is the LDS-tiled 2-D kernel (atvs_conv2d_lds_f32) used for a 3x3 stride-1 SAME convolution of this shape?"""
+    return (_FORCE_IMPL != 'gather' and _USE_CONV2D_LDS and H >= 8 and W >= 16
+            and bool(_lib.lib().atvs_conv2d_lds_supported(int(cin), int(cout), int(dilation))))
+
+
+_USE_CONV2D_LDS = True
+
+
+def use_conv2d_lds(flag):
+    """Testing / A-B hook for the LDS-tiled 2-D convolution of the feature towers."""
+    global _USE_CONV2D_LDS
+    _USE_CONV2D_LDS = bool(flag)
+
+
+def pack_conv2d_lds(key, w_host, device):
+    """Packed weights of the LDS-tiled 2-D kernel for a TF kernel [3,3,Cin,Cout]; cached."""
+    import numpy as np
+    ck = ('c2', key, str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    L = _lib.lib()
+    pf = ctypes.c_long()
+    rc = L.atvs_conv2d_lds_pack_size(cin, cout, ctypes.byref(pf))
+    if rc:
+        raise RuntimeError('atvs_conv2d_lds_pack_size failed (%d) for Cin=%d Cout=%d' % (rc, cin, cout))
+    packed = np.empty(pf.value, np.float32)
+    rc = L.atvs_conv2d_lds_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv2d_lds_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 9, 4, 0, cout // 16, cin, cout
+    pk.key = key
+    pk.tab = None
+    pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+def conv2d_lds(x, key, w_host, dilation=1, bias=None, residual=None, relu=False, want_stats=False, out=None, y_coff=0,
+               in_params=None, in_relu=False):
+    """3x3 stride-1 SAME convolution of x (G,H,W,Cin) -> (G,H,W,Cout) on the LDS-tiled 2-D kernel.
+    in_params (G,3,Cin): batch norm (+ ReLU if in_relu) of x applied on load.  want_stats: also returns the
+    per-image moments (Stats with groups = G)."""
+    G, H, W, cin = x.shape
+    pk = pack_conv2d_lds(key, w_host, x.device)
+    if pk.cin != cin:
+        raise ValueError('conv %s: input has %d channels, kernel wants %d' % (key, cin, pk.cin))
+    y = _new(x, (G, H, W, pk.cout)) if out is None else out
+    if tuple(y.shape[:3]) != (G, H, W):
+        raise ValueError('conv %s: output buffer %s does not match %s' % (key, tuple(y.shape), (G, H, W)))
+    st, sbuf = None, None
+    if want_stats:
+        rows = int(_lib.lib().atvs_conv2d_lds_rows(H, W, pk.cout))
+        sbuf = torch.empty((G, rows, 2, pk.cout), dtype=torch.float64, device=x.device)
+        st = Stats()
+        st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, pk.cout, H * W, G
+    if _dev_ok(x, y, bias, residual, in_params):
+        with _Timed(pk.key, (G, H, W, cin), pk.cout):
+            _call('atvs_conv2d_lds_f32', _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)),
+                  _p(y), ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, H, W, cin,
+                  pk.cout, int(dilation), int(y.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+    return (y, st) if want_stats else y
+
+
 def conv_xp_launch(x4, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None):
     """One atvs_conv_xp_f32 launch: x4 (D,H,W,Cin) -> y (D,H,W,ldy)[..., y_coff:y_coff+8].
     sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x4."""
@@ -543,11 +611,12 @@ def _pick_tile_m(M, ntiles):
 
 class Stats(object):
     """Per-workgroup partial sums of a tensor: feeds bn_finalize."""
-    __slots__ = ('partial', 'blocks', 'cpad', 'count', 'fold', 'params')
+    __slots__ = ('partial', 'blocks', 'cpad', 'count', 'fold', 'params', 'groups')
 
     def __init__(self):
         self.fold = 1
         self.params = None      # (3,C) moments already finished inside the producing launch
+        self.groups = 1         # independent samples: partial is (groups, blocks, 2, cpad), count per sample
 
 
 def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bias=None, residual=None, relu=False,
@@ -658,6 +727,15 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             outs.append((ins[i] - ((ks[i] - 1) * dilation + 1)) // stride + 1)
     taps = conv_taps(ks, dilation, pads)
     cout = int(w_host.shape[-1])
+    if nsp == 2 and stride == 1 and ks == (1, 3, 3) and tuple(pads[1:]) == (dilation, dilation) \
+            and tuple(outs) == tuple(ins) and plane_bias is None \
+            and (out is None or (out.shape[-1] % 4 == 0 and y_coff % 4 == 0)) \
+            and conv2d_lds_ok(w_host.shape[-2], cout, dilation, ins[1], ins[2]):
+        res = conv2d_lds(x4, key, w_host, dilation, bias, None if residual is None else residual.reshape((1,) + tuple(residual.shape)),
+                         relu, want_stats, None if out is None else out.reshape((1,) + tuple(out.shape)), y_coff)
+        y4, st = res if want_stats else (res, None)
+        y = out if out is not None else y4.reshape(tuple(y4.shape[1:]))
+        return (y, st) if want_stats else y
     tile_y = 0
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
             and tuple(outs) == tuple(ins):
@@ -937,47 +1015,56 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
 
 # --------------------------------------------------------------------------- batch norm / glue
 
-def channel_stats(x):
-    """Partial sums of x viewed as (rows, C)."""
+def channel_stats(x, groups=None):
+    """Partial sums of x viewed as (rows, C); groups=G: x is G independent samples stacked on its leading axis."""
     C = x.shape[-1]
-    rows = x.numel() // C
+    G = 1 if groups is None else int(groups)
+    rows = x.numel() // C // G
     blocks = int(_lib.lib().atvs_channel_stats_num_blocks(ctypes.c_long(rows)))
     st = Stats()
-    st.partial, st.blocks, st.cpad, st.count = _stats_buffer(x, blocks, C), blocks, C, rows
+    st.partial = torch.empty((G, blocks, 2, C), dtype=torch.float64, device=x.device)
+    st.blocks, st.cpad, st.count, st.groups = blocks, C, rows, G
     if _dev_ok(x):
-        _call('atvs_channel_stats', _p(x), ctypes.c_long(rows), C, ctypes.c_void_p(st.partial.data_ptr()), _stream())
+        _call('atvs_channel_stats', _p(x), G, ctypes.c_long(rows), C, ctypes.c_void_p(st.partial.data_ptr()), _stream())
     return st
 
 
 def bn_params(st, C, ref, beta=None, eps=1e-3):
-    """Stats -> params (3,C) = (mean, rstd, beta)."""
+    """Stats -> params (3,C) = (mean, rstd, beta); (G,3,C) for the G independent samples of a grouped tensor."""
     if st.params is not None and beta is None and abs(eps - 1e-3) < 1e-12:
         return st.params
-    params = _new(ref, (3, C))
+    G = st.groups
+    params = _new(ref, (3, C) if G == 1 else (G, 3, C))
     if _dev_ok(ref, beta):
-        _call('atvs_bn_finalize', ctypes.c_void_p(st.partial.data_ptr()), ctypes.c_long(st.blocks), st.cpad,
+        _call('atvs_bn_finalize', ctypes.c_void_p(st.partial.data_ptr()), int(G), ctypes.c_long(st.blocks), st.cpad,
               int(st.fold), ctypes.c_long(st.count), _p(beta), ctypes.c_float(eps), _p(params), C, _stream())
     return params
 
 
+def _param_groups(params):
+    return 1 if params.dim() == 2 else int(params.shape[0])
+
+
 def bn_apply(x, params, relu=False, out=None, C=None, c_off=0):
-    """y = relu((x - mean) * rstd + beta).  With C / c_off: only that channel slice of the rows of x (in place)."""
+    """y = relu((x - mean) * rstd + beta).  With C / c_off: only that channel slice of the rows of x (in place).
+    params (G,3,C): x is G independent samples stacked on its leading axis, each with its own parameters."""
     ld = x.shape[-1]
     C = ld if C is None else C
     y = x if out is None else out
+    G = _param_groups(params)
     if _dev_ok(x, params, y):
-        _call('atvs_bn_apply', _p(x), _p(params), _p(y), ctypes.c_long(x.numel() // ld), int(C), int(ld), int(c_off),
-              int(bool(relu)), _stream())
+        _call('atvs_bn_apply', _p(x), _p(params), _p(y), G, ctypes.c_long(x.numel() // ld // G), int(C), int(ld),
+              int(c_off), int(bool(relu)), _stream())
     return y
 
 
-def batch_norm(x, st=None, beta=None, relu=False, inplace=False, eps=1e-3, C=None, c_off=0):
+def batch_norm(x, st=None, beta=None, relu=False, inplace=False, eps=1e-3, C=None, c_off=0, groups=None):
     """Training-mode BN of x with its own batch statistics (st = Stats from the producer, else computed).
     C / c_off select a channel slice of a wider buffer (statistics must then come from the producer)."""
     if st is None:
         if C is not None:
             raise ValueError('batch_norm on a channel slice needs the producer\'s statistics')
-        st = channel_stats(x)
+        st = channel_stats(x, groups)
     params = bn_params(st, x.shape[-1] if C is None else C, x, beta, eps)
     if C is not None:
         return bn_apply(x, params, relu, C=C, c_off=c_off)
@@ -1027,10 +1114,14 @@ def bn_add(items):
             ps.append(None)
     C = xs[0].shape[-1]
     out = _new(xs[0], xs[0].shape)
+    gs = set(_param_groups(p) for p in ps if p is not None)
+    if len(gs) != 1:
+        raise ValueError('bn_add: the pending batch norms disagree on the number of independent samples')
+    G = gs.pop()
     if _dev_ok(*(xs + [p for p in ps if p is not None])):
         x2, p2 = (xs[2], ps[2]) if len(xs) > 2 else (None, None)
-        _call('atvs_bn_add', _p(xs[0]), _p(ps[0]), _p(xs[1]), _p(ps[1]), _p(x2), _p(p2), _p(out),
-              ctypes.c_long(out.numel() // C), C, int(mask), _stream())
+        _call('atvs_bn_add', _p(xs[0]), _p(ps[0]), _p(xs[1]), _p(ps[1]), _p(x2), _p(p2), _p(out), G,
+              ctypes.c_long(out.numel() // C // G), C, int(mask), _stream())
     return out
 
 

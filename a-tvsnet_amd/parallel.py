@@ -232,7 +232,9 @@ class ShardedGraphedInference(object):
         while not done:
             g = torch.cuda.CUDAGraph()
             item = None
-            with torch.cuda.graph(g, pool=pool):
+            # thread_local: the RCCL watchdog thread polls its events (hipEventQuery) while this thread captures;
+            # in the default global mode that call is "not permitted when stream is capturing" and aborts the process
+            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
                 try:
                     item = next(gen)
                 except StopIteration as e:

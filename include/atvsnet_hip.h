@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 2
+#define ATVS_ABI_VERSION 3
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -241,6 +241,25 @@ int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, c
                      const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, atvs_stream_t stream);
 
+/* 3x3 stride-1 SAME 2-D convolution (dilation 1, 2 or 4) of wide feature maps, LDS-tiled (conv2d_lds.hip): the
+ * heavy layers of the feature towers -- the bottlenecks' conv2 (slim.conv2d, network.py:585-587), conv0_1 / conv0_2 /
+ * fusion0 (tf.layers.conv2d, network.py:198-200; cnn_wrapper/atvsnet.py:254-292).  x (G,H,W,Cin): G independent
+ * images (one tower call each in the reference), Cin % 16 == 0, Cout in {32, 64, 128} (dilation 2 / 4: Cout 128).
+ *   atvs_conv2d_lds_supported   1 if (Cin, Cout, dilation) is served by this kernel
+ *   atvs_conv2d_lds_pack_size / _pack   HOST: pack the TF kernel [3,3,Cin,Cout] (upload the result)
+ *   atvs_conv2d_lds_rows        workgroups per image = rows per image of stats_partial ([2][Cout] doubles each)
+ *   atvs_conv2d_lds_f32         y (G,H,W,ldy)[..., y_coff + co] = conv(x) (+ bias, + residual, ReLU); in_params
+ *                               (G,3,Cin) != NULL: x is a raw convolution output and its batch norm (mean, rstd,
+ *                               beta per image) [+ ReLU if in_relu] is applied while the tile is staged
+ *                               (normalise-on-load; the SAME padding stays zero). */
+int atvs_conv2d_lds_supported(int Cin, int Cout, int dilation);
+int atvs_conv2d_lds_pack_size(int Cin, int Cout, long* packed_floats);
+int atvs_conv2d_lds_pack(const float* w, int Cin, int Cout, float* packed);
+long atvs_conv2d_lds_rows(int H, int W, int Cout);
+int atvs_conv2d_lds_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
+                        const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H, int W,
+                        int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,
  * 242,336).  x (D,H,W,8); w = the TF kernel [3,3,3,8,1] (216 floats, device); y (D,H,W).
@@ -251,29 +270,33 @@ int atvs_conv3d_8to1(const float* x, const float* w, float* y, int D, int H, int
  * Batch norm with batch statistics, element-wise glue  (cnn_wrapper/network.py)
  * ------------------------------------------------------------------------- */
 
-/* Reduce per-workgroup partial sums [num_blocks][2][cpad] (double) to
- * params [3][C] = (mean, rsqrt(var+eps), beta): the moments of
+/* `groups` in this section: the tensor is `groups` INDEPENDENT samples stacked along its leading axis, each with its
+ * own batch statistics -- the reference evaluates every network call with batch 1 and per-call statistics (quirk C1);
+ * stacking the calls of a depth map (views, siamese directions) into one launch must not change them. */
+
+/* Reduce per-workgroup partial sums [groups][num_blocks][2][cpad] (double) to
+ * params [groups][3][C] = (mean, rsqrt(var+eps), beta): the moments of
  * tf.layers.batch_normalization(training=True) / slim.batch_norm, network.py:206-212,
- * 541-547, 570-571.  count = elements per channel.  beta (C) or NULL.  fold >= 1: channel c
+ * 541-547, 570-571.  count = elements per channel of one sample.  beta (C, shared) or NULL.  fold >= 1: channel c
  * also sums columns c + C, c + 2C, ... (fold of them). */
-int atvs_bn_finalize(const double* stats_partial, long num_blocks, int cpad, int fold, long count,
+int atvs_bn_finalize(const double* stats_partial, int groups, long num_blocks, int cpad, int fold, long count,
                      const float* beta, float eps, float* params, int C, atvs_stream_t stream);
 
-/* Partial sums of an arbitrary (rows, C) tensor, C <= 256, in the layout above with
- * cpad = C and atvs_channel_stats_num_blocks(rows) blocks. */
+/* Partial sums of an arbitrary (groups, rows, C) tensor, C <= 256, in the layout above with
+ * cpad = C and atvs_channel_stats_num_blocks(rows) blocks per sample. */
 long atvs_channel_stats_num_blocks(long rows);
-int atvs_channel_stats(const float* x, long rows, int C, double* stats_partial, atvs_stream_t stream);
+int atvs_channel_stats(const float* x, int groups, long rows, int C, double* stats_partial, atvs_stream_t stream);
 
-/* y = (x - mean) * rstd + beta [, relu]; y may alias x.  x and y are rows of width ld of which the C
- * channels starting at c_off are touched (ld = C, c_off = 0 for a dense tensor). */
-int atvs_bn_apply(const float* x, const float* params, float* y, long rows, int C, int ld, int c_off,
+/* y = (x - mean) * rstd + beta [, relu]; y may alias x.  x and y are groups * rows rows of width ld of which the C
+ * channels starting at c_off are touched (ld = C, c_off = 0 for a dense tensor); params (groups, 3, C). */
+int atvs_bn_apply(const float* x, const float* params, float* y, int groups, long rows, int C, int ld, int c_off,
                   int relu, atvs_stream_t stream);
 
 /* tf.add_n of two or three tensors of which any may still be a raw convolution output whose
- * batch norm (+ ReLU, relu_mask bit i) is pending: y = sum_i bn_relu_i(x_i), params_i (3,C) or NULL
- * for an already-final tensor; x2 may be NULL.  C % 4 == 0.  (network.py:172-215 + :695-697 fused.) */
+ * batch norm (+ ReLU, relu_mask bit i) is pending: y = sum_i bn_relu_i(x_i), params_i (groups,3,C) or NULL
+ * for an already-final tensor; x2 may be NULL.  C % 4 == 0; rows per sample.  (network.py:172-215 + :695-697 fused.) */
 int atvs_bn_add(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
-                const float* params2, float* y, long rows, int C, int relu_mask, atvs_stream_t stream);
+                const float* params2, float* y, int groups, long rows, int C, int relu_mask, atvs_stream_t stream);
 
 /* tf.add_n of two or three tensors (c may be NULL), network.py:695-697. */
 int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream);

@@ -407,3 +407,52 @@ def test_tensor_on_another_device_is_refused(cuda):
     x = torch.zeros(4, 8, 8, device='cuda:1')
     with pytest.raises(RuntimeError):
         ops.channel_stats(x)
+
+
+@pytest.mark.parametrize('cin,cout,dil,H,W,G', [
+    (128, 128, 2, 32, 48, 1), (128, 128, 4, 30, 44, 2), (64, 128, 1, 17, 33, 3), (320, 128, 1, 16, 32, 1),
+    (64, 64, 1, 24, 40, 2), (32, 32, 1, 36, 52, 2), (32, 64, 1, 9, 16, 1)])
+def test_conv2d_lds_matches_oracle(cuda, cin, cout, dil, H, W, G):
+    """The LDS-tiled 2-D convolution of the feature towers (conv2d_lds.hip): every instantiation, ragged edges,
+    several independent images per launch, bias / residual / ReLU and the per-image moments."""
+    from atvsnet_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + dil)
+    x = torch.randn(G, H, W, cin, generator=g)
+    w = torch.randn(3, 3, cin, cout, generator=g) * (2.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(G, H, W, cout, generator=g)
+    assert ops.conv2d_lds_ok(cin, cout, dil, H, W)
+    y, st = ops.conv2d_lds(x.to(cuda), ('t', cin, cout, dil), w.numpy(), dil, b.to(cuda), res.to(cuda), True, True)
+    want = torch.clamp(T.conv(x, w, 1, 'SAME', dilation=dil, bias=b) + res, min=0)
+    assert float((y.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    p = ops.bn_params(st, cout, y).cpu().reshape(G, 3, cout)
+    for i in range(G):
+        flat = want[i].reshape(-1, cout).double()
+        assert float((p[i, 0] - flat.mean(0)).abs().max()) <= 1e-5
+        assert float((p[i, 1] - 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
+    # plain form through ops.conv (one image): same kernel, no epilogue operands
+    y1 = ops.conv(x[0].to(cuda), ('t', cin, cout, dil), w.numpy(), dilation=dil)
+    w1 = T.conv(x[:1], w, 1, 'SAME', dilation=dil)[0]
+    assert float((y1.cpu() - w1).abs().max()) <= 2e-5 * float(w1.abs().max())
+
+
+def test_conv2d_lds_normalise_on_load(cuda):
+    """in_params: the producer's training-mode batch norm (+ ReLU) applied while the tile is staged equals
+    normalising first; the SAME padding is zero AFTER the normalisation."""
+    from atvsnet_amd import ops
+    g = torch.Generator().manual_seed(77)
+    G, H, W, cin, cout = 2, 20, 36, 64, 64
+    x = torch.randn(G, H, W, cin, generator=g) * 3 + 1
+    w = torch.randn(3, 3, cin, cout, generator=g) * 0.05
+    beta = torch.randn(cin, generator=g) * 0.1
+    xd = x.to(cuda)
+    st = ops.channel_stats(xd, groups=G)
+    params = ops.bn_params(st, cin, xd, beta.to(cuda))
+    assert tuple(params.shape) == (G, 3, cin)
+    y = ops.conv2d_lds(xd, 'nol', w.numpy(), in_params=params, in_relu=True)
+    xn = torch.stack([torch.clamp(T.batch_norm_train(x[i:i + 1], beta)[0], min=0) for i in range(G)])
+    want = T.conv(xn, w, 1, 'SAME')
+    assert float((y.cpu() - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    # and the explicit two-pass form on the device agrees to rounding
+    two = ops.conv2d_lds(ops.bn_apply(xd.clone(), params, True), 'nol', w.numpy())
+    assert float((y - two).abs().max()) <= 1e-6 * float(two.abs().max())
