@@ -33,8 +33,10 @@ from ..tools.common import Notify
 from ..tools import xlsx
 from .eval_errors import acc_metrics_namelist, calc_error, err_metrics_namelist
 from .model import (TVSNet, TVSNet_base_siamese, TVSNet_feature_extraction, TVSNet_refine,           # noqa: F401
-                    cost_volume_aggregation, cost_volume_aggregation_refine, extract_feature_shallow, output_conv,
-                    output_conv_refine, prob2depth, prob2depth_upsample)
+                    base_stage_batch, cost_volume_aggregation, cost_volume_aggregation_refine,
+                    extract_feature_shallow, feature_extraction_batch, output_conv, output_conv_refine, prob2depth,
+                    prob2depth_upsample, refinement_batch, shallow_feature_batch)
+from .. import ops
 from ..cnn_wrapper.atvsnet import ResNetDS2SPP_shallow_f16
 
 
@@ -44,11 +46,26 @@ def depth_range(cams):
     return cams[0, 0, 1, 3, 0:1].contiguous(), cams[0, 0, 1, 3, 1:2].contiguous()
 
 
-def infer_twoview(images, cams, max_d=None):
+# Every network of a depth map is evaluated ONCE over all its independent calls (views, siamese directions) stacked on
+# the batch axis, with per-call batch statistics (model.*_batch): ~8x fewer, 8x larger launches than the reference's
+# call-per-view order, same values.  batched=False keeps the call-per-view order (per-view HIP streams).
+BATCHED = True
+
+
+def infer_twoview(images, cams, max_d=None, batched=None):
     """The graph of run_test_twoview (reference example.py:239-240, 267): images (1,2,H,W,3) float32
     BGR 0..255, cams (1,2,2,4,4), both on the device -> inverse-depth map (1,H,W,1) on the device."""
     max_d = FLAGS.max_d if max_d is None else max_d
     depth_start, depth_interval = depth_range(cams)
+    if BATCHED if batched is None else batched:
+        # model.TVSNet (reference model.py:346-377) with both towers, both siamese directions in one pass each
+        feats = feature_extraction_batch(images)
+        _, prob_b2, depth_b2, dview = base_stage_batch(feats, cams, max_d, depth_start, depth_interval, fwd=[1], rev=[1])
+        shallow = shallow_feature_batch(images)
+        _, prob_residual = refinement_batch(depth_b2, dview, prob_b2, cams, max_d, depth_start, depth_interval, [1], shallow)
+        refined_prob_volume = ops.add_n([prob_b2, prob_residual])
+        _, depth_refined = prob2depth_upsample(refined_prob_volume, max_d, depth_start, depth_interval, out_prob_map=False)
+        return depth_refined
     refined_prob_volume = TVSNet(images, cams, max_d, depth_start, depth_interval, view_i=1, ref_i=0)
     _, depth_refined = prob2depth_upsample(refined_prob_volume, max_d, depth_start, depth_interval, out_prob_map=False)
     return depth_refined
@@ -117,15 +134,50 @@ class _ViewStreams(object):
         rec(tensors)
 
 
-def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True, out_prob_map=False):
+def _infer_multiview_batched(images, cams, max_d, stages, out_prob_map):
+    """infer_multiview with every per-view network evaluated once over all views (model.*_batch)."""
+    n = images.shape[1]
+    src = list(range(1, n))
+    depth_start, depth_interval = depth_range(cams)
+    feats = feature_extraction_batch(images)
+    filtered, _, _, depth_view = base_stage_batch(feats, cams, max_d, depth_start, depth_interval, fwd=src, rev=src)
+    del feats
+    # AAM1
+    cost_volume_agg = cost_volume_aggregation(filtered, reuse=False, keepchannel=True)
+    prob_volume_agg = output_conv(cost_volume_agg, reuse=False)
+    depth_agg_init = prob2depth(prob_volume_agg, max_d, depth_start, depth_interval, out_prob_map=False)
+    del filtered
+    # refinement of every source against the aggregated estimate
+    shallow = shallow_feature_batch(images)
+    cost_residual, _ = refinement_batch(depth_agg_init, depth_view, prob_volume_agg, cams, max_d, depth_start,
+                                        depth_interval, src, shallow)
+    refined = torch.empty_like(cost_residual)
+    for b in range(len(src)):                                   # refined_cost = filtered_cost + residual (model.py:438)
+        ops.add_n([cost_volume_agg[0], cost_residual[b]], out=refined[b])
+    del cost_residual
+    # AAM2
+    refined_cost_volume_agg = cost_volume_aggregation_refine(refined, reuse=False, keepchannel=True)
+    refined_prob_volume_agg = output_conv_refine(refined_cost_volume_agg, reuse=False)
+    final = prob2depth_upsample(refined_prob_volume_agg, max_d, depth_start, depth_interval, out_prob_map=out_prob_map)
+    if stages is not None:
+        stages.update(depth_views=[depth_view[v] for v in src], cost_volume_agg=cost_volume_agg,
+                      prob_volume_agg=prob_volume_agg, depth_agg_init=depth_agg_init,
+                      refined_cost_volume_agg=refined_cost_volume_agg, refined_prob_volume_agg=refined_prob_volume_agg)
+    return final if out_prob_map else final[1]
+
+
+def infer_multiview(images, cams, max_d=None, stages=None, view_streams=True, out_prob_map=False, batched=None):
     """The run loop of run_test_multiview (reference example.py:140-181), on the device:
     base (per source) -> AAM1 -> refinement (per source) -> AAM2 -> x4 upsample + soft-argmin.
+    batched (default BATCHED): one pass of each network over all its per-view calls; otherwise call per view, and
     view_streams: issue the independent per-view stages on separate HIP streams.
     out_prob_map: return (depth, depth_up, prob_map, prob_map_up) as the ETH3D driver's last stage does
     (reference eval_pointcloud.py:268-272) instead of depth_up alone."""
     max_d = FLAGS.max_d if max_d is None else max_d
     n = images.shape[1]
     assert n > 2
+    if BATCHED if batched is None else batched:
+        return _infer_multiview_batched(images, cams, max_d, stages, out_prob_map)
     depth_start, depth_interval = depth_range(cams)
     vs = _ViewStreams(n - 1, images.device, view_streams)
     start = vs.mark() if OVERLAP_REF_TOWER else None     # the source towers need not wait for the reference tower ...
@@ -174,9 +226,10 @@ class GraphedInference(object):
     Inputs live in static device buffers: pass new images / cams to __call__ to overwrite them.
     """
 
-    def __init__(self, images, cams, max_d=None, view_streams=True, out_prob_map=False):
+    def __init__(self, images, cams, max_d=None, view_streams=True, out_prob_map=False, batched=None):
         self.max_d = FLAGS.max_d if max_d is None else max_d
         self.out_prob_map = out_prob_map
+        self.batched = BATCHED if batched is None else batched
         self.images = images.clone()
         self.cams = cams.clone()
         self.twoview = images.shape[1] == 2
@@ -198,9 +251,9 @@ class GraphedInference(object):
 
     def _run(self):
         if self.twoview:
-            return infer_twoview(self.images, self.cams, self.max_d)
+            return infer_twoview(self.images, self.cams, self.max_d, batched=self.batched)
         return infer_multiview(self.images, self.cams, self.max_d, view_streams=self.view_streams,
-                               out_prob_map=self.out_prob_map)
+                               out_prob_map=self.out_prob_map, batched=self.batched)
 
     def __call__(self, images=None, cams=None):
         if images is not None:

@@ -136,6 +136,72 @@ def cost_volume_reasoning(cost_volume, output_prob=True, output_filtered_cost=Fa
     return tower.get_output_by_name('conv_b2_6_1')
 
 
+def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_cam, ref_f, view_f, D, ds, di, depth_start,
+                        depth_interval):
+    """The volume construction of reference :247-330 for ONE (reference, source) pair, written into sample b of the
+    batched buffers `bufs` = (photo_var (B,D,h,w,F), photo_const (B,h,w,2F), geo_var (B,D,h,w,2), geo_const (B,h,w,2),
+    vis_hull (B,D,h,w,1)).  init_ref / init_view (1,h,w,1); ref_f / view_f (1,h,w,F); cams (1,2,4,4).
+    hull_cam: the camera get_visual_hull pairs the source's depth map with -- cams[:, id_reorder[1]], i.e. view 1
+    whatever the current source is (quirk C6, homography_warping.py:343-352)."""
+    photo_var, photo_const, geo_var, geo_const, hull = bufs
+    h, w = init_ref.shape[1:3]
+    chan = ref_f.shape[3]
+    init_view_trans = transform_depth(init_view, view_cam, ref_cam)
+    Hm = get_homographies(ref_cam, view_cam, depth_num=D, depth_start=depth_start, depth_interval=depth_interval)[0].contiguous()
+    rf, vf = ref_f[0].contiguous(), view_f[0].contiguous()
+    dref = init_ref.reshape(h, w).contiguous()
+    dvt = init_view_trans.reshape(h, w, 1).contiguous()
+    rc, vc = ref_cam[0].contiguous(), view_cam[0].contiguous()
+    # photo_group = [ |warp_d(view_f) - ref_f| * mask , tile(photo_err) , tile(ref_f) ]   (:270-280, 309-311, 329, 333)
+    # geo_group   = [ geo_ref(1) , geo_view (mask tiled to `chan` identical channels, quirk C7) , tile(geo_err) ,
+    #                 tile(init_ref) ]                                                    (:285-300, 313-316, 330, 334)
+    # Only the D-varying channels are built as volumes; the tiled maps stay (h,w,C) (ops.SplitVolume).
+    wfeat, mphoto = ops.warp_by_depth(vf, rc, vc, dref, 'bilinear', FLAGS.inverse_depth)
+    photo_err = ops.absdiff_mask(wfeat, rf, mphoto)
+    wdep, mgeo = ops.warp_by_depth(dvt, rc, vc, dref, 'nearest', FLAGS.inverse_depth)
+    geo_err = ops.absdiff_mask(wdep, dref.reshape(h, w, 1), mgeo)
+    ops.warp_planes(vf, Hm, out=photo_var[b], mode=1, ref=rf)                              # (D,h,w,chan)
+    ops.copy_channels(photo_err, photo_const[b], chan, 0, 0)
+    ops.copy_channels(rf, photo_const[b], chan, 0, chan)
+    ops.geo_ref_planes(dref, ds, di, geo_var[b], 0)
+    ops.warp_planes(dvt, Hm, out=geo_var[b], c_off=1, mode=2, depth_start=ds, depth_interval=di, rep=1)
+    ops.copy_channels(geo_err, geo_const[b], 1, 0, 0)
+    ops.copy_channels(dref.reshape(h, w, 1), geo_const[b], 1, 0, 1)
+    # get_visual_hull(view_num = 2) (:321-324; homography_warping.py:329-387)
+    if hull_cam is view_cam:
+        h_hull, vt_hull = Hm, init_view_trans
+    else:
+        h_hull = get_homographies(ref_cam, hull_cam, depth_num=D, depth_start=depth_start,
+                                  depth_interval=depth_interval)[0].contiguous()
+        vt_hull = transform_depth(init_view, hull_cam, ref_cam)
+    ops.visual_hull(dref, vt_hull.reshape(h, w).contiguous(), h_hull, ds, di, FLAGS.inverse_depth,
+                    out=hull[b].reshape(D, h, w))
+    return chan
+
+
+def _hull_view(ref_id):
+    """id_reorder[1] of get_visual_hull(view_num = 2) (homography_warping.py:343-346): the view whose CAMERA the hull
+    uses for the second depth map."""
+    ids = [0, 1]
+    ids[0] = ref_id
+    ids[ref_id] = 0
+    return ids[1]
+
+
+def _refine_net(bufs, prob_vol, chan, independent):
+    photo_var, photo_const, geo_var, geo_const, hull = bufs
+    photo = ops.SplitVolume(photo_var, photo_const, [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
+    geo = ops.SplitVolume(geo_var, geo_const, [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
+    tower = CostVolRefineNet({'photo_group': photo, 'geo_group': geo, 'prob_vol': prob_vol, 'vis_hull': hull},
+                             is_training=True, reuse=AUTO_REUSE, independent_samples=independent)
+    return tower.get_output_by_name('global_refine_3dconv6_1'), tower.get_output().squeeze(-1)
+
+
+def _refinement_buffers(B, D, h, w, chan, like):
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=like.device)     # noqa: E731
+    return (e(B, D, h, w, chan), e(B, h, w, 2 * chan), e(B, D, h, w, 2), e(B, h, w, 2), e(B, D, h, w, 1))
+
+
 def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, images, prob_vol, ref_id, view_id,
                view_homographies=None, num_depths=None, depth_ref_id=None, depth_view_id=None,
                shallow_features=None):
@@ -149,50 +215,90 @@ def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, 
         depth_view_id = view_id
     if num_depths is None:
         num_depths = FLAGS.view_num
+    if num_depths != 2:
+        raise NotImplementedError('refinement: num_depths=2 (every call site of the reference) is built')
     D = int(depth_num)
     ds, di = _scalar(depth_start), _scalar(depth_interval)
     init_ref = init_depth_images[:, depth_ref_id]             # (B,h,w,1)
     init_view = init_depth_images[:, depth_view_id]
     h, w = init_ref.shape[1:3]
-    ref_cam, view_cam = cams[:, ref_id], cams[:, view_id]
-    init_view_trans = transform_depth(init_view, view_cam, ref_cam)
-    if view_homographies is None:
-        view_homographies = get_homographies(ref_cam, view_cam, depth_num=D, depth_start=depth_start,
-                                             depth_interval=depth_interval)
-    Hm = view_homographies[0].contiguous()
     if shallow_features is None:
         ref_f, view_f = extract_feature_shallow(images, ref_id, view_id)
     else:
         ref_f, view_f = shallow_features
-    chan = ref_f.shape[3]
-    rf, vf = ref_f[0].contiguous(), view_f[0].contiguous()
-    dref = init_ref.reshape(h, w).contiguous()
-    dvt = init_view_trans.reshape(h, w, 1).contiguous()
-    rc, vc = ref_cam[0].contiguous(), view_cam[0].contiguous()
+    bufs = _refinement_buffers(1, D, h, w, ref_f.shape[3], ref_f)
+    view_cam = cams[:, view_id]
+    hull_cam = view_cam if _hull_view(ref_id) == view_id else cams[:, _hull_view(ref_id)]
+    chan = _refinement_volumes(0, bufs, init_ref, init_view, cams[:, ref_id], view_cam, hull_cam, ref_f, view_f, D, ds,
+                               di, depth_start, depth_interval)
+    return _refine_net(bufs, prob_vol.unsqueeze(-1), chan, False)
 
-    # photo_group = [ |warp_d(view_f) - ref_f| * mask , tile(photo_err) , tile(ref_f) ]   (:270-280, 309-311, 329, 333)
-    # geo_group   = [ geo_ref(1) , geo_view (mask tiled to `chan` identical channels, quirk C7) , tile(geo_err) ,
-    #                 tile(init_ref) ]                                                    (:285-300, 313-316, 330, 334)
-    # Only the D-varying channels are built as volumes; the tiled maps stay (h,w,C) (ops.SplitVolume).
-    wfeat, mphoto = ops.warp_by_depth(vf, rc, vc, dref, 'bilinear', FLAGS.inverse_depth)
-    photo_err = ops.absdiff_mask(wfeat, rf, mphoto)
-    wdep, mgeo = ops.warp_by_depth(dvt, rc, vc, dref, 'nearest', FLAGS.inverse_depth)
-    geo_err = ops.absdiff_mask(wdep, dref.reshape(h, w, 1), mgeo)
-    photo_var = ops.warp_planes(vf, Hm, mode=1, ref=rf)                              # (D,h,w,chan)
-    photo = ops.SplitVolume(photo_var, ops.concat_channels([photo_err, rf]),
-                            [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
-    geo_var = torch.empty((D, h, w, 2), dtype=torch.float32, device=rf.device)
-    ops.geo_ref_planes(dref, ds, di, geo_var, 0)
-    ops.warp_planes(dvt, Hm, out=geo_var, c_off=1, mode=2, depth_start=ds, depth_interval=di, rep=1)
-    geo = ops.SplitVolume(geo_var, ops.concat_channels([geo_err, dref.reshape(h, w, 1)]),
-                          [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
 
-    vis_hull = get_visual_hull(init_depth_images.squeeze(-1), cams, D, depth_start, depth_interval, ref_id=ref_id,
-                               view_num=num_depths)
-    tower = CostVolRefineNet({'photo_group': photo, 'geo_group': geo,
-                              'prob_vol': prob_vol.unsqueeze(-1), 'vis_hull': vis_hull},
-                             is_training=True, reuse=AUTO_REUSE)
-    return tower.get_output_by_name('global_refine_3dconv6_1'), tower.get_output().squeeze(-1)
+def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_start, depth_interval, sources,
+                     shallow, ref_id=0):
+    """`refinement` of several source views against one reference estimate in ONE pass of the network
+    (the reference calls it once per source, example.py:163-172): depth_ref (1,h,w,1), depth_views {source: (1,h,w,1)},
+    prob_vol (1,D,h,w) shared, shallow (N,h,w,16) features of every view -> (cost residuals (S,D,h,w,8),
+    prob residuals (S,D,h,w)), S = len(sources), each sample with its own batch statistics."""
+    D = int(depth_num)
+    S = len(sources)
+    ds, di = _scalar(depth_start), _scalar(depth_interval)
+    h, w = depth_ref.shape[1:3]
+    chan = shallow.shape[-1]
+    bufs = _refinement_buffers(S, D, h, w, chan, shallow)
+    for b, v in enumerate(sources):
+        view_cam = cams[:, v]
+        hull_cam = view_cam if _hull_view(ref_id) == v else cams[:, _hull_view(ref_id)]
+        _refinement_volumes(b, bufs, depth_ref, depth_views[v], cams[:, ref_id], view_cam, hull_cam,
+                            shallow[ref_id:ref_id + 1], shallow[v:v + 1], D, ds, di, depth_start, depth_interval)
+    pv = prob_vol.unsqueeze(-1).expand(S, -1, -1, -1, -1).contiguous() if S > 1 else prob_vol.unsqueeze(-1)
+    return _refine_net(bufs, pv, chan, True)
+
+
+def feature_extraction_batch(images):
+    """The 2-D feature tower of EVERY view in one pass: (1,N,H,W,3) -> (N,H/4,W/4,32); per-image statistics, equal to
+    N calls of TVSNet_feature_extraction."""
+    return ResNetDS2SPP({'data': images[0]}, is_training=True, reuse=AUTO_REUSE, independent_samples=True).get_output()
+
+
+def shallow_feature_batch(images):
+    """extract_feature_shallow's tower for every view in one pass: (1,N,H,W,3) -> (N,H/4,W/4,16)."""
+    return ResNetDS2SPP_shallow_f16({'data': images[0]}, is_training=True, reuse=AUTO_REUSE,
+                                    independent_samples=True).get_output()
+
+
+def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_interval):
+    """build_cost_volume for several (reference view, source view) pairs as ONE SplitVolume of len(pairs) samples:
+    features (N,h,w,F) of every view; pair (r, s) sweeps r's frustum and warps s's features into it (the depth range is
+    the given one for every pair -- quirk C11: the reverse direction of a siamese pair uses the reference's too)."""
+    D = int(depth_num)
+    N, h, w, F = features.shape
+    B = len(pairs)
+    var = torch.empty((B, D, h, w, F), dtype=torch.float32, device=features.device)
+    for b, (r, s) in enumerate(pairs):
+        Hm = get_homographies(cams[:, r], cams[:, s], depth_num=D, depth_start=depth_start, depth_interval=depth_interval)
+        ops.warp_planes(features[s], Hm[0].contiguous(), out=var[b])
+    const = torch.stack([features[r] for r, _ in pairs], 0) if B > 1 else features[pairs[0][0]:pairs[0][0] + 1]
+    return ops.SplitVolume(var, const.contiguous(), [('c', i) for i in range(F)] + [('v', i) for i in range(F)])
+
+
+def base_stage_batch(features, cams, depth_num, depth_start, depth_interval, fwd, rev, ref_i=0):
+    """TVSNet_base_siamese for several source views in ONE pass of the regulariser (the reference runs it per source,
+    example.py:144-149): `fwd` = sources whose reference->source direction is wanted (filtered cost volume, probability
+    volume, depth), `rev` = sources whose source->reference direction is wanted (depth_view).
+    -> (filtered (F,D,h,w,8), prob (F,D,h,w), depth_b2 (F,h,w,1), depth_view {source: (1,h,w,1)})."""
+    D = int(depth_num)
+    pairs = [(ref_i, v) for v in fwd] + [(v, ref_i) for v in rev]
+    cv = build_cost_volumes(features, cams, pairs, D, depth_start, depth_interval)
+    tower = StackedUNet_prob({'data': cv}, is_training=True, reuse=AUTO_REUSE, independent_samples=True)
+    del cv
+    prob = tower.get_output().squeeze(-1)                        # (B,D,h,w)
+    filt = tower.get_output_by_name('conv_b2_6_1')               # (B,D,h,w,8)
+    depth = ops.softargmin(prob, _scalar(depth_start), _scalar(depth_interval), groups=prob.shape[0])   # (B,h,w)
+    nf = len(fwd)
+    h, w = depth.shape[1:]
+    depth_view = {v: depth[nf + i].reshape(1, h, w, 1) for i, v in enumerate(rev)}
+    return filt[:nf], prob[:nf], depth[:nf].unsqueeze(-1), depth_view
 
 
 def TVSNet_feature_extraction(images, view_i):

@@ -5,12 +5,17 @@ name-based layer lookup and error behaviour as /root/reference/cnn_wrapper/netwo
 (cited per method).  Differences that follow from leaving TensorFlow-1.5 graph mode:
 
 * execution is eager: ``setup()`` runs the layers on the device as it builds them;
-* tensors are channel-last float32 torch tensors (device memory only; every op is a
-  gfx950 kernel behind ``include/atvsnet_hip.h`` reached through ``ops``); ``meta``
+* tensors are batch-first, channel-last float32 torch tensors (device memory only; every op on the
+  hot path is a gfx950 kernel behind ``include/atvsnet_hip.h`` reached through ``ops``); ``meta``
   tensors run the same host code without launching anything (shape / memory planning);
 * variables live in ``variables.default_store()`` under the TF variable names and are
   always shared by name (the reference passes reuse=tf.AUTO_REUSE or builds once);
-* batch size is 1 (FLAGS.batch_size; the kernels take no batch axis).
+* the reference evaluates every network with batch 1 (FLAGS.batch_size) and training-mode batch norm,
+  i.e. statistics per CALL (quirk C1).  A batch B > 1 is accepted only with
+  ``independent_samples=True`` and then means "B calls of this network at once": every launch
+  covers the B samples, the batch-norm statistics stay per sample, and the results equal B
+  separate calls.  (TensorFlow would pool the statistics over such a batch; the reference never
+  builds one.)
 """
 import numpy as np
 import torch
@@ -47,19 +52,11 @@ def layer(op):
     return layer_decorated
 
 
-def _b1(x, what):
-    if isinstance(x, (ops.SplitVolume, ops.PendingBN)):
-        x = x.materialize()
-    if x.shape[0] != 1:
-        raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d' % (what, x.shape[0]))
-    x = x[0]
-    return x if x.is_contiguous() else x.contiguous()      # e.g. a concat-buffer slice consumed on its own
-
-
 class Network(object):
     """Class NetWork (reference network.py:37-139)."""
 
-    def __init__(self, inputs, is_training, dropout_rate=0.9, seed=None, reuse=False, scope_name=None):
+    def __init__(self, inputs, is_training, dropout_rate=0.9, seed=None, reuse=False, scope_name=None,
+                 independent_samples=False):
         self.inputs = inputs
         self.terminals = []
         self.layers = dict(inputs)
@@ -69,6 +66,7 @@ class Network(object):
         self.training = is_training
         self.seed = seed
         self.dropout_rate = dropout_rate
+        self.independent_samples = bool(independent_samples)
         self.store = variables.default_store()
         self.setup()
 
@@ -139,6 +137,15 @@ class Network(object):
         assert padding in ('SAME', 'VALID')
 
     # ------------------------------------------------------------------ helpers
+    def _bt(self, x, what):
+        """The dense batch-first tensor of a layer input; B > 1 only for independent samples."""
+        if isinstance(x, (ops.SplitVolume, ops.PendingBN)):
+            x = x.materialize()
+        if x.shape[0] != 1 and not self.independent_samples:
+            raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d; pass independent_samples=True to '
+                             'evaluate several calls of the network at once' % (what, x.shape[0]))
+        return x if x.is_contiguous() else x.contiguous()      # e.g. a concat-buffer slice consumed on its own
+
     def _kernel(self, name, shape):
         """Host copy of a kernel variable (the pack cache uploads the arranged form)."""
         return self.store.get_host(name, shape)
@@ -158,7 +165,8 @@ class Network(object):
             self._pending_bn.setdefault(id(y), []).append((c_off, C, ops.bn_params(st, C, y, beta, BN_EPS), relu))
             return y
         if self.training:
-            return ops.batch_norm(y, st, beta=beta, relu=relu, inplace=True, eps=BN_EPS, C=C, c_off=c_off)
+            return ops.batch_norm(y, st, beta=beta, relu=relu, inplace=True, eps=BN_EPS, C=C, c_off=c_off,
+                                  groups=y.shape[0])
         if C is not None:
             raise NotImplementedError('moving-average batch norm into a concat slice')
         return self._bn_inference(y, '%s/batch_normalization' % scope, beta, relu)
@@ -170,12 +178,7 @@ class Network(object):
         buf = torch.empty(shape, dtype=torch.float32, device=like.device)
         self._concat_bufs = getattr(self, '_concat_bufs', {})
         self._concat_bufs[name] = buf
-        self._concat_views = getattr(self, '_concat_views', {})
-        self._concat_views[name] = buf[0]        # the 4-D view handed to the kernels (stable identity)
         return buf
-
-    def _buf_id(self, name):
-        return id(self._concat_views[name])
 
     def _bn_inference(self, y, scope, beta, relu):
         """Moving-average BN (never used by the reference's inference code, which passes is_training=True)."""
@@ -195,17 +198,17 @@ class Network(object):
         rank = input.dim()
         if rank not in (4, 5):
             raise ValueError('Improper input rank for layer: ' + name)
-        x = _b1(input, name)
-        cin = x.shape[-1]
+        x = self._bt(input, name)
+        G, cin = x.shape[0], x.shape[-1]
         if rank == 5 and kernel_size == 3 and filters == 1 and cin == 8 and strides == 1 and rate == 1 \
                 and padding == 'SAME' and not biased and not relu:
             # the 8 -> 1 probability heads: HBM-bound, dedicated FMA kernel
             wd = self.store.get('%s/kernel' % name, (3, 3, 3, 8, 1), x.device)
-            return ops.conv3d_8to1(x, wd).unsqueeze(0)
+            return ops.conv3d_8to1(x, wd, groups=G)
         w = self._kernel('%s/kernel' % name, (kernel_size,) * (rank - 2) + (cin, filters))
         bias = self._vec('%s/bias' % name, filters, x) if biased else None
-        y = ops.conv(x, name + '/kernel', w, stride=strides, dilation=rate, padding=padding, bias=bias, relu=relu)
-        return y.unsqueeze(0)
+        return ops.conv(x, name + '/kernel', w, stride=strides, dilation=rate, padding=padding, bias=bias, relu=relu,
+                        groups=G)
 
     @layer
     def conv_bn(self, input, kernel_size, filters, strides, name, relu=True, center=False, padding=DEFAULT_PADDING,
@@ -217,9 +220,11 @@ class Network(object):
             raise ValueError('Improper input rank for layer: ' + name)
         buf, c_off = None, 0
         if out_slice is not None:          # extension: write into a channel slice of a pre-allocated concat buffer
-            buf, c_off = self._concat_views[out_slice[0]], int(out_slice[1])
+            buf, c_off = self._concat_bufs[out_slice[0]], int(out_slice[1])
         if isinstance(input, ops.SplitVolume):
             if kernel_size == 3 and rate == 1 and padding == 'SAME' and not biased and self.training:
+                if input.shape[0] != 1 and not self.independent_samples:
+                    raise ValueError('%s: batch size must be 1 (FLAGS.batch_size)' % name)
                 vname = '%s/conv3d/kernel' % name
                 w = self._kernel(vname, (3, 3, 3, input.shape[-1], filters))
                 y, st = ops.conv_split(input, vname, w, stride=strides, want_stats=True, out=buf, y_coff=c_off)
@@ -228,22 +233,23 @@ class Network(object):
                 return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None),
                                                 c_off=c_off), out_slice, filters)
             input = input.materialize()
-        x = _b1(input, name)
-        cin = x.shape[-1]
+        x = self._bt(input, name)
+        G, cin = x.shape[0], x.shape[-1]
         kind = 'conv2d' if rank == 4 else 'conv3d'
         vname = '%s/%s/kernel' % (name, kind)
         w = self._kernel(vname, (kernel_size,) * (rank - 2) + (cin, filters))
         bias = self._vec('%s/%s/bias' % (name, kind), filters, x) if biased else None
         if self.training and defer_bn and buf is None and not center and filters % 4 == 0:
             # extension: the layer's consumers are adds only -> hand them the raw output + the moments
-            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True)
+            y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
+                             groups=G)
             return ops.PendingBN(y, ops.bn_params(st, filters, y, None, BN_EPS), relu)
         if self.training:
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
-                             out=buf, y_coff=c_off)
+                             out=buf, y_coff=c_off, groups=G)
         else:
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, out=buf,
-                             y_coff=c_off), None
+                             y_coff=c_off, groups=G), None
         return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None), c_off=c_off),
                                out_slice, filters)
 
@@ -262,8 +268,8 @@ class Network(object):
                            and d.get('padding', DEFAULT_PADDING) == 'SAME' and d.get('rate', 1) == 1
                            and d.get('out_slice') is None)
         shape = tuple(src.shape)
-        fusable = (self.training and len(shape) == 5 and shape[0] == 1 and plain(a) and plain(b)
-                   and a['strides'] == 1 and b['strides'] == 2 and not b.get('defer_bn', False)
+        fusable = (self.training and len(shape) == 5 and (shape[0] == 1 or self.independent_samples) and plain(a)
+                   and plain(b) and a['strides'] == 1 and b['strides'] == 2 and not b.get('defer_bn', False)
                    and not isinstance(src, ops.PendingBN))
         if fusable:
             if isinstance(src, ops.SplitVolume):
@@ -282,12 +288,12 @@ class Network(object):
         if isinstance(src, ops.SplitVolume):
             (ya, sa), (yb, sb) = ops.conv_split_siblings(src, va, wa, vb, wb)
         else:
-            (ya, sa), (yb, sb) = ops.conv_siblings(_b1(src, a['name']), va, wa, vb, wb)
+            (ya, sa), (yb, sb) = ops.conv_siblings(self._bt(src, a['name']), va, wa, vb, wb, groups=shape[0])
         if a.get('defer_bn', False):
             out_a = ops.PendingBN(ya, ops.bn_params(sa, a['filters'], ya, None, BN_EPS), a.get('relu', True))
         else:
-            out_a = self._bn(ya, sa, a['name'], False, a.get('relu', True)).unsqueeze(0)
-        out_b = self._bn(yb, sb, b['name'], False, b.get('relu', True)).unsqueeze(0)
+            out_a = self._bn(ya, sa, a['name'], False, a.get('relu', True))
+        out_b = self._bn(yb, sb, b['name'], False, b.get('relu', True))
         self.layers[a['name']] = out_a
         self.layers[b['name']] = out_b
         self.feed(out_b)
@@ -296,7 +302,7 @@ class Network(object):
     def _slice_out(self, y, out_slice, filters):
         """Layer result: the dense tensor, or (for out_slice) a view of the concat buffer tagged for concat()."""
         if out_slice is None:
-            return y.unsqueeze(0)
+            return y
         full = self._concat_bufs[out_slice[0]]
         view = full[..., int(out_slice[1]):int(out_slice[1]) + filters]
         view._atvs_slice = (out_slice[0], int(out_slice[1]))
@@ -313,17 +319,18 @@ class Network(object):
         if rank != 5 or kernel_size != 3 or strides != 2 or padding != 'SAME' or biased:
             raise NotImplementedError('deconv_bn: only the 3-D k=3, stride-2, SAME, unbiased form used by '
                                       'cnn_wrapper/atvsnet.py is built')
-        x = _b1(input, name)
+        x = self._bt(input, name)
+        G = x.shape[0]
         vname = '%s/conv3d_transpose/kernel' % name
         w = self._kernel(vname, (3, 3, 3, filters, x.shape[-1]))
         if self.training and defer_bn and not center and filters % 4 == 0:
-            y, st = ops.conv3d_transpose_s2(x, vname, w, want_stats=True)
+            y, st = ops.conv3d_transpose_s2(x, vname, w, want_stats=True, groups=G)
             return ops.PendingBN(y, ops.bn_params(st, filters, y, None, BN_EPS), relu)
         if self.training:
-            y, st = ops.conv3d_transpose_s2(x, vname, w, want_stats=True)
+            y, st = ops.conv3d_transpose_s2(x, vname, w, want_stats=True, groups=G)
         else:
-            y, st = ops.conv3d_transpose_s2(x, vname, w), None
-        return self._bn(y, st, name, center, relu).unsqueeze(0)
+            y, st = ops.conv3d_transpose_s2(x, vname, w, groups=G), None
+        return self._bn(y, st, name, center, relu)
 
     def bottleneck(self, inputs, kernel_size, depth, stride=1, rate=1, name=None):
         """Bottleneck residual unit variant with BN before convolutions (reference network.py:552-602).
@@ -333,13 +340,14 @@ class Network(object):
         1x1 (bias) + shortcut (added in the last convolution's epilogue).
         """
         scope = name
-        x = _b1(inputs, scope)
+        x = self._bt(inputs, scope)
+        G = x.shape[0]
         depth_in = x.shape[-1]
         beta = self._vec('%s/preact/beta' % scope, depth_in, x)
         if self.training:
             # statistics of `inputs` come from the epilogue of the convolution that produced it, when
             # that was the previous bottleneck's conv3 (+shortcut); otherwise from a channel_stats pass
-            preact = ops.batch_norm(x, getattr(inputs, '_atvs_stats', None), beta=beta, relu=True, eps=BN_EPS)
+            preact = ops.batch_norm(x, getattr(inputs, '_atvs_stats', None), beta=beta, relu=True, eps=BN_EPS, groups=G)
         else:
             preact = self._bn_inference(x.clone(), '%s/preact' % scope, beta, True)
         if depth == depth_in:
@@ -351,22 +359,22 @@ class Network(object):
         else:
             shortcut = ops.conv(preact, scope + '/shortcut/weights',
                                 self._kernel('%s/shortcut/weights' % scope, (1, 1, depth_in, depth)), stride=stride,
-                                bias=self._vec('%s/shortcut/biases' % scope, depth, x))
+                                bias=self._vec('%s/shortcut/biases' % scope, depth, x), groups=G)
         r = ops.conv(preact, scope + '/conv1/weights', self._kernel('%s/conv1/weights' % scope, (1, 1, depth_in, depth)),
-                     bias=self._vec('%s/conv1/biases' % scope, depth, x), relu=True)
+                     bias=self._vec('%s/conv1/biases' % scope, depth, x), relu=True, groups=G)
         w2 = self._kernel('%s/conv2/weights' % scope, (kernel_size, kernel_size, depth, depth))
         b2 = self._vec('%s/conv2/biases' % scope, depth, x)
         if stride == 1:
-            r = ops.conv(r, scope + '/conv2/weights', w2, dilation=rate, bias=b2, relu=True)
+            r = ops.conv(r, scope + '/conv2/weights', w2, dilation=rate, bias=b2, relu=True, groups=G)
         else:
             k_eff = kernel_size + (kernel_size - 1) * (rate - 1)
             pb = (k_eff - 1) // 2
             pe = (k_eff - 1) - pb
             r = ops.conv(r, scope + '/conv2/weights', w2, stride=stride, dilation=rate,
-                         explicit_pad=[(pb, pe), (pb, pe)], bias=b2, relu=True)
+                         explicit_pad=[(pb, pe), (pb, pe)], bias=b2, relu=True, groups=G)
         out, st = ops.conv(r, scope + '/conv3/weights', self._kernel('%s/conv3/weights' % scope, (1, 1, depth, depth)),
-                           bias=self._vec('%s/conv3/biases' % scope, depth, x), residual=shortcut, want_stats=True)
-        out = out.unsqueeze(0)
+                           bias=self._vec('%s/conv3/biases' % scope, depth, x), residual=shortcut, want_stats=True,
+                           groups=G)
         out._atvs_stats = st          # consumed by the next bottleneck's pre-activation batch norm
         return out
 
@@ -389,14 +397,16 @@ class Network(object):
         '''tf.layers.average_pooling2d (reference network.py:665-671); SAME only.'''
         if padding != 'SAME':
             raise NotImplementedError('avg_pool: only SAME padding is built')
-        return ops.avg_pool_same(_b1(input, name), pool_size, strides).unsqueeze(0)
+        x = self._bt(input, name)
+        return ops.avg_pool_same(x, pool_size, strides, groups=x.shape[0])
 
     @layer
     def image_resize(self, input, size, name, align_corners=True, method='bilinear'):
         '''tf.image.resize_images: always bilinear (reference network.py:649-655, quirk C14).'''
         if not align_corners:
             raise NotImplementedError('image_resize: only align_corners=True is built')
-        return ops.resize_bilinear(_b1(input, name), (int(size[0]), int(size[1]))).unsqueeze(0)
+        x = self._bt(input, name)
+        return ops.resize_bilinear(x, (int(size[0]), int(size[1])), groups=x.shape[0])
 
     @layer
     def concat(self, inputs, axis, name):
@@ -413,17 +423,19 @@ class Network(object):
                 off += t.shape[-1]
             buf = self._concat_bufs[name]
             if ok and off == buf.shape[-1]:
-                pend = getattr(self, '_pending_bn', {}).pop(self._buf_id(name), [])
+                pend = getattr(self, '_pending_bn', {}).pop(id(buf), [])
                 if pend:
-                    params = torch.empty((3, off), dtype=torch.float32, device=buf.device)
+                    G = buf.shape[0]
+                    pshape = (3, off) if G == 1 else (G, 3, off)
+                    params = torch.empty(pshape, dtype=torch.float32, device=buf.device)
                     relus = set()
                     for c_off, C, p, relu in pend:
                         ops.copy_channels(p, params, C, 0, c_off)
                         relus.add(bool(relu))
                     assert len(relus) == 1 and sum(pc[1] for pc in pend) == off
-                    ops.bn_apply(buf[0], params, relus.pop())
+                    ops.bn_apply(buf, params, relus.pop())
                 return buf
-        return ops.concat_channels([_b1(t, name) for t in inputs]).unsqueeze(0)
+        return ops.concat_channels([self._bt(t, name) for t in inputs])
 
     @layer
     def add(self, inputs, name):
@@ -431,9 +443,9 @@ class Network(object):
         deconv_bn with defer_bn=True) are normalised inside the add kernel.'''
         if len(inputs) in (2, 3) and any(isinstance(t, ops.PendingBN) for t in inputs) \
                 and inputs[0].shape[-1] % 4 == 0:
-            items = [t if isinstance(t, ops.PendingBN) else _b1(t, name) for t in inputs]
-            return ops.bn_add(items).unsqueeze(0)
-        return ops.add_n([_b1(t, name) for t in inputs]).unsqueeze(0)
+            items = [t if isinstance(t, ops.PendingBN) else self._bt(t, name) for t in inputs]
+            return ops.bn_add(items)
+        return ops.add_n([self._bt(t, name) for t in inputs])
 
     def attention_activation(self, input, kernel_size, name, filters=None, second_weight=False, relu=True,
                              padding=DEFAULT_PADDING, biased=False, n_view=None):
@@ -444,20 +456,25 @@ class Network(object):
                               padding=DEFAULT_PADDING, biased=False, n_view=None):
         '''AANet aggregation over views (reference network.py:378-408 -> :282-351).
 
-        input: (B,D,H,W,C,N) like the reference, or a list of N tensors (B,D,H,W,C) (no stacking
-        copy).  Variables name/attention_activation/{weight_unique,weight_shared}.  The shared and
-        unique 3x3x3 convolutions run as one C->2C convolution; the cross-view softmax and the
-        weighted sum are one kernel.  Only the form the path uses is built.
+        input: (B,D,H,W,C,N) like the reference; or a list of N tensors (B,D,H,W,C) (no stacking copy); or ONE
+        5-D tensor (N,D,H,W,C) = the N views stacked on the leading axis (B = 1; what the batched per-view
+        networks produce).  Variables name/attention_activation/{weight_unique,weight_shared}.  The shared and
+        unique 3x3x3 convolutions run as one C->2C convolution (one launch over all views when they are stacked);
+        the cross-view softmax and the weighted sum are one kernel.  Only the form the path uses is built.
         '''
         if not (second_weight and relu and not biased and padding == 'SAME' and kernel_size == 3):
             raise NotImplementedError('attention_aggregation: only second_weight=True, relu=True, biased=False, '
                                       'kernel 3, SAME (cnn_wrapper/atvsnet.py:202,234) is built')
+        stacked = None
         if isinstance(input, (list, tuple)):
-            xs = [_b1(t, name) for t in input]
+            xs = [ops_b1(t, name) for t in input]
+        elif input.dim() == 5:
+            stacked = input if input.is_contiguous() else input.contiguous()
+            xs = [stacked[n] for n in range(stacked.shape[0])]
         else:
             if input.dim() != 6:
                 raise ValueError('Improper input rank for layer: ' + name)
-            st = _b1(input, name)
+            st = ops_b1(input, name)
             nv = st.shape[-1]
             xs = []
             for n in range(nv):
@@ -472,14 +489,242 @@ class Network(object):
         ws = self.store.get_host('%s/weight_shared' % scope, (3, 3, 3, c_in, c_in))
         key = scope + '/shared|unique'
         w16 = np.concatenate([ws, wu], axis=-1)
-        srs = [ops.conv(x, key, w16, relu=True) for x in xs]
+        if stacked is not None:
+            sr = ops.conv(stacked, key, w16, relu=True, groups=stacked.shape[0])
+            srs = [sr[n] for n in range(sr.shape[0])]
+        else:
+            srs = [ops.conv(x, key, w16, relu=True) for x in xs]
         return ops.aanet_combine(srs, xs).unsqueeze(0)
 
     # ------------------------------------------------------------------ API surface off the hot path
-    # The remaining reference layers (deconv, split_separable_conv2d, attention_activation_layer,
-    # attention_activation_2d, max_pool, l2_pool, lrn, fc, softmax, dropout, ...; reference
-    # network.py:218-268, 354-376, 411-508, 619-647, 657-689, 699-775) are not used by
-    # cnn_wrapper/atvsnet.py.  The cheap tensor-shape ones are provided; the rest raise.
+    # The remaining reference layers (network.py:218-268, 354-376, 411-508, 619-647, 657-689, 699-775) are never
+    # used by cnn_wrapper/atvsnet.py.  They are provided as thin fallbacks on torch's device operators (MIOpen /
+    # ATen), i.e. NOT on the hand-written kernels and outside every parity / performance claim of this repository.
+    @layer
+    def relu(self, input, name):
+        return torch.relu(input)
+
+    @layer
+    def transpose(self, input, perm, name, conjugate=False):
+        return input.permute(*perm).contiguous()
+
+    @layer
+    def divide(self, input, denominator, name):
+        return input / denominator
+
+    @layer
+    def reduce_mean(self, input, axis, name, keepdims=True):
+        return input.mean(dim=axis, keepdim=keepdims)
+
+    @layer
+    def reduce_sum(self, input, axis, name, keepdims=True):
+        return input.sum(dim=axis, keepdim=keepdims)
+
+    @layer
+    def tile(self, input, multiples, name):
+        return input.repeat(*multiples)
+
+    @layer
+    def squeeze_and_transpose(self, input, squeeze_dims, perm, name, conjugate=False):
+        x = input
+        for d in sorted(squeeze_dims, reverse=True):
+            x = x.squeeze(d)
+        return x.permute(*perm).contiguous()
+
+    def _pool_nchw(self, x, pool_size, strides, padding, fn):
+        """SAME / VALID window pooling of a (B,H,W,C) tensor through torch (fn = max | avg with valid counts)."""
+        import torch.nn.functional as F
+        x = x.permute(0, 3, 1, 2)
+        if padding == 'SAME':
+            H, W = x.shape[2:]
+            ph = max((-(-H // strides) - 1) * strides + pool_size - H, 0)
+            pw = max((-(-W // strides) - 1) * strides + pool_size - W, 0)
+            pad = (pw // 2, pw - pw // 2, ph // 2, ph - ph // 2)
+            if fn == 'max':
+                x = F.pad(x, pad, value=float('-inf'))
+                y = F.max_pool2d(x, pool_size, strides)
+            else:
+                ones = F.pad(torch.ones_like(x[:, :1]), pad)
+                y = F.avg_pool2d(F.pad(x, pad), pool_size, strides) / F.avg_pool2d(ones, pool_size, strides)
+        else:
+            y = F.max_pool2d(x, pool_size, strides) if fn == 'max' else F.avg_pool2d(x, pool_size, strides)
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    @layer
+    def max_pool(self, input, pool_size, strides, name, padding=DEFAULT_PADDING):
+        return self._pool_nchw(input, pool_size, strides, padding, 'max')
+
+    @layer
+    def l2_pool(self, input, pool_size, strides, name, padding=DEFAULT_PADDING):
+        return torch.sqrt(self._pool_nchw(input * input, pool_size, strides, padding, 'avg'))
+
+    @layer
+    def lrn(self, input, radius, alpha, beta, name, bias=1.0):
+        # tf.nn.local_response_normalization: x / (bias + alpha * sum_{|j-i| <= radius} x_j^2) ** beta
+        import torch.nn.functional as F
+        sq = (input * input).unsqueeze(1)
+        k = 2 * radius + 1
+        s = F.avg_pool3d(F.pad(sq, (radius, radius)), (1, 1, k), stride=1) * k if input.dim() == 4 else None
+        if s is None:
+            raise ValueError('Improper input rank for layer: ' + name)
+        return input / torch.pow(bias + alpha * s.squeeze(1), beta)
+
+    @layer
+    def multiply(self, inputs, name):
+        return inputs[0] * inputs[1]
+
+    @layer
+    def multiply_channel_wise(self, inputs, name):
+        return inputs[0] * inputs[1]        # broadcasting = tile(inputs[0]) to the channels of inputs[1]
+
+    @layer
+    def fc(self, input, num_out, name, relu=True):
+        n_in = input.shape[-1]
+        w = self.store.get('%s/kernel' % name, (n_in, num_out), input.device)
+        b = self.store.get('%s/bias' % name, (num_out,), input.device)
+        y = input @ w + b
+        return torch.relu(y) if relu else y
+
+    @layer
+    def sigmoid(self, input, name):
+        return torch.sigmoid(input)
+
+    @layer
+    def softmax(self, input, name, dim=-1):
+        if input.dim() > 2:
+            if input.shape[1] == 1 and input.shape[2] == 1:
+                input = input.squeeze(2).squeeze(1)
+            else:
+                raise ValueError('Rank 2 tensor input expected for softmax!')
+        return torch.softmax(input, dim=dim)
+
+    @layer
+    def nn_softmax(self, input, name, axis=-1):
+        return torch.softmax(input, dim=axis)
+
+    @layer
+    def batch_normalization(self, input, name, center=True, scale=True, relu=False):
+        '''tf.layers.batch_normalization with its default training=False: moving averages, gamma (the reference
+        forces scale=True), optional beta.'''
+        C = input.shape[-1]
+        dev = input.device
+        mean = self.store.get('%s/moving_mean' % name, (C,), dev)
+        var = self.store.get('%s/moving_variance' % name, (C,), dev)
+        y = (input - mean) * torch.rsqrt(var + BN_EPS) * self.store.get('%s/gamma' % name, (C,), dev)
+        if center:
+            y = y + self.store.get('%s/beta' % name, (C,), dev)
+        return torch.relu(y) if relu else y
+
+    @layer
+    def dropout(self, input, name):
+        '''slim.dropout(keep_prob=self.dropout_rate, is_training=self.training).'''
+        if not self.training:
+            return input
+        g = torch.Generator(device=input.device)
+        g.manual_seed(0 if self.seed is None else int(self.seed))
+        keep = float(self.dropout_rate)
+        mask = (torch.rand(input.shape, generator=g, device=input.device) < keep).to(input.dtype)
+        return input * mask / keep
+
+    @layer
+    def l2norm(self, input, name, dim=-1):
+        return input * torch.rsqrt(torch.clamp((input * input).sum(dim=dim, keepdim=True), min=1e-12))
+
+    @layer
+    def deconv(self, input, kernel_size, filters, strides, name, relu=True, padding=DEFAULT_PADDING, biased=False):
+        '''tf.layers.conv2d_transpose / conv3d_transpose (reference network.py:479-508), SAME, kernel [k.., Cout, Cin].'''
+        import torch.nn.functional as F
+        rank = input.dim()
+        if rank not in (4, 5):
+            raise ValueError('Improper input rank for layer: ' + name)
+        if padding != 'SAME':
+            raise NotImplementedError('deconv: SAME padding')
+        nsp = rank - 2
+        cin = input.shape[-1]
+        kname = '%s/kernel' % name
+        w = self.store.get(kname, (kernel_size,) * nsp + (filters, cin), input.device)
+        x = input.permute(0, rank - 1, *range(1, rank - 1))
+        wt = w.permute(nsp + 1, nsp, *range(nsp))                     # (Cin, Cout, k..)
+        f = F.conv_transpose2d if nsp == 2 else F.conv_transpose3d
+        y = f(x, wt, stride=strides)
+        # SAME: output = input * stride; crop the (k - stride) surplus, begin-light like the gradient of a SAME conv
+        sl = [slice(None), slice(None)]
+        for a in range(nsp):
+            tot = kernel_size - strides
+            b0 = max(tot, 0) // 2
+            sl.append(slice(b0, b0 + input.shape[1 + a] * strides))
+        y = y[tuple(sl)].permute(0, *range(2, rank), 1).contiguous()
+        if biased:
+            y = y + self.store.get('%s/bias' % name, (filters,), input.device)
+        return torch.relu(y) if relu else y
+
+    @layer
+    def split_separable_conv2d(self, inputs, kernel_size, filters, rate, name, weight_decay=0.00004,
+                               depthwise_weights_initializer_stddev=0.33, pointwise_weights_initializer_stddev=0.06):
+        '''slim.separable_conv2d (depthwise, ReLU) then slim.conv2d 1x1 (ReLU), reference network.py:218-268.'''
+        import torch.nn.functional as F
+        C = inputs.shape[-1]
+        dev = inputs.device
+        wd = self.store.get('%s_depthwise/depthwise_weights' % name, (kernel_size, kernel_size, C, 1), dev)
+        bd = self.store.get('%s_depthwise/biases' % name, (C,), dev)
+        wp = self.store.get('%s_pointwise/weights' % name, (1, 1, C, filters), dev)
+        bp = self.store.get('%s_pointwise/biases' % name, (filters,), dev)
+        x = inputs.permute(0, 3, 1, 2)
+        pad = rate * (kernel_size - 1) // 2
+        y = F.conv2d(x, wd.permute(2, 3, 0, 1), bd, padding=pad, dilation=rate, groups=C)
+        y = torch.relu(y)
+        y = torch.relu(F.conv2d(y, wp.permute(3, 2, 0, 1), bp))
+        return y.permute(0, 2, 3, 1).contiguous()
+
+    @layer
+    def attention_activation_layer(self, input, kernel_size, name, filters=None, second_weight=False, relu=True,
+                                   padding=DEFAULT_PADDING, biased=False, n_view=None):
+        '''softmax over views of the attention activation (reference network.py:354-376): (B,D,H,W,C,N) scores.'''
+        import torch.nn.functional as F
+        if input.dim() != 6 or biased or padding != 'SAME':
+            raise NotImplementedError('attention_activation_layer: (B,D,H,W,C,N), unbiased, SAME')
+        c_in, nv = input.shape[-2], input.shape[-1]
+        filters = c_in if filters is None else filters
+        dev = input.device
+        scope = '%s/%s' % (name, name)         # the reference nests variable_scope(name) twice (:366, :314)
+        wu = self.store.get('%s/weight_unique' % scope, (kernel_size,) * 3 + (c_in, filters), dev)
+        act = (lambda t: torch.relu(t)) if relu else (lambda t: t)
+        conv = lambda x, w: act(F.conv3d(x.permute(0, 4, 1, 2, 3), w.permute(4, 3, 0, 1, 2), padding=kernel_size // 2)  # noqa: E731
+                                ).permute(0, 2, 3, 4, 1)
+        xs = [input[..., n] for n in range(nv)]
+        if second_weight:
+            ws = self.store.get('%s/weight_shared' % scope, (kernel_size,) * 3 + (c_in, filters), dev)
+            shared = [conv(x, ws) for x in xs]
+            ssum = sum(shared[1:], shared[0])
+            outs = [(conv(x, wu) - s) + ssum for x, s in zip(xs, shared)]
+        else:
+            outs = [conv(x, wu) for x in xs]
+        return torch.softmax(torch.stack(outs, -1), dim=-1)
+
+    @layer
+    def attention_activation_2d(self, input, kernel_size, name, filters=None, second_weight=False, relu=True,
+                                padding=DEFAULT_PADDING, biased=False):
+        '''(B,H,W,C,N) -> shared-weight 2-D convolution per view -> (B,H,W,C,N) (reference network.py:411-476).'''
+        import torch.nn.functional as F
+        if input.dim() != 5 or biased or padding != 'SAME':
+            raise NotImplementedError('attention_activation_2d: (B,H,W,C,N), unbiased, SAME')
+        c_in, nv = input.shape[-2], input.shape[-1]
+        filters = c_in if filters is None else filters
+        dev = input.device
+        wu = self.store.get('%s/weight_unique' % name, (kernel_size, kernel_size, c_in, filters), dev)
+        act = (lambda t: torch.relu(t)) if relu else (lambda t: t)
+        conv = lambda x, w: act(F.conv2d(x.permute(0, 3, 1, 2), w.permute(3, 2, 0, 1), padding=kernel_size // 2)  # noqa: E731
+                                ).permute(0, 2, 3, 1)
+        xs = [input[..., n] for n in range(nv)]
+        if second_weight:
+            ws = self.store.get('%s/weight_shared' % name, (kernel_size, kernel_size, c_in, filters), dev)
+            shared = [conv(x, ws) for x in xs]
+            ssum = sum(shared[1:], shared[0])
+            outs = [(conv(x, wu) - s) + ssum for x, s in zip(xs, shared)]
+        else:
+            outs = [conv(x, wu) for x in xs]
+        return torch.stack(outs, -1)
+
     @layer
     def squeeze(self, input, axis=None, name=None):
         return input.squeeze(axis) if axis is not None else input.squeeze()
@@ -488,14 +733,12 @@ class Network(object):
     def expand_dims(self, input, axis, name=None):
         return input.unsqueeze(axis)
 
-    def __getattr__(self, item):
-        if item in _OFF_PATH_LAYERS:
-            raise NotImplementedError('Network.%s: reference layer that cnn_wrapper/atvsnet.py never uses; '
-                                      'not built on the MI355X backend' % item)
-        raise AttributeError(item)
 
-
-_OFF_PATH_LAYERS = frozenset([
-    'relu', 'split_separable_conv2d', 'attention_activation_layer', 'attention_activation_2d', 'deconv', 'transpose', 'divide',
-    'reduce_mean', 'reduce_sum', 'tile', 'squeeze_and_transpose', 'max_pool', 'l2_pool', 'lrn', 'multiply',
-    'multiply_channel_wise', 'fc', 'sigmoid', 'softmax', 'nn_softmax', 'batch_normalization', 'dropout', 'l2norm'])
+def ops_b1(x, what):
+    """One-sample tensor (1, ...) -> (...), contiguous."""
+    if isinstance(x, (ops.SplitVolume, ops.PendingBN)):
+        x = x.materialize()
+    if x.shape[0] != 1:
+        raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d' % (what, x.shape[0]))
+    x = x[0]
+    return x if x.is_contiguous() else x.contiguous()

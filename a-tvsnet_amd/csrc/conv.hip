@@ -39,6 +39,10 @@ struct ConvArgs {
   int vec_out;
   const float* pbias;      // (Ho, Wo, 3*Cout) depth-plane bias variants or nullptr (see plane_variant)
   int pb_pz;               // z padding before, to pick the variant
+  // groups: G independent samples stacked on the leading axis of x / y / residual / plane bias; a workgroup
+  // belongs to one sample (bpg workgroups per sample), the statistics rows are (sample, workgroup)
+  int bpg;
+  long gx, gy, gpb;        // elements per sample of x, of y / residual, of the plane bias
 };
 
 template <int V>
@@ -77,7 +81,8 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs p) {
   // voxel of each of this wave's TM tiles (lane r <-> voxel r of the tile)
   int iz[TM], iy[TM], ix[TM];
   long mvox[TM];
-  const long m0 = ((long)blockIdx.x * 4 + wave) * (TM * 16);
+  const int grp = blockIdx.x / p.bpg;
+  const long m0 = ((long)(blockIdx.x - grp * p.bpg) * 4 + wave) * (TM * 16);
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     long m = m0 + t * 16 + r;
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs p) {
 #pragma unroll
     for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  const float* __restrict__ x = p.x;
+  const float* __restrict__ x = p.x + (size_t)grp * p.gx;
   const AT* __restrict__ wp = reinterpret_cast<const AT*>(p.wp);
 
   AT a_cur[TM], w_cur[NT];
@@ -155,10 +160,11 @@ __global__ __launch_bounds__(256) void conv_mfma_f32_kernel(ConvArgs p) {
     int yo = (int)(rest % p.Ho);
     int zo = (int)(rest / p.Ho);
     size_t vox = ((size_t)(zo * p.oS + p.offz) * p.Hy + (yo * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx);
-    size_t base = vox * (size_t)p.ldy + p.ycoff;
+    size_t base = (size_t)grp * p.gy + vox * (size_t)p.ldy + p.ycoff;
     const float* pb = nullptr;
     if (p.pbias)
-      pb = p.pbias + ((size_t)yo * p.Wo + xo) * (size_t)(3 * p.Cout) + plane_variant(zo * p.sI - p.pb_pz, p.Di) * p.Cout;
+      pb = p.pbias + (size_t)grp * p.gpb + ((size_t)yo * p.Wo + xo) * (size_t)(3 * p.Cout) +
+           plane_variant(zo * p.sI - p.pb_pz, p.Di) * p.Cout;
 #pragma unroll
     for (int n = 0; n < NT; ++n) {
       int co = n * 16 + 4 * q;
@@ -290,9 +296,11 @@ extern "C" int atvs_conv_pack(const float* w, int w_transposed, const int32_t* t
 extern "C" long atvs_conv_num_blocks(long M, int tile_m) { return (M + 64L * tile_m - 1) / (64L * tile_m); }
 
 template <int NT, int V>
-static int launch_tm(const ConvArgs& a, int TM, hipStream_t s) {
-  long blocks = atvs_conv_num_blocks(a.M, TM);
-  if (blocks <= 0 || blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
+static int launch_tm(ConvArgs& a, int TM, int groups, hipStream_t s) {
+  long bpg = atvs_conv_num_blocks(a.M, TM);
+  long blocks = bpg * groups;
+  if (bpg <= 0 || blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  a.bpg = (int)bpg;
   size_t lds = (size_t)a.J * 4 * sizeof(int4);
   dim3 grid((unsigned)blocks), block(256);
   switch (TM) {
@@ -312,26 +320,27 @@ static int launch_tm(const ConvArgs& a, int TM, hipStream_t s) {
 }
 
 template <int V>
-static int launch_nt(const ConvArgs& a, int NT, int TM, hipStream_t s) {
+static int launch_nt(ConvArgs& a, int NT, int TM, int groups, hipStream_t s) {
   switch (NT) {
-    case 1: return launch_tm<1, V>(a, TM, s);
-    case 2: return launch_tm<2, V>(a, TM, s);
-    case 4: return launch_tm<4, V>(a, TM, s);
-    case 8: return launch_tm<8, V>(a, TM, s);
+    case 1: return launch_tm<1, V>(a, TM, groups, s);
+    case 2: return launch_tm<2, V>(a, TM, groups, s);
+    case 4: return launch_tm<4, V>(a, TM, groups, s);
+    case 8: return launch_tm<8, V>(a, TM, groups, s);
   }
   return ATVS_ERR_ARG;
 }
 
 extern "C" int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* group_table, const float* bias,
                                   const float* residual, const float* plane_bias, int pad_z, float* y,
-                                  double* stats_partial, int Di, int Hi, int Wi,
+                                  double* stats_partial, int groups, int Di, int Hi, int Wi,
                                   int Cin, int Do, int Ho, int Wo, int in_stride, int Dy, int Hy, int Wy,
                                   int out_stride, int off_z, int off_y, int off_x, int ldy, int y_coff, int Cout,
                                   int ntaps, int tile_m, int relu, atvs_stream_t stream) {
   if (!x || !packed_w || !group_table || !y) return ATVS_ERR_NULL;
-  if (Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || in_stride <= 0 || out_stride <= 0)
+  if (groups <= 0 || Di <= 0 || Hi <= 0 || Wi <= 0 || Do <= 0 || Ho <= 0 || Wo <= 0 || in_stride <= 0 || out_stride <= 0)
     return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + Cout > ldy) return ATVS_ERR_SHAPE;
+  if ((double)Di * Hi * Wi * Cin >= 9.0e18) return ATVS_ERR_SHAPE;
   if ((Do - 1) * out_stride + off_z >= Dy || (Ho - 1) * out_stride + off_y >= Hy || (Wo - 1) * out_stride + off_x >= Wy)
     return ATVS_ERR_SHAPE;
   int V, J, NT;
@@ -346,10 +355,11 @@ extern "C" int atvs_conv_mfma_f32(const float* x, const float* packed_w, const i
   a.ldy = ldy; a.ycoff = y_coff; a.Cout = Cout; a.J = J; a.relu = relu;
   a.vec_out = (Cout % 4 == 0) && (ldy % 4 == 0) && (y_coff % 4 == 0);
   a.pbias = plane_bias; a.pb_pz = pad_z;
+  a.gx = (long)Di * Hi * Wi * Cin; a.gy = (long)Dy * Hy * Wy * ldy; a.gpb = (long)Ho * Wo * 3 * Cout; a.bpg = 0;
   if (plane_bias && (out_stride != 1 || Di < 2)) return ATVS_ERR_ARG;
   if (residual && y_coff != 0) return ATVS_ERR_ARG;   // residual shares y's addressing
   hipStream_t s = as_stream(stream);
-  rc = (V == 4) ? launch_nt<4>(a, NT, tile_m, s) : launch_nt<1>(a, NT, tile_m, s);
+  rc = (V == 4) ? launch_nt<4>(a, NT, tile_m, groups, s) : launch_nt<1>(a, NT, tile_m, groups, s);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

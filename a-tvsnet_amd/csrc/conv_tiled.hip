@@ -64,7 +64,13 @@ struct TiledArgs {
   double fin_count;
   float fin_eps;
   double* fin_stats;     // first row of the layer's statistics buffer
+  // groups: independent samples stacked on the leading axis of x / y / residual / plane bias; `wg` workgroups
+  // per sample sweep that sample's tiles (gridDim.x = groups * wg), statistics rows are (sample, workgroup)
+  int wg, ngroups;
+  long gx, gy, gpb;
 };
+
+static inline long a_groups(const TiledArgs& a) { return a.ngroups; }
 
 __device__ __forceinline__ int lds_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
 
@@ -97,8 +103,9 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
   // (blockIdx % 8) sweep one contiguous eighth of the tile range (halo re-use in that XCD's L2).
   // With N-split, workgroup (xcd, local) owns output-channel tiles nsi = local % nsplit of every
   // spatial tile it visits (gridDim.x is a multiple of 8 * nsplit).
-  const int G = gridDim.x;
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int G = p.wg;
+  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
+  const int xcd = lbk & 7, local = lbk >> 3;
   const int per_xcd = (p.ntiles + 7) >> 3;                 // spatial tiles per XCD range
   const int nsi = local % p.nsplit, tslot = local / p.nsplit;
   const int slots_per_xcd = (G >> 3) / p.nsplit;           // workgroups per (XCD, nsi)
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
     // one uniform base pointer + 32-bit per-lane element offsets (the launcher refuses inputs of 2^31
     // elements or more).  Tiles whose halo lies inside the volume skip every bounds test.
     const bool interior = FULL && z0 >= 1 && y0 >= 1 && x0 >= 1 && z0 + TILE_TZ < p.Di && y0 + TY < p.Hi && x0 + TXV < p.Wi;
-    const float* xb = p.x + cbase;
+    const float* xb = p.x + (size_t)grp * p.gx + cbase;
     const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
     if (interior) {
       const unsigned org = (unsigned)(((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin);
@@ -295,10 +302,10 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
       for (int t = 0; t < TY; ++t) {
         const int yo = y0 + t;
         if (zo >= p.Di || yo >= p.Hi || xo >= p.Wi) continue;
-        size_t base = (((size_t)zo * p.Hy + yo) * p.Wy + xo) * (size_t)p.ldy + p.ycoff + co;
+        size_t base = (size_t)grp * p.gy + (((size_t)zo * p.Hy + yo) * p.Wy + xo) * (size_t)p.ldy + p.ycoff + co;
         float4 v = make_float4(acc[t][0][0], acc[t][0][1], acc[t][0][2], acc[t][0][3]);
         if (p.pbias) {
-          float4 b = ld4(p.pbias + ((size_t)yo * p.Wi + xo) * 24 + plane_variant(zo - 1, p.Di) * 8 + co);
+          float4 b = ld4(p.pbias + (size_t)grp * p.gpb + ((size_t)yo * p.Wi + xo) * 24 + plane_variant(zo - 1, p.Di) * 8 + co);
           v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
         }
         if (p.bias) {
@@ -324,10 +331,10 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
       const int yo = y0 + t;
       if (zo >= p.Di || yo >= p.Hi || xo >= p.Wi) continue;
       size_t vox = ((size_t)(zo * p.oS + p.offz) * p.Hy + (yo * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx);
-      size_t base = vox * (size_t)p.ldy + p.ycoff;
+      size_t base = (size_t)grp * p.gy + vox * (size_t)p.ldy + p.ycoff;
       const float* pb = nullptr;
       if (p.pbias)
-        pb = p.pbias + ((size_t)yo * p.Wi + xo) * (size_t)(3 * p.Cout) + plane_variant(zo - 1, p.Di) * p.Cout;
+        pb = p.pbias + (size_t)grp * p.gpb + ((size_t)yo * p.Wi + xo) * (size_t)(3 * p.Cout) + plane_variant(zo - 1, p.Di) * p.Cout;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         int co = (nsi * NT + n) * 16 + 4 * q;
@@ -341,7 +348,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) v[kk] = fmaxf(v[kk], 0.f);
           }
-          st4(p.y + ov * (size_t)p.ldy + p.ycoff + cr, make_float4(v[0], v[1], v[2], v[3]));
+          st4(p.y + (size_t)grp * p.gy + ov * (size_t)p.ldy + p.ycoff + cr, make_float4(v[0], v[1], v[2], v[3]));
           if (STATS) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -565,7 +572,7 @@ static long tiled_ntiles(int Do, int Ho, int Wo, int tile_y, int xpair = 0) {
 
 // N-split factor: deal the 16-channel output tiles of a spatial tile to `ns` workgroups when that
 // shortens the launch: estimated time = rounds of the persistent grid x cost of one work item
-// (MFMA work ~ tiles per item, plus a fixed staging / epilogue share).
+// (MFMA work ~ tiles per item, plus a fixed staging / epilogue share).  ntiles counts every sample's tiles.
 static int tiled_nsplit(long ntiles, int NT, int tile_y, int C4, bool xp = false) {
   int best = 1;
   double best_t = 1e30;
@@ -581,31 +588,34 @@ static int tiled_nsplit(long ntiles, int NT, int tile_y, int C4, bool xp = false
   return best;
 }
 
-// workgroups of a launch (= rows of stats_partial): the persistent grid, 256 CUs x resident workgroups,
-// a multiple of 8 * nsplit.  With nsplit > 1 (returned through *nsplit_out when non-NULL) the statistics
-// buffer must be zero-filled by the caller.
-extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int* nsplit_out) {
+// workgroups PER SAMPLE of a launch over `groups` independent samples (rows of stats_partial = groups * this):
+// the persistent grid (256 CUs x resident workgroups) is shared out among the samples, a multiple of 8 * nsplit each.
+extern "C" long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int groups,
+                                     int* nsplit_out) {
   int nch, Ccp;
   tiled_chunks(Cin, &nch, &Ccp);
+  if (groups < 1) groups = 1;
   long nt = tiled_ntiles(Do, Ho, Wo, tile_y, xpair);
   int NT = xpair ? 1 : pow2_tiles(Cout);
-  int ns = tiled_nsplit(nt, NT, tile_y, Ccp / 4, xpair != 0);
+  int ns = tiled_nsplit(nt * groups, NT, tile_y, Ccp / 4, xpair != 0);
   long cap = 256L * tiled_wps(NT / ns, tile_y, Ccp / 4, xpair != 0);
-  long want = nt * ns;
-  long g = want < cap ? want : cap;
   long unit = 8L * ns;
-  g = (g + unit - 1) / unit * unit;
+  long share = cap / groups / unit * unit;           // this sample's share of the resident workgroups
+  if (share < unit) share = unit;
+  long want = (nt * ns + unit - 1) / unit * unit;
+  long g = want < share ? want : share;
   if (nsplit_out) *nsplit_out = ns;
   return g;
 }
-extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair) {
-  return atvs_conv_tiled_grid(Do, Ho, Wo, tile_y, Cin, Cout, xpair, nullptr);
+extern "C" long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int groups) {
+  return atvs_conv_tiled_grid(Do, Ho, Wo, tile_y, Cin, Cout, xpair, groups, nullptr);
 }
-extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout) {
+extern "C" int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int groups) {
   int nch, Ccp;
   tiled_chunks(Cin, &nch, &Ccp);
+  if (groups < 1) groups = 1;
   int NT = pow2_tiles(Cout);
-  return tiled_has_stats(NT / tiled_nsplit(tiled_ntiles(Do, Ho, Wo, tile_y), NT, tile_y, Ccp / 4)) ? 1 : 0;
+  return tiled_has_stats(NT / tiled_nsplit(tiled_ntiles(Do, Ho, Wo, tile_y) * groups, NT, tile_y, Ccp / 4)) ? 1 : 0;
 }
 
 template <int NT, int TY, int C4, bool FULL, bool XP = false>
@@ -624,7 +634,7 @@ static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>), dim3((unsigned)(blocks * a_groups(a))), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -649,13 +659,14 @@ static int launch_c4(const TiledArgs& a, int C4, bool full, long blocks, hipStre
 // stats_partial rows = atvs_conv_tiled_num_blocks(D,H,W,tile_y), width 16*ntiles.  tile_y in {4, 8}.
 extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
                                    const float* residual, const float* plane_bias, float* y, double* stats_partial,
-                                   int D, int H, int W, int Cin, int Dy, int Hy, int Wy, int out_stride, int off_z,
+                                   int groups, int D, int H, int W, int Cin, int Dy, int Hy, int Wy, int out_stride, int off_z,
                                    int off_y, int off_x, int ldy, int y_coff, int Cout, int ntaps, int tile_y, int relu,
                                    int class_cout, int class_base, int xpair, uint32_t* fin_counter, float* fin_params,
                                    double* fin_stats, int fin_rows, int fin_arrivals, int fin_channels, int fin_fold,
                                    long fin_count, float fin_eps, atvs_stream_t stream) {
   if (!x || !packed_w || !table || !y) return ATVS_ERR_NULL;
-  if (D <= 0 || H <= 0 || W <= 0 || out_stride <= 0) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || out_stride <= 0) return ATVS_ERR_SHAPE;
+  if (fin_counter && groups != 1) return ATVS_ERR_ARG;       // the in-launch finalize is single-sample
   if (class_cout) {
     // fused transposed convolution: Cout = classes_in_this_launch * class_cout virtual channels
     if (class_cout % 4 || Cout % class_cout || class_base < 0 || class_base + Cout / class_cout > 8) return ATVS_ERR_SHAPE;
@@ -694,8 +705,11 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   const int C4 = Ccp / 4;
   const bool full = (Cin % Ccp == 0);
   int ns = 1;
-  long blocks = atvs_conv_tiled_grid(D, H, W, tile_y, Cin, Cout, xpair, &ns);
+  long blocks = atvs_conv_tiled_grid(D, H, W, tile_y, Cin, Cout, xpair, groups, &ns);     // per sample
   a.nsplit = ns; a.nt_total = NT;
+  a.wg = (int)blocks; a.ngroups = groups;
+  a.gx = (long)D * H * W * Cin; a.gy = (long)Dy * Hy * Wy * ldy; a.gpb = (long)H * W * 3 * Cout;
+  if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
   const int NTg = NT / ns;
   if (stats_partial && !tiled_has_stats(NTg)) return ATVS_ERR_ARG;
   hipStream_t s = as_stream(stream);
@@ -737,6 +751,8 @@ __global__ __launch_bounds__(256) void conv3d_8to1_kernel(const float* __restric
   constexpr int HZ = C81_TZ + 2, HY = C81_TY + 2, HX = C81_TX + 2;
   __shared__ float4 tile[HZ * HY * HX * 2];
   const int tid = threadIdx.x;
+  x += (size_t)blockIdx.y * D * H * W * 8;                   // blockIdx.y = independent sample
+  y += (size_t)blockIdx.y * D * H * W;
   int bx = blockIdx.x % tiles_x;
   int rest = blockIdx.x / tiles_x;
   const int x0 = bx * C81_TX, y0 = (rest % tiles_y) * C81_TY, z0 = (rest / tiles_y) * C81_TZ;
@@ -777,13 +793,14 @@ __global__ __launch_bounds__(256) void conv3d_8to1_kernel(const float* __restric
 }
 
 // x (D,H,W,8), w: the TF kernel [3,3,3,8,1] as 216 floats (device), y (D,H,W).
-extern "C" int atvs_conv3d_8to1(const float* x, const float* w, float* y, int D, int H, int W, atvs_stream_t stream) {
+extern "C" int atvs_conv3d_8to1(const float* x, const float* w, float* y, int groups, int D, int H, int W,
+                                atvs_stream_t stream) {
   if (!x || !w || !y) return ATVS_ERR_NULL;
-  if (D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || groups > 65535 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
   int tz = (D + C81_TZ - 1) / C81_TZ, ty = (H + C81_TY - 1) / C81_TY, tx = (W + C81_TX - 1) / C81_TX;
   long blocks = (long)tz * ty * tx;
   if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  hipLaunchKernelGGL(conv3d_8to1_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), x, w, y, D, H, W, ty, tx);
+  hipLaunchKernelGGL(conv3d_8to1_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, as_stream(stream), x, w, y, D, H, W, ty, tx);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

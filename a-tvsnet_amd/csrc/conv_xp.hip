@@ -68,6 +68,10 @@ struct XpArgs {
   double* stats2;
   int Do2, Ho2, Wo2, ldy2, ycoff2;
   int pbz, pby, pbx;     // SAME padding in front of each axis (0 or 1)
+  // groups: independent samples stacked on the leading axis of every tensor; `wg` workgroups per sample
+  // (gridDim.x = groups * wg) sweep that sample's tiles, statistics rows are (sample, workgroup)
+  int wg;
+  long gx, gy, gpb, gy2, gpb2;
 };
 
 __device__ __forceinline__ int xp_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
@@ -151,8 +155,14 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
 
   // persistent tile list, dealt so that the workgroups of one XCD (blockIdx % 8) sweep one contiguous eighth
   // of the tile range (halo re-use in that XCD's L2)
-  const int G = gridDim.x;
-  const int xcd = blockIdx.x & 7, tslot = blockIdx.x >> 3;
+  const int G = p.wg;
+  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
+  const int xcd = lbk & 7, tslot = lbk >> 3;
+  const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
+  float* __restrict__ yg = p.y + (size_t)grp * p.gy;
+  float* __restrict__ y2g = p.y2 + (size_t)grp * p.gy2;
+  const float* __restrict__ pbg = p.pbias ? p.pbias + (size_t)grp * p.gpb : nullptr;
+  const float* __restrict__ pb2g = p.pbias2 ? p.pbias2 + (size_t)grp * p.gpb2 : nullptr;
   const int per_xcd = (p.ntiles + 7) >> 3;
   const int slots_per_xcd = G >> 3;
   int my_tiles = 0;
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     int z0, y0, x0;
     tile_origin(k, &z0, &y0, &x0);
     const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
-    T.xb = p.x + ch * CC;
+    T.xb = xg + ch * CC;
     T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
     T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
     T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
@@ -293,14 +303,14 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
       if (j < MAXS) pf_slot(T, j);
       // operands of the epilogues (depth-plane biases) of the tile's last chunk: requested a few steps before
       // the end of the main K loop, so the epilogue never waits for them
-      if (j == JC - 4 && last_chunk && p.pbias) {
+      if (j == JC - 4 && last_chunk && pbg) {
 #pragma unroll
-        for (int t = 0; t < XP_TY; ++t) epb[t] = ld4(erow_ok(t) ? p.pbias + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
+        for (int t = 0; t < XP_TY; ++t) epb[t] = ld4(erow_ok(t) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
       }
-      if (SIB && j == JC - 3 && last_chunk && p.pbias2) {
+      if (SIB && j == JC - 3 && last_chunk && pb2g) {
         const size_t o = ((size_t)yo2 * p.Wo2 + xo2) * 48 + plane_variant(2 * zo2 - p.pbz, p.Di) * 16 + 4 * q;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) epb2[t] = ld4(erow2_ok(t) ? p.pbias2 + (o + (size_t)t * p.Wo2 * 48) : p.zeros);
+        for (int t = 0; t < 2; ++t) epb2[t] = ld4(erow2_ok(t) ? pb2g + (o + (size_t)t * p.Wo2 * 48) : p.zeros);
       }
       // compiler barrier (keeps InstCombine / the scheduler from sinking the requests to their uses) +
       // scheduling barrier (keeps them in front of the MFMAs that cover their latency)
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
           v.z = (v.z < 0.f) ? 0.f : v.z;
           v.w = (v.w < 0.f) ? 0.f : v.w;
         }
-        st4(p.y + (eo + (size_t)t * erow), v);
+        st4(yg + (eo + (size_t)t * erow), v);
         ssum[0] += v.x; ssum[1] += v.y; ssum[2] += v.z; ssum[3] += v.w;
         ssq[0] += v.x * v.x; ssq[1] += v.y * v.y; ssq[2] += v.z * v.z; ssq[3] += v.w * v.w;
       }
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
       for (int t = 0; t < 2; ++t) {
         if (!erow2_ok(t)) continue;
         float4 v = make_float4(acc2[t][0] + epb2[t].x, acc2[t][1] + epb2[t].y, acc2[t][2] + epb2[t].z, acc2[t][3] + epb2[t].w);
-        st4(p.y2 + (eo2 + (size_t)t * erow2), v);
+        st4(y2g + (eo2 + (size_t)t * erow2), v);
         ssum2[0] += v.x; ssum2[1] += v.y; ssum2[2] += v.z; ssum2[3] += v.w;
         ssq2[0] += v.x * v.x; ssq2[1] += v.y * v.y; ssq2[2] += v.z * v.z; ssq2[3] += v.w * v.w;
       }
@@ -475,10 +485,14 @@ extern "C" int atvs_conv_xp_pack(const float* w, int Cin, float* packed) {
   return ATVS_OK;
 }
 
-// workgroups of a launch (= rows of the statistics buffer): one per CU, a multiple of 8
-extern "C" long atvs_conv_xp_grid(int D, int H, int W) {
+// workgroups PER SAMPLE of a launch over `groups` independent samples (rows of the statistics buffer = groups * this):
+// one workgroup per CU in all, shared out among the samples, a multiple of 8 each
+extern "C" long atvs_conv_xp_grid(int D, int H, int W, int groups) {
+  if (groups < 1) groups = 1;
   long nt = xp_ntiles(D, H, W);
-  long g = nt < 256 ? nt : 256;
+  long share = 256 / groups / 8 * 8;
+  if (share < 8) share = 8;
+  long g = nt < share ? nt : share;
   return (g + 7) / 8 * 8;
 }
 
@@ -540,12 +554,12 @@ static int launch_xp1(const XpArgs& a, long blocks, hipStream_t s) {
 // stride-2 convolution of the same x with a [3,3,3,Cin,16] kernel (+ plane_bias2 (Ho2, Wo2, 48)), its partial
 // moments in stats_partial2 (same rows, 16 channels).
 extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias,
-                                float* y, double* stats_partial, int D, int H, int W, int Cin, int ldy, int y_coff,
+                                float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
                                 int relu, const float* packed_w2, const float* plane_bias2, float* y2,
                                 double* stats_partial2, int ldy2, int y_coff2, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   const int C4 = xp_c4(Cin);
-  if (D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || !C4) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || !C4) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if (plane_bias && D < 2) return ATVS_ERR_ARG;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;   // 31-bit element offsets
@@ -568,7 +582,10 @@ extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const flo
   a.wp2 = packed_w2; a.pbias2 = plane_bias2; a.y2 = y2; a.stats2 = stats_partial2;
   a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
   a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;      // tf SAME, kernel 3, stride 2: one leading pad iff the size is odd
-  const long blocks = atvs_conv_xp_grid(D, H, W);
+  a.wg = (int)atvs_conv_xp_grid(D, H, W, groups);
+  a.gx = (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
+  a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
+  const long blocks = (long)a.wg * groups;
   hipStream_t st = as_stream(stream);
   int rc;
   if (packed_w2) rc = (C4 == 4) ? launch_xp1<4, true>(a, blocks, st) : launch_xp1<2, true>(a, blocks, st);

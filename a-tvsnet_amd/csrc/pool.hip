@@ -13,7 +13,9 @@
 __global__ __launch_bounds__(256) void avg_pool_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, int H,
                                                                int W, int C, int Wo, int k, int s, int pad_t, int pad_l) {
   __shared__ float sm[256];
-  const int oy = blockIdx.y, ox = blockIdx.x, sl = blockIdx.z;
+  const int oy = blockIdx.y, ox = blockIdx.x, sl = blockIdx.z % POOL_SLICES, grp = blockIdx.z / POOL_SLICES;
+  x += (size_t)grp * H * W * C;                               // independent image
+  ws += (size_t)grp * gridDim.y * Wo * POOL_SLICES * C;
   const int y0 = max(oy * s - pad_t, 0), y1 = min(oy * s - pad_t + k, H);
   const int x0 = max(ox * s - pad_l, 0), x1 = min(ox * s - pad_l + k, W);
   const int rows = y1 - y0;
@@ -43,12 +45,13 @@ __global__ __launch_bounds__(256) void avg_pool_partial_kernel(const float* __re
 }
 
 __global__ __launch_bounds__(256) void avg_pool_finish_kernel(const float* __restrict__ ws, float* __restrict__ y, int H, int W,
-                                                              int C, int Ho, int Wo, int k, int s, int pad_t, int pad_l) {
+                                                              int C, int Ho, int Wo, int k, int s, int pad_t, int pad_l,
+                                                              int groups) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (long)Ho * Wo * C) return;
+  if (i >= (long)groups * Ho * Wo * C) return;
   int c = (int)(i % C);
-  long pix = i / C;
-  int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+  long pix = i / C;                                           // (image, oy, ox)
+  int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
   const int y0 = max(oy * s - pad_t, 0), y1 = min(oy * s - pad_t + k, H);
   const int x0 = max(ox * s - pad_l, 0), x1 = min(ox * s - pad_l + k, W);
   float v = 0.f;
@@ -56,22 +59,22 @@ __global__ __launch_bounds__(256) void avg_pool_finish_kernel(const float* __res
   y[i] = v / (float)((y1 - y0) * (x1 - x0));
 }
 
-extern "C" long atvs_avg_pool_ws_floats(int H, int W, int C, int stride) {
+extern "C" long atvs_avg_pool_ws_floats(int H, int W, int C, int stride) {      // per image
   long Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
   return Ho * Wo * POOL_SLICES * C;
 }
 
-extern "C" int atvs_avg_pool_same(const float* x, float* y, float* ws, int H, int W, int C, int pool, int stride,
+extern "C" int atvs_avg_pool_same(const float* x, float* y, float* ws, int groups, int H, int W, int C, int pool, int stride,
                                   atvs_stream_t stream) {
   if (!x || !y || !ws) return ATVS_ERR_NULL;
-  if (H <= 0 || W <= 0 || C <= 0 || pool <= 0 || stride <= 0) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || groups * POOL_SLICES > 65535 || H <= 0 || W <= 0 || C <= 0 || pool <= 0 || stride <= 0) return ATVS_ERR_SHAPE;
   int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
   int ph = max((Ho - 1) * stride + pool - H, 0), pw = max((Wo - 1) * stride + pool - W, 0);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(avg_pool_partial_kernel, dim3(Wo, Ho, POOL_SLICES), dim3(256), 0, s, x, ws, H, W, C, Wo, pool,
+  hipLaunchKernelGGL(avg_pool_partial_kernel, dim3(Wo, Ho, POOL_SLICES * groups), dim3(256), 0, s, x, ws, H, W, C, Wo, pool,
                      stride, ph / 2, pw / 2);
-  hipLaunchKernelGGL(avg_pool_finish_kernel, dim3(cdiv((long)Ho * Wo * C, 256)), dim3(256), 0, s, ws, y, H, W, C, Ho, Wo,
-                     pool, stride, ph / 2, pw / 2);
+  hipLaunchKernelGGL(avg_pool_finish_kernel, dim3(cdiv((long)groups * Ho * Wo * C, 256)), dim3(256), 0, s, ws, y, H, W, C, Ho, Wo,
+                     pool, stride, ph / 2, pw / 2, groups);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
@@ -79,13 +82,14 @@ extern "C" int atvs_avg_pool_same(const float* x, float* y, float* ws, int H, in
 // out written into a channel slice [c_off, c_off+C) of rows of width ld
 __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int H,
                                                               int W, int C, int Ho, int Wo, float sy, float sx, int ld,
-                                                              int c_off) {
+                                                              int c_off, int groups) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  long n = (long)Ho * Wo * C;
+  long n = (long)groups * Ho * Wo * C;
   if (i >= n) return;
   int c = (int)(i % C);
-  long pix = i / C;
-  int ox = (int)(pix % Wo), oy = (int)(pix / Wo);
+  long pix = i / C;                                           // (image, oy, ox)
+  int ox = (int)(pix % Wo), oy = (int)((pix / Wo) % Ho);
+  x += (size_t)(pix / ((long)Ho * Wo)) * H * W * C;
   float fy = (float)oy * sy, fx = (float)ox * sx;
   int y0 = (int)floorf(fy), x0 = (int)floorf(fx);
   int y1 = min((int)ceilf(fy), H - 1), x1 = min((int)ceilf(fx), W - 1);
@@ -97,15 +101,15 @@ __global__ __launch_bounds__(256) void resize_bilinear_kernel(const float* __res
   y[(size_t)pix * ld + c_off + c] = t + (b - t) * ly;
 }
 
-extern "C" int atvs_resize_bilinear(const float* x, float* y, int H, int W, int C, int Ho, int Wo, int ld_out, int c_off,
-                                    atvs_stream_t stream) {
+extern "C" int atvs_resize_bilinear(const float* x, float* y, int groups, int H, int W, int C, int Ho, int Wo, int ld_out,
+                                    int c_off, atvs_stream_t stream) {
   if (!x || !y) return ATVS_ERR_NULL;
-  if (H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || c_off < 0 || c_off + C > ld_out) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || c_off < 0 || c_off + C > ld_out) return ATVS_ERR_SHAPE;
   float sy = (Ho > 1) ? (float)((double)(H - 1) / (double)(Ho - 1)) : 0.f;
   float sx = (Wo > 1) ? (float)((double)(W - 1) / (double)(Wo - 1)) : 0.f;
-  long n = (long)Ho * Wo * C;
+  long n = (long)groups * Ho * Wo * C;
   hipLaunchKernelGGL(resize_bilinear_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(stream), x, y, H, W, C, Ho, Wo,
-                     sy, sx, ld_out, c_off);
+                     sy, sx, ld_out, c_off, groups);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -40,6 +40,8 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict
                                                          int D, long npix) {
   __shared__ float sm[3][4][64];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  cost += (size_t)blockIdx.y * D * npix;                       // blockIdx.y = independent volume (same depth sweep)
+  depth_out += (size_t)blockIdx.y * npix;
   long pix = (long)blockIdx.x * 64 + lane;
   float start = depth_start[0], end;
   float step = linspace_step(start, depth_interval[0], D, &end);
@@ -71,11 +73,11 @@ __global__ __launch_bounds__(256) void softargmin_kernel(const float* __restrict
 }
 
 extern "C" int atvs_softargmin(const float* cost, const float* depth_start, const float* depth_interval, float* depth_out,
-                               int D, int h, int w, atvs_stream_t stream) {
+                               int groups, int D, int h, int w, atvs_stream_t stream) {
   if (!cost || !depth_start || !depth_interval || !depth_out) return ATVS_ERR_NULL;
-  if (D <= 0 || h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || groups > 65535 || D <= 0 || h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
   long npix = (long)h * w;
-  hipLaunchKernelGGL(softargmin_kernel, dim3(cdiv(npix, 64)), dim3(256), 0, as_stream(stream), cost, depth_start,
+  hipLaunchKernelGGL(softargmin_kernel, dim3(cdiv(npix, 64), groups), dim3(256), 0, as_stream(stream), cost, depth_start,
                      depth_interval, depth_out, D, npix);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

@@ -119,11 +119,11 @@ def geo_ref_planes(depth_ref, depth_start, depth_interval, out, c_off):
     return out
 
 
-def visual_hull(ref_depth, view_depth_in_ref, homographies, depth_start, depth_interval, inverse_depth=True):
-    """(h,w) x2 -> (D,h,w)."""
+def visual_hull(ref_depth, view_depth_in_ref, homographies, depth_start, depth_interval, inverse_depth=True, out=None):
+    """(h,w) x2 -> (D,h,w) (written into `out` when given)."""
     h, w = ref_depth.shape[:2]
     D = homographies.shape[0]
-    out = _new(ref_depth, (D, h, w))
+    out = _new(ref_depth, (D, h, w)) if out is None else out
     if _dev_ok(ref_depth, view_depth_in_ref, homographies, depth_start, depth_interval):
         _call('atvs_visual_hull', _p(ref_depth), _p(view_depth_in_ref), _p(homographies), _p(depth_start),
               _p(depth_interval), _p(out), D, h, w, int(bool(inverse_depth)), _stream())
@@ -164,12 +164,13 @@ def absdiff_mask(a, b, mask):
 
 # --------------------------------------------------------------------------- soft-argmin
 
-def softargmin(cost, depth_start, depth_interval):
-    """cost (D,h,w) -> (h,w)."""
-    D, h, w = cost.shape
-    out = _new(cost, (h, w))
+def softargmin(cost, depth_start, depth_interval, groups=None):
+    """cost (D,h,w) -> (h,w); groups=G: (G,D,h,w) -> (G,h,w), one depth sweep for all."""
+    G = 1 if groups is None else int(groups)
+    D, h, w = cost.shape[-3:]
+    out = _new(cost, (h, w) if groups is None else (G, h, w))
     if _dev_ok(cost, depth_start, depth_interval):
-        _call('atvs_softargmin', _p(cost), _p(depth_start), _p(depth_interval), _p(out), D, h, w, _stream())
+        _call('atvs_softargmin', _p(cost), _p(depth_start), _p(depth_interval), _p(out), G, D, h, w, _stream())
     return out
 
 
@@ -433,23 +434,24 @@ def conv2d_lds(x, key, w_host, dilation=1, bias=None, residual=None, relu=False,
     return (y, st) if want_stats else y
 
 
-def conv_xp_launch(x4, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None):
-    """One atvs_conv_xp_f32 launch: x4 (D,H,W,Cin) -> y (D,H,W,ldy)[..., y_coff:y_coff+8].
-    sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x4."""
-    D, H, W, Cin = x4.shape
+def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None):
+    """One atvs_conv_xp_f32 launch: x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
+    sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5."""
+    G, D, H, W, Cin = x5.shape
     ldy = y.shape[-1]
     null = ctypes.c_void_p(0)
     sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null     # noqa: E731
     pk2, y2, y_coff2, sbuf2, pb2 = sibling if sibling is not None else (None, None, 0, None, None)
-    if _dev_ok(x4, y, bias, plane_bias, y2, pb2):
-        with _Timed(pk.key, x4.shape, pk.cout + (16 if pk2 is not None else 0)):
-            _call('atvs_conv_xp_f32', _p(x4), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), D, H, W, Cin,
+    if _dev_ok(x5, y, bias, plane_bias, y2, pb2):
+        with _Timed(pk.key, x5.shape[1:], pk.cout + (16 if pk2 is not None else 0)):
+            _call('atvs_conv_xp_f32', _p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
                   ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
                   sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _stream())
 
 
-def xp_blocks(D, H, W):
-    return int(_lib.lib().atvs_conv_xp_grid(int(D), int(H), int(W)))
+def xp_blocks(D, H, W, groups=1):
+    """Workgroups per sample of an x-pair launch."""
+    return int(_lib.lib().atvs_conv_xp_grid(int(D), int(H), int(W), int(groups)))
 
 
 _USE_XP1W = True
@@ -515,36 +517,37 @@ class Fin(object):
     __slots__ = ('counter', 'params', 'stats', 'rows', 'arrivals', 'channels', 'fold', 'count')
 
 
-def conv_tiled_launch(x4, pk, y, out_stride, out_off, y_coff, tile_y, bias=None, residual=None, relu=False,
+def conv_tiled_launch(x5, pk, y, out_stride, out_off, y_coff, tile_y, bias=None, residual=None, relu=False,
                       stats_buf=None, plane_bias=None, class_cout=0, class_base=0, xpair=False, fin=None):
-    """One atvs_conv_tiled_f32 launch: logical output grid = input grid of x4 (D,H,W,Cin)."""
-    D, H, W, Cin = x4.shape
-    Dy, Hy, Wy, ldy = y.shape
-    if _dev_ok(x4, y, bias, residual, plane_bias):
-        with _Timed(pk.key, x4.shape, pk.cout):
-          _call('atvs_conv_tiled_f32', _p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
-              _p(plane_bias), _p(y), ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), D, H, W,
-              Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
-              8 if xpair else pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), int(class_cout), int(class_base),
-              int(bool(xpair)),
-              ctypes.c_void_p(fin.counter.data_ptr()) if fin is not None else ctypes.c_void_p(0),
-              _p(fin.params) if fin is not None else ctypes.c_void_p(0),
-              ctypes.c_void_p(fin.stats.data_ptr()) if fin is not None else ctypes.c_void_p(0),
-              fin.rows if fin is not None else 0, fin.arrivals if fin is not None else 0,
-              fin.channels if fin is not None else 0, fin.fold if fin is not None else 0,
-              ctypes.c_long(fin.count if fin is not None else 0), ctypes.c_float(1e-3), _stream())
+    """One atvs_conv_tiled_f32 launch: logical output grid = input grid of x5 (G,D,H,W,Cin); y (G,Dy,Hy,Wy,ldy)."""
+    G, D, H, W, Cin = x5.shape
+    Dy, Hy, Wy, ldy = y.shape[-4:]
+    if _dev_ok(x5, y, bias, residual, plane_bias):
+        with _Timed(pk.key, x5.shape[1:], pk.cout):
+            _call('atvs_conv_tiled_f32', _p(x5), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
+                  _p(plane_bias), _p(y),
+                  ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), G, D, H, W,
+                  Cin, Dy, Hy, Wy, int(out_stride), int(out_off[0]), int(out_off[1]), int(out_off[2]), ldy, int(y_coff),
+                  8 if xpair else pk.cout, pk.ntaps, int(tile_y), int(bool(relu)), int(class_cout), int(class_base),
+                  int(bool(xpair)),
+                  ctypes.c_void_p(fin.counter.data_ptr()) if fin is not None else ctypes.c_void_p(0),
+                  _p(fin.params) if fin is not None else ctypes.c_void_p(0),
+                  ctypes.c_void_p(fin.stats.data_ptr()) if fin is not None else ctypes.c_void_p(0),
+                  fin.rows if fin is not None else 0, fin.arrivals if fin is not None else 0,
+                  fin.channels if fin is not None else 0, fin.fold if fin is not None else 0,
+                  ctypes.c_long(fin.count if fin is not None else 0), ctypes.c_float(1e-3), _stream())
 
 
-def tiled_blocks(D, H, W, tile_y, cin, cout, xpair=False):
-    """Workgroups (= statistics rows) of a tiled launch: the persistent grid size."""
+def tiled_blocks(D, H, W, tile_y, cin, cout, xpair=False, groups=1):
+    """Workgroups PER SAMPLE (= statistics rows per sample) of a tiled launch: its share of the persistent grid."""
     return int(_lib.lib().atvs_conv_tiled_num_blocks(int(D), int(H), int(W), int(tile_y), int(cin), int(cout),
-                                                     int(bool(xpair))))
+                                                     int(bool(xpair)), int(groups)))
 
 
-def tiled_nsplit(D, H, W, tile_y, cin, cout, xpair=False):
+def tiled_nsplit(D, H, W, tile_y, cin, cout, xpair=False, groups=1):
     ns = ctypes.c_int()
     _lib.lib().atvs_conv_tiled_grid(int(D), int(H), int(W), int(tile_y), int(cin), int(cout), int(bool(xpair)),
-                                    ctypes.byref(ns))
+                                    int(groups), ctypes.byref(ns))
     return ns.value
 
 
@@ -619,21 +622,21 @@ class Stats(object):
         self.groups = 1         # independent samples: partial is (groups, blocks, 2, cpad), count per sample
 
 
-def conv_launch(x4, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bias=None, residual=None, relu=False,
+def conv_launch(x5, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bias=None, residual=None, relu=False,
                 stats_buf=None, tile_m=None, plane_bias=None, pad_z=0):
-    """One atvs_conv_mfma_f32 launch.  x4: (Di,Hi,Wi,Cin); y: full output (Dy,Hy,Wy,ldy)."""
-    Di, Hi, Wi, Cin = x4.shape
-    Dy, Hy, Wy, ldy = y.shape
+    """One atvs_conv_mfma_f32 launch.  x5: (G,Di,Hi,Wi,Cin); y: full output (G,Dy,Hy,Wy,ldy)."""
+    G, Di, Hi, Wi, Cin = x5.shape
+    Dy, Hy, Wy, ldy = y.shape[-4:]
     Do, Ho, Wo = out_grid
     M = Do * Ho * Wo
-    tm = tile_m or _pick_tile_m(M, pk.ntiles)
-    if _dev_ok(x4, y, bias, residual, plane_bias):
-        args = [_p(x4), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual), _p(plane_bias),
+    tm = tile_m or _pick_tile_m(M * G, pk.ntiles)
+    if _dev_ok(x5, y, bias, residual, plane_bias):
+        args = [_p(x5), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual), _p(plane_bias),
                 int(pad_z), _p(y),
                 ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0),
-                Di, Hi, Wi, Cin, Do, Ho, Wo, int(in_stride), Dy, Hy, Wy, int(out_stride), int(out_off[0]),
+                G, Di, Hi, Wi, Cin, Do, Ho, Wo, int(in_stride), Dy, Hy, Wy, int(out_stride), int(out_off[0]),
                 int(out_off[1]), int(out_off[2]), ldy, int(y_coff), pk.cout, pk.ntaps, tm, int(bool(relu)), _stream()]
-        with _Timed(pk.key, x4.shape, pk.cout):
+        with _Timed(pk.key, x5.shape[1:], pk.cout):
             _call('atvs_conv_mfma_f32', *args)
     return tm
 
@@ -685,28 +688,56 @@ def watch(tag):
     return out
 
 
-def conv_blocks(M, ntiles, tile_m=None):
-    tm = tile_m or _pick_tile_m(M, ntiles)
+def conv_blocks(M, ntiles, tile_m=None, groups=1):
+    """(workgroups per sample, tile_m) of a gather launch."""
+    tm = tile_m or _pick_tile_m(M * groups, ntiles)
     return -(-M // (64 * tm)), tm
 
 
-def _stats_buffer(ref, blocks, cpad, zero=False):
+def _stats_buffer(ref, blocks, cpad, zero=False, groups=1):
     f = torch.zeros if zero else torch.empty
-    return f((blocks, 2, cpad), dtype=torch.float64, device=ref.device)
+    return f((groups, blocks, 2, cpad), dtype=torch.float64, device=ref.device)
+
+
+def _to5(x, groups, what='tensor'):
+    """Canonical (G,D,H,W,C) view of a channel-last tensor.  groups=None: x is one sample, (H,W,C) or (D,H,W,C);
+    groups=G: x is G independent samples stacked on a leading axis, (G,H,W,C) or (G,D,H,W,C).  -> (x5, nsp)."""
+    if groups is None:
+        nsp = x.dim() - 1
+        lead = (1,)
+        rest = tuple(x.shape)
+    else:
+        nsp = x.dim() - 2
+        if x.shape[0] != groups:
+            raise ValueError('%s: leading axis %d, groups %d' % (what, x.shape[0], groups))
+        lead = (int(groups),)
+        rest = tuple(x.shape[1:])
+    if nsp not in (2, 3):
+        raise ValueError('%s: %d spatial axes' % (what, nsp))
+    return x.reshape(lead + (1,) * (3 - nsp) + rest), nsp
+
+
+def _from5(y5, nsp, groups):
+    shape = tuple(y5.shape[4 - nsp:])
+    return y5.reshape(shape if groups is None else (y5.shape[0],) + shape)
 
 
 def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None, bias=None, residual=None,
-         relu=False, want_stats=False, out=None, y_coff=0, plane_bias=None):
-    """Forward convolution of a channel-last tensor x: (H,W,C) or (D,H,W,C).
+         relu=False, want_stats=False, out=None, y_coff=0, plane_bias=None, groups=None, in_params=None,
+         in_relu=False):
+    """Forward convolution of a channel-last tensor x: (H,W,C) or (D,H,W,C); with groups=G, G independent samples
+    (G,H,W,C) / (G,D,H,W,C) in one launch (per-sample batch-norm moments).
 
     w_host: TF-layout numpy kernel [k.., Cin, Cout]; `key` names it for the pack cache.
     padding: 'SAME' | 'VALID'; explicit_pad = (before, after) per spatial axis overrides it
-    (bottleneck conv2, network.py:589-595).  Returns y or (y, Stats).
+    (bottleneck conv2, network.py:589-595).  in_params (G,3,Cin) [+ in_relu]: x is a raw convolution output whose
+    batch norm is applied on load (only where the kernel of this shape supports it, see norm_on_load_ok).
+    Returns y or (y, Stats).
     """
-    nsp = x.dim() - 1
-    x4 = x if nsp == 3 else x.reshape((1,) + tuple(x.shape))
+    x5, nsp = _to5(x, groups, 'conv input')
+    G = x5.shape[0]
     ks = (1,) * (3 - nsp) + tuple(int(k) for k in w_host.shape[:nsp])
-    ins = x4.shape[:3]
+    ins = tuple(x5.shape[1:4])
     pads, outs = [], []
     for i in range(3):
         if ks[i] == 1 and i < 3 - nsp:
@@ -726,103 +757,113 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             pads.append(0)
             outs.append((ins[i] - ((ks[i] - 1) * dilation + 1)) // stride + 1)
     taps = conv_taps(ks, dilation, pads)
-    cout = int(w_host.shape[-1])
+    cin, cout = int(w_host.shape[-2]), int(w_host.shape[-1])
+    if cin != x5.shape[4]:
+        raise ValueError('conv %s: input has %d channels, kernel wants %d' % (key, x5.shape[4], cin))
+    y5 = None
+    if out is not None:
+        y5, _ = _to5(out, groups, 'conv output buffer')
+        if tuple(y5.shape[:4]) != (G,) + tuple(outs):
+            raise ValueError('conv %s: output buffer %s does not match %s' % (key, tuple(y5.shape), (G,) + tuple(outs)))
+    res5 = _to5(residual, groups, 'residual')[0] if residual is not None else None
+    if plane_bias is not None:
+        pb_shape = ((G,) if groups is not None else ()) + (outs[1], outs[2], 3 * cout)
+        if tuple(plane_bias.shape) != pb_shape:
+            raise ValueError('conv %s: plane_bias %s, expected %s' % (key, tuple(plane_bias.shape), pb_shape))
+    M = outs[0] * outs[1] * outs[2]
+
+    # ---- 2-D, 3x3, stride 1, SAME on wide channels: the LDS-tiled tower kernel
     if nsp == 2 and stride == 1 and ks == (1, 3, 3) and tuple(pads[1:]) == (dilation, dilation) \
-            and tuple(outs) == tuple(ins) and plane_bias is None \
-            and (out is None or (out.shape[-1] % 4 == 0 and y_coff % 4 == 0)) \
-            and conv2d_lds_ok(w_host.shape[-2], cout, dilation, ins[1], ins[2]):
-        res = conv2d_lds(x4, key, w_host, dilation, bias, None if residual is None else residual.reshape((1,) + tuple(residual.shape)),
-                         relu, want_stats, None if out is None else out.reshape((1,) + tuple(out.shape)), y_coff)
-        y4, st = res if want_stats else (res, None)
-        y = out if out is not None else y4.reshape(tuple(y4.shape[1:]))
+            and tuple(outs) == ins and plane_bias is None \
+            and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)) \
+            and conv2d_lds_ok(cin, cout, dilation, ins[1], ins[2]):
+        r = conv2d_lds(x5[:, 0], key, w_host, dilation, bias, None if res5 is None else res5[:, 0], relu, want_stats,
+                       None if y5 is None else y5[:, 0], y_coff, in_params, in_relu)
+        y4, st = r if want_stats else (r, None)
+        y = out if out is not None else _from5(y4.unsqueeze(1), nsp, groups)
         return (y, st) if want_stats else y
+    if in_params is not None:
+        raise ValueError('conv %s: no normalise-on-load form for this shape' % (key,))
+
     tile_y = 0
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
-            and tuple(outs) == tuple(ins):
+            and tuple(outs) == ins:
         tile_y = tiled_tile_y(ins[1], ins[2], cout)
     xpair = bool(tile_y) and _USE_XPAIR and cout == 8 and (ins[2] >= 24 or _FORCE_IMPL == 'tiled') \
-        and (out is None or (out.shape[-1] % 4 == 0 and y_coff % 4 == 0))
-    xp1w = xpair and _USE_XP1W and w_host.shape[-2] % 8 == 0 and residual is None
+        and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0))
+    xp1w = xpair and _USE_XP1W and cin % 8 == 0 and residual is None
     if xp1w:
         pk = pack_conv_xp(key, w_host, x.device)
     elif xpair:
-        tile_y = 4 if w_host.shape[-2] > 8 else tile_y
+        tile_y = 4 if cin > 8 else tile_y
         pk = pack_conv_weights_tiled(key, _xpair_virtual_kernel(key, w_host), XPAIR_TAPS, False, x.device, tile_y, True)
         pk.cout = 8
     elif tile_y:
         pk = pack_conv_weights_tiled(key, w_host, taps, False, x.device, tile_y)
     else:
         pk = pack_conv_weights(key, w_host, taps, False, x.device)
-    if pk.cin != x4.shape[3]:
-        raise ValueError('conv %s: input has %d channels, kernel wants %d' % (key, x4.shape[3], pk.cin))
-    if out is None:
-        y4 = _new(x, tuple(outs) + (pk.cout,))
-    else:
-        y4 = out if out.dim() == 4 else out.reshape((1,) + tuple(out.shape))
-        if tuple(y4.shape[:3]) != tuple(outs):
-            raise ValueError('conv %s: output buffer %s does not match %s' % (key, tuple(y4.shape), outs))
-    res4 = None
-    if residual is not None:
-        res4 = residual if residual.dim() == 4 else residual.reshape((1,) + tuple(residual.shape))
-    M = outs[0] * outs[1] * outs[2]
+    if y5 is None:
+        y5 = _new(x, (G,) + tuple(outs) + (pk.cout,))
     if xp1w:
-        blocks, tm = xp_blocks(outs[0], outs[1], outs[2]), 0
+        blocks, tm = xp_blocks(outs[0], outs[1], outs[2], G), 0
     elif tile_y:
-        blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout, xpair), 0
+        blocks, tm = tiled_blocks(outs[0], outs[1], outs[2], tile_y, pk.cin, pk.cout, xpair, G), 0
     else:
-        blocks, tm = conv_blocks(M, pk.ntiles)
+        blocks, tm = conv_blocks(M, pk.ntiles, groups=G)
     st = None
     sbuf = None
     if want_stats:
-        sbuf = _stats_buffer(x, blocks, pk.ntiles * 16)
+        sbuf = _stats_buffer(x, blocks, pk.ntiles * 16, groups=G)
         st = Stats()
-        st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, pk.ntiles * 16, M
-    if plane_bias is not None and tuple(plane_bias.shape) != (outs[1], outs[2], 3 * pk.cout):
-        raise ValueError('conv %s: plane_bias %s, expected %s' % (key, tuple(plane_bias.shape), (outs[1], outs[2], 3 * pk.cout)))
+        st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, pk.ntiles * 16, M, G
     if xp1w:
-        conv_xp_launch(x4, pk, y4, y_coff, bias, relu, sbuf, plane_bias)
+        conv_xp_launch(x5, pk, y5, y_coff, bias, relu, sbuf, plane_bias)
     elif tile_y:
         fin = None
-        if want_stats and _FUSED_FINALIZE and pk.cout <= 64 and not x.is_meta:
+        if want_stats and _FUSED_FINALIZE and pk.cout <= 64 and not x.is_meta and G == 1:
             fin = Fin()
             fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, pk.cout)), sbuf
             fin.rows, fin.arrivals, fin.channels, fin.fold, fin.count = blocks, blocks, pk.cout, 1, M
             st.params = fin.params
-        conv_tiled_launch(x4, pk, y4, 1, (0, 0, 0), y_coff, tile_y, bias, res4, relu, sbuf, plane_bias, xpair=xpair,
+        conv_tiled_launch(x5, pk, y5, 1, (0, 0, 0), y_coff, tile_y, bias, res5, relu, sbuf, plane_bias, xpair=xpair,
                           fin=fin)
     else:
-        conv_launch(x4, pk, y4, outs, stride, 1, (0, 0, 0), y_coff, bias, res4, relu, sbuf, tm, plane_bias, pads[0])
-    y = out if out is not None else (y4 if nsp == 3 else y4.reshape(tuple(y4.shape[1:])))
+        conv_launch(x5, pk, y5, outs, stride, 1, (0, 0, 0), y_coff, bias, res5, relu, sbuf, tm, plane_bias, pads[0])
+    y = out if out is not None else _from5(y5, nsp, groups)
     return (y, st) if want_stats else y
 
 
-def conv3d_8to1(x, w_dev):
-    """3x3x3 SAME convolution (D,H,W,8) -> (D,H,W,1); w_dev: device tensor of the TF kernel [3,3,3,8,1]."""
-    D, H, W, C = x.shape
-    if C != 8 or w_dev.numel() != 216:
-        raise ValueError('conv3d_8to1: 8 input channels and a [3,3,3,8,1] kernel')
-    y = _new(x, (D, H, W, 1))
+def conv3d_8to1(x, w_dev, groups=None):
+    """3x3x3 SAME convolution (D,H,W,8) -> (D,H,W,1) (groups=G: (G,D,H,W,8) -> (G,D,H,W,1)); w_dev: device tensor
+    of the TF kernel [3,3,3,8,1]."""
+    x5, nsp = _to5(x, groups, 'conv3d_8to1 input')
+    G, D, H, W, C = x5.shape
+    if nsp != 3 or C != 8 or w_dev.numel() != 216:
+        raise ValueError('conv3d_8to1: a volume with 8 input channels and a [3,3,3,8,1] kernel')
+    y = _new(x, (D, H, W, 1) if groups is None else (G, D, H, W, 1))
     if _dev_ok(x, w_dev):
-        _call('atvs_conv3d_8to1', _p(x), _p(w_dev), _p(y), D, H, W, _stream())
+        _call('atvs_conv3d_8to1', _p(x), _p(w_dev), _p(y), G, D, H, W, _stream())
     return y
 
 
 class SplitVolume(object):
-    """A (1,D,h,w,C) network input whose channels are a concat of D-varying and D-constant parts.
+    """A (B,D,h,w,C) network input whose channels are a concat of D-varying and D-constant parts.
 
     Stands for tf.concat([...tf.tile(x, [1,D,1,1,1])...], -1) of model.py:186-195, 329-336 without
-    materialising the tiled parts.  var: (D,h,w,Cv); const: (h,w,Cc); chan_map: for each channel of
-    the reference's concat, ('v', i) or ('c', i) -- several channels may map to the same source
-    (the 16 identical geo-view channels, quirk C7)."""
+    materialising the tiled parts.  var: (B,D,h,w,Cv); const: (B,h,w,Cc) (B = independent samples; a 4-D var /
+    3-D const is one sample); chan_map: for each channel of the reference's concat, ('v', i) or ('c', i) --
+    several channels may map to the same source (the 16 identical geo-view channels, quirk C7)."""
 
     def __init__(self, var, const, chan_map):
+        if var.dim() == 4:
+            var, const = var.unsqueeze(0), const.unsqueeze(0)
         self.var, self.const, self.chan_map = var, const, list(chan_map)
         self.device = var.device
 
     @property
     def shape(self):
-        D, h, w, _ = self.var.shape
-        return (1, D, h, w, len(self.chan_map))
+        B, D, h, w, _ = self.var.shape
+        return (B, D, h, w, len(self.chan_map))
 
     def dim(self):
         return 5
@@ -832,18 +873,19 @@ class SplitVolume(object):
         return self.var.is_meta
 
     def materialize(self):
-        """The dense (1,D,h,w,C) tensor the reference would build."""
-        D, h, w, _ = self.var.shape
+        """The dense (B,D,h,w,C) tensor the reference would build."""
+        B, D, h, w, _ = self.var.shape
         C = len(self.chan_map)
-        out = _new(self.var, (D, h, w, C))
-        for ch, (kind, i) in enumerate(self.chan_map):
-            if kind == 'v':
-                copy_channels(self.var, out, 1, i, ch)
-            else:
-                src = _new(self.const, (h, w, 1))
-                copy_channels(self.const, src, 1, i, 0)
-                tile_planes(src, out, ch)
-        return out.unsqueeze(0)
+        out = _new(self.var, (B, D, h, w, C))
+        for b in range(B):
+            for ch, (kind, i) in enumerate(self.chan_map):
+                if kind == 'v':
+                    copy_channels(self.var[b], out[b], 1, i, ch)
+                else:
+                    src = _new(self.const, (h, w, 1))
+                    copy_channels(self.const[b], src, 1, i, 0)
+                    tile_planes(src, out[b], ch)
+        return out
 
 
 _fold_cache = {}
@@ -870,12 +912,15 @@ def _fold_split_weights(key, w_host, chan_map, cv, cc):
 
 
 def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
-    """3x3x3 SAME convolution of a SplitVolume: conv3d over the D-varying channels plus the 2-D convolution
-    of the D-constant channels (kd-summed kernel) added per depth plane in the epilogue."""
+    """3x3x3 SAME convolution of a SplitVolume (B samples): conv3d over the D-varying channels plus the 2-D
+    convolution of the D-constant channels (kd-summed kernel) added per depth plane in the epilogue.
+    -> (B,D,h,w,Cout) [, Stats]."""
+    B = sv.var.shape[0]
     cv, cc = sv.var.shape[-1], sv.const.shape[-1]
     wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
-    pb = conv(sv.const, (key, 'planes'), planes, stride=stride)            # (ho, wo, 3*Cout)
-    return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb, out=out, y_coff=y_coff)
+    pb = conv(sv.const, (key, 'planes'), planes, stride=stride, groups=B)            # (B, ho, wo, 3*Cout)
+    return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb, out=out, y_coff=y_coff,
+                groups=B)
 
 
 def siblings_ok(shape, cin, cout, cout2):
@@ -893,40 +938,43 @@ def use_siblings(flag):
     _USE_SIBLINGS = bool(flag)
 
 
-def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None):
+def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None, groups=None):
     """The U-Net's two convolutions of one input in ONE launch: y = conv3x3x3(x, w) (8 channels, stride 1) and
     y2 = conv3x3x3(x, w2) (16 channels, stride 2, SAME), each with the partial moments of its output.
-    x (D,H,W,Cin), Cin % 8 == 0.  Returns (y, Stats), (y2, Stats)."""
-    D, H, W, cin = x.shape
-    if not siblings_ok((D, H, W), cin, int(w_host.shape[-1]), int(w2_host.shape[-1])):
+    x (D,H,W,Cin) (groups=G: (G,D,H,W,Cin)), Cin % 8 == 0.  Returns (y, Stats), (y2, Stats)."""
+    x5, nsp = _to5(x, groups, 'conv_siblings input')
+    G, D, H, W, cin = x5.shape
+    if nsp != 3 or not siblings_ok((D, H, W), cin, int(w_host.shape[-1]), int(w2_host.shape[-1])):
         raise ValueError('conv_siblings: unsupported shapes')
     pk = pack_conv_xp(key, w_host, x.device)
     pk2 = pack_conv_xp_sibling(key2, w2_host, x.device)
     if pk.cin != cin or pk2.cin != cin:
         raise ValueError('conv_siblings %s: input has %d channels' % (key, cin))
     D2, H2, W2 = (D + 1) // 2, (H + 1) // 2, (W + 1) // 2
-    y, y2 = _new(x, (D, H, W, 8)), _new(x, (D2, H2, W2, 16))
-    blocks = xp_blocks(D, H, W)
-    sbuf, sbuf2 = _stats_buffer(x, blocks, 16), _stats_buffer(x, blocks, 16)
+    lead = () if groups is None else (G,)
+    y, y2 = _new(x, lead + (D, H, W, 8)), _new(x, lead + (D2, H2, W2, 16))
+    blocks = xp_blocks(D, H, W, G)
+    sbuf, sbuf2 = _stats_buffer(x, blocks, 16, groups=G), _stats_buffer(x, blocks, 16, groups=G)
     st, st2 = Stats(), Stats()
-    st.partial, st.blocks, st.cpad, st.count = sbuf, blocks, 16, D * H * W
-    st2.partial, st2.blocks, st2.cpad, st2.count = sbuf2, blocks, 16, D2 * H2 * W2
-    if plane_bias is not None and tuple(plane_bias.shape) != (H, W, 24):
+    st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 16, D * H * W, G
+    st2.partial, st2.blocks, st2.cpad, st2.count, st2.groups = sbuf2, blocks, 16, D2 * H2 * W2, G
+    if plane_bias is not None and tuple(plane_bias.shape) != lead + (H, W, 24):
         raise ValueError('conv_siblings %s: plane_bias %s' % (key, tuple(plane_bias.shape)))
-    if plane_bias2 is not None and tuple(plane_bias2.shape) != (H2, W2, 48):
+    if plane_bias2 is not None and tuple(plane_bias2.shape) != lead + (H2, W2, 48):
         raise ValueError('conv_siblings %s: plane_bias2 %s' % (key2, tuple(plane_bias2.shape)))
-    conv_xp_launch(x, pk, y, 0, None, False, sbuf, plane_bias, sibling=(pk2, y2, 0, sbuf2, plane_bias2))
+    conv_xp_launch(x5, pk, y, 0, None, False, sbuf, plane_bias, sibling=(pk2, y2, 0, sbuf2, plane_bias2))
     return (y, st), (y2, st2)
 
 
 def conv_split_siblings(sv, key, w_host, key2, w2_host):
-    """conv_siblings over a SplitVolume: the D-constant channels enter both outputs as depth-plane biases."""
+    """conv_siblings over a SplitVolume (B samples): the D-constant channels enter both outputs as depth-plane biases."""
+    B = sv.var.shape[0]
     cv, cc = sv.var.shape[-1], sv.const.shape[-1]
     wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
     wv2, planes2 = _fold_split_weights(key2, w2_host, sv.chan_map, cv, cc)
-    pb = conv(sv.const, (key, 'planes'), planes, stride=1)
-    pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2)
-    return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2)
+    pb = conv(sv.const, (key, 'planes'), planes, stride=1, groups=B)
+    pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2, groups=B)
+    return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B)
 
 
 _DECONV_OFFSETS = [(a, b, c) for a in (0, -1) for b in (0, -1) for c in (0, -1)]
@@ -956,15 +1004,18 @@ def _deconv_virtual_kernel(key, w_host):
     return hit
 
 
-def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
-    """tf.layers.conv3d_transpose(3, stride 2, SAME): (D,H,W,Cin) -> (2D,2H,2W,Cout).
+def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=None):
+    """tf.layers.conv3d_transpose(3, stride 2, SAME): (D,H,W,Cin) -> (2D,2H,2W,Cout) (groups=G: G samples).
 
     w_host: TF layout [3,3,3,Cout,Cin].  LDS-tiled path: all 8 output parity classes from one staged
     input tile per workgroup (N axis = class x channel); fallback: one gather launch per class.
     """
-    D, H, W, Cin = x.shape
+    x5, nsp = _to5(x, groups, 'conv3d_transpose input')
+    G, D, H, W, Cin = x5.shape
     cout = int(w_host.shape[-2])
-    y = _new(x, (2 * D, 2 * H, 2 * W, cout))
+    lead = () if groups is None else (G,)
+    y = _new(x, lead + (2 * D, 2 * H, 2 * W, cout))
+    y5 = y.reshape((G, 2 * D, 2 * H, 2 * W, cout))
     M = D * H * W
     classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
     fused = _FORCE_IMPL != 'gather' and cout % 4 == 0 and cout <= 64 and (W >= 12 or _FORCE_IMPL == 'tiled')
@@ -976,40 +1027,57 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False):
         while nt * 16 < per * cout:
             nt *= 2
         tile_y = 8 if (nt <= 2 and H >= 16) else 4
-        blocks = tiled_blocks(D, H, W, tile_y, Cin, per * cout)
+        blocks = tiled_blocks(D, H, W, tile_y, Cin, per * cout, groups=G)
         nl = 8 // per
-        in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(D, H, W, tile_y, Cin, per * cout))
-        st, sbuf = None, None
+        in_kernel = bool(_lib.lib().atvs_conv_tiled_has_stats(D, H, W, tile_y, Cin, per * cout, G))
+        st, sbufs = None, None
         if want_stats and in_kernel:
-            sbuf = _stats_buffer(x, blocks * nl, nt * 16)
+            # one statistics buffer per launch (class group), each (G, blocks, 2, cpad); bn_finalize folds the
+            # launches' columns through `fold` on a buffer laid out (G, nl * blocks, 2, cpad)
+            sall = torch.empty((G, nl * blocks, 2, nt * 16), dtype=torch.float64, device=x.device)
             st = Stats()
-            st.partial, st.blocks, st.cpad, st.count, st.fold = sbuf, blocks * nl, nt * 16, 8 * M, per
+            st.partial, st.blocks, st.cpad, st.count, st.fold, st.groups = sall, blocks * nl, nt * 16, 8 * M, per, G
+            sbufs = [_stats_buffer(x, blocks, nt * 16, groups=G) for _ in range(nl)] if (nl > 1 and G > 1) else None
         fin = None
-        if st is not None and _FUSED_FINALIZE and cout <= 64 and not x.is_meta:
+        if st is not None and _FUSED_FINALIZE and cout <= 64 and not x.is_meta and G == 1:
             fin = Fin()
-            fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, cout)), sbuf
+            fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, cout)), st.partial
             fin.rows, fin.arrivals, fin.channels, fin.fold, fin.count = blocks * nl, blocks * nl, cout, per, 8 * M
             st.params = fin.params
         for i in range(nl):
             wpart = wv[:, :, i * per * cout:(i + 1) * per * cout]
             pk = pack_conv_weights_tiled((key, 'cls', i), wpart, taps, False, x.device, tile_y)
-            sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
-            conv_tiled_launch(x, pk, y, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per, fin=fin)
+            sb = None
+            if st is not None:
+                if sbufs is not None:
+                    sb = sbufs[i]
+                else:          # G == 1 or a single launch: the launch's rows are a contiguous slice
+                    sb = st.partial.reshape(-1, 2, nt * 16)[i * blocks:(i + 1) * blocks] if G == 1 else st.partial
+            conv_tiled_launch(x5, pk, y5, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per, fin=fin)
+        if sbufs is not None:
+            for i in range(nl):
+                st.partial[:, i * blocks:(i + 1) * blocks].copy_(sbufs[i])
         if want_stats and not in_kernel:
-            st = channel_stats(y)
+            st = channel_stats(y, groups)
         return (y, st) if want_stats else y
     pks = [pack_conv_weights(key, w_host, deconv_s2_class_taps(par), True, x.device) for par in classes]
-    blocks, tm = conv_blocks(M, pks[0].ntiles)
+    blocks, tm = conv_blocks(M, pks[0].ntiles, groups=G)
     cpad = pks[0].ntiles * 16
     st = None
-    sbuf = None
+    sbufs = None
     if want_stats:
-        sbuf = _stats_buffer(x, blocks * 8, cpad)
         st = Stats()
-        st.partial, st.blocks, st.cpad, st.count = sbuf, blocks * 8, cpad, 8 * M
+        st.partial = torch.empty((G, blocks * 8, 2, cpad), dtype=torch.float64, device=x.device)
+        st.blocks, st.cpad, st.count, st.groups = blocks * 8, cpad, 8 * M, G
+        sbufs = [_stats_buffer(x, blocks, cpad, groups=G) for _ in range(8)] if G > 1 else None
     for i, (par, pk) in enumerate(zip(classes, pks)):
-        sb = sbuf[i * blocks:(i + 1) * blocks] if sbuf is not None else None
-        conv_launch(x, pk, y, (D, H, W), 1, 2, par, 0, None, None, relu, sb, tm)
+        sb = None
+        if st is not None:
+            sb = sbufs[i] if sbufs is not None else st.partial.reshape(-1, 2, cpad)[i * blocks:(i + 1) * blocks]
+        conv_launch(x5, pk, y5, (D, H, W), 1, 2, par, 0, None, None, relu, sb, tm)
+    if sbufs is not None:
+        for i in range(8):
+            st.partial[:, i * blocks:(i + 1) * blocks].copy_(sbufs[i])
     return (y, st) if want_stats else y
 
 
@@ -1075,7 +1143,8 @@ class PendingBN(object):
     """A raw convolution output whose training-mode batch norm (+ ReLU) has not been applied yet.
 
     Layers whose only consumers are `add`s never need the normalised tensor on its own: the add kernel
-    normalises on the fly (ops.bn_add).  Any other consumer calls materialize()."""
+    normalises on the fly (ops.bn_add).  Any other consumer calls materialize().  raw is batch-first
+    (B, ..., C); params (3,C), or (B,3,C) for B independent samples."""
 
     def __init__(self, raw, params, relu):
         self.raw, self.params, self.relu = raw, params, bool(relu)
@@ -1084,19 +1153,19 @@ class PendingBN(object):
 
     @property
     def shape(self):
-        return (1,) + tuple(self.raw.shape)
+        return tuple(self.raw.shape)
 
     def dim(self):
-        return self.raw.dim() + 1
+        return self.raw.dim()
 
     @property
     def is_meta(self):
         return self.raw.is_meta
 
     def materialize(self):
-        """The (1, ...) normalised tensor (computed once, in place on the raw buffer)."""
+        """The normalised tensor (computed once, in place on the raw buffer)."""
         if self._final is None:
-            self._final = bn_apply(self.raw, self.params, self.relu).unsqueeze(0)
+            self._final = bn_apply(self.raw, self.params, self.relu)
         return self._final
 
 
@@ -1109,7 +1178,7 @@ def bn_add(items):
             ps.append(it.params)
             mask |= (1 << i) if it.relu else 0
         else:
-            t = it.materialize()[0] if isinstance(it, PendingBN) else it
+            t = it.materialize() if isinstance(it, PendingBN) else it
             xs.append(t)
             ps.append(None)
     C = xs[0].shape[-1]
@@ -1125,39 +1194,46 @@ def bn_add(items):
     return out
 
 
-def add_n(tensors):
-    """tf.add_n: ((a + b) + c) + ..."""
+def add_n(tensors, out=None):
+    """tf.add_n: ((a + b) + c) + ...; out: optional destination of the final sum (same shape, may not alias)."""
     acc = tensors[0]
     i = 1
     first = True
     while i < len(tensors):
         b = tensors[i]
         c = tensors[i + 1] if (first and i + 1 < len(tensors)) else None
-        out = _new(acc, acc.shape)
-        if _dev_ok(acc, b, c):
-            _call('atvs_add_n', _p(acc), _p(b), _p(c), _p(out), ctypes.c_long(acc.numel()), _stream())
-        acc = out
-        i += 2 if c is not None else 1
+        step = 2 if c is not None else 1
+        dst = out if (out is not None and i + step >= len(tensors)) else _new(acc, acc.shape)
+        if _dev_ok(acc, b, c, dst):
+            _call('atvs_add_n', _p(acc), _p(b), _p(c), _p(dst), ctypes.c_long(acc.numel()), _stream())
+        acc = dst
+        i += step
         first = False
     return acc
 
 
-def avg_pool_same(x, pool, stride):
-    H, W, C = x.shape
+def avg_pool_same(x, pool, stride, groups=None):
+    """tf.layers.average_pooling2d(SAME) of (H,W,C) (groups=G: (G,H,W,C))."""
+    G = 1 if groups is None else int(groups)
+    H, W, C = x.shape[-3:]
     Ho, Wo = -(-H // stride), -(-W // stride)
-    y = _new(x, (Ho, Wo, C))
-    ws = _new(x, (Ho, Wo, 16, C))
+    lead = () if groups is None else (G,)
+    y = _new(x, lead + (Ho, Wo, C))
+    ws = _new(x, (G, Ho, Wo, 16, C))
     if _dev_ok(x):
-        _call('atvs_avg_pool_same', _p(x), _p(y), _p(ws), H, W, C, int(pool), int(stride), _stream())
+        _call('atvs_avg_pool_same', _p(x), _p(y), _p(ws), G, H, W, C, int(pool), int(stride), _stream())
     return y
 
 
-def resize_bilinear(x, size, out=None, c_off=0):
-    H, W, C = x.shape
+def resize_bilinear(x, size, out=None, c_off=0, groups=None):
+    """align_corners bilinear resize of (H,W,C) (groups=G: (G,H,W,C)) into out[..., c_off:c_off+C]."""
+    G = 1 if groups is None else int(groups)
+    H, W, C = x.shape[-3:]
     Ho, Wo = int(size[0]), int(size[1])
-    y = _new(x, (Ho, Wo, C)) if out is None else out
+    lead = () if groups is None else (G,)
+    y = _new(x, lead + (Ho, Wo, C)) if out is None else out
     if _dev_ok(x, y):
-        _call('atvs_resize_bilinear', _p(x), _p(y), H, W, C, Ho, Wo, y.shape[-1], int(c_off), _stream())
+        _call('atvs_resize_bilinear', _p(x), _p(y), G, H, W, C, Ho, Wo, y.shape[-1], int(c_off), _stream())
     return y
 
 

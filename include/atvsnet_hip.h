@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 3
+#define ATVS_ABI_VERSION 4
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -103,9 +103,9 @@ int atvs_absdiff_mask(const float* a, const float* b, const float* mask, float* 
  * Soft-argmin  (atvsnet/model.py)
  * ------------------------------------------------------------------------- */
 
-/* prob2depth, model.py:80-109: cost (D,h,w) -> depth (h,w). */
+/* prob2depth, model.py:80-109: cost (groups,D,h,w) -> depth (groups,h,w); the volumes of a launch share the depth sweep. */
 int atvs_softargmin(const float* cost, const float* depth_start, const float* depth_interval,
-                    float* depth_out, int D, int h, int w, atvs_stream_t stream);
+                    float* depth_out, int groups, int D, int h, int w, atvs_stream_t stream);
 
 /* upsample_prob_vol + prob2depth, model.py:68-76,121-127: cost (D,h,w) ->
  * depth (h*up, w*up) without materialising the upsampled volume. */
@@ -164,10 +164,13 @@ long atvs_conv_num_blocks(long M, int tile_m);
  *   stats_partial: NULL, or [atvs_conv_num_blocks][2][16*ntiles] doubles receiving
  *   per-workgroup (sum, sum of squares) of the values written, per channel, for
  *   training-mode batch norm (network.py:206-212).  tile_m in {1,2,4,8},
- *   tile_m * ntiles <= 16. */
+ *   tile_m * ntiles <= 16.
+ *   groups >= 1: x, y, residual and plane_bias are `groups` independent samples stacked on a leading axis (one
+ *   network call each in the reference); a workgroup never spans samples and stats_partial has
+ *   groups * atvs_conv_num_blocks rows, sample-major (atvs_bn_finalize reduces them per sample). */
 int atvs_conv_mfma_f32(const float* x, const float* packed_w, const int32_t* group_table, const float* bias,
                        const float* residual, const float* plane_bias, int pad_z, float* y,
-                       double* stats_partial, int Di, int Hi, int Wi,
+                       double* stats_partial, int groups, int Di, int Hi, int Wi,
                        int Cin, int Do, int Ho, int Wo, int in_stride, int Dy, int Hy, int Wy,
                        int out_stride, int off_z, int off_y, int off_x, int ldy, int y_coff, int Cout,
                        int ntaps, int tile_m, int relu, atvs_stream_t stream);
@@ -206,12 +209,15 @@ int atvs_conv_tiled_pack_size(int ntaps, int Cin, int Cout, int* nchunk, int* ch
                               int* ntiles, long* packed_floats, long* table_ints);
 int atvs_conv_tiled_pack(const float* w, int w_transposed, const int32_t* taps, int ntaps, int Cin, int Cout,
                          int tile_y, int xpair, float* packed, int32_t* table);
-long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair);
-long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int* nsplit_out);
-int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout);
+/* groups >= 1 independent samples stacked on the leading axis of x / y / residual / plane_bias: the persistent grid is
+ * shared out among the samples (atvs_conv_tiled_num_blocks / _grid return the workgroups PER SAMPLE; stats_partial has
+ * groups times that many rows, sample-major); the in-launch finalize needs groups == 1. */
+long atvs_conv_tiled_num_blocks(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int groups);
+long atvs_conv_tiled_grid(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int xpair, int groups, int* nsplit_out);
+int atvs_conv_tiled_has_stats(int Do, int Ho, int Wo, int tile_y, int Cin, int Cout, int groups);
 int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* table, const float* bias,
                         const float* residual, const float* plane_bias, float* y, double* stats_partial,
-                        int D, int H, int W, int Cin,
+                        int groups, int D, int H, int W, int Cin,
                         int Dy, int Hy, int Wy, int out_stride, int off_z, int off_y, int off_x, int ldy,
                         int y_coff, int Cout, int ntaps, int tile_y, int relu, int class_cout, int class_base,
                         int xpair, uint32_t* fin_counter, float* fin_params, double* fin_stats, int fin_rows,
@@ -235,9 +241,10 @@ int atvs_conv_xp_pack_size(int Cin, long* packed_floats);
 int atvs_conv_xp_pack(const float* w, int Cin, float* packed);
 int atvs_conv_xp_pack_sibling_size(int Cin, long* packed_floats);
 int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed);
-long atvs_conv_xp_grid(int D, int H, int W);
+/* groups >= 1 independent samples stacked on the leading axis of every tensor; atvs_conv_xp_grid = workgroups PER SAMPLE. */
+long atvs_conv_xp_grid(int D, int H, int W, int groups);
 int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias, float* y,
-                     double* stats_partial, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                     double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, atvs_stream_t stream);
 
@@ -264,7 +271,7 @@ int atvs_conv2d_lds_f32(const float* x, const float* packed_w, const float* bias
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,
  * 242,336).  x (D,H,W,8); w = the TF kernel [3,3,3,8,1] (216 floats, device); y (D,H,W).
  * HBM-bound (one output channel): FMA kernel, not MFMA. */
-int atvs_conv3d_8to1(const float* x, const float* w, float* y, int D, int H, int W, atvs_stream_t stream);
+int atvs_conv3d_8to1(const float* x, const float* w, float* y, int groups, int D, int H, int W, atvs_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * Batch norm with batch statistics, element-wise glue  (cnn_wrapper/network.py)
@@ -302,16 +309,16 @@ int atvs_bn_add(const float* x0, const float* params0, const float* x1, const fl
 int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream);
 
 /* tf.layers.average_pooling2d(padding='SAME'), network.py:665-671: x (H,W,C) ->
- * y (ceil(H/stride), ceil(W/stride), C), mean over the valid window elements.
- * ws: atvs_avg_pool_ws_floats(H, W, C, stride) floats of scratch. */
+ * y (ceil(H/stride), ceil(W/stride), C), mean over the valid window elements; `groups` images per launch.
+ * ws: groups * atvs_avg_pool_ws_floats(H, W, C, stride) floats of scratch. */
 long atvs_avg_pool_ws_floats(int H, int W, int C, int stride);
-int atvs_avg_pool_same(const float* x, float* y, float* ws, int H, int W, int C, int pool, int stride,
+int atvs_avg_pool_same(const float* x, float* y, float* ws, int groups, int H, int W, int C, int pool, int stride,
                        atvs_stream_t stream);
 
 /* tf.image.resize_images(BILINEAR, align_corners=True), network.py:649-655:
  * x (H,W,C) -> y (Ho,Wo,ld_out)[..., c_off:c_off+C]. */
-int atvs_resize_bilinear(const float* x, float* y, int H, int W, int C, int Ho, int Wo, int ld_out, int c_off,
-                         atvs_stream_t stream);
+int atvs_resize_bilinear(const float* x, float* y, int groups, int H, int W, int C, int Ho, int Wo, int ld_out,
+                         int c_off, atvs_stream_t stream);
 
 /* tf.concat along channels / un-stacking a trailing axis, network.py:691-693:
  * dst[r, dst_off + c] = src[r, src_off + c], c < C. */

@@ -60,7 +60,7 @@ def test_conv3d_same(cuda, impl, D, H, W, Cin, Cout, stride):
     assert tuple(got.shape) == tuple(want.shape)
     _close(got.cpu(), want)
     # statistics epilogue: per-channel sum / sum of squares of what was written
-    s = st.partial.sum(0).cpu()
+    s = st.partial.reshape(-1, 2, st.cpad).sum(0).cpu()
     _close(s[0, :Cout].float(), want.reshape(-1, Cout).double().sum(0).float(), 1e-5)
     _close(s[1, :Cout].float(), (want.reshape(-1, Cout).double() ** 2).sum(0).float(), 1e-5)
 
@@ -73,9 +73,9 @@ def test_conv3d_tile_variants(cuda, tile_m):
     want = T.conv(x, w, 1, 'SAME')[0]
     taps = ops.conv_taps((3, 3, 3), 1, (1, 1, 1))
     pk = ops.pack_conv_weights(('tv', tile_m), w.numpy(), taps, False, cuda)
-    y = torch.empty(6, 9, 21, 16, device=cuda)
-    ops.conv_launch(x[0].to(cuda), pk, y, (6, 9, 21), 1, 1, (0, 0, 0), 0, tile_m=tile_m)
-    _close(y.cpu(), want)
+    y = torch.empty(1, 6, 9, 21, 16, device=cuda)
+    ops.conv_launch(x.to(cuda), pk, y, (6, 9, 21), 1, 1, (0, 0, 0), 0, tile_m=tile_m)      # (G,D,H,W,C) operands
+    _close(y[0].cpu(), want)
 
 
 CONV2D = [
@@ -129,7 +129,7 @@ def test_conv3d_transpose(cuda, impl, D, H, W, Cin, Cout):
     got, st = ops.conv3d_transpose_s2(x[0].to(cuda), ('dc', D, H, W, Cin, Cout), w.numpy(), want_stats=True)
     assert tuple(got.shape) == (2 * D, 2 * H, 2 * W, Cout)
     _close(got.cpu(), want)
-    s = st.partial.sum(0).cpu()
+    s = st.partial.reshape(-1, 2, st.cpad).sum(0).cpu()
     folded = s[:, :st.fold * Cout].reshape(2, st.fold, Cout).sum(1)     # (class, channel) columns fold onto the channel
     _close(folded[0].float(), want.reshape(-1, Cout).double().sum(0).float(), 1e-5)
     _close(folded[1].float(), (want.reshape(-1, Cout).double() ** 2).sum(0).float(), 1e-5)
@@ -240,7 +240,7 @@ def test_split_volume_conv_matches_dense(cuda, impl, stride):
     assert torch.equal(sv.materialize().cpu()[0], dense)
     got, st = ops.conv_split(sv, ('split', stride), wgt.numpy(), stride=stride, want_stats=True)
     _close(got.cpu(), want)
-    s = st.partial.sum(0).cpu()
+    s = st.partial.reshape(-1, 2, st.cpad).sum(0).cpu()
     _close(s[0, :8].float(), want.reshape(-1, 8).double().sum(0).float(), 1e-5)
 
 
@@ -270,7 +270,7 @@ def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
         w1 = torch.clamp(want, min=0)
         _close(out.cpu()[..., 4:12], w1)
         assert float((out.cpu()[..., :4] + 7.0).abs().max()) == 0.0 and float((out.cpu()[..., 12:] + 7.0).abs().max()) == 0.0
-        s = st.partial.sum(0).cpu()
+        s = st.partial.reshape(-1, 2, st.cpad).sum(0).cpu()
         _close(s[0, :8].float(), w1.reshape(-1, 8).double().sum(0).float(), 1e-5)
         _close(s[1, :8].float(), (w1.reshape(-1, 8).double() ** 2).sum(0).float(), 1e-5)
         # 2. residual, no ReLU, dense output
@@ -310,7 +310,7 @@ def test_conv_siblings_one_launch(cuda, D, H, W, Cin):
     _close(y.cpu(), want)
     _close(y2.cpu(), want2)
     for got_st, ref, C in ((st, want, 8), (st2, want2, 16)):
-        s = got_st.partial.sum(0).cpu()
+        s = got_st.partial.reshape(-1, 2, got_st.cpad).sum(0).cpu()
         _close(s[0, :C].float(), ref.reshape(-1, C).double().sum(0).float(), 1e-5)
         _close(s[1, :C].float(), (ref.reshape(-1, C).double() ** 2).sum(0).float(), 1e-5)
         assert got_st.count == ref.shape[0] * ref.shape[1] * ref.shape[2]

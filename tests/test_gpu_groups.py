@@ -1,0 +1,108 @@
+"""-m gpu: several independent network calls in ONE launch (the `groups` axis of the C-ABI, DESIGN.md "batched
+evaluation").  The reference evaluates every network with batch 1 and per-call batch statistics (quirk C1); stacking
+the calls of a depth map (views, siamese directions) on a leading axis must give the values of the separate calls:
+the convolution outputs bit for bit (a workgroup never spans samples, same accumulation order), the batch-norm
+moments to double-precision rounding (the partial sums are grouped differently)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+@pytest.mark.parametrize('shape,cin,cout,stride,kind', [
+    ((16, 32, 48), 16, 16, 1, 'tiled'), ((12, 16, 24), 32, 32, 1, 'tiled'), ((6, 8, 12), 64, 64, 1, 'tiled/small'),
+    ((16, 32, 48), 8, 8, 1, 'x-pair'), ((16, 32, 48), 16, 32, 2, 'gather s2'), ((16, 32, 48), 8, 16, 1, 'aanet 8->16'),
+    ((16, 32, 48), 1, 8, 1, 'stem')])
+def test_conv3d_groups_equal_separate_calls(cuda, shape, cin, cout, stride, kind):
+    from atvsnet_amd import ops
+    G = 3
+    x = _rand((G,) + shape + (cin,), 5).to(cuda)
+    w = (_rand((3, 3, 3, cin, cout), 6) * 0.1).numpy()
+    yb, stb = ops.conv(x, ('g', kind, cin, cout), w, stride=stride, want_stats=True, groups=G)
+    pb = ops.bn_params(stb, cout, yb)
+    assert tuple(pb.shape) == (G, 3, cout)
+    for g in range(G):
+        y1, st1 = ops.conv(x[g], ('g', kind, cin, cout), w, stride=stride, want_stats=True)
+        assert torch.equal(yb[g], y1), kind
+        p1 = ops.bn_params(st1, cout, y1)
+        assert float((pb[g] - p1).abs().max()) <= 1e-6 * float(p1.abs().max()), kind
+    # batch norm (+ReLU) of the stacked tensor with per-sample parameters
+    zb = ops.bn_apply(yb.clone(), pb, True)
+    for g in range(G):
+        z1 = ops.bn_apply(yb[g].clone(), pb[g].contiguous(), True)
+        assert torch.equal(zb[g], z1)
+
+
+def test_siblings_deconv_head_groups(cuda):
+    from atvsnet_amd import ops
+    G = 2
+    x = _rand((G, 16, 32, 48, 16), 9).to(cuda)
+    w8 = (_rand((3, 3, 3, 16, 8), 1) * 0.1).numpy()
+    w16 = (_rand((3, 3, 3, 16, 16), 2) * 0.1).numpy()
+    pb = _rand((G, 32, 48, 24), 3).to(cuda)
+    pb2 = _rand((G, 16, 24, 48), 4).to(cuda)
+    (y, st), (y2, st2) = ops.conv_siblings(x, 'sa', w8, 'sb', w16, plane_bias=pb, plane_bias2=pb2, groups=G)
+    for g in range(G):
+        (a, sa), (b, sb) = ops.conv_siblings(x[g], 'sa', w8, 'sb', w16, plane_bias=pb[g].contiguous(),
+                                             plane_bias2=pb2[g].contiguous())
+        assert torch.equal(y[g], a) and torch.equal(y2[g], b)
+        assert float((ops.bn_params(st, 8, y)[g] - ops.bn_params(sa, 8, a)).abs().max()) <= 1e-6
+        assert float((ops.bn_params(st2, 16, y2)[g] - ops.bn_params(sb, 16, b)).abs().max()) <= 1e-6
+    # fused transposed convolution: one launch (16 -> 8) and two launches (64 -> 32)
+    for cin, cout, shp in ((16, 8, (8, 16, 24)), (64, 32, (4, 8, 12))):
+        xd = _rand((G,) + shp + (cin,), 11).to(cuda)
+        wt = (_rand((3, 3, 3, cout, cin), 12) * 0.1).numpy()
+        yd, sd = ops.conv3d_transpose_s2(xd, ('dg', cin), wt, want_stats=True, groups=G)
+        pd = ops.bn_params(sd, cout, yd)
+        for g in range(G):
+            y1, s1 = ops.conv3d_transpose_s2(xd[g], ('dg', cin), wt, want_stats=True)
+            assert torch.equal(yd[g], y1)
+            assert float((pd[g] - ops.bn_params(s1, cout, y1)).abs().max()) <= 1e-6
+    # 8 -> 1 head, soft-argmin
+    x8 = _rand((G, 12, 16, 24, 8), 13).to(cuda)
+    wh = _rand((3, 3, 3, 8, 1), 14).to(cuda)
+    h = ops.conv3d_8to1(x8, wh, groups=G)
+    ds, di = torch.tensor([0.05], device=cuda), torch.tensor([0.01], device=cuda)
+    d = ops.softargmin(h.squeeze(-1).contiguous(), ds, di, groups=G)
+    for g in range(G):
+        h1 = ops.conv3d_8to1(x8[g], wh)
+        assert torch.equal(h[g], h1)
+        assert torch.equal(d[g], ops.softargmin(h1.squeeze(-1).contiguous(), ds, di))
+
+
+def test_tower_batch_equals_separate_towers(cuda, weights):
+    """ResNetDS2SPP over all views at once == one call per view (per-image statistics)."""
+    from atvsnet_amd import synthetic
+    from atvsnet_amd.atvsnet import model
+    imgs, _ = synthetic.make_inputs(3, 128, 160, 32)
+    imgs = torch.from_numpy(imgs).to(cuda)
+    fb = model.feature_extraction_batch(imgs)
+    sb = model.shallow_feature_batch(imgs)
+    for v in range(3):
+        f1 = model.TVSNet_feature_extraction(imgs, v)[0]
+        assert float((fb[v] - f1).abs().max()) <= 2e-5 * float(f1.abs().max())
+        s1 = model.extract_feature_shallow(imgs, 0, v)[1][0]
+        assert float((sb[v] - s1).abs().max()) <= 2e-5 * float(s1.abs().max())
+
+
+@pytest.mark.parametrize('views', [2, 4])
+def test_batched_pipeline_equals_per_view_pipeline(cuda, weights, views):
+    """The whole depth-map pipeline with every network evaluated once over its per-view calls (the default) against the
+    call-per-view order of the reference, config 1 size; also as a HIP graph."""
+    from atvsnet_amd import synthetic
+    from atvsnet_amd.atvsnet import example as ex
+    imgs, cams = synthetic.make_inputs(views, 128, 160, 32)
+    imgs, cams = torch.from_numpy(imgs).to(cuda), torch.from_numpy(cams).to(cuda)
+    run = (lambda b: ex.infer_twoview(imgs, cams, 32, batched=b)) if views == 2 else \
+        (lambda b: ex.infer_multiview(imgs, cams, 32, batched=b, view_streams=False))
+    per_view, batched = run(False), run(True)
+    rel = float(((batched - per_view).abs() / per_view.abs()).mean())
+    print('%d views: batched vs per-view rel-L1 %.3e, max abs %.3e' % (views, rel, float((batched - per_view).abs().max())))
+    assert rel <= 2e-5
+    g = ex.GraphedInference(imgs, cams, 32, batched=True)
+    assert torch.equal(g(), batched)

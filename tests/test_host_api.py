@@ -71,8 +71,22 @@ def test_network_plumbing_and_errors():
 
     with pytest.raises(NotImplementedError):
         Network.setup(net)
-    with pytest.raises(NotImplementedError, match='never uses'):
-        net.lrn
+    # layers off the hot path (reference network.py:218-268, 354-376, 411-508, 619-647, 657-689, 699-775) exist as
+    # thin torch fallbacks with the reference's signatures
+    class OffPath(Network):
+        def setup(self):
+            (self.feed('data').relu(name='r').max_pool(3, 2, name='mp').l2_pool(2, 2, name='lp')
+                 .lrn(2, 1e-4, 0.75, name='n').sigmoid(name='s').nn_softmax(name='sm', axis=-1).l2norm(name='l2')
+                 .reduce_mean([1, 2], name='gap').softmax(name='p').fc(5, name='fc', relu=False).dropout(name='do'))
+            self.feed('r', 'r').multiply(name='m')
+            self.feed('data').deconv(3, 6, 2, name='up').transpose([0, 3, 1, 2], name='t')
+            self.feed('data').expand_dims(-1, name='e').tile([1, 1, 1, 1, 2], name='ti').squeeze(name='sq')
+            self.feed('data').split_separable_conv2d(3, 7, 2, name='sep')
+    o = OffPath({'data': meta(1, 8, 8, 4)}, is_training=False)
+    assert o.get_output_by_name('mp').shape == (1, 4, 4, 4) and o.get_output_by_name('lp').shape == (1, 2, 2, 4)
+    assert o.get_output_by_name('fc').shape == (1, 5) and o.get_output_by_name('up').shape == (1, 16, 16, 6)
+    assert o.get_output_by_name('t').shape == (1, 6, 16, 16) and o.get_output_by_name('sep').shape == (1, 8, 8, 7)
+    assert o.get_output_by_name('ti').shape == (1, 8, 8, 4, 2)
     # feeding another network's layer by [network, name] (reference network.py:98-104)
     class Borrow(Network):
         def setup(self):
