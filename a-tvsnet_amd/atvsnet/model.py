@@ -235,11 +235,13 @@ def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, 
 
 
 def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_start, depth_interval, sources,
-                     shallow, ref_id=0):
+                     shallow, ref_id=0, shallow_index=None):
     """`refinement` of several source views against one reference estimate in ONE pass of the network
     (the reference calls it once per source, example.py:163-172): depth_ref (1,h,w,1), depth_views {source: (1,h,w,1)},
-    prob_vol (1,D,h,w) shared, shallow (N,h,w,16) features of every view -> (cost residuals (S,D,h,w,8),
-    prob residuals (S,D,h,w)), S = len(sources), each sample with its own batch statistics."""
+    prob_vol (1,D,h,w) shared, shallow (N,h,w,16) features of every view (shallow_index: {view id: row of shallow} when
+    it holds a subset) -> (cost residuals (S,D,h,w,8), prob residuals (S,D,h,w)), S = len(sources), each sample with
+    its own batch statistics.  cams are indexed by the view ids themselves."""
+    si = (lambda v: v) if shallow_index is None else (lambda v: shallow_index[v])
     D = int(depth_num)
     S = len(sources)
     ds, di = _scalar(depth_start), _scalar(depth_interval)
@@ -250,7 +252,8 @@ def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_st
         view_cam = cams[:, v]
         hull_cam = view_cam if _hull_view(ref_id) == v else cams[:, _hull_view(ref_id)]
         _refinement_volumes(b, bufs, depth_ref, depth_views[v], cams[:, ref_id], view_cam, hull_cam,
-                            shallow[ref_id:ref_id + 1], shallow[v:v + 1], D, ds, di, depth_start, depth_interval)
+                            shallow[si(ref_id):si(ref_id) + 1], shallow[si(v):si(v) + 1], D, ds, di, depth_start,
+                            depth_interval)
     pv = prob_vol.unsqueeze(-1).expand(S, -1, -1, -1, -1).contiguous() if S > 1 else prob_vol.unsqueeze(-1)
     return _refine_net(bufs, pv, chan, True)
 
@@ -267,29 +270,31 @@ def shallow_feature_batch(images):
                                     independent_samples=True).get_output()
 
 
-def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_interval):
+def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_interval, feature_index=None):
     """build_cost_volume for several (reference view, source view) pairs as ONE SplitVolume of len(pairs) samples:
     features (N,h,w,F) of every view; pair (r, s) sweeps r's frustum and warps s's features into it (the depth range is
-    the given one for every pair -- quirk C11: the reverse direction of a siamese pair uses the reference's too)."""
+    the given one for every pair -- quirk C11: the reverse direction of a siamese pair uses the reference's too).
+    feature_index: {view id: row of `features`} when `features` holds a subset of the views; cams are indexed by view id."""
     D = int(depth_num)
     N, h, w, F = features.shape
     B = len(pairs)
+    fi = (lambda v: v) if feature_index is None else (lambda v: feature_index[v])
     var = torch.empty((B, D, h, w, F), dtype=torch.float32, device=features.device)
     for b, (r, s) in enumerate(pairs):
         Hm = get_homographies(cams[:, r], cams[:, s], depth_num=D, depth_start=depth_start, depth_interval=depth_interval)
-        ops.warp_planes(features[s], Hm[0].contiguous(), out=var[b])
-    const = torch.stack([features[r] for r, _ in pairs], 0) if B > 1 else features[pairs[0][0]:pairs[0][0] + 1]
+        ops.warp_planes(features[fi(s)], Hm[0].contiguous(), out=var[b])
+    const = torch.stack([features[fi(r)] for r, _ in pairs], 0) if B > 1 else features[fi(pairs[0][0]):fi(pairs[0][0]) + 1]
     return ops.SplitVolume(var, const.contiguous(), [('c', i) for i in range(F)] + [('v', i) for i in range(F)])
 
 
-def base_stage_batch(features, cams, depth_num, depth_start, depth_interval, fwd, rev, ref_i=0):
+def base_stage_batch(features, cams, depth_num, depth_start, depth_interval, fwd, rev, ref_i=0, feature_index=None):
     """TVSNet_base_siamese for several source views in ONE pass of the regulariser (the reference runs it per source,
     example.py:144-149): `fwd` = sources whose reference->source direction is wanted (filtered cost volume, probability
     volume, depth), `rev` = sources whose source->reference direction is wanted (depth_view).
     -> (filtered (F,D,h,w,8), prob (F,D,h,w), depth_b2 (F,h,w,1), depth_view {source: (1,h,w,1)})."""
     D = int(depth_num)
     pairs = [(ref_i, v) for v in fwd] + [(v, ref_i) for v in rev]
-    cv = build_cost_volumes(features, cams, pairs, D, depth_start, depth_interval)
+    cv = build_cost_volumes(features, cams, pairs, D, depth_start, depth_interval, feature_index)
     tower = StackedUNet_prob({'data': cv}, is_training=True, reuse=AUTO_REUSE, independent_samples=True)
     del cv
     prob = tower.get_output().squeeze(-1)                        # (B,D,h,w)

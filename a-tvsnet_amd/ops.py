@@ -427,7 +427,7 @@ def conv2d_lds(x, key, w_host, dilation=1, bias=None, residual=None, relu=False,
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, pk.cout, H * W, G
     if _dev_ok(x, y, bias, residual, in_params):
-        with _Timed(pk.key, (G, H, W, cin), pk.cout):
+        with _Timed(pk.key, (1, H, W, cin), pk.cout, G):
             _call('atvs_conv2d_lds_f32', _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)),
                   _p(y), ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, H, W, cin,
                   pk.cout, int(dilation), int(y.shape[-1]), int(y_coff), int(bool(relu)), _stream())
@@ -443,7 +443,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
     sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null     # noqa: E731
     pk2, y2, y_coff2, sbuf2, pb2 = sibling if sibling is not None else (None, None, 0, None, None)
     if _dev_ok(x5, y, bias, plane_bias, y2, pb2):
-        with _Timed(pk.key, x5.shape[1:], pk.cout + (16 if pk2 is not None else 0)):
+        with _Timed(pk.key, x5.shape[1:], pk.cout + (16 if pk2 is not None else 0), G):
             _call('atvs_conv_xp_f32', _p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
                   ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
                   sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _stream())
@@ -523,7 +523,7 @@ def conv_tiled_launch(x5, pk, y, out_stride, out_off, y_coff, tile_y, bias=None,
     G, D, H, W, Cin = x5.shape
     Dy, Hy, Wy, ldy = y.shape[-4:]
     if _dev_ok(x5, y, bias, residual, plane_bias):
-        with _Timed(pk.key, x5.shape[1:], pk.cout):
+        with _Timed(pk.key, x5.shape[1:], pk.cout, G):
             _call('atvs_conv_tiled_f32', _p(x5), _p(pk.wp), ctypes.c_void_p(pk.tab.data_ptr()), _p(bias), _p(residual),
                   _p(plane_bias), _p(y),
                   ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0), G, D, H, W,
@@ -636,7 +636,7 @@ def conv_launch(x5, pk, y, out_grid, in_stride, out_stride, out_off, y_coff, bia
                 ctypes.c_void_p(stats_buf.data_ptr()) if stats_buf is not None else ctypes.c_void_p(0),
                 G, Di, Hi, Wi, Cin, Do, Ho, Wo, int(in_stride), Dy, Hy, Wy, int(out_stride), int(out_off[0]),
                 int(out_off[1]), int(out_off[2]), ldy, int(y_coff), pk.cout, pk.ntaps, tm, int(bool(relu)), _stream()]
-        with _Timed(pk.key, x5.shape[1:], pk.cout):
+        with _Timed(pk.key, x5.shape[1:], pk.cout, G):
             _call('atvs_conv_mfma_f32', *args)
     return tm
 
@@ -652,9 +652,9 @@ def _watched(key):
 class _Timed(object):
     """HIP events around one launch on the launch stream (= torch's current stream), when `key` is watched."""
 
-    def __init__(self, key, shape, cout):
+    def __init__(self, key, shape, cout, groups=1):
         self.on = _watched(key)
-        self.info = (key, tuple(shape), cout)
+        self.info = (key, tuple(shape), cout, int(groups))
 
     def __enter__(self):
         if self.on:
@@ -672,15 +672,16 @@ class _Timed(object):
 def watch(tag):
     """Time launches with HIP events on the launch stream.  tag: a convolution's weight key, ('warp', mode) for
     atvs_warp_planes, a LIST of such keys, or '*' (every convolution launch).  watch(None) stops and returns the
-    durations in ms: a list for one key, {key: list} for a list of keys, [(key, input shape, Cout, ms)] for '*'."""
+    durations in ms: a list for one key, {key: [(ms, samples in the launch)]} for a list of keys,
+    [(key, input shape, Cout, ms)] for '*'."""
     out = None
     if tag is None:
         torch.cuda.synchronize()
         ev, old = _watch['events'], _watch['tag']
         if old == '*':
             out = [(e[2], e[3], e[4], e[0].elapsed_time(e[1])) for e in ev]
-        elif isinstance(old, list):
-            out = {k: [e[0].elapsed_time(e[1]) for e in ev if e[2] == k] for k in old}
+        elif isinstance(old, list):       # per key: (ms, independent samples in the launch)
+            out = {k: [(e[0].elapsed_time(e[1]), e[5]) for e in ev if e[2] == k] for k in old}
         else:
             out = [e[0].elapsed_time(e[1]) for e in ev]
     _watch['tag'] = tag
@@ -1265,9 +1266,10 @@ def _ptr_array(ts):
     return arr
 
 
-def aanet_combine(srs, xs):
-    """srs: list of (V..,16) [S|R] tensors, xs: list of (V..,8) -> sum_n softmax_n(U) X_n, shape of xs[0]."""
-    out = _new(xs[0], xs[0].shape)
+def aanet_combine(srs, xs, out=None):
+    """srs: list of (V..,16) [S|R] tensors, xs: list of (V..,8) -> sum_n softmax_n(U) X_n, shape of xs[0]
+    (written into `out` when given)."""
+    out = _new(xs[0], xs[0].shape) if out is None else out
     if _dev_ok(*(list(srs) + list(xs))):
         _call('atvs_aanet_combine', _ptr_array(srs), _ptr_array(xs), len(xs), _p(out),
               ctypes.c_long(out.numel() // 8), _stream())

@@ -9,8 +9,9 @@ seeded images / cameras / weights, fp32 arithmetic (fp32 MFMA for
 Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: 5 views
 (1 reference + 4 sources) of 640x512, D=192.  cfg2 = two-view 640x512x192, cfg4 = 9 views 928x480x256 (the
 8-source configuration quoted for 8 GPUs), cfg5 = two-view 1600x1184x256.
-On one GPU the step is ONE replay of a HIP graph captured from the pipeline (per-view streams forked and
-joined inside it); --eager issues every launch from Python instead.
+On one GPU the step is ONE replay of a HIP graph captured from the pipeline (every per-view network evaluated once
+over all its calls -- views, siamese directions -- stacked on the batch axis with per-call batch statistics);
+--eager issues every launch from Python instead.
 
 --gpus N > 1: this process touches no GPU; it starts N ranks (one process per GPU, RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), relays rank 0's JSON line and exits non-zero if any rank
@@ -238,7 +239,7 @@ def top_kernels(k=5):
     rows = []
     with open(path) as f:
         for r in csv.DictReader(f):
-            rows.append((r['Name'].split('(')[0].replace('void ', '').replace('(anonymous namespace)::', ''),
+            rows.append((r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0],
                          int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['Percentage'])))
     rows.sort(key=lambda t: -t[3])
     return {'source': KERNEL_STATS_FILE,
@@ -396,11 +397,18 @@ def rank_main(args):
         alg_bytes = 4 * (32 * vox + 8 * vox + (16 * vox2 if sib else 0))
         roof = roof_hbm = None
         if watched.get(DOMINANT):
-            avg_ms = float(np.mean(watched[DOMINANT]))
+            # a launch covers `samples` independent (view, direction) volumes (batched evaluation): the per-volume
+            # figures above times the samples of the launch, over the launch's duration
+            samples = float(np.mean([g for _, g in watched[DOMINANT]]))
+            avg_ms = float(np.mean([ms for ms, _ in watched[DOMINANT]]))
+            flops, alg_bytes = flops * samples, int(alg_bytes * samples)
             ach = flops / (avg_ms * 1e-3) / 1e12
             tr = pmc_traffic(args)
+            if tr:       # the PMC passes were taken on one volume per launch
+                tr = dict(tr, write=int(tr['write'] * samples), fetch_raw=int(tr['fetch_raw'] * samples),
+                          fetch_x2=int(tr['fetch_x2'] * samples))
             roof = {'bound': 'mfma', 'kernel': 'conv_xp_kernel<C4=4,SIB> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full '
-                                              'resolution, + sibling conv_b0_1_0: -> 16, stride 2)',
+                                              'resolution, + sibling conv_b0_1_0: -> 16, stride 2; %d volumes per launch)' % int(samples),
                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     'traffic': (tr['write'] + tr['fetch_x2']) if tr else None,
@@ -411,13 +419,13 @@ def rank_main(args):
                                                 'reports half the bytes of wide coalesced reads, so the true read traffic '
                                                 'lies between fetch_raw and fetch_x2; `traffic` uses write + fetch_x2')
                     if tr else None,
-                    'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[DOMINANT]),
+                    'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[DOMINANT]), 'volumes_per_launch': samples,
                     'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg_bytes}
         if watched.get(WARP):
             # plane-sweep warp of the 32-channel source features into the D-varying half of the cost volume:
             # algorithmic bytes = write D*h*w*32*4 + read h*w*32*4
             wb = 4.0 * 32 * vox + 4.0 * 32 * h * w
-            avg_ms = float(np.mean(watched[WARP]))
+            avg_ms = float(np.mean([ms for ms, _ in watched[WARP]]))
             gbs = wb / (avg_ms * 1e-3) / 1e9
             roof_hbm = {'bound': 'hbm', 'kernel': 'warp_planes_kernel<bilinear, float4> (cost-volume build, 32 channels)',
                         'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
@@ -440,8 +448,8 @@ def rank_main(args):
                        'feature_hw': [h, w], 'voxels': vox, 'parallelism': par, 'world_size': world,
                        'groups': groups if world > 1 else None,
                        'rccl': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
-                       'launch': 'eager' if graphed is None else ('HIP graph replay, per-view streams' if not sharded else
-                                                                   'HIP graphs between the exchanges, per-view streams')},
+                       'launch': 'eager' if graphed is None else ('HIP graph replay, batched per-view networks' if not sharded else
+                                                                   'HIP graphs between the exchanges')},
             'source_views_per_sec': round(n_groups * args.steps * (args.views - 1) / dt, 3),
             'roofline': roof, 'roofline_hbm': roof_hbm, 'kernels': top_kernels(),
         }

@@ -1,9 +1,9 @@
 """CPU: the view-sharded multi-GPU path with world_size 2 on the gloo backend.
 
-The collective composition of a-tvsnet_amd/parallel.py (three all-reduces inside the AANet) is
-run by two processes; the local pieces (8->16 convolution, partial reductions) are supplied by
-the CPU oracle through the `impl` hook (tests only -- the product default is the HIP kernels),
-and the result must equal the single-process oracle AANet over all views."""
+The exchange of a-tvsnet_amd/parallel.py (all-to-all of voxel shards of [S|R|X], combine on the shard, all-gather) is
+run by two / three processes; the local pieces (8->16 convolution, the cross-view softmax on a row range) are
+supplied by the CPU oracle through the `impl` hook (tests only -- the product default is the HIP kernels), and the
+result must equal the single-process oracle AANet over all views."""
 import os
 
 import pytest
@@ -13,33 +13,30 @@ import torch.multiprocessing as mp
 
 
 class OracleAttentionOps(object):
+    """The local pieces of the sharded AANet supplied by the CPU oracle (interface of parallel.HipAttentionOps)."""
+
     def __init__(self, W):
         self.W = W
 
-    def scores(self, xs, scope):
+    def scores(self, x_stack, scope):
         from oracle import tf_ops as T
         ws = self.W['%s/attention_activation/weight_shared' % scope]
         wu = self.W['%s/attention_activation/weight_unique' % scope]
         out = []
-        for x in xs:
+        for x in x_stack:
             s = torch.clamp(T.conv(x[None], ws, 1, 'SAME'), min=0)[0]
             r = torch.clamp(T.conv(x[None], wu, 1, 'SAME'), min=0)[0]
             out.append(torch.cat([s, r], -1))
-        return out
+        return torch.stack(out)
 
-    def partial(self, srs, xs, stage, ssum=None, umax=None):
+    def combine(self, srs, xs, out):
         S = [t[..., :8] for t in srs]
         R = [t[..., 8:] for t in srs]
-        if stage == 0:
-            return sum(S[1:], S[0]).clone()      # fresh buffer: all_reduce works in place
-        U = [(R[i] - S[i]) + ssum for i in range(len(srs))]
-        if stage == 1:
-            return torch.stack(U).max(0).values.contiguous()
-        e = [torch.exp(u - umax) for u in U]
-        return torch.stack([sum(e[1:], e[0]), sum([e[i] * xs[i] for i in range(1, len(xs))], e[0] * xs[0])])
-
-    def divide(self, num, den):
-        return num / den
+        ssum = sum(S[1:], S[0])
+        U = torch.stack([(R[i] - S[i]) + ssum for i in range(len(srs))], -1)
+        p = torch.softmax(U, dim=-1)
+        out.copy_(sum(p[..., i] * xs[i] for i in range(len(xs))))
+        return out
 
 
 def _worker(rank, world, port, nviews, q):
@@ -52,31 +49,33 @@ def _worker(rank, world, port, nviews, q):
         store = variables.VariableStore().init_synthetic(1234)
         W = {k: torch.from_numpy(v) for k, v in store.host.items()}
         g = torch.Generator().manual_seed(5)
-        X = torch.randn(nviews, 6, 8, 10, 8, generator=g)
-        mine = [X[v - 1] for v in parallel.local_views(nviews + 1, rank, world)]
-        out = parallel.sharded_attention(mine, 'attention_aggregate', X[0], impl=OracleAttentionOps(W))
+        X = torch.randn(nviews, 5, 7, 9, 8, generator=g)        # 315 voxels: uneven row shards
+        mine = parallel.local_views(nviews + 1, rank, world)
+        stack = torch.stack([X[v - 1] for v in mine]) if mine else None
+        out = parallel.sharded_attention(stack, mine, nviews + 1, 'attention_aggregate', X[0], impl=OracleAttentionOps(W))
         q.put((rank, out.numpy().copy()))     # plain bytes: the worker may exit before the parent reads
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('nviews', [4, 1, 3])
-def test_sharded_attention_equals_single_process(weights, nviews):
+@pytest.mark.parametrize('nviews,world', [(4, 2), (1, 2), (3, 2), (4, 3), (8, 4)])
+def test_sharded_attention_equals_single_process(weights, nviews, world):
     from oracle import nets
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + nviews
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, nviews, q)) for r in range(2)]
+    port = 29500 + (os.getpid() % 2000) + nviews * 5 + world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, nviews, q)) for r in range(world)]
     for p in procs:
         p.start()
-    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(2))}
+    outs = {r: torch.from_numpy(a) for r, a in (q.get(timeout=120) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     g = torch.Generator().manual_seed(5)
-    X = torch.randn(nviews, 6, 8, 10, 8, generator=g)
+    X = torch.randn(nviews, 5, 7, 9, 8, generator=g)        # 315 voxels: uneven row shards
     want = nets.attention_aggregation(X.permute(1, 2, 3, 4, 0)[None].contiguous(), weights, 'attention_aggregate')[0]
-    assert torch.equal(outs[0], outs[1])                     # every rank ends with the same volume
+    for r in range(1, world):
+        assert torch.equal(outs[0], outs[r])                 # every rank ends with the same volume
     assert float((outs[0] - want).abs().max()) < 1e-5
 
 

@@ -1,4 +1,6 @@
-"""A/B of pipeline variants in ONE process (interleaved rounds): usage: ab.py "<setup A>" "<setup B>" ..."""
+"""A/B of pipeline variants in ONE process (interleaved rounds): usage: ab.py "<setup A>" "<setup B>" ...
+Each setup is python code run before that variant's graph is captured; `kw` (dict) in it sets GraphedInference kwargs,
+e.g.  ab.py "kw=dict(batched=False)" "kw=dict(batched=True)"."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -12,8 +14,9 @@ imgs, cams = synthetic.make_inputs(views, H, W, D)
 imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
 variants = []
 for code in sys.argv[1:]:
-    exec(code)
-    variants.append((code, ex.GraphedInference(imgs, cams, D)))
+    ns = {'ops': ops, 'ex': ex, 'model': model, 'kw': {}}
+    exec(code, ns)
+    variants.append((code, ex.GraphedInference(imgs, cams, D, **ns['kw'])))
 res = {c: [] for c, _ in variants}
 for rnd in range(6):
     for code, g in variants:
