@@ -157,15 +157,10 @@ class CostVolRefineNet(Network):
     def setup(self):
         f = 8
         g = 'global_refine_'
-        stems = []
-        # the four stems write straight into their 8-channel slice of the 32-channel concat
-        self.concat_buffer(g + 'concat', self.layers['prob_vol'], 4 * f)
-        for i, (src, tag) in enumerate((('photo_group', 'photo'), ('geo_group', 'geo'), ('prob_vol', 'prob'),
-                                        ('vis_hull', 'vishull'))):
-            self.feed(src).conv_bn(3, f, 1, name=g + tag + '_3dconv', out_slice=(g + 'concat', i * f))
-            stems.append(g + tag + '_3dconv')
-        (self.feed(*stems)
-             .concat(axis=-1, name=g + 'concat')
+        # the four stems + their concat: one HBM-bound pass over the 32-channel buffer where the inputs allow it
+        # (Network.refine_stems), else conv_bn per stem into its slice of the buffer
+        (self.refine_stems(g + 'concat', [('photo_group', g + 'photo_3dconv'), ('geo_group', g + 'geo_3dconv'),
+                                          ('prob_vol', g + 'prob_3dconv'), ('vis_hull', g + 'vishull_3dconv')], f)
              .conv_bn_siblings(dict(kernel_size=3, filters=f, strides=1, name=g + '3dconv0_1', defer_bn=True),
                                dict(kernel_size=3, filters=f * 2, strides=2, name=g + '3dconv1_0'))
              .conv_bn(3, f * 4, 2, name=g + '3dconv2_0')

@@ -299,6 +299,50 @@ class Network(object):
         self.feed(out_b)
         return self
 
+    def refine_stems(self, concat_name, stems, filters=8):
+        """Extension: the four input stems of CostVolRefineNet (reference cnn_wrapper/atvsnet.py:300-313) and their concat,
+        i.e. exactly  feed(src).conv_bn(3, 8, 1, name=stem) for (src, stem) in `stems`; feed(*stems).concat(-1, concat_name).
+        When the inputs have the form the refinement builds (photo / geo as SplitVolumes with 16 and 2 D-varying
+        channels, 1-channel probability and visual-hull volumes) the geo | prob | vishull stems run as ONE HBM-bound pass
+        that stores whole rows of the 32-channel concat (with the raw photo-stem output passed through), and one dense
+        batch-norm + ReLU pass follows; otherwise the stems are issued one by one.  Registers every stem and the concat
+        under their names; the terminal becomes the concat."""
+        (s_photo, n_photo), (s_geo, n_geo), (s_prob, n_prob), (s_hull, n_hull) = stems
+        photo, geo, prob, hull = (self.layers[k] for k in (s_photo, s_geo, s_prob, s_hull))
+        fused = (self.training and filters == 8 and ops._USE_STEM and ops._FORCE_IMPL is None
+                 and isinstance(photo, ops.SplitVolume) and isinstance(geo, ops.SplitVolume)
+                 and geo.var.shape[-1] == 2 and not isinstance(prob, (ops.SplitVolume, ops.PendingBN))
+                 and not isinstance(hull, (ops.SplitVolume, ops.PendingBN)) and prob.dim() == 5 and hull.dim() == 5
+                 and prob.shape[-1] == 1 and hull.shape[-1] == 1
+                 and (photo.shape[0] == 1 or self.independent_samples))
+        if not fused:
+            self.concat_buffer(concat_name, prob, 4 * filters)
+            names = []
+            for i, (src, name) in enumerate(stems):
+                self.feed(src).conv_bn(3, filters, 1, name=name, out_slice=(concat_name, i * filters))
+                names.append(name)
+            return self.feed(*names).concat(axis=-1, name=concat_name)
+        B = photo.shape[0]
+        vp, vg = '%s/conv3d/kernel' % n_photo, '%s/conv3d/kernel' % n_geo
+        wp = self._kernel(vp, (3, 3, 3, photo.shape[-1], filters))
+        wg = self._kernel(vg, (3, 3, 3, geo.shape[-1], filters))
+        wpr = self._kernel('%s/conv3d/kernel' % n_prob, (3, 3, 3, 1, filters))
+        wh = self._kernel('%s/conv3d/kernel' % n_hull, (3, 3, 3, 1, filters))
+        y_photo, st_photo = ops.conv_split(photo, vp, wp, want_stats=True)                 # dense raw (B,D,h,w,8)
+        wg_var, planes_g = ops._fold_split_weights(vg, wg, geo.chan_map, geo.var.shape[-1], geo.const.shape[-1])
+        pb_geo = ops.conv(geo.const, (vg, 'planes'), planes_g, groups=B)                   # (B,h,w,24)
+        buf, st24 = ops.refine_stems(y_photo, geo.var, pb_geo, self._bt(prob, n_prob), self._bt(hull, n_hull),
+                                     (vg, 'stems'), wg_var, wpr, wh)
+        pshape = (3, 4 * filters) if B == 1 else (B, 3, 4 * filters)
+        params = torch.empty(pshape, dtype=torch.float32, device=buf.device)
+        ops.copy_channels(ops.bn_params(st_photo, filters, buf, None, BN_EPS), params, filters, 0, 0)
+        ops.copy_channels(ops.bn_params(st24, 3 * filters, buf, None, BN_EPS), params, 3 * filters, 0, filters)
+        ops.bn_apply(buf, params, True)
+        for i, name in enumerate((n_photo, n_geo, n_prob, n_hull)):
+            self.layers[name] = buf[..., i * filters:(i + 1) * filters]
+        self.layers[concat_name] = buf
+        return self.feed(buf)
+
     def _slice_out(self, y, out_slice, filters):
         """Layer result: the dense tensor, or (for out_slice) a view of the concat buffer tagged for concat()."""
         if out_slice is None:

@@ -1,0 +1,305 @@
+// 3x3x3 SAME stride-1 convolution of a volume with ONE or TWO channels to eight channels (gfx950): the probability,
+// visual-hull and geometric stems of the refinement network (global_refine_{prob,vishull,geo}_3dconv,
+// /root/reference/cnn_wrapper/atvsnet.py:300-311, layer code cnn_wrapper/network.py:172-215).
+//
+// 2 * 27 * Cin * 8 FLOP per voxel against 4 * Cin B read + 32 B written: HBM-bound by a wide margin (1 channel:
+// 432 FLOP per 36 B).  On the matrix cores 1-2 input channels fill 1/4-1/2 of one K group and the layer ran at 9 TF/s;
+// here it is plain FMAs: a workgroup stages the (8+2) x (8+2) x (32+2) halo of its tile in LDS, a thread owns one
+// (y, x) column of 8 voxels with all their accumulators in registers and walks the 27 taps in the OUTER loop, so that a
+// tap's weights -- wave-uniform scalar registers -- are loaded once and serve the whole column.  Epilogue as in the MFMA kernels: depth-plane bias (the D-constant channels
+// of the geometric stem), ReLU, channel-last stores into a slice of the concat buffer, per-workgroup batch-norm moments.
+#include "conv_common.h"
+
+namespace {
+
+constexpr int ST_TZ = 4, ST_TY = 8, ST_TX = 32;
+constexpr int ST_HZ = ST_TZ + 2, ST_HY = ST_TY + 2, ST_HX = ST_TX + 2;
+
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ pbias, float* __restrict__ y,
+                                                        double* __restrict__ stats, int D, int H, int W, int ldy, int ycoff,
+                                                        int relu, int tiles_y, int tiles_x, int tiles) {
+  __shared__ float tile[ST_HZ * ST_HY * ST_HX * CIN];
+  __shared__ double s_red[4][2][8];
+  const int tid = threadIdx.x;
+  const int grp = blockIdx.x / tiles, t = blockIdx.x - grp * tiles;
+  const int x0 = (t % tiles_x) * ST_TX, y0 = ((t / tiles_x) % tiles_y) * ST_TY, z0 = (t / (tiles_x * tiles_y)) * ST_TZ;
+  const size_t vol = (size_t)D * H * W;
+  const float* xg = x + (size_t)grp * vol * CIN;
+  for (int s = tid; s < ST_HZ * ST_HY * ST_HX * CIN; s += 256) {
+    const int c = s % CIN, v = s / CIN;
+    const int xx = v % ST_HX, yy = (v / ST_HX) % ST_HY, zz = v / (ST_HX * ST_HY);
+    const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+    float val = 0.f;
+    if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
+      val = xg[(((size_t)gz * H + gy) * W + gx) * CIN + c];
+    tile[s] = val;
+  }
+  __syncthreads();
+  const int lx = tid & 31, ly = tid >> 5;
+  const int xo = x0 + lx, yo = y0 + ly;
+  const bool col_ok = xo < W && yo < H;
+  // tap-outer, z-inner: the 8 * CIN weights of a tap are wave-uniform (scalar registers) and serve the thread's
+  // whole column of ST_TZ voxels
+  float acc[ST_TZ][8];
+#pragma unroll
+  for (int z = 0; z < ST_TZ; ++z)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[z][k] = 0.f;
+#pragma unroll 1
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll 1
+    for (int j = 0; j < 9; ++j) {
+      const float* wk = w + ((kd * 9 + j) * CIN) * 8;           // uniform address: scalar loads
+      float wr[CIN][8];
+#pragma unroll
+      for (int c = 0; c < CIN; ++c)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) wr[c][k] = wk[c * 8 + k];
+#pragma unroll
+      for (int z = 0; z < ST_TZ; ++z) {
+        const float* src = tile + (((z + kd) * ST_HY + ly + j / 3) * ST_HX + lx + j % 3) * CIN;
+#pragma unroll
+        for (int c = 0; c < CIN; ++c) {
+          const float v = src[c];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) acc[z][k] = fmaf(v, wr[c][k], acc[z][k]);
+        }
+      }
+    }
+  float ssum[8], ssq[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) ssum[k] = ssq[k] = 0.f;
+  float* yg = y + (size_t)grp * vol * ldy;
+  const float* pbg = pbias ? pbias + (size_t)grp * H * W * 24 : nullptr;
+#pragma unroll
+  for (int z = 0; z < ST_TZ; ++z) {
+    const int zo = z0 + z;
+    if (!col_ok || zo >= D) continue;
+    float* a8 = acc[z];
+    if (pbg) {
+      const float* pb = pbg + ((size_t)yo * W + xo) * 24 + plane_variant(zo - 1, D) * 8;
+      const float4 b0 = ld4(pb), b1 = ld4(pb + 4);
+      a8[0] += b0.x; a8[1] += b0.y; a8[2] += b0.z; a8[3] += b0.w;
+      a8[4] += b1.x; a8[5] += b1.y; a8[6] += b1.z; a8[7] += b1.w;
+    }
+    if (relu) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a8[k] = fmaxf(a8[k], 0.f);
+    }
+    float* dst = yg + (((size_t)zo * H + yo) * W + xo) * ldy + ycoff;
+    st4(dst, make_float4(a8[0], a8[1], a8[2], a8[3]));
+    st4(dst + 4, make_float4(a8[4], a8[5], a8[6], a8[7]));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      ssum[k] += a8[k];
+      ssq[k] += a8[k] * a8[k];
+    }
+  }
+  if (stats) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      double a = (double)ssum[k], b = (double)ssq[k];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+      }
+      if (lane == 0) {
+        s_red[wave][0][k] = a;
+        s_red[wave][1][k] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {                      // row [2][16]: columns 0..7 = channels, 8..15 = 0 (the x-pair kernels' layout)
+      const int which = tid >> 4, col = tid & 15;
+      double v = 0.0;
+      if (col < 8) v = (s_red[0][which][col] + s_red[1][which][col]) + (s_red[2][which][col] + s_red[3][which][col]);
+      stats[((size_t)blockIdx.x * 2 + which) * 16 + col] = v;
+    }
+  }
+}
+
+// ---- the four stems of the refinement network as ONE pass over the 32-channel concat buffer -------------------------
+// CostVolRefineNet (cnn_wrapper/atvsnet.py:300-313) concatenates photo | geo | prob | vishull stems (8 channels each)
+// into the 32-channel input of its U-Net.  Written stem by stem, every launch touches 32 of the 128 bytes of each row
+// of that buffer (partial-line HBM writes: 0.7 ms per stem for 4 volumes, whatever the arithmetic).  Here the three
+// FMA stems (geo: 2 channels + depth-plane bias, prob: 1, vishull: 1) are computed together and stored, with the RAW
+// output of the photo stem (MFMA, dense 8-channel tensor) passed through, as whole 128-byte rows.
+//   w: [27 taps][4 input channels: geo0, geo1, prob, hull][8] floats (device);
+//   stats rows: [2][24] doubles (geo 0..7 | prob 8..15 | hull 16..23), one row per workgroup.
+__global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restrict__ photo, const float* __restrict__ geo,
+                                                           const float* __restrict__ geo_pb, const float* __restrict__ prob,
+                                                           const float* __restrict__ hull, const float* __restrict__ w,
+                                                           float* __restrict__ y, double* __restrict__ stats, int D, int H,
+                                                           int W, int tiles_y, int tiles_x, int tiles) {
+  __shared__ float4 tile[ST_HZ * ST_HY * ST_HX];          // (geo0, geo1, prob, hull) per halo voxel
+  __shared__ double s_red[4][2][24];
+  const int tid = threadIdx.x;
+  const int grp = blockIdx.x / tiles, t = blockIdx.x - grp * tiles;
+  const int x0 = (t % tiles_x) * ST_TX, y0 = ((t / tiles_x) % tiles_y) * ST_TY, z0 = (t / (tiles_x * tiles_y)) * ST_TZ;
+  const size_t vol = (size_t)D * H * W;
+  const float* gg = geo + (size_t)grp * vol * 2;
+  const float* pg = prob + (size_t)grp * vol;
+  const float* hg = hull + (size_t)grp * vol;
+  for (int s = tid; s < ST_HZ * ST_HY * ST_HX; s += 256) {
+    const int xx = s % ST_HX, yy = (s / ST_HX) % ST_HY, zz = s / (ST_HX * ST_HY);
+    const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+      const size_t v = ((size_t)gz * H + gy) * W + gx;
+      const float2 g2 = *reinterpret_cast<const float2*>(gg + v * 2);
+      val = make_float4(g2.x, g2.y, pg[v], hg[v]);
+    }
+    tile[s] = val;
+  }
+  __syncthreads();
+  const int lx = tid & 31, ly = tid >> 5;
+  const int xo = x0 + lx, yo = y0 + ly;
+  const bool col_ok = xo < W && yo < H;
+  // tap-outer, z-inner: the 32 weights of a tap are wave-uniform (scalar registers) and serve the thread's whole
+  // column of ST_TZ voxels (one ds_read_b128 of (geo0, geo1, prob, hull) per 32 FMAs)
+  float acc[ST_TZ][24];
+#pragma unroll
+  for (int z = 0; z < ST_TZ; ++z)
+#pragma unroll
+    for (int k = 0; k < 24; ++k) acc[z][k] = 0.f;
+#pragma unroll 1
+  for (int kd = 0; kd < 3; ++kd)
+#pragma unroll 1
+    for (int j = 0; j < 9; ++j) {
+      const float* wk = w + (kd * 9 + j) * 32;                  // uniform address: scalar loads
+      float wr[32];
+#pragma unroll
+      for (int k = 0; k < 32; ++k) wr[k] = wk[k];
+#pragma unroll
+      for (int z = 0; z < ST_TZ; ++z) {
+        const float4 v = tile[((z + kd) * ST_HY + ly + j / 3) * ST_HX + lx + j % 3];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          // fused multiply-adds, as on the matrix cores (the file is built with -ffp-contract=off for the geometry)
+          acc[z][k] = fmaf(v.x, wr[k], acc[z][k]);               // geo: channel 0, then channel 1 (the kernel's ci order)
+          acc[z][k] = fmaf(v.y, wr[8 + k], acc[z][k]);
+          acc[z][8 + k] = fmaf(v.z, wr[16 + k], acc[z][8 + k]);
+          acc[z][16 + k] = fmaf(v.w, wr[24 + k], acc[z][16 + k]);
+        }
+      }
+    }
+  float ssum[24], ssq[24];
+#pragma unroll
+  for (int k = 0; k < 24; ++k) ssum[k] = ssq[k] = 0.f;
+  float* yg = y + (size_t)grp * vol * 32;
+  const float* phg = photo + (size_t)grp * vol * 8;
+  const float* pbg = geo_pb ? geo_pb + (size_t)grp * H * W * 24 : nullptr;
+#pragma unroll
+  for (int z = 0; z < ST_TZ; ++z) {
+    const int zo = z0 + z;
+    if (!col_ok || zo >= D) continue;
+    float* a24 = acc[z];
+    const size_t vox = ((size_t)zo * H + yo) * W + xo;
+    if (pbg) {
+      const float* pb = pbg + ((size_t)yo * W + xo) * 24 + plane_variant(zo - 1, D) * 8;
+      const float4 b0 = ld4(pb), b1 = ld4(pb + 4);
+      a24[0] += b0.x; a24[1] += b0.y; a24[2] += b0.z; a24[3] += b0.w;
+      a24[4] += b1.x; a24[5] += b1.y; a24[6] += b1.z; a24[7] += b1.w;
+    }
+    float* dst = yg + vox * 32;
+    st4(dst, ld4(phg + vox * 8));
+    st4(dst + 4, ld4(phg + vox * 8 + 4));
+#pragma unroll
+    for (int k = 0; k < 24; k += 4) st4(dst + 8 + k, make_float4(a24[k], a24[k + 1], a24[k + 2], a24[k + 3]));
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      ssum[k] += a24[k];
+      ssq[k] += a24[k] * a24[k];
+    }
+  }
+  if (stats) {
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 24; ++k) {
+      double a = (double)ssum[k], b = (double)ssq[k];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        a += __shfl_xor(a, o);
+        b += __shfl_xor(b, o);
+      }
+      if (lane == 0) {
+        s_red[wave][0][k] = a;
+        s_red[wave][1][k] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < 48) {
+      const int which = tid / 24, col = tid % 24;
+      stats[((size_t)blockIdx.x * 2 + which) * 24 + col] =
+          (s_red[0][which][col] + s_red[1][which][col]) + (s_red[2][which][col] + s_red[3][which][col]);
+    }
+  }
+}
+
+}  // namespace
+
+// workgroups per sample = rows per sample of stats_partial ([2][16] doubles each)
+extern "C" long atvs_conv_stem_rows(int D, int H, int W) {
+  return (long)((D + ST_TZ - 1) / ST_TZ) * ((H + ST_TY - 1) / ST_TY) * ((W + ST_TX - 1) / ST_TX);
+}
+
+// y (G,D,H,W,ldy)[..., y_coff + co] = conv3x3x3(x (G,D,H,W,Cin), w) (+ plane_bias (G,H,W,24), ReLU), co < 8, Cin in {1, 2};
+// w: the TF kernel [3,3,3,Cin,8] on the device.  stats_partial: groups * atvs_conv_stem_rows rows or NULL.
+extern "C" int atvs_conv_stem_f32(const float* x, const float* w, const float* plane_bias, float* y, double* stats_partial,
+                                  int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                                  atvs_stream_t stream) {
+  if (!x || !w || !y) return ATVS_ERR_NULL;
+  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || (Cin != 1 && Cin != 2)) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if (plane_bias && D < 2) return ATVS_ERR_ARG;
+  const int ty = (H + ST_TY - 1) / ST_TY, tx = (W + ST_TX - 1) / ST_TX;
+  const long tiles = atvs_conv_stem_rows(D, H, W);
+  if (tiles * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  dim3 grid((unsigned)(tiles * groups)), block(256);
+  hipStream_t s = as_stream(stream);
+  if (Cin == 1)
+    hipLaunchKernelGGL((conv_stem_kernel<1>), grid, block, 0, s, x, w, plane_bias, y, stats_partial, D, H, W, ldy, y_coff, relu,
+                       ty, tx, (int)tiles);
+  else
+    hipLaunchKernelGGL((conv_stem_kernel<2>), grid, block, 0, s, x, w, plane_bias, y, stats_partial, D, H, W, ldy, y_coff, relu,
+                       ty, tx, (int)tiles);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// The geo | prob | vishull stems of CostVolRefineNet in one pass, written with the raw photo-stem output as whole rows of
+// the 32-channel concat buffer: y (G,D,H,W,32) = [photo_raw (G,D,H,W,8) | conv(geo (G,D,H,W,2)) + geo_plane_bias
+// (G,H,W,24) | conv(prob (G,D,H,W,1)) | conv(hull (G,D,H,W,1))] (no activation: the batch norm + ReLU of the concat
+// follows).  w: [27][geo0, geo1, prob, hull][8] floats on the device (atvs_refine_stems_pack arranges the three TF
+// kernels).  stats_partial: groups * atvs_conv_stem_rows rows of [2][24] doubles (the 24 computed channels) or NULL.
+extern "C" int atvs_refine_stems_f32(const float* photo_raw, const float* geo, const float* geo_plane_bias, const float* prob,
+                                     const float* hull, const float* w, float* y, double* stats_partial, int groups, int D,
+                                     int H, int W, atvs_stream_t stream) {
+  if (!photo_raw || !geo || !prob || !hull || !w || !y) return ATVS_ERR_NULL;
+  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (geo_plane_bias && D < 2) return ATVS_ERR_ARG;
+  const int ty = (H + ST_TY - 1) / ST_TY, tx = (W + ST_TX - 1) / ST_TX;
+  const long tiles = atvs_conv_stem_rows(D, H, W);
+  if (tiles * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL(refine_stems_kernel, dim3((unsigned)(tiles * groups)), dim3(256), 0, as_stream(stream), photo_raw, geo,
+                     geo_plane_bias, prob, hull, w, y, stats_partial, D, H, W, ty, tx, (int)tiles);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// HOST function: w_geo [3,3,3,2,8], w_prob [3,3,3,1,8], w_hull [3,3,3,1,8] (TF layouts) -> packed [27][4][8].
+extern "C" int atvs_refine_stems_pack(const float* w_geo, const float* w_prob, const float* w_hull, float* packed) {
+  if (!w_geo || !w_prob || !w_hull || !packed) return ATVS_ERR_NULL;
+  for (int t = 0; t < 27; ++t)
+    for (int k = 0; k < 8; ++k) {
+      packed[(t * 4 + 0) * 8 + k] = w_geo[(t * 2 + 0) * 8 + k];
+      packed[(t * 4 + 1) * 8 + k] = w_geo[(t * 2 + 1) * 8 + k];
+      packed[(t * 4 + 2) * 8 + k] = w_prob[t * 8 + k];
+      packed[(t * 4 + 3) * 8 + k] = w_hull[t * 8 + k];
+    }
+  return ATVS_OK;
+}

@@ -373,6 +373,13 @@ def conv2d_lds_ok(cin, cout, dilation, H, W):
 
 
 _USE_CONV2D_LDS = True
+_USE_STEM = True
+
+
+def use_stem(flag):
+    """Testing / A-B hook for the FMA kernel of the 1-2 channel refinement stems."""
+    global _USE_STEM
+    _USE_STEM = bool(flag)
 
 
 def use_conv2d_lds(flag):
@@ -786,6 +793,34 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     if in_params is not None:
         raise ValueError('conv %s: no normalise-on-load form for this shape' % (key,))
 
+    # ---- 3-D, 3x3x3, 1-2 input channels -> 8: the refinement stems, HBM-bound FMA kernel
+    if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) and cout == 8 \
+            and cin <= 2 and bias is None and residual is None and _USE_STEM and _FORCE_IMPL is None \
+            and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
+        import numpy as np
+        ck = ('stem', key, str(x.device))
+        wd = _pack_cache.get(ck)
+        if wd is None:
+            wd = _Packed()
+            wd.key, wd.tab, wd.cin, wd.cout = key, None, cin, cout
+            wd.wp = None if x.is_meta else torch.from_numpy(np.ascontiguousarray(w_host, dtype=np.float32)).to(x.device)
+            _pack_cache[ck] = wd
+        if y5 is None:
+            y5 = _new(x, (G,) + tuple(outs) + (8,))
+        st, sbuf = None, None
+        if want_stats:
+            rows = int(_lib.lib().atvs_conv_stem_rows(*outs))
+            sbuf = _stats_buffer(x, rows, 16, groups=G)
+            st = Stats()
+            st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, 16, M, G
+        if _dev_ok(x5, y5, plane_bias):
+            with _Timed(key, x5.shape[1:], 8, G):
+                _call('atvs_conv_stem_f32', _p(x5), _p(wd.wp), _p(plane_bias), _p(y5),
+                      ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, outs[0], outs[1],
+                      outs[2], cin, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+        y = out if out is not None else _from5(y5, nsp, groups)
+        return (y, st) if want_stats else y
+
     tile_y = 0
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
             and tuple(outs) == ins:
@@ -922,6 +957,40 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
     pb = conv(sv.const, (key, 'planes'), planes, stride=stride, groups=B)            # (B, ho, wo, 3*Cout)
     return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb, out=out, y_coff=y_coff,
                 groups=B)
+
+
+def refine_stems(photo_raw, geo_var, geo_plane_bias, prob, hull, key, w_geo, w_prob, w_hull):
+    """The geo | prob | vishull stems of CostVolRefineNet in one pass, stored with the raw photo-stem output as whole
+    rows of the 32-channel concat buffer (atvs_refine_stems_f32).  photo_raw (B,D,h,w,8), geo_var (B,D,h,w,2),
+    geo_plane_bias (B,h,w,24), prob / hull (B,D,h,w,1); w_*: TF kernels [3,3,3,Cin,8] (numpy, D-varying channels only).
+    -> (buffer (B,D,h,w,32) raw, Stats over the 24 computed channels)."""
+    import numpy as np
+    B, D, H, W, _ = photo_raw.shape
+    ck = ('stems', key, str(photo_raw.device))
+    pk = _pack_cache.get(ck)
+    if pk is None:
+        packed = np.empty(27 * 4 * 8, np.float32)
+        args = [np.ascontiguousarray(a, dtype=np.float32) for a in (w_geo, w_prob, w_hull)]
+        if args[0].shape != (3, 3, 3, 2, 8) or args[1].shape != (3, 3, 3, 1, 8) or args[2].shape != (3, 3, 3, 1, 8):
+            raise ValueError('refine_stems: kernels [3,3,3,2,8], [3,3,3,1,8], [3,3,3,1,8]')
+        rc = _lib.lib().atvs_refine_stems_pack(*[a.ctypes.data_as(ctypes.c_void_p) for a in args],
+                                               packed.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise RuntimeError('atvs_refine_stems_pack failed (%d)' % rc)
+        pk = _Packed()
+        pk.key, pk.tab, pk.cin, pk.cout = key, None, 4, 24
+        pk.wp = None if photo_raw.is_meta else torch.from_numpy(packed).to(photo_raw.device)
+        _pack_cache[ck] = pk
+    buf = _new(photo_raw, (B, D, H, W, 32))
+    rows = int(_lib.lib().atvs_conv_stem_rows(D, H, W))
+    st = Stats()
+    st.partial = torch.empty((B, rows, 2, 24), dtype=torch.float64, device=photo_raw.device)
+    st.blocks, st.cpad, st.count, st.groups = rows, 24, D * H * W, B
+    if _dev_ok(photo_raw, geo_var, geo_plane_bias, prob, hull, buf):
+        with _Timed(key, (D, H, W, 4), 24, B):
+            _call('atvs_refine_stems_f32', _p(photo_raw), _p(geo_var), _p(geo_plane_bias), _p(prob), _p(hull), _p(pk.wp),
+                  _p(buf), ctypes.c_void_p(st.partial.data_ptr()), B, D, H, W, _stream())
+    return buf, st
 
 
 def siblings_ok(shape, cin, cout, cout2):

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 4
+#define ATVS_ABI_VERSION 6
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -266,6 +266,26 @@ long atvs_conv2d_lds_rows(int H, int W, int Cout);
 int atvs_conv2d_lds_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
                         const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H, int W,
                         int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
+ * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a
+ * sliding register window along z, not MFMA (conv_stem.hip).  x (groups,D,H,W,Cin), Cin in {1,2}; w = the TF kernel
+ * [3,3,3,Cin,8] on the device; y (groups,D,H,W,ldy)[..., y_coff + co]; plane_bias (groups,H,W,24) or NULL (see
+ * atvs_conv_mfma_f32); stats_partial: groups * atvs_conv_stem_rows rows of [2][16] doubles (columns 0..7) or NULL. */
+long atvs_conv_stem_rows(int D, int H, int W);
+int atvs_conv_stem_f32(const float* x, const float* w, const float* plane_bias, float* y, double* stats_partial,
+                       int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* The geo | prob | vishull stems of CostVolRefineNet (cnn_wrapper/atvsnet.py:300-313) in ONE pass, stored together with
+ * the RAW output of the photo stem as whole 128-byte rows of the 32-channel concat buffer (stem-by-stem slices are
+ * partial-line HBM writes): y (groups,D,H,W,32) = [photo_raw (..,8) | conv(geo (..,2)) + geo_plane_bias (groups,H,W,24) |
+ * conv(prob (..,1)) | conv(hull (..,1))], no activation.  atvs_refine_stems_pack (HOST) arranges the three TF kernels
+ * [3,3,3,Cin,8] as [27][geo0, geo1, prob, hull][8] (upload the 864 floats).  stats_partial: groups * atvs_conv_stem_rows
+ * rows of [2][24] doubles over the 24 computed channels, or NULL. */
+int atvs_refine_stems_pack(const float* w_geo, const float* w_prob, const float* w_hull, float* packed);
+int atvs_refine_stems_f32(const float* photo_raw, const float* geo, const float* geo_plane_bias, const float* prob,
+                          const float* hull, const float* w, float* y, double* stats_partial, int groups, int D, int H,
+                          int W, atvs_stream_t stream);
 
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,

@@ -106,3 +106,37 @@ def test_batched_pipeline_equals_per_view_pipeline(cuda, weights, views):
     assert rel <= 2e-5
     g = ex.GraphedInference(imgs, cams, 32, batched=True)
     assert torch.equal(g(), batched)
+
+
+@pytest.mark.parametrize('cin,shape,G', [(1, (16, 24, 40), 2), (2, (9, 13, 35), 3), (1, (8, 8, 32), 1)])
+def test_stem_kernel_matches_oracle(cuda, cin, shape, G):
+    """conv_stem.hip (1-2 channels -> 8, FMA): values, depth-plane bias, ReLU, per-sample moments, a slice of a wider
+    buffer; and the MFMA form of the same layer."""
+    from atvsnet_amd import ops
+    from oracle import tf_ops as T
+    D, H, W = shape
+    x = _rand((G, D, H, W, cin), 31)
+    w = _rand((3, 3, 3, cin, 8), 32) * 0.3
+    pb = _rand((G, H, W, 24), 33)
+    buf = torch.zeros(G, D, H, W, 32, device=cuda)
+    y, st = ops.conv(x.to(cuda), ('stem', cin, shape), w.numpy(), relu=True, want_stats=True, out=buf, y_coff=8,
+                     plane_bias=pb.to(cuda), groups=G)
+    want = T.conv(x, w, 1, 'SAME')
+    for z in range(D):
+        v = 0 if z == 0 else (2 if z == D - 1 else 1)
+        want[:, z] += pb[..., v * 8:v * 8 + 8]
+    want = torch.clamp(want, min=0)
+    got = buf[..., 8:16].cpu()
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    assert float(buf[..., :8].abs().max()) == 0 and float(buf[..., 16:].abs().max()) == 0
+    p = ops.bn_params(st, 8, buf).cpu().reshape(G, 3, 8)
+    for g in range(G):
+        flat = want[g].reshape(-1, 8).double()
+        assert float((p[g, 0] - flat.mean(0)).abs().max()) <= 1e-5
+        assert float((p[g, 1] - 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
+    ops.use_stem(False)
+    try:
+        y2 = ops.conv(x.to(cuda), ('stem-mfma', cin, shape), w.numpy(), relu=True, plane_bias=pb.to(cuda), groups=G)
+    finally:
+        ops.use_stem(True)
+    assert float((y2.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
