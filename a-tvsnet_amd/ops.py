@@ -1359,3 +1359,17 @@ def divide(num, den):
     if _dev_ok(num, den):
         _call('atvs_divide', _p(num), _p(den), _p(out), ctypes.c_long(num.numel()), _stream())
     return out
+
+
+# --------------------------------------------------------------------------- depth-map fusion (after the hot path)
+
+def fusibile(cams, normals_depths, images, ref, disp_thresh, normal_thresh, num_consistent):
+    """The consistency-voting kernel of the reference's fusibile for reference camera `ref` (atvs_fusibile).
+    cams (N,28), normals_depths / images (N,rows,cols,4) -> coord, normal, texture (rows,cols,4), created (rows,cols)."""
+    N, rows, cols, _ = normals_depths.shape
+    coord, normal, tex = (_new(images, (rows, cols, 4)) for _ in range(3))
+    created = _new(images, (rows, cols))
+    if _dev_ok(cams, normals_depths, images):
+        _call('atvs_fusibile', _p(cams), _p(normals_depths), _p(images), N, int(ref), rows, cols, ctypes.c_float(disp_thresh),
+              ctypes.c_float(normal_thresh), int(num_consistent), _p(coord), _p(normal), _p(tex), _p(created), _stream())
+    return coord, normal, tex, created

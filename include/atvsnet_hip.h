@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 6
+#define ATVS_ABI_VERSION 7
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -365,6 +365,22 @@ int atvs_aanet_partial(const float* const* sr_ptrs, const float* const* x_ptrs, 
 
 /* out = num / den, n % 4 == 0 (last step of the sharded AANet). */
 int atvs_divide(const float* num, const float* den, float* out, long n, atvs_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ * Depth-map fusion  (fusibile/fusibile.cu, after the hot path: SURVEY.md 8 f-4)
+ * ------------------------------------------------------------------------- */
+
+/* The consistency-voting kernel `fusibile` (fusibile/fusibile.cu:138-277) for reference camera `ref`.
+ * cams (nviews, 28) floats per camera: P[12] (3x4 projection, row-major) | M_inv[9] (inverse of P's left 3x3) |
+ * C[3] (camera centre) | P_col34[3] (P's last column) | f (K[0,0]) -- cameraGeometryUtils.h:377-433.
+ * normals_depths, images: (nviews, rows, cols, 4) floats = (nx, ny, nz, depth) and (b, g, r, unused), the two float4
+ * textures of main.cpp:816-822, sampled bilinearly with clamped addressing and 8-bit weights (no texture unit).
+ * Outputs, all for the pixels of `ref`: coord / normal / texture (rows, cols, 4) = the pixel's 3-D point, the normal and
+ * the colour averaged over the agreeing views; created (rows, cols) = 1 when at least num_consistent views agree
+ * (relative disparity difference < disp_thresh and normal angle < normal_thresh), else 0. */
+int atvs_fusibile(const float* cams, const float* normals_depths, const float* images, int nviews, int ref, int rows,
+                  int cols, float disp_thresh, float normal_thresh, int num_consistent, float* coord, float* normal,
+                  float* texture, float* created, atvs_stream_t stream);
 
 
 #ifdef __cplusplus
