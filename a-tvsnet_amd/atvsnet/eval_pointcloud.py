@@ -44,6 +44,38 @@ def _inverse_depth_range(cam):
     cam[1][3][:] = (disp_min, (disp_max - disp_min) / FLAGS.max_d, FLAGS.max_d, disp_max)
 
 
+def _ground_truth_depth_range(ref_image, cams):
+    """use ground truth depth range (reference :170-192): `<ref image>.txt` names the original image; when
+    `<its folder with /images/ -> /depths/>/<name>.exr` exists, the (inverse-)depth sweep of EVERY view becomes
+    [min, max] of that map over FLAGS.max_d hypotheses.  The EXR is read by tools/exr.py; an EXR that exists but cannot
+    be decoded raises (a silently different sweep would change every depth map)."""
+    note = ref_image[0:ref_image.rfind('.') + 1] + 'txt'
+    if not os.path.exists(note):
+        return
+    with open(note, "r") as f:
+        filename = f.readline()
+    ref_image_path = ref_image[0:ref_image.rfind('/') + 1] + filename
+    depth_path = ref_image_path.replace('/images/', '/depths/')
+    depth_path = depth_path[0:depth_path.rfind('.') + 1] + 'exr'
+    if not os.path.exists(depth_path):
+        print(depth_path, 'not exist.')
+        return
+    from ..tools import exr
+    depth_gt = exr.imread_first_channel(depth_path)
+    if FLAGS.inverse_depth:
+        depth_gt[depth_gt <= 0.0] = float("inf")
+        depth_gt = 1.0 / (depth_gt)
+    disp_max = np.max(depth_gt)
+    depth_gt[depth_gt <= 0.0] = float("inf")
+    disp_min = np.min(depth_gt)
+    disp_interval = (disp_max - disp_min) / FLAGS.max_d
+    for cam in cams:
+        cam[1][3][0] = disp_min
+        cam[1][3][1] = disp_interval
+        cam[1][3][2] = FLAGS.max_d
+        cam[1][3][3] = disp_max
+
+
 def load_data(sample_list, data_index):
     """One pair.txt entry -> (scaled BGR images (1,N,h/4,w/4,3), centred images (1,N,h,w,3), cameras at
     sample_scale (1,N,2,4,4), a (1,h/4,w/4,1) placeholder, reference image index) (reference :97-203)."""
@@ -75,9 +107,7 @@ def load_data(sample_list, data_index):
     if FLAGS.inverse_depth:
         for cam in cams:
             _inverse_depth_range(cam)
-    gt_note = data[0][0:data[0].rfind('.') + 1] + 'txt'
-    if os.path.exists(gt_note):
-        print(gt_note, ': ground-truth depth range (EXR) is not read here; the camera file range is used')
+    _ground_truth_depth_range(data[0], cams)
     cams = scale_mvs_camera(cams, scale=FLAGS.sample_scale)
     scaled = [scale_image(im, scale=FLAGS.sample_scale) for im in images]
     scaled_depth = scaled[-1][:, :, 0:1].copy()

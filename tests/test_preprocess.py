@@ -166,3 +166,85 @@ def test_oracle_probability_map_known_answer():
     v = torch.randn(1, 4, 3, 3)
     d, p = OM.prob2depth(v, 4, ds, di, True)
     assert p.shape == (1, 3, 3, 1) and float(p.min()) > 0 and float(p.max()) <= 4.0
+
+
+def _hand_made_zip_exr(path, depth):
+    """An RGB float scan-line EXR with ZIP blocks assembled here byte by byte from the file-layout document (NOT with
+    tools.exr.write_exr): header attributes, offset table, 16-line blocks = zlib(delta-predicted(even bytes | odd bytes))."""
+    import zlib
+    H, W = depth.shape
+    att = lambda n, t, d: n.encode() + b'\0' + t.encode() + b'\0' + struct.pack('<i', len(d)) + d      # noqa: E731
+    chl = b''.join(c + b'\0' + struct.pack('<i', 2) + bytes([0, 0, 0, 0]) + struct.pack('<ii', 1, 1) for c in (b'B', b'G', b'R')) + b'\0'
+    box = struct.pack('<4i', 0, 0, W - 1, H - 1)
+    head = struct.pack('<i', 20000630) + struct.pack('<i', 2)
+    head += att('channels', 'chlist', chl) + att('compression', 'compression', b'\x03') + att('dataWindow', 'box2i', box)
+    head += att('displayWindow', 'box2i', box) + att('lineOrder', 'lineOrder', b'\x00')
+    head += att('pixelAspectRatio', 'float', struct.pack('<f', 1.0)) + att('screenWindowCenter', 'v2f', struct.pack('<ff', 0, 0))
+    head += att('screenWindowWidth', 'float', struct.pack('<f', 1.0)) + b'\0'
+    blocks = []
+    for y in range(0, H, 16):
+        raw = bytearray()
+        for r in range(y, min(y + 16, H)):
+            for k in (3.0, 2.0, 1.0):                       # B, G, R planes of the line: R = depth
+                raw += (depth[r] * np.float32(k)).astype('<f4').tobytes()
+        t = bytes(raw[0::2]) + bytes(raw[1::2])
+        d = bytearray(t)
+        for i in range(len(t) - 1, 0, -1):
+            d[i] = (t[i] - t[i - 1] + 128) & 255
+        z = zlib.compress(bytes(d))
+        assert len(z) < len(raw)                                  # (a block that does not shrink is stored raw)
+        blocks.append(struct.pack('<ii', y, len(z)) + z)
+    pos = len(head) + 8 * len(blocks)
+    table = b''
+    for b in blocks:
+        table += struct.pack('<Q', pos)
+        pos += len(b)
+    with open(path, 'wb') as f:
+        f.write(head + table + b''.join(blocks))
+
+
+def test_exr_reader_and_ground_truth_depth_range(tmp_path):
+    """tools/exr.py on a ZIP file assembled by hand, and the ground-truth range branch of the ETH3D driver
+    (reference eval_pointcloud.py:170-192) that uses it."""
+    from atvsnet_amd.atvsnet import eval_pointcloud as EP
+    from atvsnet_amd.tools import exr
+    rng = np.random.default_rng(5)
+    yy, xx = np.meshgrid(np.arange(37), np.arange(21), indexing='ij')
+    depth = (2.0 + 0.25 * (xx + 2 * yy) + rng.integers(0, 2, (37, 21)) * 0.125).astype(np.float32)    # compressible
+    depth[3, 4] = 0.0                                           # a hole: excluded from the range
+    scene = tmp_path / 'scene'
+    (scene / 'images').mkdir(parents=True)
+    (scene / 'depths').mkdir()
+    _hand_made_zip_exr(str(scene / 'depths' / 'orig_0007.exr'), depth)
+    ch = exr.read_exr(str(scene / 'depths' / 'orig_0007.exr'))
+    assert sorted(ch) == ['B', 'G', 'R'] and np.array_equal(ch['R'], depth) and np.array_equal(ch['B'], depth * np.float32(3.0))
+    assert np.array_equal(exr.imread_first_channel(str(scene / 'depths' / 'orig_0007.exr')), depth)
+    # the writer (used by nothing but tests) agrees with the hand-made file
+    exr.write_exr(str(tmp_path / 'w.exr'), {'R': depth, 'G': depth * np.float32(2.0), 'B': depth * np.float32(3.0)}, 'ZIP')
+    assert np.array_equal(exr.read_exr(str(tmp_path / 'w.exr'))['G'], depth * np.float32(2.0))
+    with pytest.raises(exr.ExrError):
+        open(str(tmp_path / 'bad.exr'), 'wb').write(b'not an exr file at all')
+        exr.read_exr(str(tmp_path / 'bad.exr'))
+    # the driver: <ref>.txt names the original image, whose /images/ -> /depths/ .exr gives the sweep of every view
+    ref = scene / 'images' / '00000000.jpg'
+    ref.write_bytes(b'')
+    (scene / 'images' / '00000000.txt').write_text('orig_0007.png\n')
+    FLAGS.max_d, FLAGS.inverse_depth = 128, True
+    cams = [np.zeros((2, 4, 4)) for _ in range(3)]
+    EP._ground_truth_depth_range(str(ref), cams)
+    valid = depth[depth > 0]
+    dmin, dmax = 1.0 / float(valid.max()), 1.0 / float(valid.min())
+    for cam in cams:
+        assert abs(cam[1][3][0] - dmin) < 1e-7 and abs(cam[1][3][3] - dmax) < 1e-7
+        assert cam[1][3][2] == 128 and abs(cam[1][3][1] - (dmax - dmin) / 128) < 1e-9
+    # no note, or no EXR behind it: the camera-file range stays
+    cams2 = [np.ones((2, 4, 4))]
+    EP._ground_truth_depth_range(str(scene / 'images' / '00000009.jpg'), cams2)
+    (scene / 'images' / '00000001.txt').write_text('missing.png\n')
+    EP._ground_truth_depth_range(str(scene / 'images' / '00000001.jpg'), cams2)
+    assert np.array_equal(cams2[0], np.ones((2, 4, 4)))
+    # an EXR that exists but cannot be decoded must raise, not change the sweep silently
+    (scene / 'depths' / 'broken.exr').write_bytes(b'\x76\x2f\x31\x01' + b'\x02\x00\x00\x00' + b'garbage')
+    (scene / 'images' / '00000002.txt').write_text('broken.png\n')
+    with pytest.raises(Exception):
+        EP._ground_truth_depth_range(str(scene / 'images' / '00000002.jpg'), cams2)
