@@ -14,13 +14,18 @@ over all its calls -- views, siamese directions -- stacked on the batch axis wit
 --eager issues every launch from Python instead.
 
 --gpus N > 1: this process touches no GPU; it starts N ranks (one process per GPU, RANK / LOCAL_RANK /
-WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), relays rank 0's JSON line and exits non-zero if any rank
-fails or if fewer than N devices are visible.  (Launched under torch.distributed.run -- WORLD_SIZE already in
-the environment -- it is a rank itself.)  The ranks form groups of at most one rank per source view
-(a-tvsnet_amd/parallel.py): inside a group the source views of ONE depth map are sharded over the ranks and
-exchanged inside both AANet modules over RCCL; when there are more ranks than sources, the extra ranks form
-further groups that work on further depth maps (other reference views of the scene).  value = depth maps
-completed by all groups per second.
+WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), prints ONE JSON line and exits non-zero if a rank of the primary
+measurement fails or if fewer than N devices are visible.  (Launched under torch.distributed.run -- WORLD_SIZE
+already in the environment -- it is a rank itself and measures the mode --parallel names.)  Two ways to use N GPUs
+(a-tvsnet_amd/parallel.py):
+  --parallel maps   (primary; `value`): the unit of the metric is a depth map and the depth maps of a scene are
+                    independent (one per reference view, reference eval_pointcloud.py:399-424): every rank computes
+                    its own depth maps, no data-path collective, "scaling": "weak".
+  --parallel views  (secondary; reported under "view_sharded" of the same line): the source views of ONE depth map
+                    are sharded over groups of at most one rank per source and exchanged inside both AANet modules
+                    over RCCL (all-to-all of voxel shards + all-gather) -- lower latency per depth map, fewer depth
+                    maps per second than `maps` (DESIGN.md 5 has the model).  Measured best-effort by a second set of
+                    ranks after the primary result is safe; a failure there is reported, not fatal.
 
 One JSON line on rank 0.  `roofline` = the dominant kernel (conv_xp.hip: the 3x3x3 convolution of the 32 warped
 channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch) against
@@ -69,6 +74,9 @@ def parse(argv=None):
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
     p.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
+    p.add_argument('--parallel', choices=['maps', 'views', 'both'], default=None,
+                   help='N > 1: maps = one depth map per rank (no collective), views = source views sharded inside groups; '
+                        'the launcher default measures maps, then views as a secondary result of the same line')
     p.add_argument('--split-directions', action='store_true',
                    help='with >= 2 ranks per source: one siamese direction per rank instead of further depth-map groups')
     p.add_argument('--dry', action='store_true',
@@ -93,15 +101,9 @@ def _free_port():
     return port
 
 
-def launch(args, argv):
-    """Start args.gpus ranks of this script as child processes; no GPU call happens in this process."""
-    n = args.gpus
-    if not args.dry:
-        import torch
-        have = torch.cuda.device_count()          # counts devices without initialising the GPU
-        if have < n:
-            sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to run a smaller world\n' % (n, have))
-            return 2
+def _run_ranks(n, argv, timeout_s):
+    """Start n ranks of this script; -> (rank 0's stdout text, return codes).  Children that outlive the timeout are
+    killed (the exact processes started here)."""
     port = _free_port()
     procs = []
     for r in range(n):
@@ -111,23 +113,62 @@ def launch(args, argv):
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
                                       stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode]
-    deadline = time.time() + 120
-    for p in procs[1:]:
+    deadline = time.time() + timeout_s
+    out0 = b''
+    try:
+        out0, _ = procs[0].communicate(timeout=timeout_s)
+    except subprocess.TimeoutExpired:
+        pass
+    rcs = []
+    for p in procs:
         try:
             p.wait(timeout=max(1.0, deadline - time.time()))
         except subprocess.TimeoutExpired:
             p.kill()          # the exact child we started
             p.wait()
         rcs.append(p.returncode)
-    text = out0.decode('utf-8', 'replace') if out0 else ''
-    sys.stdout.write(text)
-    sys.stdout.flush()
+    return (out0.decode('utf-8', 'replace') if out0 else ''), rcs
+
+
+def _last_json(text):
+    lines = [ln for ln in text.splitlines() if ln.startswith('{')]
+    return json.loads(lines[-1]) if lines else None
+
+
+def launch(args, argv):
+    """Start args.gpus ranks of this script as child processes; no GPU call happens in this process."""
+    n = args.gpus
+    if not args.dry:
+        import torch
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to run a smaller world\n' % (n, have))
+            return 2
+    base = [a for i, a in enumerate(argv) if a != '--parallel' and (i == 0 or argv[i - 1] != '--parallel')]
+    first = 'views' if args.parallel == 'views' else 'maps'
+    text, rcs = _run_ranks(n, base + ([] if args.dry else ['--parallel', first]), 1500)
     bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
+    line = _last_json(text)
+    if bad or line is None:
+        sys.stdout.write(text)
         sys.stderr.write('bench.py: rank(s) failed: %s\n' % bad)
         return 1
+    if not args.dry and args.parallel in (None, 'both') and args.views > 2:
+        # secondary, best-effort: the view-sharded form of the same workload (a failure / hang there must not cost the
+        # primary result)
+        try:
+            t2, rc2 = _run_ranks(n, base + ['--parallel', 'views', '--no-cpu-baseline'], 600)
+            l2 = _last_json(t2)
+            if l2 is not None and all(rc == 0 for rc in rc2):
+                line['view_sharded'] = {k: l2.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'exchange', 'parity')}
+                line['view_sharded']['parallelism'] = l2['config']['parallelism']
+                line['view_sharded']['groups'] = l2['config']['groups']
+            else:
+                line['view_sharded'] = {'error': 'ranks returned %s' % rc2}
+        except Exception as e:
+            line['view_sharded'] = {'error': repr(e)}
+    print(json.dumps(line))
+    sys.stdout.flush()
     return 0
 
 
@@ -322,12 +363,17 @@ def rank_main(args):
     imgs, cams = torch.from_numpy(imgs).to(dev), torch.from_numpy(cams).to(dev)
     twoview = args.views == 2
 
-    # ranks -> groups of at most one rank per source (each group computes its own depth map)
-    groups = parallel.rank_groups(args.views, world, args.split_directions) if world > 1 else [[0]]
+    # maps: every rank is its own group (its own depth maps, no data-path collective); views: groups of at most one rank
+    # per source view, the sources of one depth map sharded inside a group
+    mode = args.parallel if args.parallel in ('maps', 'views') else 'maps'
+    if world > 1 and (mode == 'maps' or twoview):
+        mode, groups = 'maps', [[r] for r in range(world)]
+    else:
+        groups = parallel.rank_groups(args.views, world, args.split_directions) if world > 1 else [[0]]
     group, gsize, n_groups = None, 1, len(groups)
     if world > 1:
         for g in groups:
-            h = dist.new_group(g) if len(groups) > 1 else None       # every rank creates every group
+            h = dist.new_group(g) if (len(groups) > 1 and len(g) > 1) else None       # every rank creates every group
             if rank in g:
                 group, gsize = h, len(g)
     sharded = gsize > 1
@@ -432,7 +478,9 @@ def rank_main(args):
                         'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[WARP]),
                         'algorithmic_bytes_per_launch': wb, 'traffic': None}
         par = 'single GPU'
-        if world > 1:
+        if world > 1 and not sharded:
+            par = '%d ranks, one depth map each per step (independent reference views of a scene), no data-path collective' % world
+        elif world > 1:
             par = ('%d group(s) of %d rank(s); inside a group the source views of one depth map are sharded over the ranks, '
                    'exchange inside AAM1/AAM2 over RCCL (%s)' % (n_groups, len(groups[0]), parallel.EXCHANGE))
         line = {
@@ -440,7 +488,7 @@ def rank_main(args):
             'value': round(n_groups * args.steps / dt, 4),
             'unit': 'depth-maps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
-            'scaling': 'strong', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': '%d depth map(s) per step: %d views (1 ref + %d src) %dx%d, D=%d, example.py %s pipeline'
                                    % (n_groups, args.views, args.views - 1, args.width, args.height, args.depths,
                                       'two-view' if twoview else 'multi-view'),
