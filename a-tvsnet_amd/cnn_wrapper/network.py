@@ -388,24 +388,47 @@ class Network(object):
         G = x.shape[0]
         depth_in = x.shape[-1]
         beta = self._vec('%s/preact/beta' % scope, depth_in, x)
+        # pre-activation (slim.batch_norm + relu, :570-571).  Its consumers are 1x1 convolutions: where the GEMM kernel
+        # serves them the normalisation is applied as they load x and the pre-activated tensor is never written.
+        pre_params = None
+        _pre = []
+
+        def preact():
+            if not _pre:
+                if self.training:
+                    _pre.append(ops.bn_apply(x, pre_params, True, out=torch.empty_like(x)))
+                else:
+                    _pre.append(self._bn_inference(x.clone(), '%s/preact' % scope, beta, True))
+            return _pre[0]
         if self.training:
             # statistics of `inputs` come from the epilogue of the convolution that produced it, when
             # that was the previous bottleneck's conv3 (+shortcut); otherwise from a channel_stats pass
-            preact = ops.batch_norm(x, getattr(inputs, '_atvs_stats', None), beta=beta, relu=True, eps=BN_EPS, groups=G)
-        else:
-            preact = self._bn_inference(x.clone(), '%s/preact' % scope, beta, True)
+            st_in = getattr(inputs, '_atvs_stats', None)
+            if st_in is None:
+                st_in = ops.channel_stats(x, groups=G)
+            pre_params = ops.bn_params(st_in, depth_in, x, beta, BN_EPS)
+        on_load = self.training and ops.conv1x1_ok(depth_in, depth)
         if depth == depth_in:
             if stride == 1:
                 shortcut = x
             else:
                 raise NotImplementedError('bottleneck: max_pool shortcut (same depth, stride != 1) is never '
                                           'reached by cnn_wrapper/atvsnet.py and is not built')
+        elif on_load and stride == 1:
+            shortcut = ops.conv(x, scope + '/shortcut/weights',
+                                self._kernel('%s/shortcut/weights' % scope, (1, 1, depth_in, depth)),
+                                bias=self._vec('%s/shortcut/biases' % scope, depth, x), groups=G, in_params=pre_params,
+                                in_relu=True)
         else:
-            shortcut = ops.conv(preact, scope + '/shortcut/weights',
+            shortcut = ops.conv(preact(), scope + '/shortcut/weights',
                                 self._kernel('%s/shortcut/weights' % scope, (1, 1, depth_in, depth)), stride=stride,
                                 bias=self._vec('%s/shortcut/biases' % scope, depth, x), groups=G)
-        r = ops.conv(preact, scope + '/conv1/weights', self._kernel('%s/conv1/weights' % scope, (1, 1, depth_in, depth)),
-                     bias=self._vec('%s/conv1/biases' % scope, depth, x), relu=True, groups=G)
+        w1 = self._kernel('%s/conv1/weights' % scope, (1, 1, depth_in, depth))
+        b1 = self._vec('%s/conv1/biases' % scope, depth, x)
+        if on_load:
+            r = ops.conv(x, scope + '/conv1/weights', w1, bias=b1, relu=True, groups=G, in_params=pre_params, in_relu=True)
+        else:
+            r = ops.conv(preact(), scope + '/conv1/weights', w1, bias=b1, relu=True, groups=G)
         w2 = self._kernel('%s/conv2/weights' % scope, (kernel_size, kernel_size, depth, depth))
         b2 = self._vec('%s/conv2/biases' % scope, depth, x)
         if stride == 1:

@@ -441,6 +441,59 @@ def conv2d_lds(x, key, w_host, dilation=1, bias=None, residual=None, relu=False,
     return (y, st) if want_stats else y
 
 
+def conv1x1_ok(cin, cout):
+    """Is the LDS-staged GEMM kernel (atvs_conv1x1_f32) used for a stride-1 1x1 convolution of these channel counts?"""
+    return (_FORCE_IMPL != 'gather' and _USE_CONV1X1 and bool(_lib.lib().atvs_conv1x1_supported(int(cin), int(cout))))
+
+
+_USE_CONV1X1 = True
+
+
+def use_conv1x1(flag):
+    """Testing / A-B hook for the 1x1 GEMM kernel of the feature towers."""
+    global _USE_CONV1X1
+    _USE_CONV1X1 = bool(flag)
+
+
+def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=False, out=None, y_coff=0, in_params=None,
+            in_relu=False):
+    """1x1 stride-1 convolution of x (G, ..., Cin) -> (G, ..., Cout) (any spatial axes between) on the GEMM kernel.
+    in_params (G,3,Cin): batch norm (+ ReLU if in_relu) of x applied on load."""
+    import numpy as np
+    G, cin = x.shape[0], x.shape[-1]
+    pixels = x.numel() // G // cin
+    ck = ('c1', key, str(x.device))
+    pk = _pack_cache.get(ck)
+    if pk is None:
+        w = np.ascontiguousarray(w_host, dtype=np.float32).reshape(cin, -1)
+        cout = int(w.shape[1])
+        pf = ctypes.c_long()
+        rc = _lib.lib().atvs_conv1x1_pack_size(cin, cout, ctypes.byref(pf))
+        if rc:
+            raise RuntimeError('atvs_conv1x1_pack_size failed (%d) for Cin=%d Cout=%d' % (rc, cin, cout))
+        packed = np.empty(pf.value, np.float32)
+        rc = _lib.lib().atvs_conv1x1_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise RuntimeError('atvs_conv1x1_pack failed (%d)' % rc)
+        pk = _Packed()
+        pk.key, pk.tab, pk.cin, pk.cout, pk.ntiles = key, None, cin, cout, cout // 16
+        pk.wp = None if x.is_meta else torch.from_numpy(packed).to(x.device)
+        _pack_cache[ck] = pk
+    y = _new(x, tuple(x.shape[:-1]) + (pk.cout,)) if out is None else out
+    st, sbuf = None, None
+    if want_stats:
+        rows = int(_lib.lib().atvs_conv1x1_rows(ctypes.c_long(pixels)))
+        sbuf = torch.empty((G, rows, 2, pk.cout), dtype=torch.float64, device=x.device)
+        st = Stats()
+        st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, pk.cout, pixels, G
+    if _dev_ok(x, y, bias, residual, in_params):
+        with _Timed(pk.key, (1, 1, pixels, cin), pk.cout, G):
+            _call('atvs_conv1x1_f32', _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)), _p(y),
+                  ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, ctypes.c_long(pixels),
+                  cin, pk.cout, int(y.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+    return (y, st) if want_stats else y
+
+
 def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None):
     """One atvs_conv_xp_f32 launch: x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
     sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5."""
@@ -787,6 +840,14 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             and conv2d_lds_ok(cin, cout, dilation, ins[1], ins[2]):
         r = conv2d_lds(x5[:, 0], key, w_host, dilation, bias, None if res5 is None else res5[:, 0], relu, want_stats,
                        None if y5 is None else y5[:, 0], y_coff, in_params, in_relu)
+        y4, st = r if want_stats else (r, None)
+        y = out if out is not None else _from5(y4.unsqueeze(1), nsp, groups)
+        return (y, st) if want_stats else y
+    # ---- 2-D 1x1, stride 1: the LDS-staged GEMM kernel
+    if nsp == 2 and stride == 1 and ks == (1, 1, 1) and plane_bias is None and conv1x1_ok(cin, cout) \
+            and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
+        r = conv1x1(x5[:, 0], key, w_host, bias, None if res5 is None else res5[:, 0], relu, want_stats,
+                    None if y5 is None else y5[:, 0], y_coff, in_params, in_relu)
         y4, st = r if want_stats else (r, None)
         y = out if out is not None else _from5(y4.unsqueeze(1), nsp, groups)
         return (y, st) if want_stats else y

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 7
+#define ATVS_ABI_VERSION 8
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -266,6 +266,22 @@ long atvs_conv2d_lds_rows(int H, int W, int Cout);
 int atvs_conv2d_lds_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
                         const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H, int W,
                         int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* 1x1 convolution of feature maps (the bottlenecks' conv1 / conv3 / shortcut, fusion1: slim.conv2d 1x1,
+ * network.py:573-601; cnn_wrapper/atvsnet.py:254-292) as a tall GEMM: weights staged once per workgroup in LDS, pixels
+ * streamed once (conv1x1.hip).  x (groups, pixels, Cin), Cin % 16 == 0, Cin <= 128, Cout in {32, 64, 128}.
+ *   atvs_conv1x1_pack_size / _pack   HOST: pack the TF kernel [1,1,Cin,Cout]
+ *   atvs_conv1x1_rows                workgroups per image = rows per image of stats_partial ([2][Cout] doubles each)
+ *   atvs_conv1x1_f32                 y (groups,pixels,ldy)[..., y_coff + co] = x W (+ bias, + residual, ReLU); in_params
+ *                                    (groups,3,Cin) != NULL: batch norm (+ ReLU if in_relu) of x applied on load -- the
+ *                                    bottleneck's pre-activation (network.py:570-571) is never materialised. */
+int atvs_conv1x1_supported(int Cin, int Cout);
+int atvs_conv1x1_pack_size(int Cin, int Cout, long* packed_floats);
+int atvs_conv1x1_pack(const float* w, int Cin, int Cout, float* packed);
+long atvs_conv1x1_rows(long pixels);
+int atvs_conv1x1_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
+                     const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
+                     int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
  * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a

@@ -456,3 +456,36 @@ def test_conv2d_lds_normalise_on_load(cuda):
     # and the explicit two-pass form on the device agrees to rounding
     two = ops.conv2d_lds(ops.bn_apply(xd.clone(), params, True), 'nol', w.numpy())
     assert float((y - two).abs().max()) <= 1e-6 * float(two.abs().max())
+
+
+@pytest.mark.parametrize('cin,cout,H,W,G', [(128, 128, 16, 20, 2), (64, 128, 9, 13, 3), (32, 64, 7, 11, 1), (128, 32, 16, 16, 2),
+                                            (64, 64, 5, 50, 2)])
+def test_conv1x1_matches_oracle(cuda, cin, cout, H, W, G):
+    """The 1x1 GEMM kernel of the towers (conv1x1.hip): bias / residual / ReLU / per-image moments, ragged pixel counts,
+    and the bottleneck's pre-activation applied on load."""
+    from atvsnet_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(G, H, W, cin, generator=g) * 2 + 0.5
+    w = torch.randn(1, 1, cin, cout, generator=g) * (1.0 / cin) ** 0.5
+    b = torch.randn(cout, generator=g)
+    res = torch.randn(G, H, W, cout, generator=g)
+    assert ops.conv1x1_ok(cin, cout)
+    y, st = ops.conv(x.to(cuda), ('p', cin, cout), w.numpy(), bias=b.to(cuda), residual=res.to(cuda), want_stats=True, groups=G)
+    want = T.conv(x, w, 1, 'SAME', bias=b) + res
+    assert float((y.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    p = ops.bn_params(st, cout, y).cpu().reshape(G, 3, cout)
+    for i in range(G):
+        flat = want[i].reshape(-1, cout).double()
+        assert float((p[i, 0] - flat.mean(0)).abs().max()) <= 1e-5
+        assert float((p[i, 1] - 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
+    # normalise-on-load == normalising first
+    beta = torch.randn(cin, generator=g) * 0.1
+    xd = x.to(cuda)
+    params = ops.bn_params(ops.channel_stats(xd, groups=G), cin, xd, beta.to(cuda))
+    y2 = ops.conv(xd, ('p', cin, cout), w.numpy(), bias=b.to(cuda), relu=True, groups=G, in_params=params, in_relu=True)
+    xn = torch.stack([torch.clamp(T.batch_norm_train(x[i:i + 1], beta)[0], min=0) for i in range(G)])
+    want2 = torch.clamp(T.conv(xn, w, 1, 'SAME', bias=b), min=0)
+    assert float((y2.cpu() - want2).abs().max()) <= 3e-5 * float(want2.abs().max())
+    # one image, legacy (unbatched) call form
+    y1 = ops.conv(x[0].to(cuda), ('p', cin, cout), w.numpy())
+    assert float((y1.cpu() - T.conv(x[:1], w, 1, 'SAME')[0]).abs().max()) <= 2e-5 * float(want.abs().max())
