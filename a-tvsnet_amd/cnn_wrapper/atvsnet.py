@@ -23,7 +23,7 @@ def _stacked_unet(net, with_prob_head):
             src = 'data'
         else:
             src = n('0_0')
-            net.feed(p('6_0'), p('0_1')).add(name=src)
+            net.feed(p('6_0'), p('0_1')).add(name=src, defer=True)     # formed on load by the siblings below
         # defer_bn: these layers are consumed by `add`s only, which normalise them on the fly.
         # conv_b*_0_1 and the encoder branch conv_b*_1_0 read the same tensor: issued as siblings (one launch)
         (net.feed(src)

@@ -105,11 +105,11 @@ class Network(object):
     def get_output(self):
         '''Returns the current network output.'''
         t = self.terminals[-1]
-        return t.materialize() if isinstance(t, ops.PendingBN) else t
+        return t.materialize() if isinstance(t, ops.LAZY) else t
 
     def get_output_by_name(self, layer_name):
         t = self.layers[layer_name]
-        return t.materialize() if isinstance(t, ops.PendingBN) else t
+        return t.materialize() if isinstance(t, ops.LAZY) else t
 
     def get_shape_by_name(self, layer_name):
         '''Shape of a layer (a tuple here; tf.shape in the reference :121-127).
@@ -139,7 +139,7 @@ class Network(object):
     # ------------------------------------------------------------------ helpers
     def _bt(self, x, what):
         """The dense batch-first tensor of a layer input; B > 1 only for independent samples."""
-        if isinstance(x, (ops.SplitVolume, ops.PendingBN)):
+        if isinstance(x, (ops.SplitVolume,) + ops.LAZY):
             x = x.materialize()
         if x.shape[0] != 1 and not self.independent_samples:
             raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d; pass independent_samples=True to '
@@ -269,8 +269,9 @@ class Network(object):
                            and d.get('out_slice') is None)
         shape = tuple(src.shape)
         fusable = (self.training and len(shape) == 5 and (shape[0] == 1 or self.independent_samples) and plain(a)
-                   and plain(b) and a['strides'] == 1 and b['strides'] == 2 and not b.get('defer_bn', False)
-                   and not isinstance(src, ops.PendingBN))
+                   and plain(b) and a['strides'] == 1 and b['strides'] == 2 and not b.get('defer_bn', False))
+        if fusable and isinstance(src, ops.LAZY) and not ops.siblings_prologue_ok(src):
+            src = src.materialize()        # a lazy input the kernel cannot form on load
         if fusable:
             if isinstance(src, ops.SplitVolume):
                 cin_var = src.var.shape[-1]
@@ -278,6 +279,8 @@ class Network(object):
             else:
                 fusable = ops.siblings_ok(shape[1:4], shape[4], a['filters'], b['filters'])
         if not fusable:
+            if isinstance(src, ops.LAZY):
+                src = src.materialize()
             self.feed(src).conv_bn(**a)
             self.feed(src).conv_bn(**b)
             return self
@@ -288,7 +291,9 @@ class Network(object):
         if isinstance(src, ops.SplitVolume):
             (ya, sa), (yb, sb) = ops.conv_split_siblings(src, va, wa, vb, wb)
         else:
-            (ya, sa), (yb, sb) = ops.conv_siblings(self._bt(src, a['name']), va, wa, vb, wb, groups=shape[0])
+            # a lazy src (pending batch norm / pending sum) is formed inside the launch: normalise- and add-on-load
+            xin = src if isinstance(src, ops.LAZY) else self._bt(src, a['name'])
+            (ya, sa), (yb, sb) = ops.conv_siblings(xin, va, wa, vb, wb, groups=shape[0])
         if a.get('defer_bn', False):
             out_a = ops.PendingBN(ya, ops.bn_params(sa, a['filters'], ya, None, BN_EPS), a.get('relu', True))
         else:
@@ -337,11 +342,13 @@ class Network(object):
         params = torch.empty(pshape, dtype=torch.float32, device=buf.device)
         ops.copy_channels(ops.bn_params(st_photo, filters, buf, None, BN_EPS), params, filters, 0, 0)
         ops.copy_channels(ops.bn_params(st24, 3 * filters, buf, None, BN_EPS), params, 3 * filters, 0, filters)
-        ops.bn_apply(buf, params, True)
+        # the batch norm + ReLU of the 32 channels stays pending: the concat's consumer (3dconv0_1 | 3dconv1_0) normalises
+        # on load; anything else that asks for a stem or the concat gets the materialised tensor
+        out = ops.PendingBN(buf, params, True)
         for i, name in enumerate((n_photo, n_geo, n_prob, n_hull)):
-            self.layers[name] = buf[..., i * filters:(i + 1) * filters]
-        self.layers[concat_name] = buf
-        return self.feed(buf)
+            self.layers[name] = ops.LazySlice(out, i * filters, (i + 1) * filters)
+        self.layers[concat_name] = out
+        return self.feed(out)
 
     def _slice_out(self, y, out_slice, filters):
         """Layer result: the dense tensor, or (for out_slice) a view of the concat buffer tagged for concat()."""
@@ -505,9 +512,13 @@ class Network(object):
         return ops.concat_channels([self._bt(t, name) for t in inputs])
 
     @layer
-    def add(self, inputs, name):
+    def add(self, inputs, name, defer=False):
         '''tf.add_n (reference network.py:695-697).  Inputs whose batch norm is still pending (conv_bn /
-        deconv_bn with defer_bn=True) are normalised inside the add kernel.'''
+        deconv_bn with defer_bn=True) are normalised inside the add kernel.  defer=True (extension): a sum of two
+        whose consumer can add on load (conv_bn_siblings) is handed over unformed.'''
+        inputs = [t.materialize() if isinstance(t, (ops.PendingSum, ops.LazySlice)) else t for t in inputs]
+        if defer and self.training and len(inputs) == 2 and all(t.dim() == 5 for t in inputs):
+            return ops.PendingSum([t if isinstance(t, ops.PendingBN) else self._bt(t, name) for t in inputs])
         if len(inputs) in (2, 3) and any(isinstance(t, ops.PendingBN) for t in inputs) \
                 and inputs[0].shape[-1] % 4 == 0:
             items = [t if isinstance(t, ops.PendingBN) else self._bt(t, name) for t in inputs]
@@ -803,7 +814,7 @@ class Network(object):
 
 def ops_b1(x, what):
     """One-sample tensor (1, ...) -> (...), contiguous."""
-    if isinstance(x, (ops.SplitVolume, ops.PendingBN)):
+    if isinstance(x, (ops.SplitVolume,) + ops.LAZY):
         x = x.materialize()
     if x.shape[0] != 1:
         raise ValueError('%s: batch size must be 1 (FLAGS.batch_size), got %d' % (what, x.shape[0]))

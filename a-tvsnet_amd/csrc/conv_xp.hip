@@ -72,6 +72,14 @@ struct XpArgs {
   // (gridDim.x = groups * wg) sweep that sample's tiles, statistics rows are (sample, workgroup)
   int wg;
   long gx, gy, gpb, gy2, gpb2;
+  // prologue (template PRO): the convolution's input is  act_a(bn_a(x)) [+ act_b(bn_b(x2))]  formed while the halo is
+  // staged -- the batch norm (+ ReLU) of the producing layer(s) and the U-Net's skip add (network.py:206-212, 695-697)
+  // without a pass of their own.  in_pa / in_pb: (groups, 3, Cin) = mean, rstd, beta, or nullptr = identity;
+  // out-of-volume lanes stay zero (the reference pads the finished tensor).
+  const float* x2;
+  const float* in_pa;
+  const float* in_pb;
+  int relu_a, relu_b;
 };
 
 __device__ __forceinline__ int xp_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
@@ -84,7 +92,7 @@ __device__ __forceinline__ int xp_swz(int a) { return a ^ (((a >> 8) & 1) << 5);
 // even / odd x runs make a stride-2 tap read 16 consecutive voxels as well); wavefront w owns output plane
 // w>>1, rows 2(w&1), 2(w&1)+1.  K steps:  C4 == 4: tap (kd,kh,kw) = (i/9, i/3%3, i%3), q = channel group;
 //                                        C4 == 2: (kd,kh) = (i/6, i/2%3), kw = 2*(i%2) + (q>>1) (kw 3 = zero), q&1.
-template <int C4, bool SIB>
+template <int C4, bool SIB, int PRO>
 __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int VB = C4 * 16;                      // bytes per voxel in LDS
@@ -159,6 +167,10 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
   const int xcd = lbk & 7, tslot = lbk >> 3;
   const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
+  const float* __restrict__ xg2 = (PRO == 2) ? p.x2 + (size_t)grp * p.gx : nullptr;
+  const float* __restrict__ ipa = (PRO >= 1 && p.in_pa) ? p.in_pa + (size_t)grp * 3 * p.Cin : nullptr;
+  const float* __restrict__ ipb = (PRO == 2 && p.in_pb) ? p.in_pb + (size_t)grp * 3 * p.Cin : nullptr;
+  const int c4t = tid % C4;                       // 256 % C4 == 0: every slot of this thread is channel group c4t
   float* __restrict__ yg = p.y + (size_t)grp * p.gy;
   float* __restrict__ y2g = p.y2 + (size_t)grp * p.gy2;
   const float* __restrict__ pbg = p.pbias ? p.pbias + (size_t)grp * p.gpb : nullptr;
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   // uniform description of the (tile, chunk) whose halo is being fetched
   struct PfTile {
     const float* xb;      // p.x + first channel of the chunk
+    const float* xb2;     // second source (PRO == 2)
     int org;              // element offset of the halo origin (may be negative: first layer of the halo is outside)
     unsigned lo, hi1;     // packed bounds: valid iff lo_f <= f <= hi_f in every field (hi1 = hi + 1 per byte)
   };
@@ -194,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     tile_origin(k, &z0, &y0, &x0);
     const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
     T.xb = xg + ch * CC;
+    T.xb2 = (PRO == 2) ? xg2 + ch * CC : nullptr;
     T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
     T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
     T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
@@ -201,6 +215,8 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     return T;
   };
   float4 pf[MAXS];
+  float4 pf2[PRO == 2 ? MAXS : 1];
+  unsigned vmask = 0;                          // PRO: which slots of the halo in flight lie inside the volume
   // slot i of the halo: lanes outside the volume (or past the last slot) read the 16 zero bytes instead
   auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
     const unsigned t1 = pg[i] - T.lo;          // byte f keeps its top bit iff f >= lo_f
@@ -208,6 +224,8 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
     const float* src = ok ? (T.xb + (T.org + goff[i])) : p.zeros;
     pf[i] = ld4(src);
+    if (PRO >= 1) vmask = (vmask & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+    if (PRO == 2) pf2[i] = ld4(ok ? (T.xb2 + (T.org + goff[i])) : p.zeros);
   };
 
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -246,6 +264,35 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
 
     __syncthreads();                       // every wave is done reading the previous stage's image
     DBG_T(0)
+    if (PRO >= 1) {
+      // the producers' batch norm (+ ReLU) and the skip add, on the way into LDS; this thread's slots all carry channel
+      // group c4t of the chunk, so one set of parameters serves them
+      const int cch = ch * CC + c4t * 4;
+      float4 ma, sa, ba, mb, sb, bb;
+      if (ipa) { ma = ld4(ipa + cch); sa = ld4(ipa + p.Cin + cch); ba = ld4(ipa + 2 * p.Cin + cch); }
+      if (PRO == 2 && ipb) { mb = ld4(ipb + cch); sb = ld4(ipb + p.Cin + cch); bb = ld4(ipb + 2 * p.Cin + cch); }
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        if ((vmask >> i) & 1u) {
+          float4 v = pf[i];
+          if (ipa) {
+            v.x = (v.x - ma.x) * sa.x + ba.x; v.y = (v.y - ma.y) * sa.y + ba.y;
+            v.z = (v.z - ma.z) * sa.z + ba.z; v.w = (v.w - ma.w) * sa.w + ba.w;
+            if (p.relu_a) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+          }
+          if (PRO == 2) {
+            float4 u = pf2[i];
+            if (ipb) {
+              u.x = (u.x - mb.x) * sb.x + bb.x; u.y = (u.y - mb.y) * sb.y + bb.y;
+              u.z = (u.z - mb.z) * sb.z + bb.z; u.w = (u.w - mb.w) * sb.w + bb.w;
+              if (p.relu_b) { u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f); }
+            }
+            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+          }
+          pf[i] = v;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < SLOTS) *reinterpret_cast<float4*>(smem + laddr[i]) = pf[i];
@@ -531,7 +578,7 @@ extern "C" int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed
   return ATVS_OK;
 }
 
-template <int C4, bool SIB>
+template <int C4, bool SIB, int PRO>
 static int launch_xp1(const XpArgs& a, long blocks, hipStream_t s) {
   size_t lds = (size_t)XP_HZ * XP_HY * XP_HXP * C4 * 16;
   // the attribute is per device: one flag per device ordinal of this process
@@ -539,12 +586,12 @@ static int launch_xp1(const XpArgs& a, long blocks, hipStream_t s) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xp_kernel<C4, SIB>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xp_kernel<C4, SIB, PRO>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv_xp_kernel<C4, SIB>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_xp_kernel<C4, SIB, PRO>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -556,8 +603,10 @@ static int launch_xp1(const XpArgs& a, long blocks, hipStream_t s) {
 extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias,
                                 float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
                                 int relu, const float* packed_w2, const float* plane_bias2, float* y2,
-                                double* stats_partial2, int ldy2, int y_coff2, atvs_stream_t stream) {
+                                double* stats_partial2, int ldy2, int y_coff2, const float* x2, const float* in_params,
+                                const float* in_params2, int in_relu, int in_relu2, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (in_params2 && !x2) return ATVS_ERR_ARG;
   const int C4 = xp_c4(Cin);
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || !C4) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
@@ -587,9 +636,21 @@ extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const flo
   a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
   const long blocks = (long)a.wg * groups;
   hipStream_t st = as_stream(stream);
+  a.x2 = x2; a.in_pa = in_params; a.in_pb = in_params2; a.relu_a = in_relu; a.relu_b = in_relu2;
+  const int pro = x2 ? 2 : (in_params ? 1 : 0);
   int rc;
-  if (packed_w2) rc = (C4 == 4) ? launch_xp1<4, true>(a, blocks, st) : launch_xp1<2, true>(a, blocks, st);
-  else rc = (C4 == 4) ? launch_xp1<4, false>(a, blocks, st) : launch_xp1<2, false>(a, blocks, st);
+  // instantiated prologue forms: none (every shape); single-source normalise (the refinement's concat -> 3dconv0_1 |
+  // 3dconv1_0, 32 channels + sibling); two-source normalise + add (the U-Net's stack inputs, 8 channels + sibling)
+  if (pro == 0) {
+    if (packed_w2) rc = (C4 == 4) ? launch_xp1<4, true, 0>(a, blocks, st) : launch_xp1<2, true, 0>(a, blocks, st);
+    else rc = (C4 == 4) ? launch_xp1<4, false, 0>(a, blocks, st) : launch_xp1<2, false, 0>(a, blocks, st);
+  } else if (pro == 1 && packed_w2 && C4 == 4) {
+    rc = launch_xp1<4, true, 1>(a, blocks, st);
+  } else if (pro == 2 && packed_w2 && C4 == 2) {
+    rc = launch_xp1<2, true, 2>(a, blocks, st);
+  } else {
+    return ATVS_ERR_ARG;
+  }
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

@@ -494,19 +494,29 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
     return (y, st) if want_stats else y
 
 
-def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None):
+def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None,
+                   prologue=None):
     """One atvs_conv_xp_f32 launch: x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
-    sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5."""
+    sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5.
+    prologue = (x2 | None, params | None, params2 | None, relu, relu2): the input is formed on load as
+    act(bn(x5)) [+ act(bn(x2))] (include/atvsnet_hip.h)."""
     G, D, H, W, Cin = x5.shape
     ldy = y.shape[-1]
     null = ctypes.c_void_p(0)
     sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null     # noqa: E731
     pk2, y2, y_coff2, sbuf2, pb2 = sibling if sibling is not None else (None, None, 0, None, None)
-    if _dev_ok(x5, y, bias, plane_bias, y2, pb2):
+    x2, ipa, ipb, relu_a, relu_b = prologue if prologue is not None else (None, None, None, False, False)
+    if x2 is not None and (tuple(x2.shape) != tuple(x5.shape) or not x2.is_contiguous()):
+        raise ValueError('conv_xp: the second source must have the shape of the first')
+    for ip in (ipa, ipb):
+        if ip is not None and (ip.numel() != G * 3 * Cin or not ip.is_contiguous()):
+            raise ValueError('conv_xp: prologue parameters must be (groups, 3, Cin)')
+    if _dev_ok(x5, y, bias, plane_bias, y2, pb2, x2, ipa, ipb):
         with _Timed(pk.key, x5.shape[1:], pk.cout + (16 if pk2 is not None else 0), G):
             _call('atvs_conv_xp_f32', _p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
                   ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
-                  sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _stream())
+                  sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _p(x2), _p(ipa), _p(ipb),
+                  int(bool(relu_a)), int(bool(relu_b)), _stream())
 
 
 def xp_blocks(D, H, W, groups=1):
@@ -1072,7 +1082,14 @@ def use_siblings(flag):
 def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None, groups=None):
     """The U-Net's two convolutions of one input in ONE launch: y = conv3x3x3(x, w) (8 channels, stride 1) and
     y2 = conv3x3x3(x, w2) (16 channels, stride 2, SAME), each with the partial moments of its output.
-    x (D,H,W,Cin) (groups=G: (G,D,H,W,Cin)), Cin % 8 == 0.  Returns (y, Stats), (y2, Stats)."""
+    x (D,H,W,Cin) (groups=G: (G,D,H,W,Cin)), Cin % 8 == 0.  Returns (y, Stats), (y2, Stats).
+    x may be a PendingBN / PendingSum for which siblings_prologue_ok() holds: the batch norm (+ ReLU) of its producer(s)
+    and the sum are then formed inside the launch, while the input is staged (no pass of their own)."""
+    prologue = None
+    if isinstance(x, LAZY):
+        if not siblings_prologue_ok(x):
+            raise ValueError('conv_siblings: this lazy input must be materialised first')
+        x, prologue = x.prologue()
     x5, nsp = _to5(x, groups, 'conv_siblings input')
     G, D, H, W, cin = x5.shape
     if nsp != 3 or not siblings_ok((D, H, W), cin, int(w_host.shape[-1]), int(w2_host.shape[-1])):
@@ -1093,7 +1110,10 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
         raise ValueError('conv_siblings %s: plane_bias %s' % (key, tuple(plane_bias.shape)))
     if plane_bias2 is not None and tuple(plane_bias2.shape) != lead + (H2, W2, 48):
         raise ValueError('conv_siblings %s: plane_bias2 %s' % (key2, tuple(plane_bias2.shape)))
-    conv_xp_launch(x5, pk, y, 0, None, False, sbuf, plane_bias, sibling=(pk2, y2, 0, sbuf2, plane_bias2))
+    if prologue is not None and prologue[0] is not None:
+        prologue = (_to5(prologue[0], groups, 'conv_siblings second source')[0],) + tuple(prologue[1:])
+    conv_xp_launch(x5, pk, y, 0, None, False, sbuf, plane_bias, sibling=(pk2, y2, 0, sbuf2, plane_bias2),
+                   prologue=prologue)
     return (y, st), (y2, st2)
 
 
@@ -1298,6 +1318,103 @@ class PendingBN(object):
         if self._final is None:
             self._final = bn_apply(self.raw, self.params, self.relu)
         return self._final
+
+    def prologue(self):
+        """(tensor, (None, params, None, relu, False)): this layer as the normalise-on-load input of a convolution."""
+        if self._final is not None:
+            return self._final, None
+        return self.raw, (None, self.params, None, self.relu, False)
+
+
+class PendingSum(object):
+    """tf.add_n of two items (dense tensors or PendingBNs) that has not been formed yet: a consumer that can add on
+    load (conv_siblings) takes the items, any other consumer calls materialize() (= ops.bn_add / add_n)."""
+
+    def __init__(self, items):
+        if len(items) != 2 or any(tuple(t.shape) != tuple(items[0].shape) for t in items):
+            raise ValueError('PendingSum: two items of one shape')
+        self.items = list(items)
+        self._final = None
+        self.device = items[0].device
+
+    @property
+    def shape(self):
+        return tuple(self.items[0].shape)
+
+    def dim(self):
+        return len(self.shape)
+
+    @property
+    def is_meta(self):
+        return any(getattr(t, 'is_meta', False) for t in self.items)
+
+    def materialize(self):
+        if self._final is None:
+            if any(isinstance(t, PendingBN) and t._final is None for t in self.items) and self.shape[-1] % 4 == 0:
+                self._final = bn_add(self.items)
+            else:
+                self._final = add_n([t.materialize() if isinstance(t, PendingBN) else t for t in self.items])
+        return self._final
+
+    def prologue(self):
+        if self._final is not None:
+            return self._final, None
+        (a, pa), (b, pb) = (t.prologue() if isinstance(t, PendingBN) else (t, None) for t in self.items)
+        return a, (b, pa[1] if pa else None, pb[1] if pb else None, bool(pa and pa[3]), bool(pb and pb[3]))
+
+
+class LazySlice(object):
+    """Channels [lo, hi) of a lazy layer (the stems inside the refinement's pending concat)."""
+
+    def __init__(self, parent, lo, hi):
+        self.parent, self.lo, self.hi = parent, int(lo), int(hi)
+        self.device = parent.device
+
+    @property
+    def shape(self):
+        return tuple(self.parent.shape[:-1]) + (self.hi - self.lo,)
+
+    def dim(self):
+        return len(self.shape)
+
+    @property
+    def is_meta(self):
+        return self.parent.is_meta
+
+    def materialize(self):
+        return self.parent.materialize()[..., self.lo:self.hi]
+
+
+LAZY = (PendingBN, PendingSum, LazySlice)
+
+_USE_PROLOGUE = True
+
+
+def use_prologue(flag):
+    """Testing / A-B hook: normalise-on-load / add-on-load in the x-pair convolution (else the inputs are materialised)."""
+    global _USE_PROLOGUE
+    _USE_PROLOGUE = bool(flag)
+
+
+def siblings_prologue_ok(src):
+    """Can conv_siblings take this lazy input as it is (the kernel forms it while staging)?  Built forms: one pending
+    batch norm with Cin % 16 == 0 (the refinement's concat); a sum of two with Cin % 16 == 8 (the U-Net's stack inputs)."""
+    if not _USE_PROLOGUE or _FORCE_IMPL is not None or not _USE_XP1W:
+        return False
+    if isinstance(src, PendingBN):
+        return src._final is None and src.shape[-1] % 16 == 0 and src.raw.is_contiguous()
+    if isinstance(src, PendingSum):
+        if src._final is not None or src.shape[-1] % 16 != 8:
+            return False
+        gs = set()
+        for t in src.items:
+            raw = t.raw if isinstance(t, PendingBN) else t
+            if isinstance(t, PendingBN) and t._final is None:
+                gs.add(_param_groups(t.params))
+            if not raw.is_contiguous():
+                return False
+        return len(gs) <= 1
+    return False
 
 
 def bn_add(items):

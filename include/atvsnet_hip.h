@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 8
+#define ATVS_ABI_VERSION 9
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -241,12 +241,18 @@ int atvs_conv_xp_pack_size(int Cin, long* packed_floats);
 int atvs_conv_xp_pack(const float* w, int Cin, float* packed);
 int atvs_conv_xp_pack_sibling_size(int Cin, long* packed_floats);
 int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed);
-/* groups >= 1 independent samples stacked on the leading axis of every tensor; atvs_conv_xp_grid = workgroups PER SAMPLE. */
+/* groups >= 1 independent samples stacked on the leading axis of every tensor; atvs_conv_xp_grid = workgroups PER SAMPLE.
+ * Prologue (normalise-on-load / add-on-load): with in_params != NULL the convolution's input is relu?((x - mean) * rstd +
+ * beta) per sample, parameters (groups, 3, Cin) -- the producer's training-mode batch norm, network.py:206-212 -- and with
+ * x2 != NULL the SUM of two such terms (in_params2 for x2; either parameter block may be NULL = that term as is): the
+ * U-Net's skip add (network.py:695-697) formed while the halo is staged.  Out-of-volume taps stay zero.  Built for the
+ * shapes the path has: in_params with Cin % 16 == 0 and a sibling; x2 with Cin % 16 == 8 and a sibling (else ATVS_ERR_ARG). */
 long atvs_conv_xp_grid(int D, int H, int W, int groups);
 int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias, float* y,
                      double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
-                     int y_coff2, atvs_stream_t stream);
+                     int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
+                     int in_relu2, atvs_stream_t stream);
 
 /* 3x3 stride-1 SAME 2-D convolution (dilation 1, 2 or 4) of wide feature maps, LDS-tiled (conv2d_lds.hip): the
  * heavy layers of the feature towers -- the bottlenecks' conv2 (slim.conv2d, network.py:585-587), conv0_1 / conv0_2 /

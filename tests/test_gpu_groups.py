@@ -140,3 +140,85 @@ def test_stem_kernel_matches_oracle(cuda, cin, shape, G):
     finally:
         ops.use_stem(True)
     assert float((y2.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+def _pending(x, w, key, G, relu=True):
+    """A raw convolution output with its pending training-mode batch norm (what conv_bn(defer_bn=True) hands on)."""
+    from atvsnet_amd import ops
+    y, st = ops.conv(x, key, w, want_stats=True, groups=G)
+    return ops.PendingBN(y, ops.bn_params(st, y.shape[-1], y), relu)
+
+
+@pytest.mark.parametrize('G,shape', [(1, (16, 32, 48)), (3, (12, 24, 40)), (2, (9, 21, 37))])
+def test_siblings_add_on_load_is_bitwise_the_materialised_sum(cuda, G, shape):
+    """The U-Net's stack input I_b = bn_relu(conv_6_0) + bn_relu(conv_0_1) (reference cnn_wrapper/atvsnet.py:38-39,
+    network.py:695-697) formed inside the x-pair launch: same values as bn_add followed by the plain launch."""
+    from atvsnet_amd import ops
+    xa, xb = _rand((G,) + shape + (8,), 1).to(cuda), _rand((G,) + shape + (8,), 2).to(cuda)
+    wa, wb = (_rand((3, 3, 3, 8, 8), 3) * 0.2).numpy(), (_rand((3, 3, 3, 8, 8), 4) * 0.2).numpy()
+    w8, w16 = (_rand((3, 3, 3, 8, 8), 5) * 0.1).numpy(), (_rand((3, 3, 3, 8, 16), 6) * 0.1).numpy()
+    for dense_second in (False, True):
+        a = _pending(xa, wa, ('pa', G), G)
+        b = xb.clone() if dense_second else _pending(xb, wb, ('pb', G), G)
+        lazy = ops.PendingSum([a, b])
+        assert ops.siblings_prologue_ok(lazy)
+        (y, st), (y2, st2) = ops.conv_siblings(lazy, 'pl8', w8, 'pl16', w16, groups=G)
+        dense = ops.PendingSum([a, b]).materialize()
+        (r, rt), (r2, rt2) = ops.conv_siblings(dense, 'pl8', w8, 'pl16', w16, groups=G)
+        assert torch.equal(y, r) and torch.equal(y2, r2)
+        assert torch.equal(ops.bn_params(st, 8, y), ops.bn_params(rt, 8, r))
+        assert torch.equal(ops.bn_params(st2, 16, y2), ops.bn_params(rt2, 16, r2))
+
+
+@pytest.mark.parametrize('G,shape', [(1, (16, 32, 48)), (4, (10, 20, 36))])
+def test_siblings_normalise_on_load_is_bitwise_the_materialised_input(cuda, G, shape):
+    """The refinement's 32-channel concat with its pending batch norm + ReLU (reference cnn_wrapper/atvsnet.py:300-316)
+    normalised while the x-pair launch stages it; out-of-volume taps must read post-activation zeros."""
+    from atvsnet_amd import ops
+    x = _rand((G,) + shape + (32,), 7).to(cuda) + 0.5
+    params = torch.stack([_rand((G, 32), 8) * 0.3, _rand((G, 32), 9).abs() + 0.5, _rand((G, 32), 10) + 0.7], 1).to(cuda)
+    params = params.contiguous() if G > 1 else params[0].contiguous()
+    w8, w16 = (_rand((3, 3, 3, 32, 8), 5) * 0.1).numpy(), (_rand((3, 3, 3, 32, 16), 6) * 0.1).numpy()
+    lazy = ops.PendingBN(x.clone(), params, True)
+    assert ops.siblings_prologue_ok(lazy)
+    (y, st), (y2, st2) = ops.conv_siblings(lazy, 'nl8', w8, 'nl16', w16, groups=G)
+    assert lazy._final is None                       # consumed raw
+    dense = ops.bn_apply(x.clone(), params, True)
+    (r, rt), (r2, rt2) = ops.conv_siblings(dense, 'nl8', w8, 'nl16', w16, groups=G)
+    assert torch.equal(y, r) and torch.equal(y2, r2)
+    assert torch.equal(st.partial, rt.partial) and torch.equal(st2.partial, rt2.partial)
+    # a lazy input of a shape the kernel has no prologue for is refused (callers materialise it)
+    bad = ops.PendingBN(_rand((G,) + shape + (8,), 1).to(cuda), params[..., :8].contiguous(), True)
+    assert not ops.siblings_prologue_ok(bad)
+    with pytest.raises(ValueError):
+        ops.conv_siblings(bad, 'pl8', w8[:, :, :, :8], 'pl16', w16[:, :, :, :8], groups=G)
+
+
+def test_networks_with_prologue_equal_materialised_inputs(cuda, weights):
+    """StackedUNet_prob and CostVolRefineNet with add- / normalise-on-load against the same networks with the inputs
+    materialised first (ops.use_prologue(False)): every output bit for bit."""
+    from atvsnet_amd import ops
+    from atvsnet_amd.cnn_wrapper.atvsnet import StackedUNet_prob, CostVolRefineNet
+    G = 2
+    cost = _rand((G, 16, 32, 48, 64), 3).to(cuda)
+    chan = 16                                        # the shallow features (model.py:309-316)
+    photo = ops.SplitVolume(_rand((G, 16, 32, 48, chan), 20).to(cuda), _rand((G, 32, 48, 2 * chan), 21).to(cuda),
+                            [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
+    geo = ops.SplitVolume(_rand((G, 16, 32, 48, 2), 30).to(cuda), _rand((G, 32, 48, 2), 31).to(cuda),
+                          [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
+    res = {}
+    for flag in (True, False):
+        ops.use_prologue(flag)
+        try:
+            net = StackedUNet_prob({'data': cost}, is_training=True, independent_samples=True)
+            ref = CostVolRefineNet({'photo_group': photo, 'geo_group': geo,
+                                    'prob_vol': _rand((G, 16, 32, 48, 1), 40).to(cuda),
+                                    'vis_hull': _rand((G, 16, 32, 48, 1), 41).to(cuda)}, is_training=True,
+                                   independent_samples=True)
+            res[flag] = [net.get_output_by_name('conv_b2_6_1').clone(), net.get_output_by_name('conv_b2_6_2').clone(),
+                         ref.get_output().clone(), ref.get_output_by_name('global_refine_geo_3dconv').clone(),
+                         ref.get_output_by_name('global_refine_concat').clone()]
+        finally:
+            ops.use_prologue(True)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)
