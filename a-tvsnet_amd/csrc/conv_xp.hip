@@ -228,6 +228,53 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     if (PRO == 2) pf2[i] = ld4(ok ? (T.xb2 + (T.org + goff[i])) : p.zeros);
   };
 
+  // PRO: the producers' batch norm (+ ReLU) and the skip add, applied to a halo slot between its arrival and its LDS
+  // write.  Every slot of this thread carries channel group c4t of the chunk, so one set of parameters per stage serves
+  // them; out-of-volume slots stay zero.  Arithmetic = bn_apply / bn_add (norm.hip): (x - mean) * rstd + beta, then max.
+  struct Par { float4 ma, sa, ba, mb, sb, bb; };
+  // branch-free throughout (a branch inside the unrolled K loop would split its scheduling region): absent parameters
+  // read the 16 zero bytes and are deselected below; no ReLU = a floor of -inf
+  const bool has_a = PRO >= 1 && ipa != nullptr, has_b = PRO == 2 && ipb != nullptr;
+  const float floor_a = p.relu_a ? 0.f : -__builtin_huge_valf(), floor_b = p.relu_b ? 0.f : -__builtin_huge_valf();
+  auto load_par = [&](int chunk) __attribute__((always_inline)) {
+    Par P;
+    const int cch = chunk * CC + c4t * 4;
+    const int sa = has_a ? p.Cin : 0, sb = has_b ? p.Cin : 0;
+    const float* a = has_a ? ipa + cch : p.zeros;
+    P.ma = ld4(a); P.sa = ld4(a + sa); P.ba = ld4(a + 2 * sa);
+    if (PRO == 2) {
+      const float* b = has_b ? ipb + cch : p.zeros;
+      P.mb = ld4(b); P.sb = ld4(b + sb); P.bb = ld4(b + 2 * sb);
+    }
+    return P;
+  };
+  // two channels per instruction (v_pk_add_f32 / v_pk_mul_f32: the same IEEE operations as the scalar forms)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto bn2 = [&](f32x2 v, f32x2 m, f32x2 sc, f32x2 be, float lo, bool has) __attribute__((always_inline)) {
+    f32x2 t = (v - m) * sc + be;
+    t.x = fmaxf(t.x, lo);
+    t.y = fmaxf(t.y, lo);
+    t.x = has ? t.x : v.x;
+    t.y = has ? t.y : v.y;
+    return t;
+  };
+  auto xform = [&](int i, const Par& P) __attribute__((always_inline)) {
+    const bool ok = (vmask >> i) & 1u;
+    f32x2 lo = {pf[i].x, pf[i].y}, hi = {pf[i].z, pf[i].w};
+    lo = bn2(lo, (f32x2){P.ma.x, P.ma.y}, (f32x2){P.sa.x, P.sa.y}, (f32x2){P.ba.x, P.ba.y}, floor_a, has_a);
+    hi = bn2(hi, (f32x2){P.ma.z, P.ma.w}, (f32x2){P.sa.z, P.sa.w}, (f32x2){P.ba.z, P.ba.w}, floor_a, has_a);
+    if (PRO == 2) {
+      f32x2 ul = {pf2[i].x, pf2[i].y}, uh = {pf2[i].z, pf2[i].w};
+      ul = bn2(ul, (f32x2){P.mb.x, P.mb.y}, (f32x2){P.sb.x, P.sb.y}, (f32x2){P.bb.x, P.bb.y}, floor_b, has_b);
+      uh = bn2(uh, (f32x2){P.mb.z, P.mb.w}, (f32x2){P.sb.z, P.sb.w}, (f32x2){P.bb.z, P.bb.w}, floor_b, has_b);
+      lo += ul;
+      hi += uh;
+    }
+    pf[i] = make_float4(ok ? lo.x : 0.f, ok ? lo.y : 0.f, ok ? hi.x : 0.f, ok ? hi.y : 0.f);
+  };
+  // K steps between a slot's request and its transform (the steps of the sibling loop count on after the main loop's)
+  constexpr int XLAG = (C4 == 4) ? 4 : 5;
+  static_assert(PRO == 0 || (MAXS - 1 + XLAG <= JC + J2 - 1), "every slot is transformed inside the K loops");
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);        // bias of this lane's 4 output channels
   if (p.bias) bv = ld4(p.bias + (q & 1) * 4);
@@ -264,34 +311,11 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
 
     __syncthreads();                       // every wave is done reading the previous stage's image
     DBG_T(0)
-    if (PRO >= 1) {
-      // the producers' batch norm (+ ReLU) and the skip add, on the way into LDS; this thread's slots all carry channel
-      // group c4t of the chunk, so one set of parameters serves them
-      const int cch = ch * CC + c4t * 4;
-      float4 ma, sa, ba, mb, sb, bb;
-      if (ipa) { ma = ld4(ipa + cch); sa = ld4(ipa + p.Cin + cch); ba = ld4(ipa + 2 * p.Cin + cch); }
-      if (PRO == 2 && ipb) { mb = ld4(ipb + cch); sb = ld4(ipb + p.Cin + cch); bb = ld4(ipb + 2 * p.Cin + cch); }
+    // PRO: the halo of stage 0 is transformed here; every later one during the K loop of the stage before it
+    if (PRO >= 1 && stage == 0) {
+      const Par P0 = load_par(0);
 #pragma unroll
-      for (int i = 0; i < MAXS; ++i) {
-        if ((vmask >> i) & 1u) {
-          float4 v = pf[i];
-          if (ipa) {
-            v.x = (v.x - ma.x) * sa.x + ba.x; v.y = (v.y - ma.y) * sa.y + ba.y;
-            v.z = (v.z - ma.z) * sa.z + ba.z; v.w = (v.w - ma.w) * sa.w + ba.w;
-            if (p.relu_a) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-          }
-          if (PRO == 2) {
-            float4 u = pf2[i];
-            if (ipb) {
-              u.x = (u.x - mb.x) * sb.x + bb.x; u.y = (u.y - mb.y) * sb.y + bb.y;
-              u.z = (u.z - mb.z) * sb.z + bb.z; u.w = (u.w - mb.w) * sb.w + bb.w;
-              if (p.relu_b) { u.x = fmaxf(u.x, 0.f); u.y = fmaxf(u.y, 0.f); u.z = fmaxf(u.z, 0.f); u.w = fmaxf(u.w, 0.f); }
-            }
-            v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
-          }
-          pf[i] = v;
-        }
-      }
+      for (int i = 0; i < MAXS; ++i) xform(i, P0);
     }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
@@ -339,6 +363,8 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
         b2[i & 1][t] = *reinterpret_cast<const float4*>(smem + base2[xs] + (rowoff + 2 * t) * ROWB);
     };
     float4 w2[SIB ? J2 : 1];
+    Par Pn;
+    if (PRO >= 1) Pn = load_par(min(stage + 1, nstage - 1) % p.nchunk);
     request_b(0);
     asm volatile("" ::: "memory");
 #pragma unroll
@@ -368,6 +394,9 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
 #pragma unroll
         for (int t = 0; t < XP_TY; ++t)
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w[j], s), f4get(b[j & 1][t], s), acc[t], 0, 0, 0);
+      // PRO: the slot requested XLAG steps ago has arrived; its transform shares this step's scheduling region with the
+      // MFMAs above (VALU in their shadow)
+      if (PRO >= 1 && j >= XLAG && j - XLAG < MAXS) xform(j - XLAG, Pn);
     }
     if (SIB) {
       // ---- the sibling's K steps on the same image (weights and the first fragments are already on their way)
@@ -382,6 +411,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             acc2[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w2[i], s), f4get(b2[i & 1][t], s), acc2[t], 0, 0, 0);
+        if (PRO >= 1 && JC + i - XLAG < MAXS) xform(JC + i - XLAG, Pn);
       }
     }
     DBG_T(4)
