@@ -26,7 +26,21 @@
 //            (36 virtual taps instead of 27): 3/4 of the MFMA work is useful instead of 1/2, a third fewer
 //            MFMAs per voxel.  The LDS image keeps even and odd x in separate runs so a tap read is
 //            still 16 voxels x 64 B contiguous.
+#include <type_traits>
+
 #include "conv_common.h"
+
+// Development build (-DATVS_TILED_DEBUG): per-wavefront cycle counts of the phases, read back with
+// atvs_debug_read_tiled (tools_dev/phase_times.py --tiled).
+#ifdef ATVS_TILED_DEBUG
+__device__ unsigned long long atvs_dbg_tiled[4096 * 8];
+extern "C" int atvs_debug_read_tiled(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(atvs_dbg_tiled), sizeof(atvs_dbg_tiled));
+}
+#define TDBG(i) { unsigned long long t_ = clock64(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; }
+#else
+#define TDBG(i)
+#endif
 
 #define TILE_TZ 4
 #define TILE_TX 16
@@ -125,6 +139,22 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
 #pragma unroll
     for (int k = 0; k < 4; ++k) ssum[n][k] = ssq[n][k] = 0.f;
 
+  // channel part of this lane's output offsets, per 16-channel tile: plain = first channel + y_coff; transposed
+  // convolution = parity-class displacement + real channel + y_coff; ~0 = no such channel
+  unsigned ycoff[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) {
+    const int co = (nsi * NT + n) * 16 + 4 * q;
+    if (co >= p.Cout) {
+      ycoff[n] = ~0u;
+    } else if (p.cls_cout) {
+      const int cls = p.cls_base + co / p.cls_cout, cr = co % p.cls_cout;
+      ycoff[n] = (((unsigned)(cls >> 2) * p.Hy + ((cls >> 1) & 1)) * p.Wy + (cls & 1)) * p.ldy + p.ycoff + cr;
+    } else {
+      ycoff[n] = (unsigned)(p.ycoff + co);
+    }
+  }
+
   int vbase[TY];
 #pragma unroll
   for (int t = 0; t < TY; ++t) vbase[t] = ((wave * HY + t) * HX + r) * VB;   // XP: r = pair index within the even/odd run
@@ -142,6 +172,22 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
     *z0 = (rest / p.tiles_y) * TILE_TZ;
   };
 
+  // Halo slot s = tid + 256 i of this thread = (zz, yy, xx, channel group c4) of the halo; the coordinates are packed once
+  // (15 bits: zz << 12 | yy << 8 | xx << 2 | c4, two slots per register) so that a stage's address generation is a few
+  // shifts and 24-bit multiply-adds per slot instead of six divisions by constants and three full multiplies.
+  unsigned slot_pk[(MAXS + 1) / 2];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    const int s = min(tid + i * 256, SLOTS - 1);            // past the end: a duplicate (never written to LDS)
+    const int c4 = s % C4, v = s / C4;
+    const int xx = v % HX, v2 = v / HX;
+    const int yy = v2 % HY, zz = v2 / HY;
+    const unsigned code = (unsigned)(zz << 12 | yy << 8 | xx << 2 | c4);
+    if (i & 1) slot_pk[i >> 1] |= code << 16;
+    else slot_pk[i >> 1] = code;
+  }
+  const unsigned SY = (unsigned)p.Wi * p.Cin, SZ = (unsigned)p.Hi * SY;     // elements per row / plane
+
   float4 pf[MAXS];
   auto prefetch = [&](int stage) {
     int k = stage / p.nchunk, ch = stage - k * p.nchunk;
@@ -153,36 +199,26 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
     const bool interior = FULL && z0 >= 1 && y0 >= 1 && x0 >= 1 && z0 + TILE_TZ < p.Di && y0 + TY < p.Hi && x0 + TXV < p.Wi;
     const float* xb = p.x + (size_t)grp * p.gx + cbase;
     const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
-    if (interior) {
-      const unsigned org = (unsigned)(((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin);
-#pragma unroll
-      for (int i = 0; i < MAXS; ++i) {
-        int s = tid + i * 256;
-        int c4 = s % C4, v = s / C4;
-        int xx = v % HX, v2 = v / HX;
-        int yy = v2 % HY, zz = v2 / HY;
-        unsigned off = org + (unsigned)(((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4);
-        if (s < SLOTS) pf[i] = ld4(xb + off);
-      }
-      return;
-    }
+    // wrap-around arithmetic: org may be "negative" for border tiles, the sum is right whenever the slot is in bounds
+    const unsigned org = (unsigned)gz0 * SZ + (unsigned)gy0 * SY + (unsigned)gx0 * (unsigned)p.Cin;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
-      int s = tid + i * 256;
-      int c4 = s % C4, v = s / C4;
-      int xx = v % HX, v2 = v / HX;
-      int yy = v2 % HY, zz = v2 / HY;
-      int gz = gz0 + zz, gy = gy0 + yy, gx = gx0 + xx;
+      const unsigned code = (i & 1) ? (slot_pk[i >> 1] >> 16) : (slot_pk[i >> 1] & 0xffffu);
+      const unsigned zz = code >> 12, yy = (code >> 8) & 15u, xx = (code >> 2) & 63u, c4 = code & 3u;
+      const unsigned off = org + zz * SZ + __umul24(yy, SY) + __umul24(xx, (unsigned)p.Cin) + c4 * 4u;
+      if (interior) {
+        pf[i] = ld4(xb + off);
+        continue;
+      }
       float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-      bool ok = (s < SLOTS) && ((unsigned)gz < (unsigned)p.Di) && ((unsigned)gy < (unsigned)p.Hi) &&
-                ((unsigned)gx < (unsigned)p.Wi);
+      const bool ok = ((unsigned)(gz0 + (int)zz) < (unsigned)p.Di) && ((unsigned)(gy0 + (int)yy) < (unsigned)p.Hi) &&
+                      ((unsigned)(gx0 + (int)xx) < (unsigned)p.Wi);
       if (ok) {
-        unsigned off = (unsigned)(((gz * p.Hi + gy) * p.Wi + gx) * p.Cin + c4 * 4);
         const float* src = xb + off;
         if (FULL) {
           val = ld4(src);
         } else {
-          int left = p.Cin - cbase - c4 * 4;        // real channels from here
+          int left = p.Cin - cbase - (int)c4 * 4;        // real channels from here
           if (left > 0) val.x = src[0];
           if (left > 1) val.y = src[1];
           if (left > 2) val.z = src[2];
@@ -195,9 +231,14 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
 
   if (nstage > 0) prefetch(0);
   __syncthreads();   // s_tab
+#ifdef ATVS_TILED_DEBUG
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
 
   for (int stage = 0; stage < nstage; ++stage) {
     const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    TDBG(6)
     if (ch == 0) {
 #pragma unroll
       for (int t = 0; t < TY; ++t)
@@ -205,6 +246,7 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
         for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();                       // every wave is done reading the previous stage's image
+    TDBG(0)
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       int s = tid + i * 256;
@@ -220,75 +262,174 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
         *reinterpret_cast<float4*>(smem + a) = pf[i];
       }
     }
+    TDBG(1)
     __syncthreads();
-    if (stage + 1 < nstage) prefetch(stage + 1);   // in flight during this stage's MFMAs
+    TDBG(2)
 
-    // ---- K steps of this chunk.  Operands are software-pipelined by hand: the LDS fragments of step
-    // j+1 and the packed weights of step j+2 (L2, ~600+ cycles) are requested at the top of step j,
-    // so that neither latency sits between two MFMAs.  Indices past the end are clamped (harmless re-reads)
-    // to keep the body straight-line.
+    // ---- K steps of this chunk.  Operands are software-pipelined by hand through register RINGS: weights W[j % 3]
+    // (L2, ~600+ cycles), LDS fragments B[j % 2].  Order of the memory requests (the vector-memory counter retires in
+    // order, so a wait for one load waits for every older one):
+    //   weights of steps 0, 1, 2  ->  the next stage's halo (HBM / L2, the longest latency)  ->  in step j, AFTER its
+    //   MFMAs are issued, the weights of step j + 3 into the ring slot step j just freed.
+    // Steps 0..2 therefore never wait for the halo, and step 3 waits for loads that are three steps old.  The loop body
+    // is written out for 6 consecutive steps (lcm of the ring periods) so that every ring index is a compile-time
+    // constant: no register copies (a copy of a register with a load in flight is a wait), no moves.  The trip count is
+    // a run-time value and MFMAs are convergent operations, so the compiler may not unroll the loop itself.
     const float4* wch = wp + ((size_t)ch * p.Jc * p.nt_total + nsi * NT) * 64;
     const int wstep = p.nt_total * 64;                                          // float4 per K step
     const int jlast = p.Jc - 1;
-    float4 w_cur[NT], w_nx1[NT], b_cur[TY];
-    {
-      int off = s_tab[q];
-      const int j1 = min(1, jlast);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        w_cur[n] = wch[n * 64 + lane];
-        w_nx1[n] = wch[(size_t)j1 * wstep + n * 64 + lane];
-      }
-#pragma unroll
-      for (int t = 0; t < TY; ++t) {
-        int a = vbase[t] + off;
-        if (SWZ) a = lds_swz(a);
-        b_cur[t] = *reinterpret_cast<const float4*>(lds + a);
-      }
-    }
-    for (int j = 0; j < p.Jc; ++j) {
-      float4 w_nx2[NT], b_nxt[TY];
-      const int off_n = s_tab[min(j + 1, jlast) * 4 + q];
-      const int j2 = min(j + 2, jlast);
-#pragma unroll
-      for (int n = 0; n < NT; ++n) w_nx2[n] = wch[(size_t)j2 * wstep + n * 64 + lane];
-#pragma unroll
-      for (int t = 0; t < TY; ++t) {
-        int a = vbase[t] + off_n;
-        if (SWZ) a = lds_swz(a);
-        b_nxt[t] = *reinterpret_cast<const float4*>(lds + a);
-      }
-      // output-channel tiles whose weights of this K step are all zero are skipped (the fused transposed
-      // convolution's (offset, parity class) blocks: 42-56 % of its tile-steps are non-zero); the mask is uniform
-      // (only instantiations with >= 2 tiles test it: the narrow ones have no structural zeros and no registers to spare)
-      if constexpr (NT >= 2) {
-        const unsigned msk = (unsigned)__builtin_amdgcn_readfirstlane(s_tab[p.Jc * 4 + j]) >> (nsi * NT);
-#pragma unroll
+    if constexpr (TY == 4) {
+      float4 W[3][NT], B[2][TY];
+      int msk_n = 0;
+      {
+        const int j1 = min(1, jlast), j2 = min(2, jlast);
+  #pragma unroll
         for (int n = 0; n < NT; ++n) {
-          if (!((msk >> n) & 1u)) continue;
-#pragma unroll
-          for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int t = 0; t < TY; ++t)
-              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
+          W[0][n] = wch[n * 64 + lane];
+          W[1][n] = wch[(size_t)j1 * wstep + n * 64 + lane];
+          W[2][n] = wch[(size_t)j2 * wstep + n * 64 + lane];
         }
-      } else {
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-          for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int t = 0; t < TY; ++t)
-              acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
       }
-#pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        w_cur[n] = w_nx1[n];
-        w_nx1[n] = w_nx2[n];
+      if (stage + 1 < nstage) prefetch(stage + 1);   // in flight during this stage's MFMAs
+      TDBG(3)
+      {
+        int off = s_tab[q];
+        if (NT >= 2) msk_n = s_tab[p.Jc * 4];
+  #pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          int a = vbase[t] + off;
+          if (SWZ) a = lds_swz(a);
+          B[0][t] = *reinterpret_cast<const float4*>(lds + a);
+        }
       }
-#pragma unroll
-      for (int t = 0; t < TY; ++t) b_cur[t] = b_nxt[t];
+      auto kstep = [&](int j, auto WC, auto BC) __attribute__((always_inline)) {
+        constexpr int wc = decltype(WC)::value, bc = decltype(BC)::value, bn = bc ^ 1;
+        const int msk_c = msk_n;
+        // the next step's tile mask is requested ahead of the fragments (LDS returns in order)
+        if (NT >= 2) msk_n = s_tab[p.Jc * 4 + min(j + 1, jlast)];
+        const int off_n = s_tab[min(j + 1, jlast) * 4 + q];
+  #pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          int a = vbase[t] + off_n;
+          if (SWZ) a = lds_swz(a);
+          B[bn][t] = *reinterpret_cast<const float4*>(lds + a);
+        }
+        // output-channel tiles whose weights of this K step are all zero are skipped (the fused transposed
+        // convolution's (offset, parity class) blocks: 42-56 % of its tile-steps are non-zero); the mask is uniform
+        // (only instantiations with >= 2 tiles test it: the narrow ones have no structural zeros)
+        if constexpr (NT >= 2) {
+          const unsigned msk = (unsigned)__builtin_amdgcn_readfirstlane(msk_c) >> (nsi * NT);
+  #pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (!((msk >> n) & 1u)) continue;
+  #pragma unroll
+            for (int s = 0; s < 4; ++s)
+  #pragma unroll
+              for (int t = 0; t < TY; ++t)
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(W[wc][n], s), f4get(B[bc][t], s), acc[t][n], 0, 0, 0);
+          }
+        } else {
+  #pragma unroll
+          for (int s = 0; s < 4; ++s)
+  #pragma unroll
+            for (int n = 0; n < NT; ++n)
+  #pragma unroll
+              for (int t = 0; t < TY; ++t)
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(W[wc][n], s), f4get(B[bc][t], s), acc[t][n], 0, 0, 0);
+        }
+        // the ring slot of this step is free: weights of step j + 3 (clamped: a harmless re-read past the end)
+        const int j3 = min(j + 3, jlast);
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) W[wc][n] = wch[(size_t)j3 * wstep + n * 64 + lane];
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      int j = 0;
+      for (; j + 6 <= p.Jc; j += 6) {
+        kstep(j, I0{}, I0{});
+        kstep(j + 1, I1{}, I1{});
+        kstep(j + 2, I2{}, I0{});
+        kstep(j + 3, I0{}, I1{});
+        kstep(j + 4, I1{}, I0{});
+        kstep(j + 5, I2{}, I1{});
+      }
+      {
+        const int rem = p.Jc - j;            // 0..5 trailing steps, same ring positions
+        if (rem > 0) kstep(j, I0{}, I0{});
+        if (rem > 1) kstep(j + 1, I1{}, I1{});
+        if (rem > 2) kstep(j + 2, I2{}, I0{});
+        if (rem > 3) kstep(j + 3, I0{}, I1{});
+        if (rem > 4) kstep(j + 4, I1{}, I0{});
+      }
+    } else {
+      // 8-row tiles: the ring form does not fit 256 registers (two workgroups per CU); their K loops are long (27 steps
+      // of 32 MFMAs), so the rotating-copy form's one-step effective look-ahead is amortised
+      float4 w_cur[NT], w_nx1[NT], b_cur[TY];
+      {
+        const int j1 = min(1, jlast);
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          w_cur[n] = wch[n * 64 + lane];
+          w_nx1[n] = wch[(size_t)j1 * wstep + n * 64 + lane];
+        }
+      }
+      if (stage + 1 < nstage) prefetch(stage + 1);   // in flight during this stage's MFMAs (after the first weights: the
+      TDBG(3)                                        // vector-memory counter retires in order)
+      {
+        int off = s_tab[q];
+  #pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          int a = vbase[t] + off;
+          if (SWZ) a = lds_swz(a);
+          b_cur[t] = *reinterpret_cast<const float4*>(lds + a);
+        }
+      }
+      for (int j = 0; j < p.Jc; ++j) {
+        float4 w_nx2[NT], b_nxt[TY];
+        const int off_n = s_tab[min(j + 1, jlast) * 4 + q];
+        const int j2 = min(j + 2, jlast);
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) w_nx2[n] = wch[(size_t)j2 * wstep + n * 64 + lane];
+  #pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          int a = vbase[t] + off_n;
+          if (SWZ) a = lds_swz(a);
+          b_nxt[t] = *reinterpret_cast<const float4*>(lds + a);
+        }
+        // output-channel tiles whose weights of this K step are all zero are skipped (the fused transposed
+        // convolution's (offset, parity class) blocks: 42-56 % of its tile-steps are non-zero); the mask is uniform
+        // (only instantiations with >= 2 tiles test it: the narrow ones have no structural zeros and no registers to spare)
+        if constexpr (NT >= 2) {
+          const unsigned msk = (unsigned)__builtin_amdgcn_readfirstlane(s_tab[p.Jc * 4 + j]) >> (nsi * NT);
+  #pragma unroll
+          for (int n = 0; n < NT; ++n) {
+            if (!((msk >> n) & 1u)) continue;
+  #pragma unroll
+            for (int s = 0; s < 4; ++s)
+  #pragma unroll
+              for (int t = 0; t < TY; ++t)
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
+          }
+        } else {
+  #pragma unroll
+          for (int s = 0; s < 4; ++s)
+  #pragma unroll
+            for (int n = 0; n < NT; ++n)
+  #pragma unroll
+              for (int t = 0; t < TY; ++t)
+                acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(w_cur[n], s), f4get(b_cur[t], s), acc[t][n], 0, 0, 0);
+        }
+  #pragma unroll
+        for (int n = 0; n < NT; ++n) {
+          w_cur[n] = w_nx1[n];
+          w_nx1[n] = w_nx2[n];
+        }
+  #pragma unroll
+        for (int t = 0; t < TY; ++t) b_cur[t] = b_nxt[t];
+      }
     }
+    TDBG(4)
     if (ch != p.nchunk - 1) continue;
 
     // ---- epilogue of this tile: lane holds channels n*16 + 4q .. +3 of voxel (z0+wave, y0+t, x0+r)
@@ -325,30 +466,28 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
       }
       continue;
     }
+    // 32-bit element offsets inside the sample (the launcher refuses outputs of 2^32 elements or more); everything that
+    // does not depend on the row t is formed once per tile, the per-lane channel part (ycoff) once per kernel
     const int xo = x0 + r;
+    const bool vox_ok = zo < p.Di && xo < p.Wi;
+    float* __restrict__ ys = p.y + (size_t)grp * p.gy;
+    if (p.cls_cout) {
+      // fused transposed convolution: virtual channel -> (parity class, real channel), output voxel (2z+pz, 2y+py, 2x+px)
+      const unsigned row0 = (((unsigned)(2 * zo) * p.Hy + 2 * y0) * p.Wy + 2 * xo) * p.ldy;
+      const unsigned rstep = 2u * p.Wy * p.ldy;
 #pragma unroll
-    for (int t = 0; t < TY; ++t) {
-      const int yo = y0 + t;
-      if (zo >= p.Di || yo >= p.Hi || xo >= p.Wi) continue;
-      size_t vox = ((size_t)(zo * p.oS + p.offz) * p.Hy + (yo * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx);
-      size_t base = (size_t)grp * p.gy + vox * (size_t)p.ldy + p.ycoff;
-      const float* pb = nullptr;
-      if (p.pbias)
-        pb = p.pbias + (size_t)grp * p.gpb + ((size_t)yo * p.Wi + xo) * (size_t)(3 * p.Cout) + plane_variant(zo - 1, p.Di) * p.Cout;
+      for (int t = 0; t < TY; ++t) {
+        if (!vox_ok || y0 + t >= p.Hi) continue;
+        const unsigned rowt = row0 + t * rstep;
 #pragma unroll
-      for (int n = 0; n < NT; ++n) {
-        int co = (nsi * NT + n) * 16 + 4 * q;
-        if (co >= p.Cout) continue;
-        float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
-        if (p.cls_cout) {
-          // virtual channel -> (parity class, real channel); output voxel (2z+pz, 2y+py, 2x+px)
-          int cls = p.cls_base + co / p.cls_cout, cr = co % p.cls_cout;
-          size_t ov = ((size_t)(zo * 2 + (cls >> 2)) * p.Hy + (yo * 2 + ((cls >> 1) & 1))) * p.Wy + (xo * 2 + (cls & 1));
+        for (int n = 0; n < NT; ++n) {
+          if (ycoff[n] == ~0u) continue;
+          float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
           if (p.relu) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) v[kk] = fmaxf(v[kk], 0.f);
           }
-          st4(p.y + (size_t)grp * p.gy + ov * (size_t)p.ldy + p.ycoff + cr, make_float4(v[0], v[1], v[2], v[3]));
+          st4(ys + rowt + ycoff[n], make_float4(v[0], v[1], v[2], v[3]));
           if (STATS) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -356,8 +495,26 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
               ssq[n % SN][kk] += v[kk] * v[kk];
             }
           }
-          continue;
         }
+      }
+      TDBG(5)
+      continue;
+    }
+    const unsigned row0 = ((((unsigned)(zo * p.oS + p.offz)) * p.Hy + (y0 * p.oS + p.offy)) * p.Wy + (xo * p.oS + p.offx)) * p.ldy;
+    const unsigned rstep = (unsigned)p.oS * p.Wy * p.ldy;
+    const float* __restrict__ rs = p.res ? p.res + (size_t)grp * p.gy : nullptr;
+    const float* __restrict__ pbs = p.pbias ? p.pbias + (size_t)grp * p.gpb : nullptr;
+    const unsigned pb0 = (((unsigned)y0 * p.Wi + xo) * 3u + plane_variant(zo - 1, p.Di)) * p.Cout, pbstep = (unsigned)p.Wi * 3u * p.Cout;
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+      if (!vox_ok || y0 + t >= p.Hi) continue;
+      const unsigned base = row0 + t * rstep;
+      const float* pb = pbs ? pbs + (pb0 + t * pbstep) : nullptr;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        if (ycoff[n] == ~0u) continue;
+        const int co = (nsi * NT + n) * 16 + 4 * q;
+        float v[4] = {acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]};
         if (pb) {
 #pragma unroll
           for (int kk = 0; kk < 4; ++kk)
@@ -368,15 +525,15 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
             float4 b = ld4(p.bias + co);
             v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
           }
-          if (p.res) {
-            float4 rr = ld4(p.res + base + co);
+          if (rs) {
+            float4 rr = ld4(rs + base + ycoff[n]);
             v[0] += rr.x; v[1] += rr.y; v[2] += rr.z; v[3] += rr.w;
           }
           if (p.relu) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) v[kk] = fmaxf(v[kk], 0.f);
           }
-          st4(p.y + base + co, make_float4(v[0], v[1], v[2], v[3]));
+          st4(ys + base + ycoff[n], make_float4(v[0], v[1], v[2], v[3]));
           if (STATS) {
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -390,9 +547,9 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
             if (co + kk < p.Cout) {
               float u = v[kk];
               if (p.bias) u += p.bias[co + kk];
-              if (p.res) u += p.res[base + co + kk];
+              if (rs) u += rs[base + ycoff[n] + kk];
               if (p.relu) u = fmaxf(u, 0.f);
-              p.y[base + co + kk] = u;
+              ys[base + ycoff[n] + kk] = u;
               if (STATS) {
                 ssum[n % SN][kk] += u;
                 ssq[n % SN][kk] += u * u;
@@ -402,7 +559,12 @@ __global__ __launch_bounds__(256, tiled_wps(NT, TY, C4, XP)) void conv_tiled_f32
         }
       }
     }
+    TDBG(5)
   }
+#ifdef ATVS_TILED_DEBUG
+  if (lane == 0 && blockIdx.x < 1024)
+    for (int i = 0; i < 8; ++i) atvs_dbg_tiled[(blockIdx.x * 4 + wave) * 8 + i] = dbg_acc[i];
+#endif
 
   if (STATS && p.stats) {
     __syncthreads();     // the tile image is dead: reuse LDS for the cross-wave reduction
@@ -680,6 +842,7 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   if (residual && y_coff != 0) return ATVS_ERR_ARG;
   if (plane_bias && (out_stride != 1 || D < 2)) return ATVS_ERR_ARG;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;   // 31-bit tile-relative element offsets
+  if ((double)Dy * Hy * Wy * ldy >= 4294967296.0 || (double)W * Cin >= 16777216.0) return ATVS_ERR_SHAPE;   // 32-bit output offsets, 24-bit row pitch
   if (xpair && (Cout != 8 || class_cout || out_stride != 1 || (ldy % 4) || (y_coff % 4) || ntaps != 36)) return ATVS_ERR_ARG;
   int nch, Ccp, Jc, NT;
   int rc = atvs_conv_tiled_pack_size(ntaps, Cin, xpair ? 16 : Cout, &nch, &Ccp, &Jc, &NT, nullptr, nullptr);

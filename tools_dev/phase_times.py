@@ -5,15 +5,23 @@ import numpy as np
 import torch
 import atvsnet_amd
 from atvsnet_amd import ops, _lib
+# usage: phase_times.py [--tiled|--deconv] D H W cin cout [G]    (--deconv: the fused transposed convolution, tiled kernel)
+mode = 'xp'
+if sys.argv[1].startswith('--'):
+    mode = sys.argv.pop(1)[2:]
 D, H, W, cin, cout = [int(v) for v in sys.argv[1:6]]
+G = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 dev = torch.device('cuda:0')
-x = torch.randn(D, H, W, cin, device=dev)
+x = torch.randn(G, D, H, W, cin, device=dev)
 w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, cout)) * 0.1).astype(np.float32)
 for _ in range(3):
-    y, st = ops.conv(x, 'bench', w, want_stats=True)
+    if mode == 'deconv':
+        y, st = ops.conv3d_transpose_s2(x, 'bench_t', np.ascontiguousarray(np.swapaxes(w, -1, -2)), want_stats=True, groups=G)
+    else:
+        y, st = ops.conv(x, 'bench', w, want_stats=True, groups=G)
 torch.cuda.synchronize()
 buf = np.zeros(4096 * 8, np.uint64)
-rc = _lib.lib().atvs_debug_read(buf.ctypes.data_as(ctypes.c_void_p))
+rc = getattr(_lib.lib(), 'atvs_debug_read' if mode == 'xp' else 'atvs_debug_read_tiled')(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 b = buf.reshape(-1, 8).astype(np.float64)
 b = b[b.sum(1) > 0]
