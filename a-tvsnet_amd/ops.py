@@ -337,6 +337,46 @@ def pack_conv_xp(key, w_host, device):
     return pk
 
 
+def pack_deconv_up(key, w_host, device):
+    """Packed weights of the 8-channel transposed-convolution kernel (atvs_deconv_up_f32); cached."""
+    import numpy as np
+    ck = ('up', key, str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)           # [3,3,3,Cout,Cin]
+    cout, cin = int(w.shape[-2]), int(w.shape[-1])
+    L = _lib.lib()
+    pf = ctypes.c_long()
+    rc = L.atvs_deconv_up_pack_size(cin, cout, ctypes.byref(pf))
+    if rc:
+        raise RuntimeError('atvs_deconv_up_pack_size failed (%d) for %d -> %d' % (rc, cin, cout))
+    packed = np.empty(pf.value, np.float32)
+    rc = L.atvs_deconv_up_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_deconv_up_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, cout
+    pk.key = key
+    pk.tab = None
+    pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+_USE_DECONV_UP = True
+
+
+def use_deconv_up(flag):
+    """Testing / A-B hook: the one-workgroup-per-CU transposed-convolution kernel for Cout == 8."""
+    global _USE_DECONV_UP
+    _USE_DECONV_UP = bool(flag)
+
+
+def deconv_up_ok(cin, cout):
+    return _USE_DECONV_UP and _FORCE_IMPL is None and cout == 8 and cin % 16 == 0 and 0 < cin <= 64
+
+
 def pack_conv_xp_sibling(key, w_host, device):
     """Packed weights of the stride-2 sibling [3,3,3,Cin,16] of an x-pair launch; cached."""
     import numpy as np
@@ -1168,6 +1208,20 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
     y = _new(x, lead + (2 * D, 2 * H, 2 * W, cout))
     y5 = y.reshape((G, 2 * D, 2 * H, 2 * W, cout))
     M = D * H * W
+    if deconv_up_ok(Cin, cout):
+        # all 8 parity classes from one staged input tile, one workgroup per CU (csrc/deconv_up.hip)
+        pk = pack_deconv_up(key, w_host, x.device)
+        blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), int(G)))
+        st, sbuf = None, None
+        if want_stats:
+            sbuf = _stats_buffer(x, blocks, 16, groups=G)
+            st = Stats()
+            st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 16, 8 * M, G
+        if _dev_ok(x5, y5):
+            with _Timed(key, x5.shape[1:], cout, G):
+                _call('atvs_deconv_up_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
+                      int(bool(relu)), _stream())
+        return (y, st) if want_stats else y
     classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
     fused = _FORCE_IMPL != 'gather' and cout % 4 == 0 and cout <= 64 and (W >= 12 or _FORCE_IMPL == 'tiled')
     if fused:
