@@ -368,13 +368,13 @@ _USE_DECONV_UP = True
 
 
 def use_deconv_up(flag):
-    """Testing / A-B hook: the one-workgroup-per-CU transposed-convolution kernel for Cout == 8."""
+    """Testing / A-B hook: the one-workgroup-per-CU transposed-convolution kernel for Cout 8 / 16."""
     global _USE_DECONV_UP
     _USE_DECONV_UP = bool(flag)
 
 
 def deconv_up_ok(cin, cout):
-    return _USE_DECONV_UP and _FORCE_IMPL is None and cout == 8 and cin % 16 == 0 and 0 < cin <= 64
+    return _USE_DECONV_UP and _FORCE_IMPL is None and cout in (8, 16) and cin % 16 == 0 and 0 < cin <= 64
 
 
 def pack_conv_xp_sibling(key, w_host, device):
@@ -1208,10 +1208,10 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
     y = _new(x, lead + (2 * D, 2 * H, 2 * W, cout))
     y5 = y.reshape((G, 2 * D, 2 * H, 2 * W, cout))
     M = D * H * W
-    if deconv_up_ok(Cin, cout):
+    if deconv_up_ok(Cin, cout) and 32.0 * M * cout < 2.0 ** 32:
         # all 8 parity classes from one staged input tile, one workgroup per CU (csrc/deconv_up.hip)
         pk = pack_deconv_up(key, w_host, x.device)
-        blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), int(G)))
+        blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), int(cout), int(G)))
         st, sbuf = None, None
         if want_stats:
             sbuf = _stats_buffer(x, blocks, 16, groups=G)

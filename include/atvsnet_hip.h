@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 10
+#define ATVS_ABI_VERSION 11
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -405,15 +405,16 @@ int atvs_fusibile(const float* cams, const float* normals_depths, const float* i
                   float* texture, float* created, atvs_stream_t stream);
 
 
-/* ---- 3x3x3 stride-2 SAME transposed convolution to 8 channels, all 8 output parity classes per staged input tile
- * (csrc/deconv_up.hip): the decoders conv_b*_6_0 / global_refine_3dconv6_0 (cnn_wrapper/atvsnet.py StackedUNet /
- * CostVolRefineNet; tf.layers.conv3d_transpose, cnn_wrapper/network.py:510-550).  Cout == 8, Cin % 16 == 0, Cin <= 64
- * (else ATVS_ERR_SHAPE: callers use the class-fused form of atvs_conv_tiled_f32).
- * w: TF layout [3,3,3,Cout,Cin].  x (groups, D,H,W, Cin) -> y (groups, 2D,2H,2W, ldy)[..., y_coff : y_coff + 8].
+/* ---- 3x3x3 stride-2 SAME transposed convolution to 8 or 16 channels, all 8 output parity classes per staged input tile
+ * (csrc/deconv_up.hip): the decoders conv_b*_6_0 / conv_b*_5_0, global_refine_3dconv6_0 / 5_0 (cnn_wrapper/atvsnet.py
+ * StackedUNet / CostVolRefineNet; tf.layers.conv3d_transpose, cnn_wrapper/network.py:510-550).  Cout in {8, 16},
+ * Cin % 16 == 0, Cin <= 64, output below 4 GiB per sample (else ATVS_ERR_SHAPE: callers use the class-fused form of
+ * atvs_conv_tiled_f32).
+ * w: TF layout [3,3,3,Cout,Cin].  x (groups, D,H,W, Cin) -> y (groups, 2D,2H,2W, ldy)[..., y_coff : y_coff + Cout].
  * stats_partial: groups * atvs_deconv_up_grid rows of [2][16] doubles (sum / sum of squares per channel) or NULL. */
 int atvs_deconv_up_pack_size(int Cin, int Cout, long* packed_floats);
 int atvs_deconv_up_pack(const float* w, int Cin, int Cout, float* packed);        /* host function */
-long atvs_deconv_up_grid(int D, int H, int W, int groups);                        /* workgroups PER SAMPLE */
+long atvs_deconv_up_grid(int D, int H, int W, int Cout, int groups);              /* workgroups PER SAMPLE */
 int atvs_deconv_up_f32(const float* x, const float* packed_w, float* y, double* stats_partial, int groups, int D, int H,
                        int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 

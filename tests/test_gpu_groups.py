@@ -224,36 +224,38 @@ def test_networks_with_prologue_equal_materialised_inputs(cuda, weights):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('G,shape,cin', [(1, (9, 17, 33), 16), (2, (4, 8, 16), 32), (3, (5, 9, 18), 64), (2, (12, 24, 40), 16)])
-def test_deconv_up_against_torch_and_the_class_fused_form(cuda, G, shape, cin):
-    """The 8-channel transposed convolution (conv_b*_6_0, reference cnn_wrapper/network.py:510-550) on its own kernel
+@pytest.mark.parametrize('G,shape,cin,cout', [(1, (9, 17, 33), 16, 8), (2, (4, 8, 16), 32, 8), (3, (5, 9, 18), 64, 8),
+                                             (2, (12, 24, 40), 16, 8), (1, (9, 17, 33), 32, 16), (3, (5, 9, 18), 16, 16),
+                                             (2, (8, 12, 40), 64, 16)])
+def test_deconv_up_against_torch_and_the_class_fused_form(cuda, G, shape, cin, cout):
+    """The 8- / 16-channel transposed convolutions (conv_b*_6_0, conv_b*_5_0, reference cnn_wrapper/network.py:510-550) on its own kernel
     (csrc/deconv_up.hip): against tf.layers.conv3d_transpose restated with torch (tolerance 2e-5 of the output scale: a
     different accumulation order), and its statistics / grouped form against the separate calls."""
     from oracle import tf_ops as T
     from atvsnet_amd import ops
     x = _rand((G,) + shape + (cin,), 21)
-    w = _rand((3, 3, 3, 8, cin), 22) * 0.2
-    got, st = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin), w.numpy(), want_stats=True, groups=G)
+    w = _rand((3, 3, 3, cout, cin), 22) * 0.2
+    got, st = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin, cout), w.numpy(), want_stats=True, groups=G)
     assert st.cpad == 16 and st.groups == G and st.fold == 1
     D, H, W = shape
-    assert tuple(got.shape) == (G, 2 * D, 2 * H, 2 * W, 8)
-    params = ops.bn_params(st, 8, got)
+    assert tuple(got.shape) == (G, 2 * D, 2 * H, 2 * W, cout)
+    params = ops.bn_params(st, cout, got)
     for g in range(G):
         want = T.conv3d_transpose_same(x[g:g + 1], w, 2)[0]
         err = float((got[g].cpu() - want).abs().max())
         assert err <= 2e-5 * float(want.abs().max()) + 1e-6, (g, err)
-        one, st1 = ops.conv3d_transpose_s2(x[g].to(cuda), ('up', cin), w.numpy(), want_stats=True)
+        one, st1 = ops.conv3d_transpose_s2(x[g].to(cuda), ('up', cin, cout), w.numpy(), want_stats=True)
         assert torch.equal(one, got[g])
-        p1 = ops.bn_params(st1, 8, one)
+        p1 = ops.bn_params(st1, cout, one)
         pg = params[g] if G > 1 else params
         assert float((pg - p1).abs().max()) <= 1e-6 * float(p1.abs().max())
-        mean = want.reshape(-1, 8).double().mean(0)
+        mean = want.reshape(-1, cout).double().mean(0)
         assert float((pg[0].cpu().double() - mean).abs().max()) <= 1e-5
     ops.use_deconv_up(False)
     try:
-        ref, _ = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin), w.numpy(), want_stats=True, groups=G)
+        ref, _ = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin, cout), w.numpy(), want_stats=True, groups=G)
     finally:
         ops.use_deconv_up(True)
     assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max())
-    relu = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin), w.numpy(), relu=True, groups=G)
+    relu = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin, cout), w.numpy(), relu=True, groups=G)
     assert torch.equal(relu, torch.clamp(got, min=0))
