@@ -31,8 +31,14 @@ namespace {
 
 constexpr int UP_TZ = 4, UP_TX = 16;
 constexpr int UP_HZ = UP_TZ + 1, UP_HX = UP_TX + 1;
-constexpr int UP_VB = 64;                              // bytes per voxel of a 16-channel chunk in LDS
-constexpr int UP_ROWB = UP_HX * UP_VB;                 // bytes per image row
+// LDS image: 64 bytes per voxel (16 channels), rows of 24 voxels (17 used): the row pitch is a multiple of 512 bytes, so
+// every (dz, dy, row) displacement is an immediate that commutes with the bank swizzle (bit 5 ^= bit 8: the 16-lane
+// groups of a 128-bit read -- lanes {0-3,12-15,20-27}, ... -- then fall into 16 distinct 16-byte bank slots whatever the
+// x alignment; unswizzled, 37 % of the LDS cycles were conflict cycles).  The two x offsets get a base register each.
+constexpr int UP_VB = 64;
+constexpr int UP_PITCHV = 24;
+constexpr int UP_ROWB = UP_PITCHV * UP_VB;             // bytes per image row
+__device__ __forceinline__ int up_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
 
 template <int COUT>
 struct Up {
@@ -113,14 +119,16 @@ __global__ __launch_bounds__(256, 1) void deconv_up_kernel(UpArgs p) {
     for (int i = tid; i < p.nchunk * (U::WCH / 16); i += 256) dst[i] = src[i];
   }
 
-  // LDS read base: this lane's fragment at halo voxel (wave, 0, r) = offset (-1,-1,-1) of row 0 of the wavefront's plane;
-  // every (offset, row) is a non-negative immediate from here
-  const int fbase = ((wave * HY) * UP_HX + r) * UP_VB + q * 16;
+  // LDS read bases: this lane's fragment at halo voxel (wave, 0, r + 1 - ox) = offset (-1, -1, ox) of row 0 of the
+  // wavefront's plane, swizzled; every (dz, dy, row) is a non-negative immediate from there
+  int fbase[2];
+#pragma unroll
+  for (int ox = 0; ox < 2; ++ox) fbase[ox] = up_swz(((wave * HY) * UP_PITCHV + r + 1 - ox) * UP_VB + q * 16);
   const int wbase = U::IMG + lane * 16;
 
   // per-slot constants of this thread: global element offset from the halo origin and the packed halo coordinate
-  // (zz | yy<<8 | xx<<16, each byte with its top bit set) for the bounds test; slot s lives at LDS byte 16 s
-  int goff[MAXS];
+  // (zz | yy<<8 | xx<<16, each byte with its top bit set) for the bounds test; its swizzled LDS byte address
+  int goff[MAXS], laddr[MAXS];
   unsigned pg[MAXS];
 #pragma unroll
   for (int i = 0; i < MAXS; ++i) {
@@ -131,6 +139,7 @@ __global__ __launch_bounds__(256, 1) void deconv_up_kernel(UpArgs p) {
     const int xx = v % UP_HX, v2 = v / UP_HX;
     const int yy = v2 % HY, zz = v2 / HY;
     goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
+    laddr[i] = up_swz(((zz * HY + yy) * UP_PITCHV + xx) * UP_VB + c4 * 16);
     pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
   }
 
@@ -209,7 +218,7 @@ __global__ __launch_bounds__(256, 1) void deconv_up_kernel(UpArgs p) {
     __syncthreads();                       // every wavefront is done reading the previous stage's image
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
-      if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) *reinterpret_cast<float4*>(smem + (tid + i * 256) * 16) = pf[i];
+      if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) *reinterpret_cast<float4*>(smem + laddr[i]) = pf[i];
     __syncthreads();
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
@@ -259,10 +268,10 @@ __global__ __launch_bounds__(256, 1) void deconv_up_kernel(UpArgs p) {
     float4 B[2][TY], Wt[2][NT];
     auto request = [&](auto OT) __attribute__((always_inline)) {
       constexpr int o = decltype(OT)::value, oz = o >> 2, oy = (o >> 1) & 1, ox = o & 1;
-      constexpr int disp = (((1 - oz) * HY + (1 - oy)) * UP_HX + (1 - ox)) * UP_VB;
+      constexpr int disp = ((1 - oz) * HY + (1 - oy)) * UP_ROWB;
 #pragma unroll
       for (int t = 0; t < TY; ++t)
-        B[o & 1][t] = *reinterpret_cast<const float4*>(smem + fbase + (disp + t * UP_ROWB));
+        B[o & 1][t] = *reinterpret_cast<const float4*>(smem + fbase[ox] + (disp + t * UP_ROWB));
       static_for<NT>([&](auto MT) __attribute__((always_inline)) {
         constexpr int m = decltype(MT)::value;
         if constexpr (U::active(m, o))
