@@ -116,21 +116,38 @@ def load_data(sample_list, data_index):
 
 
 class _Pipelines(object):
-    """One captured HIP graph per input shape (scenes of one data set share it)."""
+    """One set of captured HIP graphs per input shape (scenes of one data set share it), two depth maps in flight:
+    submit() issues a depth map asynchronously, fetch() returns the oldest one's results as numpy arrays."""
+
+    SLOTS = 2
 
     def __init__(self, device, use_graph=True):
         self.device, self.use_graph, self.cache = device, use_graph, {}
+        self.pending = []            # (pipeline, ticket) or (None, tensors) in submission order
 
-    def __call__(self, images_data, cams_data):
+    def submit(self, images_data, cams_data):
         images = torch.from_numpy(np.ascontiguousarray(images_data, dtype=np.float32)).to(self.device)
         cams = torch.from_numpy(np.ascontiguousarray(cams_data, dtype=np.float32)).to(self.device)
         if not self.use_graph:
-            return example.infer_multiview(images, cams, FLAGS.max_d, out_prob_map=True)
+            self.pending.append((None, example.infer_multiview(images, cams, FLAGS.max_d, out_prob_map=True)))
+            return
         key = tuple(images.shape)
-        g = self.cache.get(key)
-        if g is None:
-            g = self.cache[key] = example.GraphedInference(images, cams, FLAGS.max_d, out_prob_map=True)
-        return g(images, cams)
+        p = self.cache.get(key)
+        if p is None:
+            p = self.cache[key] = example.PipelinedInference(images, cams, FLAGS.max_d, slots=self.SLOTS, out_prob_map=True)
+        self.pending.append((p, p.submit(images, cams)))
+
+    def room(self):
+        return len(self.pending) < self.SLOTS
+
+    def fetch(self):
+        p, t = self.pending.pop(0)
+        out = t if p is None else p.result(t)
+        return [o.cpu().numpy() for o in out]
+
+    def __call__(self, images_data, cams_data):
+        self.submit(images_data, cams_data)
+        return self.fetch()
 
 
 def run_eval_pc(savepath, image_infos, use_graph=True):
@@ -149,11 +166,12 @@ def run_eval_pc(savepath, image_infos, use_graph=True):
         output_folder = os.path.join(savepath_current, 'depths_atvsnet')
         os.makedirs(output_folder, exist_ok=True)
         scene_runtime = 0.0
-        for current_i in range(len(mvs_list)):
-            image_data_raw, images_data, cams_data, _depth, out_index = load_data(mvs_list, current_i)
-            start_time = time.time()
-            depth, depth_up, prob, prob_up = [t.cpu().numpy() for t in run(images_data, cams_data)]
-            scene_runtime += time.time() - start_time
+        start_time = time.time()
+        queued = []                  # host-side data of the depth maps in flight, in submission order
+
+        def finish():
+            image_data_raw, cams_data, out_index = queued.pop(0)
+            depth, depth_up, prob, prob_up = run.fetch()
             disp_up = np.squeeze(depth_up.copy())
             if FLAGS.inverse_depth:
                 for m in (depth, depth_up):
@@ -168,6 +186,18 @@ def run_eval_pc(savepath, image_infos, use_graph=True):
             Image.fromarray(np.ascontiguousarray(image_data_raw[0, 0][:, :, ::-1])).save(stem + '.jpg')
             write_cam(stem + '.txt', cams_data[0, 0])
             plt.imsave(stem + '.png', disp_up, cmap='viridis')
+
+        # the depth maps of a scene are independent: the next one is issued before the previous one's results are
+        # fetched and written (two in flight), so file I/O and the GPU's under-filled phases overlap
+        for current_i in range(len(mvs_list)):
+            image_data_raw, images_data, cams_data, _depth, out_index = load_data(mvs_list, current_i)
+            if not run.room():
+                finish()
+            run.submit(images_data, cams_data)
+            queued.append((image_data_raw, cams_data, out_index))
+        while queued:
+            finish()
+        scene_runtime = time.time() - start_time       # wall clock of the scene (the reference sums sess.run times)
         with open(os.path.join(savepath_current, 'zz_runtime.txt'), "w") as text_file:
             text_file.write('runtime ' + str(scene_runtime))
         print(Notify.INFO, '%s: %d depth maps, %.2f s' % (image_info[2], len(mvs_list), scene_runtime), Notify.ENDC)

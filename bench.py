@@ -11,7 +11,10 @@ Default workload = BASELINE.json configs[2], the configuration the metric is quo
 8-source configuration quoted for 8 GPUs), cfg5 = two-view 1600x1184x256.
 On one GPU the step is ONE replay of a HIP graph captured from the pipeline (every per-view network evaluated once
 over all its calls -- views, siamese directions -- stacked on the batch axis with per-call batch statistics);
---eager issues every launch from Python instead.
+--eager issues every launch from Python instead.  --inflight N (default 2): the K timed depth maps are issued round-robin
+on N streams (one captured graph + static buffers each, example.PipelinedInference) -- the depth maps of a scene are
+independent (one per reference view) and a second one in flight fills the phases in which one pipeline leaves the GPU
+under-filled; `ms_per_step` stays wall time / K, the line also carries `latency_ms` = one depth map alone.
 
 --gpus N > 1: this process touches no GPU; it starts N ranks (one process per GPU, RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), prints ONE JSON line and exits non-zero if a rank of the primary
@@ -74,6 +77,8 @@ def parse(argv=None):
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
     p.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
+    p.add_argument('--inflight', type=int, default=2,
+                   help='depth maps in flight per GPU (streams with one captured graph each); 1 = strictly one after the other')
     p.add_argument('--parallel', choices=['maps', 'views', 'both'], default=None,
                    help='N > 1: maps = one depth map per rank (no collective), views = source views sharded inside groups; '
                         'the launcher default measures maps, then views as a secondary result of the same line')
@@ -378,13 +383,15 @@ def rank_main(args):
                 group, gsize = h, len(g)
     sharded = gsize > 1
 
-    graphed = None
+    graphed, pipe = None, None
     if not args.eager:
         if sharded:
             # per rank: a chain of HIP graphs (the local compute between two exchanges) with the RCCL calls between
             graphed = parallel.ShardedGraphedInference(imgs, cams, args.depths, group=group)
         else:
-            graphed = ex.GraphedInference(imgs, cams, args.depths)      # one HIP graph per depth map
+            # one HIP graph per depth map; `inflight` of them (own static buffers and stream each) for the timed region
+            pipe = ex.PipelinedInference(imgs, cams, args.depths, slots=max(1, args.inflight))
+            graphed = pipe.graphs[0]
 
     def eager_step(view_streams=True):
         if sharded:
@@ -402,14 +409,29 @@ def rank_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    dt = time.perf_counter() - t0
+    latency_ms = None
+    if pipe is not None and pipe.slots > 1:
+        pipe.run(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        pipe.run(args.steps)                 # K depth maps, round-robin over the slots' streams
+        barrier()
+        dt = time.perf_counter() - t0
+        out = graphed.out
+        t1 = time.perf_counter()             # one depth map alone (untimed region: reported next to the throughput)
+        for _ in range(3):
+            graphed()
+        torch.cuda.synchronize()
+        latency_ms = (time.perf_counter() - t1) / 3 * 1e3
+    else:
+        for _ in range(args.warmup):
+            out = step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -497,8 +519,10 @@ def rank_main(args):
                        'groups': groups if world > 1 else None,
                        'rccl': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
                        'launch': 'eager' if graphed is None else ('HIP graph replay, batched per-view networks' if not sharded else
-                                                                   'HIP graphs between the exchanges')},
+                                                                   'HIP graphs between the exchanges'),
+                       'inflight': pipe.slots if pipe is not None else 1},
             'source_views_per_sec': round(n_groups * args.steps * (args.views - 1) / dt, 3),
+            'latency_ms': round(latency_ms, 3) if latency_ms is not None else round(1e3 * dt / args.steps, 3),
             'roofline': roof, 'roofline_hbm': roof_hbm, 'kernels': top_kernels(),
         }
         if comm is not None:

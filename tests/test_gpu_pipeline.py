@@ -182,3 +182,31 @@ def test_graft_entry_build_then_smoke_in_one_process(cuda):
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     out = r.stdout.decode('utf-8', 'replace')
     assert r.returncode == 0 and 'smoke ok' in out, out[-2000:]
+
+
+def test_pipelined_inference_two_in_flight(cuda, weights):
+    """example.PipelinedInference: two depth maps in flight (independent reference views of a scene, reference
+    eval_pointcloud.py:399-424) give, per depth map, exactly what one pipeline gives."""
+    from atvsnet_amd.atvsnet import example as ex
+    from atvsnet_amd import synthetic
+    imgs, cams = _inputs(3)
+    imgs, cams = imgs.to(cuda), cams.to(cuda)
+    imgs2 = torch.from_numpy(synthetic.make_inputs(3, 128, 160, 32, seed=7)[0]).to(cuda)
+    want1 = ex.infer_multiview(imgs, cams, 32).clone()
+    want2 = ex.infer_multiview(imgs2, cams, 32).clone()
+    assert not torch.equal(want1, want2)
+    p = ex.PipelinedInference(imgs, cams, 32, slots=2)
+    t1 = p.submit(imgs, cams)
+    t2 = p.submit(imgs2, cams)
+    with pytest.raises(RuntimeError):
+        p.submit(imgs, cams)                        # both slots hold unfetched results
+    got1 = p.result(t1).clone()
+    t3 = p.submit(imgs2, cams)                      # slot of t1 again, other inputs
+    got2 = p.result(t2).clone()
+    got3 = p.result(t3).clone()
+    assert torch.equal(got1, want1) and torch.equal(got2, want2) and torch.equal(got3, want2)
+    with pytest.raises(RuntimeError):
+        p.result(t1)
+    p.run(5)                                        # the benchmark loop: captured inputs of each slot, all complete on return
+    torch.cuda.synchronize()
+    assert torch.isfinite(p.graphs[0].out).all() and torch.isfinite(p.graphs[1].out).all()
