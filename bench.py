@@ -277,7 +277,10 @@ def pmc_traffic(args):
 
 
 def top_kernels(k=5):
-    """Top kernels of the committed rocprofv3 --kernel-trace --stats summary of this command."""
+    """Top kernels of the committed rocprofv3 --kernel-trace --stats summary of this command with --inflight 1 (one
+    depth map at a time: the kernel times add up to the step; with two in flight -- profiles/
+    round2_bench_inflight2_kernel_stats.csv -- small kernels wait behind the other stream's and their durations
+    overlap; the dominant kernel's average is the same in both: 5.97 ms)."""
     import csv
     path = os.path.join(ROOT, KERNEL_STATS_FILE)
     if not os.path.exists(path):
@@ -288,7 +291,7 @@ def top_kernels(k=5):
             rows.append((r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0],
                          int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['Percentage'])))
     rows.sort(key=lambda t: -t[3])
-    return {'source': KERNEL_STATS_FILE,
+    return {'source': KERNEL_STATS_FILE, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --inflight 1',
             'top': [{'kernel': n, 'calls': c, 'avg_us': round(a, 1), 'pct': round(p, 2)} for n, c, a, p in rows[:k]]}
 
 
