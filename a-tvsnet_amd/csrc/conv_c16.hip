@@ -1,0 +1,358 @@
+// 3x3x3 SAME stride-1 convolution to SIXTEEN output channels from 16 k input channels, one wavefront per SIMD (gfx950).
+//
+// These are the half-resolution layers of the stacked U-Nets / the refinement net (conv_b*_1_1, global_refine_3dconv1_1:
+// 16 -> 16 channels on a (D/2, h/2, w/2) volume; cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, layer code
+// /root/reference/cnn_wrapper/network.py:165-215): 16 output channels fill the 16 rows of an MFMA tile exactly (every
+// issued MFMA is useful), and on the generic LDS-tiled kernel (conv_tiled.hip) they were its largest block of time at
+// 55 % of the fp32 MFMA peak (MFMA pipe busy 58 %, 2.75 other VALU instructions per MFMA: run-time tap tables, rotating
+// register copies, a halo burst in front of the K loop, two workgroups per CU on half the register file each).
+//
+// Built like conv_xp.hip / deconv_up.hip: ONE workgroup of 4 wavefronts per CU with the whole register file; tile =
+// 4(z) x 8(y) x 16(x) output voxels, wavefront w owns plane z0 + w (8 accumulator tiles); the K loop is fully unrolled
+// (27 taps x 4 MFMAs x 8 rows per 16-channel chunk), every LDS read is one of three swizzled base registers (the x
+// displacement) + an immediate (the row pitch of the image is a multiple of 512 bytes); the fragments and the weights of
+// tap j + 1 are requested in front of the MFMAs of tap j, the next tile's halo one slot per tap behind them; the packed
+// weights of every chunk stay in LDS for the whole launch.
+#include <type_traits>
+#include <utility>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int C16_TZ = 4, C16_TY = 8, C16_TX = 16;
+constexpr int C16_HZ = C16_TZ + 2, C16_HY = C16_TY + 2, C16_HX = C16_TX + 2;
+constexpr int C16_VB = 64;                                // bytes per voxel of a 16-channel chunk in LDS
+constexpr int C16_PITCHV = 24;                            // voxels per image row (18 used): 1536 B = 3 x 512
+constexpr int C16_ROWB = C16_PITCHV * C16_VB;
+constexpr int C16_IMG = C16_HZ * C16_HY * C16_ROWB;       // 92,160 bytes
+constexpr int C16_SLOTS = C16_HZ * C16_HY * C16_HX * 4;   // 16-byte halo slots
+constexpr int C16_MAXS = (C16_SLOTS + 255) / 256;         // 17 per thread
+constexpr int C16_TAPS = 27;
+constexpr int C16_WCH = C16_TAPS * 1024;                  // bytes of packed weights per chunk
+static_assert(C16_MAXS <= C16_TAPS, "one halo slot per tap");
+static_assert(((2 * C16_HY + 2) + C16_TY) * C16_ROWB < 65536, "ds_read immediate offset");
+
+struct C16Args {
+  const float* x;
+  const float* wp;       // packed weights (atvs_conv_c16_pack) + 4 trailing zeros
+  const float* zeros;    // those 16 zero bytes: source of the zero padding
+  const float* bias;     // 16 floats or nullptr
+  float* y;
+  double* stats;
+  int Di, Hi, Wi, Cin;
+  int ldy, ycoff;
+  int nchunk;
+  int tiles_y, tiles_x, ntiles;
+  int wg;                // workgroups per sample (gridDim.x = groups * wg)
+  long gx, gy;           // elements per sample of x / y
+};
+
+__device__ __forceinline__ int c16_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+template <class F, int... I>
+__device__ __forceinline__ void c16_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void c16_static_for(F&& f) {
+  c16_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
+  constexpr int TY = C16_TY, HY = C16_HY, MAXS = C16_MAXS;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+
+  // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wp);
+    float4* dst = reinterpret_cast<float4*>(smem + C16_IMG);
+    for (int i = tid; i < p.nchunk * (C16_WCH / 16); i += 256) dst[i] = src[i];
+  }
+
+  // LDS read bases: this lane's fragment at halo voxel (wave, 0, r + kw) = tap (0, 0, kw) of row 0 of the wavefront's
+  // plane, swizzled; every (kd, kh, row) is an immediate from there
+  int fbase[3];
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw) fbase[kw] = c16_swz(((wave * HY) * C16_PITCHV + r + kw) * C16_VB + q * 16);
+  const int wbase = C16_IMG + lane * 16;
+
+  // per-slot constants of this thread: global element offset from the halo origin, swizzled LDS byte address and the
+  // packed halo coordinate (zz | yy<<8 | xx<<16, each byte with its top bit set) for the bounds test
+  int goff[MAXS], laddr[MAXS];
+  unsigned pg[MAXS];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < C16_SLOTS;
+    s = min(s, C16_SLOTS - 1);
+    const int c4 = s & 3, v = s >> 2;
+    const int xx = v % C16_HX, v2 = v / C16_HX;
+    const int yy = v2 % HY, zz = v2 / HY;
+    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
+    laddr[i] = c16_swz(((zz * HY + yy) * C16_PITCHV + xx) * C16_VB + c4 * 16);
+    pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+  }
+
+  // persistent tile list, dealt so that the workgroups of one XCD (blockIdx % 8) sweep one contiguous eighth of the
+  // tile range (halo re-use in that XCD's L2)
+  const int G = p.wg;
+  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
+  const int xcd = lbk & 7, tslot = lbk >> 3;
+  const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
+  float* __restrict__ yg = p.y + (size_t)grp * p.gy;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int slots_per_xcd = G >> 3;
+  int my_tiles = 0;
+  {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);
+    if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
+  }
+  const int nstage = my_tiles * p.nchunk;
+
+  auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
+    int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
+    int bx = tl % p.tiles_x;
+    int rest = tl / p.tiles_x;
+    *x0 = bx * C16_TX;
+    *y0 = (rest % p.tiles_y) * TY;
+    *z0 = (rest / p.tiles_y) * C16_TZ;
+  };
+
+  struct PfTile {
+    const float* xb;      // sample + first channel of the chunk
+    int org;              // element offset of the halo origin (may be negative: the first layer is outside)
+    unsigned lo, hi1;     // packed bounds: valid iff lo_f <= f <= hi_f in every field (hi1 = hi + 1 per byte)
+  };
+  auto pf_tile = [&](int stage) __attribute__((always_inline)) {
+    PfTile T;
+    int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
+    T.xb = xg + ch * 16;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
+    T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+    T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+            ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+    return T;
+  };
+  float4 pf[MAXS];
+  auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
+    const unsigned t1 = pg[i] - T.lo;          // byte f keeps its top bit iff f >= lo_f
+    const unsigned t2 = T.hi1 + ~pg[i];        // byte f has its top bit iff f <= hi_f
+    const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
+    pf[i] = ld4(ok ? (T.xb + (T.org + goff[i])) : p.zeros);
+  };
+
+  // moments of this lane's channels 4q + {0,1 | 2,3}
+  f32x2 ssum2[2] = {{0.f, 0.f}, {0.f, 0.f}}, ssq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  f32x4 acc[TY];
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bv = ld4(p.bias + q * 4);
+  // this sample's output as a buffer: stores at or beyond ybytes are dropped by the range check
+  const unsigned ybytes = (unsigned)(p.gy * 4);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
+
+  if (nstage > 0) {
+    const PfTile T0 = pf_tile(0);
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+  }
+
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    if (ch == 0) {
+#pragma unroll
+      for (int t = 0; t < TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                       // every wavefront is done reading the previous stage's image
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i)
+      if (i < MAXS - 1 || tid + i * 256 < C16_SLOTS) *reinterpret_cast<float4*>(smem + laddr[i]) = pf[i];
+    __syncthreads();
+
+    const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
+    const int wb = wbase + ch * C16_WCH;
+
+    // ---- K loop: 27 taps, fully unrolled
+    float4 B[2][TY], Wt[2];
+    auto request = [&](auto JT) __attribute__((always_inline)) {
+      constexpr int j = decltype(JT)::value, kd = j / 9, kh = (j / 3) % 3, kw = j % 3;
+      constexpr int disp = (kd * HY + kh) * C16_ROWB;
+#pragma unroll
+      for (int t = 0; t < TY; ++t)
+        B[j & 1][t] = *reinterpret_cast<const float4*>(smem + fbase[kw] + (disp + t * C16_ROWB));
+      Wt[j & 1] = *reinterpret_cast<const float4*>(smem + wb + j * 1024);
+    };
+    request(IC<0>{});
+    asm volatile("" ::: "memory");
+    c16_static_for<C16_TAPS>([&](auto JT) __attribute__((always_inline)) {
+      constexpr int j = decltype(JT)::value;
+      if constexpr (j + 1 < C16_TAPS) request(IC<j + 1>{});
+      if constexpr (j < MAXS) pf_slot(T, j);
+      // compiler barrier (keeps the requests from sinking to their uses) + scheduling barrier (keeps them in front of
+      // the MFMAs that cover their latency)
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int t = 0; t < TY; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Wt[j & 1], s), f4get(B[j & 1][t], s), acc[t], 0, 0, 0);
+    });
+    if (ch != p.nchunk - 1) continue;
+
+    // ---- epilogue: this lane holds channels 4q..4q+3 of voxel (z0 + wave, y0 + t, x0 + r); 32-bit element offsets inside
+    // the sample, branch-free buffer stores (rows outside the volume get an out-of-range offset and are dropped)
+    int tz0, ty0, tx0;
+    tile_origin(k, &tz0, &ty0, &tx0);
+    const int zo = tz0 + wave, xo = tx0 + r;
+    const bool evox_ok = zo < p.Di && xo < p.Wi;
+    const unsigned erow = (unsigned)p.Wi * p.ldy;
+    const unsigned eo = (((unsigned)zo * p.Hi + ty0) * p.Wi + xo) * p.ldy + p.ycoff + q * 4;
+    const unsigned vo_ok = evox_ok ? eo * 4u : ybytes;
+    c16_static_for<TY>([&](auto TT) __attribute__((always_inline)) {
+      constexpr int t = decltype(TT)::value;
+      float a0 = acc[t][0] + bv.x, a1 = acc[t][1] + bv.y, a2 = acc[t][2] + bv.z, a3 = acc[t][3] + bv.w;
+      if (RELU) {                                    // NaN passes through, as in tf.nn.relu
+        a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
+        a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
+      }
+      const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                          __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
+      const bool row_ok = ty0 + t < p.Hi;            // uniform
+      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, t * erow * 4u, 0);
+      const bool ok = evox_ok && row_ok;
+      f32x2 lo = {ok ? a0 : 0.f, ok ? a1 : 0.f}, hi = {ok ? a2 : 0.f, ok ? a3 : 0.f};
+      ssum2[0] += lo;
+      ssum2[1] += hi;
+      ssq2[0] = __builtin_elementwise_fma(lo, lo, ssq2[0]);
+      ssq2[1] = __builtin_elementwise_fma(hi, hi, ssq2[1]);
+    });
+  }
+
+  // ---- per-workgroup partial moments (sum, sum of squares) per output channel -> row blockIdx of stats: [2][16] doubles
+  if (p.stats) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a = (double)ssum2[kk >> 1][kk & 1], bq = (double)ssq2[kk >> 1][kk & 1];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        bq += __shfl_xor(bq, o);
+      }
+      if (r == 0) {
+        s_red[(wave * 2 + 0) * 16 + q * 4 + kk] = a;
+        s_red[(wave * 2 + 1) * 16 + q * 4 + kk] = bq;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, col = tid & 15;
+      p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] =
+          (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
+          (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
+    }
+  }
+}
+
+long c16_ntiles(int D, int H, int W) {
+  return (long)((D + C16_TZ - 1) / C16_TZ) * ((H + C16_TY - 1) / C16_TY) * ((W + C16_TX - 1) / C16_TX);
+}
+
+// weights of every chunk + the image must fit 160 KB of LDS: Cin 16 or 32
+bool c16_shape_ok(int Cin) { return Cin == 16 || Cin == 32; }
+
+template <bool RELU>
+int launch_c16(const C16Args& a, long grid, atvs_stream_t stream) {
+  const size_t lds = (size_t)C16_IMG + (size_t)a.nchunk * C16_WCH;
+  // the attribute is per device: one flag per device ordinal of this process (and per instantiation)
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_kernel<RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return ATVS_ERR_LAUNCH;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((conv_c16_kernel<RELU>), dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
+  return ATVS_OK;
+}
+
+}  // namespace
+
+// Floats of the packed form of a kernel [3,3,3,Cin,16] (Cin 16 or 32), including 4 trailing zeros.
+extern "C" int atvs_conv_c16_pack_size(int Cin, long* packed_floats) {
+  if (!packed_floats) return ATVS_ERR_NULL;
+  if (!c16_shape_ok(Cin)) return ATVS_ERR_SHAPE;
+  *packed_floats = (long)(Cin / 16) * C16_TAPS * 256 + 4;
+  return ATVS_OK;
+}
+
+// HOST function.  w: TF kernel [3,3,3,Cin,16].  packed[chunk][tap][lane = q*16 + co][s] = w[tap][chunk*16 + 4q + s][co].
+extern "C" int atvs_conv_c16_pack(const float* w, int Cin, float* packed) {
+  if (!w || !packed) return ATVS_ERR_NULL;
+  long pf;
+  int rc = atvs_conv_c16_pack_size(Cin, &pf);
+  if (rc) return rc;
+  for (long i = 0; i < pf; ++i) packed[i] = 0.f;
+  for (int ch = 0; ch < Cin / 16; ++ch)
+    for (int j = 0; j < C16_TAPS; ++j)
+      for (int q = 0; q < 4; ++q)
+        for (int co = 0; co < 16; ++co)
+          for (int s = 0; s < 4; ++s)
+            packed[((((size_t)ch * C16_TAPS + j) * 64) + q * 16 + co) * 4 + s] =
+                w[((size_t)j * Cin + ch * 16 + 4 * q + s) * 16 + co];
+  return ATVS_OK;
+}
+
+// workgroups PER SAMPLE of a launch over `groups` independent samples (rows of the statistics buffer = groups * this):
+// one workgroup per CU in all, shared out among the samples, a multiple of 8 each
+extern "C" long atvs_conv_c16_grid(int D, int H, int W, int groups) {
+  if (groups < 1) groups = 1;
+  long nt = c16_ntiles(D, H, W);
+  long share = 256 / groups / 8 * 8;
+  if (share < 8) share = 8;
+  long g = nt < share ? nt : share;
+  return (g + 7) / 8 * 8;
+}
+
+// y (D,H,W,ldy)[..., y_coff : y_coff + 16] = conv3d(x (D,H,W,Cin), w, stride 1, SAME) (+ bias, ReLU), `groups` independent
+// samples on the leading axis of x / y.  stats_partial: groups * atvs_conv_c16_grid rows of [2][16] doubles (partial
+// sums / sums of squares per channel of the stored values), or NULL.
+extern "C" int atvs_conv_c16_f32(const float* x, const float* packed_w, const float* bias, float* y, double* stats_partial,
+                                 int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                                 atvs_stream_t stream) {
+  if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (!c16_shape_ok(Cin) || groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + 16 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;            // 31-bit halo-relative element offsets
+  if ((double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;      // 32-bit output BYTE offsets (buffer stores)
+  C16Args a;
+  a.x = x; a.wp = packed_w; a.zeros = packed_w + (size_t)(Cin / 16) * C16_TAPS * 256;
+  a.bias = bias; a.y = y; a.stats = stats_partial;
+  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16;
+  a.tiles_y = (H + C16_TY - 1) / C16_TY; a.tiles_x = (W + C16_TX - 1) / C16_TX;
+  a.ntiles = (int)c16_ntiles(D, H, W);
+  const long blocks = atvs_conv_c16_grid(D, H, W, groups);
+  a.wg = (int)blocks;
+  a.gx = (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy;
+  if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  int rc = relu ? launch_c16<true>(a, blocks * groups, stream) : launch_c16<false>(a, blocks * groups, stream);
+  if (rc) return rc;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

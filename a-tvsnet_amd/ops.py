@@ -364,6 +364,42 @@ def pack_deconv_up(key, w_host, device):
     return pk
 
 
+def pack_conv_c16(key, w_host, device):
+    """Packed weights of the 16-output-channel 3x3x3 kernel (atvs_conv_c16_f32); cached."""
+    import numpy as np
+    ck = ('c16', key, str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)           # [3,3,3,Cin,16]
+    cin = int(w.shape[-2])
+    L = _lib.lib()
+    pf = ctypes.c_long()
+    rc = L.atvs_conv_c16_pack_size(cin, ctypes.byref(pf))
+    if rc:
+        raise RuntimeError('atvs_conv_c16_pack_size failed (%d) for Cin=%d' % (rc, cin))
+    packed = np.empty(pf.value, np.float32)
+    rc = L.atvs_conv_c16_pack(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv_c16_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, 16
+    pk.key = key
+    pk.tab = None
+    pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+_USE_C16 = True
+
+
+def use_conv_c16(flag):
+    """Testing / A-B hook: the one-workgroup-per-CU kernel for 3x3x3 convolutions 16 / 32 -> 16 channels."""
+    global _USE_C16
+    _USE_C16 = bool(flag)
+
+
 _USE_DECONV_UP = True
 
 
@@ -929,6 +965,27 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
                 _call('atvs_conv_stem_f32', _p(x5), _p(wd.wp), _p(plane_bias), _p(y5),
                       ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, outs[0], outs[1],
                       outs[2], cin, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+        y = out if out is not None else _from5(y5, nsp, groups)
+        return (y, st) if want_stats else y
+
+    # ---- 3-D, 3x3x3, 16 / 32 -> 16 channels: one workgroup per CU, fully unrolled (the half-resolution U-Net layers)
+    if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) and cout == 16 \
+            and cin in (16, 32) and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
+            and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (16 if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
+            and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
+        pk = pack_conv_c16(key, w_host, x.device)
+        if y5 is None:
+            y5 = _new(x, (G,) + tuple(outs) + (16,))
+        st, sbuf = None, None
+        if want_stats:
+            rows = int(_lib.lib().atvs_conv_c16_grid(outs[0], outs[1], outs[2], G))
+            sbuf = _stats_buffer(x, rows, 16, groups=G)
+            st = Stats()
+            st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, 16, M, G
+        if _dev_ok(x5, y5, bias):
+            with _Timed(key, x5.shape[1:], 16, G):
+                _call('atvs_conv_c16_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
+                      int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 
