@@ -1,11 +1,14 @@
-// 3x3x3 SAME stride-1 convolution to SIXTEEN output channels from 16 k input channels, one wavefront per SIMD (gfx950).
+// 3x3x3 SAME stride-1 convolution to SIXTEEN output channels from 8, 16 or 32 input channels, one wavefront per SIMD
+// (gfx950).
 //
 // These are the half-resolution layers of the stacked U-Nets / the refinement net (conv_b*_1_1, global_refine_3dconv1_1:
 // 16 -> 16 channels on a (D/2, h/2, w/2) volume; cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, layer code
-// /root/reference/cnn_wrapper/network.py:165-215): 16 output channels fill the 16 rows of an MFMA tile exactly (every
-// issued MFMA is useful), and on the generic LDS-tiled kernel (conv_tiled.hip) they were its largest block of time at
-// 55 % of the fp32 MFMA peak (MFMA pipe busy 58 %, 2.75 other VALU instructions per MFMA: run-time tap tables, rotating
-// register copies, a halo burst in front of the K loop, two workgroups per CU on half the register file each).
+// /root/reference/cnn_wrapper/network.py:165-215) and the shared | unique convolution of the AANet modules (8 -> 8 + 8
+// channels at full resolution, network.py:282-351 issued as one 8 -> 16 convolution): 16 output channels fill the 16 rows
+// of an MFMA tile exactly (every issued MFMA is useful; 27 of 28 with 8 input channels, two taps per K step), and on the
+// generic LDS-tiled kernel (conv_tiled.hip) they were its largest blocks of time at 55-57 % of the fp32 MFMA peak (MFMA
+// pipe busy 58 %, 2.75 other VALU instructions per MFMA: run-time tap tables, rotating register copies, a halo burst in
+// front of the K loop, two workgroups per CU on half the register file each).
 //
 // Built like conv_xp.hip / deconv_up.hip: ONE workgroup of 4 wavefronts per CU with the whole register file; tile =
 // 4(z) x 8(y) x 16(x) output voxels, wavefront w owns plane z0 + w (8 accumulator tiles); the K loop is fully unrolled
@@ -22,16 +25,32 @@ namespace {
 
 constexpr int C16_TZ = 4, C16_TY = 8, C16_TX = 16;
 constexpr int C16_HZ = C16_TZ + 2, C16_HY = C16_TY + 2, C16_HX = C16_TX + 2;
-constexpr int C16_VB = 64;                                // bytes per voxel of a 16-channel chunk in LDS
-constexpr int C16_PITCHV = 24;                            // voxels per image row (18 used): 1536 B = 3 x 512
-constexpr int C16_ROWB = C16_PITCHV * C16_VB;
-constexpr int C16_IMG = C16_HZ * C16_HY * C16_ROWB;       // 92,160 bytes
-constexpr int C16_SLOTS = C16_HZ * C16_HY * C16_HX * 4;   // 16-byte halo slots
-constexpr int C16_MAXS = (C16_SLOTS + 255) / 256;         // 17 per thread
 constexpr int C16_TAPS = 27;
-constexpr int C16_WCH = C16_TAPS * 1024;                  // bytes of packed weights per chunk
-static_assert(C16_MAXS <= C16_TAPS, "one halo slot per tap");
-static_assert(((2 * C16_HY + 2) + C16_TY) * C16_ROWB < 65536, "ds_read immediate offset");
+
+// C4 = float4 channel groups per voxel of a chunk: 4 (16-channel chunks; Cin 16 / 32) or 2 (Cin 8).
+//   C4 == 4: one tap per K step, lane group q = channel group; the image is bank-swizzled (bit 5 ^= bit 8) and its row
+//            pitch (24 voxels = 1536 B) a multiple of 512 B, so (kd, kh, row) displacements are immediates.
+//   C4 == 2: two taps per K step, tap = 2 j + (q >> 1), channel group q & 1; 32-byte voxels need no swizzle (the 16-lane
+//            groups of a 128-bit read already fall into distinct bank slots), every displacement is a plain addend.
+template <int C4>
+struct C16 {
+  static_assert(C4 == 4 || C4 == 2, "8- or 16-channel chunks");
+  static constexpr int VB = C4 * 16;                           // bytes per voxel in LDS
+  static constexpr int PITCHV = (C4 == 4) ? 24 : C16_HX;       // voxels per image row
+  static constexpr int ROWB = PITCHV * VB;
+  static constexpr int IMG = C16_HZ * C16_HY * ROWB;           // 92,160 / 34,560 bytes
+  static constexpr int SLOTS = C16_HZ * C16_HY * C16_HX * C4;  // 16-byte halo slots
+  static constexpr int MAXS = (SLOTS + 255) / 256;             // 17 / 9 per thread
+  static constexpr int JC = (C4 == 4) ? C16_TAPS : (C16_TAPS + 1) / 2;      // K steps per chunk
+  static constexpr int WCH = JC * 1024;                        // bytes of packed weights per chunk
+  static constexpr int CC = 4 * C4;                            // channels per chunk
+  static_assert(MAXS <= JC, "one halo slot per K step");
+  static_assert(((2 * C16_HY + 2) + C16_TY) * ROWB + 2 * VB < 65536, "ds_read immediate offset");
+  // byte displacement of tap t from the halo voxel (wave, 0, r): (kd, kh) rows (+ kw voxels when it is not a base register)
+  static constexpr int disp(int t, bool with_kw) {
+    return ((t / 9) * C16_HY + (t / 3) % 3) * ROWB + (with_kw ? (t % 3) * VB : 0);
+  }
+};
 
 struct C16Args {
   const float* x;
@@ -64,9 +83,10 @@ __device__ __forceinline__ void c16_static_for(F&& f) {
   c16_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <bool RELU>
+template <int C4, bool RELU>
 __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
-  constexpr int TY = C16_TY, HY = C16_HY, MAXS = C16_MAXS;
+  using K = C16<C4>;
+  constexpr int TY = C16_TY, HY = C16_HY, MAXS = K::MAXS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -75,16 +95,19 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
   // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
   {
     const float4* src = reinterpret_cast<const float4*>(p.wp);
-    float4* dst = reinterpret_cast<float4*>(smem + C16_IMG);
-    for (int i = tid; i < p.nchunk * (C16_WCH / 16); i += 256) dst[i] = src[i];
+    float4* dst = reinterpret_cast<float4*>(smem + K::IMG);
+    for (int i = tid; i < p.nchunk * (K::WCH / 16); i += 256) dst[i] = src[i];
   }
 
   // LDS read bases: this lane's fragment at halo voxel (wave, 0, r + kw) = tap (0, 0, kw) of row 0 of the wavefront's
-  // plane, swizzled; every (kd, kh, row) is an immediate from there
+  // plane.  C4 == 4: one swizzled base per kw, every (kd, kh, row) an immediate from there; C4 == 2: one base (kw = 0)
   int fbase[3];
 #pragma unroll
-  for (int kw = 0; kw < 3; ++kw) fbase[kw] = c16_swz(((wave * HY) * C16_PITCHV + r + kw) * C16_VB + q * 16);
-  const int wbase = C16_IMG + lane * 16;
+  for (int kw = 0; kw < 3; ++kw) {
+    const int a = ((wave * HY) * K::PITCHV + r + kw) * K::VB + ((C4 == 4) ? q : (q & 1)) * 16;
+    fbase[kw] = (C4 == 4) ? c16_swz(a) : a;
+  }
+  const int wbase = K::IMG + lane * 16;
 
   // per-slot constants of this thread: global element offset from the halo origin, swizzled LDS byte address and the
   // packed halo coordinate (zz | yy<<8 | xx<<16, each byte with its top bit set) for the bounds test
@@ -93,13 +116,14 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
 #pragma unroll
   for (int i = 0; i < MAXS; ++i) {
     int s = tid + i * 256;
-    const bool live = s < C16_SLOTS;
-    s = min(s, C16_SLOTS - 1);
-    const int c4 = s & 3, v = s >> 2;
+    const bool live = s < K::SLOTS;
+    s = min(s, K::SLOTS - 1);
+    const int c4 = s % C4, v = s / C4;
     const int xx = v % C16_HX, v2 = v / C16_HX;
     const int yy = v2 % HY, zz = v2 / HY;
     goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
-    laddr[i] = c16_swz(((zz * HY + yy) * C16_PITCHV + xx) * C16_VB + c4 * 16);
+    const int la = ((zz * HY + yy) * K::PITCHV + xx) * K::VB + c4 * 16;
+    laddr[i] = (C4 == 4) ? c16_swz(la) : la;
     pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
   }
 
@@ -139,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
     int z0, y0, x0;
     tile_origin(k, &z0, &y0, &x0);
     const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
-    T.xb = xg + ch * 16;
+    T.xb = xg + ch * K::CC;
     T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
     T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
     T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
@@ -178,27 +202,35 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
     __syncthreads();                       // every wavefront is done reading the previous stage's image
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
-      if (i < MAXS - 1 || tid + i * 256 < C16_SLOTS) *reinterpret_cast<float4*>(smem + laddr[i]) = pf[i];
+      if (i < MAXS - 1 || tid + i * 256 < K::SLOTS) *reinterpret_cast<float4*>(smem + laddr[i]) = pf[i];
     __syncthreads();
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
-    const int wb = wbase + ch * C16_WCH;
+    const int wb = wbase + ch * K::WCH;
 
-    // ---- K loop: 27 taps, fully unrolled
+    // ---- K loop, fully unrolled: 27 steps of one tap (C4 == 4) or 14 steps of two taps (C4 == 2; the 28th tap has zero
+    // weights and re-reads the 27th's fragment)
     float4 B[2][TY], Wt[2];
     auto request = [&](auto JT) __attribute__((always_inline)) {
-      constexpr int j = decltype(JT)::value, kd = j / 9, kh = (j / 3) % 3, kw = j % 3;
-      constexpr int disp = (kd * HY + kh) * C16_ROWB;
+      constexpr int j = decltype(JT)::value;
+      if constexpr (C4 == 4) {
+        constexpr int disp = K::disp(j, false);
 #pragma unroll
-      for (int t = 0; t < TY; ++t)
-        B[j & 1][t] = *reinterpret_cast<const float4*>(smem + fbase[kw] + (disp + t * C16_ROWB));
+        for (int t = 0; t < TY; ++t)
+          B[j & 1][t] = *reinterpret_cast<const float4*>(smem + fbase[j % 3] + (disp + t * K::ROWB));
+      } else {
+        constexpr int t0 = 2 * j, t1 = (2 * j + 1 < C16_TAPS) ? 2 * j + 1 : C16_TAPS - 1;
+        const int a = fbase[0] + ((q >> 1) ? K::disp(t1, true) : K::disp(t0, true));
+#pragma unroll
+        for (int t = 0; t < TY; ++t) B[j & 1][t] = *reinterpret_cast<const float4*>(smem + a + t * K::ROWB);
+      }
       Wt[j & 1] = *reinterpret_cast<const float4*>(smem + wb + j * 1024);
     };
     request(IC<0>{});
     asm volatile("" ::: "memory");
-    c16_static_for<C16_TAPS>([&](auto JT) __attribute__((always_inline)) {
+    c16_static_for<K::JC>([&](auto JT) __attribute__((always_inline)) {
       constexpr int j = decltype(JT)::value;
-      if constexpr (j + 1 < C16_TAPS) request(IC<j + 1>{});
+      if constexpr (j + 1 < K::JC) request(IC<j + 1>{});
       if constexpr (j < MAXS) pf_slot(T, j);
       // compiler barrier (keeps the requests from sinking to their uses) + scheduling barrier (keeps them in front of
       // the MFMAs that cover their latency)
@@ -272,43 +304,58 @@ long c16_ntiles(int D, int H, int W) {
   return (long)((D + C16_TZ - 1) / C16_TZ) * ((H + C16_TY - 1) / C16_TY) * ((W + C16_TX - 1) / C16_TX);
 }
 
-// weights of every chunk + the image must fit 160 KB of LDS: Cin 16 or 32
-bool c16_shape_ok(int Cin) { return Cin == 16 || Cin == 32; }
+// weights of every chunk + the image must fit 160 KB of LDS: Cin 8 (one 8-channel chunk), 16 or 32 (16-channel chunks)
+bool c16_shape_ok(int Cin) { return Cin == 8 || Cin == 16 || Cin == 32; }
+int c16_c4(int Cin) { return Cin == 8 ? 2 : 4; }
+long c16_packed_floats(int Cin) { return Cin == 8 ? (long)C16<2>::JC * 256 : (long)(Cin / 16) * C16<4>::JC * 256; }
 
-template <bool RELU>
+template <int C4, bool RELU>
 int launch_c16(const C16Args& a, long grid, atvs_stream_t stream) {
-  const size_t lds = (size_t)C16_IMG + (size_t)a.nchunk * C16_WCH;
+  const size_t lds = (size_t)C16<C4>::IMG + (size_t)a.nchunk * C16<C4>::WCH;
   // the attribute is per device: one flag per device ordinal of this process (and per instantiation)
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_kernel<RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_kernel<C4, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv_c16_kernel<RELU>), dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
+  hipLaunchKernelGGL((conv_c16_kernel<C4, RELU>), dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
   return ATVS_OK;
 }
 
 }  // namespace
 
-// Floats of the packed form of a kernel [3,3,3,Cin,16] (Cin 16 or 32), including 4 trailing zeros.
+// Floats of the packed form of a kernel [3,3,3,Cin,16] (Cin 8, 16 or 32), including 4 trailing zeros.
 extern "C" int atvs_conv_c16_pack_size(int Cin, long* packed_floats) {
   if (!packed_floats) return ATVS_ERR_NULL;
   if (!c16_shape_ok(Cin)) return ATVS_ERR_SHAPE;
-  *packed_floats = (long)(Cin / 16) * C16_TAPS * 256 + 4;
+  *packed_floats = c16_packed_floats(Cin) + 4;
   return ATVS_OK;
 }
 
-// HOST function.  w: TF kernel [3,3,3,Cin,16].  packed[chunk][tap][lane = q*16 + co][s] = w[tap][chunk*16 + 4q + s][co].
+// HOST function.  w: TF kernel [3,3,3,Cin,16].  Cin 16 / 32: packed[chunk][tap][lane = q*16 + co][s] =
+// w[tap][chunk*16 + 4q + s][co];  Cin 8: packed[step][lane = q*16 + co][s] = w[tap = 2 step + (q>>1)][(q&1)*4 + s][co]
+// (zero for tap 27).
 extern "C" int atvs_conv_c16_pack(const float* w, int Cin, float* packed) {
   if (!w || !packed) return ATVS_ERR_NULL;
   long pf;
   int rc = atvs_conv_c16_pack_size(Cin, &pf);
   if (rc) return rc;
   for (long i = 0; i < pf; ++i) packed[i] = 0.f;
+  if (Cin == 8) {
+    for (int j = 0; j < C16<2>::JC; ++j)
+      for (int q = 0; q < 4; ++q) {
+        const int tap = 2 * j + (q >> 1);
+        if (tap >= C16_TAPS) continue;
+        for (int co = 0; co < 16; ++co)
+          for (int s = 0; s < 4; ++s)
+            packed[(((size_t)j * 64) + q * 16 + co) * 4 + s] = w[((size_t)tap * 8 + (q & 1) * 4 + s) * 16 + co];
+      }
+    return ATVS_OK;
+  }
   for (int ch = 0; ch < Cin / 16; ++ch)
     for (int j = 0; j < C16_TAPS; ++j)
       for (int q = 0; q < 4; ++q)
@@ -342,16 +389,18 @@ extern "C" int atvs_conv_c16_f32(const float* x, const float* packed_w, const fl
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;            // 31-bit halo-relative element offsets
   if ((double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;      // 32-bit output BYTE offsets (buffer stores)
   C16Args a;
-  a.x = x; a.wp = packed_w; a.zeros = packed_w + (size_t)(Cin / 16) * C16_TAPS * 256;
+  a.x = x; a.wp = packed_w; a.zeros = packed_w + c16_packed_floats(Cin);
   a.bias = bias; a.y = y; a.stats = stats_partial;
-  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16;
+  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = (Cin == 8) ? 1 : Cin / 16;
   a.tiles_y = (H + C16_TY - 1) / C16_TY; a.tiles_x = (W + C16_TX - 1) / C16_TX;
   a.ntiles = (int)c16_ntiles(D, H, W);
   const long blocks = atvs_conv_c16_grid(D, H, W, groups);
   a.wg = (int)blocks;
   a.gx = (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy;
   if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  int rc = relu ? launch_c16<true>(a, blocks * groups, stream) : launch_c16<false>(a, blocks * groups, stream);
+  int rc;
+  if (c16_c4(Cin) == 2) rc = relu ? launch_c16<2, true>(a, blocks * groups, stream) : launch_c16<2, false>(a, blocks * groups, stream);
+  else rc = relu ? launch_c16<4, true>(a, blocks * groups, stream) : launch_c16<4, false>(a, blocks * groups, stream);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

@@ -395,7 +395,7 @@ _USE_C16 = True
 
 
 def use_conv_c16(flag):
-    """Testing / A-B hook: the one-workgroup-per-CU kernel for 3x3x3 convolutions 16 / 32 -> 16 channels."""
+    """Testing / A-B hook: the one-workgroup-per-CU kernel for 3x3x3 convolutions 8 / 16 / 32 -> 16 channels."""
     global _USE_C16
     _USE_C16 = bool(flag)
 
@@ -968,9 +968,10 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 
-    # ---- 3-D, 3x3x3, 16 / 32 -> 16 channels: one workgroup per CU, fully unrolled (the half-resolution U-Net layers)
+    # ---- 3-D, 3x3x3, 8 / 16 / 32 -> 16 channels: one workgroup per CU, fully unrolled (the half-resolution U-Net layers,
+    # the AANet modules' shared | unique convolution)
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) and cout == 16 \
-            and cin in (16, 32) and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
+            and cin in (8, 16, 32) and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
             and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (16 if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
         pk = pack_conv_c16(key, w_host, x.device)

@@ -261,7 +261,8 @@ def test_deconv_up_against_torch_and_the_class_fused_form(cuda, G, shape, cin, c
     assert torch.equal(relu, torch.clamp(got, min=0))
 
 
-@pytest.mark.parametrize('G,shape,cin', [(1, (9, 17, 33), 16), (2, (4, 8, 16), 32), (3, (5, 9, 18), 16), (2, (12, 24, 40), 32)])
+@pytest.mark.parametrize('G,shape,cin', [(1, (9, 17, 33), 16), (2, (4, 8, 16), 32), (3, (5, 9, 18), 16), (2, (12, 24, 40), 32),
+                                        (1, (9, 17, 33), 8), (3, (5, 9, 18), 8), (2, (12, 24, 40), 8)])
 def test_conv_c16_against_torch_and_the_tiled_kernel(cuda, G, shape, cin):
     """The 16 / 32 -> 16 channel 3x3x3 convolutions (conv_b*_1_1, reference cnn_wrapper/network.py:165-215) on their own
     kernel (csrc/conv_c16.hip): against tf.nn.conv3d restated with torch (2e-5 of the output scale: another accumulation
