@@ -151,6 +151,72 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
   if (mask_out && c == 0) mask_out[(size_t)d * npix + pix] = t.valid;
 }
 
+// The same warp with the per-pixel geometry computed ONCE and shared by the pixel's channel-group lanes.  In the kernel
+// above every one of the C/4 lanes of a pixel repeats the homography, the floor / clip and the four area weights (~100
+// VALU instructions for one 16-byte store: the kernel was instruction-bound at 46 % of the HBM peak).  Here a workgroup
+// owns 256 pixels of one plane: phase 1, one pixel per thread -> taps and weights into LDS (48 bytes per pixel); phase 2,
+// C/4 passes in which thread t handles pixel pass * (256 / cg) + t / cg, channel group t % cg: two broadcast LDS reads,
+// four gathers, the blend in packed fp32 (two channels per instruction; the same IEEE operations in the same order as
+// blend4, so the result is bit-identical), one 16-byte store -- every pass writes 4 KB contiguous.
+template <int MODE>
+__global__ __launch_bounds__(256) void warp_planes_shared_kernel(
+    const float* __restrict__ src, const float* __restrict__ Hmats, const float* __restrict__ ref,
+    float* __restrict__ out, float* __restrict__ mask_out, int h, int w, int C, int ld, int c_off) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  __shared__ __attribute__((aligned(16))) float s_geo[256 * 12];
+  const int d = blockIdx.y;
+  const int tid = threadIdx.x;
+  const long npix = (long)h * w;
+  const long pix0 = (long)blockIdx.x * 256;
+  {
+    const long pix = pix0 + tid;
+    Tap4 t;
+    t.i00 = t.i01 = t.i10 = t.i11 = 0;
+    t.wa = t.wb = t.wc = t.wd = t.valid = 0.f;
+    if (pix < npix) {
+      float Hm[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Hm[i] = Hmats[d * 9 + i];
+      const int y = (int)(pix / w), x = (int)(pix % w);
+      float xw, yw;
+      homography_apply(Hm, x, y, &xw, &yw);
+      t = bilinear_taps(xw, yw, h, w);
+      if (mask_out) mask_out[(size_t)d * npix + pix] = t.valid;
+    }
+    float4* g = reinterpret_cast<float4*>(s_geo + tid * 12);
+    g[0] = make_float4(__int_as_float(t.i00), __int_as_float(t.i01), __int_as_float(t.i10), __int_as_float(t.i11));
+    g[1] = make_float4(t.wa, t.wb, t.wc, t.wd);
+    g[2] = make_float4(t.valid, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  const int cg = C >> 2;                 // lanes per pixel: 4, 8 or 16 (a divisor of 256)
+  const int ppp = 256 / cg;              // pixels per pass
+  const int lp = tid / cg, c = (tid % cg) * 4;
+  for (int pass = 0; pass < cg; ++pass) {
+    const int pl = pass * ppp + lp;
+    const long pix = pix0 + pl;
+    if (pix >= npix) break;              // pixels ascend with the pass
+    const float4* g = reinterpret_cast<const float4*>(s_geo + pl * 12);
+    const float4 gi = g[0], gw = g[1];
+    const float4 a = ld4(src + (size_t)__float_as_int(gi.x) * C + c), b = ld4(src + (size_t)__float_as_int(gi.y) * C + c);
+    const float4 cc = ld4(src + (size_t)__float_as_int(gi.z) * C + c), dd = ld4(src + (size_t)__float_as_int(gi.w) * C + c);
+    // ((wa a + wb b) + wc c) + wd d per component, two components per instruction
+    const f32x2 wa = {gw.x, gw.x}, wb = {gw.y, gw.y}, wc = {gw.z, gw.z}, wd = {gw.w, gw.w};
+    f32x2 lo = ((wa * (f32x2){a.x, a.y} + wb * (f32x2){b.x, b.y}) + wc * (f32x2){cc.x, cc.y}) + wd * (f32x2){dd.x, dd.y};
+    f32x2 hi = ((wa * (f32x2){a.z, a.w} + wb * (f32x2){b.z, b.w}) + wc * (f32x2){cc.z, cc.w}) + wd * (f32x2){dd.z, dd.w};
+    float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
+    if (MODE == 1) {
+      const float valid = g[2].x;
+      const float4 r = ld4(ref + (size_t)pix * C + c);
+      o.x = fabsf(o.x - r.x) * valid;
+      o.y = fabsf(o.y - r.y) * valid;
+      o.z = fabsf(o.z - r.z) * valid;
+      o.w = fabsf(o.w - r.w) * valid;
+    }
+    st4(out + ((size_t)d * npix + pix) * (size_t)ld + c_off + c, o);
+  }
+}
+
 extern "C" int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
                                 const float* depth_start, const float* depth_interval, float* out, float* mask_out,
                                 int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep,
@@ -164,6 +230,18 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
   long lanes = (long)h * w * (mode == 2 ? 1 : (vec ? C / 4 : C));
   dim3 grid(cdiv(lanes, 256), D), block(256);
   hipStream_t s = as_stream(stream);
+  if (vec && (C == 16 || C == 32 || C == 64)) {
+    // geometry once per pixel, shared by its channel-group lanes
+    dim3 g2(cdiv((long)h * w, 256), D);
+    if (mode == 0)
+      hipLaunchKernelGGL((warp_planes_shared_kernel<0>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
+                         ld_out, c_off);
+    else
+      hipLaunchKernelGGL((warp_planes_shared_kernel<1>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
+                         ld_out, c_off);
+    ATVS_LAUNCH_CHECK();
+    return ATVS_OK;
+  }
 #define LAUNCH(M, V)                                                                                            \
   hipLaunchKernelGGL((warp_planes_kernel<M, V>), grid, block, 0, s, src, homographies, ref, depth_start,        \
                      depth_interval, out, mask_out, D, h, w, C, ld_out, c_off, rep)

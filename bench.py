@@ -498,7 +498,7 @@ def rank_main(args):
             wb = 4.0 * 32 * vox + 4.0 * 32 * h * w
             avg_ms = float(np.mean([ms for ms, _ in watched[WARP]]))
             gbs = wb / (avg_ms * 1e-3) / 1e9
-            roof_hbm = {'bound': 'hbm', 'kernel': 'warp_planes_kernel<bilinear, float4> (cost-volume build, 32 channels)',
+            roof_hbm = {'bound': 'hbm', 'kernel': 'warp_planes_shared_kernel<bilinear> (cost-volume build, 32 channels; geometry once per pixel)',
                         'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
                         'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[WARP]),
                         'algorithmic_bytes_per_launch': wb, 'traffic': None}
