@@ -161,31 +161,43 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
   const bool col_ok = xo < W && yo < H;
   // tap-outer, z-inner: the 32 weights of a tap are wave-uniform (scalar registers) and serve the thread's whole
   // column of ST_TZ voxels (one ds_read_b128 of (geo0, geo1, prob, hull) per 32 FMAs)
-  float acc[ST_TZ][24];
+  // packed fp32 fused multiply-adds: two output channels per instruction (v_pk_fma_f32; each half is the same IEEE
+  // fused operation as fmaf) -- the kernel is VALU-bound (864 FMAs per voxel against 200 bytes of traffic)
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc2[ST_TZ][12];
 #pragma unroll
   for (int z = 0; z < ST_TZ; ++z)
 #pragma unroll
-    for (int k = 0; k < 24; ++k) acc[z][k] = 0.f;
+    for (int k = 0; k < 12; ++k) acc2[z][k] = (f32x2){0.f, 0.f};
 #pragma unroll 1
   for (int kd = 0; kd < 3; ++kd)
 #pragma unroll 1
     for (int j = 0; j < 9; ++j) {
       const float* wk = w + (kd * 9 + j) * 32;                  // uniform address: scalar loads
-      float wr[32];
+      f32x2 wr[16];
 #pragma unroll
-      for (int k = 0; k < 32; ++k) wr[k] = wk[k];
+      for (int k = 0; k < 16; ++k) wr[k] = (f32x2){wk[2 * k], wk[2 * k + 1]};
 #pragma unroll
       for (int z = 0; z < ST_TZ; ++z) {
         const float4 v = tile[((z + kd) * ST_HY + ly + j / 3) * ST_HX + lx + j % 3];
+        const f32x2 vx = {v.x, v.x}, vy = {v.y, v.y}, vz = {v.z, v.z}, vw = {v.w, v.w};
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          // fused multiply-adds, as on the matrix cores (the file is built with -ffp-contract=off for the geometry)
-          acc[z][k] = fmaf(v.x, wr[k], acc[z][k]);               // geo: channel 0, then channel 1 (the kernel's ci order)
-          acc[z][k] = fmaf(v.y, wr[8 + k], acc[z][k]);
-          acc[z][8 + k] = fmaf(v.z, wr[16 + k], acc[z][8 + k]);
-          acc[z][16 + k] = fmaf(v.w, wr[24 + k], acc[z][16 + k]);
+        for (int k = 0; k < 4; ++k) {
+          // geo: channel 0, then channel 1 (the kernel's ci order)
+          acc2[z][k] = __builtin_elementwise_fma(vx, wr[k], acc2[z][k]);
+          acc2[z][k] = __builtin_elementwise_fma(vy, wr[4 + k], acc2[z][k]);
+          acc2[z][4 + k] = __builtin_elementwise_fma(vz, wr[8 + k], acc2[z][4 + k]);
+          acc2[z][8 + k] = __builtin_elementwise_fma(vw, wr[12 + k], acc2[z][8 + k]);
         }
       }
+    }
+  float acc[ST_TZ][24];
+#pragma unroll
+  for (int z = 0; z < ST_TZ; ++z)
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      acc[z][2 * k] = acc2[z][k].x;
+      acc[z][2 * k + 1] = acc2[z][k].y;
     }
   float ssum[24], ssq[24];
 #pragma unroll
