@@ -83,17 +83,23 @@ __device__ __forceinline__ void c16_static_for(F&& f) {
   c16_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int C4, bool RELU>
+// NT = 16-channel output tiles: 1 (16 channels; packed weights of every chunk resident in LDS) or 2 (32 channels: the
+// weights no longer fit next to the image and stream from L2, requested C16_LOOK steps ahead like conv_xp.hip's).
+constexpr int C16_LOOK = 4;
+
+template <int C4, int NT, bool RELU>
 __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
   using K = C16<C4>;
   constexpr int TY = C16_TY, HY = C16_HY, MAXS = K::MAXS;
+  constexpr bool WLDS = (NT == 1);
+  static_assert(NT == 1 || C4 == 4, "32 output channels: 16-channel chunks only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
 
   // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
-  {
+  if (WLDS) {
     const float4* src = reinterpret_cast<const float4*>(p.wp);
     float4* dst = reinterpret_cast<float4*>(smem + K::IMG);
     for (int i = tid; i < p.nchunk * (K::WCH / 16); i += 256) dst[i] = src[i];
@@ -179,10 +185,14 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
   };
 
   // moments of this lane's channels 4q + {0,1 | 2,3}
-  f32x2 ssum2[2] = {{0.f, 0.f}, {0.f, 0.f}}, ssq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-  f32x4 acc[TY];
-  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (p.bias) bv = ld4(p.bias + q * 4);
+  f32x2 ssum2[NT][2], ssq2[NT][2];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) ssum2[n][0] = ssum2[n][1] = ssq2[n][0] = ssq2[n][1] = (f32x2){0.f, 0.f};
+  f32x4 acc[TY][NT];
+  float4 bv[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) bv[n] = p.bias ? ld4(p.bias + n * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4* __restrict__ wpg = reinterpret_cast<const float4*>(p.wp);
   // this sample's output as a buffer: stores at or beyond ybytes are dropped by the range check
   const unsigned ybytes = (unsigned)(p.gy * 4);
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
@@ -197,7 +207,18 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
     const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
     if (ch == 0) {
 #pragma unroll
-      for (int t = 0; t < TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < TY; ++t)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // streamed weights: those of the first steps are on their way while the image is written
+    const float4* wch = wpg + (size_t)ch * K::JC * NT * 64 + lane;
+    float4 Wg[WLDS ? 1 : K::JC][NT];
+    if (!WLDS) {
+#pragma unroll
+      for (int jj = 0; jj < C16_LOOK; ++jj)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Wg[jj][n] = wch[(jj * NT + n) * 64];
     }
     __syncthreads();                       // every wavefront is done reading the previous stage's image
 #pragma unroll
@@ -224,12 +245,16 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
 #pragma unroll
         for (int t = 0; t < TY; ++t) B[j & 1][t] = *reinterpret_cast<const float4*>(smem + a + t * K::ROWB);
       }
-      Wt[j & 1] = *reinterpret_cast<const float4*>(smem + wb + j * 1024);
+      if constexpr (WLDS) Wt[j & 1] = *reinterpret_cast<const float4*>(smem + wb + j * 1024);
     };
     request(IC<0>{});
     asm volatile("" ::: "memory");
     c16_static_for<K::JC>([&](auto JT) __attribute__((always_inline)) {
       constexpr int j = decltype(JT)::value;
+      if constexpr (!WLDS && j + C16_LOOK < K::JC) {
+#pragma unroll
+        for (int n = 0; n < NT; ++n) Wg[(WLDS ? 0 : j + C16_LOOK)][n] = wch[((j + C16_LOOK) * NT + n) * 64];
+      }
       if constexpr (j + 1 < K::JC) request(IC<j + 1>{});
       if constexpr (j < MAXS) pf_slot(T, j);
       // compiler barrier (keeps the requests from sinking to their uses) + scheduling barrier (keeps them in front of
@@ -237,10 +262,14 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int n = 0; n < NT; ++n) {
+        const float4 wv = WLDS ? Wt[j & 1] : Wg[WLDS ? 0 : j][n];
 #pragma unroll
-        for (int t = 0; t < TY; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(Wt[j & 1], s), f4get(B[j & 1][t], s), acc[t], 0, 0, 0);
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int t = 0; t < TY; ++t)
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(f4get(wv, s), f4get(B[j & 1][t], s), acc[t][n], 0, 0, 0);
+      }
     });
     if (ch != p.nchunk - 1) continue;
 
@@ -255,47 +284,53 @@ __global__ __launch_bounds__(256, 1) void conv_c16_kernel(C16Args p) {
     const unsigned vo_ok = evox_ok ? eo * 4u : ybytes;
     c16_static_for<TY>([&](auto TT) __attribute__((always_inline)) {
       constexpr int t = decltype(TT)::value;
-      float a0 = acc[t][0] + bv.x, a1 = acc[t][1] + bv.y, a2 = acc[t][2] + bv.z, a3 = acc[t][3] + bv.w;
-      if (RELU) {                                    // NaN passes through, as in tf.nn.relu
-        a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
-        a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
-      }
-      const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
-                          __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
       const bool row_ok = ty0 + t < p.Hi;            // uniform
-      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, t * erow * 4u, 0);
       const bool ok = evox_ok && row_ok;
-      f32x2 lo = {ok ? a0 : 0.f, ok ? a1 : 0.f}, hi = {ok ? a2 : 0.f, ok ? a3 : 0.f};
-      ssum2[0] += lo;
-      ssum2[1] += hi;
-      ssq2[0] = __builtin_elementwise_fma(lo, lo, ssq2[0]);
-      ssq2[1] = __builtin_elementwise_fma(hi, hi, ssq2[1]);
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        float a0 = acc[t][n][0] + bv[n].x, a1 = acc[t][n][1] + bv[n].y, a2 = acc[t][n][2] + bv[n].z, a3 = acc[t][n][3] + bv[n].w;
+        if (RELU) {                                  // NaN passes through, as in tf.nn.relu
+          a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
+          a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
+        }
+        const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                            __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
+        __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, (t * erow + n * 16) * 4u, 0);
+        f32x2 lo = {ok ? a0 : 0.f, ok ? a1 : 0.f}, hi = {ok ? a2 : 0.f, ok ? a3 : 0.f};
+        ssum2[n][0] += lo;
+        ssum2[n][1] += hi;
+        ssq2[n][0] = __builtin_elementwise_fma(lo, lo, ssq2[n][0]);
+        ssq2[n][1] = __builtin_elementwise_fma(hi, hi, ssq2[n][1]);
+      }
     });
   }
 
-  // ---- per-workgroup partial moments (sum, sum of squares) per output channel -> row blockIdx of stats: [2][16] doubles
+  // ---- per-workgroup partial moments (sum, sum of squares) per output channel -> row blockIdx of stats: [2][16 NT] doubles
   if (p.stats) {
+    constexpr int CP = 16 * NT;
     __syncthreads();
-    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][CP]
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      double a = (double)ssum2[kk >> 1][kk & 1], bq = (double)ssq2[kk >> 1][kk & 1];
+    for (int n = 0; n < NT; ++n)
 #pragma unroll
-      for (int o = 1; o < 16; o <<= 1) {
-        a += __shfl_xor(a, o);
-        bq += __shfl_xor(bq, o);
+      for (int kk = 0; kk < 4; ++kk) {
+        double a = (double)ssum2[n][kk >> 1][kk & 1], bq = (double)ssq2[n][kk >> 1][kk & 1];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o);
+          bq += __shfl_xor(bq, o);
+        }
+        if (r == 0) {
+          s_red[(wave * 2 + 0) * CP + n * 16 + q * 4 + kk] = a;
+          s_red[(wave * 2 + 1) * CP + n * 16 + q * 4 + kk] = bq;
+        }
       }
-      if (r == 0) {
-        s_red[(wave * 2 + 0) * 16 + q * 4 + kk] = a;
-        s_red[(wave * 2 + 1) * 16 + q * 4 + kk] = bq;
-      }
-    }
     __syncthreads();
-    if (tid < 32) {
-      const int which = tid >> 4, col = tid & 15;
-      p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] =
-          (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
-          (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
+    if (tid < 2 * CP) {
+      const int which = tid / CP, col = tid % CP;
+      p.stats[((size_t)blockIdx.x * 2 + which) * CP + col] =
+          (s_red[(0 * 2 + which) * CP + col] + s_red[(1 * 2 + which) * CP + col]) +
+          (s_red[(2 * 2 + which) * CP + col] + s_red[(3 * 2 + which) * CP + col]);
     }
   }
 }
@@ -304,45 +339,52 @@ long c16_ntiles(int D, int H, int W) {
   return (long)((D + C16_TZ - 1) / C16_TZ) * ((H + C16_TY - 1) / C16_TY) * ((W + C16_TX - 1) / C16_TX);
 }
 
-// weights of every chunk + the image must fit 160 KB of LDS: Cin 8 (one 8-channel chunk), 16 or 32 (16-channel chunks)
-bool c16_shape_ok(int Cin) { return Cin == 8 || Cin == 16 || Cin == 32; }
+// 16 channels out: the weights of every chunk + the image must fit 160 KB of LDS: Cin 8 (one 8-channel chunk), 16 or 32
+// (16-channel chunks); 32 channels out: streamed weights, Cin a multiple of 16 up to 64
+bool c16_shape_ok(int Cin, int Cout) {
+  if (Cout == 16) return Cin == 8 || Cin == 16 || Cin == 32;
+  return Cout == 32 && Cin % 16 == 0 && Cin > 0 && Cin <= 64;
+}
 int c16_c4(int Cin) { return Cin == 8 ? 2 : 4; }
-long c16_packed_floats(int Cin) { return Cin == 8 ? (long)C16<2>::JC * 256 : (long)(Cin / 16) * C16<4>::JC * 256; }
+long c16_packed_floats(int Cin, int Cout) {
+  return Cin == 8 ? (long)C16<2>::JC * 256 : (long)(Cin / 16) * C16<4>::JC * (Cout / 16) * 256;
+}
 
-template <int C4, bool RELU>
+template <int C4, int NT, bool RELU>
 int launch_c16(const C16Args& a, long grid, atvs_stream_t stream) {
-  const size_t lds = (size_t)C16<C4>::IMG + (size_t)a.nchunk * C16<C4>::WCH;
+  const size_t lds = (size_t)C16<C4>::IMG + (NT == 1 ? (size_t)a.nchunk * C16<C4>::WCH : 0);
   // the attribute is per device: one flag per device ordinal of this process (and per instantiation)
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_kernel<C4, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_kernel<C4, NT, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv_c16_kernel<C4, RELU>), dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
+  hipLaunchKernelGGL((conv_c16_kernel<C4, NT, RELU>), dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
   return ATVS_OK;
 }
 
 }  // namespace
 
-// Floats of the packed form of a kernel [3,3,3,Cin,16] (Cin 8, 16 or 32), including 4 trailing zeros.
-extern "C" int atvs_conv_c16_pack_size(int Cin, long* packed_floats) {
+// Floats of the packed form of a kernel [3,3,3,Cin,Cout] (Cout 16: Cin 8, 16 or 32; Cout 32: Cin 16, 32, 48 or 64),
+// including 4 trailing zeros.
+extern "C" int atvs_conv_c16_pack_size(int Cin, int Cout, long* packed_floats) {
   if (!packed_floats) return ATVS_ERR_NULL;
-  if (!c16_shape_ok(Cin)) return ATVS_ERR_SHAPE;
-  *packed_floats = c16_packed_floats(Cin) + 4;
+  if (!c16_shape_ok(Cin, Cout)) return ATVS_ERR_SHAPE;
+  *packed_floats = c16_packed_floats(Cin, Cout) + 4;
   return ATVS_OK;
 }
 
-// HOST function.  w: TF kernel [3,3,3,Cin,16].  Cin 16 / 32: packed[chunk][tap][lane = q*16 + co][s] =
-// w[tap][chunk*16 + 4q + s][co];  Cin 8: packed[step][lane = q*16 + co][s] = w[tap = 2 step + (q>>1)][(q&1)*4 + s][co]
+// HOST function.  w: TF kernel [3,3,3,Cin,Cout].  Cin % 16 == 0: packed[chunk][tap][tile n][lane = q*16 + co][s] =
+// w[tap][chunk*16 + 4q + s][n*16 + co];  Cin 8: packed[step][lane = q*16 + co][s] = w[tap = 2 step + (q>>1)][(q&1)*4 + s][co]
 // (zero for tap 27).
-extern "C" int atvs_conv_c16_pack(const float* w, int Cin, float* packed) {
+extern "C" int atvs_conv_c16_pack(const float* w, int Cin, int Cout, float* packed) {
   if (!w || !packed) return ATVS_ERR_NULL;
   long pf;
-  int rc = atvs_conv_c16_pack_size(Cin, &pf);
+  int rc = atvs_conv_c16_pack_size(Cin, Cout, &pf);
   if (rc) return rc;
   for (long i = 0; i < pf; ++i) packed[i] = 0.f;
   if (Cin == 8) {
@@ -356,13 +398,15 @@ extern "C" int atvs_conv_c16_pack(const float* w, int Cin, float* packed) {
       }
     return ATVS_OK;
   }
+  const int NT = Cout / 16;
   for (int ch = 0; ch < Cin / 16; ++ch)
     for (int j = 0; j < C16_TAPS; ++j)
-      for (int q = 0; q < 4; ++q)
-        for (int co = 0; co < 16; ++co)
-          for (int s = 0; s < 4; ++s)
-            packed[((((size_t)ch * C16_TAPS + j) * 64) + q * 16 + co) * 4 + s] =
-                w[((size_t)j * Cin + ch * 16 + 4 * q + s) * 16 + co];
+      for (int n = 0; n < NT; ++n)
+        for (int q = 0; q < 4; ++q)
+          for (int co = 0; co < 16; ++co)
+            for (int s = 0; s < 4; ++s)
+              packed[(((((size_t)ch * C16_TAPS + j) * NT + n) * 64) + q * 16 + co) * 4 + s] =
+                  w[((size_t)j * Cin + ch * 16 + 4 * q + s) * Cout + n * 16 + co];
   return ATVS_OK;
 }
 
@@ -377,19 +421,19 @@ extern "C" long atvs_conv_c16_grid(int D, int H, int W, int groups) {
   return (g + 7) / 8 * 8;
 }
 
-// y (D,H,W,ldy)[..., y_coff : y_coff + 16] = conv3d(x (D,H,W,Cin), w, stride 1, SAME) (+ bias, ReLU), `groups` independent
-// samples on the leading axis of x / y.  stats_partial: groups * atvs_conv_c16_grid rows of [2][16] doubles (partial
-// sums / sums of squares per channel of the stored values), or NULL.
+// y (D,H,W,ldy)[..., y_coff : y_coff + Cout] = conv3d(x (D,H,W,Cin), w, stride 1, SAME) (+ bias, ReLU), `groups`
+// independent samples on the leading axis of x / y.  stats_partial: groups * atvs_conv_c16_grid rows of [2][Cout] doubles
+// (partial sums / sums of squares per channel of the stored values), or NULL.
 extern "C" int atvs_conv_c16_f32(const float* x, const float* packed_w, const float* bias, float* y, double* stats_partial,
-                                 int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                                 int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu,
                                  atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
-  if (!c16_shape_ok(Cin) || groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
-  if (y_coff < 0 || y_coff + 16 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if (!c16_shape_ok(Cin, Cout) || groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;            // 31-bit halo-relative element offsets
   if ((double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;      // 32-bit output BYTE offsets (buffer stores)
   C16Args a;
-  a.x = x; a.wp = packed_w; a.zeros = packed_w + c16_packed_floats(Cin);
+  a.x = x; a.wp = packed_w; a.zeros = packed_w + c16_packed_floats(Cin, Cout);
   a.bias = bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = (Cin == 8) ? 1 : Cin / 16;
   a.tiles_y = (H + C16_TY - 1) / C16_TY; a.tiles_x = (W + C16_TX - 1) / C16_TX;
@@ -398,9 +442,11 @@ extern "C" int atvs_conv_c16_f32(const float* x, const float* packed_w, const fl
   a.wg = (int)blocks;
   a.gx = (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy;
   if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  const long grid = blocks * groups;
   int rc;
-  if (c16_c4(Cin) == 2) rc = relu ? launch_c16<2, true>(a, blocks * groups, stream) : launch_c16<2, false>(a, blocks * groups, stream);
-  else rc = relu ? launch_c16<4, true>(a, blocks * groups, stream) : launch_c16<4, false>(a, blocks * groups, stream);
+  if (Cout == 32) rc = relu ? launch_c16<4, 2, true>(a, grid, stream) : launch_c16<4, 2, false>(a, grid, stream);
+  else if (c16_c4(Cin) == 2) rc = relu ? launch_c16<2, 1, true>(a, grid, stream) : launch_c16<2, 1, false>(a, grid, stream);
+  else rc = relu ? launch_c16<4, 1, true>(a, grid, stream) : launch_c16<4, 1, false>(a, grid, stream);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

@@ -371,19 +371,19 @@ def pack_conv_c16(key, w_host, device):
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
-    w = np.ascontiguousarray(w_host, dtype=np.float32)           # [3,3,3,Cin,16]
-    cin = int(w.shape[-2])
+    w = np.ascontiguousarray(w_host, dtype=np.float32)           # [3,3,3,Cin,Cout]
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
     L = _lib.lib()
     pf = ctypes.c_long()
-    rc = L.atvs_conv_c16_pack_size(cin, ctypes.byref(pf))
+    rc = L.atvs_conv_c16_pack_size(cin, cout, ctypes.byref(pf))
     if rc:
-        raise RuntimeError('atvs_conv_c16_pack_size failed (%d) for Cin=%d' % (rc, cin))
+        raise RuntimeError('atvs_conv_c16_pack_size failed (%d) for %d -> %d' % (rc, cin, cout))
     packed = np.empty(pf.value, np.float32)
-    rc = L.atvs_conv_c16_pack(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
+    rc = L.atvs_conv_c16_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
         raise RuntimeError('atvs_conv_c16_pack failed (%d)' % rc)
     pk = _Packed()
-    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, 16
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, cout // 16, cin, cout
     pk.key = key
     pk.tab = None
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
@@ -395,7 +395,7 @@ _USE_C16 = True
 
 
 def use_conv_c16(flag):
-    """Testing / A-B hook: the one-workgroup-per-CU kernel for 3x3x3 convolutions 8 / 16 / 32 -> 16 channels."""
+    """Testing / A-B hook: the one-workgroup-per-CU kernel for 3x3x3 convolutions to 16 / 32 channels."""
     global _USE_C16
     _USE_C16 = bool(flag)
 
@@ -968,25 +968,26 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 
-    # ---- 3-D, 3x3x3, 8 / 16 / 32 -> 16 channels: one workgroup per CU, fully unrolled (the half-resolution U-Net layers,
-    # the AANet modules' shared | unique convolution)
-    if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) and cout == 16 \
-            and cin in (8, 16, 32) and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
-            and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (16 if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
+    # ---- 3-D, 3x3x3, 8 / 16 / 32 -> 16 and 16..64 -> 32 channels: one workgroup per CU, fully unrolled (the half- and
+    # quarter-resolution U-Net layers, the AANet modules' shared | unique convolution)
+    if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
+            and ((cout == 16 and cin in (8, 16, 32)) or (cout == 32 and cin in (16, 32, 48, 64))) \
+            and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
+            and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
         pk = pack_conv_c16(key, w_host, x.device)
         if y5 is None:
-            y5 = _new(x, (G,) + tuple(outs) + (16,))
+            y5 = _new(x, (G,) + tuple(outs) + (cout,))
         st, sbuf = None, None
         if want_stats:
             rows = int(_lib.lib().atvs_conv_c16_grid(outs[0], outs[1], outs[2], G))
-            sbuf = _stats_buffer(x, rows, 16, groups=G)
+            sbuf = _stats_buffer(x, rows, cout, groups=G)
             st = Stats()
-            st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, 16, M, G
+            st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, cout, M, G
         if _dev_ok(x5, y5, bias):
-            with _Timed(key, x5.shape[1:], 16, G):
+            with _Timed(key, x5.shape[1:], cout, G):
                 _call('atvs_conv_c16_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
-                      int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                      cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 12
+#define ATVS_ABI_VERSION 13
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -418,17 +418,19 @@ long atvs_deconv_up_grid(int D, int H, int W, int Cout, int groups);            
 int atvs_deconv_up_f32(const float* x, const float* packed_w, float* y, double* stats_partial, int groups, int D, int H,
                        int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
-/* ---- 3x3x3 SAME stride-1 convolution, Cin in {8, 16, 32} -> 16 channels, one workgroup per CU (csrc/conv_c16.hip): the
- * half-resolution layers conv_b*_1_1 / global_refine_3dconv1_1 (cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet;
- * cnn_wrapper/network.py:165-215) and the AANet modules' shared | unique convolution (network.py:282-351, 8 -> 8 + 8).
- * Other shapes: ATVS_ERR_SHAPE (callers use atvs_conv_tiled_f32).
- * w: TF layout [3,3,3,Cin,16].  x (groups, D,H,W, Cin) -> y (groups, D,H,W, ldy)[..., y_coff : y_coff + 16] (+ bias, ReLU).
- * stats_partial: groups * atvs_conv_c16_grid rows of [2][16] doubles (sum / sum of squares per channel) or NULL. */
-int atvs_conv_c16_pack_size(int Cin, long* packed_floats);
-int atvs_conv_c16_pack(const float* w, int Cin, float* packed);                   /* host function */
+/* ---- 3x3x3 SAME stride-1 convolution to 16 channels (Cin in {8, 16, 32}) or 32 channels (Cin in {16, 32, 48, 64}), one
+ * workgroup per CU (csrc/conv_c16.hip): the half- / quarter-resolution layers conv_b*_1_1, conv_b*_2_1,
+ * global_refine_3dconv1_1 / 2_1 (cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet; cnn_wrapper/network.py:165-215)
+ * and the AANet modules' shared | unique convolution (network.py:282-351, 8 -> 8 + 8).  Other shapes: ATVS_ERR_SHAPE
+ * (callers use atvs_conv_tiled_f32).
+ * w: TF layout [3,3,3,Cin,Cout].  x (groups, D,H,W, Cin) -> y (groups, D,H,W, ldy)[..., y_coff : y_coff + Cout] (+ bias,
+ * ReLU).  stats_partial: groups * atvs_conv_c16_grid rows of [2][Cout] doubles (sum / sum of squares per channel) or NULL. */
+int atvs_conv_c16_pack_size(int Cin, int Cout, long* packed_floats);
+int atvs_conv_c16_pack(const float* w, int Cin, int Cout, float* packed);         /* host function */
 long atvs_conv_c16_grid(int D, int H, int W, int groups);                         /* workgroups PER SAMPLE */
 int atvs_conv_c16_f32(const float* x, const float* packed_w, const float* bias, float* y, double* stats_partial,
-                      int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu, atvs_stream_t stream);
+                      int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu,
+                      atvs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -358,6 +358,7 @@ def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
     w = _rand((3, 3, 3, cin, cout), 51, 0.2).numpy()
     ops.fused_finalize(True)
     ops.use_xp1w(False)           # the in-launch finalize lives in the tiled kernel
+    ops.use_conv_c16(False)
     ref = None
     for it in range(12):
         y, st = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
@@ -372,6 +373,7 @@ def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
     ops.fused_finalize(False)
     y2, st2 = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
     ops.use_xp1w(True)
+    ops.use_conv_c16(True)
     assert st2.params is None and torch.equal(y2, y)
 
 

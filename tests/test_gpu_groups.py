@@ -261,37 +261,39 @@ def test_deconv_up_against_torch_and_the_class_fused_form(cuda, G, shape, cin, c
     assert torch.equal(relu, torch.clamp(got, min=0))
 
 
-@pytest.mark.parametrize('G,shape,cin', [(1, (9, 17, 33), 16), (2, (4, 8, 16), 32), (3, (5, 9, 18), 16), (2, (12, 24, 40), 32),
-                                        (1, (9, 17, 33), 8), (3, (5, 9, 18), 8), (2, (12, 24, 40), 8)])
-def test_conv_c16_against_torch_and_the_tiled_kernel(cuda, G, shape, cin):
+@pytest.mark.parametrize('G,shape,cin,cout', [(1, (9, 17, 33), 16, 16), (2, (4, 8, 16), 32, 16), (3, (5, 9, 18), 16, 16),
+                                             (2, (12, 24, 40), 32, 16), (1, (9, 17, 33), 8, 16), (3, (5, 9, 18), 8, 16),
+                                             (2, (12, 24, 40), 8, 16), (1, (9, 17, 33), 32, 32), (3, (5, 9, 18), 16, 32),
+                                             (2, (12, 24, 40), 64, 32)])
+def test_conv_c16_against_torch_and_the_tiled_kernel(cuda, G, shape, cin, cout):
     """The 16 / 32 -> 16 channel 3x3x3 convolutions (conv_b*_1_1, reference cnn_wrapper/network.py:165-215) on their own
     kernel (csrc/conv_c16.hip): against tf.nn.conv3d restated with torch (2e-5 of the output scale: another accumulation
     order), grouped form == separate calls bit for bit, moments, bias + ReLU, channel-slice output."""
     from oracle import tf_ops as T
     from atvsnet_amd import ops
     x = _rand((G,) + shape + (cin,), 31)
-    w = _rand((3, 3, 3, cin, 16), 32) * 0.2
-    got, st = ops.conv(x.to(cuda), ('c16', cin), w.numpy(), want_stats=True, groups=G)
-    assert st.cpad == 16 and st.groups == G
-    params = ops.bn_params(st, 16, got)
+    w = _rand((3, 3, 3, cin, cout), 32) * 0.2
+    got, st = ops.conv(x.to(cuda), ('c16', cin, cout), w.numpy(), want_stats=True, groups=G)
+    assert st.cpad == cout and st.groups == G
+    params = ops.bn_params(st, cout, got)
     for g in range(G):
         want = T.conv(x[g:g + 1], w, 1, 'SAME')[0]
         err = float((got[g].cpu() - want).abs().max())
         assert err <= 2e-5 * float(want.abs().max()) + 1e-6, (g, err)
-        one, st1 = ops.conv(x[g].to(cuda), ('c16', cin), w.numpy(), want_stats=True)
+        one, st1 = ops.conv(x[g].to(cuda), ('c16', cin, cout), w.numpy(), want_stats=True)
         assert torch.equal(one, got[g])
         pg = params[g] if G > 1 else params
-        assert float((pg - ops.bn_params(st1, 16, one)).abs().max()) <= 1e-6 * float(pg.abs().max())
-        assert float((pg[0].cpu().double() - want.reshape(-1, 16).double().mean(0)).abs().max()) <= 1e-5
+        assert float((pg - ops.bn_params(st1, cout, one)).abs().max()) <= 1e-6 * float(pg.abs().max())
+        assert float((pg[0].cpu().double() - want.reshape(-1, cout).double().mean(0)).abs().max()) <= 1e-5
     ops.use_conv_c16(False)
     try:
-        ref = ops.conv(x.to(cuda), ('c16', cin), w.numpy(), groups=G)
+        ref = ops.conv(x.to(cuda), ('c16', cin, cout), w.numpy(), groups=G)
     finally:
         ops.use_conv_c16(True)
     assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max())
-    b = _rand((16,), 33)
-    buf = torch.full((G,) + shape + (32,), -7.0, device=cuda)
-    ops.conv(x.to(cuda), ('c16', cin), w.numpy(), bias=b.to(cuda), relu=True, out=buf, y_coff=16, groups=G)
+    b = _rand((cout,), 33)
+    buf = torch.full((G,) + shape + (16 + cout,), -7.0, device=cuda)
+    ops.conv(x.to(cuda), ('c16', cin, cout), w.numpy(), bias=b.to(cuda), relu=True, out=buf, y_coff=16, groups=G)
     assert torch.equal(buf[..., 16:], torch.clamp(got + b.to(cuda), min=0)) or \
         float((buf[..., 16:] - torch.clamp(got + b.to(cuda), min=0)).abs().max()) <= 1e-6
     assert torch.all(buf[..., :16] == -7.0)
