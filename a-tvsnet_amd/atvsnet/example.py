@@ -269,7 +269,7 @@ class PipelinedInference(object):
 
     The depth maps of a scene are independent (one per reference view, reference eval_pointcloud.py:399-424), and a
     single pipeline leaves the GPU under-filled in its low-resolution / 2-D phases; issuing the next depth map on a second
-    stream fills them (config 3 on MI355X: 37.2 -> 34.5 ms per depth map with 2 in flight, no gain from a third).
+    stream fills them (config 3 on MI355X: 35.7 -> 33.2 ms per depth map with 2 in flight, no gain from a third).
     Every slot computes exactly what GraphedInference computes.
 
         t = p.submit(images, cams)      # asynchronous: copies the inputs, replays the slot's graph on its stream
