@@ -80,6 +80,7 @@ struct XpArgs {
   const float* in_pa;
   const float* in_pb;
   int relu_a, relu_b;
+  int sample_major;      // 8 samples: sample = blockIdx % 8 = XCD (all its workgroups behind one L2), tiles dealt round-robin
 };
 
 __device__ __forceinline__ int xp_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
@@ -164,8 +165,10 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   // persistent tile list, dealt so that the workgroups of one XCD (blockIdx % 8) sweep one contiguous eighth
   // of the tile range (halo re-use in that XCD's L2)
   const int G = p.wg;
-  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
-  const int xcd = lbk & 7, tslot = lbk >> 3;
+  const int grp = p.sample_major ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / p.wg);
+  const int lbk = p.sample_major ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x - grp * p.wg);
+  const int xcd = p.sample_major ? 0 : (lbk & 7), tslot = p.sample_major ? lbk : (lbk >> 3);
+  const unsigned srow = (unsigned)(grp * p.wg + lbk);        // this workgroup's row of the statistics buffers
   const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
   const float* __restrict__ xg2 = (PRO == 2) ? p.x2 + (size_t)grp * p.gx : nullptr;
   const float* __restrict__ ipa = (PRO >= 1 && p.in_pa) ? p.in_pa + (size_t)grp * 3 * p.Cin : nullptr;
@@ -175,8 +178,8 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
   float* __restrict__ y2g = p.y2 + (size_t)grp * p.gy2;
   const float* __restrict__ pbg = p.pbias ? p.pbias + (size_t)grp * p.gpb : nullptr;
   const float* __restrict__ pb2g = p.pbias2 ? p.pbias2 + (size_t)grp * p.gpb2 : nullptr;
-  const int per_xcd = (p.ntiles + 7) >> 3;
-  const int slots_per_xcd = G >> 3;
+  const int per_xcd = p.sample_major ? p.ntiles : ((p.ntiles + 7) >> 3);
+  const int slots_per_xcd = p.sample_major ? G : (G >> 3);
   int my_tiles = 0;
   {
     int last = min(per_xcd, p.ntiles - xcd * per_xcd);
@@ -485,7 +488,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
       if (col < 8)
         v = (s_red[(0 * 2 + which) * 8 + col] + s_red[(1 * 2 + which) * 8 + col]) +
             (s_red[(2 * 2 + which) * 8 + col] + s_red[(3 * 2 + which) * 8 + col]);
-      p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] = v;
+      p.stats[((size_t)srow * 2 + which) * 16 + col] = v;
     }
   }
   if (SIB && p.stats2) {
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(256, 1) void conv_xp_kernel(XpArgs p) {
     __syncthreads();
     if (tid < 32) {
       const int which = tid >> 4, col = tid & 15;
-      p.stats2[((size_t)blockIdx.x * 2 + which) * 16 + col] =
+      p.stats2[((size_t)srow * 2 + which) * 16 + col] =
           (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
           (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
     }
@@ -666,6 +669,9 @@ extern "C" int atvs_conv_xp_f32(const float* x, const float* packed_w, const flo
   a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
   const long blocks = (long)a.wg * groups;
   hipStream_t st = as_stream(stream);
+  // eight samples (the eight U-Nets of a 5-view depth map): one sample per XCD -- its workgroups sweep neighbouring tiles
+  // behind one L2 (measured: -0.8 % on the dominant launch against spreading every sample over all XCDs)
+  a.sample_major = (groups == 8) ? 1 : 0;
   a.x2 = x2; a.in_pa = in_params; a.in_pb = in_params2; a.relu_a = in_relu; a.relu_b = in_relu2;
   const int pro = x2 ? 2 : (in_params ? 1 : 0);
   int rc;
