@@ -21,7 +21,6 @@ import argparse
 import os
 import shutil
 import time
-from struct import pack, unpack
 
 import numpy as np
 
@@ -29,34 +28,28 @@ from .preprocess import load_cam, load_pfm, write_pfm
 from ..tools import ply
 
 
+_DMB_HEADER = np.dtype([('type', '<i4'), ('height', '<i4'), ('width', '<i4'), ('channels', '<i4')])
+
+
 def read_gipuma_dmb(path):
-    '''read Gipuma .dmb format image (reference :24-35)'''
-    with open(path, "rb") as fid:
-        _image_type = unpack('<i', fid.read(4))[0]
-        height = unpack('<i', fid.read(4))[0]
-        width = unpack('<i', fid.read(4))[0]
-        channel = unpack('<i', fid.read(4))[0]
-        array = np.fromfile(fid, np.float32)
-    array = array.reshape((width, height, channel), order="F")
-    return np.transpose(array, (1, 0, 2)).squeeze()
+    """Gipuma .dmb image -> (h, w) or (h, w, c) float32 (reference :24-35).  File = 16-byte header
+    (int32 type, height, width, channels) + float32 channel PLANES, each plane row-major (h, w)."""
+    raw = np.fromfile(path, dtype=np.uint8)
+    head = raw[:_DMB_HEADER.itemsize].view(_DMB_HEADER)[0]
+    h, w, c = int(head['height']), int(head['width']), int(head['channels'])
+    planes = raw[_DMB_HEADER.itemsize:].view('<f4').reshape(c, h, w)
+    return np.moveaxis(planes, 0, -1).squeeze()
 
 
 def write_gipuma_dmb(path, image):
-    '''write Gipuma .dmb format image (reference :37-58): int32 type = 1, height, width, channels, then float32 data
-    (channel planes for a 3-channel image, as the reference's transpose stores them)'''
+    """(h, w) or (h, w, c) -> Gipuma .dmb (reference :37-58): header with type = 1, then the channel planes."""
     image = np.asarray(image, np.float32)
-    image_shape = np.shape(image)
-    width = image_shape[1]
-    height = image_shape[0]
-    channels = image_shape[2] if len(image_shape) == 3 else 1
-    if len(image_shape) == 3:
-        image = np.transpose(image, (2, 0, 1)).squeeze()
-    with open(path, "wb") as fid:
-        fid.write(pack('<i', 1))
-        fid.write(pack('<i', height))
-        fid.write(pack('<i', width))
-        fid.write(pack('<i', channels))
-        np.ascontiguousarray(image).tofile(fid)
+    planes = image[None] if image.ndim == 2 else np.moveaxis(image, -1, 0)
+    head = np.zeros(1, _DMB_HEADER)
+    head['type'], head['height'], head['width'], head['channels'] = (1,) + planes.shape[1:] + planes.shape[:1]
+    with open(path, 'wb') as fid:
+        fid.write(head.tobytes())
+        fid.write(np.ascontiguousarray(planes, '<f4').tobytes())
 
 
 def atvsnet_to_gipuma_dmb(in_path, out_path):

@@ -298,6 +298,11 @@ class PipelinedInference(object):
         self.next = (s + 1) % len(self.graphs)
         st = self.streams[s]
         st.wait_stream(torch.cuda.current_stream(self.device))      # inputs prepared on the caller's stream
+        for t in (images, cams):
+            # the copy into the slot's static buffers runs on the slot's stream, possibly long after this call returns:
+            # tell the caching allocator, or the caller's next allocation could re-use the block while it is still read
+            if t is not None and t.is_cuda:
+                t.record_stream(st)
         with torch.cuda.stream(st):
             self.graphs[s](images, cams)
             self.events[s].record(st)

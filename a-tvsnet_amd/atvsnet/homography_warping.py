@@ -36,15 +36,16 @@ def get_homographies(left_cam, right_cam, depth_num, depth_start, depth_interval
 def homography_warping(input_image, homography, method='bilinear', output_mask=False):
     """Warp (B,H,W,C) by (B,3,3) -> (B,H,W,C) [, bool mask (B,H,W,1)] (reference :230-271).
 
-    With a (B,D,3,3) stack: -> (B,D,H,W,C) [, mask (B,D,H,W,1)].  Bilinear only here; the nearest
-    mode is used by get_visual_hull alone and is fused into its kernel.
+    With a (B,D,3,3) stack: -> (B,D,H,W,C) [, mask (B,D,H,W,1)].  method 'nearest' (reference :45-56):
+    tf.round, out-of-range pixels read pixel (0,0) un-masked (quirk C4).  (get_visual_hull has its own fused
+    kernel and does not come through here.)
     """
-    if method != 'bilinear':
-        raise NotImplementedError('homography_warping(method=%r): nearest sampling is built into '
-                                  'get_visual_hull only' % method)
+    if method not in ('bilinear', 'nearest'):
+        raise ValueError('homography_warping: unknown method %r' % (method,))
     stack = homography.dim() == 4
     Hm = (homography[0] if stack else homography).contiguous()
-    res = ops.warp_planes(input_image[0].contiguous(), Hm, want_mask=output_mask)
+    res = ops.warp_planes(input_image[0].contiguous(), Hm, want_mask=output_mask,
+                          mode=ops.WARP_NEAREST if method == 'nearest' else 0)
     out, mask = res if output_mask else (res, None)
     if not stack:
         out = out[0]

@@ -100,6 +100,7 @@ extern "C" int atvs_get_homographies(const float* left_cam, const float* right_c
 //   1 |warp - ref| * mask                     (model.py:272-279, photo volume)
 //   2 (|warp - delta_d| / interval / D) * mask replicated to `rep` channels,
 //     source has one channel                  (model.py:292-297, geo view volume)
+//   3 nearest-neighbour warp (homography_warping.py:45-56: tf.round, invalid -> pixel (0,0), value NOT masked)
 // VEC = 4: C % 4 == 0, float4 per lane.  VEC = 1: scalar per lane.
 // ---------------------------------------------------------------------------
 template <int MODE, int VEC>
@@ -120,8 +121,16 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
   for (int i = 0; i < 9; ++i) Hm[i] = Hmats[d * 9 + i];
   float xw, yw;
   homography_apply(Hm, x, y, &xw, &yw);
-  Tap4 t = bilinear_taps(xw, yw, h, w);
   size_t obase = ((size_t)d * npix + pix) * (size_t)ld + c_off;
+  if (MODE == 3) {
+    float valid;
+    const int idx = nearest_tap(xw, yw, h, w, &valid);
+    if (VEC == 4) st4(out + obase + c, ld4(src + (size_t)idx * C + c));
+    else out[obase + c] = src[(size_t)idx * C + c];
+    if (mask_out && c == 0) mask_out[(size_t)d * npix + pix] = valid;
+    return;
+  }
+  Tap4 t = bilinear_taps(xw, yw, h, w);
   if (MODE == 2) {
     float v = ((t.wa * src[t.i00] + t.wb * src[t.i01]) + t.wc * src[t.i10]) + t.wd * src[t.i11];
     float val = depth_start[0] + (float)d * depth_interval[0];
@@ -226,11 +235,12 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
   if (mode == 1 && !ref) return ATVS_ERR_NULL;
   if (mode == 2 && (C != 1 || !depth_start || !depth_interval || rep < 1 || c_off + rep > ld_out)) return ATVS_ERR_SHAPE;
   if (mode != 2 && c_off + C > ld_out) return ATVS_ERR_SHAPE;
+  if (mode < 0 || mode > 3) return ATVS_ERR_ARG;
   bool vec = (C % 4 == 0) && (ld_out % 4 == 0) && (c_off % 4 == 0) && mode != 2;
   long lanes = (long)h * w * (mode == 2 ? 1 : (vec ? C / 4 : C));
   dim3 grid(cdiv(lanes, 256), D), block(256);
   hipStream_t s = as_stream(stream);
-  if (vec && (C == 16 || C == 32 || C == 64)) {
+  if (vec && mode < 2 && (C == 16 || C == 32 || C == 64)) {
     // geometry once per pixel, shared by its channel-group lanes
     dim3 g2(cdiv((long)h * w, 256), D);
     if (mode == 0)
@@ -248,7 +258,7 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
   if (mode == 0) { if (vec) LAUNCH(0, 4); else LAUNCH(0, 1); }
   else if (mode == 1) { if (vec) LAUNCH(1, 4); else LAUNCH(1, 1); }
   else if (mode == 2) LAUNCH(2, 1);
-  else return ATVS_ERR_ARG;
+  else { if (vec) LAUNCH(3, 4); else LAUNCH(3, 1); }
 #undef LAUNCH
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

@@ -70,6 +70,9 @@ def get_homographies(left_cam, right_cam, depth_start, depth_interval, depth_num
     return out
 
 
+WARP_NEAREST = 3      # atvs_warp_planes mode: nearest-neighbour sampling (include/atvsnet_hip.h)
+
+
 def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=None, depth_start=None,
                 depth_interval=None, rep=1, want_mask=False):
     """src (h,w,C), homographies (D,3,3) -> out (D,h,w,ld_out) [, mask (D,h,w)]."""

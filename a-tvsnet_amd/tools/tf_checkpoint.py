@@ -15,6 +15,12 @@ Format (tensorflow/core/util/tensor_bundle, tensorflow/core/lib/io/table -- a Le
                 offset = 4, size = 5, crc32c = 6, slices = 7)
   data shard  = the tensors' raw bytes (little endian) at [offset, offset + size)
 
+Checksums: every table block's trailer and every BundleEntryProto carry a MASKED crc32c (Castagnoli polynomial
+0x1EDC6F41 reflected = 0x82F63B78; mask(c) = rotr(c, 15) + 0xa282ead8, tensorflow/core/lib/hash/crc32c.h) -- of the
+block payload + compression byte, and of the tensor's bytes.  TensorFlow's reader fails with DataLoss on a mismatch;
+so does this one (`verify=False` skips the tensor checks only).  Pinned by the standard crc32c check values
+(RFC 3720 B.4) in tests/test_tf_checkpoint.py.
+
 There is no checkpoint in the reference repository to test against: the parser is checked against bundles
 assembled byte by byte from this description (tests/test_tf_checkpoint.py) -- UNPINNED against real TF output.
 """
@@ -26,6 +32,51 @@ import numpy as np
 TABLE_MAGIC = 0xdb4775248b80fb57
 _DTYPES = {1: np.float32, 2: np.float64, 3: np.int32, 4: np.uint8, 5: np.int16, 6: np.int8, 9: np.int64, 10: np.bool_,
            17: np.uint16, 19: np.float16, 22: np.uint32, 23: np.uint64}
+
+
+_CRC_MASK_DELTA = 0xa282ead8
+
+
+def _crc_tables():
+    t0 = []
+    for i in range(256):
+        c = i
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+        t0.append(c)
+    tabs = [t0]
+    for k in range(1, 8):
+        prev = tabs[-1]
+        tabs.append([(prev[i] >> 8) ^ t0[prev[i] & 0xff] for i in range(256)])
+    return tabs
+
+
+_T = _crc_tables()
+
+
+def crc32c(data, crc=0):
+    """CRC-32C (Castagnoli) of a bytes-like object, slicing-by-8."""
+    data = bytes(data)
+    c = crc ^ 0xffffffff
+    n8 = len(data) // 8
+    t0, t1, t2, t3, t4, t5, t6, t7 = _T
+    if n8:
+        for lo, hi in struct.iter_unpack('<II', data[:n8 * 8]):
+            lo ^= c
+            c = (t7[lo & 0xff] ^ t6[(lo >> 8) & 0xff] ^ t5[(lo >> 16) & 0xff] ^ t4[lo >> 24] ^
+                 t3[hi & 0xff] ^ t2[(hi >> 8) & 0xff] ^ t1[(hi >> 16) & 0xff] ^ t0[hi >> 24])
+    for b in data[n8 * 8:]:
+        c = (c >> 8) ^ t0[(c ^ b) & 0xff]
+    return c ^ 0xffffffff
+
+
+def crc_mask(c):
+    return (((c >> 15) | (c << 17)) + _CRC_MASK_DELTA) & 0xffffffff
+
+
+def crc_unmask(m):
+    r = (m - _CRC_MASK_DELTA) & 0xffffffff
+    return ((r >> 17) | (r << 15)) & 0xffffffff
 
 
 def _varint(buf, pos):
@@ -44,6 +95,9 @@ def _block(buf, offset, size):
     kind = buf[offset + size]
     if kind != 0:
         raise NotImplementedError('compressed table block (type %d): tensor-bundle indexes are written uncompressed' % kind)
+    stored = struct.unpack_from('<I', buf, offset + size + 1)[0]
+    if crc_unmask(stored) != crc32c(buf[offset:offset + size + 1]):
+        raise ValueError('table block at offset %d: block checksum mismatch (corrupt index file)' % offset)
     data = buf[offset:offset + size]
     n_restarts = struct.unpack_from('<I', data, len(data) - 4)[0]
     end = len(data) - 4 - 4 * n_restarts
@@ -81,7 +135,7 @@ def _fields(msg):
 
 
 def _entry(value):
-    e = {'dtype': 0, 'shape': [], 'shard_id': 0, 'offset': 0, 'size': 0, 'sliced': False}
+    e = {'dtype': 0, 'shape': [], 'shard_id': 0, 'offset': 0, 'size': 0, 'sliced': False, 'crc32c': None}
     for num, wt, val in _fields(value):
         if num == 1:
             e['dtype'] = val
@@ -97,6 +151,8 @@ def _entry(value):
             e['offset'] = val
         elif num == 5:
             e['size'] = val
+        elif num == 6 and wt == 5:
+            e['crc32c'] = struct.unpack('<I', val)[0]          # masked
         elif num == 7:
             e['sliced'] = True
     return e
@@ -134,8 +190,10 @@ def list_variables(prefix):
     return sorted((k, tuple(e['shape'])) for k, e in read_index(prefix)[1].items())
 
 
-def read_checkpoint(prefix, names=None):
-    """{variable name: ndarray} of every (or the named) numeric tensor of the bundle `<prefix>`."""
+def read_checkpoint(prefix, names=None, verify=True):
+    """{variable name: ndarray} of every (or the named) numeric tensor of the bundle `<prefix>`.  verify: check each
+    tensor's bytes against the masked crc32c its index entry carries (ValueError on a mismatch, as TensorFlow's
+    BundleReader returns DataLoss)."""
     header, entries = read_index(prefix)
     if header['endianness'] != 0:
         raise NotImplementedError('big-endian tensor bundle')
@@ -158,5 +216,9 @@ def read_checkpoint(prefix, names=None):
         if count * dt.itemsize != e['size']:
             raise ValueError('%s: %d bytes stored, shape %s needs %d' % (name, e['size'], e['shape'], count * dt.itemsize))
         raw = shards[sid][e['offset']:e['offset'] + e['size']]
+        if len(raw) != e['size']:
+            raise ValueError('%s: data shard ends before offset %d + %d' % (name, e['offset'], e['size']))
+        if verify and e['crc32c'] is not None and crc_unmask(e['crc32c']) != crc32c(raw):
+            raise ValueError('%s: checksum does not match the stored crc32c (corrupt data shard)' % name)
         out[name] = np.frombuffer(bytes(raw), dtype=dt).reshape(e['shape']).astype(_DTYPES[e['dtype']])
     return out

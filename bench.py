@@ -11,10 +11,11 @@ Default workload = BASELINE.json configs[2], the configuration the metric is quo
 8-source configuration quoted for 8 GPUs), cfg5 = two-view 1600x1184x256.
 On one GPU the step is ONE replay of a HIP graph captured from the pipeline (every per-view network evaluated once
 over all its calls -- views, siamese directions -- stacked on the batch axis with per-call batch statistics);
---eager issues every launch from Python instead.  --inflight N (default 2): the K timed depth maps are issued round-robin
-on N streams (one captured graph + static buffers each, example.PipelinedInference) -- the depth maps of a scene are
-independent (one per reference view) and a second one in flight fills the phases in which one pipeline leaves the GPU
-under-filled; `ms_per_step` stays wall time / K, the line also carries `latency_ms` = one depth map alone.
+--eager issues every launch from Python instead.  `value` = K depth maps strictly one after the other (1 / wall
+time of one depth map).  --inflight N (default 2): a SECOND timed region issues K depth maps round-robin on N streams
+(one captured graph + static buffers each, example.PipelinedInference) -- the depth maps of a scene are independent (one
+per reference view) and a second one in flight fills the phases in which one pipeline leaves the GPU under-filled; that
+throughput is reported under `pipelined`, never as `value`.
 
 --gpus N > 1: this process touches no GPU; it starts N ranks (one process per GPU, RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), prints ONE JSON line and exits non-zero if a rank of the primary
@@ -140,13 +141,38 @@ def _last_json(text):
     return json.loads(lines[-1]) if lines else None
 
 
+def visible_gpus(env=None, kfd_nodes='/sys/class/kfd/kfd/topology/nodes'):
+    """Number of GPUs the ranks will see, WITHOUT opening the GPU runtime in this process (no HIP call, no torch.cuda:
+    on ROCm wheels without amdsmi torch.cuda.device_count() falls through to hipGetDeviceCount, which opens KFD).
+    KFD topology nodes with simd_count > 0 are GPUs; HIP_/ROCR_/CUDA_VISIBLE_DEVICES restrict them.  None when the
+    topology is not readable (then the ranks' own `device_count() > local_rank` check decides)."""
+    env = os.environ if env is None else env
+    total = None
+    try:
+        total = 0
+        for node in os.listdir(kfd_nodes):
+            try:
+                with open(os.path.join(kfd_nodes, node, 'properties')) as f:
+                    props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            except OSError:
+                continue
+            if int(props.get('simd_count', '0')) > 0:
+                total += 1
+    except OSError:
+        total = None
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        if var in env:
+            ids = [t for t in env[var].split(',') if t.strip() != '']
+            total = len(ids) if total is None else min(total, len(ids))
+    return total
+
+
 def launch(args, argv):
     """Start args.gpus ranks of this script as child processes; no GPU call happens in this process."""
     n = args.gpus
     if not args.dry:
-        import torch
-        have = torch.cuda.device_count()          # counts devices without initialising the GPU
-        if have < n:
+        have = visible_gpus()
+        if have is not None and have < n:
             sys.stderr.write('bench.py: --gpus %d but only %d device(s) visible; refusing to run a smaller world\n' % (n, have))
             return 2
     base = [a for i, a in enumerate(argv) if a != '--parallel' and (i == 0 or argv[i - 1] != '--parallel')]
@@ -248,6 +274,8 @@ def cpu_baseline(args):
     else:
         per_map = twoview
     return {'value': 1.0 / per_map, 'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'port',
+            'kind_detail': 'restatement: the CPU oracle (torch-CPU / numpy restatement of the reference\'s TF-1.5 path); '
+                           'TensorFlow itself cannot be installed here',
             'host_cpus': ncpu, 'cpu_model': model_name,
             'configs0_s': round(cfg1, 3), 'configs0_runs_s': [round(r, 3) for r in runs],
             'twoview_fullsize_s': round(twoview, 2), 'stage_s': {k: round(v, 2) for k, v in T.items()},
@@ -291,8 +319,23 @@ def top_kernels(k=5):
             rows.append((r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0],
                          int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['Percentage'])))
     rows.sort(key=lambda t: -t[3])
-    return {'source': KERNEL_STATS_FILE, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --inflight 1',
+    return {'source': KERNEL_STATS_FILE, 'measured_in_run': False, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --inflight 1',
             'top': [{'kernel': n, 'calls': c, 'avg_us': round(a, 1), 'pct': round(p, 2)} for n, c, a, p in rows[:k]]}
+
+
+def profiled_avg_us(substr):
+    """Average duration (us) of the kernels whose name contains `substr` in the committed kernel-trace summary."""
+    import csv
+    path = os.path.join(ROOT, KERNEL_STATS_FILE)
+    if not os.path.exists(path):
+        return None
+    tot = calls = 0
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if substr in r['Name']:
+                tot += float(r['AverageNs']) * int(r['Calls'])
+                calls += int(r['Calls'])
+    return tot / calls / 1e3 if calls else None
 
 
 def parity_check(args, out, eager_out):
@@ -412,29 +455,33 @@ def rank_main(args):
             dist.barrier()
         torch.cuda.synchronize()
 
-    latency_ms = None
+    # Timed region = K depth maps strictly one after the other (the metric is 1 / wall time of ONE depth map,
+    # images resident -> depth map resident).  The pipelined rate (`inflight` maps in flight on their own streams) is
+    # measured in a second region and reported under `pipelined`, never as `value`.
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    pipelined = None
     if pipe is not None and pipe.slots > 1:
         pipe.run(args.warmup)
         barrier()
-        t0 = time.perf_counter()
+        t1 = time.perf_counter()
         pipe.run(args.steps)                 # K depth maps, round-robin over the slots' streams
         barrier()
-        dt = time.perf_counter() - t0
-        out = graphed.out
-        t1 = time.perf_counter()             # one depth map alone (untimed region: reported next to the throughput)
-        for _ in range(3):
-            graphed()
-        torch.cuda.synchronize()
-        latency_ms = (time.perf_counter() - t1) / 3 * 1e3
-    else:
-        for _ in range(args.warmup):
-            out = step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
-        barrier()
-        dt = time.perf_counter() - t0
+        dtp = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dtp], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtp = float(t.item())
+        pipelined = {'value': round(n_groups * args.steps / dtp, 4), 'unit': 'depth-maps/sec', 'inflight': pipe.slots,
+                     'ms_per_step': round(1e3 * dtp / args.steps, 3),
+                     'note': '%d depth maps in flight (one captured graph + stream each, example.PipelinedInference): '
+                             'throughput of independent depth maps of a scene, NOT the per-map rate `value` reports' % pipe.slots}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -500,8 +547,14 @@ def rank_main(args):
             gbs = wb / (avg_ms * 1e-3) / 1e9
             roof_hbm = {'bound': 'hbm', 'kernel': 'warp_planes_shared_kernel<bilinear> (cost-volume build, 32 channels; geometry once per pixel)',
                         'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 4),
+                        'timing': 'HIP events around eager launches in this run (includes launch gaps of ~10 us)',
                         'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[WARP]),
                         'algorithmic_bytes_per_launch': wb, 'traffic': None}
+            prof_us = profiled_avg_us('warp_planes_shared_kernel<0>')
+            if prof_us and (args.width, args.height, args.depths) == (640, 512, 192):
+                roof_hbm['profile'] = {'source': KERNEL_STATS_FILE, 'measured_in_run': False, 'avg_launch_ms': round(prof_us / 1e3, 4),
+                                       'achieved': round(wb / (prof_us * 1e-6) / 1e9, 1),
+                                       'frac': round(wb / (prof_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
         par = 'single GPU'
         if world > 1 and not sharded:
             par = '%d ranks, one depth map each per step (independent reference views of a scene), no data-path collective' % world
@@ -523,9 +576,10 @@ def rank_main(args):
                        'rccl': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
                        'launch': 'eager' if graphed is None else ('HIP graph replay, batched per-view networks' if not sharded else
                                                                    'HIP graphs between the exchanges'),
-                       'inflight': pipe.slots if pipe is not None else 1},
+                       'inflight': 1},
             'source_views_per_sec': round(n_groups * args.steps * (args.views - 1) / dt, 3),
-            'latency_ms': round(latency_ms, 3) if latency_ms is not None else round(1e3 * dt / args.steps, 3),
+            'latency_ms': round(1e3 * dt / args.steps, 3),
+            'pipelined': pipelined,
             'roofline': roof, 'roofline_hbm': roof_hbm, 'kernels': top_kernels(),
         }
         if comm is not None:

@@ -59,7 +59,9 @@ int atvs_get_homographies(const float* left_cam, const float* right_cam, const f
  *   [c_off, c_off+C) (mode 2: [c_off, c_off+rep)); mask_out (D,h,w) or NULL.
  *   mode 0: warp.   mode 1: |warp - ref| * mask, ref (h,w,C) (photo volume).
  *   mode 2: C == 1; (|warp - delta_d| / interval / D) * mask replicated to `rep`
- *           channels (geo view volume, reference quirk: 16 identical channels). */
+ *           channels (geo view volume, reference quirk: 16 identical channels).
+ *   mode 3: nearest-neighbour warp (homography_warping.py:45-56: tf.round half-to-even,
+ *           out-of-range pixels read source pixel (0,0) and are NOT zeroed; mask_out tells). */
 int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
                      const float* depth_start, const float* depth_interval, float* out, float* mask_out,
                      int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep,

@@ -8,6 +8,7 @@ configurations on the seeded synthetic inputs and weights (the same ones bench.p
     cfg3    5 views 640x512, D=192, multi-view     (BASELINE configs[2], the metric's configuration)
     cfg4    9 views 928x480, D=256, multi-view     (BASELINE configs[3]: 8 sources)
     cfg5    two-view 1600x1184, D=256              (BASELINE configs[4])
+    cfg5f64 the float64-network evaluation of cfg5 (noise floor of the tightest configuration; ~40 GB of host memory)
 
 Each fixture holds the final full-resolution inverse-depth map plus a few intermediate maps / single depth
 planes of stage volumes (a few MB).  Run from the repository root in the BUILD container (CPU only):
@@ -106,8 +107,8 @@ def main(argv):
     for name in argv:
         t0 = time.time()
         with torch.no_grad():
-            if name == 'cfg2f64':
-                out = twoview_f64('cfg2')
+            if name.endswith('f64'):
+                out = twoview_f64(name[:-3])
             elif CONFIGS[name][0] == 2:
                 out = twoview(name)
             else:

@@ -7,8 +7,9 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _run(*argv):
+def _run(*argv, **extra_env):
     env = dict(os.environ)
+    env.update(extra_env)
     for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
         env.pop(k, None)
     p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), env=env, stdout=subprocess.PIPE,
@@ -35,6 +36,27 @@ def test_launcher_groups_beyond_one_rank_per_source():
 
 def test_launcher_refuses_a_smaller_world():
     """Fewer visible devices than --gpus: non-zero exit and a message, never a silent world of 1."""
-    rc, line, err = _run('--gpus', '64')
+    rc, line, err = _run('--gpus', '64', HIP_VISIBLE_DEVICES='0,1')
     assert rc != 0 and line is None
     assert 'device' in err
+
+
+def test_visible_gpus_counts_without_the_gpu_runtime(tmp_path):
+    """The launcher parent counts devices from the KFD topology + *_VISIBLE_DEVICES and never imports torch.cuda /
+    calls HIP (a parent that opened KFD would fork+exec its ranks from a GPU-initialised process)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    nodes = tmp_path / 'nodes'
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):          # two CPU nodes, three GPUs
+        d = nodes / str(i)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text('cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n' % (64 if simd == 0 else 0, simd))
+    assert bench.visible_gpus({}, str(nodes)) == 3
+    assert bench.visible_gpus({'HIP_VISIBLE_DEVICES': '0,2'}, str(nodes)) == 2
+    assert bench.visible_gpus({'ROCR_VISIBLE_DEVICES': '1', 'HIP_VISIBLE_DEVICES': '0,1,2'}, str(nodes)) == 1
+    assert bench.visible_gpus({'HIP_VISIBLE_DEVICES': ''}, str(nodes)) == 0
+    assert bench.visible_gpus({}, str(tmp_path / 'absent')) is None          # unknown: the ranks decide
+    assert bench.visible_gpus({'CUDA_VISIBLE_DEVICES': '0,1,2,3'}, str(tmp_path / 'absent')) == 4
+    src = open(os.path.join(ROOT, 'bench.py')).read()
+    body = src[src.index('def launch('):src.index('# ---', src.index('def launch('))]
+    assert 'torch' not in body

@@ -61,6 +61,30 @@ def test_warp_planes_bit_exact(cuda, h, w, C, D):
     assert 0.05 < wm.float().mean() < 1.0          # both valid and invalid samples are present
 
 
+@pytest.mark.parametrize('h,w,C,D', [(32, 40, 32, 8), (17, 23, 4, 5), (32, 40, 1, 16), (9, 11, 3, 4)])
+def test_homography_warping_nearest_bit_exact(cuda, h, w, C, D):
+    """homography_warping(method='nearest') through the reference-named face (reference homography_warping.py:45-56,
+    230-271): tf.round sampling, out-of-range pixels read pixel (0,0) and are NOT zeroed (quirk C4)."""
+    from atvsnet_amd.atvsnet import homography_warping as HW
+    cams = _example_cams()
+    ds, di = OM.depth_start_interval(cams)
+    H = G.get_homographies(cams[:, 0], cams[:, 1], D, ds, di)
+    src = _feat(h, w, C, 7)
+    want = torch.stack([G.homography_warping(src, H[:, d], method='nearest')[0] for d in range(D)])
+    wm = torch.stack([G.homography_warping(src, H[:, d], method='nearest', output_mask=True)[1][0] for d in range(D)])
+    got, mask = HW.homography_warping(src.to(cuda), H.to(cuda), method='nearest', output_mask=True)
+    assert got.shape == (1, D, h, w, C) and mask.shape == (1, D, h, w, 1) and mask.dtype == torch.bool
+    assert torch.equal(got[0].cpu(), want)
+    assert torch.equal(mask[0].cpu(), wm)
+    inv = ~wm[..., 0]
+    assert inv.any() and torch.equal(want[inv], src[0, 0, 0].expand_as(want[inv]))      # un-masked pixel (0,0)
+    # single homography (B,3,3), no mask: the reference's plain call form
+    one = HW.homography_warping(src.to(cuda), H[:, 1].to(cuda), method='nearest')
+    assert torch.equal(one[0].cpu(), want[1])
+    with pytest.raises(ValueError):
+        HW.homography_warping(src.to(cuda), H[:, 1].to(cuda), method='cubic')
+
+
 def test_cost_volume_bit_exact(cuda):
     from atvsnet_amd import ops
     cams = _example_cams()

@@ -25,14 +25,28 @@ def field(num, wt, payload):
     return vi((num << 3) | wt) + (vi(len(payload)) + payload if wt == 2 else payload)
 
 
-def entry_proto(dtype, shape, offset, size, shard=0):
+def crc32c_bitwise(data):
+    """Independent bit-at-a-time CRC-32C (the writer side of these tests; the reader uses slicing-by-8 tables)."""
+    c = 0xffffffff
+    for b in data:
+        c ^= b
+        for _ in range(8):
+            c = (c >> 1) ^ (0x82F63B78 if c & 1 else 0)
+    return c ^ 0xffffffff
+
+
+def masked(c):
+    return (((c >> 15) | (c << 17)) + 0xa282ead8) & 0xffffffff
+
+
+def entry_proto(dtype, shape, offset, size, shard=0, crc=0):
     dims = b''.join(field(2, 2, field(1, 0, vi(d))) for d in shape)
     msg = field(1, 0, vi(dtype)) + field(2, 2, dims)
     if shard:
         msg += field(3, 0, vi(shard))
     if offset:
         msg += field(4, 0, vi(offset))
-    return msg + field(5, 0, vi(size)) + field(6, 5, struct.pack('<I', 0x12345678))
+    return msg + field(5, 0, vi(size)) + field(6, 5, struct.pack('<I', masked(crc)))
 
 
 def block(pairs, restart_every=2):
@@ -48,7 +62,8 @@ def block(pairs, restart_every=2):
         body += vi(shared) + vi(len(k) - shared) + vi(len(v)) + k[shared:] + v
         prev = k
     body += b''.join(struct.pack('<I', r) for r in restarts) + struct.pack('<I', len(restarts))
-    return bytes(body), bytes(body) + b'\x00' + b'\xde\xad\xbe\xef'       # (payload, payload + trailer)
+    trailer = struct.pack('<I', masked(crc32c_bitwise(bytes(body) + b'\x00')))
+    return bytes(body), bytes(body) + b'\x00' + trailer                   # (payload, payload + type byte + crc)
 
 
 def write_bundle(prefix, tensors, n_blocks=2, num_shards=1):
@@ -57,7 +72,7 @@ def write_bundle(prefix, tensors, n_blocks=2, num_shards=1):
         arr = tensors[name]
         code = {np.dtype('float32'): 1, np.dtype('int32'): 3, np.dtype('int64'): 9}[arr.dtype]
         raw = arr.astype(arr.dtype.newbyteorder('<')).tobytes()
-        entries.append((name.encode(), entry_proto(code, arr.shape, len(data), len(raw))))
+        entries.append((name.encode(), entry_proto(code, arr.shape, len(data), len(raw), crc=crc32c_bitwise(raw))))
         data += raw
     header = field(1, 0, vi(num_shards)) + field(2, 0, vi(0)) + field(3, 2, field(1, 0, vi(1)))
     pairs = [(b'', header)] + entries
@@ -103,6 +118,48 @@ def test_read_checkpoint_round_trip(tmp_path):
         assert C.list_variables(prefix)[0] == ('beta1_power', ())
         only = C.read_checkpoint(prefix, names={'conv0_x_0/conv1/biases'})
         assert list(only) == ['conv0_x_0/conv1/biases']
+
+
+def test_crc32c_known_answers():
+    """RFC 3720 appendix B.4 check values + the classic '123456789' vector; mask / unmask as crc32c.h defines them."""
+    assert C.crc32c(b'123456789') == 0xE3069283
+    assert C.crc32c(b'\x00' * 32) == 0x8A9136AA
+    assert C.crc32c(b'\xff' * 32) == 0x62A8AB43
+    assert C.crc32c(bytes(range(32))) == 0x46DD794E
+    assert C.crc32c(bytes(range(31, -1, -1))) == 0x113FDB5C
+    assert C.crc32c(b'') == 0
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 8, 9, 63, 1000):
+        buf = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert C.crc32c(buf) == crc32c_bitwise(buf)
+        assert C.crc32c(buf[3:], C.crc32c(buf[:3])) == C.crc32c(buf)           # incremental form
+    for c in (0, 1, 0xE3069283, 0xffffffff):
+        assert C.crc_unmask(C.crc_mask(c)) == c and C.crc_mask(c) == masked(c)
+    assert C.crc_mask(0xE3069283) != 0xE3069283
+
+
+def test_corrupt_bytes_raise(tmp_path):
+    """One flipped byte in a tensor or in an index block is an error (TensorFlow: DataLoss), never silently different
+    weights."""
+    p = str(tmp_path / 'c.ckpt')
+    w = np.arange(64, dtype=np.float32)
+    write_bundle(p, {'w': w, 'v': np.ones((3,), np.float32)})
+    assert np.array_equal(C.read_checkpoint(p)['w'], w)
+    shard = p + '.data-00000-of-00001'
+    raw = bytearray(open(shard, 'rb').read())
+    raw[17] ^= 0x40
+    open(shard, 'wb').write(bytes(raw))
+    with pytest.raises(ValueError, match='checksum'):
+        C.read_checkpoint(p)
+    assert not np.array_equal(C.read_checkpoint(p, verify=False)['w'], w)       # explicit opt-out still reads
+    assert np.array_equal(C.read_checkpoint(p, names={'w'}, verify=False)['w'].shape, w.shape)
+    raw[17] ^= 0x40
+    open(shard, 'wb').write(bytes(raw))
+    idx = bytearray(open(p + '.index', 'rb').read())
+    idx[5] ^= 0x01                                     # inside the first data block
+    open(p + '.index', 'wb').write(bytes(idx))
+    with pytest.raises(ValueError, match='checksum'):
+        C.read_index(p)
 
 
 def test_store_loads_checkpoint_and_is_strict(tmp_path):
