@@ -236,7 +236,7 @@ _pack_cache = {}
 
 
 class _Packed(object):
-    __slots__ = ('wp', 'tab', 'ntaps', 'vec', 'ksteps', 'ntiles', 'cin', 'cout', 'key')
+    __slots__ = ('wp', 'tab', 'ntaps', 'vec', 'ksteps', 'ntiles', 'cin', 'cout', 'key', 'xw')
 
 
 def pack_conv_weights(key, w_host, taps, transposed, device):
@@ -313,10 +313,20 @@ def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y, xpair
     return pk
 
 
+_USE_XW = True
+
+
+def use_xw(flag):
+    """Testing / A-B hook: the Winograd F(2,3)-along-y form of the x-pair kernel (conv_xw.hip) instead of conv_xp.hip."""
+    global _USE_XW
+    _USE_XW = bool(flag)
+
+
 def pack_conv_xp(key, w_host, device):
-    """Packed weights of the one-workgroup-per-CU x-pair kernel (atvs_conv_xp_f32); cached."""
+    """Packed weights of the one-workgroup-per-CU x-pair kernel (atvs_conv_xp_f32 / atvs_conv_xw_f32); cached."""
     import numpy as np
-    ck = ('xp', key, str(device))
+    xw = _USE_XW
+    ck = ('xw' if xw else 'xp', key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
@@ -324,15 +334,17 @@ def pack_conv_xp(key, w_host, device):
     cin = w.shape[-2]
     L = _lib.lib()
     pf = ctypes.c_long()
-    rc = L.atvs_conv_xp_pack_size(cin, ctypes.byref(pf))
+    size_fn, pack_fn = (L.atvs_conv_xw_pack_size, L.atvs_conv_xw_pack) if xw else (L.atvs_conv_xp_pack_size, L.atvs_conv_xp_pack)
+    rc = size_fn(cin, ctypes.byref(pf))
     if rc:
-        raise RuntimeError('atvs_conv_xp_pack_size failed (%d) for Cin=%d' % (rc, cin))
+        raise RuntimeError('atvs_conv_x%s_pack_size failed (%d) for Cin=%d' % ('w' if xw else 'p', rc, cin))
     packed = np.empty(pf.value, np.float32)
-    rc = L.atvs_conv_xp_pack(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
+    rc = pack_fn(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
-        raise RuntimeError('atvs_conv_xp_pack failed (%d)' % rc)
+        raise RuntimeError('atvs_conv_x%s_pack failed (%d)' % ('w' if xw else 'p', rc))
     pk = _Packed()
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 36, 4, 0, 1, cin, 8
+    pk.xw = xw
     pk.key = key
     pk.tab = None
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
@@ -419,7 +431,8 @@ def deconv_up_ok(cin, cout):
 def pack_conv_xp_sibling(key, w_host, device):
     """Packed weights of the stride-2 sibling [3,3,3,Cin,16] of an x-pair launch; cached."""
     import numpy as np
-    ck = ('xp2', key, str(device))
+    xw = _USE_XW
+    ck = ('xw2' if xw else 'xp2', key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
@@ -429,15 +442,18 @@ def pack_conv_xp_sibling(key, w_host, device):
         raise ValueError('x-pair sibling: 16 output channels, got %d' % w.shape[-1])
     L = _lib.lib()
     pf = ctypes.c_long()
-    rc = L.atvs_conv_xp_pack_sibling_size(cin, ctypes.byref(pf))
+    size_fn, pack_fn = ((L.atvs_conv_xw_pack_sibling_size, L.atvs_conv_xw_pack_sibling) if xw else
+                        (L.atvs_conv_xp_pack_sibling_size, L.atvs_conv_xp_pack_sibling))
+    rc = size_fn(cin, ctypes.byref(pf))
     if rc:
-        raise RuntimeError('atvs_conv_xp_pack_sibling_size failed (%d) for Cin=%d' % (rc, cin))
+        raise RuntimeError('x-pair sibling pack size failed (%d) for Cin=%d' % (rc, cin))
     packed = np.empty(pf.value, np.float32)
-    rc = L.atvs_conv_xp_pack_sibling(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
+    rc = pack_fn(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
-        raise RuntimeError('atvs_conv_xp_pack_sibling failed (%d)' % rc)
+        raise RuntimeError('x-pair sibling pack failed (%d)' % rc)
     pk = _Packed()
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, 16
+    pk.xw = xw
     pk.key = key
     pk.tab = None
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
@@ -590,9 +606,12 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
     for ip in (ipa, ipb):
         if ip is not None and (ip.numel() != G * 3 * Cin or not ip.is_contiguous()):
             raise ValueError('conv_xp: prologue parameters must be (groups, 3, Cin)')
+    xw = bool(getattr(pk, 'xw', False))
+    if pk2 is not None and bool(getattr(pk2, 'xw', False)) != xw:
+        raise ValueError('conv_xp: the main and the sibling weights are packed for different kernels')
     if _dev_ok(x5, y, bias, plane_bias, y2, pb2, x2, ipa, ipb):
         with _Timed(pk.key, x5.shape[1:], pk.cout + (16 if pk2 is not None else 0), G):
-            _call('atvs_conv_xp_f32', _p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
+            _call('atvs_conv_xw_f32' if xw else 'atvs_conv_xp_f32', _p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
                   ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
                   sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _p(x2), _p(ipa), _p(ipb),
                   int(bool(relu_a)), int(bool(relu_b)), _stream())

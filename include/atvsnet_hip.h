@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 13
+#define ATVS_ABI_VERSION 14
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -251,6 +251,23 @@ int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed);
  * shapes the path has: in_params with Cin % 16 == 0 and a sibling; x2 with Cin % 16 == 8 and a sibling (else ATVS_ERR_ARG). */
 long atvs_conv_xp_grid(int D, int H, int W, int groups);
 int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias, float* y,
+                     double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                     const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
+                     int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
+                     int in_relu2, atvs_stream_t stream);
+
+/* The same layers (same contract, grid and statistics rows as atvs_conv_xp_f32, every Cin % 8 == 0) on the
+ * Winograd kernel conv_xw.hip: x-pair rows x minimal filtering F(2,3) along y -- two output rows from 4 products per
+ * (kd, x offset, channel) instead of 6, i.e. 2/3 of the MFMAs of atvs_conv_xp_f32.  The filter transform
+ * U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2] is applied by the HOST packer in double; the input transform
+ * [d0-d2, d1+d2, d2-d1, d1-d3] in registers from the raw rows staged in LDS (8-channel chunks, double-buffered image).
+ * Results differ from the direct sum by fp32 rounding only (one 32 -> 8 layer: 7.7e-7 of the output maximum against
+ * 4.2e-7 for atvs_conv_xp_f32).  Weights must be packed with atvs_conv_xw_pack / _pack_sibling (NOT the xp forms). */
+int atvs_conv_xw_pack_size(int Cin, long* packed_floats);
+int atvs_conv_xw_pack(const float* w, int Cin, float* packed);
+int atvs_conv_xw_pack_sibling_size(int Cin, long* packed_floats);
+int atvs_conv_xw_pack_sibling(const float* w2, int Cin, float* packed);
+int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias, float* y,
                      double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,

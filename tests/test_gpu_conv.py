@@ -244,14 +244,16 @@ def test_split_volume_conv_matches_dense(cuda, impl, stride):
     _close(s[0, :8].float(), want.reshape(-1, 8).double().sum(0).float(), 1e-5)
 
 
-@pytest.mark.parametrize('xp1w', [True, False])
+@pytest.mark.parametrize('xp1w', ['xw', 'xp', False])
 @pytest.mark.parametrize('D,H,W,Cin', [(9, 19, 70, 32), (4, 8, 32, 16), (6, 21, 45, 8), (13, 9, 33, 24), (2, 3, 24, 16)])
 def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
-    """Both x-pair kernels for the 8-output-channel layers (one workgroup per CU / the tiled kernel's x-pair form):
-    ragged sizes, 16- and 8-channel chunks, with depth-plane bias + bias + residual + ReLU, written into a
+    """The three x-pair kernels for the 8-output-channel layers (one workgroup per CU: Winograd F(2,3)-along-y form
+    conv_xw.hip and the direct form conv_xp.hip / the tiled kernel's x-pair form): ragged sizes (odd H: a row pair that
+    straddles the end), 16- and 8-channel chunks, with depth-plane bias + bias + residual + ReLU, written into a
     channel slice of a wider (concat) buffer, statistics of what was written."""
     from atvsnet_amd import ops
-    ops.use_xp1w(xp1w)
+    ops.use_xp1w(bool(xp1w))
+    ops.use_xw(xp1w == 'xw')
     ops.clear_pack_cache()
     try:
         x = _rand((1, D, H, W, Cin), 50)
@@ -280,11 +282,23 @@ def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
         _close(got2.cpu(), want + res)
     finally:
         ops.use_xp1w(True)
+        ops.use_xw(True)
         ops.clear_pack_cache()
 
 
+@pytest.fixture(params=['xw', 'xp'])
+def xkernel(request):
+    """Run a test on both one-workgroup-per-CU x-pair kernels: conv_xw.hip (default) and conv_xp.hip."""
+    from atvsnet_amd import ops
+    ops.use_xw(request.param == 'xw')
+    ops.clear_pack_cache()
+    yield request.param
+    ops.use_xw(True)
+    ops.clear_pack_cache()
+
+
 @pytest.mark.parametrize('D,H,W,Cin', [(8, 16, 64, 32), (9, 19, 70, 16), (6, 21, 45, 8), (5, 8, 33, 24), (4, 7, 32, 8)])
-def test_conv_siblings_one_launch(cuda, D, H, W, Cin):
+def test_conv_siblings_one_launch(cuda, xkernel, D, H, W, Cin):
     """conv(8 channels, stride 1) and conv(16 channels, stride 2, SAME) of one input from ONE launch equal the two
     separate convolutions (even and odd sizes: the stride-2 SAME padding moves), with plane biases and statistics."""
     from atvsnet_amd import ops
