@@ -235,71 +235,101 @@ def sharded_attention(local_xs, my_views, num_views, scope, like, impl=None, gro
 
 # --------------------------------------------------------------------------------------------- the pipeline of one rank
 
-def _sharded_steps(images, cams, max_d, world, rank):
-    """example.infer_multiview for this rank's share of the source views, as a generator: local compute runs
-    between the yields, every yield is a communication step all ranks of the group must perform.
-    Returns the full-resolution inverse-depth map (1,H,W,1), identical on every rank of the group."""
-    from .atvsnet import example as ex
-    from .atvsnet import model
-    n = images.shape[1]
-    mine = plan(n, world)[rank]
-    fwd = sorted(v for kind, v in mine if kind == 'fwd')
-    rev = sorted(v for kind, v in mine if kind == 'rev')
-    views = sorted(set(fwd + rev))
-    depth_start, depth_interval = ex.depth_range(cams)
-    dev = images.device
-    h, w = images.shape[2] // 4, images.shape[3] // 4
-    dv_all = torch.zeros((n - 1, h, w), dtype=torch.float32, device=dev)
+class HipLocalStages(object):
+    """The rank-local compute of the sharded pipeline on the HIP kernels (model.*_batch: every network evaluated once over
+    all the (view, direction) calls the rank owns).  The CPU tests substitute an oracle-backed object with the same four
+    methods (tests/test_parallel_gloo.py); the product default is this class."""
 
-    # ---- base stage (reference model.py:398-417): every owned (view, direction) in ONE pass of each network
-    filtered = None
-    if views:
+    attention = None          # -> HipAttentionOps()
+
+    def base(self, images, cams, max_d, depth_start, depth_interval, fwd, rev):
+        """Base stage (reference model.py:398-417) of the owned directions -> (filtered cost volumes (len(fwd),D,h,w,8) in
+        `fwd` order or None, {v: depth_view (h,w) for v in rev})."""
+        from .atvsnet import model
+        views = sorted(set(fwd) | set(rev))
         local = [0] + views                                    # the reference view and the owned sources
         index = {v: i for i, v in enumerate(local)}
         feats = model.feature_extraction_batch(torch.cat([images[:, i] for i in local], 0).unsqueeze(0))
         filtered, _, _, dview = model.base_stage_batch(feats, cams, max_d, depth_start, depth_interval, fwd=fwd, rev=rev,
                                                        ref_i=0, feature_index=index)
+        h, w = images.shape[2] // 4, images.shape[3] // 4
+        return (filtered if fwd else None), {v: dview[v].reshape(h, w) for v in rev}
+
+    def head(self, cost_agg, max_d, depth_start, depth_interval):
+        """AAM1's output conv + soft-argmin: (D,h,w,8) -> (prob_agg (1,D,h,w), depth_init (1,h,w,1))."""
+        from .atvsnet import model
+        prob_agg = model.output_conv(cost_agg.unsqueeze(0), reuse=False)
+        return prob_agg, model.prob2depth(prob_agg, max_d, depth_start, depth_interval)
+
+    def refine(self, images, cams, max_d, depth_start, depth_interval, fwd, depth_init, dviews, prob_agg, cost_agg):
+        """Refinement of the owned sources in one pass -> refined cost volumes (len(fwd),D,h,w,8) = cost_agg + residual."""
+        from .atvsnet import model
+        local = [0] + list(fwd)
+        index = {v: i for i, v in enumerate(local)}
+        shallow = model.shallow_feature_batch(torch.cat([images[:, i] for i in local], 0).unsqueeze(0))
+        cres, _ = model.refinement_batch(depth_init, dviews, prob_agg, cams, max_d, depth_start, depth_interval, list(fwd),
+                                         shallow, ref_id=0, shallow_index=index)
+        refined = torch.empty_like(cres)
+        for b in range(len(fwd)):
+            ops.add_n([cost_agg, cres[b]], out=refined[b])
+        return refined
+
+    def final(self, rcost_agg, max_d, depth_start, depth_interval):
+        """AAM2's output conv, x4 upsample + soft-argmin: (D,h,w,8) -> (1,H,W,1)."""
+        from .atvsnet import model
+        rprob_agg = model.output_conv_refine(rcost_agg.unsqueeze(0), reuse=False)
+        return model.prob2depth_upsample(rprob_agg, max_d, depth_start, depth_interval)[1]
+
+
+def _sharded_steps(images, cams, max_d, world, rank, stages=None):
+    """example.infer_multiview for this rank's share of the source views, as a generator: local compute runs
+    between the yields, every yield is a communication step all ranks of the group must perform.
+    Returns the full-resolution inverse-depth map (1,H,W,1), identical on every rank of the group.
+    A rank may own no forward direction (more ranks than sources with split directions) or nothing at all (more ranks
+    than directions): it still takes part in every exchange and ends with the same map."""
+    from .atvsnet import example as ex
+    stages = stages or HipLocalStages()
+    n = images.shape[1]
+    mine = plan(n, world)[rank]
+    fwd = sorted(v for kind, v in mine if kind == 'fwd')
+    rev = sorted(v for kind, v in mine if kind == 'rev')
+    depth_start, depth_interval = ex.depth_range(cams)
+    dev = images.device
+    h, w = images.shape[2] // 4, images.shape[3] // 4
+    dv_all = torch.zeros((n - 1, h, w), dtype=torch.float32, device=dev)
+
+    # ---- base stage: every owned (view, direction) in ONE pass of each network
+    filtered = None
+    if fwd or rev:
+        filtered, dview = stages.base(images, cams, max_d, depth_start, depth_interval, fwd, rev)
         for v in rev:      # quirk C11: the reverse direction swept the reference camera's depth range
-            dv_all[v - 1].copy_(dview[v].reshape(h, w))
-        del feats
-        if not fwd:
-            filtered = None
+            dv_all[v - 1].copy_(dview[v])
     yield 'allreduce', dv_all, dist.ReduceOp.SUM                # every view has exactly one contributor
 
     # ---- AAM1 across the group
-    cost_agg = (yield from _attention_steps(filtered, fwd, n, 'attention_aggregate', (max_d, h, w), dev, world,
-                                            rank)).unsqueeze(0)
-    prob_agg = model.output_conv(cost_agg, reuse=False)
-    depth_init = model.prob2depth(prob_agg, max_d, depth_start, depth_interval)
+    cost_agg = yield from _attention_steps(filtered, fwd, n, 'attention_aggregate', (max_d, h, w), dev, world, rank,
+                                           stages.attention)
+    prob_agg, depth_init = stages.head(cost_agg, max_d, depth_start, depth_interval)
     del filtered
 
     # ---- refinement of the owned sources, one pass
     refined = None
     if fwd:
-        local = [0] + fwd
-        index = {v: i for i, v in enumerate(local)}
-        shallow = model.shallow_feature_batch(torch.cat([images[:, i] for i in local], 0).unsqueeze(0))
         dviews = {v: dv_all[v - 1].reshape(1, h, w, 1) for v in fwd}
-        cres, _ = model.refinement_batch(depth_init, dviews, prob_agg, cams, max_d, depth_start, depth_interval, fwd,
-                                         shallow, ref_id=0, shallow_index=index)
-        refined = torch.empty_like(cres)
-        for b in range(len(fwd)):
-            ops.add_n([cost_agg[0], cres[b]], out=refined[b])
-        del cres
+        refined = stages.refine(images, cams, max_d, depth_start, depth_interval, fwd, depth_init, dviews, prob_agg, cost_agg)
 
     # ---- AAM2 across the group, head, x4 upsample + soft-argmin (replicated)
-    rcost_agg = yield from _attention_steps(refined, fwd, n, 'attention_aggregate_refine', (max_d, h, w), dev, world, rank)
-    rprob_agg = model.output_conv_refine(rcost_agg.unsqueeze(0), reuse=False)
-    _, depth_refined = model.prob2depth_upsample(rprob_agg, max_d, depth_start, depth_interval)
-    return depth_refined
+    rcost_agg = yield from _attention_steps(refined, fwd, n, 'attention_aggregate_refine', (max_d, h, w), dev, world, rank,
+                                            stages.attention)
+    return stages.final(rcost_agg, max_d, depth_start, depth_interval)
 
 
-def infer_multiview_sharded(images, cams, max_d=None, group=None, view_streams=True):
+def infer_multiview_sharded(images, cams, max_d=None, group=None, view_streams=True, stages=None):
     """example.infer_multiview with the source views sharded over the process group (every launch issued from
     Python).  Every rank returns the same full-resolution inverse-depth map (1,H,W,1).  (view_streams is accepted
-    for compatibility: a rank evaluates its views in one batched pass.)"""
+    for compatibility: a rank evaluates its views in one batched pass.  stages: test hook, see HipLocalStages.)"""
     max_d = FLAGS.max_d if max_d is None else max_d
-    return _drive(_sharded_steps(images, cams, max_d, dist.get_world_size(group), dist.get_rank(group)), group)
+    return _drive(_sharded_steps(images, cams, max_d, dist.get_world_size(group), dist.get_rank(group), stages), group)
 
 
 class ShardedGraphedInference(object):

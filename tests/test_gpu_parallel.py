@@ -63,12 +63,14 @@ def _sharded_worker(rank, world, port, n_views, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('world,n_views', [(2, 4), (2, 3), (4, 3)])
+@pytest.mark.parametrize('world,n_views', [(2, 4), (2, 3), (4, 3), (8, 9)])
 def test_sharded_path_multi_rank_on_one_gpu(cuda, world, n_views):
     """The COMPLETE view-sharded pipeline on the HIP kernels with several ranks (all on this one GPU, gloo carrying the
     collectives -- RCCL refuses two ranks per device): sources dealt round-robin (world 2) and the two siamese
-    directions of a source on different ranks with the depth_view exchange (world 4, 2 sources).  Every rank must
-    end with the single-process depth map."""
+    directions of a source on different ranks with the depth_view exchange (world 4, 2 sources: the odd ranks own NO
+    forward view -- nothing to refine, empty AANet input -- and still run the eager path and the ShardedGraphedInference
+    chain), and BASELINE configs[3]'s partition (world 8, 9 views: one source per rank).  Every rank must end with the
+    single-process depth map."""
     import numpy as np
     import torch.multiprocessing as mp
     ctx = mp.get_context('spawn')
@@ -89,5 +91,6 @@ def test_sharded_path_multi_rank_on_one_gpu(cuda, world, n_views):
     kinds = [sorted(k for k, _ in r[3]) for r in res]
     if world >= 2 * (n_views - 1):
         assert all(len(k) == 1 for k in kinds)               # one direction per rank
+        assert sum(k == ['rev'] for k in kinds) == n_views - 1      # ranks without a forward view took part
     else:
         assert all(k.count('fwd') == k.count('rev') for k in kinds)
