@@ -28,8 +28,12 @@ already in the environment -- it is a rank itself and measures the mode --parall
   --parallel views  (secondary; reported under "view_sharded" of the same line): the source views of ONE depth map
                     are sharded over groups of at most one rank per source and exchanged inside both AANet modules
                     over RCCL (all-to-all of voxel shards + all-gather) -- lower latency per depth map, fewer depth
-                    maps per second than `maps` (DESIGN.md 5 has the model).  Measured best-effort by a second set of
-                    ranks after the primary result is safe; a failure there is reported, not fatal.
+                    maps per second than `maps` (DESIGN.md 5 has the model).  Measured by a second set of ranks after
+                    the primary result is safe; a failure there is reported in the line and on stderr.
+With the default workload the launcher ALSO measures BASELINE configs[3] ("view_sharded_cfg4": 9 views 928x480x256, the 8
+sources dealt over the N ranks -- one per GPU at N = 8 -- with `source_views_per_sec`, the exchange's share, the parity
+against tests/golden/fullsize_cfg4.npz, and the same depth map on ONE rank measured in the same invocation, so that
+speed-up and fraction-of-linear come from one run).
 
 One JSON line on rank 0.  `roofline` = the dominant kernel (conv_xp.hip: the 3x3x3 convolution of the 32 warped
 channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch) against
@@ -61,8 +65,8 @@ DOMINANT = ('conv_b0_0_1/conv3d/kernel', 'var')   # the D-varying half of conv_b
 WARP = ('warp', 0)                                 # atvs_warp_planes, bilinear (the cost-volume build)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md, HBM3E peak (6.29 TB/s achievable by a float4 copy)
-PMC_FILE = os.path.join('profiles', 'round1_pmc_dominant_kernel_v2.json')
-KERNEL_STATS_FILE = os.path.join('profiles', 'round2_bench_kernel_stats.csv')
+PMC_FILE = os.path.join('profiles', 'round3_pmc_xw.json')
+KERNEL_STATS_FILE = os.path.join('profiles', 'round3_bench_kernel_stats.csv')
 
 
 def parse(argv=None):
@@ -184,23 +188,67 @@ def launch(args, argv):
         sys.stdout.write(text)
         sys.stderr.write('bench.py: rank(s) failed: %s\n' % bad)
         return 1
-    if not args.dry and args.parallel in (None, 'both') and args.views > 2:
-        # secondary, best-effort: the view-sharded form of the same workload (a failure / hang there must not cost the
-        # primary result)
-        try:
-            t2, rc2 = _run_ranks(n, base + ['--parallel', 'views', '--no-cpu-baseline'], 600)
-            l2 = _last_json(t2)
-            if l2 is not None and all(rc == 0 for rc in rc2):
-                line['view_sharded'] = {k: l2.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'exchange', 'parity')}
-                line['view_sharded']['parallelism'] = l2['config']['parallelism']
-                line['view_sharded']['groups'] = l2['config']['groups']
-            else:
-                line['view_sharded'] = {'error': 'ranks returned %s' % rc2}
-        except Exception as e:
-            line['view_sharded'] = {'error': repr(e)}
+    if not args.dry and args.parallel in (None, 'both'):
+        # secondary results of the same line, measured after the primary one is safe (a failure / hang there is reported
+        # inside the line and on stderr, it does not cost the primary number):
+        #   view_sharded       the same workload with its source views sharded inside groups (RCCL exchange in both AANets)
+        #   view_sharded_cfg4  BASELINE configs[3]: 9 views 928x480x256, its 8 sources dealt over the N ranks (N = 8: one
+        #                      per GPU), next to the same depth map on ONE rank measured in the same invocation
+        def secondary(nranks, extra, timeout_s):
+            try:
+                t2, rc2 = _run_ranks(nranks, extra + ['--no-cpu-baseline'], timeout_s)
+                l2 = _last_json(t2)
+                if l2 is not None and all(rc == 0 for rc in rc2):
+                    return l2, None
+                return None, 'ranks returned %s' % rc2
+            except Exception as e:
+                return None, repr(e)
+        if args.views > 2:
+            l2, err = secondary(n, base + ['--parallel', 'views'], 600)
+            line['view_sharded'] = view_sharded_entry(l2, err)
+        if not args.custom and args.workload == 'cfg3':
+            wl = [a for i, a in enumerate(base) if a != '--workload' and (i == 0 or base[i - 1] != '--workload')]
+            wl = [a for i, a in enumerate(wl) if a not in ('--gpus',) and (i == 0 or wl[i - 1] != '--gpus')]
+            one, err1 = secondary(1, wl + ['--gpus', '1', '--workload', 'cfg4', '--inflight', '1', '--steps', '3', '--warmup', '1'], 900)
+            shd, err2 = secondary(n, wl + ['--gpus', str(n), '--workload', 'cfg4', '--parallel', 'views', '--steps', '5', '--warmup', '2'], 900)
+            line['view_sharded_cfg4'] = cfg4_entry(one, err1, shd, err2, n)
+        for key in ('view_sharded', 'view_sharded_cfg4'):
+            if isinstance(line.get(key), dict) and line[key].get('error'):
+                sys.stderr.write('bench.py: secondary measurement %s FAILED: %s\n' % (key, line[key]['error']))
     print(json.dumps(line))
     sys.stdout.flush()
     return 0
+
+
+def view_sharded_entry(l2, err):
+    """The view-sharded run of the primary workload as a sub-object of the primary line."""
+    if l2 is None:
+        return {'ok': False, 'error': err}
+    out = {k: l2.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'source_views_per_sec', 'exchange', 'parity')}
+    out.update(ok=True, mode='views (source views of one depth map sharded inside a group, RCCL exchange in AAM1/AAM2)',
+               parallelism=l2['config']['parallelism'], groups=l2['config']['groups'])
+    return out
+
+
+def cfg4_entry(one, err1, shd, err2, n):
+    """BASELINE configs[3] (9 views 928x480, D=256): the 8 sources sharded over n ranks vs the same depth map on one rank."""
+    out = {'workload': 'cfg4: 9 views (1 ref + 8 src) 928x480, D=256 (BASELINE configs[3])', 'n_gpus': n,
+           'mode': 'views: the 8 source views dealt over the ranks, all-to-all + all-gather inside both AANets'}
+    if one is not None:
+        out['single_gpu'] = {'ms_per_step': one.get('ms_per_step'), 'value': one.get('value'), 'parity': one.get('parity')}
+    else:
+        out['single_gpu'] = {'ok': False, 'error': err1}
+    if shd is None:
+        out.update(ok=False, error=err2)
+        return out
+    out.update(ok=True, value=shd.get('value'), unit=shd.get('unit'), ms_per_step=shd.get('ms_per_step'),
+               scaling='strong', source_views_per_sec=shd.get('source_views_per_sec'), exchange=shd.get('exchange'),
+               parity=shd.get('parity'), parallelism=shd['config']['parallelism'], groups=shd['config']['groups'])
+    if one is not None and one.get('ms_per_step') and shd.get('ms_per_step'):
+        speedup = one['ms_per_step'] / shd['ms_per_step']
+        out['speedup_vs_single_gpu'] = round(speedup, 3)
+        out['fraction_of_linear'] = round(speedup / n, 4)
+    return out
 
 
 # --------------------------------------------------------------------------------------------- CPU baseline
@@ -289,17 +337,20 @@ def cpu_baseline(args):
 
 # --------------------------------------------------------------------------------------------- reporting helpers
 
-def pmc_traffic(args):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (only valid for the
-    640x512x192 volume they were taken on).  FETCH_SIZE on gfx950 counts wide coalesced reads at half their
-    bytes (MI355X_MICROARCH.md, HBM): both the raw and the doubled figure are given."""
+def pmc_traffic(args, samples):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS kernel as bench.py
+    launches it (profiles/round3_pmc_xw.json: conv_xw_kernel<true,0>, 8 volumes per launch, 640x512x192; only valid for
+    that form).  FETCH_SIZE on gfx950 counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md, HBM) and
+    is uncalibrated for this kernel's 32-byte pieces: the raw and the doubled figure are both given."""
     if (args.width, args.height, args.depths) != (640, 512, 192):
         return None
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
-            d = json.load(f)['derived']
-        return {'write': d['write_bytes_pmc'], 'fetch_raw': d['fetch_bytes_pmc_raw'],
-                'fetch_x2': 2 * d['fetch_bytes_pmc_raw'], 'source': PMC_FILE}
+            d = json.load(f)['dominant']
+        if int(d['volumes_per_launch']) != int(samples):
+            return None
+        return {'write': int(d['write_bytes']), 'fetch_raw': int(d['fetch_bytes_raw']), 'fetch_x2': 2 * int(d['fetch_bytes_raw']),
+                'source': PMC_FILE, 'measured_in_run': False}
     except Exception:
         return None
 
@@ -521,21 +572,22 @@ def rank_main(args):
             avg_ms = float(np.mean([ms for ms, _ in watched[DOMINANT]]))
             flops, alg_bytes = flops * samples, int(alg_bytes * samples)
             ach = flops / (avg_ms * 1e-3) / 1e12
-            tr = pmc_traffic(args)
-            if tr:       # the PMC passes were taken on one volume per launch
-                tr = dict(tr, write=int(tr['write'] * samples), fetch_raw=int(tr['fetch_raw'] * samples),
-                          fetch_x2=int(tr['fetch_x2'] * samples))
-            roof = {'bound': 'mfma', 'kernel': 'conv_xp_kernel<C4=4,SIB> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full '
-                                              'resolution, + sibling conv_b0_1_0: -> 16, stride 2; %d volumes per launch)' % int(samples),
+            tr = pmc_traffic(args, samples)
+            roof = {'bound': 'mfma', 'kernel': 'conv_xw_kernel<SIB> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full resolution, '
+                                              'x-pair rows x Winograd F(2,3) along y, + sibling conv_b0_1_0: -> 16, stride 2; '
+                                              '%d volumes per launch)' % int(samples),
+                    'flops_convention': 'algorithmic = direct-convolution FLOPs (SURVEY 8d); the kernel issues 8/9 of them as '
+                                        'MFMA work (F(2,3): 2/3, x-pair rows: 4/3)',
                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     'traffic': (tr['write'] + tr['fetch_x2']) if tr else None,
                     'traffic_detail': dict(tr, algorithmic=alg_bytes,
                                            ratio_raw=round((tr['write'] + tr['fetch_raw']) / alg_bytes, 3),
                                            ratio_x2=round((tr['write'] + tr['fetch_x2']) / alg_bytes, 3),
-                                           note='HBM bytes per launch from rocprofv3 --pmc passes; FETCH_SIZE on gfx950 '
-                                                'reports half the bytes of wide coalesced reads, so the true read traffic '
-                                                'lies between fetch_raw and fetch_x2; `traffic` uses write + fetch_x2')
+                                           note='memory-side bytes per launch from rocprofv3 --pmc passes of this kernel (8 volumes '
+                                                'per launch); FETCH_SIZE counts Infinity-Cache hits too and on gfx950 reports half '
+                                                'the bytes of wide coalesced reads: the true read traffic lies between fetch_raw '
+                                                'and fetch_x2; `traffic` uses write + fetch_x2')
                     if tr else None,
                     'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[DOMINANT]), 'volumes_per_launch': samples,
                     'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg_bytes}

@@ -60,3 +60,22 @@ def test_visible_gpus_counts_without_the_gpu_runtime(tmp_path):
     src = open(os.path.join(ROOT, 'bench.py')).read()
     body = src[src.index('def launch('):src.index('# ---', src.index('def launch('))]
     assert 'torch' not in body
+
+
+def test_secondary_entries_name_their_mode_and_failures():
+    """What `--gpus N` adds to the primary line: every sub-object says which mode it is, carries ok / error, and the cfg4
+    entry computes speed-up and fraction-of-linear from the two runs of the same invocation."""
+    sys.path.insert(0, ROOT)
+    import bench
+    one = {'ms_per_step': 120.0, 'value': 8.33, 'parity': {'ok': True}}
+    shd = {'ms_per_step': 24.0, 'value': 41.7, 'unit': 'depth-maps/sec', 'source_views_per_sec': 333.3, 'exchange': {'comm_total_ms': 3.1},
+           'parity': {'ok': True, 'rel_l1': 6e-5}, 'config': {'parallelism': '1 group(s) of 8 rank(s)', 'groups': [list(range(8))]}}
+    e = bench.cfg4_entry(one, None, shd, None, 8)
+    assert e['ok'] and e['speedup_vs_single_gpu'] == 5.0 and e['fraction_of_linear'] == 0.625 and e['scaling'] == 'strong'
+    assert e['source_views_per_sec'] == 333.3 and e['parity']['rel_l1'] == 6e-5 and 'views' in e['mode']
+    bad = bench.cfg4_entry(one, None, None, 'ranks returned [1, 0]', 8)
+    assert bad['ok'] is False and 'ranks returned' in bad['error'] and bad['single_gpu']['ms_per_step'] == 120.0
+    v = bench.view_sharded_entry(None, 'timeout')
+    assert v == {'ok': False, 'error': 'timeout'}
+    l2 = dict(shd, scaling='strong')
+    assert bench.view_sharded_entry(l2, None)['ok'] is True
