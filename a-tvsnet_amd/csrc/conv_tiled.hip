@@ -89,9 +89,11 @@ static inline long a_groups(const TiledArgs& a) { return a.ngroups; }
 __device__ __forceinline__ int lds_swz(int a) { return a ^ (((a >> 8) & 1) << 5); }
 
 // Wavefronts per SIMD the register budget of an instantiation allows (accumulators + prefetch
-// registers + operands): 2 workgroups per CU when it fits in 256 VGPRs, else 1 (512).
+// registers + operands): 2 workgroups per CU when it fits in 256 VGPRs, else 1 (512).  The bound is set where the compiler's
+// allocation stops spilling: the forms estimated at 168-188 (<1,4,4,XP>, <1,8,2,XP>, <1,8,4>: fallback paths behind
+// conv_xw / conv_c16) needed 4-40 spilled registers at two workgroups per CU and get the whole register file instead.
 __host__ __device__ constexpr int tiled_wps(int NT, int TY, int C4, bool XP = false) {
-  return (NT * TY * 4 + ((TILE_TZ + 2) * (TY + 2) * ((XP ? 2 : 1) * TILE_TX + 2) * C4 + 255) / 256 * 4 + TY * 4 + NT * 16 + 40 <= 200) ? 2 : 1;
+  return (NT * TY * 4 + ((TILE_TZ + 2) * (TY + 2) * ((XP ? 2 : 1) * TILE_TX + 2) * C4 + 255) / 256 * 4 + TY * 4 + NT * 16 + 40 <= 165) ? 2 : 1;
 }
 // statistics in the epilogue cost 8*NT registers; the widest variant leaves them to a separate pass
 __host__ __device__ constexpr bool tiled_has_stats(int NT) { return NT < 8; }
