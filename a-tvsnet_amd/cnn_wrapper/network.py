@@ -274,7 +274,7 @@ class Network(object):
             src = src.materialize()        # a lazy input the kernel cannot form on load
         if fusable:
             if isinstance(src, ops.SplitVolume):
-                cin_var = src.var.shape[-1]
+                cin_var = src.cv
                 fusable = ops.siblings_ok(shape[1:4], cin_var, a['filters'], b['filters'])
             else:
                 fusable = ops.siblings_ok(shape[1:4], shape[4], a['filters'], b['filters'])

@@ -90,6 +90,11 @@ struct XwArgs {
   const float* in_pb;
   int relu_a, relu_b;
   int sample_major;
+  // layout of x (and x2): floats between voxels / between 8-channel chunks.  Channel-last (D,H,W,Cin): Cin / 8;
+  // chunk-planar [Cin/8][D][H][W][8] (x_planar: what the plane-sweep warp writes for this kernel -- a chunk's halo rows are
+  // then dense 32-byte voxels instead of 32 of every 128 bytes): 8 / D*H*W*8
+  int vstride;
+  long cstride;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, 1) void conv_xw_kernel(XwArgs p) {
     const int c4 = s & 1, v = s >> 1;
     const int xx = v % XW_HX, v2 = v / XW_HX;
     const int yy = v2 % XW_HY, zz = v2 / XW_HY;
-    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
+    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.vstride + c4 * 4;
     laddr[i] = ((zz * XW_HY + yy) * XW_HXP + (xx & 1) * XW_ODD + (xx >> 1)) * VB + c4 * 16;
     pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
   }
@@ -207,9 +212,9 @@ __global__ __launch_bounds__(256, 1) void conv_xw_kernel(XwArgs p) {
     int z0, y0, x0;
     tile_origin(k, &z0, &y0, &x0);
     const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
-    T.xb = xg + ch * 8;
-    T.xb2 = (PRO == 2) ? xg2 + ch * 8 : nullptr;
-    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
+    T.xb = xg + (size_t)ch * p.cstride;
+    T.xb2 = (PRO == 2) ? xg2 + (size_t)ch * p.cstride : nullptr;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.vstride;
     T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
     T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
             ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
@@ -634,10 +639,11 @@ extern "C" int atvs_conv_xw_f32(const float* x, const float* packed_w, const flo
                                 float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
                                 int relu, const float* packed_w2, const float* plane_bias2, float* y2,
                                 double* stats_partial2, int ldy2, int y_coff2, const float* x2, const float* in_params,
-                                const float* in_params2, int in_relu, int in_relu2, atvs_stream_t stream) {
+                                const float* in_params2, int in_relu, int in_relu2, int x_planar, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (in_params2 && !x2) return ATVS_ERR_ARG;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8)) return ATVS_ERR_SHAPE;
+  if (x_planar && (x2 || in_params)) return ATVS_ERR_ARG;          // the planar form is the plain (cost-volume) launch's
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if (plane_bias && D < 2) return ATVS_ERR_ARG;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;   // 31-bit element offsets
@@ -667,6 +673,8 @@ extern "C" int atvs_conv_xw_f32(const float* x, const float* packed_w, const flo
   hipStream_t st = as_stream(stream);
   a.sample_major = (groups == 8) ? 1 : 0;
   a.x2 = x2; a.in_pa = in_params; a.in_pb = in_params2; a.relu_a = in_relu; a.relu_b = in_relu2;
+  a.vstride = x_planar ? 8 : Cin;
+  a.cstride = x_planar ? (long)D * H * W * 8 : 8;
   const int pro = x2 ? 2 : (in_params ? 1 : 0);
   int rc;
   if (pro == 0) rc = packed_w2 ? launch_xw<true, 0>(a, blocks, st) : launch_xw<false, 0>(a, blocks, st);

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
 template <int MODE>
 __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     const float* __restrict__ src, const float* __restrict__ Hmats, const float* __restrict__ ref,
-    float* __restrict__ out, float* __restrict__ mask_out, int h, int w, int C, int ld, int c_off) {
+    float* __restrict__ out, float* __restrict__ mask_out, int h, int w, int C, int ld, int c_off, long plane_stride) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float s_geo[256 * 12];
   const int d = blockIdx.y;
@@ -200,7 +200,16 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
   __syncthreads();
   const int cg = C >> 2;                 // lanes per pixel: 4, 8 or 16 (a divisor of 256)
   const int ppp = 256 / cg;              // pixels per pass
-  const int lp = tid / cg, c = (tid % cg) * 4;
+  // channel-last: the cg lanes of a pixel are neighbours (one pixel = C*4 contiguous bytes; cg is a power of two).
+  // Chunk-planar: the same pixels per wavefront (all their channel groups: the gathers stay whole 128-byte rows), but lane
+  // order (pixel / 4, chunk, pixel % 4, half) so that eight neighbouring lanes write one whole 128-byte line of a chunk plane
+  const int cgs = __builtin_ctz(cg);
+  int lp = tid >> cgs, c = (tid & (cg - 1)) * 4;
+  if (plane_stride > 0) {
+    const int i = tid & (4 * cg - 1);               // index inside a group of four pixels
+    lp = ((tid >> (cgs + 2)) << 2) | ((i >> 1) & 3);
+    c = (((i >> 3) << 1) | (i & 1)) * 4;
+  }
   for (int pass = 0; pass < cg; ++pass) {
     const int pl = pass * ppp + lp;
     const long pix = pix0 + pl;
@@ -222,15 +231,19 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
       o.z = fabsf(o.z - r.z) * valid;
       o.w = fabsf(o.w - r.w) * valid;
     }
-    st4(out + ((size_t)d * npix + pix) * (size_t)ld + c_off + c, o);
+    // plane_stride > 0: chunk-planar output [C/8][D][h][w][8] (the layout atvs_conv_xw_f32 reads with x_planar)
+    if (plane_stride > 0) st4(out + (size_t)(c >> 3) * (size_t)plane_stride + ((size_t)d * npix + pix) * 8 + (c & 7), o);
+    else st4(out + ((size_t)d * npix + pix) * (size_t)ld + c_off + c, o);
   }
 }
 
 extern "C" int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
                                 const float* depth_start, const float* depth_interval, float* out, float* mask_out,
-                                int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep,
+                                int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, int planar,
                                 atvs_stream_t stream) {
   if (!src || !homographies || !out) return ATVS_ERR_NULL;
+  if (planar && (mode != 0 || (C != 16 && C != 32 && C != 64) || ld_out != C || c_off != 0)) return ATVS_ERR_ARG;
+  const long plane_stride = planar ? (long)D * h * w * 8 : 0;
   if (D <= 0 || h <= 0 || w <= 0 || C <= 0 || ld_out < C || c_off < 0) return ATVS_ERR_SHAPE;
   if (mode == 1 && !ref) return ATVS_ERR_NULL;
   if (mode == 2 && (C != 1 || !depth_start || !depth_interval || rep < 1 || c_off + rep > ld_out)) return ATVS_ERR_SHAPE;
@@ -245,10 +258,10 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
     dim3 g2(cdiv((long)h * w, 256), D);
     if (mode == 0)
       hipLaunchKernelGGL((warp_planes_shared_kernel<0>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
-                         ld_out, c_off);
+                         ld_out, c_off, plane_stride);
     else
       hipLaunchKernelGGL((warp_planes_shared_kernel<1>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
-                         ld_out, c_off);
+                         ld_out, c_off, 0L);
     ATVS_LAUNCH_CHECK();
     return ATVS_OK;
   }

@@ -74,12 +74,22 @@ WARP_NEAREST = 3      # atvs_warp_planes mode: nearest-neighbour sampling (inclu
 
 
 def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=None, depth_start=None,
-                depth_interval=None, rep=1, want_mask=False):
-    """src (h,w,C), homographies (D,3,3) -> out (D,h,w,ld_out) [, mask (D,h,w)]."""
+                depth_interval=None, rep=1, want_mask=False, planar=False):
+    """src (h,w,C), homographies (D,3,3) -> out (D,h,w,ld_out) [, mask (D,h,w)].
+    planar=True (plain warp, C in {16,32,64}): out is chunk-planar (C/8, D, h, w, 8) -- the layout the Winograd x-pair
+    kernel reads as dense 32-byte voxels (SplitVolume(planar=True))."""
     h, w, C = src.shape
     D = homographies.shape[0]
     width = rep if mode == 2 else C
-    if out is None:
+    if planar:
+        if mode != 0 or C not in (16, 32, 64) or c_off != 0:
+            raise ValueError('warp_planes(planar=True): plain warp of 16 / 32 / 64 channels')
+        if out is None:
+            out = _new(src, (C // 8, D, h, w, 8))
+        elif tuple(out.shape) != (C // 8, D, h, w, 8) or not out.is_contiguous():
+            raise ValueError('warp_planes(planar=True): out must be a contiguous (C/8, D, h, w, 8) tensor')
+        ld_out = C
+    elif out is None:
         ld_out = width if ld_out is None else ld_out
         out = _new(src, (D, h, w, ld_out))
     else:
@@ -88,7 +98,7 @@ def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=N
     if _dev_ok(src, homographies, out, ref, depth_start, depth_interval):
         with _Timed(('warp', int(mode)), (D, h, w, C), width):
             _call('atvs_warp_planes', _p(src), _p(homographies), _p(ref), _p(depth_start), _p(depth_interval),
-                  _p(out), _p(mask), D, h, w, C, int(ld_out), int(c_off), int(mode), int(rep), _stream())
+                  _p(out), _p(mask), D, h, w, C, int(ld_out), int(c_off), int(mode), int(rep), int(bool(planar)), _stream())
     return (out, mask) if want_mask else out
 
 
@@ -314,6 +324,19 @@ def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y, xpair
 
 
 _USE_XW = True
+_USE_PLANAR = True
+
+
+def use_planar(flag):
+    """Testing / A-B hook: the chunk-planar warped half of the cost volume (dense halo rows for conv_xw.hip)."""
+    global _USE_PLANAR
+    _USE_PLANAR = bool(flag)
+
+
+def planar_cost_volume_ok(shape, F):
+    """Should build_cost_volumes write the warped half chunk-planar?  Only when its one consumer -- the x-pair launch of
+    conv_b0_0_1 | conv_b0_1_0 -- is the Winograd kernel."""
+    return (_USE_PLANAR and _USE_XW and F in (16, 32, 64) and siblings_ok(tuple(shape), F, 8, 16))
 
 
 def use_xw(flag):
@@ -590,12 +613,16 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
 
 
 def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None,
-                   prologue=None):
+                   prologue=None, planar=False):
     """One atvs_conv_xp_f32 launch: x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
     sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5.
     prologue = (x2 | None, params | None, params2 | None, relu, relu2): the input is formed on load as
     act(bn(x5)) [+ act(bn(x2))] (include/atvsnet_hip.h)."""
-    G, D, H, W, Cin = x5.shape
+    if planar:
+        G, K, D, H, W, _ = x5.shape
+        Cin = K * 8
+    else:
+        G, D, H, W, Cin = x5.shape
     ldy = y.shape[-1]
     null = ctypes.c_void_p(0)
     sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null     # noqa: E731
@@ -609,12 +636,18 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
     xw = bool(getattr(pk, 'xw', False))
     if pk2 is not None and bool(getattr(pk2, 'xw', False)) != xw:
         raise ValueError('conv_xp: the main and the sibling weights are packed for different kernels')
+    if planar and not xw:
+        raise ValueError('conv_xp: the chunk-planar input layout belongs to the Winograd kernel')
     if _dev_ok(x5, y, bias, plane_bias, y2, pb2, x2, ipa, ipb):
-        with _Timed(pk.key, x5.shape[1:], pk.cout + (16 if pk2 is not None else 0), G):
-            _call('atvs_conv_xw_f32' if xw else 'atvs_conv_xp_f32', _p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
-                  ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
-                  sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _p(x2), _p(ipa), _p(ipb),
-                  int(bool(relu_a)), int(bool(relu_b)), _stream())
+        with _Timed(pk.key, (D, H, W, Cin), pk.cout + (16 if pk2 is not None else 0), G):
+            args = [_p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
+                    ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
+                    sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _p(x2), _p(ipa), _p(ipb),
+                    int(bool(relu_a)), int(bool(relu_b))]
+            if xw:
+                _call('atvs_conv_xw_f32', *(args + [int(bool(planar)), _stream()]))
+            else:
+                _call('atvs_conv_xp_f32', *(args + [_stream()]))
 
 
 def xp_blocks(D, H, W, groups=1):
@@ -1080,17 +1113,42 @@ class SplitVolume(object):
     Stands for tf.concat([...tf.tile(x, [1,D,1,1,1])...], -1) of model.py:186-195, 329-336 without
     materialising the tiled parts.  var: (B,D,h,w,Cv); const: (B,h,w,Cc) (B = independent samples; a 4-D var /
     3-D const is one sample); chan_map: for each channel of the reference's concat, ('v', i) or ('c', i) --
-    several channels may map to the same source (the 16 identical geo-view channels, quirk C7)."""
+    several channels may map to the same source (the 16 identical geo-view channels, quirk C7).
+    planar=True: var is stored chunk-planar, (B, Cv/8, D, h, w, 8) (warp_planes(planar=True)): conv_split_siblings hands
+    it to the Winograd x-pair kernel as it is, every other consumer gets the channel-last copy var_cl() makes."""
 
-    def __init__(self, var, const, chan_map):
-        if var.dim() == 4:
+    def __init__(self, var, const, chan_map, planar=False):
+        self.planar = bool(planar)
+        if var.dim() == (5 if self.planar else 4):
             var, const = var.unsqueeze(0), const.unsqueeze(0)
-        self.var, self.const, self.chan_map = var, const, list(chan_map)
+        self._var, self.const, self.chan_map = var, const, list(chan_map)
+        self._cl = None
         self.device = var.device
 
     @property
+    def var(self):
+        """The D-varying part channel-last, (B,D,h,w,Cv)."""
+        return self.var_cl()
+
+    def var_cl(self):
+        if not self.planar:
+            return self._var
+        if self._cl is None:
+            B, K, D, h, w, _ = self._var.shape
+            self._cl = self._var.permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, K * 8).contiguous()
+        return self._cl
+
+    @property
+    def cv(self):
+        """Channels of the D-varying part."""
+        return self._var.shape[1] * 8 if self.planar else self._var.shape[-1]
+
+    @property
     def shape(self):
-        B, D, h, w, _ = self.var.shape
+        if self.planar:
+            B, _, D, h, w, _ = self._var.shape
+        else:
+            B, D, h, w, _ = self._var.shape
         return (B, D, h, w, len(self.chan_map))
 
     def dim(self):
@@ -1098,7 +1156,7 @@ class SplitVolume(object):
 
     @property
     def is_meta(self):
-        return self.var.is_meta
+        return self._var.is_meta
 
     def materialize(self):
         """The dense (B,D,h,w,C) tensor the reference would build."""
@@ -1143,8 +1201,8 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
     """3x3x3 SAME convolution of a SplitVolume (B samples): conv3d over the D-varying channels plus the 2-D
     convolution of the D-constant channels (kd-summed kernel) added per depth plane in the epilogue.
     -> (B,D,h,w,Cout) [, Stats]."""
-    B = sv.var.shape[0]
-    cv, cc = sv.var.shape[-1], sv.const.shape[-1]
+    B = sv.shape[0]
+    cv, cc = sv.cv, sv.const.shape[-1]
     wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
     pb = conv(sv.const, (key, 'planes'), planes, stride=stride, groups=B)            # (B, ho, wo, 3*Cout)
     return conv(sv.var, (key, 'var'), wv, stride=stride, want_stats=want_stats, plane_bias=pb, out=out, y_coff=y_coff,
@@ -1200,7 +1258,7 @@ def use_siblings(flag):
     _USE_SIBLINGS = bool(flag)
 
 
-def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None, groups=None):
+def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None, groups=None, planar=False):
     """The U-Net's two convolutions of one input in ONE launch: y = conv3x3x3(x, w) (8 channels, stride 1) and
     y2 = conv3x3x3(x, w2) (16 channels, stride 2, SAME), each with the partial moments of its output.
     x (D,H,W,Cin) (groups=G: (G,D,H,W,Cin)), Cin % 8 == 0.  Returns (y, Stats), (y2, Stats).
@@ -1211,8 +1269,14 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
         if not siblings_prologue_ok(x):
             raise ValueError('conv_siblings: this lazy input must be materialised first')
         x, prologue = x.prologue()
-    x5, nsp = _to5(x, groups, 'conv_siblings input')
-    G, D, H, W, cin = x5.shape
+    if planar:             # x: (G, Cin/8, D, H, W, 8), chunk-planar (SplitVolume(planar=True)); Winograd x-pair kernel only
+        if prologue is not None or not _USE_XW or groups is None or x.dim() != 6 or not x.is_contiguous():
+            raise ValueError('conv_siblings(planar=True): a contiguous (G, Cin/8, D, H, W, 8) tensor, no prologue')
+        G, K, D, H, W, _ = x.shape
+        x5, nsp, cin = x, 3, K * 8
+    else:
+        x5, nsp = _to5(x, groups, 'conv_siblings input')
+        G, D, H, W, cin = x5.shape
     if nsp != 3 or not siblings_ok((D, H, W), cin, int(w_host.shape[-1]), int(w2_host.shape[-1])):
         raise ValueError('conv_siblings: unsupported shapes')
     pk = pack_conv_xp(key, w_host, x.device)
@@ -1234,18 +1298,21 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
     if prologue is not None and prologue[0] is not None:
         prologue = (_to5(prologue[0], groups, 'conv_siblings second source')[0],) + tuple(prologue[1:])
     conv_xp_launch(x5, pk, y, 0, None, False, sbuf, plane_bias, sibling=(pk2, y2, 0, sbuf2, plane_bias2),
-                   prologue=prologue)
+                   prologue=prologue, planar=planar)
     return (y, st), (y2, st2)
 
 
 def conv_split_siblings(sv, key, w_host, key2, w2_host):
     """conv_siblings over a SplitVolume (B samples): the D-constant channels enter both outputs as depth-plane biases."""
-    B = sv.var.shape[0]
-    cv, cc = sv.var.shape[-1], sv.const.shape[-1]
+    B = sv.shape[0]
+    cv, cc = sv.cv, sv.const.shape[-1]
     wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
     wv2, planes2 = _fold_split_weights(key2, w2_host, sv.chan_map, cv, cc)
     pb = conv(sv.const, (key, 'planes'), planes, stride=1, groups=B)
     pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2, groups=B)
+    if sv.planar and _USE_XW:
+        return conv_siblings(sv._var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B,
+                             planar=True)
     return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B)
 
 

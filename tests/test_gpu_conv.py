@@ -4,6 +4,8 @@ Floating point: fp32 MFMA products are exact fp32 FMAs, only the summation order
 differs from the oracle's (oneDNN) -> tolerance 2e-5 * max|ref| (stated per test).
 """
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -332,6 +334,48 @@ def test_conv_siblings_one_launch(cuda, xkernel, D, H, W, Cin):
     (y, _), (y2, _) = ops.conv_siblings(x[0].to(cuda), ('sib', D, H, W, Cin), w.numpy(), ('sib2', D, H, W, Cin), w2.numpy())
     _close(y2.cpu(), T.conv(x, w2, 2, 'SAME')[0])
     _close(y.cpu(), T.conv(x, w, 1, 'SAME')[0])
+
+
+@pytest.mark.parametrize('B,D,h,w', [(1, 6, 16, 40), (2, 9, 19, 70)])
+def test_planar_cost_volume_is_bitwise_the_channel_last_one(cuda, B, D, h, w):
+    """The warped half of the cost volume written chunk-planar (F/8, D, h, w, 8) (atvs_warp_planes planar) and read by the
+    Winograd x-pair launch (atvs_conv_xw_f32 x_planar): same values as the channel-last pair, bit for bit -- the warp,
+    both convolutions, their statistics -- and the SplitVolume still materialises the reference's dense concat."""
+    from atvsnet_amd import ops
+    from oracle import homography_warping as G
+    from oracle import model as OM
+    ops.clear_pack_cache()
+    F = 32
+    cams = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'example2_0_cam.npy')))[None, None]
+    cam2 = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'example2_1_cam.npy')))[None, None]
+    cams = torch.cat([cams, cam2], 1).float()
+    ds, di = OM.depth_start_interval(cams)
+    Hm = G.get_homographies(cams[:, 0], cams[:, 1], D, ds, di)[0].to(cuda)
+    feats = _rand((B, h, w, F), 90).to(cuda)
+    const = _rand((B, h, w, F), 91).to(cuda)
+    cl = torch.stack([ops.warp_planes(feats[b], Hm) for b in range(B)])
+    pl = torch.stack([ops.warp_planes(feats[b], Hm, planar=True) for b in range(B)])
+    assert tuple(pl.shape) == (B, F // 8, D, h, w, 8)
+    assert torch.equal(pl.permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, F), cl)
+    cmap = [('c', i) for i in range(F)] + [('v', i) for i in range(F)]
+    sv_cl, sv_pl = ops.SplitVolume(cl, const, cmap), ops.SplitVolume(pl, const, cmap, planar=True)
+    assert sv_pl.shape == sv_cl.shape and sv_pl.cv == F
+    w8, w16 = (_rand((3, 3, 3, 2 * F, 8), 92) * 0.1).numpy(), (_rand((3, 3, 3, 2 * F, 16), 93) * 0.1).numpy()
+    (y, st), (y2, st2) = ops.conv_split_siblings(sv_pl, 'pl8', w8, 'pl16', w16)
+    (r, rt), (r2, rt2) = ops.conv_split_siblings(sv_cl, 'pl8', w8, 'pl16', w16)
+    assert torch.equal(y, r) and torch.equal(y2, r2)
+    assert torch.equal(st.partial, rt.partial) and torch.equal(st2.partial, rt2.partial)
+    assert torch.equal(sv_pl.materialize(), sv_cl.materialize())
+    # a consumer without the planar form (the direct x-pair kernel) gets the channel-last copy
+    ops.use_xw(False)
+    ops.clear_pack_cache()
+    try:
+        (z, _), (z2, _) = ops.conv_split_siblings(sv_pl, 'pl8', w8, 'pl16', w16)
+        (q, _), (q2, _) = ops.conv_split_siblings(sv_cl, 'pl8', w8, 'pl16', w16)
+        assert torch.equal(z, q) and torch.equal(z2, q2)
+    finally:
+        ops.use_xw(True)
+        ops.clear_pack_cache()
 
 
 def test_conv_split_siblings_match_dense(cuda):
