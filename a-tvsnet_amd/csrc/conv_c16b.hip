@@ -1,0 +1,364 @@
+// EXPERIMENTAL (off by default, ops.use_bf16x3): the 16 -> 16 channel 3x3x3 convolution of conv_c16.hip on the bf16 matrix
+// cores with SPLIT operands -- BASELINE.json configs[1] names "bf16 conv3d MFMA"; plain bf16 operands miss the 1e-3 depth
+// bar by a factor 200, so every fp32 operand is split into three bf16 pieces
+//     x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)        (24 mantissa bits kept)
+// and the six products x_i * w_j with i + j <= 2 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (a product of two
+// bf16 values is exact in fp32; dropped terms ~2^-24): fp32-class results (tools_dev/bf16_split_emulation.py: final depth
+// 1.2e-5 from the fp32 oracle at configs[0], 4.5e-4 from the float64 networks at configs[1] against the fp32 oracle's
+// 4.3e-4) for 6/16 of the fp32 MFMA time: one K = 32 instruction (16 cycles) covers two taps x 16 channels, which takes
+// eight 16x16x4 fp32 instructions (256 cycles); six of them = 96 cycles.
+//
+// Structure = conv_c16.hip's 8-channel form (32-byte voxels, two taps per K step, lane half q >> 1 picks the tap): here a
+// voxel of one PIECE image is 16 channels x 2 bytes = 32 bytes, the three piece images lie IMG bytes apart, the split is
+// done once per staged element on its way into LDS, the packed weights (three pieces per K step, split on the host) are
+// resident in LDS.  Cin = Cout = 16 only (conv_b*_1_1, global_refine_3dconv1_1).
+#include <cstring>
+#include <type_traits>
+#include <utility>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int B16_TZ = 4, B16_TY = 8, B16_TX = 16;
+constexpr int B16_HZ = B16_TZ + 2, B16_HY = B16_TY + 2, B16_HX = B16_TX + 2;
+constexpr int B16_VB = 32;                                    // bytes per voxel of one piece image
+constexpr int B16_ROWB = B16_HX * B16_VB;                     // 576
+constexpr int B16_IMG = B16_HZ * B16_HY * B16_ROWB;           // 34,560 bytes per piece
+constexpr int B16_SLOTS = B16_HZ * B16_HY * B16_HX * 4;       // float4 slots of the fp32 halo (16 channels per voxel)
+constexpr int B16_MAXS = (B16_SLOTS + 255) / 256;             // 17 per thread
+constexpr int B16_JC = 14;                                    // K steps: taps 2 j + (q >> 1), tap 27 = zero weights
+constexpr int B16_WSTEP = 3 * 1024;                           // bytes of packed weights per K step (3 pieces x 64 lanes x 16 B)
+static_assert(B16_MAXS <= 3 * B16_JC, "one halo slot per phase of the K loop");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct B16Args {
+  const float* x;
+  const unsigned char* wp;     // packed bf16 pieces (atvs_conv_c16b_pack)
+  const float* zeros;          // 16 zero bytes
+  const float* bias;
+  float* y;
+  double* stats;
+  int Di, Hi, Wi;
+  int ldy, ycoff;
+  int tiles_y, tiles_x, ntiles;
+  int wg;
+  long gx, gy;
+};
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+template <class F, int... I>
+__device__ __forceinline__ void b16_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void b16_static_for(F&& f) {
+  b16_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// byte displacement of tap t from halo voxel (wave, 0, r): (kd, kh) rows + kw voxels
+__device__ __host__ constexpr int b16_disp(int t) { return ((t / 9) * B16_HY + (t / 3) % 3) * B16_ROWB + (t % 3) * B16_VB; }
+
+// the three bf16 pieces of four fp32 values
+__device__ __forceinline__ void b16_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    (*p0)[i] = a;
+    (*p1)[i] = b;
+    (*p2)[i] = (__bf16)r2;
+  }
+}
+
+template <bool RELU>
+__global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
+  constexpr int TY = B16_TY, HY = B16_HY, MAXS = B16_MAXS, JC = B16_JC;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+
+  // packed weights -> LDS, once
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wp);
+    float4* dst = reinterpret_cast<float4*>(smem + 3 * B16_IMG);
+    for (int i = tid; i < JC * (B16_WSTEP / 16); i += 256) dst[i] = src[i];
+  }
+  // this lane's B fragment (8 consecutive channels (q & 1) * 8 .. of a voxel) at halo voxel (wave, 0, r), tap (0,0,0)
+  const int fbase = ((wave * HY) * B16_HX + r) * B16_VB + (q & 1) * 16;
+  const int wbase = 3 * B16_IMG + lane * 16;
+
+  // halo slots: float4 = channels 4 c4 .. of a voxel -> 8 bytes at (voxel, c4) of each piece image
+  int goff[MAXS], laddr[MAXS];
+  unsigned pg[MAXS];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < B16_SLOTS;
+    s = min(s, B16_SLOTS - 1);
+    const int c4 = s & 3, v = s >> 2;
+    const int xx = v % B16_HX, v2 = v / B16_HX;
+    const int yy = v2 % HY, zz = v2 / HY;
+    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * 16 + c4 * 4;
+    laddr[i] = ((zz * HY + yy) * B16_HX + xx) * B16_VB + c4 * 8;
+    pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+  }
+
+  const int G = p.wg;
+  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
+  const int xcd = lbk & 7, tslot = lbk >> 3;
+  const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
+  float* __restrict__ yg = p.y + (size_t)grp * p.gy;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int slots_per_xcd = G >> 3;
+  int my_tiles = 0;
+  {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);
+    if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
+  }
+  auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
+    int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
+    int bx = tl % p.tiles_x;
+    int rest = tl / p.tiles_x;
+    *x0 = bx * B16_TX;
+    *y0 = (rest % p.tiles_y) * TY;
+    *z0 = (rest / p.tiles_y) * B16_TZ;
+  };
+  struct PfTile {
+    int org;
+    unsigned lo, hi1;
+  };
+  auto pf_tile = [&](int k) __attribute__((always_inline)) {
+    PfTile T;
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * 16;
+    T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+    T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+            ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+    return T;
+  };
+  float4 pf[MAXS];
+  auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
+    const unsigned t1 = pg[i] - T.lo;
+    const unsigned t2 = T.hi1 + ~pg[i];
+    const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
+    pf[i] = ld4(ok ? (xg + (T.org + goff[i])) : p.zeros);
+  };
+
+  f32x2 ssum2[2], ssq2[2];
+  ssum2[0] = ssum2[1] = ssq2[0] = ssq2[1] = (f32x2){0.f, 0.f};
+  f32x4 acc[TY];
+  const float4 bv = p.bias ? ld4(p.bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const unsigned ybytes = (unsigned)(p.gy * 4);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
+
+  if (my_tiles > 0) {
+    const PfTile T0 = pf_tile(0);
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+  }
+
+  for (int k = 0; k < my_tiles; ++k) {
+#pragma unroll
+    for (int t = 0; t < TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();                       // every wavefront is done reading the previous tile's images
+    // split the staged fp32 halo into its three bf16 pieces on the way into LDS
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      if (i < MAXS - 1 || tid + i * 256 < B16_SLOTS) {
+        bf16x4 p0, p1, p2;
+        b16_split(pf[i], &p0, &p1, &p2);
+        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<bf16x4*>(smem + B16_IMG + laddr[i]) = p1;
+        *reinterpret_cast<bf16x4*>(smem + 2 * B16_IMG + laddr[i]) = p2;
+      }
+    }
+    __syncthreads();
+
+    const PfTile T = pf_tile(min(k + 1, my_tiles - 1));      // last tile: harmless re-read of its own halo
+
+    // ---- K loop: 14 steps of two taps x 16 channels, each in three phases -- input piece i = 0, 1, 2 with the weight
+    // pieces j <= 2 - i (24 / 16 / 8 MFMAs): the fragments of ONE input piece are live at a time (the next phase's are
+    // requested in front of this phase's MFMAs), the three weight pieces of a step are requested one step ahead
+    bf16x8 Bq[2][TY], A[2][3];
+    auto request_B = [&](auto PH) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
+      constexpr int t0 = 2 * j, t1 = (2 * j + 1 < 27) ? 2 * j + 1 : 26;
+      const int a = fbase + ((q >> 1) ? b16_disp(t1) : b16_disp(t0));
+#pragma unroll
+      for (int t = 0; t < TY; ++t)
+        Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
+    };
+    auto request_A = [&](auto JT) __attribute__((always_inline)) {
+      constexpr int j = decltype(JT)::value;
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) A[j & 1][pc] = *reinterpret_cast<const bf16x8*>(smem + wbase + j * B16_WSTEP + pc * 1024);
+    };
+    request_A(IC<0>{});
+    request_B(IC<0>{});
+    asm volatile("" ::: "memory");
+    b16_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
+      if constexpr (ph + 1 < 3 * JC) request_B(IC<ph + 1>{});
+      if constexpr (pc == 0 && j + 1 < JC) request_A(IC<j + 1>{});
+      if constexpr (ph < MAXS) pf_slot(T, ph);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jw = 0; jw <= 2 - pc; ++jw)
+#pragma unroll
+        for (int t = 0; t < TY; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][jw], Bq[ph & 1][t], acc[t], 0, 0, 0);
+    });
+
+    // ---- epilogue (conv_c16.hip): this lane holds channels 4q..4q+3 of voxel (z0 + wave, y0 + t, x0 + r)
+    int tz0, ty0, tx0;
+    tile_origin(k, &tz0, &ty0, &tx0);
+    const int zo = tz0 + wave, xo = tx0 + r;
+    const bool evox_ok = zo < p.Di && xo < p.Wi;
+    const unsigned erow = (unsigned)p.Wi * p.ldy;
+    const unsigned eo = (((unsigned)zo * p.Hi + ty0) * p.Wi + xo) * p.ldy + p.ycoff + q * 4;
+    const unsigned vo_ok = evox_ok ? eo * 4u : ybytes;
+    b16_static_for<TY>([&](auto TT) __attribute__((always_inline)) {
+      constexpr int t = decltype(TT)::value;
+      const bool row_ok = ty0 + t < p.Hi;
+      const bool ok = evox_ok && row_ok;
+      float a0 = acc[t][0] + bv.x, a1 = acc[t][1] + bv.y, a2 = acc[t][2] + bv.z, a3 = acc[t][3] + bv.w;
+      if (RELU) {
+        a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
+        a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
+      }
+      const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                          __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
+      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, (t * erow) * 4u, 0);
+      f32x2 lo = {ok ? a0 : 0.f, ok ? a1 : 0.f}, hi = {ok ? a2 : 0.f, ok ? a3 : 0.f};
+      ssum2[0] += lo;
+      ssum2[1] += hi;
+      ssq2[0] = __builtin_elementwise_fma(lo, lo, ssq2[0]);
+      ssq2[1] = __builtin_elementwise_fma(hi, hi, ssq2[1]);
+    });
+  }
+
+  if (p.stats) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a = (double)ssum2[kk >> 1][kk & 1], bq = (double)ssq2[kk >> 1][kk & 1];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        bq += __shfl_xor(bq, o);
+      }
+      if (r == 0) {
+        s_red[(wave * 2 + 0) * 16 + q * 4 + kk] = a;
+        s_red[(wave * 2 + 1) * 16 + q * 4 + kk] = bq;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid / 16, col = tid % 16;
+      p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] =
+          (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
+          (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
+    }
+  }
+}
+
+// round-to-nearest-even bf16 of a finite float, as a float
+static float b16_round(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  float o;
+  std::memcpy(&o, &u, 4);
+  return o;
+}
+static uint16_t b16_bits(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+// Bytes of the packed form of a TF kernel [3,3,3,16,16] for atvs_conv_c16b_f32 (+ 16 trailing zero bytes).
+extern "C" int atvs_conv_c16b_pack_size(long* packed_bytes) {
+  if (!packed_bytes) return ATVS_ERR_NULL;
+  *packed_bytes = (long)B16_JC * B16_WSTEP + 16;
+  return ATVS_OK;
+}
+
+// HOST function.  packed[step j][piece][lane = q*16 + co][8 bf16] = piece of w[tap = 2 j + (q >> 1)][ci = (q & 1)*8 + e][co]
+// (zero for tap 27), pieces w0 = bf16(w), w1 = bf16(w - w0), w2 = bf16(w - w0 - w1), round to nearest even.
+extern "C" int atvs_conv_c16b_pack(const float* w, unsigned char* packed) {
+  if (!w || !packed) return ATVS_ERR_NULL;
+  long pb;
+  atvs_conv_c16b_pack_size(&pb);
+  std::memset(packed, 0, (size_t)pb);
+  uint16_t* out = reinterpret_cast<uint16_t*>(packed);
+  for (int j = 0; j < B16_JC; ++j)
+    for (int q = 0; q < 4; ++q) {
+      const int tap = 2 * j + (q >> 1);
+      if (tap > 26) continue;
+      for (int co = 0; co < 16; ++co)
+        for (int e = 0; e < 8; ++e) {
+          const int ci = (q & 1) * 8 + e;
+          const float v = w[((size_t)tap * 16 + ci) * 16 + co];
+          const float p0 = b16_round(v), p1 = b16_round(v - p0), p2 = b16_round((v - p0) - p1);
+          const float pc[3] = {p0, p1, p2};
+          for (int k = 0; k < 3; ++k)
+            out[(((size_t)j * 3 + k) * 64 + q * 16 + co) * 8 + e] = b16_bits(pc[k]);
+        }
+    }
+  return ATVS_OK;
+}
+
+// y (G,D,H,W,ldy)[..., y_coff : y_coff + 16] = conv3d(x (G,D,H,W,16), w [3,3,3,16,16], stride 1, SAME) (+ bias, ReLU) with
+// split-bf16 operands (fp32-class results; rounding differs from atvs_conv_c16_f32).  Grid / statistics rows =
+// atvs_conv_c16_grid.
+extern "C" int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
+                                  double* stats_partial, int groups, int D, int H, int W, int ldy, int y_coff, int relu,
+                                  atvs_stream_t stream) {
+  if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + 16 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if ((double)D * H * W * 16 >= 2147483648.0 || (double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;
+  B16Args a;
+  long pb;
+  atvs_conv_c16b_pack_size(&pb);
+  a.x = x; a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  a.bias = bias; a.y = y; a.stats = stats_partial;
+  a.Di = D; a.Hi = H; a.Wi = W; a.ldy = ldy; a.ycoff = y_coff;
+  a.tiles_y = (H + B16_TY - 1) / B16_TY; a.tiles_x = (W + B16_TX - 1) / B16_TX;
+  a.ntiles = ((D + B16_TZ - 1) / B16_TZ) * a.tiles_y * a.tiles_x;
+  const long blocks = atvs_conv_c16_grid(D, H, W, groups);
+  a.wg = (int)blocks;
+  a.gx = (long)D * H * W * 16; a.gy = (long)D * H * W * ldy;
+  const long grid = blocks * groups;
+  if (grid > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  const size_t lds = 3 * (size_t)B16_IMG + (size_t)B16_JC * B16_WSTEP;
+  static bool attr_set[64][2] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  const void* fn = relu ? reinterpret_cast<const void*>(conv_c16b_kernel<true>) : reinterpret_cast<const void*>(conv_c16b_kernel<false>);
+  if (!attr_set[dev][relu ? 1 : 0]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ATVS_ERR_LAUNCH;
+    attr_set[dev][relu ? 1 : 0] = true;
+  }
+  if (relu) hipLaunchKernelGGL(conv_c16b_kernel<true>, dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
+  else hipLaunchKernelGGL(conv_c16b_kernel<false>, dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

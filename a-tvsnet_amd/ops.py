@@ -8,6 +8,7 @@ planning and CPU plumbing tests).  CPU tensors are refused: there is no CPU
 fallback on the product path.
 """
 import ctypes
+import os
 
 import torch
 
@@ -424,6 +425,41 @@ def pack_conv_c16(key, w_host, device):
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, cout // 16, cin, cout
     pk.key = key
     pk.tab = None
+    pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
+_USE_BF16X3 = os.environ.get('ATVS_BF16X3', '0') == '1'      # experiment switch for whole-pipeline runs
+
+
+def use_bf16x3(flag):
+    """EXPERIMENTAL (default off): the 16 -> 16 channel 3x3x3 convolutions on the bf16 matrix cores with split operands
+    (x = x0 + x1 + x2, six products, fp32 accumulation: conv_c16b.hip) instead of fp32 MFMA."""
+    global _USE_BF16X3
+    _USE_BF16X3 = bool(flag)
+
+
+def pack_conv_c16b(key, w_host, device):
+    """Packed bf16 pieces of a [3,3,3,16,16] kernel for atvs_conv_c16b_f32; cached."""
+    import numpy as np
+    ck = ('c16b', key, str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)
+    L = _lib.lib()
+    pb = ctypes.c_long()
+    rc = L.atvs_conv_c16b_pack_size(ctypes.byref(pb))
+    if rc:
+        raise RuntimeError('atvs_conv_c16b_pack_size failed (%d)' % rc)
+    packed = np.empty(pb.value, np.uint8)
+    rc = L.atvs_conv_c16b_pack(w.ctypes.data_as(ctypes.c_void_p), packed.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv_c16b_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, 16, 16
+    pk.key, pk.tab, pk.xw = key, None, False
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
     _pack_cache[ck] = pk
     return pk
@@ -1030,7 +1066,8 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
             and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
-        pk = pack_conv_c16(key, w_host, x.device)
+        b16 = _USE_BF16X3 and cin == 16 and cout == 16
+        pk = pack_conv_c16b(key, w_host, x.device) if b16 else pack_conv_c16(key, w_host, x.device)
         if y5 is None:
             y5 = _new(x, (G,) + tuple(outs) + (cout,))
         st, sbuf = None, None
@@ -1041,8 +1078,12 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, cout, M, G
         if _dev_ok(x5, y5, bias):
             with _Timed(key, x5.shape[1:], cout, G):
-                _call('atvs_conv_c16_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
-                      cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                if b16:
+                    _call('atvs_conv_c16b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2],
+                          int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                else:
+                    _call('atvs_conv_c16_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
+                          cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 

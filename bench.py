@@ -81,6 +81,7 @@ def parse(argv=None):
     p.add_argument('--views', type=int, default=None)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
+    p.add_argument('--no-split-bf16', action='store_true', help='skip the secondary measurement with the split-bf16 16 -> 16 layers')
     p.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
     p.add_argument('--inflight', type=int, default=2,
                    help='depth maps in flight per GPU (streams with one captured graph each); 1 = strictly one after the other')
@@ -539,6 +540,32 @@ def rank_main(args):
         dt = float(t.item())
     out = out.clone()
 
+    # secondary: the same step with the EXPERIMENTAL split-bf16 form of the 16 -> 16 channel 3x3x3 layers (conv_c16b.hip: three
+    # bf16 pieces per operand, six products, fp32 accumulation; BASELINE configs[1] names "bf16 conv3d MFMA").  `value` stays
+    # the all-fp32-MFMA path; this is reported next to it with its own parity.
+    split = None
+    if world == 1 and graphed is not None and not args.no_split_bf16:
+        try:
+            ops.use_bf16x3(True)
+            g2 = ex.GraphedInference(imgs, cams, args.depths)
+            for _ in range(args.warmup):
+                g2()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            for _ in range(args.steps):
+                o2 = g2()
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t2
+            split = {'layers': '3x3x3 16 -> 16 channels (conv_b*_1_1, global_refine_3dconv1_1) on v_mfma_f32_16x16x32_bf16: '
+                               'x = x0 + x1 + x2, w = w0 + w1 + w2 in bf16, the 6 products with i + j <= 2, fp32 accumulation',
+                     'default': False, 'ms_per_step': round(1e3 * dt2 / args.steps, 3), 'value': round(args.steps / dt2, 4),
+                     'unit': 'depth-maps/sec', 'parity': None if args.no_parity else parity_check(args, o2.clone(), None)}
+            del g2
+        except Exception as e:
+            split = {'error': repr(e)}
+        finally:
+            ops.use_bf16x3(False)
+
     # the dominant kernel and the warp, timed by HIP events on their launch stream in two eager single-stream passes
     # of the same step right after the timed region (kernels inside a replayed graph cannot be bracketed by events;
     # single stream: no other kernel shares the GPU with the one being timed)
@@ -632,6 +659,7 @@ def rank_main(args):
             'source_views_per_sec': round(n_groups * args.steps * (args.views - 1) / dt, 3),
             'latency_ms': round(1e3 * dt / args.steps, 3),
             'pipelined': pipelined,
+            'split_bf16': split,
             'roofline': roof, 'roofline_hbm': roof_hbm, 'kernels': top_kernels(),
         }
         if comm is not None:
