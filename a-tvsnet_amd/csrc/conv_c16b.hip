@@ -1,4 +1,4 @@
-// EXPERIMENTAL (off by default, ops.use_bf16x3): the 16 -> 16 channel 3x3x3 convolution of conv_c16.hip on the bf16 matrix
+// The 8 / 16 -> 16 channel 3x3x3 convolutions of conv_c16.hip on the bf16 matrix
 // cores with SPLIT operands -- BASELINE.json configs[1] names "bf16 conv3d MFMA"; plain bf16 operands miss the 1e-3 depth
 // bar by a factor 200, so every fp32 operand is split into three bf16 pieces
 //     x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)        (24 mantissa bits kept)
@@ -11,7 +11,8 @@
 // Structure = conv_c16.hip's 8-channel form (32-byte voxels, two taps per K step, lane half q >> 1 picks the tap): here a
 // voxel of one PIECE image is 16 channels x 2 bytes = 32 bytes, the three piece images lie IMG bytes apart, the split is
 // done once per staged element on its way into LDS, the packed weights (three pieces per K step, split on the host) are
-// resident in LDS.  Cin = Cout = 16 only (conv_b*_1_1, global_refine_3dconv1_1).
+// resident in LDS.  Cout = 16, Cin = 16 (conv_b*_1_1, global_refine_3dconv1_1: two taps per K step) or Cin = 8 (the AANet
+// modules' shared | unique convolution: four taps per K step, 16-byte voxels).
 #include <cstring>
 #include <type_traits>
 #include <utility>
@@ -22,14 +23,27 @@ namespace {
 
 constexpr int B16_TZ = 4, B16_TY = 8, B16_TX = 16;
 constexpr int B16_HZ = B16_TZ + 2, B16_HY = B16_TY + 2, B16_HX = B16_TX + 2;
-constexpr int B16_VB = 32;                                    // bytes per voxel of one piece image
-constexpr int B16_ROWB = B16_HX * B16_VB;                     // 576
-constexpr int B16_IMG = B16_HZ * B16_HY * B16_ROWB;           // 34,560 bytes per piece
-constexpr int B16_SLOTS = B16_HZ * B16_HY * B16_HX * 4;       // float4 slots of the fp32 halo (16 channels per voxel)
-constexpr int B16_MAXS = (B16_SLOTS + 255) / 256;             // 17 per thread
-constexpr int B16_JC = 14;                                    // K steps: taps 2 j + (q >> 1), tap 27 = zero weights
+
+// CIN input channels (8 or 16): a K = 32 instruction covers TPS = 32 / CIN taps; lane group q carries tap TPS*j + q / (4/TPS)
+// and channels 8 * (q % (4/TPS)) .. + 7 of it.
+template <int CIN>
+struct B16 {
+  static_assert(CIN == 8 || CIN == 16, "8 or 16 input channels");
+  static constexpr int TPS = 32 / CIN;                          // taps per K step: 4 / 2
+  static constexpr int LPT = 4 / TPS;                           // lane groups per tap: 1 / 2
+  static constexpr int VB = CIN * 2;                            // bytes per voxel of one piece image: 16 / 32
+  static constexpr int ROWB = B16_HX * VB;
+  static constexpr int IMG = B16_HZ * B16_HY * ROWB;            // 17,280 / 34,560 bytes per piece
+  static constexpr int C4 = CIN / 4;                            // float4 slots per voxel of the fp32 halo
+  static constexpr int SLOTS = B16_HZ * B16_HY * B16_HX * C4;
+  static constexpr int MAXS = (SLOTS + 255) / 256;              // 9 / 17 per thread
+  static constexpr int JC = (27 + TPS - 1) / TPS;               // K steps: 7 / 14 (taps past 26 = zero weights)
+  static_assert(MAXS <= 3 * JC, "one halo slot per phase of the K loop");
+  // byte displacement of tap t from halo voxel (wave, 0, r): (kd, kh) rows + kw voxels
+  static constexpr int clamp26(int t) { return t < 26 ? t : 26; }
+  static constexpr int disp(int t) { return ((t / 9) * B16_HY + (t / 3) % 3) * ROWB + (t % 3) * VB; }
+};
 constexpr int B16_WSTEP = 3 * 1024;                           // bytes of packed weights per K step (3 pieces x 64 lanes x 16 B)
-static_assert(B16_MAXS <= 3 * B16_JC, "one halo slot per phase of the K loop");
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -61,9 +75,6 @@ __device__ __forceinline__ void b16_static_for(F&& f) {
   b16_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// byte displacement of tap t from halo voxel (wave, 0, r): (kd, kh) rows + kw voxels
-__device__ __host__ constexpr int b16_disp(int t) { return ((t / 9) * B16_HY + (t / 3) % 3) * B16_ROWB + (t % 3) * B16_VB; }
-
 // the three bf16 pieces of four fp32 values
 __device__ __forceinline__ void b16_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
   const float x[4] = {v.x, v.y, v.z, v.w};
@@ -79,9 +90,11 @@ __device__ __forceinline__ void b16_split(const float4& v, bf16x4* p0, bf16x4* p
   }
 }
 
-template <bool RELU>
+template <int CIN, bool RELU>
 __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
-  constexpr int TY = B16_TY, HY = B16_HY, MAXS = B16_MAXS, JC = B16_JC;
+  using K = B16<CIN>;
+  constexpr int TY = B16_TY, HY = B16_HY, MAXS = K::MAXS, JC = K::JC;
+  constexpr int B16_IMG = K::IMG, B16_VB = K::VB, B16_ROWB = K::ROWB, B16_SLOTS = K::SLOTS;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -93,8 +106,8 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     float4* dst = reinterpret_cast<float4*>(smem + 3 * B16_IMG);
     for (int i = tid; i < JC * (B16_WSTEP / 16); i += 256) dst[i] = src[i];
   }
-  // this lane's B fragment (8 consecutive channels (q & 1) * 8 .. of a voxel) at halo voxel (wave, 0, r), tap (0,0,0)
-  const int fbase = ((wave * HY) * B16_HX + r) * B16_VB + (q & 1) * 16;
+  // this lane's B fragment (8 consecutive channels of a voxel) at halo voxel (wave, 0, r), tap (0,0,0)
+  const int fbase = ((wave * HY) * B16_HX + r) * B16_VB + (q % K::LPT) * 16;
   const int wbase = 3 * B16_IMG + lane * 16;
 
   // halo slots: float4 = channels 4 c4 .. of a voxel -> 8 bytes at (voxel, c4) of each piece image
@@ -105,10 +118,10 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     int s = tid + i * 256;
     const bool live = s < B16_SLOTS;
     s = min(s, B16_SLOTS - 1);
-    const int c4 = s & 3, v = s >> 2;
+    const int c4 = s % K::C4, v = s / K::C4;
     const int xx = v % B16_HX, v2 = v / B16_HX;
     const int yy = v2 % HY, zz = v2 / HY;
-    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * 16 + c4 * 4;
+    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * CIN + c4 * 4;
     laddr[i] = ((zz * HY + yy) * B16_HX + xx) * B16_VB + c4 * 8;
     pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
   }
@@ -142,7 +155,7 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     int z0, y0, x0;
     tile_origin(k, &z0, &y0, &x0);
     const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
-    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * 16;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * CIN;
     T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
     T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
             ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
@@ -194,8 +207,11 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     bf16x8 Bq[2][TY], A[2][3];
     auto request_B = [&](auto PH) __attribute__((always_inline)) {
       constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
-      constexpr int t0 = 2 * j, t1 = (2 * j + 1 < 27) ? 2 * j + 1 : 26;
-      const int a = fbase + ((q >> 1) ? b16_disp(t1) : b16_disp(t0));
+      // this lane group's tap of the step (taps past 26 have zero weights: re-read tap 26's fragment)
+      constexpr int tA = K::clamp26(K::TPS * j), tB = K::clamp26(K::TPS * j + 1), tC = K::clamp26(K::TPS * j + 2), tD = K::clamp26(K::TPS * j + 3);
+      int a;
+      if constexpr (K::TPS == 2) a = fbase + ((q >> 1) ? K::disp(tB) : K::disp(tA));
+      else a = fbase + ((q & 2) ? ((q & 1) ? K::disp(tD) : K::disp(tC)) : ((q & 1) ? K::disp(tB) : K::disp(tA)));
 #pragma unroll
       for (int t = 0; t < TY; ++t)
         Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
@@ -293,29 +309,33 @@ static uint16_t b16_bits(float v) {
 
 }  // namespace
 
-// Bytes of the packed form of a TF kernel [3,3,3,16,16] for atvs_conv_c16b_f32 (+ 16 trailing zero bytes).
-extern "C" int atvs_conv_c16b_pack_size(long* packed_bytes) {
+// Bytes of the packed form of a TF kernel [3,3,3,Cin,16] (Cin 8 or 16) for atvs_conv_c16b_f32 (+ 16 trailing zero bytes).
+extern "C" int atvs_conv_c16b_pack_size(int Cin, long* packed_bytes) {
   if (!packed_bytes) return ATVS_ERR_NULL;
-  *packed_bytes = (long)B16_JC * B16_WSTEP + 16;
+  if (Cin != 8 && Cin != 16) return ATVS_ERR_SHAPE;
+  *packed_bytes = (long)(Cin == 8 ? B16<8>::JC : B16<16>::JC) * B16_WSTEP + 16;
   return ATVS_OK;
 }
 
-// HOST function.  packed[step j][piece][lane = q*16 + co][8 bf16] = piece of w[tap = 2 j + (q >> 1)][ci = (q & 1)*8 + e][co]
-// (zero for tap 27), pieces w0 = bf16(w), w1 = bf16(w - w0), w2 = bf16(w - w0 - w1), round to nearest even.
-extern "C" int atvs_conv_c16b_pack(const float* w, unsigned char* packed) {
+// HOST function.  packed[step j][piece][lane = q*16 + co][8 bf16] = piece of w[tap = TPS*j + q / LPT][ci = (q % LPT)*8 + e][co]
+// (TPS = 32 / Cin taps per step, LPT = 4 / TPS lane groups per tap; zero for taps past 26), pieces w0 = bf16(w),
+// w1 = bf16(w - w0), w2 = bf16(w - w0 - w1), round to nearest even.
+extern "C" int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packed) {
   if (!w || !packed) return ATVS_ERR_NULL;
   long pb;
-  atvs_conv_c16b_pack_size(&pb);
+  int rc = atvs_conv_c16b_pack_size(Cin, &pb);
+  if (rc) return rc;
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
-  for (int j = 0; j < B16_JC; ++j)
+  const int TPS = 32 / Cin, LPT = 4 / TPS, JC = (27 + TPS - 1) / TPS;
+  for (int j = 0; j < JC; ++j)
     for (int q = 0; q < 4; ++q) {
-      const int tap = 2 * j + (q >> 1);
+      const int tap = TPS * j + q / LPT;
       if (tap > 26) continue;
       for (int co = 0; co < 16; ++co)
         for (int e = 0; e < 8; ++e) {
-          const int ci = (q & 1) * 8 + e;
-          const float v = w[((size_t)tap * 16 + ci) * 16 + co];
+          const int ci = (q % LPT) * 8 + e;
+          const float v = w[((size_t)tap * Cin + ci) * 16 + co];
           const float p0 = b16_round(v), p1 = b16_round(v - p0), p2 = b16_round((v - p0) - p1);
           const float pc[3] = {p0, p1, p2};
           for (int k = 0; k < 3; ++k)
@@ -325,19 +345,37 @@ extern "C" int atvs_conv_c16b_pack(const float* w, unsigned char* packed) {
   return ATVS_OK;
 }
 
-// y (G,D,H,W,ldy)[..., y_coff : y_coff + 16] = conv3d(x (G,D,H,W,16), w [3,3,3,16,16], stride 1, SAME) (+ bias, ReLU) with
-// split-bf16 operands (fp32-class results; rounding differs from atvs_conv_c16_f32).  Grid / statistics rows =
+namespace {
+template <int CIN, bool RELU>
+int launch_c16b(const B16Args& a, long grid, hipStream_t s) {
+  const size_t lds = 3 * (size_t)B16<CIN>::IMG + (size_t)B16<CIN>::JC * B16_WSTEP;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16b_kernel<CIN, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return ATVS_ERR_LAUNCH;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((conv_c16b_kernel<CIN, RELU>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  return ATVS_OK;
+}
+}  // namespace
+
+// y (G,D,H,W,ldy)[..., y_coff : y_coff + 16] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,16], stride 1, SAME) (+ bias, ReLU), Cin 8
+// or 16, with split-bf16 operands (fp32-class results; rounding differs from atvs_conv_c16_f32).  Grid / statistics rows =
 // atvs_conv_c16_grid.
 extern "C" int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
-                                  double* stats_partial, int groups, int D, int H, int W, int ldy, int y_coff, int relu,
+                                  double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                                   atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
-  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || (Cin != 8 && Cin != 16)) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + 16 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
-  if ((double)D * H * W * 16 >= 2147483648.0 || (double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;
+  if ((double)D * H * W * Cin >= 2147483648.0 || (double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;
   B16Args a;
   long pb;
-  atvs_conv_c16b_pack_size(&pb);
+  atvs_conv_c16b_pack_size(Cin, &pb);
   a.x = x; a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
   a.bias = bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.ldy = ldy; a.ycoff = y_coff;
@@ -345,20 +383,14 @@ extern "C" int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w,
   a.ntiles = ((D + B16_TZ - 1) / B16_TZ) * a.tiles_y * a.tiles_x;
   const long blocks = atvs_conv_c16_grid(D, H, W, groups);
   a.wg = (int)blocks;
-  a.gx = (long)D * H * W * 16; a.gy = (long)D * H * W * ldy;
+  a.gx = (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy;
   const long grid = blocks * groups;
   if (grid > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  const size_t lds = 3 * (size_t)B16_IMG + (size_t)B16_JC * B16_WSTEP;
-  static bool attr_set[64][2] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  const void* fn = relu ? reinterpret_cast<const void*>(conv_c16b_kernel<true>) : reinterpret_cast<const void*>(conv_c16b_kernel<false>);
-  if (!attr_set[dev][relu ? 1 : 0]) {
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return ATVS_ERR_LAUNCH;
-    attr_set[dev][relu ? 1 : 0] = true;
-  }
-  if (relu) hipLaunchKernelGGL(conv_c16b_kernel<true>, dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
-  else hipLaunchKernelGGL(conv_c16b_kernel<false>, dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
+  hipStream_t st = as_stream(stream);
+  int rc;
+  if (Cin == 8) rc = relu ? launch_c16b<8, true>(a, grid, st) : launch_c16b<8, false>(a, grid, st);
+  else rc = relu ? launch_c16b<16, true>(a, grid, st) : launch_c16b<16, false>(a, grid, st);
+  if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

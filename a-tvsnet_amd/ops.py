@@ -430,35 +430,38 @@ def pack_conv_c16(key, w_host, device):
     return pk
 
 
-_USE_BF16X3 = os.environ.get('ATVS_BF16X3', '0') == '1'      # experiment switch for whole-pipeline runs
+_USE_BF16X3 = os.environ.get('ATVS_BF16X3', '1') == '1'      # ATVS_BF16X3=0: every convolution on the fp32 matrix cores
 
 
 def use_bf16x3(flag):
-    """EXPERIMENTAL (default off): the 16 -> 16 channel 3x3x3 convolutions on the bf16 matrix cores with split operands
-    (x = x0 + x1 + x2, six products, fp32 accumulation: conv_c16b.hip) instead of fp32 MFMA."""
+    """The 8 / 16 -> 16 channel 3x3x3 convolutions on the bf16 matrix cores with split operands (x = x0 + x1 + x2, six
+    products, fp32 accumulation: conv_c16b.hip; default) or on the fp32 matrix cores (conv_c16.hip).  Default on since
+    every full-size oracle fixture passes with it at the unchanged 1e-3 bar and its per-layer error against a float64
+    evaluation equals the fp32 MFMA kernel's (tests/test_gpu_conv.py::test_conv_c16b_split_bf16_matches_oracle)."""
     global _USE_BF16X3
     _USE_BF16X3 = bool(flag)
 
 
 def pack_conv_c16b(key, w_host, device):
-    """Packed bf16 pieces of a [3,3,3,16,16] kernel for atvs_conv_c16b_f32; cached."""
+    """Packed bf16 pieces of a [3,3,3,Cin,16] kernel (Cin 8 or 16) for atvs_conv_c16b_f32; cached."""
     import numpy as np
     ck = ('c16b', key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
     w = np.ascontiguousarray(w_host, dtype=np.float32)
+    cin = int(w.shape[-2])
     L = _lib.lib()
     pb = ctypes.c_long()
-    rc = L.atvs_conv_c16b_pack_size(ctypes.byref(pb))
+    rc = L.atvs_conv_c16b_pack_size(cin, ctypes.byref(pb))
     if rc:
         raise RuntimeError('atvs_conv_c16b_pack_size failed (%d)' % rc)
     packed = np.empty(pb.value, np.uint8)
-    rc = L.atvs_conv_c16b_pack(w.ctypes.data_as(ctypes.c_void_p), packed.ctypes.data_as(ctypes.c_void_p))
+    rc = L.atvs_conv_c16b_pack(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
         raise RuntimeError('atvs_conv_c16b_pack failed (%d)' % rc)
     pk = _Packed()
-    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, 16, 16
+    pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, 16
     pk.key, pk.tab, pk.xw = key, None, False
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
     _pack_cache[ck] = pk
@@ -1066,7 +1069,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
             and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
-        b16 = _USE_BF16X3 and cin == 16 and cout == 16
+        b16 = _USE_BF16X3 and cin in (8, 16) and cout == 16
         pk = pack_conv_c16b(key, w_host, x.device) if b16 else pack_conv_c16(key, w_host, x.device)
         if y5 is None:
             y5 = _new(x, (G,) + tuple(outs) + (cout,))
@@ -1079,7 +1082,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         if _dev_ok(x5, y5, bias):
             with _Timed(key, x5.shape[1:], cout, G):
                 if b16:
-                    _call('atvs_conv_c16b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2],
+                    _call('atvs_conv_c16b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
                           int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
                 else:
                     _call('atvs_conv_c16_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,

@@ -81,7 +81,7 @@ def parse(argv=None):
     p.add_argument('--views', type=int, default=None)
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-parity', action='store_true')
-    p.add_argument('--no-split-bf16', action='store_true', help='skip the secondary measurement with the split-bf16 16 -> 16 layers')
+    p.add_argument('--no-split-bf16', action='store_true', help='skip the secondary measurement with the split-bf16 layers switched the other way')
     p.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
     p.add_argument('--inflight', type=int, default=2,
                    help='depth maps in flight per GPU (streams with one captured graph each); 1 = strictly one after the other')
@@ -540,13 +540,16 @@ def rank_main(args):
         dt = float(t.item())
     out = out.clone()
 
-    # secondary: the same step with the EXPERIMENTAL split-bf16 form of the 16 -> 16 channel 3x3x3 layers (conv_c16b.hip: three
-    # bf16 pieces per operand, six products, fp32 accumulation; BASELINE configs[1] names "bf16 conv3d MFMA").  `value` stays
-    # the all-fp32-MFMA path; this is reported next to it with its own parity.
+    # secondary: the same step with EVERY convolution on the fp32 matrix cores (ops.use_bf16x3(False)).  The default path runs
+    # the 8 / 16 -> 16 channel 3x3x3 layers (AANet shared | unique, conv_b*_1_1, global_refine_3dconv1_1) on
+    # v_mfma_f32_16x16x32_bf16 with SPLIT operands -- x = x0 + x1 + x2, w = w0 + w1 + w2 in bf16 (24 mantissa bits kept),
+    # the 6 products with i + j <= 2, fp32 accumulation: fp32-class results (per-layer error against float64 equal to the fp32
+    # MFMA kernel's; BASELINE configs[1] names "bf16 conv3d MFMA") -- so the all-fp32-MFMA figure is printed next to it.
     split = None
     if world == 1 and graphed is not None and not args.no_split_bf16:
         try:
-            ops.use_bf16x3(True)
+            default_on = ops._USE_BF16X3
+            ops.use_bf16x3(not default_on)
             g2 = ex.GraphedInference(imgs, cams, args.depths)
             for _ in range(args.warmup):
                 g2()
@@ -556,15 +559,17 @@ def rank_main(args):
                 o2 = g2()
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t2
-            split = {'layers': '3x3x3 16 -> 16 channels (conv_b*_1_1, global_refine_3dconv1_1) on v_mfma_f32_16x16x32_bf16: '
-                               'x = x0 + x1 + x2, w = w0 + w1 + w2 in bf16, the 6 products with i + j <= 2, fp32 accumulation',
-                     'default': False, 'ms_per_step': round(1e3 * dt2 / args.steps, 3), 'value': round(args.steps / dt2, 4),
-                     'unit': 'depth-maps/sec', 'parity': None if args.no_parity else parity_check(args, o2.clone(), None)}
+            split = {'layers': '3x3x3 8 / 16 -> 16 channels on v_mfma_f32_16x16x32_bf16: x = x0 + x1 + x2, w = w0 + w1 + w2 in '
+                               'bf16, the 6 products with i + j <= 2, fp32 accumulation (conv_c16b.hip)',
+                     'in_value': bool(default_on),
+                     'other_path': 'every convolution on the fp32 matrix cores' if default_on else 'split-bf16 layers enabled',
+                     'other_ms_per_step': round(1e3 * dt2 / args.steps, 3), 'other_value': round(args.steps / dt2, 4),
+                     'unit': 'depth-maps/sec', 'other_parity': None if args.no_parity else parity_check(args, o2.clone(), None)}
             del g2
         except Exception as e:
             split = {'error': repr(e)}
         finally:
-            ops.use_bf16x3(False)
+            ops.use_bf16x3(default_on)
 
     # the dominant kernel and the warp, timed by HIP events on their launch stream in two eager single-stream passes
     # of the same step right after the timed region (kernels inside a replayed graph cannot be bracketed by events;
@@ -646,6 +651,9 @@ def rank_main(args):
             'unit': 'depth-maps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'precision': ('fp32 accumulation everywhere; fp32 MFMA operands except the 8 / 16 -> 16 channel 3x3x3 layers, whose '
+                          'fp32 operands are split into three bf16 pieces each (24 mantissa bits kept, 6 products: fp32-class, '
+                          'see `split_bf16` for the all-fp32-MFMA figure)') if ops._USE_BF16X3 else 'fp32 MFMA operands, fp32 accumulation',
             'config': {'workload': '%d depth map(s) per step: %d views (1 ref + %d src) %dx%d, D=%d, example.py %s pipeline'
                                    % (n_groups, args.views, args.views - 1, args.width, args.height, args.depths,
                                       'two-view' if twoview else 'multi-view'),

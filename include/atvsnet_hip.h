@@ -455,15 +455,15 @@ int atvs_conv_c16_f32(const float* x, const float* packed_w, const float* bias, 
                       int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu,
                       atvs_stream_t stream);
 
-/* EXPERIMENTAL: the 16 -> 16 channel form of atvs_conv_c16_f32 on the bf16 matrix cores with SPLIT operands (conv_c16b.hip;
+/* The 8 / 16 -> 16 channel forms of atvs_conv_c16_f32 on the bf16 matrix cores with SPLIT operands (conv_c16b.hip;
  * BASELINE.json configs[1] names "bf16 conv3d MFMA"): x = x0 + x1 + x2 and w = w0 + w1 + w2 in bf16 (24 mantissa bits kept),
  * the six products x_i * w_j with i + j <= 2 accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- fp32-class results (rounding
  * differs from the fp32 MFMA form), 6/16 of its matrix-core time.  Same grid / statistics rows as atvs_conv_c16_f32.
- *   atvs_conv_c16b_pack_size / _pack   HOST: split and pack the TF kernel [3,3,3,16,16] (bytes; upload the result) */
-int atvs_conv_c16b_pack_size(long* packed_bytes);
-int atvs_conv_c16b_pack(const float* w, unsigned char* packed);
+ *   atvs_conv_c16b_pack_size / _pack   HOST: split and pack the TF kernel [3,3,3,Cin,16], Cin 8 or 16 (bytes; upload the result) */
+int atvs_conv_c16b_pack_size(int Cin, long* packed_bytes);
+int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packed);
 int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
-                       int groups, int D, int H, int W, int ldy, int y_coff, int relu, atvs_stream_t stream);
+                       int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 #ifdef __cplusplus
 }

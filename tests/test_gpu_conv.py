@@ -378,15 +378,16 @@ def test_planar_cost_volume_is_bitwise_the_channel_last_one(cuda, B, D, h, w):
         ops.clear_pack_cache()
 
 
+@pytest.mark.parametrize('cin', [16, 8])
 @pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 37), (2, 5, 8, 12)])
-def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W):
-    """EXPERIMENTAL split-bf16 form of the 16 -> 16 channel convolution (conv_c16b.hip: three bf16 pieces per operand, six
+def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W, cin):
+    """Split-bf16 form of the 8 / 16 -> 16 channel convolution (conv_c16b.hip: three bf16 pieces per operand, six
     products, fp32 accumulation on v_mfma_f32_16x16x32_bf16) against the oracle at the UNCHANGED fp32 bar (2e-5 of the
     maximum), and no further from a float64 evaluation than the fp32 MFMA kernel is (x 2): bias + ReLU into a channel
     slice, statistics, ragged sizes, per-sample groups equal to single launches bit for bit."""
     from atvsnet_amd import ops
-    x = _rand((G, D, H, W, 16), 70)
-    w = _rand((3, 3, 3, 16, 16), 71, 0.15)
+    x = _rand((G, D, H, W, cin), 70)
+    w = _rand((3, 3, 3, cin, 16), 71, 0.15)
     b = _rand((16,), 72)
     want = torch.clamp(T.conv(x, w, 1, 'SAME', bias=b), min=0)
     ref64 = torch.clamp(T.conv(x.double(), w.double(), 1, 'SAME', bias=b.double()), min=0)
@@ -397,7 +398,7 @@ def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W):
             ops.use_bf16x3(flag)
             ops.clear_pack_cache()
             buf = torch.full((G, D, H, W, 24), -3.0, device=cuda)
-            got, st = ops.conv(x.to(cuda), ('c16b', G, D, H, W), w.numpy(), bias=b.to(cuda), relu=True, want_stats=True,
+            got, st = ops.conv(x.to(cuda), ('c16b', G, D, H, W, cin), w.numpy(), bias=b.to(cuda), relu=True, want_stats=True,
                                out=buf, y_coff=4, groups=G)
             y = buf.cpu()
             _close(y[..., 4:20], want)
@@ -408,14 +409,14 @@ def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W):
                 _close(s[g, 1, :16].float(), (want[g].reshape(-1, 16).double() ** 2).sum(0).float(), 1e-5)
             outs[flag] = y[..., 4:20].double()
             if flag:
-                one = ops.conv(x[1 % G].to(cuda), ('c16b', G, D, H, W), w.numpy(), bias=b.to(cuda), relu=True)
+                one = ops.conv(x[1 % G].to(cuda), ('c16b', G, D, H, W, cin), w.numpy(), bias=b.to(cuda), relu=True)
                 assert torch.equal(one.cpu(), y[1 % G, ..., 4:20])
         e32 = float((outs[False] - ref64).abs().max())
         e16 = float((outs[True] - ref64).abs().max())
         print('max abs error vs float64: fp32 MFMA %.3e, split bf16 %.3e' % (e32, e16))
         assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
     finally:
-        ops.use_bf16x3(False)
+        ops.use_bf16x3(True)             # the default
         ops.clear_pack_cache()
 
 
