@@ -1,0 +1,620 @@
+// 3x3x3 SAME stride-1 convolution to EIGHT output channels in x-pair form on the bf16 matrix cores with SPLIT operands, one
+// wavefront per SIMD (gfx950): conv_xp.hip's layers (conv_b*_0_1, global_refine_3dconv0_1, the photo stem; stride-2 sibling
+// conv_b*_1_0 / 3dconv1_0 from the same staged image; /root/reference/cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet,
+// layer code network.py:165-215) with every fp32 operand split into three bf16 pieces (conv_c16b.hip has the arithmetic:
+// x = x0 + x1 + x2, the six products x_i * w_j with i + j <= 2, fp32 accumulation on v_mfma_f32_16x16x32_bf16 -- fp32-class
+// results for 6/16 of the fp32 matrix-core time).
+//
+// One K = 32 instruction covers the FOUR x offsets a voxel pair touches x 8 channels: lane group q = x offset xl, so a
+// (kd, kh) tap row of an 8-channel chunk is ONE K step (36 fp32 16x16x4 steps of conv_xp become 9), rows = (x parity,
+// channel) as in conv_xp (3/4 of the MFMA work useful).  Per 8-channel chunk and 8 rows: 9 steps x 6 products x 8 = 432
+// instructions of 16 cycles against conv_xw's 384 of 32 (Winograd does not combine with split pieces: the transform of a
+// piece is not a bf16 number).
+//
+// Structure: tile 4(z) x 8(y) x 32(x), wavefront w owns plane z0 + w (8 accumulator tiles); the input is staged in 8-channel
+// chunks as THREE piece images [6][10][36 voxel columns: even x | odd x][8 bf16] (34.6 KB each, single-buffered: the next
+// stage's halo waits in registers as in conv_xp, two barriers per stage); the split happens once per staged element, after
+// the optional prologue (batch norm + ReLU of the producers, skip add).  Weights (three pieces per step, split on the host)
+// stream from L2 two steps ahead.  Sibling: K step i = taps 4 i + q of the 27 (7 steps), 2 rows per wavefront.
+#include <cstring>
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int XB_TZ = 4, XB_TY = 8, XB_TXV = 32;
+constexpr int XB_HZ = XB_TZ + 2, XB_HY = XB_TY + 2, XB_HX = XB_TXV + 2;
+constexpr int XB_HXP = 36;       // voxel columns per image row: even x in columns 0..16, odd x in columns XB_ODD..XB_ODD+16
+constexpr int XB_ODD = 18;
+constexpr int XB_VB = 16;        // bytes per voxel of one piece image (8 bf16)
+constexpr int XB_ROWB = XB_HXP * XB_VB;                     // 576
+constexpr int XB_IMG = XB_HZ * XB_HY * XB_ROWB;             // 34,560 bytes per piece
+constexpr int XB_SLOTS = XB_HZ * XB_HY * XB_HX * 2;         // float4 slots of the fp32 halo of a chunk
+constexpr int XB_MAXS = (XB_SLOTS + 255) / 256;             // 16 per thread
+constexpr int XB_JC = 9;                                    // main K steps per chunk: (kd, kh)
+constexpr int XB_J2 = 7;                                    // sibling K steps per chunk: taps 4 i + q
+constexpr int XB_LOOK = 2;                                  // weight look-ahead in K steps
+static_assert(XB_MAXS <= 3 * XB_JC, "one halo slot per phase of the main K loop");
+static_assert(2 * XB_IMG + (2 * XB_HY + 2 + XB_TY) * XB_ROWB < 3 * XB_IMG, "fragment reads stay inside the images");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct XbArgs {
+  const float* x;
+  const bf16x8* wp;      // packed weight pieces, see atvs_conv_xb_pack
+  const float* zeros;    // 16 bytes of zeros (tail of the packed weights)
+  const float* bias;
+  const float* pbias;    // (H, W, 24) or nullptr
+  float* y;
+  double* stats;
+  int Di, Hi, Wi, Cin;
+  int ldy, ycoff;
+  int nchunk;
+  int tiles_y, tiles_x, ntiles;
+  int relu;
+  const bf16x8* wp2;     // packed sibling weight pieces (atvs_conv_xb_pack_sibling) or nullptr
+  const float* pbias2;   // (Ho2, Wo2, 48) or nullptr
+  float* y2;
+  double* stats2;
+  int Do2, Ho2, Wo2, ldy2, ycoff2;
+  int pbz, pby, pbx;
+  int wg;
+  long gx, gy, gpb, gy2, gpb2;
+  const float* x2;
+  const float* in_pa;
+  const float* in_pb;
+  int relu_a, relu_b;
+  int sample_major;
+  int vstride;           // floats between voxels / between 8-channel chunks of x (channel-last or chunk-planar: conv_xw.hip)
+  long cstride;
+};
+
+// the three bf16 pieces of four fp32 values
+__device__ __forceinline__ void xb_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    (*p0)[i] = a;
+    (*p1)[i] = b;
+    (*p2)[i] = (__bf16)r2;
+  }
+}
+
+template <bool SIB, int PRO>
+__global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int MAXS = XB_MAXS, JC = XB_JC, J2 = SIB ? XB_J2 : 0, ROWB = XB_ROWB;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+
+  // this lane's fragment (the 8 channels of one voxel of a piece image) of halo row 0 of the wavefront's plane at its x
+  // offset xl = q; piece images XB_IMG apart (one base each: the displacements exceed the 16-bit immediate otherwise)
+  int fb[3];
+#pragma unroll
+  for (int pc = 0; pc < 3; ++pc) fb[pc] = pc * XB_IMG + ((wave * XB_HY) * XB_HXP + (q & 1) * XB_ODD + (q >> 1) + r) * XB_VB;
+  // sibling: this lane's tap of step i is 4 i + q (taps past 26: zero weights, tap 26's fragment); per-step byte offsets
+  int sd[SIB ? XB_J2 : 1];
+  if (SIB) {
+    const int row0 = (2 * (wave >> 1) + 1 - p.pbz) * XB_HY + (4 * (wave & 1) + 1 - p.pby);
+#pragma unroll
+    for (int i = 0; i < XB_J2; ++i) {
+      const int tap = min(4 * i + q, 26);
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      const int xh = kw + 1 - p.pbx;                                  // halo x of output column 0
+      sd[i] = ((row0 + kd * XB_HY + kh) * XB_HXP + (xh & 1) * XB_ODD + (xh >> 1) + r) * XB_VB;
+    }
+  }
+
+  // per-slot constants: float4 = channels 4 c4 .. of a halo voxel of the fp32 chunk -> 8 bytes of each piece image
+  int goff[MAXS], laddr[MAXS];
+  unsigned pg[MAXS];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < XB_SLOTS;
+    s = min(s, XB_SLOTS - 1);
+    const int c4 = s & 1, v = s >> 1;
+    const int xx = v % XB_HX, v2 = v / XB_HX;
+    const int yy = v2 % XB_HY, zz = v2 / XB_HY;
+    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.vstride + c4 * 4;
+    laddr[i] = ((zz * XB_HY + yy) * XB_HXP + (xx & 1) * XB_ODD + (xx >> 1)) * XB_VB + c4 * 8;
+    pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+  }
+  const bool last_live = tid + (MAXS - 1) * 256 < XB_SLOTS;
+
+  // persistent tile list (conv_xp.hip)
+  const int G = p.wg;
+  const int grp = p.sample_major ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / p.wg);
+  const int lbk = p.sample_major ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x - grp * p.wg);
+  const int xcd = p.sample_major ? 0 : (lbk & 7), tslot = p.sample_major ? lbk : (lbk >> 3);
+  const unsigned srow = (unsigned)(grp * p.wg + lbk);
+  const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
+  const float* __restrict__ xg2 = (PRO == 2) ? p.x2 + (size_t)grp * p.gx : nullptr;
+  const float* __restrict__ ipa = (PRO >= 1 && p.in_pa) ? p.in_pa + (size_t)grp * 3 * p.Cin : nullptr;
+  const float* __restrict__ ipb = (PRO == 2 && p.in_pb) ? p.in_pb + (size_t)grp * 3 * p.Cin : nullptr;
+  const int c4t = tid & 1;                        // every slot of this thread is channel group c4t of the chunk
+  float* __restrict__ yg = p.y + (size_t)grp * p.gy;
+  float* __restrict__ y2g = p.y2 + (size_t)grp * p.gy2;
+  const float* __restrict__ pbg = p.pbias ? p.pbias + (size_t)grp * p.gpb : nullptr;
+  const float* __restrict__ pb2g = p.pbias2 ? p.pbias2 + (size_t)grp * p.gpb2 : nullptr;
+  const int per_xcd = p.sample_major ? p.ntiles : ((p.ntiles + 7) >> 3);
+  const int slots_per_xcd = p.sample_major ? G : (G >> 3);
+  int my_tiles = 0;
+  {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);
+    if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
+  }
+  const int nstage = my_tiles * p.nchunk;
+
+  auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
+    int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
+    int bx = tl % p.tiles_x;
+    int rest = tl / p.tiles_x;
+    *x0 = bx * XB_TXV;
+    *y0 = (rest % p.tiles_y) * XB_TY;
+    *z0 = (rest / p.tiles_y) * XB_TZ;
+  };
+
+  struct PfTile {
+    const float* xb;
+    const float* xb2;
+    int org;
+    unsigned lo, hi1;
+  };
+  auto pf_tile = [&](int stage) __attribute__((always_inline)) {
+    PfTile T;
+    int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
+    T.xb = xg + (size_t)ch * p.cstride;
+    T.xb2 = (PRO == 2) ? xg2 + (size_t)ch * p.cstride : nullptr;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.vstride;
+    T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+    T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+            ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+    return T;
+  };
+  float4 pf[MAXS];
+  float4 pf2[PRO == 2 ? MAXS : 1];
+  unsigned vmask = 0;
+  auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
+    const unsigned t1 = pg[i] - T.lo;
+    const unsigned t2 = T.hi1 + ~pg[i];
+    const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
+    pf[i] = ld4(ok ? (T.xb + (T.org + goff[i])) : p.zeros);
+    if (PRO >= 1) vmask = (vmask & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+    if (PRO == 2) pf2[i] = ld4(ok ? (T.xb2 + (T.org + goff[i])) : p.zeros);
+  };
+
+  // prologue transform: arithmetic of bn_apply / bn_add (norm.hip), as conv_xp.hip / conv_xw.hip
+  struct Par { float4 ma, sa, ba, mb, sb, bb; };
+  const bool has_a = PRO >= 1 && ipa != nullptr, has_b = PRO == 2 && ipb != nullptr;
+  const float floor_a = p.relu_a ? 0.f : -__builtin_huge_valf(), floor_b = p.relu_b ? 0.f : -__builtin_huge_valf();
+  auto load_par = [&](int chunk) __attribute__((always_inline)) {
+    Par P;
+    const int cch = chunk * 8 + c4t * 4;
+    const int sa = has_a ? p.Cin : 0, sb = has_b ? p.Cin : 0;
+    const float* a = has_a ? ipa + cch : p.zeros;
+    P.ma = ld4(a); P.sa = ld4(a + sa); P.ba = ld4(a + 2 * sa);
+    if (PRO == 2) {
+      const float* b = has_b ? ipb + cch : p.zeros;
+      P.mb = ld4(b); P.sb = ld4(b + sb); P.bb = ld4(b + 2 * sb);
+    }
+    return P;
+  };
+  auto bn2 = [&](f32x2 v, f32x2 m, f32x2 sc, f32x2 be, float lo, bool has) __attribute__((always_inline)) {
+    f32x2 t = (v - m) * sc + be;
+    t.x = fmaxf(t.x, lo);
+    t.y = fmaxf(t.y, lo);
+    t.x = has ? t.x : v.x;
+    t.y = has ? t.y : v.y;
+    return t;
+  };
+  auto xform = [&](int i, const Par& P) __attribute__((always_inline)) {
+    const bool ok = (vmask >> i) & 1u;
+    f32x2 lo = {pf[i].x, pf[i].y}, hi = {pf[i].z, pf[i].w};
+    lo = bn2(lo, (f32x2){P.ma.x, P.ma.y}, (f32x2){P.sa.x, P.sa.y}, (f32x2){P.ba.x, P.ba.y}, floor_a, has_a);
+    hi = bn2(hi, (f32x2){P.ma.z, P.ma.w}, (f32x2){P.sa.z, P.sa.w}, (f32x2){P.ba.z, P.ba.w}, floor_a, has_a);
+    if (PRO == 2) {
+      f32x2 ul = {pf2[i].x, pf2[i].y}, uh = {pf2[i].z, pf2[i].w};
+      ul = bn2(ul, (f32x2){P.mb.x, P.mb.y}, (f32x2){P.sb.x, P.sb.y}, (f32x2){P.bb.x, P.bb.y}, floor_b, has_b);
+      uh = bn2(uh, (f32x2){P.mb.z, P.mb.w}, (f32x2){P.sb.z, P.sb.w}, (f32x2){P.bb.z, P.bb.w}, floor_b, has_b);
+      lo += ul;
+      hi += uh;
+    }
+    pf[i] = make_float4(ok ? lo.x : 0.f, ok ? lo.y : 0.f, ok ? hi.x : 0.f, ok ? hi.y : 0.f);
+  };
+
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+  float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (p.bias) bv = ld4(p.bias + (q & 1) * 4);
+  f32x4 acc[XB_TY];
+  f32x4 acc2[2];
+  float ssum2[4] = {0.f, 0.f, 0.f, 0.f}, ssq2[4] = {0.f, 0.f, 0.f, 0.f};
+
+  if (nstage > 0) {
+    const PfTile T0 = pf_tile(0);
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+  }
+
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    if (ch == 0) {
+#pragma unroll
+      for (int t = 0; t < XB_TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[0] = acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    // weight pieces of this chunk: [step][piece][lane]; those of the first steps are on their way while the images are written
+    const bf16x8* wch = p.wp + ((size_t)ch * JC * 3) * 64 + lane;
+    const bf16x8* wch2 = p.wp2 + ((size_t)ch * J2 * 3) * 64 + lane;
+    bf16x8 A[JC][3], A2[SIB ? XB_J2 : 1][3];
+#pragma unroll
+    for (int s = 0; s < XB_LOOK; ++s)
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) A[s][pc] = wch[(s * 3 + pc) * 64];
+
+    __syncthreads();                       // every wavefront is done reading the previous stage's images
+    if (PRO >= 1) {
+      const Par P0 = load_par(ch);
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) xform(i, P0);
+    }
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i)
+      if (i < MAXS - 1 || last_live) {
+        bf16x4 p0, p1, p2;
+        xb_split(pf[i], &p0, &p1, &p2);
+        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<bf16x4*>(smem + XB_IMG + laddr[i]) = p1;
+        *reinterpret_cast<bf16x4*>(smem + 2 * XB_IMG + laddr[i]) = p2;
+      }
+    __syncthreads();
+
+    const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
+    const bool last_chunk = (ch == p.nchunk - 1);
+    int tz0, ty0, tx0;
+    tile_origin(k, &tz0, &ty0, &tx0);
+    const int zo = tz0 + wave, xo = tx0 + 2 * r + (q >> 1), co = (q & 1) * 4;
+    const bool evox_ok = zo < p.Di && xo < p.Wi;
+    const size_t erow = (size_t)p.Wi * p.ldy;
+    const size_t eo = (((size_t)zo * p.Hi + ty0) * p.Wi + xo) * (size_t)p.ldy + p.ycoff + co;
+    const size_t epb_off = ((size_t)ty0 * p.Wi + xo) * 24 + plane_variant(zo - 1, p.Di) * 8 + co;
+    auto erow_ok = [&](int t) __attribute__((always_inline)) { return evox_ok && ty0 + t < p.Hi; };
+    float4 epb[XB_TY], epb2[2];
+    const int zo2 = (tz0 >> 1) + (wave >> 1), yo2 = (ty0 >> 1) + 2 * (wave & 1), xo2 = (tx0 >> 1) + r;
+    const bool evox2_ok = SIB && zo2 < p.Do2 && xo2 < p.Wo2;
+    auto erow2_ok = [&](int t) __attribute__((always_inline)) { return evox2_ok && yo2 + t < p.Ho2; };
+    const size_t erow2 = (size_t)p.Wo2 * p.ldy2;
+    const size_t eo2 = (((size_t)zo2 * p.Ho2 + yo2) * p.Wo2 + xo2) * (size_t)p.ldy2 + p.ycoff2 + 4 * q;
+
+    // ---- main K loop: 9 steps (kd, kh) x 3 phases (input piece pc with the weight pieces jw <= 2 - pc: 24 / 16 / 8 MFMAs);
+    // the fragments of ONE input piece are live at a time, requested one phase ahead
+    bf16x8 Bq[2][XB_TY], B2[2][2];
+    auto request_B = [&](int ph) __attribute__((always_inline)) {
+      const int s = ph / 3, pc = ph % 3;
+      const int off = ((s / 3) * XB_HY + (s % 3)) * ROWB;
+#pragma unroll
+      for (int t = 0; t < XB_TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + fb[pc] + (off + t * ROWB));
+    };
+    auto request_B2 = [&](int ph) __attribute__((always_inline)) {
+      const int i = ph / 3, pc = ph % 3;
+#pragma unroll
+      for (int t = 0; t < 2; ++t) B2[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * XB_IMG + sd[i] + 2 * t * ROWB);
+    };
+    request_B(0);
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int ph = 0; ph < 3 * JC; ++ph) {
+      const int s = ph / 3, pc = ph % 3;
+      if (pc == 0) {
+        if (s + XB_LOOK < JC) {
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) A[s + XB_LOOK][w3] = wch[((s + XB_LOOK) * 3 + w3) * 64];
+        } else if (SIB) {
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) A2[s + XB_LOOK - JC][w3] = wch2[((s + XB_LOOK - JC) * 3 + w3) * 64];
+        }
+      }
+      if (ph + 1 < 3 * JC) request_B(ph + 1);
+      else if (SIB) request_B2(0);
+      if (ph < MAXS) pf_slot(T, ph);
+      if (!SIB && ph == 3 * JC - 6) {
+        const bool use = last_chunk && pbg;
+#pragma unroll
+        for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((use && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jw = 0; jw < 3; ++jw) {
+        if (jw > 2 - pc) continue;
+#pragma unroll
+        for (int t = 0; t < XB_TY; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][jw], Bq[ph & 1][t], acc[t], 0, 0, 0);
+      }
+    }
+    if (SIB) {
+#pragma unroll
+      for (int ph = 0; ph < 3 * J2; ++ph) {
+        const int i = ph / 3, pc = ph % 3;
+        if (pc == 0 && i + XB_LOOK < J2) {
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) A2[i + XB_LOOK][w3] = wch2[((i + XB_LOOK) * 3 + w3) * 64];
+        }
+        if (ph + 1 < 3 * J2) request_B2(ph + 1);
+        if (ph == 3 * J2 - 9) {       // the epilogues' depth-plane biases, behind the last weight request of the stage
+          const bool use = last_chunk && pbg;
+#pragma unroll
+          for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((use && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
+          const bool use2 = last_chunk && pb2g;
+          const size_t o = ((size_t)yo2 * p.Wo2 + xo2) * 48 + plane_variant(2 * zo2 - p.pbz, p.Di) * 16 + 4 * q;
+#pragma unroll
+          for (int t = 0; t < 2; ++t) epb2[t] = ld4((use2 && erow2_ok(t)) ? pb2g + (o + (size_t)t * p.Wo2 * 48) : p.zeros);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jw = 0; jw < 3; ++jw) {
+          if (jw > 2 - pc) continue;
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[i][jw], B2[ph & 1][t], acc2[t], 0, 0, 0);
+        }
+      }
+    }
+    if (!last_chunk) continue;
+
+    // ---- epilogue (conv_xp.hip): this lane holds channels co..co+3 of voxel xo for the 8 rows of plane zo
+    auto store_rows = [&](auto relu_tag) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < XB_TY; ++t) {
+        if (!erow_ok(t)) continue;
+        float4 v;
+        v.x = (acc[t][0] + bv.x) + epb[t].x;
+        v.y = (acc[t][1] + bv.y) + epb[t].y;
+        v.z = (acc[t][2] + bv.z) + epb[t].z;
+        v.w = (acc[t][3] + bv.w) + epb[t].w;
+        if (decltype(relu_tag)::value) {          // NaN passes through, as in tf.nn.relu
+          v.x = (v.x < 0.f) ? 0.f : v.x;
+          v.y = (v.y < 0.f) ? 0.f : v.y;
+          v.z = (v.z < 0.f) ? 0.f : v.z;
+          v.w = (v.w < 0.f) ? 0.f : v.w;
+        }
+        st4(yg + (eo + (size_t)t * erow), v);
+        ssum[0] += v.x; ssum[1] += v.y; ssum[2] += v.z; ssum[3] += v.w;
+        ssq[0] += v.x * v.x; ssq[1] += v.y * v.y; ssq[2] += v.z * v.z; ssq[3] += v.w * v.w;
+      }
+    };
+    if (p.relu) store_rows(std::true_type{});
+    else store_rows(std::false_type{});
+    if (SIB) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        if (!erow2_ok(t)) continue;
+        const float4 v = make_float4(acc2[t][0] + epb2[t].x, acc2[t][1] + epb2[t].y, acc2[t][2] + epb2[t].z, acc2[t][3] + epb2[t].w);
+        st4(y2g + (eo2 + (size_t)t * erow2), v);
+        ssum2[0] += v.x; ssum2[1] += v.y; ssum2[2] += v.z; ssum2[3] += v.w;
+        ssq2[0] += v.x * v.x; ssq2[1] += v.y * v.y; ssq2[2] += v.z * v.z; ssq2[3] += v.w * v.w;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- per-workgroup partial moments -> row `srow` of stats: [2][16] doubles (columns 0..7 = channels), as conv_xp.hip
+  if (p.stats) {
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][8]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a = (double)ssum[kk], bq = (double)ssq[kk];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        bq += __shfl_xor(bq, o);
+      }
+      a += __shfl_xor(a, 32);      // lanes q and q^2 hold the same channels (the two x parities)
+      bq += __shfl_xor(bq, 32);
+      if (r == 0 && q < 2) {
+        s_red[(wave * 2 + 0) * 8 + q * 4 + kk] = a;
+        s_red[(wave * 2 + 1) * 8 + q * 4 + kk] = bq;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, col = tid & 15;
+      double v = 0.0;
+      if (col < 8)
+        v = (s_red[(0 * 2 + which) * 8 + col] + s_red[(1 * 2 + which) * 8 + col]) +
+            (s_red[(2 * 2 + which) * 8 + col] + s_red[(3 * 2 + which) * 8 + col]);
+      p.stats[((size_t)srow * 2 + which) * 16 + col] = v;
+    }
+  }
+  if (SIB && p.stats2) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a = (double)ssum2[kk], bq = (double)ssq2[kk];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        bq += __shfl_xor(bq, o);
+      }
+      if (r == 0) {
+        s_red[(wave * 2 + 0) * 16 + q * 4 + kk] = a;
+        s_red[(wave * 2 + 1) * 16 + q * 4 + kk] = bq;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, col = tid & 15;
+      p.stats2[((size_t)srow * 2 + which) * 16 + col] =
+          (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
+          (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
+    }
+  }
+}
+
+
+long xb_ntiles(int D, int H, int W) {
+  return (long)((D + XB_TZ - 1) / XB_TZ) * ((H + XB_TY - 1) / XB_TY) * ((W + XB_TXV - 1) / XB_TXV);
+}
+
+template <bool SIB, int PRO>
+int launch_xb(const XbArgs& a, long blocks, hipStream_t s) {
+  const size_t lds = 3 * (size_t)XB_IMG;
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<SIB, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return ATVS_ERR_LAUNCH;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((conv_xb_kernel<SIB, PRO>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  return ATVS_OK;
+}
+
+// round-to-nearest-even bf16 of a finite float, as a float / its 16 bits
+float xb_round(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  float o;
+  std::memcpy(&o, &u, 4);
+  return o;
+}
+uint16_t xb_bits(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  return (uint16_t)(u >> 16);
+}
+void xb_put(uint16_t* out, size_t base, float v) {      // the three pieces of v at out[base + piece * 64 * 8]
+  const float p0 = xb_round(v), p1 = xb_round(v - p0), p2 = xb_round((v - p0) - p1);
+  out[base] = xb_bits(p0);
+  out[base + 64 * 8] = xb_bits(p1);
+  out[base + 2 * 64 * 8] = xb_bits(p2);
+}
+
+}  // namespace
+
+// Bytes of the packed form of a [3,3,3,Cin,8] kernel (Cin % 8 == 0) for atvs_conv_xb_f32, including 16 trailing zero bytes.
+extern "C" int atvs_conv_xb_pack_size(int Cin, long* packed_bytes) {
+  if (Cin <= 0 || (Cin % 8) || !packed_bytes) return ATVS_ERR_SHAPE;
+  *packed_bytes = (long)(Cin / 8) * XB_JC * 3 * 1024 + 16;
+  return ATVS_OK;
+}
+
+// HOST function.  w: TF kernel [3,3,3,Cin,8].  packed[chunk][step s = kd*3 + kh][piece][lane = q*16 + (jx*8 + co)][e] =
+// piece of w[kd][kh][kw = q - jx][ci = chunk*8 + e][co] (0 for kw outside 0..2): lane group q = x offset of the pair window.
+extern "C" int atvs_conv_xb_pack(const float* w, int Cin, unsigned char* packed) {
+  if (!w || !packed) return ATVS_ERR_NULL;
+  long pb;
+  int rc = atvs_conv_xb_pack_size(Cin, &pb);
+  if (rc) return rc;
+  std::memset(packed, 0, (size_t)pb);
+  uint16_t* out = reinterpret_cast<uint16_t*>(packed);
+  for (int ch = 0; ch < Cin / 8; ++ch)
+    for (int s = 0; s < XB_JC; ++s)
+      for (int q = 0; q < 4; ++q)
+        for (int jx = 0; jx < 2; ++jx) {
+          const int kd = s / 3, kh = s % 3, kw = q - jx;
+          if (kw < 0 || kw > 2) continue;
+          for (int co = 0; co < 8; ++co)
+            for (int e = 0; e < 8; ++e)
+              xb_put(out, ((((size_t)ch * XB_JC + s) * 3) * 64 + q * 16 + jx * 8 + co) * 8 + e,
+                     w[((((size_t)kd * 3 + kh) * 3 + kw) * Cin + ch * 8 + e) * 8 + co]);
+        }
+  return ATVS_OK;
+}
+
+extern "C" int atvs_conv_xb_pack_sibling_size(int Cin, long* packed_bytes) {
+  if (Cin <= 0 || (Cin % 8) || !packed_bytes) return ATVS_ERR_SHAPE;
+  *packed_bytes = (long)(Cin / 8) * XB_J2 * 3 * 1024;
+  return ATVS_OK;
+}
+
+// HOST function.  w2: TF kernel [3,3,3,Cin,16] of the stride-2 sibling.  packed[chunk][step i][piece][lane = q*16 + co][e] =
+// piece of w2[tap = 4 i + q][chunk*8 + e][co] (0 for taps past 26).
+extern "C" int atvs_conv_xb_pack_sibling(const float* w2, int Cin, unsigned char* packed) {
+  if (!w2 || !packed) return ATVS_ERR_NULL;
+  long pb;
+  int rc = atvs_conv_xb_pack_sibling_size(Cin, &pb);
+  if (rc) return rc;
+  std::memset(packed, 0, (size_t)pb);
+  uint16_t* out = reinterpret_cast<uint16_t*>(packed);
+  for (int ch = 0; ch < Cin / 8; ++ch)
+    for (int i = 0; i < XB_J2; ++i)
+      for (int q = 0; q < 4; ++q) {
+        const int tap = 4 * i + q;
+        if (tap > 26) continue;
+        for (int co = 0; co < 16; ++co)
+          for (int e = 0; e < 8; ++e)
+            xb_put(out, ((((size_t)ch * XB_J2 + i) * 3) * 64 + q * 16 + co) * 8 + e, w2[((size_t)tap * Cin + ch * 8 + e) * 16 + co]);
+      }
+  return ATVS_OK;
+}
+
+// Same contract as atvs_conv_xw_f32 (x_planar included), weights packed by atvs_conv_xb_pack[_sibling]; grid and statistics
+// rows = atvs_conv_xp_grid.  fp32-class results (split-bf16 operands, fp32 accumulation); rounding differs from the fp32 forms.
+extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* plane_bias,
+                                float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
+                                int relu, const unsigned char* packed_w2, const float* plane_bias2, float* y2,
+                                double* stats_partial2, int ldy2, int y_coff2, const float* x2, const float* in_params,
+                                const float* in_params2, int in_relu, int in_relu2, int x_planar, atvs_stream_t stream) {
+  if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (in_params2 && !x2) return ATVS_ERR_ARG;
+  if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8)) return ATVS_ERR_SHAPE;
+  if (x_planar && (x2 || in_params)) return ATVS_ERR_ARG;
+  if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if (plane_bias && D < 2) return ATVS_ERR_ARG;
+  if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
+  if (packed_w2) {
+    if (!y2) return ATVS_ERR_NULL;
+    if (y_coff2 < 0 || y_coff2 + 16 > ldy2 || (ldy2 % 4) || (y_coff2 % 4)) return ATVS_ERR_SHAPE;
+  } else if (plane_bias2 || y2 || stats_partial2) {
+    return ATVS_ERR_ARG;
+  }
+  long pb;
+  atvs_conv_xb_pack_size(Cin, &pb);
+  XbArgs a;
+  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  a.bias = bias; a.pbias = plane_bias; a.y = y; a.stats = stats_partial;
+  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff;
+  a.nchunk = Cin / 8;
+  a.tiles_y = (H + XB_TY - 1) / XB_TY; a.tiles_x = (W + XB_TXV - 1) / XB_TXV;
+  a.ntiles = (int)xb_ntiles(D, H, W);
+  a.relu = relu;
+  a.wp2 = reinterpret_cast<const bf16x8*>(packed_w2); a.pbias2 = plane_bias2; a.y2 = y2; a.stats2 = stats_partial2;
+  a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
+  a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;
+  a.wg = (int)atvs_conv_xp_grid(D, H, W, groups);
+  a.gx = (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
+  a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
+  const long blocks = (long)a.wg * groups;
+  hipStream_t st = as_stream(stream);
+  a.sample_major = (groups == 8) ? 1 : 0;
+  a.x2 = x2; a.in_pa = in_params; a.in_pb = in_params2; a.relu_a = in_relu; a.relu_b = in_relu2;
+  a.vstride = x_planar ? 8 : Cin;
+  a.cstride = x_planar ? (long)D * H * W * 8 : 8;
+  const int pro = x2 ? 2 : (in_params ? 1 : 0);
+  int rc;
+  if (pro == 0) rc = packed_w2 ? launch_xb<true, 0>(a, blocks, st) : launch_xb<false, 0>(a, blocks, st);
+  else if (pro == 1 && packed_w2) rc = launch_xb<true, 1>(a, blocks, st);
+  else if (pro == 2 && packed_w2) rc = launch_xb<true, 2>(a, blocks, st);
+  else return ATVS_ERR_ARG;
+  if (rc) return rc;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

@@ -247,7 +247,7 @@ _pack_cache = {}
 
 
 class _Packed(object):
-    __slots__ = ('wp', 'tab', 'ntaps', 'vec', 'ksteps', 'ntiles', 'cin', 'cout', 'key', 'xw')
+    __slots__ = ('wp', 'tab', 'ntaps', 'vec', 'ksteps', 'ntiles', 'cin', 'cout', 'key', 'xw', 'kind')
 
 
 def pack_conv_weights(key, w_host, taps, transposed, device):
@@ -325,7 +325,20 @@ def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y, xpair
 
 
 _USE_XW = True
+_USE_XB = os.environ.get('ATVS_BF16X3', '1') == '1'
 _USE_PLANAR = True
+
+
+def use_xb(flag):
+    """Testing / A-B hook: the split-bf16 form of the x-pair kernel (conv_xb.hip: three bf16 pieces per operand, six
+    products, fp32 accumulation) in front of the fp32 kernels (conv_xw.hip / conv_xp.hip)."""
+    global _USE_XB
+    _USE_XB = bool(flag)
+
+
+def _xkind():
+    """Which one-workgroup-per-CU x-pair kernel serves the 8-output-channel layers."""
+    return 'xb' if _USE_XB else ('xw' if _USE_XW else 'xp')
 
 
 def use_planar(flag):
@@ -337,7 +350,7 @@ def use_planar(flag):
 def planar_cost_volume_ok(shape, F):
     """Should build_cost_volumes write the warped half chunk-planar?  Only when its one consumer -- the x-pair launch of
     conv_b0_0_1 | conv_b0_1_0 -- is the Winograd kernel."""
-    return (_USE_PLANAR and _USE_XW and F in (16, 32, 64) and siblings_ok(tuple(shape), F, 8, 16))
+    return (_USE_PLANAR and _xkind() != 'xp' and F in (16, 32, 64) and siblings_ok(tuple(shape), F, 8, 16))
 
 
 def use_xw(flag):
@@ -349,8 +362,9 @@ def use_xw(flag):
 def pack_conv_xp(key, w_host, device):
     """Packed weights of the one-workgroup-per-CU x-pair kernel (atvs_conv_xp_f32 / atvs_conv_xw_f32); cached."""
     import numpy as np
-    xw = _USE_XW
-    ck = ('xw' if xw else 'xp', key, str(device))
+    kind = _xkind()
+    xw = kind == 'xw'
+    ck = (kind, key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
@@ -358,17 +372,17 @@ def pack_conv_xp(key, w_host, device):
     cin = w.shape[-2]
     L = _lib.lib()
     pf = ctypes.c_long()
-    size_fn, pack_fn = (L.atvs_conv_xw_pack_size, L.atvs_conv_xw_pack) if xw else (L.atvs_conv_xp_pack_size, L.atvs_conv_xp_pack)
+    size_fn, pack_fn = getattr(L, 'atvs_conv_%s_pack_size' % kind), getattr(L, 'atvs_conv_%s_pack' % kind)
     rc = size_fn(cin, ctypes.byref(pf))
     if rc:
-        raise RuntimeError('atvs_conv_x%s_pack_size failed (%d) for Cin=%d' % ('w' if xw else 'p', rc, cin))
-    packed = np.empty(pf.value, np.float32)
+        raise RuntimeError('atvs_conv_%s_pack_size failed (%d) for Cin=%d' % (kind, rc, cin))
+    packed = np.empty(pf.value, np.uint8 if kind == 'xb' else np.float32)      # xb: bytes (bf16 pieces)
     rc = pack_fn(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
-        raise RuntimeError('atvs_conv_x%s_pack failed (%d)' % ('w' if xw else 'p', rc))
+        raise RuntimeError('atvs_conv_%s_pack failed (%d)' % (kind, rc))
     pk = _Packed()
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 36, 4, 0, 1, cin, 8
-    pk.xw = xw
+    pk.xw, pk.kind = xw, kind
     pk.key = key
     pk.tab = None
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
@@ -493,8 +507,9 @@ def deconv_up_ok(cin, cout):
 def pack_conv_xp_sibling(key, w_host, device):
     """Packed weights of the stride-2 sibling [3,3,3,Cin,16] of an x-pair launch; cached."""
     import numpy as np
-    xw = _USE_XW
-    ck = ('xw2' if xw else 'xp2', key, str(device))
+    kind = _xkind()
+    xw = kind == 'xw'
+    ck = (kind + '2', key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
@@ -504,18 +519,17 @@ def pack_conv_xp_sibling(key, w_host, device):
         raise ValueError('x-pair sibling: 16 output channels, got %d' % w.shape[-1])
     L = _lib.lib()
     pf = ctypes.c_long()
-    size_fn, pack_fn = ((L.atvs_conv_xw_pack_sibling_size, L.atvs_conv_xw_pack_sibling) if xw else
-                        (L.atvs_conv_xp_pack_sibling_size, L.atvs_conv_xp_pack_sibling))
+    size_fn, pack_fn = getattr(L, 'atvs_conv_%s_pack_sibling_size' % kind), getattr(L, 'atvs_conv_%s_pack_sibling' % kind)
     rc = size_fn(cin, ctypes.byref(pf))
     if rc:
         raise RuntimeError('x-pair sibling pack size failed (%d) for Cin=%d' % (rc, cin))
-    packed = np.empty(pf.value, np.float32)
+    packed = np.empty(pf.value, np.uint8 if kind == 'xb' else np.float32)
     rc = pack_fn(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
         raise RuntimeError('x-pair sibling pack failed (%d)' % rc)
     pk = _Packed()
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, 16
-    pk.xw = xw
+    pk.xw, pk.kind = xw, kind
     pk.key = key
     pk.tab = None
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
@@ -672,8 +686,9 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
     for ip in (ipa, ipb):
         if ip is not None and (ip.numel() != G * 3 * Cin or not ip.is_contiguous()):
             raise ValueError('conv_xp: prologue parameters must be (groups, 3, Cin)')
-    xw = bool(getattr(pk, 'xw', False))
-    if pk2 is not None and bool(getattr(pk2, 'xw', False)) != xw:
+    kind = pk.kind
+    xw = kind in ('xw', 'xb')             # the kernels that take the chunk-planar layout
+    if pk2 is not None and pk2.kind != kind:
         raise ValueError('conv_xp: the main and the sibling weights are packed for different kernels')
     if planar and not xw:
         raise ValueError('conv_xp: the chunk-planar input layout belongs to the Winograd kernel')
@@ -684,7 +699,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
                     sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _p(x2), _p(ipa), _p(ipb),
                     int(bool(relu_a)), int(bool(relu_b))]
             if xw:
-                _call('atvs_conv_xw_f32', *(args + [int(bool(planar)), _stream()]))
+                _call('atvs_conv_%s_f32' % kind, *(args + [int(bool(planar)), _stream()]))
             else:
                 _call('atvs_conv_xp_f32', *(args + [_stream()]))
 
@@ -1314,7 +1329,7 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
             raise ValueError('conv_siblings: this lazy input must be materialised first')
         x, prologue = x.prologue()
     if planar:             # x: (G, Cin/8, D, H, W, 8), chunk-planar (SplitVolume(planar=True)); Winograd x-pair kernel only
-        if prologue is not None or not _USE_XW or groups is None or x.dim() != 6 or not x.is_contiguous():
+        if prologue is not None or _xkind() == 'xp' or groups is None or x.dim() != 6 or not x.is_contiguous():
             raise ValueError('conv_siblings(planar=True): a contiguous (G, Cin/8, D, H, W, 8) tensor, no prologue')
         G, K, D, H, W, _ = x.shape
         x5, nsp, cin = x, 3, K * 8
@@ -1354,7 +1369,7 @@ def conv_split_siblings(sv, key, w_host, key2, w2_host):
     wv2, planes2 = _fold_split_weights(key2, w2_host, sv.chan_map, cv, cc)
     pb = conv(sv.const, (key, 'planes'), planes, stride=1, groups=B)
     pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2, groups=B)
-    if sv.planar and _USE_XW:
+    if sv.planar and _xkind() != 'xp':
         return conv_siblings(sv._var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B,
                              planar=True)
     return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B)

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 15
+#define ATVS_ABI_VERSION 16
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -274,6 +274,21 @@ int atvs_conv_xw_pack_sibling(const float* w2, int Cin, float* packed);
 int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias, float* y,
                      double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
+                     int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
+                     int in_relu2, int x_planar, atvs_stream_t stream);
+
+/* The same layers (same contract as atvs_conv_xw_f32, x_planar included) on the bf16 matrix cores with SPLIT operands
+ * (conv_xb.hip): every fp32 operand = three bf16 pieces, the six products x_i * w_j with i + j <= 2 accumulated in fp32 by
+ * v_mfma_f32_16x16x32_bf16 (the arithmetic of atvs_conv_c16b_f32) -- fp32-class results, 9 K steps of 16-cycle instructions
+ * per (8-channel chunk, kd, kh) row instead of 36 fp32 steps of 32 cycles.  Weights: atvs_conv_xb_pack / _pack_sibling
+ * (HOST; sizes in BYTES). */
+int atvs_conv_xb_pack_size(int Cin, long* packed_bytes);
+int atvs_conv_xb_pack(const float* w, int Cin, unsigned char* packed);
+int atvs_conv_xb_pack_sibling_size(int Cin, long* packed_bytes);
+int atvs_conv_xb_pack_sibling(const float* w2, int Cin, unsigned char* packed);
+int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* plane_bias, float* y,
+                     double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                     const unsigned char* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
                      int in_relu2, int x_planar, atvs_stream_t stream);
 

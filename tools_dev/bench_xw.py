@@ -1,5 +1,5 @@
 """The four x-pair launches of a depth map as bench.py issues them (batched), timed one by one with HIP events:
-usage: [ATVS_LIB=tools_dev/_dbg/lib_X.so] python tools_dev/bench_xw.py [reps]"""
+usage: [ATVS_LIB=tools_dev/_dbg/lib_X.so] python tools_dev/bench_xw.py [reps] [xb|xw|xp]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -7,6 +7,10 @@ import torch
 import atvsnet_amd
 from atvsnet_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+kind = sys.argv[2] if len(sys.argv) > 2 else 'xb'
+ops.use_xb(kind == 'xb')
+ops.use_xw(kind == 'xw')
+print('x-pair kernel:', kind)
 dev = torch.device('cuda:0')
 D, H, W = 192, 128, 160
 rng = np.random.default_rng(0)
