@@ -12,7 +12,7 @@
 // piece is not a bf16 number).
 //
 // Structure: tile 4(z) x 8(y) x 32(x), wavefront w owns plane z0 + w (8 accumulator tiles); the input is staged in 8-channel
-// chunks as THREE piece images [6][10][36 voxel columns: even x | odd x][8 bf16] (34.6 KB each, single-buffered: the next
+// chunks as THREE piece images [6][10][even / odd x interleaved in runs of eight][8 bf16] (46 KB each, single-buffered: the next
 // stage's halo waits in registers as in conv_xp, two barriers per stage); the split happens once per staged element, after
 // the optional prologue (batch norm + ReLU of the producers, skip add).  Weights (three pieces per step, split on the host)
 // stream from L2 two steps ahead.  Sibling: K step i = taps 4 i + q of the 27 (7 steps), 2 rows per wavefront.
@@ -21,15 +21,23 @@
 
 #include "conv_common.h"
 
+// Development build (-DATVS_XB_DEBUG): per-wavefront cycle counts of the phases (tools_dev/phase_xw.py xb ...).
+#ifdef ATVS_XB_DEBUG
+__device__ unsigned long long atvs_dbg_xb[4096 * 8];
+extern "C" int atvs_debug_read_xw(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(atvs_dbg_xb), sizeof(atvs_dbg_xb));
+}
+#define XDBG(i) { unsigned long long t_ = clock64(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; }
+#else
+#define XDBG(i)
+#endif
+
 namespace {
 
 constexpr int XB_TZ = 4, XB_TY = 8, XB_TXV = 32;
 constexpr int XB_HZ = XB_TZ + 2, XB_HY = XB_TY + 2, XB_HX = XB_TXV + 2;
-constexpr int XB_HXP = 36;       // voxel columns per image row: even x in columns 0..16, odd x in columns XB_ODD..XB_ODD+16
-constexpr int XB_ODD = 18;
-constexpr int XB_VB = 16;        // bytes per voxel of one piece image (8 bf16)
-constexpr int XB_ROWB = XB_HXP * XB_VB;                     // 576
-constexpr int XB_IMG = XB_HZ * XB_HY * XB_ROWB;             // 34,560 bytes per piece
+constexpr int XB_ROWB = 3 * 256;                            // an image row: 17 even-x + 17 odd-x voxels, see xb_col
+constexpr int XB_IMG = XB_HZ * XB_HY * XB_ROWB;             // 46,080 bytes per piece
 constexpr int XB_SLOTS = XB_HZ * XB_HY * XB_HX * 2;         // float4 slots of the fp32 halo of a chunk
 constexpr int XB_MAXS = (XB_SLOTS + 255) / 256;             // 16 per thread
 constexpr int XB_JC = 9;                                    // main K steps per chunk: (kd, kh)
@@ -72,6 +80,13 @@ struct XbArgs {
   long cstride;
 };
 
+// Byte offset inside an image row of the voxel with x parity `par` and index i = x / 2 (0..16): even and odd voxels
+// alternate in 128-byte runs of eight.  A fragment read takes lane group q to parity q & 1, index (q >> 1) + r; with this
+// interleave the 16 lanes of every ds_read_b128 lane group ({0-3,12-15 | 20-27}, ...: MI355X_MICROARCH.md) cover all 64
+// banks once -- with the even | odd column split of conv_xp.hip (16-byte voxels) every fragment read was 2-way conflicted
+// (PMC: half of the LDS cycles).
+__device__ __forceinline__ constexpr int xb_col(int par, int i) { return (i >> 3) * 256 + par * 128 + (i & 7) * 16; }
+
 // the three bf16 pieces of four fp32 values
 __device__ __forceinline__ void xb_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
   const float x[4] = {v.x, v.y, v.z, v.w};
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
   // offset xl = q; piece images XB_IMG apart (one base each: the displacements exceed the 16-bit immediate otherwise)
   int fb[3];
 #pragma unroll
-  for (int pc = 0; pc < 3; ++pc) fb[pc] = pc * XB_IMG + ((wave * XB_HY) * XB_HXP + (q & 1) * XB_ODD + (q >> 1) + r) * XB_VB;
+  for (int pc = 0; pc < 3; ++pc) fb[pc] = pc * XB_IMG + (wave * XB_HY) * XB_ROWB + xb_col(q & 1, (q >> 1) + r);
   // sibling: this lane's tap of step i is 4 i + q (taps past 26: zero weights, tap 26's fragment); per-step byte offsets
   int sd[SIB ? XB_J2 : 1];
   if (SIB) {
@@ -110,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
       const int tap = min(4 * i + q, 26);
       const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
       const int xh = kw + 1 - p.pbx;                                  // halo x of output column 0
-      sd[i] = ((row0 + kd * XB_HY + kh) * XB_HXP + (xh & 1) * XB_ODD + (xh >> 1) + r) * XB_VB;
+      sd[i] = (row0 + kd * XB_HY + kh) * XB_ROWB + xb_col(xh & 1, (xh >> 1) + r);
     }
   }
 
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     const int xx = v % XB_HX, v2 = v / XB_HX;
     const int yy = v2 % XB_HY, zz = v2 / XB_HY;
     goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.vstride + c4 * 4;
-    laddr[i] = ((zz * XB_HY + yy) * XB_HXP + (xx & 1) * XB_ODD + (xx >> 1)) * XB_VB + c4 * 8;
+    laddr[i] = (zz * XB_HY + yy) * XB_ROWB + xb_col(xx & 1, xx >> 1) + c4 * 8;
     pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
   }
   const bool last_live = tid + (MAXS - 1) * 256 < XB_SLOTS;
@@ -248,8 +263,13 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
   }
 
+#ifdef ATVS_XB_DEBUG
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
   for (int stage = 0; stage < nstage; ++stage) {
     const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    XDBG(0)
     if (ch == 0) {
 #pragma unroll
       for (int t = 0; t < XB_TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -265,6 +285,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
       for (int pc = 0; pc < 3; ++pc) A[s][pc] = wch[(s * 3 + pc) * 64];
 
     __syncthreads();                       // every wavefront is done reading the previous stage's images
+    XDBG(5)
     if (PRO >= 1) {
       const Par P0 = load_par(ch);
 #pragma unroll
@@ -279,7 +300,9 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
         *reinterpret_cast<bf16x4*>(smem + XB_IMG + laddr[i]) = p1;
         *reinterpret_cast<bf16x4*>(smem + 2 * XB_IMG + laddr[i]) = p2;
       }
+    XDBG(1)
     __syncthreads();
+    XDBG(6)
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
     const bool last_chunk = (ch == p.nchunk - 1);
@@ -300,20 +323,23 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
 
     // ---- main K loop: 9 steps (kd, kh) x 3 phases (input piece pc with the weight pieces jw <= 2 - pc: 24 / 16 / 8 MFMAs);
     // the fragments of ONE input piece are live at a time, requested one phase ahead
-    bf16x8 Bq[2][XB_TY], B2[2][2];
+    bf16x8 Bq[2][XB_TY], B2[2][3][2];
     auto request_B = [&](int ph) __attribute__((always_inline)) {
       const int s = ph / 3, pc = ph % 3;
       const int off = ((s / 3) * XB_HY + (s % 3)) * ROWB;
 #pragma unroll
       for (int t = 0; t < XB_TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + fb[pc] + (off + t * ROWB));
     };
-    auto request_B2 = [&](int ph) __attribute__((always_inline)) {
-      const int i = ph / 3, pc = ph % 3;
+    auto request_B2 = [&](int i) __attribute__((always_inline)) {         // the three pieces of sibling step i (12 MFMAs)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) B2[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * XB_IMG + sd[i] + 2 * t * ROWB);
+      for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+          B2[i & 1][pc][t] = *reinterpret_cast<const bf16x8*>(smem + pc * XB_IMG + sd[i] + 2 * t * ROWB);
     };
     request_B(0);
     asm volatile("" ::: "memory");
+    XDBG(0)
 #pragma unroll
     for (int ph = 0; ph < 3 * JC; ++ph) {
       const int s = ph / 3, pc = ph % 3;
@@ -344,16 +370,17 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][jw], Bq[ph & 1][t], acc[t], 0, 0, 0);
       }
     }
+    XDBG(2)
     if (SIB) {
+      // one phase per step here: with two rows per wavefront a per-piece phase would be 2-6 MFMAs long
 #pragma unroll
-      for (int ph = 0; ph < 3 * J2; ++ph) {
-        const int i = ph / 3, pc = ph % 3;
-        if (pc == 0 && i + XB_LOOK < J2) {
+      for (int i = 0; i < J2; ++i) {
+        if (i + XB_LOOK < J2) {
 #pragma unroll
           for (int w3 = 0; w3 < 3; ++w3) A2[i + XB_LOOK][w3] = wch2[((i + XB_LOOK) * 3 + w3) * 64];
         }
-        if (ph + 1 < 3 * J2) request_B2(ph + 1);
-        if (ph == 3 * J2 - 9) {       // the epilogues' depth-plane biases, behind the last weight request of the stage
+        if (i + 1 < J2) request_B2(i + 1);
+        if (i == J2 - 3) {            // the epilogues' depth-plane biases, behind the last weight request of the stage
           const bool use = last_chunk && pbg;
 #pragma unroll
           for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((use && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
@@ -365,14 +392,17 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int jw = 0; jw < 3; ++jw) {
-          if (jw > 2 - pc) continue;
+        for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
-            acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[i][jw], B2[ph & 1][t], acc2[t], 0, 0, 0);
-        }
+          for (int jw = 0; jw < 3; ++jw) {
+            if (jw > 2 - pc) continue;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+              acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[i][jw], B2[i & 1][pc][t], acc2[t], 0, 0, 0);
+          }
       }
     }
+    XDBG(3)
     if (!last_chunk) continue;
 
     // ---- epilogue (conv_xp.hip): this lane holds channels co..co+3 of voxel xo for the 8 rows of plane zo
@@ -408,7 +438,14 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
         ssq2[0] += v.x * v.x; ssq2[1] += v.y * v.y; ssq2[2] += v.z * v.z; ssq2[3] += v.w * v.w;
       }
     }
+    XDBG(4)
   }
+#ifdef ATVS_XB_DEBUG
+  if (lane == 0 && blockIdx.x < 1024) {
+    dbg_acc[7] = (unsigned long long)nstage;
+    for (int i = 0; i < 8; ++i) atvs_dbg_xb[(blockIdx.x * 4 + wave) * 8 + i] = dbg_acc[i];
+  }
+#endif
   __syncthreads();
 
   // ---- per-workgroup partial moments -> row `srow` of stats: [2][16] doubles (columns 0..7 = channels), as conv_xp.hip

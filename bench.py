@@ -64,8 +64,9 @@ WORKLOADS = {          # name: (views, width, height, depths)
 DOMINANT = ('conv_b0_0_1/conv3d/kernel', 'var')   # the D-varying half of conv_b0_0_1 (see ops.conv_split)
 WARP = ('warp', 0)                                 # atvs_warp_planes, bilinear (the cost-volume build)
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense BF16 MFMA
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md, HBM3E peak (6.29 TB/s achievable by a float4 copy)
-PMC_FILE = os.path.join('profiles', 'round3_pmc_xw.json')
+PMC_FILE = os.path.join('profiles', 'round3_pmc_xpair.json')
 KERNEL_STATS_FILE = os.path.join('profiles', 'round3_bench_kernel_stats.csv')
 
 
@@ -340,15 +341,16 @@ def cpu_baseline(args):
 
 def pmc_traffic(args, samples):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS kernel as bench.py
-    launches it (profiles/round3_pmc_xw.json: conv_xw_kernel<true,0>, 8 volumes per launch, 640x512x192; only valid for
-    that form).  FETCH_SIZE on gfx950 counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md, HBM) and
+    launches it (profiles/round3_pmc_xpair.json: the dominant x-pair launch, 8 volumes per launch, 640x512x192; only valid
+    for that form and that kernel).  FETCH_SIZE on gfx950 counts wide coalesced reads at half their bytes (MI355X_MICROARCH.md, HBM) and
     is uncalibrated for this kernel's 32-byte pieces: the raw and the doubled figure are both given."""
     if (args.width, args.height, args.depths) != (640, 512, 192):
         return None
     try:
         with open(os.path.join(ROOT, PMC_FILE)) as f:
             d = json.load(f)['dominant']
-        if int(d['volumes_per_launch']) != int(samples):
+        from atvsnet_amd import ops
+        if int(d['volumes_per_launch']) != int(samples) or ('conv_%s_kernel' % ops._xkind()) not in d['kernel']:
             return None
         return {'write': int(d['write_bytes']), 'fetch_raw': int(d['fetch_bytes_raw']), 'fetch_x2': 2 * int(d['fetch_bytes_raw']),
                 'source': PMC_FILE, 'measured_in_run': False}
@@ -605,11 +607,19 @@ def rank_main(args):
             flops, alg_bytes = flops * samples, int(alg_bytes * samples)
             ach = flops / (avg_ms * 1e-3) / 1e12
             tr = pmc_traffic(args, samples)
-            roof = {'bound': 'mfma', 'kernel': 'conv_xw_kernel<SIB> (conv_b0_0_1: 32 warped channels -> 8, 3x3x3, full resolution, '
-                                              'x-pair rows x Winograd F(2,3) along y, + sibling conv_b0_1_0: -> 16, stride 2; '
-                                              '%d volumes per launch)' % int(samples),
-                    'flops_convention': 'algorithmic = direct-convolution FLOPs (SURVEY 8d); the kernel issues 8/9 of them as '
-                                        'MFMA work (F(2,3): 2/3, x-pair rows: 4/3)',
+            kind = ops._xkind()
+            kdesc = {'xb': 'conv_xb_kernel<SIB> (x-pair rows on v_mfma_f32_16x16x32_bf16, every fp32 operand split into three bf16 '
+                           'pieces, six products, fp32 accumulation)',
+                     'xw': 'conv_xw_kernel<SIB> (x-pair rows x Winograd F(2,3) along y on v_mfma_f32_16x16x4_f32)',
+                     'xp': 'conv_xp_kernel<C4=4,SIB> (x-pair rows on v_mfma_f32_16x16x4_f32)'}[kind]
+            roof = {'bound': 'mfma', 'kernel': '%s: conv_b0_0_1 (32 warped channels -> 8, 3x3x3, full resolution) + sibling conv_b0_1_0 '
+                                              '(-> 16, stride 2), %d volumes per launch' % (kdesc, int(samples)),
+                    'flops_convention': 'achieved = ALGORITHMIC (direct fp32 convolution, SURVEY 8d) FLOPs / time, priced against the '
+                                        'fp32 matrix peak the path is specified in; ' +
+                                        ('the kernel issues 6 x 4/3 = 8 bf16 MFMA FLOPs per algorithmic FLOP (six piece products, x-pair '
+                                         'rows): see `issued_bf16`' if kind == 'xb' else
+                                         'the kernel issues 8/9 of them as MFMA work (F(2,3): 2/3, x-pair rows: 4/3)' if kind == 'xw' else
+                                         'the kernel issues 4/3 of them as MFMA work (x-pair rows)'),
                     'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                     'traffic': (tr['write'] + tr['fetch_x2']) if tr else None,
@@ -623,6 +633,15 @@ def rank_main(args):
                     if tr else None,
                     'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[DOMINANT]), 'volumes_per_launch': samples,
                     'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg_bytes}
+            if kind == 'xb':
+                # main: 9 steps x 6 products per (8-channel chunk, 16 pairs x row): 2*16*16*32 FLOP each = 8 x the useful
+                # fp32 FLOPs (x-pair zero taps 4/3, six products); sibling: 7 steps of 4 taps for 27 -> 28/27 x 6
+                main = 2.0 * 27 * 32 * 8 * vox * samples
+                sibf = (flops - main)
+                issued = main * 8.0 + sibf * 6.0 * 28.0 / 27.0
+                roof['issued_bf16'] = {'flops_per_launch': issued, 'achieved': round(issued / (avg_ms * 1e-3) / 1e12, 1),
+                                       'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                       'frac': round(issued / (avg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
         if watched.get(WARP):
             # plane-sweep warp of the 32-channel source features into the D-varying half of the cost volume:
             # algorithmic bytes = write D*h*w*32*4 + read h*w*32*4

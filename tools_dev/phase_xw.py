@@ -48,8 +48,11 @@ assert rc == 0
 b = buf.reshape(-1, 8).astype(np.float64)
 b = b[b[:, 7] > 0]
 ns = b[:, 7].mean()
-tot = b[:, :6].sum(1).mean()
+NP = 7 if os.environ.get('XB') else 6
+tot = b[:, :NP].sum(1).mean()
 print('%s: waves %d, stages per wave %.0f, mean cycles per stage %.0f (s_memtime ticks = 100 MHz x ? -- ratios matter)' % (which, len(b), ns, tot / ns))
 names = ['loop top (+acc zero)', 'stage setup (pf_tile, addresses)', 'main K loop (%d MFMAs)' % mf[0], 'sibling K loop (%d MFMAs)' % mf[1], 'epilogue (every nchunk-th stage)', 'barrier']
+if os.environ.get('XB'):
+    names = ['setup (tile, addresses, first fragments)', 'transform + split + LDS write', 'main K loop (432 MFMAs x 16 cyc)', 'sibling K loop (84 MFMAs x 16 cyc)', 'epilogue', 'barrier 1 (others done reading)', 'barrier 2 (images written)']
 for i, n in enumerate(names):
     print('%-40s %9.0f per stage (%.1f%%)' % (n, b[:, i].mean() / ns, 100 * b[:, i].mean() / tot))
