@@ -609,11 +609,11 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
                                 float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
                                 int relu, const unsigned char* packed_w2, const float* plane_bias2, float* y2,
                                 double* stats_partial2, int ldy2, int y_coff2, const float* x2, const float* in_params,
-                                const float* in_params2, int in_relu, int in_relu2, int x_planar, atvs_stream_t stream) {
+                                const float* in_params2, int in_relu, int in_relu2, long x_planar, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (in_params2 && !x2) return ATVS_ERR_ARG;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8)) return ATVS_ERR_SHAPE;
-  if (x_planar && (x2 || in_params)) return ATVS_ERR_ARG;
+  if (x_planar && (x2 || in_params || x_planar < (long)D * H * W * 8)) return ATVS_ERR_ARG;
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if (plane_bias && D < 2) return ATVS_ERR_ARG;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
@@ -637,14 +637,14 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
   a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
   a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;
   a.wg = (int)atvs_conv_xp_grid(D, H, W, groups);
-  a.gx = (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
+  a.gx = x_planar ? x_planar * (Cin / 8) : (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
   a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
   const long blocks = (long)a.wg * groups;
   hipStream_t st = as_stream(stream);
   a.sample_major = (groups == 8) ? 1 : 0;
   a.x2 = x2; a.in_pa = in_params; a.in_pb = in_params2; a.relu_a = in_relu; a.relu_b = in_relu2;
   a.vstride = x_planar ? 8 : Cin;
-  a.cstride = x_planar ? (long)D * H * W * 8 : 8;
+  a.cstride = x_planar ? x_planar : 8;
   const int pro = x2 ? 2 : (in_params ? 1 : 0);
   int rc;
   if (pro == 0) rc = packed_w2 ? launch_xb<true, 0>(a, blocks, st) : launch_xb<false, 0>(a, blocks, st);

@@ -239,11 +239,12 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
 
 extern "C" int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
                                 const float* depth_start, const float* depth_interval, float* out, float* mask_out,
-                                int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, int planar,
+                                int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, long planar,
                                 atvs_stream_t stream) {
   if (!src || !homographies || !out) return ATVS_ERR_NULL;
   if (planar && (mode != 0 || (C != 16 && C != 32 && C != 64) || ld_out != C || c_off != 0)) return ATVS_ERR_ARG;
-  const long plane_stride = planar ? (long)D * h * w * 8 : 0;
+  if (planar && planar < (long)D * h * w * 8) return ATVS_ERR_ARG;
+  const long plane_stride = planar;       // floats between the 8-channel chunk planes (>= D*h*w*8; callers pad it)
   if (D <= 0 || h <= 0 || w <= 0 || C <= 0 || ld_out < C || c_off < 0) return ATVS_ERR_SHAPE;
   if (mode == 1 && !ref) return ATVS_ERR_NULL;
   if (mode == 2 && (C != 1 || !depth_start || !depth_interval || rep < 1 || c_off + rep > ld_out)) return ATVS_ERR_SHAPE;

@@ -77,18 +77,19 @@ WARP_NEAREST = 3      # atvs_warp_planes mode: nearest-neighbour sampling (inclu
 def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=None, depth_start=None,
                 depth_interval=None, rep=1, want_mask=False, planar=False):
     """src (h,w,C), homographies (D,3,3) -> out (D,h,w,ld_out) [, mask (D,h,w)].
-    planar=True (plain warp, C in {16,32,64}): out is chunk-planar (C/8, D, h, w, 8) -- the layout the Winograd x-pair
-    kernel reads as dense 32-byte voxels (SplitVolume(planar=True))."""
+    planar=True (plain warp, C in {16,32,64}): out is chunk-planar, a PlanarVolume-shaped (C/8, plane_floats(D,h,w)) buffer
+    whose rows hold (D,h,w,8) -- the layout the x-pair kernels read as dense 32-byte voxels (SplitVolume(planar=True))."""
     h, w, C = src.shape
     D = homographies.shape[0]
     width = rep if mode == 2 else C
     if planar:
         if mode != 0 or C not in (16, 32, 64) or c_off != 0:
             raise ValueError('warp_planes(planar=True): plain warp of 16 / 32 / 64 channels')
+        pstride = planar_stride(D, h, w)
         if out is None:
-            out = _new(src, (C // 8, D, h, w, 8))
-        elif tuple(out.shape) != (C // 8, D, h, w, 8) or not out.is_contiguous():
-            raise ValueError('warp_planes(planar=True): out must be a contiguous (C/8, D, h, w, 8) tensor')
+            out = _new(src, (C // 8, pstride))
+        elif tuple(out.shape) != (C // 8, pstride) or not out.is_contiguous():
+            raise ValueError('warp_planes(planar=True): out must be a contiguous (C/8, planar_stride(D,h,w)) tensor')
         ld_out = C
     elif out is None:
         ld_out = width if ld_out is None else ld_out
@@ -99,7 +100,8 @@ def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=N
     if _dev_ok(src, homographies, out, ref, depth_start, depth_interval):
         with _Timed(('warp', int(mode)), (D, h, w, C), width):
             _call('atvs_warp_planes', _p(src), _p(homographies), _p(ref), _p(depth_start), _p(depth_interval),
-                  _p(out), _p(mask), D, h, w, C, int(ld_out), int(c_off), int(mode), int(rep), int(bool(planar)), _stream())
+                  _p(out), _p(mask), D, h, w, C, int(ld_out), int(c_off), int(mode), int(rep),
+                  ctypes.c_long(planar_stride(D, h, w) if planar else 0), _stream())
     return (out, mask) if want_mask else out
 
 
@@ -347,6 +349,20 @@ def use_planar(flag):
     _USE_PLANAR = bool(flag)
 
 
+PLANAR_PAD = int(os.environ.get('ATVS_PLANAR_PAD', 4096 + 64))         # floats between chunk planes beyond D*h*w*8: 16.25 KiB, so that the C/8 write streams of the
+                               # warp (same offset in every plane) do not all start on the same HBM channel / bank
+
+
+def planar_stride(D, h, w):
+    """Floats between the 8-channel chunk planes of a chunk-planar volume."""
+    return D * h * w * 8 + PLANAR_PAD
+
+
+def planar_view(buf, D, h, w):
+    """(.., K, planar_stride) chunk-planar buffer -> the (.., K, D, h, w, 8) view of its planes."""
+    return buf[..., :D * h * w * 8].unflatten(-1, (D, h, w, 8))
+
+
 def planar_cost_volume_ok(shape, F):
     """Should build_cost_volumes write the warped half chunk-planar?  Only when its one consumer -- the x-pair launch of
     conv_b0_0_1 | conv_b0_1_0 -- is the Winograd kernel."""
@@ -448,12 +464,13 @@ _USE_BF16X3 = os.environ.get('ATVS_BF16X3', '1') == '1'      # ATVS_BF16X3=0: ev
 
 
 def use_bf16x3(flag):
-    """The 8 / 16 -> 16 channel 3x3x3 convolutions on the bf16 matrix cores with split operands (x = x0 + x1 + x2, six
-    products, fp32 accumulation: conv_c16b.hip; default) or on the fp32 matrix cores (conv_c16.hip).  Default on since
+    """The split-bf16 kernels (x = x0 + x1 + x2, six products, fp32 accumulation; default) or their fp32-MFMA forms: the
+    8 / 16 -> 16 channel 3x3x3 convolutions (conv_c16b.hip | conv_c16.hip) and the 8-output-channel x-pair layers
+    (conv_xb.hip | conv_xw.hip; use_xb switches those alone).  Default on since
     every full-size oracle fixture passes with it at the unchanged 1e-3 bar and its per-layer error against a float64
     evaluation equals the fp32 MFMA kernel's (tests/test_gpu_conv.py::test_conv_c16b_split_bf16_matches_oracle)."""
-    global _USE_BF16X3
-    _USE_BF16X3 = bool(flag)
+    global _USE_BF16X3, _USE_XB
+    _USE_BF16X3 = _USE_XB = bool(flag)
 
 
 def pack_conv_c16b(key, w_host, device):
@@ -672,7 +689,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
     prologue = (x2 | None, params | None, params2 | None, relu, relu2): the input is formed on load as
     act(bn(x5)) [+ act(bn(x2))] (include/atvsnet_hip.h)."""
     if planar:
-        G, K, D, H, W, _ = x5.shape
+        (G, K), (D, H, W) = x5.shape[:2], planar
         Cin = K * 8
     else:
         G, D, H, W, Cin = x5.shape
@@ -699,7 +716,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
                     sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _p(x2), _p(ipa), _p(ipb),
                     int(bool(relu_a)), int(bool(relu_b))]
             if xw:
-                _call('atvs_conv_%s_f32' % kind, *(args + [int(bool(planar)), _stream()]))
+                _call('atvs_conv_%s_f32' % kind, *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0), _stream()]))
             else:
                 _call('atvs_conv_xp_f32', *(args + [_stream()]))
 
@@ -1173,12 +1190,13 @@ class SplitVolume(object):
     materialising the tiled parts.  var: (B,D,h,w,Cv); const: (B,h,w,Cc) (B = independent samples; a 4-D var /
     3-D const is one sample); chan_map: for each channel of the reference's concat, ('v', i) or ('c', i) --
     several channels may map to the same source (the 16 identical geo-view channels, quirk C7).
-    planar=True: var is stored chunk-planar, (B, Cv/8, D, h, w, 8) (warp_planes(planar=True)): conv_split_siblings hands
-    it to the Winograd x-pair kernel as it is, every other consumer gets the channel-last copy var_cl() makes."""
+    planar=(D,h,w): var is stored chunk-planar, a (B, Cv/8, planar_stride(D,h,w)) buffer whose rows hold (D,h,w,8)
+    (warp_planes(planar=True)): conv_split_siblings hands it to the x-pair kernel as it is, every other consumer gets the
+    channel-last copy var_cl() makes."""
 
     def __init__(self, var, const, chan_map, planar=False):
-        self.planar = bool(planar)
-        if var.dim() == (5 if self.planar else 4):
+        self.planar = tuple(int(v) for v in planar) if planar else False
+        if var.dim() == (2 if self.planar else 4):
             var, const = var.unsqueeze(0), const.unsqueeze(0)
         self._var, self.const, self.chan_map = var, const, list(chan_map)
         self._cl = None
@@ -1193,8 +1211,9 @@ class SplitVolume(object):
         if not self.planar:
             return self._var
         if self._cl is None:
-            B, K, D, h, w, _ = self._var.shape
-            self._cl = self._var.permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, K * 8).contiguous()
+            B, K = self._var.shape[:2]
+            D, h, w = self.planar
+            self._cl = planar_view(self._var, D, h, w).permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, K * 8).contiguous()
         return self._cl
 
     @property
@@ -1205,7 +1224,7 @@ class SplitVolume(object):
     @property
     def shape(self):
         if self.planar:
-            B, _, D, h, w, _ = self._var.shape
+            B, (D, h, w) = self._var.shape[0], self.planar
         else:
             B, D, h, w, _ = self._var.shape
         return (B, D, h, w, len(self.chan_map))
@@ -1328,10 +1347,12 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
         if not siblings_prologue_ok(x):
             raise ValueError('conv_siblings: this lazy input must be materialised first')
         x, prologue = x.prologue()
-    if planar:             # x: (G, Cin/8, D, H, W, 8), chunk-planar (SplitVolume(planar=True)); Winograd x-pair kernel only
-        if prologue is not None or _xkind() == 'xp' or groups is None or x.dim() != 6 or not x.is_contiguous():
-            raise ValueError('conv_siblings(planar=True): a contiguous (G, Cin/8, D, H, W, 8) tensor, no prologue')
-        G, K, D, H, W, _ = x.shape
+    if planar:             # x: (G, Cin/8, planar_stride(D,H,W)) chunk-planar buffer, planar = (D,H,W); not the direct fp32 kernel
+        D, H, W = planar
+        if prologue is not None or _xkind() == 'xp' or groups is None or x.dim() != 3 or not x.is_contiguous() \
+                or x.shape[2] != planar_stride(D, H, W):
+            raise ValueError('conv_siblings(planar=(D,H,W)): a contiguous (G, Cin/8, planar_stride) buffer, no prologue')
+        G, K = x.shape[:2]
         x5, nsp, cin = x, 3, K * 8
     else:
         x5, nsp = _to5(x, groups, 'conv_siblings input')
@@ -1371,7 +1392,7 @@ def conv_split_siblings(sv, key, w_host, key2, w2_host):
     pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2, groups=B)
     if sv.planar and _xkind() != 'xp':
         return conv_siblings(sv._var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B,
-                             planar=True)
+                             planar=sv.planar)
     return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B)
 
 

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 16
+#define ATVS_ABI_VERSION 17
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -63,11 +63,12 @@ int atvs_get_homographies(const float* left_cam, const float* right_cam, const f
  *   mode 3: nearest-neighbour warp (homography_warping.py:45-56: tf.round half-to-even,
  *           out-of-range pixels read source pixel (0,0) and are NOT zeroed; mask_out tells).
  *   planar != 0 (mode 0, C in {16, 32, 64}, ld_out == C, c_off == 0): out is written chunk-planar,
- *           [C/8][D][h][w][8] -- the layout atvs_conv_xw_f32 reads with x_planar (dense 32-byte voxels per
- *           8-channel chunk); same values, another place. */
+ *           [C/8] planes of [D][h][w][8], `planar` floats apart (>= D*h*w*8; pad it so that the planes do not start
+ *           on the same HBM channel) -- the layout atvs_conv_xw_f32 / _xb_f32 read with x_planar (dense 32-byte
+ *           voxels per 8-channel chunk); same values, another place. */
 int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
                      const float* depth_start, const float* depth_interval, float* out, float* mask_out,
-                     int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, int planar,
+                     int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, long planar,
                      atvs_stream_t stream);
 
 /* build_cost_volume, model.py:157-200: tf.tile(ref) ++ stack_d(warp_d(view)) ->
@@ -266,7 +267,8 @@ int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, c
  * [d0-d2, d1+d2, d2-d1, d1-d3] in registers from the raw rows staged in LDS (8-channel chunks, double-buffered image).
  * Results differ from the direct sum by fp32 rounding only (one 32 -> 8 layer: 7.7e-7 of the output maximum against
  * 4.2e-7 for atvs_conv_xp_f32).  Weights must be packed with atvs_conv_xw_pack / _pack_sibling (NOT the xp forms).
- * x_planar != 0 (no prologue): x is chunk-planar [Cin/8][D][H][W][8] per sample, as atvs_warp_planes writes it with planar. */
+ * x_planar != 0 (no prologue): x is chunk-planar per sample, Cin/8 planes of [D][H][W][8] x_planar floats apart, as
+ * atvs_warp_planes writes it with the same `planar` (sample stride = x_planar * Cin / 8). */
 int atvs_conv_xw_pack_size(int Cin, long* packed_floats);
 int atvs_conv_xw_pack(const float* w, int Cin, float* packed);
 int atvs_conv_xw_pack_sibling_size(int Cin, long* packed_floats);
@@ -275,7 +277,7 @@ int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, c
                      double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
-                     int in_relu2, int x_planar, atvs_stream_t stream);
+                     int in_relu2, long x_planar, atvs_stream_t stream);
 
 /* The same layers (same contract as atvs_conv_xw_f32, x_planar included) on the bf16 matrix cores with SPLIT operands
  * (conv_xb.hip): every fp32 operand = three bf16 pieces, the six products x_i * w_j with i + j <= 2 accumulated in fp32 by
@@ -290,7 +292,7 @@ int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, const float*
                      double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const unsigned char* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
-                     int in_relu2, int x_planar, atvs_stream_t stream);
+                     int in_relu2, long x_planar, atvs_stream_t stream);
 
 /* 3x3 stride-1 SAME 2-D convolution (dilation 1, 2 or 4) of wide feature maps, LDS-tiled (conv2d_lds.hip): the
  * heavy layers of the feature towers -- the bottlenecks' conv2 (slim.conv2d, network.py:585-587), conv0_1 / conv0_2 /

@@ -360,10 +360,10 @@ def test_planar_cost_volume_is_bitwise_the_channel_last_one(cuda, B, D, h, w):
     const = _rand((B, h, w, F), 91).to(cuda)
     cl = torch.stack([ops.warp_planes(feats[b], Hm) for b in range(B)])
     pl = torch.stack([ops.warp_planes(feats[b], Hm, planar=True) for b in range(B)])
-    assert tuple(pl.shape) == (B, F // 8, D, h, w, 8)
-    assert torch.equal(pl.permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, F), cl)
+    assert tuple(pl.shape) == (B, F // 8, ops.planar_stride(D, h, w))            # padded chunk planes
+    assert torch.equal(ops.planar_view(pl, D, h, w).permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, F), cl)
     cmap = [('c', i) for i in range(F)] + [('v', i) for i in range(F)]
-    sv_cl, sv_pl = ops.SplitVolume(cl, const, cmap), ops.SplitVolume(pl, const, cmap, planar=True)
+    sv_cl, sv_pl = ops.SplitVolume(cl, const, cmap), ops.SplitVolume(pl, const, cmap, planar=(D, h, w))
     assert sv_pl.shape == sv_cl.shape and sv_pl.cv == F
     w8, w16 = (_rand((3, 3, 3, 2 * F, 8), 92) * 0.1).numpy(), (_rand((3, 3, 3, 2 * F, 16), 93) * 0.1).numpy()
     (y, st), (y2, st2) = ops.conv_split_siblings(sv_pl, 'pl8', w8, 'pl16', w16)
