@@ -1,0 +1,384 @@
+// 3x3 (dilated) stride-1 SAME 2-D convolution of wide feature maps on the bf16 matrix cores with SPLIT operands (gfx950):
+// conv2d_lds.hip's layers (the bottlenecks' conv2, conv0_1 / conv0_2, fusion0 of the 2-D feature towers,
+// /root/reference/cnn_wrapper/atvsnet.py:254-292, network.py:198-200,585-587) with every fp32 operand split into three bf16
+// pieces, the six products x_i * w_j (i + j <= 2) accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (conv_c16b.hip has the
+// arithmetic and its error measurements: fp32-class).
+//
+// Structure = conv2d_lds.hip (one workgroup per tile of R x 16 pixels of one image, the WAVES SPLIT THE OUTPUT CHANNELS and share
+// the pixels, two LDS buffers, the next 16-channel chunk's halo fetched one slot per phase and written after the loop, optional
+// normalise-on-load, same epilogue / statistics rows) with: a K = 32 step = two taps x 16 channels (lane half q >> 1 picks the
+// tap: 5 steps per chunk, the 10th tap has zero weights); three piece images per buffer (32-byte pixels, row pitch 768 B:
+// conflict-free ds_read_b128 without a swizzle); the split done once per staged element on its way into LDS; three phases per
+// step (input piece pc with the weight pieces jw <= 2 - pc), the weight pieces (three per step and output tile, split by the
+// host packer) streamed from L2 one step ahead.
+#include <cstring>
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int C2B_PITCH = 24;                 // pixels per LDS row (16 + 2 * 4)
+constexpr int C2B_ROWB = C2B_PITCH * 32;      // bytes per row of one piece image (16 channels x 2 B per pixel)
+constexpr int C2B_JS = 5;                     // K steps per 16-channel chunk: taps 2 j + (q >> 1) of the 9 (10th = zero)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct C2bArgs {
+  const float* x;
+  const bf16x8* wp;
+  const float* bias;
+  const float* res;
+  const float* in_params;
+  float* y;
+  double* stats;
+  int G, H, W, Cin, Cout;
+  int ldy, ycoff;
+  int nchunk;
+  int tiles_x, tiles;
+  int relu, in_relu;
+  long gx, gy;
+  long total;
+};
+
+__device__ __forceinline__ void c2b_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    (*p0)[i] = a;
+    (*p1)[i] = b;
+    (*p2)[i] = (__bf16)r2;
+  }
+}
+
+// NTW = 16-channel output tiles per wave, WR = row groups across the waves (4 / WR waves split the channels),
+// TY = rows per wave, DIL = dilation.  Cout = 16 * NTW * (4 / WR); tile = (TY * WR) rows x 16 columns.
+template <int NTW, int WR, int TY, int DIL>
+__global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int R = TY * WR;
+  constexpr int HR = R + 2 * DIL, HC = 16 + 2 * DIL;
+  constexpr int SLOTS = HR * HC * 4;
+  constexpr int MAXS = (SLOTS + 255) / 256;
+  constexpr int PIMG = HR * C2B_ROWB;          // bytes of one piece image
+  constexpr int BUFB = 3 * PIMG;
+  constexpr int WN = 4 / WR;
+  constexpr int NT = NTW * WN;
+  constexpr int JS = C2B_JS;
+  static_assert(MAXS <= 3 * JS, "one halo slot per phase");
+  static_assert(HC <= C2B_PITCH, "row pitch");
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wn = wave % WN, wr = wave / WN;
+
+  const long per = (p.total + 7) >> 3;
+  const long lin = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  if (lin >= p.total) return;
+  const int g = (int)(lin / p.tiles), tile = (int)(lin % p.tiles);
+  const int y0 = (tile / p.tiles_x) * R, x0 = (tile % p.tiles_x) * 16;
+
+  // ---- halo slots of this thread: float4 = channels 4 c4 .. of a pixel of the fp32 chunk -> 8 bytes of each piece image
+  const float* xg = p.x + (size_t)g * p.gx;
+  int goff[MAXS], laddr[MAXS];
+  unsigned valid = 0;
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < SLOTS;
+    s = min(s, SLOTS - 1);
+    const int c4 = s & 3, v = s >> 2;
+    const int xx = v % HC, yy = v / HC;
+    const int gy = y0 - DIL + yy, gxx = x0 - DIL + xx;
+    const bool ok = live && (unsigned)gy < (unsigned)p.H && (unsigned)gxx < (unsigned)p.W;
+    goff[i] = ok ? ((gy * p.W + gxx) * p.Cin + c4 * 4) : 0;
+    laddr[i] = live ? ((yy * C2B_PITCH + xx) * 32 + c4 * 8) : -1;
+    valid |= (ok ? 1u : 0u) << i;
+  }
+  float4 pf[MAXS];
+  auto pf_slot = [&](int i, int ch) __attribute__((always_inline)) {
+    pf[i] = ((valid >> i) & 1u) ? ld4(xg + goff[i] + ch * 16) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto write_image = [&](int buf, int ch) __attribute__((always_inline)) {
+    const float* ip = p.in_params ? p.in_params + (size_t)g * 3 * p.Cin + ch * 16 : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      if (laddr[i] < 0) continue;
+      float4 v = pf[i];
+      if (ip && ((valid >> i) & 1u)) {
+        const int c = ((tid + i * 256) & 3) * 4;
+        const float4 m = ld4(ip + c), s = ld4(ip + p.Cin + c), b = ld4(ip + 2 * p.Cin + c);
+        v.x = (v.x - m.x) * s.x + b.x;
+        v.y = (v.y - m.y) * s.y + b.y;
+        v.z = (v.z - m.z) * s.z + b.z;
+        v.w = (v.w - m.w) * s.w + b.w;
+        if (p.in_relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      bf16x4 p0, p1, p2;
+      c2b_split(v, &p0, &p1, &p2);
+      unsigned char* d = smem + buf * BUFB + laddr[i];
+      *reinterpret_cast<bf16x4*>(d) = p0;
+      *reinterpret_cast<bf16x4*>(d + PIMG) = p1;
+      *reinterpret_cast<bf16x4*>(d + 2 * PIMG) = p2;
+    }
+  };
+
+  // ---- LDS read offsets: this lane's fragment (8 channels (q & 1) * 8 .. of a pixel) for its tap of step j, row 0 of its row
+  // group; taps past 8: zero weights, the 9th tap's fragment
+  int bd[JS];
+#pragma unroll
+  for (int j = 0; j < JS; ++j) {
+    const int tap = min(2 * j + (q >> 1), 8);
+    const int ky = tap / 3, kx = tap % 3;
+    bd[j] = ((wr * TY + ky * DIL) * C2B_PITCH + r + kx * DIL) * 32 + (q & 1) * 16;
+  }
+
+  // ---- packed weight pieces: [K step = chunk * 5 + j][NT tiles][3 pieces][64 lanes] bf16x8, zero steps at the end.  Two
+  // register slots, the pieces of step gs + 1 requested at the first phase of step gs (with two workgroups per CU the
+  // other wavefront of the SIMD covers what is left of the L2 latency); a chunk has 5 steps, so the slot parity flips from
+  // chunk to chunk: the chunk loop is unrolled by two (Cin / 16 is even for every shape the towers have).
+  const bf16x8* __restrict__ wl = p.wp + (size_t)(wn * NTW) * 3 * 64 + lane;
+  constexpr int WSTEP = NT * 3 * 64;
+  bf16x8 Aw[2][NTW][3];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n)
+#pragma unroll
+    for (int w3 = 0; w3 < 3; ++w3) Aw[0][n][w3] = wl[(n * 3 + w3) * 64];
+
+  f32x4 acc[TY][NTW];
+#pragma unroll
+  for (int t = 0; t < TY; ++t)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) pf_slot(i, 0);
+  write_image(0, 0);
+  __syncthreads();
+
+  bf16x8 Bq[2][TY];
+  auto chunk = [&](auto PAR, int ch) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value;                 // ch & 1: LDS buffer and weight-slot parity of the chunk
+    const unsigned char* lb = smem + par * BUFB;
+    const bool more = ch + 1 < p.nchunk;
+    const bf16x8* wc = wl + (size_t)ch * JS * WSTEP;
+    auto request_b = [&](int ph) __attribute__((always_inline)) {
+      const int j = ph / 3, pc = ph % 3;
+#pragma unroll
+      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(lb + pc * PIMG + bd[j] + t * C2B_ROWB);
+    };
+    request_b(0);
+#pragma unroll
+    for (int ph = 0; ph < 3 * JS; ++ph) {
+      const int j = ph / 3, pc = ph % 3;
+      const int slot = (par * JS + j) & 1;
+      if (pc == 0) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) Aw[slot ^ 1][n][w3] = wc[(size_t)(j + 1) * WSTEP + (n * 3 + w3) * 64];
+      }
+      if (ph + 1 < 3 * JS) request_b(ph + 1);
+      if (ph < MAXS && more) pf_slot(ph, ch + 1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jw = 0; jw < 3; ++jw) {
+        if (jw > 2 - pc) continue;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int t = 0; t < TY; ++t)
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Aw[slot][n][jw], Bq[ph & 1][t], acc[t][n], 0, 0, 0);
+      }
+    }
+    if (more) {
+      write_image(par ^ 1, ch + 1);          // the other buffer: last read in chunk ch - 1, behind the barrier below
+      __syncthreads();
+    }
+  };
+  for (int ch = 0; ch < p.nchunk; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    chunk(std::integral_constant<int, 1>{}, ch + 1);
+  }
+
+  // ---- epilogue: lane holds channels co..co+3 of pixel (y0 + wr*TY + t, x0 + r)
+  const int xo = x0 + r;
+  float ssum[NTW][4], ssq[NTW][4];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ssum[n][k] = ssq[n][k] = 0.f;
+  float* yg = p.y + (size_t)g * p.gy;
+  const float* rg = p.res ? p.res + (size_t)g * p.gy : nullptr;
+#pragma unroll
+  for (int t = 0; t < TY; ++t) {
+    const int yo = y0 + wr * TY + t;
+    if (yo >= p.H || xo >= p.W) continue;
+    const size_t rowb = ((size_t)yo * p.W + xo) * p.ldy + p.ycoff;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const int co = (wn * NTW + n) * 16 + 4 * q;
+      float4 v = make_float4(acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]);
+      if (p.bias) {
+        const float4 bb = ld4(p.bias + co);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (rg) {
+        const float4 rr = ld4(rg + rowb + co);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      if (p.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      st4(yg + rowb + co, v);
+      ssum[n][0] += v.x; ssum[n][1] += v.y; ssum[n][2] += v.z; ssum[n][3] += v.w;
+      ssq[n][0] += v.x * v.x; ssq[n][1] += v.y * v.y; ssq[n][2] += v.z * v.z; ssq[n][3] += v.w * v.w;
+    }
+  }
+  if (p.stats) {
+    // row (image, tile): [2][Cout] doubles.  Channels are private to a wave (WR == 1) or shared by the WR waves of
+    // a column of row groups (combined through LDS).
+    double* row = p.stats + (size_t)lin * 2 * p.Cout;
+    double* s_red = reinterpret_cast<double*>(smem);           // [wr][2][Cout], the images are dead
+    if (WR > 1) __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double a = (double)ssum[n][k], bq = (double)ssq[n][k];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o);
+          bq += __shfl_xor(bq, o);
+        }
+        if (r == 0) {
+          const int c = (wn * NTW + n) * 16 + 4 * q + k;
+          if (WR == 1) {
+            row[c] = a;
+            row[p.Cout + c] = bq;
+          } else {
+            s_red[(wr * 2 + 0) * p.Cout + c] = a;
+            s_red[(wr * 2 + 1) * p.Cout + c] = bq;
+          }
+        }
+      }
+    if (WR > 1) {
+      __syncthreads();
+      for (int i = tid; i < 2 * p.Cout; i += 256) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < WR; ++a) v += s_red[a * 2 * p.Cout + i];
+        row[i] = v;
+      }
+    }
+  }
+}
+
+template <int NTW, int WR, int TY, int DIL>
+int launch_c2b(const C2bArgs& a, hipStream_t s) {
+  constexpr int R = TY * WR, HR = R + 2 * DIL;
+  size_t lds = (size_t)2 * 3 * HR * C2B_ROWB;
+  const long blocks = ((a.total + 7) / 8) * 8;
+  if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL((conv2d_b_kernel<NTW, WR, TY, DIL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  return ATVS_OK;
+}
+
+float c2b_round(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  float o;
+  std::memcpy(&o, &u, 4);
+  return o;
+}
+uint16_t c2b_bits(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+// Bytes of the packed form of a TF kernel [3][3][Cin][Cout] for atvs_conv2d_b_f32 (the shapes atvs_conv2d_lds_supported takes).
+extern "C" int atvs_conv2d_b_pack_size(int Cin, int Cout, long* packed_bytes) {
+  if (!packed_bytes) return ATVS_ERR_NULL;
+  if (!atvs_conv2d_lds_supported(Cin, Cout, 1)) return ATVS_ERR_SHAPE;
+  *packed_bytes = (long)((Cin / 16) * C2B_JS + 1) * (Cout / 16) * 3 * 1024;
+  return ATVS_OK;
+}
+
+// HOST function.  packed[K step = chunk * 5 + j][tile n][piece][lane = q * 16 + co16][e] = piece of
+// w[tap = 2 j + (q >> 1)][chunk * 16 + (q & 1) * 8 + e][n * 16 + co16] (zero for tap 9); one zero K step of padding at the end (the weight slots read ahead).
+extern "C" int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed) {
+  if (!w || !packed) return ATVS_ERR_NULL;
+  long pb;
+  int rc = atvs_conv2d_b_pack_size(Cin, Cout, &pb);
+  if (rc) return rc;
+  std::memset(packed, 0, (size_t)pb);
+  uint16_t* out = reinterpret_cast<uint16_t*>(packed);
+  const int NT = Cout / 16, nch = Cin / 16;
+  for (int ch = 0; ch < nch; ++ch)
+    for (int j = 0; j < C2B_JS; ++j)
+      for (int n = 0; n < NT; ++n)
+        for (int q = 0; q < 4; ++q) {
+          const int tap = 2 * j + (q >> 1);
+          if (tap > 8) continue;
+          for (int co16 = 0; co16 < 16; ++co16)
+            for (int e = 0; e < 8; ++e) {
+              const int ci = ch * 16 + (q & 1) * 8 + e, co = n * 16 + co16;
+              const float v = w[((size_t)tap * Cin + ci) * Cout + co];
+              const float p0 = c2b_round(v), p1 = c2b_round(v - p0), p2 = c2b_round((v - p0) - p1);
+              const float pc[3] = {p0, p1, p2};
+              for (int k = 0; k < 3; ++k)
+                out[(((((size_t)(ch * C2B_JS + j) * NT + n) * 3 + k) * 64) + q * 16 + co16) * 8 + e] = c2b_bits(pc[k]);
+            }
+        }
+  return ATVS_OK;
+}
+
+// Same contract as atvs_conv2d_lds_f32 (shapes, statistics rows = atvs_conv2d_lds_rows) with split-bf16 operands; weights from
+// atvs_conv2d_b_pack.  fp32-class results; rounding differs from the fp32 MFMA form.
+extern "C" int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
+                                 const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H,
+                                 int W, int Cin, int Cout, int dilation, int ldy, int y_coff, int relu,
+                                 atvs_stream_t stream) {
+  if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (G <= 0 || H <= 0 || W <= 0 || !atvs_conv2d_lds_supported(Cin, Cout, dilation) || (Cin % 32)) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if (residual && y_coff != 0) return ATVS_ERR_ARG;
+  if ((double)H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
+  C2bArgs a;
+  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.bias = bias; a.res = residual; a.in_params = in_params;
+  a.y = y; a.stats = stats_partial;
+  a.G = G; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16;
+  const int R = (Cout == 32) ? 8 : 4;
+  a.tiles_x = (W + 15) / 16;
+  a.tiles = ((H + R - 1) / R) * a.tiles_x;
+  a.relu = relu; a.in_relu = in_relu;
+  a.gx = (long)H * W * Cin; a.gy = (long)H * W * ldy;
+  a.total = (long)G * a.tiles;
+  hipStream_t s = as_stream(stream);
+  int rc = ATVS_ERR_ARG;
+  if (Cout == 128) {
+    if (dilation == 1) rc = launch_c2b<2, 1, 4, 1>(a, s);
+    else if (dilation == 2) rc = launch_c2b<2, 1, 4, 2>(a, s);
+    else rc = launch_c2b<2, 1, 4, 4>(a, s);
+  } else if (Cout == 64) {
+    rc = launch_c2b<1, 1, 4, 1>(a, s);
+  } else {
+    rc = launch_c2b<1, 2, 4, 1>(a, s);
+  }
+  if (rc) return rc;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

@@ -579,24 +579,26 @@ def use_conv2d_lds(flag):
 def pack_conv2d_lds(key, w_host, device):
     """Packed weights of the LDS-tiled 2-D kernel for a TF kernel [3,3,Cin,Cout]; cached."""
     import numpy as np
-    ck = ('c2', key, str(device))
+    w = np.ascontiguousarray(w_host, dtype=np.float32)
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    split = _USE_BF16X3 and cin % 32 == 0          # conv2d_b.hip: split-bf16 operands (its chunk loop runs in pairs)
+    kind = 'b' if split else 'lds'
+    ck = ('c2' + kind, key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
-    w = np.ascontiguousarray(w_host, dtype=np.float32)
-    cin, cout = int(w.shape[-2]), int(w.shape[-1])
     L = _lib.lib()
     pf = ctypes.c_long()
-    rc = L.atvs_conv2d_lds_pack_size(cin, cout, ctypes.byref(pf))
+    rc = getattr(L, 'atvs_conv2d_%s_pack_size' % kind)(cin, cout, ctypes.byref(pf))
     if rc:
-        raise RuntimeError('atvs_conv2d_lds_pack_size failed (%d) for Cin=%d Cout=%d' % (rc, cin, cout))
-    packed = np.empty(pf.value, np.float32)
-    rc = L.atvs_conv2d_lds_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+        raise RuntimeError('atvs_conv2d_%s_pack_size failed (%d) for Cin=%d Cout=%d' % (kind, rc, cin, cout))
+    packed = np.empty(pf.value, np.uint8 if split else np.float32)
+    rc = getattr(L, 'atvs_conv2d_%s_pack' % kind)(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
-        raise RuntimeError('atvs_conv2d_lds_pack failed (%d)' % rc)
+        raise RuntimeError('atvs_conv2d_%s_pack failed (%d)' % (kind, rc))
     pk = _Packed()
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 9, 4, 0, cout // 16, cin, cout
-    pk.key = key
+    pk.key, pk.kind = key, kind
     pk.tab = None
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
     _pack_cache[ck] = pk
@@ -623,7 +625,7 @@ def conv2d_lds(x, key, w_host, dilation=1, bias=None, residual=None, relu=False,
         st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, pk.cout, H * W, G
     if _dev_ok(x, y, bias, residual, in_params):
         with _Timed(pk.key, (1, H, W, cin), pk.cout, G):
-            _call('atvs_conv2d_lds_f32', _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)),
+            _call('atvs_conv2d_%s_f32' % pk.kind, _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)),
                   _p(y), ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, H, W, cin,
                   pk.cout, int(dilation), int(y.shape[-1]), int(y_coff), int(bool(relu)), _stream())
     return (y, st) if want_stats else y

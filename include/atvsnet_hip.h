@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 17
+#define ATVS_ABI_VERSION 18
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -312,6 +312,15 @@ long atvs_conv2d_lds_rows(int H, int W, int Cout);
 int atvs_conv2d_lds_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
                         const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H, int W,
                         int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* The same layers (same contract, shapes with Cin % 32 == 0, statistics rows = atvs_conv2d_lds_rows) with split-bf16 operands
+ * (conv2d_b.hip: every fp32 operand = three bf16 pieces, six products, fp32 accumulation on v_mfma_f32_16x16x32_bf16; the
+ * arithmetic of atvs_conv_c16b_f32).  Weights: atvs_conv2d_b_pack (HOST; size in BYTES). */
+int atvs_conv2d_b_pack_size(int Cin, int Cout, long* packed_bytes);
+int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
+int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
+                      const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H, int W, int Cin,
+                      int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* 1x1 convolution of feature maps (the bottlenecks' conv1 / conv3 / shortcut, fusion1: slim.conv2d 1x1,
  * network.py:573-601; cnn_wrapper/atvsnet.py:254-292) as a tall GEMM: weights staged once per workgroup in LDS, pixels

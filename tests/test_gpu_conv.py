@@ -520,12 +520,24 @@ def test_tensor_on_another_device_is_refused(cuda):
         ops.channel_stats(x)
 
 
+@pytest.fixture(params=['split-bf16', 'fp32'])
+def towerkernel(request):
+    """Run a test on both 3x3 tower kernels: conv2d_b.hip (split-bf16 operands, default) and conv2d_lds.hip (fp32 MFMA)."""
+    from atvsnet_amd import ops
+    ops.use_bf16x3(request.param == 'split-bf16')
+    ops.clear_pack_cache()
+    yield request.param
+    ops.use_bf16x3(True)
+    ops.clear_pack_cache()
+
+
 @pytest.mark.parametrize('cin,cout,dil,H,W,G', [
     (128, 128, 2, 32, 48, 1), (128, 128, 4, 30, 44, 2), (64, 128, 1, 17, 33, 3), (320, 128, 1, 16, 32, 1),
     (64, 64, 1, 24, 40, 2), (32, 32, 1, 36, 52, 2), (32, 64, 1, 9, 16, 1)])
-def test_conv2d_lds_matches_oracle(cuda, cin, cout, dil, H, W, G):
-    """The LDS-tiled 2-D convolution of the feature towers (conv2d_lds.hip): every instantiation, ragged edges,
-    several independent images per launch, bias / residual / ReLU and the per-image moments."""
+def test_conv2d_lds_matches_oracle(cuda, towerkernel, cin, cout, dil, H, W, G):
+    """The LDS-tiled 2-D convolutions of the feature towers (conv2d_b.hip: split-bf16 operands; conv2d_lds.hip: fp32 MFMA):
+    every instantiation, ragged edges, several independent images per launch, bias / residual / ReLU and the per-image
+    moments, both at the same fp32 bar."""
     from atvsnet_amd import ops
     g = torch.Generator().manual_seed(cin + cout + dil)
     x = torch.randn(G, H, W, cin, generator=g)
@@ -547,7 +559,7 @@ def test_conv2d_lds_matches_oracle(cuda, cin, cout, dil, H, W, G):
     assert float((y1.cpu() - w1).abs().max()) <= 2e-5 * float(w1.abs().max())
 
 
-def test_conv2d_lds_normalise_on_load(cuda):
+def test_conv2d_lds_normalise_on_load(cuda, towerkernel):
     """in_params: the producer's training-mode batch norm (+ ReLU) applied while the tile is staged equals
     normalising first; the SAME padding is zero AFTER the normalisation."""
     from atvsnet_amd import ops
