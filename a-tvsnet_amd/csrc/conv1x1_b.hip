@@ -1,0 +1,337 @@
+// 1x1 convolution of feature maps (a tall GEMM Y[p, co] = sum_ci X[p, ci] W[ci, co]) on the bf16 matrix cores with SPLIT operands
+// (gfx950): conv1x1.hip's layers (the bottlenecks' conv1 / conv3 / shortcut and fusion1 of the 2-D towers,
+// /root/reference/cnn_wrapper/network.py:552-602, cnn_wrapper/atvsnet.py:254-292) with every fp32 operand split into three bf16
+// pieces, six products, fp32 accumulation (conv_c16b.hip has the arithmetic).  At 128 -> 128 the fp32 MFMA form is as much
+// matrix-core- as HBM-bound (32 FLOP per byte); with the products 2.7x cheaper the layer is HBM-bound.
+//
+// Structure = conv2d_b.hip without a halo: one workgroup per 128 consecutive pixels of one image, the WAVES SPLIT THE OUTPUT
+// CHANNELS and share the pixels, K loop in chunks of 32 input channels = ONE K = 32 step (lane group q = channels 8 q ..), three
+// phases per step; two LDS buffers of three piece images [128 pixels][32 channels] (64-byte pixels, bit 5 of the byte address
+// XOR-ed with bit 9: conflict-free ds_read_b128); the next chunk's pixels are fetched during the phases and split + written after
+// them; weight pieces streamed from L2 one step ahead (two register slots, the chunk loop unrolled by two); optional
+// normalise-on-load; epilogue as conv1x1.hip (bias, residual, ReLU, per-(image, workgroup) moments).
+#include <cstring>
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+constexpr int C1B_PX = 128;                   // pixels per workgroup
+constexpr int C1B_PIMG = C1B_PX * 64;         // bytes of one piece image (32 channels x 2 B per pixel)
+constexpr int C1B_BUFB = 3 * C1B_PIMG;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+struct C1bArgs {
+  const float* x;
+  const bf16x8* wp;
+  const float* bias;
+  const float* res;
+  const float* in_params;
+  float* y;
+  double* stats;
+  int Cin, Cout, ldy, ycoff;
+  int relu, in_relu;
+  long rows;                // pixels per image
+  int wgs;                  // workgroups per image
+  int nchunk;
+};
+
+__device__ __forceinline__ int c1b_swz(int a) { return a ^ (((a >> 9) & 1) << 5); }
+
+__device__ __forceinline__ void c1b_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    (*p0)[i] = a;
+    (*p1)[i] = b;
+    (*p2)[i] = (__bf16)r2;
+  }
+}
+
+// NTW = 16-channel output tiles per wave, WR = pixel groups across the waves (4 / WR waves split the channels).
+// Cout = 16 * NTW * (4 / WR); a wave owns TYW = 8 / WR tiles of 16 pixels.
+template <int NTW, int WR>
+__global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int WN = 4 / WR, NT = NTW * WN, TYW = 8 / WR;
+  constexpr int MAXS = C1B_PX * 8 / 256;       // float4 slots per thread and chunk: 4
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int wn = wave % WN, wr = wave / WN;
+  const int grp = blockIdx.x / p.wgs, wb = blockIdx.x - grp * p.wgs;
+  const long pix0 = (long)wb * C1B_PX;
+  const float* __restrict__ xg = p.x + (size_t)grp * p.rows * p.Cin;
+
+  // ---- staging slots: float4 = channels 4 c4 .. of pixel px of the fp32 chunk -> 8 bytes of each piece image
+  int goff[MAXS], laddr[MAXS];
+  unsigned valid = 0;
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    const int s = tid + i * 256;
+    const int c4 = s & 7, px = s >> 3;
+    const bool ok = pix0 + px < p.rows;
+    goff[i] = ok ? (px * p.Cin + c4 * 4) : 0;
+    laddr[i] = c1b_swz(px * 64 + c4 * 8);
+    valid |= (ok ? 1u : 0u) << i;
+  }
+  const float* xt = xg + (size_t)pix0 * p.Cin;
+  float4 pf[MAXS];
+  auto pf_slot = [&](int i, int ch) __attribute__((always_inline)) {
+    pf[i] = ((valid >> i) & 1u) ? ld4(xt + goff[i] + ch * 32) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto write_image = [&](int buf, int ch) __attribute__((always_inline)) {
+    const float* ip = p.in_params ? p.in_params + (size_t)grp * 3 * p.Cin + ch * 32 : nullptr;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      float4 v = pf[i];
+      if (ip && ((valid >> i) & 1u)) {
+        const int c = ((tid + i * 256) & 7) * 4;
+        const float4 m = ld4(ip + c), s = ld4(ip + p.Cin + c), b = ld4(ip + 2 * p.Cin + c);
+        v.x = (v.x - m.x) * s.x + b.x;
+        v.y = (v.y - m.y) * s.y + b.y;
+        v.z = (v.z - m.z) * s.z + b.z;
+        v.w = (v.w - m.w) * s.w + b.w;
+        if (p.in_relu) {
+          v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        }
+      }
+      bf16x4 p0, p1, p2;
+      c1b_split(v, &p0, &p1, &p2);
+      unsigned char* d = smem + buf * C1B_BUFB + laddr[i];
+      *reinterpret_cast<bf16x4*>(d) = p0;
+      *reinterpret_cast<bf16x4*>(d + C1B_PIMG) = p1;
+      *reinterpret_cast<bf16x4*>(d + 2 * C1B_PIMG) = p2;
+    }
+  };
+
+  // this lane's fragment (channels 8 q .. of pixel r of a 16-pixel tile); tiles are 1024 bytes apart
+  const int fb = c1b_swz(r * 64 + q * 16) + wr * TYW * 1024;
+
+  // packed weight pieces: [chunk][NT tiles][3 pieces][64 lanes] bf16x8, one zero chunk at the end
+  const bf16x8* __restrict__ wl = p.wp + (size_t)(wn * NTW) * 3 * 64 + lane;
+  constexpr int WSTEP = NT * 3 * 64;
+  bf16x8 Aw[2][NTW][3];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n)
+#pragma unroll
+    for (int w3 = 0; w3 < 3; ++w3) Aw[0][n][w3] = wl[(n * 3 + w3) * 64];
+
+  f32x4 acc[TYW][NTW];
+#pragma unroll
+  for (int t = 0; t < TYW; ++t)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) pf_slot(i, 0);
+  write_image(0, 0);
+  __syncthreads();
+
+  bf16x8 Bq[2][TYW];
+  auto chunk = [&](auto PAR, int ch) __attribute__((always_inline)) {
+    constexpr int par = decltype(PAR)::value;                 // ch & 1: LDS buffer and weight slot of the chunk
+    const unsigned char* lb = smem + par * C1B_BUFB;
+    const bool more = ch + 1 < p.nchunk;
+    auto request_b = [&](int pc) __attribute__((always_inline)) {
+#pragma unroll
+      for (int t = 0; t < TYW; ++t) Bq[pc & 1][t] = *reinterpret_cast<const bf16x8*>(lb + pc * C1B_PIMG + fb + t * 1024);
+    };
+    request_b(0);
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc) {
+      if (pc == 0) {
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int w3 = 0; w3 < 3; ++w3) Aw[par ^ 1][n][w3] = wl[(size_t)(ch + 1) * WSTEP + (n * 3 + w3) * 64];
+      }
+      if (pc + 1 < 3) request_b(pc + 1);
+      if (more) {
+        if (pc == 0) { pf_slot(0, ch + 1); pf_slot(1, ch + 1); }
+        if (pc == 1) { pf_slot(2, ch + 1); pf_slot(3, ch + 1); }
+      }
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jw = 0; jw < 3; ++jw) {
+        if (jw > 2 - pc) continue;
+#pragma unroll
+        for (int n = 0; n < NTW; ++n)
+#pragma unroll
+          for (int t = 0; t < TYW; ++t)
+            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Aw[par][n][jw], Bq[pc & 1][t], acc[t][n], 0, 0, 0);
+      }
+    }
+    if (more) {
+      write_image(par ^ 1, ch + 1);          // the other buffer: last read in chunk ch - 1, behind the barrier below
+      __syncthreads();
+    }
+  };
+  for (int ch = 0; ch < p.nchunk; ch += 2) {
+    chunk(std::integral_constant<int, 0>{}, ch);
+    if (ch + 1 < p.nchunk) chunk(std::integral_constant<int, 1>{}, ch + 1);
+  }
+
+  // ---- epilogue: lane holds channels (wn*NTW + n)*16 + 4q .. +3 of pixel pix0 + (wr*TYW + t)*16 + r
+  float ssum[NTW][4], ssq[NTW][4];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ssum[n][k] = ssq[n][k] = 0.f;
+  float* yg = p.y + (size_t)grp * p.rows * p.ldy;
+  const float* rg = p.res ? p.res + (size_t)grp * p.rows * p.ldy : nullptr;
+#pragma unroll
+  for (int t = 0; t < TYW; ++t) {
+    const long px = pix0 + (wr * TYW + t) * 16 + r;
+    if (px >= p.rows) continue;
+    const size_t rowb = (size_t)px * p.ldy + p.ycoff;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) {
+      const int co = (wn * NTW + n) * 16 + 4 * q;
+      float4 v = make_float4(acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]);
+      if (p.bias) {
+        const float4 bb = ld4(p.bias + co);
+        v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+      }
+      if (rg) {
+        const float4 rr = ld4(rg + rowb + co);
+        v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      }
+      if (p.relu) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+      }
+      st4(yg + rowb + co, v);
+      ssum[n][0] += v.x; ssum[n][1] += v.y; ssum[n][2] += v.z; ssum[n][3] += v.w;
+      ssq[n][0] += v.x * v.x; ssq[n][1] += v.y * v.y; ssq[n][2] += v.z * v.z; ssq[n][3] += v.w * v.w;
+    }
+  }
+  if (p.stats) {
+    // row (image, workgroup): [2][Cout] doubles; channels are private to a wave (WR == 1) or shared by WR waves
+    double* row = p.stats + (size_t)blockIdx.x * 2 * p.Cout;
+    double* s_red = reinterpret_cast<double*>(smem);
+    if (WR > 1) __syncthreads();
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        double a = (double)ssum[n][k], bq = (double)ssq[n][k];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o);
+          bq += __shfl_xor(bq, o);
+        }
+        if (r == 0) {
+          const int c = (wn * NTW + n) * 16 + 4 * q + k;
+          if (WR == 1) {
+            row[c] = a;
+            row[p.Cout + c] = bq;
+          } else {
+            s_red[(wr * 2 + 0) * p.Cout + c] = a;
+            s_red[(wr * 2 + 1) * p.Cout + c] = bq;
+          }
+        }
+      }
+    if (WR > 1) {
+      __syncthreads();
+      for (int i = tid; i < 2 * p.Cout; i += 256) {
+        double v = 0.0;
+#pragma unroll
+        for (int a = 0; a < WR; ++a) v += s_red[a * 2 * p.Cout + i];
+        row[i] = v;
+      }
+    }
+  }
+}
+
+template <int NTW, int WR>
+int launch_c1b(const C1bArgs& a, int groups, hipStream_t s) {
+  const long blocks = (long)groups * a.wgs;
+  if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL((conv1x1_b_kernel<NTW, WR>), dim3((unsigned)blocks), dim3(256), 2 * C1B_BUFB, s, a);
+  return ATVS_OK;
+}
+
+float c1b_round(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  float o;
+  std::memcpy(&o, &u, 4);
+  return o;
+}
+uint16_t c1b_bits(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  return (uint16_t)(u >> 16);
+}
+
+}  // namespace
+
+extern "C" int atvs_conv1x1_b_supported(int Cin, int Cout) {
+  return (Cin > 0 && Cin % 32 == 0 && Cin <= 1024 && (Cout == 32 || Cout == 64 || Cout == 128)) ? 1 : 0;
+}
+
+// workgroups per image = rows per image of stats_partial ([2][Cout] doubles each): 128 pixels per workgroup
+extern "C" long atvs_conv1x1_b_rows(long pixels) { return (pixels + C1B_PX - 1) / C1B_PX; }
+
+extern "C" int atvs_conv1x1_b_pack_size(int Cin, int Cout, long* packed_bytes) {
+  if (!packed_bytes) return ATVS_ERR_NULL;
+  if (!atvs_conv1x1_b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
+  *packed_bytes = (long)(Cin / 32 + 1) * (Cout / 16) * 3 * 1024;
+  return ATVS_OK;
+}
+
+// HOST function.  w: [Cin][Cout].  packed[chunk][tile n][piece][lane = q * 16 + co16][e] = piece of
+// w[chunk * 32 + q * 8 + e][n * 16 + co16]; one zero chunk of padding at the end (the weight slots read ahead).
+extern "C" int atvs_conv1x1_b_pack(const float* w, int Cin, int Cout, unsigned char* packed) {
+  if (!w || !packed) return ATVS_ERR_NULL;
+  long pb;
+  int rc = atvs_conv1x1_b_pack_size(Cin, Cout, &pb);
+  if (rc) return rc;
+  std::memset(packed, 0, (size_t)pb);
+  uint16_t* out = reinterpret_cast<uint16_t*>(packed);
+  const int NT = Cout / 16;
+  for (int ch = 0; ch < Cin / 32; ++ch)
+    for (int n = 0; n < NT; ++n)
+      for (int q = 0; q < 4; ++q)
+        for (int co16 = 0; co16 < 16; ++co16)
+          for (int e = 0; e < 8; ++e) {
+            const float v = w[(size_t)(ch * 32 + q * 8 + e) * Cout + n * 16 + co16];
+            const float p0 = c1b_round(v), p1 = c1b_round(v - p0), p2 = c1b_round((v - p0) - p1);
+            const float pc[3] = {p0, p1, p2};
+            for (int k = 0; k < 3; ++k) out[((((size_t)ch * NT + n) * 3 + k) * 64 + q * 16 + co16) * 8 + e] = c1b_bits(pc[k]);
+          }
+  return ATVS_OK;
+}
+
+// Same contract as atvs_conv1x1_f32 except the statistics rows (atvs_conv1x1_b_rows: 128 pixels per workgroup) and the weights
+// (atvs_conv1x1_b_pack); split-bf16 operands, fp32-class results.
+extern "C" int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
+                                  const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
+                                  int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream) {
+  if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (groups <= 0 || pixels <= 0 || !atvs_conv1x1_b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if (residual && y_coff != 0) return ATVS_ERR_ARG;
+  if ((double)pixels * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
+  C1bArgs a;
+  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.bias = bias; a.res = residual; a.in_params = in_params;
+  a.y = y; a.stats = stats_partial;
+  a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.ycoff = y_coff; a.relu = relu; a.in_relu = in_relu;
+  a.rows = pixels; a.wgs = (int)atvs_conv1x1_b_rows(pixels); a.nchunk = Cin / 32;
+  hipStream_t s = as_stream(stream);
+  int rc;
+  if (Cout == 128) rc = launch_c1b<2, 1>(a, groups, s);
+  else if (Cout == 64) rc = launch_c1b<1, 1>(a, groups, s);
+  else rc = launch_c1b<1, 2>(a, groups, s);
+  if (rc) return rc;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

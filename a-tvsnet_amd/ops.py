@@ -632,8 +632,10 @@ def conv2d_lds(x, key, w_host, dilation=1, bias=None, residual=None, relu=False,
 
 
 def conv1x1_ok(cin, cout):
-    """Is the LDS-staged GEMM kernel (atvs_conv1x1_f32) used for a stride-1 1x1 convolution of these channel counts?"""
-    return (_FORCE_IMPL != 'gather' and _USE_CONV1X1 and bool(_lib.lib().atvs_conv1x1_supported(int(cin), int(cout))))
+    """Is a GEMM kernel (atvs_conv1x1_b_f32 / atvs_conv1x1_f32) used for a stride-1 1x1 convolution of these channel counts?"""
+    lib = _lib.lib()
+    return (_FORCE_IMPL != 'gather' and _USE_CONV1X1 and
+            bool((_USE_BF16X3 and lib.atvs_conv1x1_b_supported(int(cin), int(cout))) or lib.atvs_conv1x1_supported(int(cin), int(cout))))
 
 
 _USE_CONV1X1 = True
@@ -652,35 +654,38 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
     import numpy as np
     G, cin = x.shape[0], x.shape[-1]
     pixels = x.numel() // G // cin
-    ck = ('c1', key, str(x.device))
+    lib = _lib.lib()
+    kind = '_b' if (_USE_BF16X3 and lib.atvs_conv1x1_b_supported(int(cin), int(np.asarray(w_host).size // cin))) else ''
+    ck = ('c1' + kind, key, str(x.device))
     pk = _pack_cache.get(ck)
     if pk is None:
         w = np.ascontiguousarray(w_host, dtype=np.float32).reshape(cin, -1)
         cout = int(w.shape[1])
         pf = ctypes.c_long()
-        rc = _lib.lib().atvs_conv1x1_pack_size(cin, cout, ctypes.byref(pf))
+        rc = getattr(lib, 'atvs_conv1x1%s_pack_size' % kind)(cin, cout, ctypes.byref(pf))
         if rc:
-            raise RuntimeError('atvs_conv1x1_pack_size failed (%d) for Cin=%d Cout=%d' % (rc, cin, cout))
-        packed = np.empty(pf.value, np.float32)
-        rc = _lib.lib().atvs_conv1x1_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+            raise RuntimeError('atvs_conv1x1%s_pack_size failed (%d) for Cin=%d Cout=%d' % (kind, rc, cin, cout))
+        packed = np.empty(pf.value, np.uint8 if kind else np.float32)       # split kernel: bytes of bf16 pieces
+        rc = getattr(lib, 'atvs_conv1x1%s_pack' % kind)(w.ctypes.data_as(ctypes.c_void_p), cin, cout,
+                                                        packed.ctypes.data_as(ctypes.c_void_p))
         if rc:
-            raise RuntimeError('atvs_conv1x1_pack failed (%d)' % rc)
+            raise RuntimeError('atvs_conv1x1%s_pack failed (%d)' % (kind, rc))
         pk = _Packed()
-        pk.key, pk.tab, pk.cin, pk.cout, pk.ntiles = key, None, cin, cout, cout // 16
+        pk.key, pk.tab, pk.cin, pk.cout, pk.ntiles, pk.kind = key, None, cin, cout, cout // 16, kind
         pk.wp = None if x.is_meta else torch.from_numpy(packed).to(x.device)
         _pack_cache[ck] = pk
     y = _new(x, tuple(x.shape[:-1]) + (pk.cout,)) if out is None else out
     st, sbuf = None, None
     if want_stats:
-        rows = int(_lib.lib().atvs_conv1x1_rows(ctypes.c_long(pixels)))
+        rows = int(getattr(lib, 'atvs_conv1x1%s_rows' % kind)(ctypes.c_long(pixels)))
         sbuf = torch.empty((G, rows, 2, pk.cout), dtype=torch.float64, device=x.device)
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, pk.cout, pixels, G
     if _dev_ok(x, y, bias, residual, in_params):
         with _Timed(pk.key, (1, 1, pixels, cin), pk.cout, G):
-            _call('atvs_conv1x1_f32', _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)), _p(y),
-                  ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, ctypes.c_long(pixels),
-                  cin, pk.cout, int(y.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+            _call('atvs_conv1x1%s_f32' % kind, _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)),
+                  _p(y), ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G,
+                  ctypes.c_long(pixels), cin, pk.cout, int(y.shape[-1]), int(y_coff), int(bool(relu)), _stream())
     return (y, st) if want_stats else y
 
 

@@ -561,8 +561,9 @@ def rank_main(args):
                 o2 = g2()
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t2
-            split = {'layers': '3x3x3 8 / 16 -> 16 channels on v_mfma_f32_16x16x32_bf16: x = x0 + x1 + x2, w = w0 + w1 + w2 in '
-                               'bf16, the 6 products with i + j <= 2, fp32 accumulation (conv_c16b.hip)',
+            split = {'layers': 'the 3x3x3 layers with 8 / 16 / 32 input channels (conv_xb.hip, conv_c16b.hip) and the 3x3 / 1x1 tower '
+                               'layers with Cin % 32 == 0 (conv2d_b.hip, conv1x1_b.hip) on v_mfma_f32_16x16x32_bf16: '
+                               'x = x0 + x1 + x2, w = w0 + w1 + w2 in bf16, the 6 products with i + j <= 2, fp32 accumulation',
                      'in_value': bool(default_on),
                      'other_path': 'every convolution on the fp32 matrix cores' if default_on else 'split-bf16 layers enabled',
                      'other_ms_per_step': round(1e3 * dt2 / args.steps, 3), 'other_value': round(args.steps / dt2, 4),
@@ -670,9 +671,10 @@ def rank_main(args):
             'unit': 'depth-maps/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'precision': ('fp32 accumulation everywhere; fp32 MFMA operands except the 8 / 16 -> 16 channel 3x3x3 layers, whose '
-                          'fp32 operands are split into three bf16 pieces each (24 mantissa bits kept, 6 products: fp32-class, '
-                          'see `split_bf16` for the all-fp32-MFMA figure)') if ops._USE_BF16X3 else 'fp32 MFMA operands, fp32 accumulation',
+            'precision': ('fp32 storage and fp32 accumulation everywhere; the heavy convolutions (3x3x3 with 8 / 16 / 32 input '
+                          'channels, 3x3 and 1x1 tower layers) split every fp32 operand into three bf16 pieces (24 mantissa bits '
+                          'kept) and form 6 of the 9 piece products: fp32-class, same parity bar; the other layers use fp32 MFMA '
+                          'operands; see `split_bf16` for the all-fp32-MFMA figure') if ops._USE_BF16X3 else 'fp32 MFMA operands, fp32 accumulation',
             'config': {'workload': '%d depth map(s) per step: %d views (1 ref + %d src) %dx%d, D=%d, example.py %s pipeline'
                                    % (n_groups, args.views, args.views - 1, args.width, args.height, args.depths,
                                       'two-view' if twoview else 'multi-view'),

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 18
+#define ATVS_ABI_VERSION 19
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -337,6 +337,17 @@ long atvs_conv1x1_rows(long pixels);
 int atvs_conv1x1_f32(const float* x, const float* packed_w, const float* bias, const float* residual,
                      const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
                      int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* The same layers (network.py:573-601) with SPLIT bf16 operands on the bf16 matrix cores (conv1x1_b.hip; the arithmetic of
+ * atvs_conv_c16b_f32): Cin % 32 == 0, Cin <= 1024, Cout in {32, 64, 128}.  Same contract as atvs_conv1x1_f32 except the
+ * packed weights (bytes of bf16 pieces) and the statistics rows (128 pixels per workgroup: atvs_conv1x1_b_rows). */
+int atvs_conv1x1_b_supported(int Cin, int Cout);
+int atvs_conv1x1_b_pack_size(int Cin, int Cout, long* packed_bytes);
+int atvs_conv1x1_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
+long atvs_conv1x1_b_rows(long pixels);
+int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
+                       const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
+                       int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
  * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a
