@@ -502,6 +502,31 @@ def pack_conv_c16b(key, w_host, device):
 _USE_C16 = True
 
 
+def pack_conv3d_b(key, w_host, device):
+    """Packed bf16 pieces of a [3,3,3,Cin,Cout] kernel (Cin % 16 == 0, Cout 32 / 64) for atvs_conv3d_b_f32; cached."""
+    import numpy as np
+    ck = ('c3b', key, str(device))
+    pk = _pack_cache.get(ck)
+    if pk is not None:
+        return pk
+    w = np.ascontiguousarray(w_host, dtype=np.float32)
+    cin, cout = int(w.shape[-2]), int(w.shape[-1])
+    L = _lib.lib()
+    pb = ctypes.c_long()
+    rc = L.atvs_conv3d_b_pack_size(cin, cout, ctypes.byref(pb))
+    if rc:
+        raise RuntimeError('atvs_conv3d_b_pack_size failed (%d) for %d -> %d' % (rc, cin, cout))
+    packed = np.empty(pb.value, np.uint8)
+    rc = L.atvs_conv3d_b_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+    if rc:
+        raise RuntimeError('atvs_conv3d_b_pack failed (%d)' % rc)
+    pk = _Packed()
+    pk.key, pk.tab, pk.cin, pk.cout = key, None, cin, cout
+    pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
+    _pack_cache[ck] = pk
+    return pk
+
+
 def use_conv_c16(flag):
     """Testing / A-B hook: the one-workgroup-per-CU kernel for 3x3x3 convolutions to 16 / 32 channels."""
     global _USE_C16
@@ -1103,13 +1128,15 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
 
     # ---- 3-D, 3x3x3, 8 / 16 / 32 -> 16 and 16..64 -> 32 channels: one workgroup per CU, fully unrolled (the half- and
     # quarter-resolution U-Net layers, the AANet modules' shared | unique convolution)
+    b3 = _USE_BF16X3 and cin % 16 == 0 and cout in (32, 64) and bool(_lib.lib().atvs_conv3d_b_supported(int(cin), int(cout)))
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
-            and ((cout == 16 and cin in (8, 16, 32)) or (cout == 32 and cin in (16, 32, 48, 64))) \
+            and ((cout == 16 and cin in (8, 16, 32)) or (cout == 32 and cin in (16, 32, 48, 64)) or b3) \
             and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
             and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
         b16 = _USE_BF16X3 and cin in (8, 16) and cout == 16
-        pk = pack_conv_c16b(key, w_host, x.device) if b16 else pack_conv_c16(key, w_host, x.device)
+        pk = pack_conv3d_b(key, w_host, x.device) if b3 else \
+            pack_conv_c16b(key, w_host, x.device) if b16 else pack_conv_c16(key, w_host, x.device)
         if y5 is None:
             y5 = _new(x, (G,) + tuple(outs) + (cout,))
         st, sbuf = None, None
@@ -1120,7 +1147,10 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, cout, M, G
         if _dev_ok(x5, y5, bias):
             with _Timed(key, x5.shape[1:], cout, G):
-                if b16:
+                if b3:
+                    _call('atvs_conv3d_b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
+                          cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                elif b16:
                     _call('atvs_conv_c16b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
                           int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
                 else:

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 19
+#define ATVS_ABI_VERSION 20
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -348,6 +348,17 @@ long atvs_conv1x1_b_rows(long pixels);
 int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
                        const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
                        int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* 3x3x3 SAME stride-1 convolutions with Cin % 16 == 0 and 32 / 64 output channels (conv_b*_2_1, conv_b*_3_1,
+ * global_refine_3dconv{2,3}_1: cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, network.py:172-215) with SPLIT bf16
+ * operands on the bf16 matrix cores (conv3d_b.hip; the arithmetic of atvs_conv_c16b_f32).  x (groups,D,H,W,Cin) ->
+ * y (groups,D,H,W,ldy)[..., y_coff : y_coff + Cout]; stats_partial: groups * atvs_conv_c16_grid rows of [2][Cout] doubles or NULL.
+ * Weights: atvs_conv3d_b_pack (HOST; size in BYTES). */
+int atvs_conv3d_b_supported(int Cin, int Cout);
+int atvs_conv3d_b_pack_size(int Cin, int Cout, long* packed_bytes);
+int atvs_conv3d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
+int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
+                      int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
  * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a

@@ -429,6 +429,47 @@ def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W, cin):
         ops.clear_pack_cache()
 
 
+@pytest.mark.parametrize('cin,cout', [(32, 32), (64, 64), (16, 32), (48, 64)])
+@pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 21), (2, 5, 8, 12)])
+def test_conv3d_b_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cout):
+    """Split-bf16 form of the 16 k -> 32 / 64 channel 3x3x3 convolutions (conv3d_b.hip: several 16-channel chunks, two or
+    four output tiles per wavefront, weights streamed) against the oracle at the fp32 bar, and no further from a float64
+    evaluation than the fp32 kernel the layer used before (x 2): bias + ReLU into a channel slice, statistics, ragged
+    sizes, per-sample groups equal to single launches bit for bit."""
+    from atvsnet_amd import ops
+    x = _rand((G, D, H, W, cin), 80)
+    w = _rand((3, 3, 3, cin, cout), 81, (2.0 / (27 * cin)) ** 0.5)
+    b = _rand((cout,), 82)
+    want = torch.clamp(T.conv(x, w, 1, 'SAME', bias=b), min=0)
+    ref64 = torch.clamp(T.conv(x.double(), w.double(), 1, 'SAME', bias=b.double()), min=0)
+    try:
+        outs = {}
+        for flag in (False, True):
+            ops.use_bf16x3(flag)
+            ops.clear_pack_cache()
+            buf = torch.full((G, D, H, W, cout + 8), -3.0, device=cuda)
+            got, st = ops.conv(x.to(cuda), ('c3b', G, D, H, W, cin, cout), w.numpy(), bias=b.to(cuda), relu=True,
+                               want_stats=True, out=buf, y_coff=4, groups=G)
+            y = buf.cpu()
+            _close(y[..., 4:4 + cout], want)
+            assert float((y[..., :4] + 3.0).abs().max()) == 0.0 and float((y[..., 4 + cout:] + 3.0).abs().max()) == 0.0
+            s = st.partial.reshape(G, -1, 2, st.cpad).sum(1).cpu()
+            for g in range(G):
+                _close(s[g, 0, :cout].float(), want[g].reshape(-1, cout).double().sum(0).float(), 1e-5)
+                _close(s[g, 1, :cout].float(), (want[g].reshape(-1, cout).double() ** 2).sum(0).float(), 1e-5)
+            outs[flag] = y[..., 4:4 + cout].double()
+            if flag:
+                one = ops.conv(x[1 % G].to(cuda), ('c3b', G, D, H, W, cin, cout), w.numpy(), bias=b.to(cuda), relu=True)
+                assert torch.equal(one.cpu(), y[1 % G, ..., 4:4 + cout])
+        e32 = float((outs[False] - ref64).abs().max())
+        e16 = float((outs[True] - ref64).abs().max())
+        print('max abs error vs float64: fp32 MFMA %.3e, split bf16 %.3e' % (e32, e16))
+        assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
+    finally:
+        ops.use_bf16x3(True)             # the default
+        ops.clear_pack_cache()
+
+
 def test_conv_split_siblings_match_dense(cuda):
     from atvsnet_amd import ops
     ops.clear_pack_cache()
