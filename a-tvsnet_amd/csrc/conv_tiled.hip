@@ -899,75 +899,3 @@ extern "C" int atvs_conv_tiled_f32(const float* x, const float* packed_w, const 
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
-
-// ===========================================================================
-// 3x3x3, 8 -> 1 channel, stride 1, SAME, no bias / activation: the probability heads
-// conv_b2_6_2, attention_prob_vol[_refine], global_refined_cost_vol
-// (/root/reference/cnn_wrapper/atvsnet.py:192,213,220,226,242,336).  One output channel cannot feed a
-// 16-wide MFMA tile (1/16 useful), and the layer is HBM-bound anyway (read V*32 B, write V*4 B):
-// plain FMAs from an LDS halo tile, weights in scalar registers.
-// ===========================================================================
-#define C81_TZ 2
-#define C81_TY 8
-#define C81_TX 16
-__global__ __launch_bounds__(256) void conv3d_8to1_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ y, int D, int H, int W, int tiles_y,
-                                                          int tiles_x) {
-  constexpr int HZ = C81_TZ + 2, HY = C81_TY + 2, HX = C81_TX + 2;
-  __shared__ float4 tile[HZ * HY * HX * 2];
-  const int tid = threadIdx.x;
-  x += (size_t)blockIdx.y * D * H * W * 8;                   // blockIdx.y = independent sample
-  y += (size_t)blockIdx.y * D * H * W;
-  int bx = blockIdx.x % tiles_x;
-  int rest = blockIdx.x / tiles_x;
-  const int x0 = bx * C81_TX, y0 = (rest % tiles_y) * C81_TY, z0 = (rest / tiles_y) * C81_TZ;
-  for (int s = tid; s < HZ * HY * HX * 2; s += 256) {
-    int c4 = s & 1, v = s >> 1;
-    int xx = v % HX;
-    int v2 = v / HX;
-    int yy = v2 % HY, zz = v2 / HY;
-    int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
-    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W)
-      val = ld4(x + (((size_t)gz * H + gy) * W + gx) * 8 + c4 * 4);
-    tile[s] = val;
-  }
-  __syncthreads();
-  const int lx = tid % C81_TX, ly = (tid / C81_TX) % C81_TY, lz = tid / (C81_TX * C81_TY);
-  float acc = 0.f;
-#pragma unroll
-  for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const float4* t = tile + (((lz + kd) * HY + (ly + kh)) * HX + (lx + kw)) * 2;
-        float4 a = t[0], b = t[1];
-        const float* wk = w + ((kd * 3 + kh) * 3 + kw) * 8;     // uniform -> scalar loads
-        // fused multiply-adds, as on the matrix cores (the file is built with -ffp-contract=off for other kernels):
-        // the layer is VALU-bound (216 FMAs per output voxel against 36 bytes of traffic)
-        acc = fmaf(a.x, wk[0], acc);
-        acc = fmaf(a.y, wk[1], acc);
-        acc = fmaf(a.z, wk[2], acc);
-        acc = fmaf(a.w, wk[3], acc);
-        acc = fmaf(b.x, wk[4], acc);
-        acc = fmaf(b.y, wk[5], acc);
-        acc = fmaf(b.z, wk[6], acc);
-        acc = fmaf(b.w, wk[7], acc);
-      }
-  const int zo = z0 + lz, yo = y0 + ly, xo = x0 + lx;
-  if (zo < D && yo < H && xo < W) y[((size_t)zo * H + yo) * W + xo] = acc;
-}
-
-// x (D,H,W,8), w: the TF kernel [3,3,3,8,1] as 216 floats (device), y (D,H,W).
-extern "C" int atvs_conv3d_8to1(const float* x, const float* w, float* y, int groups, int D, int H, int W,
-                                atvs_stream_t stream) {
-  if (!x || !w || !y) return ATVS_ERR_NULL;
-  if (groups <= 0 || groups > 65535 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
-  int tz = (D + C81_TZ - 1) / C81_TZ, ty = (H + C81_TY - 1) / C81_TY, tx = (W + C81_TX - 1) / C81_TX;
-  long blocks = (long)tz * ty * tx;
-  if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  hipLaunchKernelGGL(conv3d_8to1_kernel, dim3((unsigned)blocks, groups), dim3(256), 0, as_stream(stream), x, w, y, D, H, W, ty, tx);
-  ATVS_LAUNCH_CHECK();
-  return ATVS_OK;
-}

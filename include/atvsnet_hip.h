@@ -383,7 +383,7 @@ int atvs_refine_stems_f32(const float* photo_raw, const float* geo, const float*
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,
  * 242,336).  x (D,H,W,8); w = the TF kernel [3,3,3,8,1] (216 floats, device); y (D,H,W).
- * HBM-bound (one output channel): FMA kernel, not MFMA. */
+ * One output channel: packed-FMA kernel with four outputs per thread, not MFMA (conv8to1.hip). */
 int atvs_conv3d_8to1(const float* x, const float* w, float* y, int groups, int D, int H, int W, atvs_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
