@@ -112,6 +112,7 @@ def lib():
         _lib.atvs_conv_stem_rows.restype = ctypes.c_long
         _lib.atvs_conv1x1_rows.restype = ctypes.c_long
         _lib.atvs_conv1x1_b_rows.restype = ctypes.c_long
+        _lib.atvs_conv3d_s2b_grid.restype = ctypes.c_long
         _lib.atvs_deconv_up_grid.restype = ctypes.c_long
         _lib.atvs_conv_c16_grid.restype = ctypes.c_long
     return _lib

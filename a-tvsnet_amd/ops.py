@@ -502,10 +502,11 @@ def pack_conv_c16b(key, w_host, device):
 _USE_C16 = True
 
 
-def pack_conv3d_b(key, w_host, device):
-    """Packed bf16 pieces of a [3,3,3,Cin,Cout] kernel (Cin % 16 == 0, Cout 32 / 64) for atvs_conv3d_b_f32; cached."""
+def pack_conv3d_b(key, w_host, device, kind='b'):
+    """Packed bf16 pieces of a [3,3,3,Cin,Cout] kernel (Cin % 16 == 0, Cout 32 / 64) for atvs_conv3d_b_f32 (kind 'b') or the
+    stride-2 atvs_conv3d_s2b_f32 (kind 's2b'); cached."""
     import numpy as np
-    ck = ('c3b', key, str(device))
+    ck = ('c3' + kind, key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
@@ -513,13 +514,14 @@ def pack_conv3d_b(key, w_host, device):
     cin, cout = int(w.shape[-2]), int(w.shape[-1])
     L = _lib.lib()
     pb = ctypes.c_long()
-    rc = L.atvs_conv3d_b_pack_size(cin, cout, ctypes.byref(pb))
+    rc = getattr(L, 'atvs_conv3d_%s_pack_size' % kind)(cin, cout, ctypes.byref(pb))
     if rc:
-        raise RuntimeError('atvs_conv3d_b_pack_size failed (%d) for %d -> %d' % (rc, cin, cout))
+        raise RuntimeError('atvs_conv3d_%s_pack_size failed (%d) for %d -> %d' % (kind, rc, cin, cout))
     packed = np.empty(pb.value, np.uint8)
-    rc = L.atvs_conv3d_b_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+    rc = getattr(L, 'atvs_conv3d_%s_pack' % kind)(w.ctypes.data_as(ctypes.c_void_p), cin, cout,
+                                                    packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
-        raise RuntimeError('atvs_conv3d_b_pack failed (%d)' % rc)
+        raise RuntimeError('atvs_conv3d_%s_pack failed (%d)' % (kind, rc))
     pk = _Packed()
     pk.key, pk.tab, pk.cin, pk.cout = key, None, cin, cout
     pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
@@ -1156,6 +1158,28 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
                 else:
                     _call('atvs_conv_c16_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
                           cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+        y = out if out is not None else _from5(y5, nsp, groups)
+        return (y, st) if want_stats else y
+
+    # ---- 3-D, 3x3x3, stride 2, SAME, 16 k -> 32 / 64 channels: the U-Net encoders below half resolution on split-bf16 operands
+    if nsp == 3 and stride == 2 and dilation == 1 and ks == (3, 3, 3) and padding == 'SAME' and explicit_pad is None \
+            and _USE_BF16X3 and _USE_C16 and _FORCE_IMPL is None and residual is None and plane_bias is None \
+            and bool(_lib.lib().atvs_conv3d_s2b_supported(int(cin), int(cout))) and outs[2] >= 8 \
+            and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
+            and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
+        pk = pack_conv3d_b(key, w_host, x.device, kind='s2b')
+        if y5 is None:
+            y5 = _new(x, (G,) + tuple(outs) + (cout,))
+        st, sbuf = None, None
+        if want_stats:
+            rows = int(_lib.lib().atvs_conv3d_s2b_grid(outs[0], outs[1], outs[2], G))
+            sbuf = _stats_buffer(x, rows, cout, groups=G)
+            st = Stats()
+            st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, cout, M, G
+        if _dev_ok(x5, y5, bias):
+            with _Timed(key, x5.shape[1:], cout, G):
+                _call('atvs_conv3d_s2b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, ins[0], ins[1], ins[2], cin,
+                      cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 

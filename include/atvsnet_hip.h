@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 20
+#define ATVS_ABI_VERSION 21
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -359,6 +359,17 @@ int atvs_conv3d_b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_conv3d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
 int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
                       int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* The STRIDE-2 form (conv_b*_2_0: 16 -> 32, conv_b*_3_0: 32 -> 64, global_refine_3dconv{2,3}_0; network.py:172-215) with split
+ * bf16 operands (conv3d_s2b.hip): x (groups,D,H,W,Cin) -> y (groups,Do,Ho,Wo,ldy)[..., y_coff : y_coff + Cout], Do = ceil(D / 2) ...,
+ * TF SAME padding (pad_before = (2 (Do - 1) + 3 - D) / 2 per axis).  stats_partial: groups * atvs_conv3d_s2b_grid(Do,Ho,Wo,groups)
+ * rows of [2][Cout] doubles or NULL.  Weights: atvs_conv3d_s2b_pack (HOST; size in BYTES). */
+int atvs_conv3d_s2b_supported(int Cin, int Cout);
+long atvs_conv3d_s2b_grid(int Do, int Ho, int Wo, int groups);
+int atvs_conv3d_s2b_pack_size(int Cin, int Cout, long* packed_bytes);
+int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
+int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
+                        int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
  * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a

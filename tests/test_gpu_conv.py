@@ -470,6 +470,47 @@ def test_conv3d_b_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cout):
         ops.clear_pack_cache()
 
 
+@pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64), (48, 32)])
+@pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 21), (2, 6, 8, 17), (1, 5, 7, 33)])
+def test_conv3d_s2b_stride2_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cout):
+    """Split-bf16 stride-2 3x3x3 convolutions (conv3d_s2b.hip: even | odd de-interleaved halo rows, waves split z plane and
+    output-channel half) against the oracle at the fp32 bar and against a float64 evaluation (no further than the gather kernel
+    x 2): TF SAME padding for even and odd sizes on every axis, bias + ReLU into a channel slice, statistics, groups."""
+    from atvsnet_amd import ops
+    x = _rand((G, D, H, W, cin), 90)
+    w = _rand((3, 3, 3, cin, cout), 91, (2.0 / (27 * cin)) ** 0.5)
+    b = _rand((cout,), 92)
+    want = torch.clamp(T.conv(x, w, 2, 'SAME', bias=b), min=0)
+    ref64 = torch.clamp(T.conv(x.double(), w.double(), 2, 'SAME', bias=b.double()), min=0)
+    Do, Ho, Wo = want.shape[1:4]
+    try:
+        outs = {}
+        for flag in (False, True):
+            ops.use_bf16x3(flag)
+            ops.clear_pack_cache()
+            buf = torch.full((G, Do, Ho, Wo, cout + 8), -3.0, device=cuda)
+            got, st = ops.conv(x.to(cuda), ('s2b', G, D, H, W, cin, cout), w.numpy(), stride=2, bias=b.to(cuda), relu=True,
+                               want_stats=True, out=buf, y_coff=4, groups=G)
+            y = buf.cpu()
+            _close(y[..., 4:4 + cout], want)
+            assert float((y[..., :4] + 3.0).abs().max()) == 0.0 and float((y[..., 4 + cout:] + 3.0).abs().max()) == 0.0
+            s = st.partial.reshape(G, -1, 2, st.cpad).sum(1).cpu()
+            for g in range(G):
+                _close(s[g, 0, :cout].float(), want[g].reshape(-1, cout).double().sum(0).float(), 1e-5)
+                _close(s[g, 1, :cout].float(), (want[g].reshape(-1, cout).double() ** 2).sum(0).float(), 1e-5)
+            outs[flag] = y[..., 4:4 + cout].double()
+            if flag:
+                one = ops.conv(x[1 % G].to(cuda), ('s2b', G, D, H, W, cin, cout), w.numpy(), stride=2, bias=b.to(cuda), relu=True)
+                assert torch.equal(one.cpu(), y[1 % G, ..., 4:4 + cout])
+        e32 = float((outs[False] - ref64).abs().max())
+        e16 = float((outs[True] - ref64).abs().max())
+        print('max abs error vs float64: fp32 MFMA %.3e, split bf16 %.3e' % (e32, e16))
+        assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
+    finally:
+        ops.use_bf16x3(True)             # the default
+        ops.clear_pack_cache()
+
+
 def test_conv_split_siblings_match_dense(cuda):
     from atvsnet_amd import ops
     ops.clear_pack_cache()
