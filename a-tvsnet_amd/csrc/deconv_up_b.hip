@@ -1,0 +1,448 @@
+// 3x3x3 stride-2 SAME transposed convolution to 8 or 16 output channels on the bf16 matrix cores with SPLIT operands (gfx950):
+// deconv_up.hip's layers (conv_b*_6_0, global_refine_3dconv6_0: 16 -> 8, full-resolution output; conv_b*_5_0,
+// global_refine_3dconv5_0: 32 -> 16; /root/reference/cnn_wrapper/network.py:510-550) with every fp32 operand split into three
+// bf16 pieces, six products, fp32 accumulation (conv_c16b.hip has the arithmetic).
+//
+// Form of deconv_up.hip: per input voxel M = 8 parity classes x Cout rows, K = 8 offsets x Cin; here a K = 32 instruction
+// covers the TWO x offsets of an (oz, oy) pair x 16 channels (lane group q: ox = q >> 1, channels 8 (q & 1) ..), so
+//   Cout =  8: tile m = (pz, py), rows = (px, channel): 9 (tile, oz, oy) steps (18 fp32 blocks of four 32-cycle MFMAs become
+//              9 steps of six 16-cycle ones);
+//   Cout = 16: tile m = (pz, py, px), rows = channel: 18 steps (the odd-px tiles use only the ox = 0 half of K).
+// Steps are issued in GROUPS of up to four tiles that share (oz, oy), hence the input fragments; a group runs in three phases
+// (input piece pc with the weight pieces jw <= 2 - pc), fragments requested one phase ahead, the group's weights (from LDS,
+// resident for the launch) one group ahead.  Tile 4(z) x TY(y) x 16(x) input voxels, TY = 8 / 4; one-sided halo 5 x (TY+1) x 17;
+// three piece images of 32-byte voxels (no swizzle needed: 16 lanes read 16 consecutive voxels, the channel half shifts by 16
+// bytes); branch-free buffer stores as in deconv_up.hip.
+#include <cstring>
+#include <type_traits>
+#include <utility>
+
+#include "conv_common.h"
+
+extern "C" long atvs_deconv_up_grid(int D, int H, int W, int Cout, int groups);
+
+namespace {
+
+constexpr int UB_TZ = 4, UB_TX = 16;
+constexpr int UB_HZ = UB_TZ + 1, UB_HX = UB_TX + 1;
+constexpr int UB_VB = 32;
+constexpr int UB_ROWB = UB_HX * UB_VB;                 // 544
+
+template <int COUT>
+struct UpB {
+  static_assert(COUT == 8 || COUT == 16, "built for 8 and 16 output channels");
+  static constexpr int NT = (COUT == 8) ? 4 : 8;
+  static constexpr int TY = 32 / NT;
+  static constexpr int HY = TY + 1;
+  static constexpr int IMG = UB_HZ * HY * UB_ROWB;     // bytes of one piece image
+  static constexpr int SLOTS = UB_HZ * HY * UB_HX * 4;
+  static constexpr int MAXS = (SLOTS + 255) / 256;     // 12 / 7
+  static constexpr int NG = (COUT == 8) ? 4 : 5;       // groups
+  // group g: its (oz, oy) pair o2 = oz * 2 + oy, its tiles
+  static constexpr int o2_of(int g) { return (COUT == 8) ? g : (g < 2 ? 0 : g - 1); }
+  static constexpr int ntg(int g) { return (COUT == 8) ? (g == 0 ? 4 : g == 3 ? 1 : 2) : (g == 4 ? 2 : 4); }
+  static constexpr int tile(int g, int i) {
+    if (COUT == 8) return g == 0 ? i : g == 1 ? 2 * i : g == 2 ? i : 0;       // o2 = 1 (oy = -1): py = 0; o2 = 2 (oz = -1): pz = 0
+    // Cout 16, tile = pz * 4 + py * 2 + px
+    return g == 0 ? i : g == 1 ? 4 + i : g == 2 ? (i < 2 ? i : 2 + i) : g == 3 ? i : i;      // g2: {0,1,4,5}; g3: {0,1,2,3}; g4: {0,1}
+  }
+  static constexpr int first_step(int g) {
+    int n = 0;
+    for (int k = 0; k < g; ++k) n += ntg(k);
+    return n;
+  }
+  static constexpr int NSTEP = first_step(NG);
+  static constexpr int WCH = NSTEP * 3 * 1024;         // bytes of packed weights per chunk
+};
+static_assert(UpB<8>::NSTEP == 9 && UpB<16>::NSTEP == 18, "(tile, oz, oy) steps");
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+struct UpBArgs {
+  const float* x;
+  const unsigned char* wp;
+  const float* zeros;
+  float* y;
+  double* stats;
+  int Di, Hi, Wi, Cin;
+  int ldy, ycoff;
+  int nchunk;
+  int tiles_y, tiles_x, ntiles;
+  int wg;
+  int relu;
+  long gx, gy;
+};
+
+template <int N>
+using IC = std::integral_constant<int, N>;
+template <class F, int... I>
+__device__ __forceinline__ void ub_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(IC<I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void ub_static_for(F&& f) {
+  ub_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+__device__ __forceinline__ void ub_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const __bf16 a = (__bf16)x[i];
+    const float r1 = x[i] - (float)a;
+    const __bf16 b = (__bf16)r1;
+    const float r2 = r1 - (float)b;
+    (*p0)[i] = a;
+    (*p1)[i] = b;
+    (*p2)[i] = (__bf16)r2;
+  }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
+  using U = UpB<COUT>;
+  constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+
+  // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wp);
+    float4* dst = reinterpret_cast<float4*>(smem + 3 * U::IMG);
+    for (int i = tid; i < p.nchunk * (U::WCH / 16); i += 256) dst[i] = src[i];
+  }
+  // this lane's fragment at halo voxel (wave, 0, r + 1 - ox), ox = q >> 1: offset (-1, -1, ox) of row 0 of the wavefront's plane
+  const int fbase = ((wave * HY) * UB_HX + r + 1 - (q >> 1)) * UB_VB + (q & 1) * 16;
+  const int wbase = 3 * U::IMG + lane * 16;
+
+  int goff[MAXS], laddr[MAXS];
+  unsigned pg[MAXS];
+#pragma unroll
+  for (int i = 0; i < MAXS; ++i) {
+    int s = tid + i * 256;
+    const bool live = s < U::SLOTS;
+    s = min(s, U::SLOTS - 1);
+    const int c4 = s & 3, v = s >> 2;
+    const int xx = v % UB_HX, v2 = v / UB_HX;
+    const int yy = v2 % HY, zz = v2 / HY;
+    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
+    laddr[i] = ((zz * HY + yy) * UB_HX + xx) * UB_VB + c4 * 8;
+    pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+  }
+
+  const int G = p.wg;
+  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
+  const int xcd = lbk & 7, tslot = lbk >> 3;
+  const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
+  float* __restrict__ yg = p.y + (size_t)grp * p.gy;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int slots_per_xcd = G >> 3;
+  int my_tiles = 0;
+  {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);
+    if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
+  }
+  const int nstage = my_tiles * p.nchunk;
+  auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
+    int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
+    int bx = tl % p.tiles_x;
+    int rest = tl / p.tiles_x;
+    *x0 = bx * UB_TX;
+    *y0 = (rest % p.tiles_y) * TY;
+    *z0 = (rest / p.tiles_y) * UB_TZ;
+  };
+  struct PfTile {
+    const float* xb;
+    int org;
+    unsigned lo, hi1;
+  };
+  auto pf_tile = [&](int stage) __attribute__((always_inline)) {
+    PfTile T;
+    int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    int z0, y0, x0;
+    tile_origin(k, &z0, &y0, &x0);
+    const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
+    T.xb = xg + ch * 16;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
+    T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+    T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+            ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+    return T;
+  };
+  float4 pf[MAXS];
+  auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
+    const unsigned t1 = pg[i] - T.lo;
+    const unsigned t2 = T.hi1 + ~pg[i];
+    const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
+    pf[i] = ld4(ok ? (T.xb + (T.org + goff[i])) : p.zeros);
+  };
+
+  f32x2 ssum2[2] = {{0.f, 0.f}, {0.f, 0.f}}, ssq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
+  f32x4 acc[TY][NT];
+  const unsigned ybytes = (unsigned)(p.gy * 4);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
+
+  if (nstage > 0) {
+    const PfTile T0 = pf_tile(0);
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+  }
+
+  for (int stage = 0; stage < nstage; ++stage) {
+    const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    if (ch == 0) {
+#pragma unroll
+      for (int t = 0; t < TY; ++t)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                       // every wavefront is done reading the previous stage's images
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i)
+      if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) {
+        bf16x4 p0, p1, p2;
+        ub_split(pf[i], &p0, &p1, &p2);
+        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<bf16x4*>(smem + U::IMG + laddr[i]) = p1;
+        *reinterpret_cast<bf16x4*>(smem + 2 * U::IMG + laddr[i]) = p2;
+      }
+    __syncthreads();
+
+    const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
+    const int wb = wbase + ch * U::WCH;
+
+    // ---- K loop: groups of tiles sharing (oz, oy), three phases each
+    bf16x8 Bq[2][TY], A[2][4][3];
+    auto request_B = [&](auto PH) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH)::value, g = ph / 3, pc = ph % 3, o2 = U::o2_of(g), oz = o2 >> 1, oy = o2 & 1;
+      constexpr int disp = ((1 - oz) * HY + (1 - oy)) * UB_ROWB;
+#pragma unroll
+      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * U::IMG + fbase + (disp + t * UB_ROWB));
+    };
+    auto request_A = [&](auto GT) __attribute__((always_inline)) {
+      constexpr int g = decltype(GT)::value;
+      ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
+        constexpr int i = decltype(IT)::value;
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          A[g & 1][i][pc] = *reinterpret_cast<const bf16x8*>(smem + wb + ((U::first_step(g) + i) * 3 + pc) * 1024);
+      });
+    };
+    request_A(IC<0>{});
+    request_B(IC<0>{});
+    asm volatile("" ::: "memory");
+    ub_static_for<3 * NG>([&](auto PH) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH)::value, g = ph / 3, pc = ph % 3;
+      if constexpr (ph + 1 < 3 * NG) request_B(IC<ph + 1>{});
+      if constexpr (pc == 1 && g + 1 < NG) request_A(IC<g + 1>{});
+      if constexpr (ph < MAXS) pf_slot(T, ph);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int jw = 0; jw <= 2 - pc; ++jw)
+        ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
+          constexpr int i = decltype(IT)::value, m = U::tile(g, i);
+#pragma unroll
+          for (int t = 0; t < TY; ++t)
+            acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][i][jw], Bq[ph & 1][t], acc[t][m], 0, 0, 0);
+        });
+    });
+    static_assert(3 * NG >= MAXS, "every halo slot is requested inside the K loop");
+    if (ch != p.nchunk - 1) continue;
+
+    // ---- epilogue (deconv_up.hip): this lane holds, of tile m,
+    //   Cout  8: channels (q&1)*4..+3 of output voxel (2z+pz, 2(y0+t)+py, 2(x0+r) + (q>>1)), (pz,py) = m;
+    //   Cout 16: channels 4q..+3      of output voxel (2z+pz, 2(y0+t)+py, 2(x0+r) + px),     (pz,py,px) = m.
+    int tz0, ty0, tx0;
+    tile_origin(k, &tz0, &ty0, &tx0);
+    const int zo = tz0 + wave, xo = tx0 + r;
+    const bool evox_ok = zo < p.Di && xo < p.Wi;
+    const unsigned Hy = 2u * p.Hi, Wy = 2u * p.Wi;
+    const unsigned erow = Wy * p.ldy;
+    const unsigned eplane = Hy * erow;
+    const unsigned lane_c = (COUT == 8) ? (unsigned)((q >> 1) * p.ldy + (q & 1) * 4) : (unsigned)(q * 4);
+    const unsigned eo = (((unsigned)(2 * zo) * Hy + 2 * ty0) * Wy + 2 * xo) * p.ldy + p.ycoff + lane_c;
+    const unsigned vo_ok = evox_ok ? eo * 4u : ybytes;
+    ub_static_for<NT>([&](auto MT) __attribute__((always_inline)) {
+      ub_static_for<TY>([&](auto TT) __attribute__((always_inline)) {
+        constexpr int m = decltype(MT)::value, t = decltype(TT)::value;
+        constexpr int pz = (COUT == 8) ? (m >> 1) : (m >> 2), py = (COUT == 8) ? (m & 1) : ((m >> 1) & 1);
+        constexpr int px = (COUT == 8) ? 0 : (m & 1);
+        float a0 = acc[t][m][0], a1 = acc[t][m][1], a2 = acc[t][m][2], a3 = acc[t][m][3];
+        if (p.relu) {
+          a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
+          a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
+        }
+        const unsigned soff = (pz * eplane + (2 * t + py) * erow + px * p.ldy) * 4u;
+        const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                            __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
+        const bool row_ok = ty0 + t < p.Hi;
+        __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, soff, 0);
+        const bool ok = evox_ok && row_ok;
+        f32x2 lo = {ok ? a0 : 0.f, ok ? a1 : 0.f}, hi = {ok ? a2 : 0.f, ok ? a3 : 0.f};
+        ssum2[0] += lo;
+        ssum2[1] += hi;
+        ssq2[0] = __builtin_elementwise_fma(lo, lo, ssq2[0]);
+        ssq2[1] = __builtin_elementwise_fma(hi, hi, ssq2[1]);
+      });
+    });
+  }
+
+  // ---- per-workgroup partial moments -> row blockIdx of stats: [2][16] doubles (Cout 8: columns 8..15 = 0)
+  if (p.stats) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a = (double)ssum2[kk >> 1][kk & 1], bq = (double)ssq2[kk >> 1][kk & 1];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        a += __shfl_xor(a, o);
+        bq += __shfl_xor(bq, o);
+      }
+      if (COUT == 8) {
+        a += __shfl_xor(a, 32);
+        bq += __shfl_xor(bq, 32);
+      }
+      const int col = (COUT == 8) ? (q & 1) * 4 + kk : q * 4 + kk;
+      if (r == 0 && (COUT == 16 || q < 2)) {
+        s_red[(wave * 2 + 0) * 16 + col] = a;
+        s_red[(wave * 2 + 1) * 16 + col] = bq;
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, col = tid & 15;
+      double v = 0.0;
+      if (col < COUT)
+        v = (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
+            (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
+      p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] = v;
+    }
+  }
+}
+
+float ub_round(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+  float o;
+  std::memcpy(&o, &u, 4);
+  return o;
+}
+uint16_t ub_bits(float v) {
+  uint32_t u;
+  std::memcpy(&u, &v, 4);
+  return (uint16_t)(u >> 16);
+}
+
+size_t ub_lds(int Cin, int Cout) {
+  return Cout == 8 ? 3 * (size_t)UpB<8>::IMG + (size_t)(Cin / 16) * UpB<8>::WCH : 3 * (size_t)UpB<16>::IMG + (size_t)(Cin / 16) * UpB<16>::WCH;
+}
+
+template <int COUT>
+int launch_upb(const UpBArgs& a, long grid, size_t lds, hipStream_t s) {
+  static bool attr_set[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  if (!attr_set[dev]) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_up_b_kernel<COUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            160 * 1024) != hipSuccess)
+      return ATVS_ERR_LAUNCH;
+    attr_set[dev] = true;
+  }
+  hipLaunchKernelGGL((deconv_up_b_kernel<COUT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  return ATVS_OK;
+}
+
+template <int COUT>
+void pack_upb(const float* w, int Cin, uint16_t* out) {
+  using U = UpB<COUT>;
+  auto kof = [](int par, int off) { return par ? (off ? -1 : 1) : (off ? 2 : 0); };
+  for (int ch = 0; ch < Cin / 16; ++ch)
+    for (int g = 0; g < U::NG; ++g)
+      for (int i = 0; i < U::ntg(g); ++i) {
+        const int m = U::tile(g, i), o2 = U::o2_of(g), oz = o2 >> 1, oy = o2 & 1, step = U::first_step(g) + i;
+        const int pz = (COUT == 8) ? (m >> 1) : (m >> 2), py = (COUT == 8) ? (m & 1) : ((m >> 1) & 1);
+        const int kd = kof(pz, oz), kh = kof(py, oy);
+        if (kd < 0 || kh < 0) continue;                   // never: the groups hold active (tile, oz, oy) only
+        for (int q = 0; q < 4; ++q)
+          for (int row = 0; row < 16; ++row) {
+            const int px = (COUT == 8) ? (row >> 3) : (m & 1), co = (COUT == 8) ? (row & 7) : row;
+            const int kw = kof(px, q >> 1);
+            if (kw < 0) continue;
+            for (int e = 0; e < 8; ++e) {
+              const int ci = ch * 16 + (q & 1) * 8 + e;
+              const float v = w[((((size_t)kd * 3 + kh) * 3 + kw) * COUT + co) * Cin + ci];
+              const float p0 = ub_round(v), p1 = ub_round(v - p0), p2 = ub_round((v - p0) - p1);
+              const float pc[3] = {p0, p1, p2};
+              for (int k = 0; k < 3; ++k)
+                out[((((size_t)ch * U::NSTEP + step) * 3 + k) * 64 + q * 16 + row) * 8 + e] = ub_bits(pc[k]);
+            }
+          }
+      }
+}
+
+}  // namespace
+
+// the packed weights of all chunks stay in LDS beside the three piece images
+extern "C" int atvs_deconv_up_b_supported(int Cin, int Cout) {
+  if ((Cout != 8 && Cout != 16) || Cin <= 0 || Cin % 16) return 0;
+  return ub_lds(Cin, Cout) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int atvs_deconv_up_b_pack_size(int Cin, int Cout, long* packed_bytes) {
+  if (!packed_bytes) return ATVS_ERR_NULL;
+  if (!atvs_deconv_up_b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
+  *packed_bytes = (long)(Cin / 16) * (Cout == 8 ? UpB<8>::WCH : UpB<16>::WCH) + 16;
+  return ATVS_OK;
+}
+
+// HOST function.  w: TF kernel of tf.layers.conv3d_transpose, [3,3,3,Cout,Cin].  packed[chunk][step][piece][lane = q*16 + row]
+// [8 bf16]: step = the (tile, oz, oy) steps in group order; row as in atvs_deconv_up_pack; lane group q: ox = q >> 1, input
+// channels chunk*16 + 8 (q & 1) + e; value = piece of w[kd][kh][kw][co][ci], k per axis from (parity, offset): (0,0) -> 0,
+// (0,-1) -> 2, (1,0) -> 1, (1,-1) -> structural zero.
+extern "C" int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned char* packed) {
+  if (!w || !packed) return ATVS_ERR_NULL;
+  long pb;
+  int rc = atvs_deconv_up_b_pack_size(Cin, Cout, &pb);
+  if (rc) return rc;
+  std::memset(packed, 0, (size_t)pb);
+  if (Cout == 8) pack_upb<8>(w, Cin, reinterpret_cast<uint16_t*>(packed));
+  else pack_upb<16>(w, Cin, reinterpret_cast<uint16_t*>(packed));
+  return ATVS_OK;
+}
+
+// Contract of atvs_deconv_up_f32 (grid / statistics rows = atvs_deconv_up_grid) with split-bf16 operands (fp32-class results).
+extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups,
+                                    int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream) {
+  if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (!atvs_deconv_up_b_supported(Cin, Cout) || groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
+  if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
+  if (8.0 * D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;
+  UpBArgs a;
+  long pb;
+  atvs_deconv_up_b_pack_size(Cin, Cout, &pb);
+  a.x = x; a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  a.y = y; a.stats = stats_partial;
+  a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16; a.relu = relu;
+  const int ty = (Cout == 8) ? UpB<8>::TY : UpB<16>::TY;
+  a.tiles_y = (H + ty - 1) / ty; a.tiles_x = (W + UB_TX - 1) / UB_TX;
+  a.ntiles = ((D + UB_TZ - 1) / UB_TZ) * a.tiles_y * a.tiles_x;
+  const long blocks = atvs_deconv_up_grid(D, H, W, Cout, groups);
+  a.wg = (int)blocks;
+  a.gx = (long)D * H * W * Cin; a.gy = 8L * D * H * W * ldy;
+  if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  hipStream_t st = as_stream(stream);
+  const size_t lds = ub_lds(Cin, Cout);
+  int rc = (Cout == 8) ? launch_upb<8>(a, blocks * groups, lds, st) : launch_upb<16>(a, blocks * groups, lds, st);
+  if (rc) return rc;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

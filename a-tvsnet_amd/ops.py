@@ -406,10 +406,11 @@ def pack_conv_xp(key, w_host, device):
     return pk
 
 
-def pack_deconv_up(key, w_host, device):
-    """Packed weights of the 8-channel transposed-convolution kernel (atvs_deconv_up_f32); cached."""
+def pack_deconv_up(key, w_host, device, kind=''):
+    """Packed weights of the 8- / 16-channel transposed-convolution kernels (atvs_deconv_up_f32; kind '_b': the split-bf16
+    atvs_deconv_up_b_f32, bytes of bf16 pieces); cached."""
     import numpy as np
-    ck = ('up', key, str(device))
+    ck = ('up' + kind, key, str(device))
     pk = _pack_cache.get(ck)
     if pk is not None:
         return pk
@@ -417,13 +418,14 @@ def pack_deconv_up(key, w_host, device):
     cout, cin = int(w.shape[-2]), int(w.shape[-1])
     L = _lib.lib()
     pf = ctypes.c_long()
-    rc = L.atvs_deconv_up_pack_size(cin, cout, ctypes.byref(pf))
+    rc = getattr(L, 'atvs_deconv_up%s_pack_size' % kind)(cin, cout, ctypes.byref(pf))
     if rc:
-        raise RuntimeError('atvs_deconv_up_pack_size failed (%d) for %d -> %d' % (rc, cin, cout))
-    packed = np.empty(pf.value, np.float32)
-    rc = L.atvs_deconv_up_pack(w.ctypes.data_as(ctypes.c_void_p), cin, cout, packed.ctypes.data_as(ctypes.c_void_p))
+        raise RuntimeError('atvs_deconv_up%s_pack_size failed (%d) for %d -> %d' % (kind, rc, cin, cout))
+    packed = np.empty(pf.value, np.uint8 if kind else np.float32)
+    rc = getattr(L, 'atvs_deconv_up%s_pack' % kind)(w.ctypes.data_as(ctypes.c_void_p), cin, cout,
+                                                    packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
-        raise RuntimeError('atvs_deconv_up_pack failed (%d)' % rc)
+        raise RuntimeError('atvs_deconv_up%s_pack failed (%d)' % (kind, rc))
     pk = _Packed()
     pk.ntaps, pk.vec, pk.ksteps, pk.ntiles, pk.cin, pk.cout = 27, 4, 0, 1, cin, cout
     pk.key = key
@@ -1499,7 +1501,8 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
     M = D * H * W
     if deconv_up_ok(Cin, cout) and 32.0 * M * cout < 2.0 ** 32:
         # all 8 parity classes from one staged input tile, one workgroup per CU (csrc/deconv_up.hip)
-        pk = pack_deconv_up(key, w_host, x.device)
+        split = _USE_BF16X3 and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), int(cout)))     # deconv_up_b.hip
+        pk = pack_deconv_up(key, w_host, x.device, '_b' if split else '')
         blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), int(cout), int(G)))
         st, sbuf = None, None
         if want_stats:
@@ -1508,7 +1511,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
             st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 16, 8 * M, G
         if _dev_ok(x5, y5):
             with _Timed(key, x5.shape[1:], cout, G):
-                _call('atvs_deconv_up_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
+                _call('atvs_deconv_up%s_f32' % ('_b' if split else ''), _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
                       int(bool(relu)), _stream())
         return (y, st) if want_stats else y
     classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 21
+#define ATVS_ABI_VERSION 22
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -370,6 +370,16 @@ int atvs_conv3d_s2b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
 int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
                         int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* atvs_deconv_up_f32's layers and contract (grid / statistics rows = atvs_deconv_up_grid) with SPLIT bf16 operands on the bf16
+ * matrix cores (deconv_up_b.hip; the arithmetic of atvs_conv_c16b_f32).  The packed weights of all chunks stay in LDS beside
+ * three piece images: atvs_deconv_up_b_supported (Cout 8: Cin <= 48; Cout 16: Cin <= 32).  Weights: atvs_deconv_up_b_pack
+ * (HOST; size in BYTES). */
+int atvs_deconv_up_b_supported(int Cin, int Cout);
+int atvs_deconv_up_b_pack_size(int Cin, int Cout, long* packed_bytes);
+int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
+int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups, int D, int H,
+                         int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
  * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a

@@ -227,14 +227,25 @@ def test_networks_with_prologue_equal_materialised_inputs(cuda, weights):
 @pytest.mark.parametrize('G,shape,cin,cout', [(1, (9, 17, 33), 16, 8), (2, (4, 8, 16), 32, 8), (3, (5, 9, 18), 64, 8),
                                              (2, (12, 24, 40), 16, 8), (1, (9, 17, 33), 32, 16), (3, (5, 9, 18), 16, 16),
                                              (2, (8, 12, 40), 64, 16)])
-def test_deconv_up_against_torch_and_the_class_fused_form(cuda, G, shape, cin, cout):
-    """The 8- / 16-channel transposed convolutions (conv_b*_6_0, conv_b*_5_0, reference cnn_wrapper/network.py:510-550) on its own kernel
-    (csrc/deconv_up.hip): against tf.layers.conv3d_transpose restated with torch (tolerance 2e-5 of the output scale: a
+@pytest.mark.parametrize('split', [True, False])
+def test_deconv_up_against_torch_and_the_class_fused_form(cuda, G, shape, cin, cout, split):
+    """The 8- / 16-channel transposed convolutions (conv_b*_6_0, conv_b*_5_0, reference cnn_wrapper/network.py:510-550) on their own
+    kernels (csrc/deconv_up_b.hip: split-bf16 operands, default where its weights fit LDS; csrc/deconv_up.hip: fp32 MFMA): against tf.layers.conv3d_transpose restated with torch (tolerance 2e-5 of the output scale: a
     different accumulation order), and its statistics / grouped form against the separate calls."""
     from oracle import tf_ops as T
     from atvsnet_amd import ops
     x = _rand((G,) + shape + (cin,), 21)
     w = _rand((3, 3, 3, cout, cin), 22) * 0.2
+    ops.use_bf16x3(split)
+    ops.clear_pack_cache()
+    try:
+        _deconv_up_checks(cuda, ops, T, x, w, G, shape, cin, cout)
+    finally:
+        ops.use_bf16x3(True)
+        ops.clear_pack_cache()
+
+
+def _deconv_up_checks(cuda, ops, T, x, w, G, shape, cin, cout):
     got, st = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin, cout), w.numpy(), want_stats=True, groups=G)
     assert st.cpad == 16 and st.groups == G and st.fold == 1
     D, H, W = shape

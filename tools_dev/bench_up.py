@@ -1,0 +1,28 @@
+"""The transposed convolutions to 8 / 16 channels: fp32 MFMA (deconv_up.hip) vs split-bf16 (deconv_up_b.hip)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import atvsnet_amd
+from atvsnet_amd import ops
+dev = torch.device('cuda:0')
+for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 8), (4, 96, 64, 80, 16, 8), (8, 48, 32, 40, 32, 16), (4, 48, 32, 40, 32, 16)):
+    x = torch.randn(G, D, H, W, cin, device=dev)
+    w = (np.random.default_rng(0).standard_normal((3, 3, 3, cout, cin)) * 0.05).astype(np.float32)
+    for name, flag in (('fp32', False), ('split-bf16', True)):
+        ops.use_bf16x3(flag)
+        ops.clear_pack_cache()
+        run = lambda: ops.conv3d_transpose_s2(x, ('u', cin, cout), w, want_stats=True, groups=G)      # noqa: E731
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            run()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        gb = 4.0 * G * D * H * W * (cin + 8 * cout) / 1e9
+        print('G=%d %dx%dx%d %3d -> %3d  %-10s %.4f ms  %.2f TB/s' % (G, D, H, W, cin, cout, name, ms, gb / ms), flush=True)
+ops.use_bf16x3(True)
