@@ -50,6 +50,24 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE_STREAMS = True
+_side_pool = {}
+
+
+def use_side_streams(flag):
+    """Testing / A-B hook: independent small launches of one layer on side streams (parallel branches of a captured graph)."""
+    global _SIDE_STREAMS
+    _SIDE_STREAMS = bool(flag)
+
+
+def _side_stream(device, i):
+    key = (str(device), i)
+    s = _side_pool.get(key)
+    if s is None:
+        s = _side_pool[key] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _call(name, *args):
     rc = getattr(_lib.lib(), name)(*args)
     if rc != 0:
@@ -1541,6 +1559,10 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
             fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, cout)), st.partial
             fin.rows, fin.arrivals, fin.channels, fin.fold, fin.count = blocks * nl, blocks * nl, cout, per, 8 * M
             st.params = fin.params
+        # the class groups are independent launches that each fill only part of the chip at the resolutions this path serves
+        # (eighth resolution: 384 tiles): launches after the first go to side streams (parallel branches of a captured graph)
+        main = torch.cuda.current_stream() if (nl > 1 and _SIDE_STREAMS and x.is_cuda) else None
+        sides = []
         for i in range(nl):
             wpart = wv[:, :, i * per * cout:(i + 1) * per * cout]
             pk = pack_conv_weights_tiled((key, 'cls', i), wpart, taps, False, x.device, tile_y)
@@ -1550,7 +1572,16 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
                     sb = sbufs[i]
                 else:          # G == 1 or a single launch: the launch's rows are a contiguous slice
                     sb = st.partial.reshape(-1, 2, nt * 16)[i * blocks:(i + 1) * blocks] if G == 1 else st.partial
-            conv_tiled_launch(x5, pk, y5, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per, fin=fin)
+            if main is not None and i > 0:
+                side = _side_stream(x.device, i - 1)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    conv_tiled_launch(x5, pk, y5, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per, fin=fin)
+                sides.append(side)
+            else:
+                conv_tiled_launch(x5, pk, y5, 2, (0, 0, 0), 0, tile_y, None, None, relu, sb, None, cout, i * per, fin=fin)
+        for side in sides:
+            main.wait_stream(side)
         if sbufs is not None:
             for i in range(nl):
                 st.partial[:, i * blocks:(i + 1) * blocks].copy_(sbufs[i])
