@@ -137,6 +137,10 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
                                                            int W, int tiles_y, int tiles_x, int tiles) {
   __shared__ float4 tile[ST_HZ * ST_HY * ST_HX];          // (geo0, geo1, prob, hull) per halo voxel
   __shared__ double s_red[4][2][24];
+#ifdef ST_EXP_LDSW
+  __shared__ __attribute__((aligned(16))) float s_w[27 * 32];
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) s_w[i] = w[i];
+#endif
   const int tid = threadIdx.x;
   const int grp = blockIdx.x / tiles, t = blockIdx.x - grp * tiles;
   const int x0 = (t % tiles_x) * ST_TX, y0 = ((t / tiles_x) % tiles_y) * ST_TY, z0 = (t / (tiles_x * tiles_y)) * ST_TZ;
@@ -173,7 +177,11 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
   for (int kd = 0; kd < 3; ++kd)
 #pragma unroll 1
     for (int j = 0; j < 9; ++j) {
+#ifdef ST_EXP_LDSW
+      const float* wk = s_w + (kd * 9 + j) * 32;                // broadcast LDS reads: in order with the fragment reads
+#else
       const float* wk = w + (kd * 9 + j) * 32;                  // uniform address: scalar loads
+#endif
       f32x2 wr[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) wr[k] = (f32x2){wk[2 * k], wk[2 * k + 1]};
