@@ -73,6 +73,7 @@ struct UpBArgs {
   int tiles_y, tiles_x, ntiles;
   int wg;
   int relu;
+  int stats_ld, stats_coff;   // doubles per half row of stats, first column of this launch's channels
   long gx, gy;
 };
 
@@ -101,7 +102,9 @@ __device__ __forceinline__ void ub_split(const float4& v, bf16x4* p0, bf16x4* p1
   }
 }
 
-template <int COUT>
+// STREAMW: the packed weights of ONE chunk live in LDS and are re-read from L2 at every stage (Cin too large for all chunks to
+// stay resident: the 64 -> 32 layer as two 16-channel launches)
+template <int COUT, bool STREAMW>
 __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
   using U = UpB<COUT>;
   constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
   const int r = lane & 15, q = lane >> 4;
 
   // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
-  {
+  if (!STREAMW) {
     const float4* src = reinterpret_cast<const float4*>(p.wp);
     float4* dst = reinterpret_cast<float4*>(smem + 3 * U::IMG);
     for (int i = tid; i < p.nchunk * (U::WCH / 16); i += 256) dst[i] = src[i];
@@ -201,7 +204,12 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
 #pragma unroll
         for (int m = 0; m < NT; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    __syncthreads();                       // every wavefront is done reading the previous stage's images
+    __syncthreads();                       // every wavefront is done reading the previous stage's images (and weights)
+    if (STREAMW) {
+      const float4* src = reinterpret_cast<const float4*>(p.wp + (size_t)ch * U::WCH);
+      float4* dst = reinterpret_cast<float4*>(smem + 3 * U::IMG);
+      for (int i = tid; i < U::WCH / 16; i += 256) dst[i] = src[i];
+    }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) {
@@ -214,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
     __syncthreads();
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
-    const int wb = wbase + ch * U::WCH;
+    const int wb = wbase + (STREAMW ? 0 : ch * U::WCH);
 
     // ---- K loop: groups of tiles sharing (oz, oy), three phases each
     bf16x8 Bq[2][TY], A[2][4][3];
@@ -322,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
       if (col < COUT)
         v = (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
             (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
-      p.stats[((size_t)blockIdx.x * 2 + which) * 16 + col] = v;
+      if (col < COUT || p.stats_ld == 16) p.stats[((size_t)blockIdx.x * 2 + which) * p.stats_ld + p.stats_coff + col] = v;
     }
   }
 }
@@ -344,19 +352,21 @@ uint16_t ub_bits(float v) {
 size_t ub_lds(int Cin, int Cout) {
   return Cout == 8 ? 3 * (size_t)UpB<8>::IMG + (size_t)(Cin / 16) * UpB<8>::WCH : 3 * (size_t)UpB<16>::IMG + (size_t)(Cin / 16) * UpB<16>::WCH;
 }
+// all chunks resident if they fit, else one chunk at a time (Cout 16 only)
+bool ub_stream(int Cin, int Cout) { return Cout == 16 && ub_lds(Cin, Cout) > 160 * 1024; }
 
-template <int COUT>
+template <int COUT, bool STREAMW>
 int launch_upb(const UpBArgs& a, long grid, size_t lds, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_up_b_kernel<COUT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_up_b_kernel<COUT, STREAMW>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((deconv_up_b_kernel<COUT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((deconv_up_b_kernel<COUT, STREAMW>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -390,10 +400,11 @@ void pack_upb(const float* w, int Cin, uint16_t* out) {
 
 }  // namespace
 
-// the packed weights of all chunks stay in LDS beside the three piece images
+// the packed weights of all chunks stay in LDS beside the three piece images where they fit (Cout 8: Cin <= 48; Cout 16:
+// Cin <= 32); Cout 16 with more input channels re-reads one chunk's weights per stage
 extern "C" int atvs_deconv_up_b_supported(int Cin, int Cout) {
-  if ((Cout != 8 && Cout != 16) || Cin <= 0 || Cin % 16) return 0;
-  return ub_lds(Cin, Cout) <= 160 * 1024 ? 1 : 0;
+  if ((Cout != 8 && Cout != 16) || Cin <= 0 || Cin % 16 || Cin > 256) return 0;
+  return (ub_lds(Cin, Cout) <= 160 * 1024 || Cout == 16) ? 1 : 0;
 }
 
 extern "C" int atvs_deconv_up_b_pack_size(int Cin, int Cout, long* packed_bytes) {
@@ -419,9 +430,13 @@ extern "C" int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned
 }
 
 // Contract of atvs_deconv_up_f32 (grid / statistics rows = atvs_deconv_up_grid) with split-bf16 operands (fp32-class results).
+// stats_ld / stats_coff: a statistics row is [2][stats_ld] doubles and this launch's channels start at column stats_coff
+// (16 / 0 = atvs_deconv_up_f32's layout; a wider layer computed 16 channels per launch passes its width and 0, 16, ...).
 extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups,
-                                    int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream) {
+                                    int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, int stats_ld,
+                                    int stats_coff, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (stats_ld < 16 || stats_coff < 0 || stats_coff + (stats_ld == 16 ? 16 : Cout) > stats_ld) return ATVS_ERR_ARG;
   if (!atvs_deconv_up_b_supported(Cin, Cout) || groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
@@ -432,6 +447,7 @@ extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_
   a.x = x; a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
   a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16; a.relu = relu;
+  a.stats_ld = stats_ld; a.stats_coff = stats_coff;
   const int ty = (Cout == 8) ? UpB<8>::TY : UpB<16>::TY;
   a.tiles_y = (H + ty - 1) / ty; a.tiles_x = (W + UB_TX - 1) / UB_TX;
   a.ntiles = ((D + UB_TZ - 1) / UB_TZ) * a.tiles_y * a.tiles_x;
@@ -440,8 +456,10 @@ extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_
   a.gx = (long)D * H * W * Cin; a.gy = 8L * D * H * W * ldy;
   if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
-  const size_t lds = ub_lds(Cin, Cout);
-  int rc = (Cout == 8) ? launch_upb<8>(a, blocks * groups, lds, st) : launch_upb<16>(a, blocks * groups, lds, st);
+  const bool stream_w = ub_stream(Cin, Cout);
+  const size_t lds = stream_w ? 3 * (size_t)UpB<16>::IMG + UpB<16>::WCH : ub_lds(Cin, Cout);
+  int rc = (Cout == 8) ? launch_upb<8, false>(a, blocks * groups, lds, st)
+                       : stream_w ? launch_upb<16, true>(a, blocks * groups, lds, st) : launch_upb<16, false>(a, blocks * groups, lds, st);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

@@ -1529,8 +1529,30 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
             st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 16, 8 * M, G
         if _dev_ok(x5, y5):
             with _Timed(key, x5.shape[1:], cout, G):
-                _call('atvs_deconv_up%s_f32' % ('_b' if split else ''), _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
-                      int(bool(relu)), _stream())
+                if split:
+                    _call('atvs_deconv_up_b_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
+                          int(bool(relu)), 16, 0, _stream())
+                else:
+                    _call('atvs_deconv_up_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
+                          int(bool(relu)), _stream())
+        return (y, st) if want_stats else y
+    if cout == 32 and _USE_DECONV_UP and _USE_BF16X3 and _FORCE_IMPL is None and 32.0 * M * cout < 2.0 ** 32 \
+            and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), 16)):
+        # the 64 -> 32 layer (conv_b*_4_0) as two 16-channel launches of the split-bf16 kernel into the halves of y
+        import numpy as np
+        blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), 16, int(G)))
+        st, sbuf = None, None
+        if want_stats:
+            sbuf = _stats_buffer(x, blocks, 32, groups=G)
+            st = Stats()
+            st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 32, 8 * M, G
+        w = np.asarray(w_host)
+        for h in range(2):
+            pk = pack_deconv_up((key, 'half', h), np.ascontiguousarray(w[:, :, :, 16 * h:16 * h + 16, :]), x.device, '_b')
+            if _dev_ok(x5, y5):
+                with _Timed(key, x5.shape[1:], 16, G):
+                    _call('atvs_deconv_up_b_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, 16, 32, 16 * h,
+                          int(bool(relu)), 32, 16 * h, _stream())
         return (y, st) if want_stats else y
     classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
     fused = _FORCE_IMPL != 'gather' and cout % 4 == 0 and cout <= 64 and (W >= 12 or _FORCE_IMPL == 'tiled')

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 23
+#define ATVS_ABI_VERSION 24
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -373,13 +373,16 @@ int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const flo
 
 /* atvs_deconv_up_f32's layers and contract (grid / statistics rows = atvs_deconv_up_grid) with SPLIT bf16 operands on the bf16
  * matrix cores (deconv_up_b.hip; the arithmetic of atvs_conv_c16b_f32).  The packed weights of all chunks stay in LDS beside
- * three piece images: atvs_deconv_up_b_supported (Cout 8: Cin <= 48; Cout 16: Cin <= 32).  Weights: atvs_deconv_up_b_pack
- * (HOST; size in BYTES). */
+ * three piece images where they fit (Cout 8: Cin <= 48; Cout 16: Cin <= 32); Cout 16 with more input channels re-reads one chunk's
+ * weights per stage (atvs_deconv_up_b_supported).  stats_ld / stats_coff: a statistics row is [2][stats_ld] doubles and this
+ * launch's channels start at column stats_coff (16, 0 = atvs_deconv_up_f32's layout): a 32-channel layer (conv_b*_4_0) runs as two
+ * 16-channel launches with y_coff / stats_coff 0 and 16, ldy = stats_ld = 32.  Weights: atvs_deconv_up_b_pack (HOST; size in BYTES). */
 int atvs_deconv_up_b_supported(int Cin, int Cout);
 int atvs_deconv_up_b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
 int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups, int D, int H,
-                         int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+                         int W, int Cin, int Cout, int ldy, int y_coff, int relu, int stats_ld, int stats_coff,
+                         atvs_stream_t stream);
 
 /* AANet aggregation over nv source views in ONE launch (aanet_fused.hip; network.py:282-351, 378-408): the shared | unique
  * 3x3x3 8 -> 16 convolution of every view (split-bf16 operands, ReLU: atvs_conv_c16b_f32 with packed_w =

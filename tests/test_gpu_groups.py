@@ -224,6 +224,40 @@ def test_networks_with_prologue_equal_materialised_inputs(cuda, weights):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('G,shape,cin', [(2, (6, 8, 20), 64), (1, (5, 9, 18), 32), (3, (3, 4, 17), 48)])
+def test_deconv_32_channels_as_two_split_launches(cuda, G, shape, cin):
+    """conv_b*_4_0 (64 -> 32 at eighth resolution) as two 16-channel launches of the split-bf16 transposed-convolution kernel
+    (weights of one chunk re-read per stage, channel halves of y and of the statistics rows): against torch, its moments, its
+    grouped form against single launches, and against the class-fused fp32 form."""
+    from oracle import tf_ops as T
+    from atvsnet_amd import ops
+    cout = 32
+    x = _rand((G,) + shape + (cin,), 31)
+    w = _rand((3, 3, 3, cout, cin), 32) * 0.2
+    ops.clear_pack_cache()
+    got, st = ops.conv3d_transpose_s2(x.to(cuda), ('up32', cin), w.numpy(), want_stats=True, groups=G)
+    assert st.cpad == 32 and st.groups == G and st.fold == 1
+    params = ops.bn_params(st, cout, got)
+    for g in range(G):
+        want = T.conv3d_transpose_same(x[g:g + 1], w, 2)[0]
+        assert float((got[g].cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max()) + 1e-6
+        one, st1 = ops.conv3d_transpose_s2(x[g].to(cuda), ('up32', cin), w.numpy(), want_stats=True)
+        assert torch.equal(one, got[g])
+        pg = params[g] if G > 1 else params
+        mean = want.reshape(-1, cout).double().mean(0)
+        rstd = 1.0 / torch.sqrt(want.reshape(-1, cout).double().var(0, unbiased=False) + 1e-3)
+        assert float((pg[0].cpu().double() - mean).abs().max()) <= 1e-5
+        assert float((pg[1].cpu().double() - rstd).abs().max()) <= 1e-4 * float(rstd.abs().max())
+    ops.use_bf16x3(False)
+    ops.clear_pack_cache()
+    try:
+        ref, _ = ops.conv3d_transpose_s2(x.to(cuda), ('up32', cin), w.numpy(), want_stats=True, groups=G)
+    finally:
+        ops.use_bf16x3(True)
+        ops.clear_pack_cache()
+    assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize('G,shape,cin,cout', [(1, (9, 17, 33), 16, 8), (2, (4, 8, 16), 32, 8), (3, (5, 9, 18), 64, 8),
                                              (2, (12, 24, 40), 16, 8), (1, (9, 17, 33), 32, 16), (3, (5, 9, 18), 16, 16),
                                              (2, (8, 12, 40), 64, 16)])

@@ -6,7 +6,7 @@ import torch
 import atvsnet_amd
 from atvsnet_amd import ops
 dev = torch.device('cuda:0')
-for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 8), (4, 96, 64, 80, 16, 8), (8, 48, 32, 40, 32, 16), (4, 48, 32, 40, 32, 16)):
+for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 8), (4, 96, 64, 80, 16, 8), (8, 48, 32, 40, 32, 16), (4, 48, 32, 40, 32, 16), (8, 24, 16, 20, 64, 32), (4, 24, 16, 20, 64, 32)):
     x = torch.randn(G, D, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, 3, cout, cin)) * 0.05).astype(np.float32)
     for name, flag in (('fp32', False), ('split-bf16', True)):
