@@ -167,15 +167,14 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
 // C/4 passes in which thread t handles pixel pass * (256 / cg) + t / cg, channel group t % cg: two broadcast LDS reads,
 // four gathers, the blend in packed fp32 (two channels per instruction; the same IEEE operations in the same order as
 // blend4, so the result is bit-identical), one 16-byte store -- every pass writes 4 KB contiguous.
-// CG = C / 4 lanes per pixel (4, 8, 16) at compile time: the CG passes are unrolled in batches of WARP_UNROLL so that the gathers
-// of several passes are in flight while earlier passes store (rolled, a wave's gathers and stores alternated: 0.178 ms per
-// 32-channel view against 0.096 ms for the stores alone and 0.112 ms for the gathers alone).
-constexpr int WARP_UNROLL = 4;
-template <int MODE, int CG>
+// (Tried and WITHDRAWN in round 3: the channel-group count as a template parameter with the passes unrolled in batches of
+// four -- 2 % faster alone, but beside a wavefront of another kernel on the same SIMD (two depth maps in flight) the first
+// component of its 16-byte stores came out wrong in lanes 16-31 / 48-63; the same unrolled loop with scalar instead of packed
+// arithmetic was correct, as is this rolled form.  tests/test_gpu_pipeline.py::test_pipelined_inference_two_in_flight.)
+template <int MODE>
 __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     const float* __restrict__ src, const float* __restrict__ Hmats, const float* __restrict__ ref,
-    float* __restrict__ out, float* __restrict__ mask_out, int h, int w, int C_rt, int ld, int c_off, long plane_stride) {
-  constexpr int C = CG * 4;
+    float* __restrict__ out, float* __restrict__ mask_out, int h, int w, int C, int ld, int c_off, long plane_stride) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float s_geo[256 * 12];
   const int d = blockIdx.y;
@@ -203,8 +202,8 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     g[2] = make_float4(t.valid, 0.f, 0.f, 0.f);
   }
   __syncthreads();
-  constexpr int cg = CG;                 // lanes per pixel: 4, 8 or 16 (a divisor of 256)
-  constexpr int ppp = 256 / cg;          // pixels per pass
+  const int cg = C >> 2;                 // lanes per pixel: 4, 8 or 16 (a divisor of 256)
+  const int ppp = 256 / cg;              // pixels per pass
   // channel-last: the cg lanes of a pixel are neighbours (one pixel = C*4 contiguous bytes; cg is a power of two).
   // Chunk-planar: the same pixels per wavefront (all their channel groups: the gathers stay whole 128-byte rows), but lane
   // order (pixel / 4, chunk, pixel % 4, half) so that eight neighbouring lanes write one whole 128-byte line of a chunk plane
@@ -215,48 +214,30 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     lp = ((tid >> (cgs + 2)) << 2) | ((i >> 1) & 3);
     c = (((i >> 3) << 1) | (i & 1)) * 4;
   }
-  for (int p0 = 0; p0 < cg; p0 += WARP_UNROLL) {
-    float4 ga[WARP_UNROLL], gb[WARP_UNROLL], gc[WARP_UNROLL], gd[WARP_UNROLL], gwt[WARP_UNROLL], rr[WARP_UNROLL];
-    float vld[WARP_UNROLL];
-#pragma unroll
-    for (int u = 0; u < WARP_UNROLL; ++u) {
-      const int pl = (p0 + u) * ppp + lp;
-      const bool ok = pix0 + pl < npix;
-      const float4* g = reinterpret_cast<const float4*>(s_geo + pl * 12);
-      const float4 gi = g[0];
-      gwt[u] = g[1];
-      ga[u] = ld4(src + (size_t)(ok ? __float_as_int(gi.x) : 0) * C + c);
-      gb[u] = ld4(src + (size_t)(ok ? __float_as_int(gi.y) : 0) * C + c);
-      gc[u] = ld4(src + (size_t)(ok ? __float_as_int(gi.z) : 0) * C + c);
-      gd[u] = ld4(src + (size_t)(ok ? __float_as_int(gi.w) : 0) * C + c);
-      if (MODE == 1) {
-        vld[u] = g[2].x;
-        rr[u] = ld4(ref + (size_t)(ok ? pix0 + pl : 0) * C + c);
-      }
+  for (int pass = 0; pass < cg; ++pass) {
+    const int pl = pass * ppp + lp;
+    const long pix = pix0 + pl;
+    if (pix >= npix) break;              // pixels ascend with the pass
+    const float4* g = reinterpret_cast<const float4*>(s_geo + pl * 12);
+    const float4 gi = g[0], gw = g[1];
+    const float4 a = ld4(src + (size_t)__float_as_int(gi.x) * C + c), b = ld4(src + (size_t)__float_as_int(gi.y) * C + c);
+    const float4 cc = ld4(src + (size_t)__float_as_int(gi.z) * C + c), dd = ld4(src + (size_t)__float_as_int(gi.w) * C + c);
+    // ((wa a + wb b) + wc c) + wd d per component, two components per instruction
+    const f32x2 wa = {gw.x, gw.x}, wb = {gw.y, gw.y}, wc = {gw.z, gw.z}, wd = {gw.w, gw.w};
+    f32x2 lo = ((wa * (f32x2){a.x, a.y} + wb * (f32x2){b.x, b.y}) + wc * (f32x2){cc.x, cc.y}) + wd * (f32x2){dd.x, dd.y};
+    f32x2 hi = ((wa * (f32x2){a.z, a.w} + wb * (f32x2){b.z, b.w}) + wc * (f32x2){cc.z, cc.w}) + wd * (f32x2){dd.z, dd.w};
+    float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
+    if (MODE == 1) {
+      const float valid = g[2].x;
+      const float4 r = ld4(ref + (size_t)pix * C + c);
+      o.x = fabsf(o.x - r.x) * valid;
+      o.y = fabsf(o.y - r.y) * valid;
+      o.z = fabsf(o.z - r.z) * valid;
+      o.w = fabsf(o.w - r.w) * valid;
     }
-#pragma unroll
-    for (int u = 0; u < WARP_UNROLL; ++u) {
-      const int pl = (p0 + u) * ppp + lp;
-      const long pix = pix0 + pl;
-      if (pix >= npix) continue;
-      const float4 a = ga[u], b = gb[u], cc = gc[u], dd = gd[u], gw = gwt[u];
-      // ((wa a + wb b) + wc c) + wd d per component, two components per instruction
-      const f32x2 wa = {gw.x, gw.x}, wb = {gw.y, gw.y}, wc = {gw.z, gw.z}, wd = {gw.w, gw.w};
-      f32x2 lo = ((wa * (f32x2){a.x, a.y} + wb * (f32x2){b.x, b.y}) + wc * (f32x2){cc.x, cc.y}) + wd * (f32x2){dd.x, dd.y};
-      f32x2 hi = ((wa * (f32x2){a.z, a.w} + wb * (f32x2){b.z, b.w}) + wc * (f32x2){cc.z, cc.w}) + wd * (f32x2){dd.z, dd.w};
-      float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
-      if (MODE == 1) {
-        const float valid = vld[u];
-        const float4 r = rr[u];
-        o.x = fabsf(o.x - r.x) * valid;
-        o.y = fabsf(o.y - r.y) * valid;
-        o.z = fabsf(o.z - r.z) * valid;
-        o.w = fabsf(o.w - r.w) * valid;
-      }
-      // plane_stride > 0: chunk-planar output [C/8][D][h][w][8] (the layout atvs_conv_xw_f32 reads with x_planar)
-      if (plane_stride > 0) st4(out + (size_t)(c >> 3) * (size_t)plane_stride + ((size_t)d * npix + pix) * 8 + (c & 7), o);
-      else st4(out + ((size_t)d * npix + pix) * (size_t)ld + c_off + c, o);
-    }
+    // plane_stride > 0: chunk-planar output [C/8][D][h][w][8] (the layout atvs_conv_xw_f32 reads with x_planar)
+    if (plane_stride > 0) st4(out + (size_t)(c >> 3) * (size_t)plane_stride + ((size_t)d * npix + pix) * 8 + (c & 7), o);
+    else st4(out + ((size_t)d * npix + pix) * (size_t)ld + c_off + c, o);
   }
 }
 
@@ -280,19 +261,12 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
   if (vec && mode < 2 && (C == 16 || C == 32 || C == 64)) {
     // geometry once per pixel, shared by its channel-group lanes
     dim3 g2(cdiv((long)h * w, 256), D);
-#define LAUNCH_SHARED(M, CGV, PS) \
-  hipLaunchKernelGGL((warp_planes_shared_kernel<M, CGV>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C, ld_out, \
-                     c_off, PS)
-    if (mode == 0) {
-      if (C == 16) LAUNCH_SHARED(0, 4, plane_stride);
-      else if (C == 32) LAUNCH_SHARED(0, 8, plane_stride);
-      else LAUNCH_SHARED(0, 16, plane_stride);
-    } else {
-      if (C == 16) LAUNCH_SHARED(1, 4, 0L);
-      else if (C == 32) LAUNCH_SHARED(1, 8, 0L);
-      else LAUNCH_SHARED(1, 16, 0L);
-    }
-#undef LAUNCH_SHARED
+    if (mode == 0)
+      hipLaunchKernelGGL((warp_planes_shared_kernel<0>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
+                         ld_out, c_off, plane_stride);
+    else
+      hipLaunchKernelGGL((warp_planes_shared_kernel<1>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
+                         ld_out, c_off, 0L);
     ATVS_LAUNCH_CHECK();
     return ATVS_OK;
   }

@@ -483,6 +483,21 @@ def pack_conv_c16(key, w_host, device):
 _USE_BF16X3 = os.environ.get('ATVS_BF16X3', '1') == '1'      # ATVS_BF16X3=0: every convolution on the fp32 matrix cores
 
 
+_SPLIT_OFF = set(v for v in os.environ.get('ATVS_SPLIT_OFF', '').split(',') if v)
+
+
+def split_on(name):
+    """Is the split-bf16 kernel family `name` enabled?  (c16b, c3b, s2b, upb, c2b, c1b; `ops.split_off(...)` / ATVS_SPLIT_OFF=a,b
+    keep single families on the fp32 matrix cores -- testing / A-B hook; conv_xb has ops.use_xb.)"""
+    return _USE_BF16X3 and name not in _SPLIT_OFF
+
+
+def split_off(*names):
+    """Testing / A-B hook: exactly these split-bf16 kernel families off (see split_on)."""
+    _SPLIT_OFF.clear()
+    _SPLIT_OFF.update(names)
+
+
 def use_bf16x3(flag):
     """The split-bf16 kernels (x = x0 + x1 + x2, six products, fp32 accumulation; default) or their fp32-MFMA forms: the
     8 / 16 -> 16 channel 3x3x3 convolutions (conv_c16b.hip | conv_c16.hip) and the 8-output-channel x-pair layers
@@ -628,7 +643,7 @@ def pack_conv2d_lds(key, w_host, device):
     import numpy as np
     w = np.ascontiguousarray(w_host, dtype=np.float32)
     cin, cout = int(w.shape[-2]), int(w.shape[-1])
-    split = _USE_BF16X3 and cin % 32 == 0          # conv2d_b.hip: split-bf16 operands (its chunk loop runs in pairs)
+    split = split_on('c2b') and cin % 32 == 0      # conv2d_b.hip: split-bf16 operands (its chunk loop runs in pairs)
     kind = 'b' if split else 'lds'
     ck = ('c2' + kind, key, str(device))
     pk = _pack_cache.get(ck)
@@ -682,7 +697,7 @@ def conv1x1_ok(cin, cout):
     """Is a GEMM kernel (atvs_conv1x1_b_f32 / atvs_conv1x1_f32) used for a stride-1 1x1 convolution of these channel counts?"""
     lib = _lib.lib()
     return (_FORCE_IMPL != 'gather' and _USE_CONV1X1 and
-            bool((_USE_BF16X3 and lib.atvs_conv1x1_b_supported(int(cin), int(cout))) or lib.atvs_conv1x1_supported(int(cin), int(cout))))
+            bool((split_on('c1b') and lib.atvs_conv1x1_b_supported(int(cin), int(cout))) or lib.atvs_conv1x1_supported(int(cin), int(cout))))
 
 
 _USE_CONV1X1 = True
@@ -702,7 +717,7 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
     G, cin = x.shape[0], x.shape[-1]
     pixels = x.numel() // G // cin
     lib = _lib.lib()
-    kind = '_b' if (_USE_BF16X3 and lib.atvs_conv1x1_b_supported(int(cin), int(np.asarray(w_host).size // cin))) else ''
+    kind = '_b' if (split_on('c1b') and lib.atvs_conv1x1_b_supported(int(cin), int(np.asarray(w_host).size // cin))) else ''
     ck = ('c1' + kind, key, str(x.device))
     pk = _pack_cache.get(ck)
     if pk is None:
@@ -1150,13 +1165,13 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
 
     # ---- 3-D, 3x3x3, 8 / 16 / 32 -> 16 and 16..64 -> 32 channels: one workgroup per CU, fully unrolled (the half- and
     # quarter-resolution U-Net layers, the AANet modules' shared | unique convolution)
-    b3 = _USE_BF16X3 and cin % 16 == 0 and cout in (32, 64) and bool(_lib.lib().atvs_conv3d_b_supported(int(cin), int(cout)))
+    b3 = split_on('c3b') and cin % 16 == 0 and cout in (32, 64) and bool(_lib.lib().atvs_conv3d_b_supported(int(cin), int(cout)))
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
             and ((cout == 16 and cin in (8, 16, 32)) or (cout == 32 and cin in (16, 32, 48, 64)) or b3) \
             and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
             and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
-        b16 = _USE_BF16X3 and cin in (8, 16) and cout == 16
+        b16 = split_on('c16b') and cin in (8, 16) and cout == 16
         pk = pack_conv3d_b(key, w_host, x.device) if b3 else \
             pack_conv_c16b(key, w_host, x.device) if b16 else pack_conv_c16(key, w_host, x.device)
         if y5 is None:
@@ -1183,7 +1198,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
 
     # ---- 3-D, 3x3x3, stride 2, SAME, 16 k -> 32 / 64 channels: the U-Net encoders below half resolution on split-bf16 operands
     if nsp == 3 and stride == 2 and dilation == 1 and ks == (3, 3, 3) and padding == 'SAME' and explicit_pad is None \
-            and _USE_BF16X3 and _USE_C16 and _FORCE_IMPL is None and residual is None and plane_bias is None \
+            and split_on('s2b') and _USE_C16 and _FORCE_IMPL is None and residual is None and plane_bias is None \
             and bool(_lib.lib().atvs_conv3d_s2b_supported(int(cin), int(cout))) and outs[2] >= 8 \
             and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
@@ -1519,7 +1534,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
     M = D * H * W
     if deconv_up_ok(Cin, cout) and 32.0 * M * cout < 2.0 ** 32:
         # all 8 parity classes from one staged input tile, one workgroup per CU (csrc/deconv_up.hip)
-        split = _USE_BF16X3 and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), int(cout)))     # deconv_up_b.hip
+        split = split_on('upb') and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), int(cout)))     # deconv_up_b.hip
         pk = pack_deconv_up(key, w_host, x.device, '_b' if split else '')
         blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), int(cout), int(G)))
         st, sbuf = None, None
@@ -1536,7 +1551,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
                     _call('atvs_deconv_up_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
                           int(bool(relu)), _stream())
         return (y, st) if want_stats else y
-    if cout == 32 and _USE_DECONV_UP and _USE_BF16X3 and _FORCE_IMPL is None and 32.0 * M * cout < 2.0 ** 32 \
+    if cout == 32 and _USE_DECONV_UP and split_on('upb') and _FORCE_IMPL is None and 32.0 * M * cout < 2.0 ** 32 \
             and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), 16)):
         # the 64 -> 32 layer (conv_b*_4_0) as two 16-channel launches of the split-bf16 kernel into the halves of y
         import numpy as np

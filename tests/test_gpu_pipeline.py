@@ -210,3 +210,66 @@ def test_pipelined_inference_two_in_flight(cuda, weights):
     p.run(5)                                        # the benchmark loop: captured inputs of each slot, all complete on return
     torch.cuda.synchronize()
     assert torch.isfinite(p.graphs[0].out).all() and torch.isfinite(p.graphs[1].out).all()
+
+
+def test_small_kernels_beside_other_wavefronts(cuda):
+    """Two depth maps in flight put wavefronts of DIFFERENT kernels on one SIMD.  An unrolled form of the plane-sweep warp
+    (packed arithmetic, four passes in flight) produced wrong first components of its 16-byte stores only then -- beside a
+    wavefront of the stride-2 encoder kernel -- and passed every single-stream test.  Here the small kernels of the pipeline
+    run on one stream while register-light convolution kernels run on another; every output must equal its single-stream
+    value."""
+    import numpy as np
+    from atvsnet_amd import ops, synthetic
+    rng = np.random.default_rng(0)
+    wt = lambda *s: (rng.standard_normal(s) * 0.1).astype(np.float32)      # noqa: E731
+    D, h, w, C, G = 32, 32, 40, 32, 4
+    src = torch.randn(h, w, C, device=cuda)
+    cams = torch.from_numpy(synthetic.make_inputs(2, 128, 160, D)[1]).to(cuda)[0]
+    cams4 = cams.clone()
+    cams4[:, 1, :2, :3] /= 4.0
+    Hm = ops.get_homographies(cams4[0], cams4[1], cams[0, 1, 3, 0:1].contiguous(), cams[0, 1, 3, 1:2].contiguous(), D)
+    vol = torch.empty(C // 8, ops.planar_stride(D, h, w), device=cuda)
+    x8 = torch.randn(G, D, h, w, 8, device=cuda)
+    wh = torch.randn(3, 3, 3, 8, 1, device=cuda) * 0.1
+    par = torch.stack([torch.randn(G, 8) * 0.1, torch.rand(G, 8) + 0.5, torch.randn(G, 8) * 0.1], 1).to(cuda).contiguous()
+    victims = {
+        'warp': lambda: ops.planar_view(ops.warp_planes(src, Hm, out=vol, planar=True), D, h, w),
+        'warp channel-last': lambda: ops.warp_planes(src, Hm),
+        '8to1': lambda: ops.conv3d_8to1(x8, wh, groups=G),
+        'bn_add': lambda: ops.bn_add([ops.PendingBN(x8, par, True), ops.PendingBN(x8, par, False)]),
+    }
+    x16 = torch.randn(G, 16, 16, 20, 16, device=cuda)
+    x32 = torch.randn(G, 8, 8, 16, 32, device=cuda)
+    x2d = torch.randn(3, 32, 40, 128, device=cuda)
+    w1632, w3232, w2d, w1 = wt(3, 3, 3, 16, 32), wt(3, 3, 3, 32, 32), wt(3, 3, 128, 128), wt(1, 1, 128, 128)
+    aggressors = {
+        'stride-2 encoder': lambda: ops.conv(x16, 'race_s2b', w1632, stride=2, want_stats=True, groups=G)[0],
+        '32 -> 32': lambda: ops.conv(x32, 'race_c3b', w3232, want_stats=True, groups=G)[0],
+        'tower 3x3': lambda: ops.conv2d_lds(x2d, 'race_c2b', w2d, 2, want_stats=True)[0],
+        'tower 1x1': lambda: ops.conv1x1(x2d, 'race_c1b', w1, want_stats=True)[0],
+    }
+    ref = {k: f().clone() for k, f in victims.items()}
+    for f in aggressors.values():
+        f()
+    torch.cuda.synchronize()
+
+    def capture(f, n):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            outs = [f() for _ in range(n)]
+        return g, outs
+
+    vg = {k: capture(f, 4) for k, f in victims.items()}
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    for an, fa in aggressors.items():
+        ga, _ = capture(fa, 16)
+        for vn, (gv, outs) in vg.items():
+            for rep in range(4):
+                torch.cuda.synchronize()
+                with torch.cuda.stream(sa):
+                    ga.replay()
+                with torch.cuda.stream(sb):
+                    gv.replay()
+                torch.cuda.synchronize()
+                for o in outs:
+                    assert torch.equal(o, ref[vn]), '%s beside %s' % (vn, an)
