@@ -216,6 +216,14 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
       for (int t = 0; t < TY; ++t)
         Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
     };
+    auto request_B1 = [&](auto PH, auto TT) __attribute__((always_inline)) {      // row t of phase ph
+      constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3, t = decltype(TT)::value;
+      constexpr int tA = K::clamp26(K::TPS * j), tB = K::clamp26(K::TPS * j + 1), tC = K::clamp26(K::TPS * j + 2), tD = K::clamp26(K::TPS * j + 3);
+      int a;
+      if constexpr (K::TPS == 2) a = fbase + ((q >> 1) ? K::disp(tB) : K::disp(tA));
+      else a = fbase + ((q & 2) ? ((q & 1) ? K::disp(tD) : K::disp(tC)) : ((q & 1) ? K::disp(tB) : K::disp(tA)));
+      Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
+    };
     auto request_A = [&](auto JT) __attribute__((always_inline)) {
       constexpr int j = decltype(JT)::value;
 #pragma unroll
@@ -224,19 +232,26 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     request_A(IC<0>{});
     request_B(IC<0>{});
     asm volatile("" ::: "memory");
+    // every memory instruction behind ONE MFMA (tools_dev/micro/mfma_bf16_rate.hip: issued in a bunch at the top of a phase they
+    // cost matrix-core time): MFMA m of a phase = (weight piece jw, row t); behind the first eight the next phase's fragments,
+    // then (first phase of a step) the next step's weights, then a halo slot of the next stage
     b16_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
       constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
-      if constexpr (ph + 1 < 3 * JC) request_B(IC<ph + 1>{});
-      if constexpr (pc == 0 && j + 1 < JC) request_A(IC<j + 1>{});
-      if constexpr (ph < MAXS) pf_slot(T, ph);
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int jw = 0; jw <= 2 - pc; ++jw)
-#pragma unroll
-        for (int t = 0; t < TY; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][jw], Bq[ph & 1][t], acc[t], 0, 0, 0);
+      b16_static_for<(3 - pc) * TY>([&](auto M) __attribute__((always_inline)) {
+        constexpr int m = decltype(M)::value, jw = m / TY, t = m % TY;
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][jw], Bq[ph & 1][t], acc[t], 0, 0, 0);
+        if constexpr (m < TY) {
+          if constexpr (ph + 1 < 3 * JC) request_B1(IC<ph + 1>{}, IC<m>{});
+        } else if constexpr (pc == 0 && m < TY + 3) {
+          if constexpr (j + 1 < JC) A[(j + 1) & 1][m - TY] = *reinterpret_cast<const bf16x8*>(smem + wbase + (j + 1) * B16_WSTEP + (m - TY) * 1024);
+        } else if constexpr (m == TY + 4 && pc < 2) {
+          if constexpr (2 * j + pc < MAXS) pf_slot(T, 2 * j + pc);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      });
     });
+    static_assert(2 * JC >= MAXS, "two halo slots per K step");
 
     // ---- epilogue (conv_c16.hip): this lane holds channels 4q..4q+3 of voxel (z0 + wave, y0 + t, x0 + r)
     int tz0, ty0, tx0;
