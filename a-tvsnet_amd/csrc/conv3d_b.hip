@@ -206,32 +206,65 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
         for (int t = 0; t < TY; ++t)
           Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * C3B_IMG + a + t * C3B_ROWB);
       };
-      auto request_A = [&](auto JT, auto HH) __attribute__((always_inline)) {      // step j of tile pair hh -> slot j & 1
-        constexpr int j = decltype(JT)::value, hh = decltype(HH)::value;
-#pragma unroll
-        for (int nn = 0; nn < 2; ++nn)
-#pragma unroll
-          for (int pc = 0; pc < 3; ++pc) A[j & 1][nn][pc] = wch[((j * NT + hh * 2 + nn) * 3 + pc) * 64];
+      auto request_B1 = [&](auto PH, auto TT) __attribute__((always_inline)) {      // row t of phase ph
+        constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3, t = decltype(TT)::value;
+        constexpr int tA = c3b_clamp26(2 * j), tB = c3b_clamp26(2 * j + 1);
+        const int a = fbase + ((q >> 1) ? c3b_disp(tB) : c3b_disp(tA));
+        Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * C3B_IMG + a + t * C3B_ROWB);
       };
       static_assert(JC % 2 == 0, "step 0 of the next tile pair goes to slot 0 while the last step reads slot 1");
       request_B(IC<0>{});
       asm volatile("" ::: "memory");
-      c3b_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
-        constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
-        if constexpr (ph + 1 < 3 * JC) request_B(IC<ph + 1>{});
-        if constexpr (pc == 0 && j + 1 < JC) request_A(IC<j + 1>{}, IC<half>{});
-        if constexpr (pc == 0 && j + 1 == JC && half + 1 < NH) request_A(IC<0>{}, IC<half + 1>{});    // step 0 of the next pair
-        if constexpr (half == 0 && ph < MAXS) pf_slot(T, ph);
-        asm volatile("" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int jw = 0; jw <= 2 - pc; ++jw)
+      if constexpr (NT == 2) {
+      // every memory instruction behind ONE MFMA (tools_dev/micro/mfma_bf16_rate.hip): MFMA m of a phase = (weight piece jw,
+        // tile nn, row t); behind the first eight the next phase's fragments, then (first phase of a step) the six weight
+        // registers of the next step, then a halo slot of the next stage
+        c3b_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
+          constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
+          c3b_static_for<(3 - pc) * 2 * TY>([&](auto M) __attribute__((always_inline)) {
+            constexpr int m = decltype(M)::value, jw = m / (2 * TY), nn = (m / TY) % 2, t = m % TY;
+            acc[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][nn][jw], Bq[ph & 1][t], acc[half * 2 + nn][t], 0, 0, 0);
+            if constexpr (m < TY) {
+              if constexpr (ph + 1 < 3 * JC) request_B1(IC<ph + 1>{}, IC<m>{});
+            } else if constexpr (pc == 0 && m < TY + 6) {
+              constexpr int e = m - TY, en = e / 3, ep = e % 3;
+              if constexpr (j + 1 < JC) A[(j + 1) & 1][en][ep] = wch[(((j + 1) * NT + half * 2 + en) * 3 + ep) * 64];
+              else if constexpr (half + 1 < NH) A[0][en][ep] = wch[((0 * NT + (half + 1) * 2 + en) * 3 + ep) * 64];      // step 0 of the next pair
+            } else if constexpr (half == 0 && pc < 2 && m == TY + 8) {
+              if constexpr (2 * j + pc < MAXS) pf_slot(T, 2 * j + pc);
+            }
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          });
+        });
+      } else {
+        // four tiles per wavefront: the interleaved form spills (74 registers against 36) and is slower -- requests at the top
+        // of each phase
+        auto request_A = [&](auto JT, auto HH) __attribute__((always_inline)) {      // step j of tile pair hh -> slot j & 1
+          constexpr int j = decltype(JT)::value, hh = decltype(HH)::value;
 #pragma unroll
           for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-            for (int t = 0; t < TY; ++t)
-              acc[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][nn][jw], Bq[ph & 1][t], acc[half * 2 + nn][t], 0, 0, 0);
-      });
+            for (int pc = 0; pc < 3; ++pc) A[j & 1][nn][pc] = wch[((j * NT + hh * 2 + nn) * 3 + pc) * 64];
+        };
+        c3b_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
+          constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
+          if constexpr (ph + 1 < 3 * JC) request_B(IC<ph + 1>{});
+          if constexpr (pc == 0 && j + 1 < JC) request_A(IC<j + 1>{}, IC<half>{});
+          if constexpr (pc == 0 && j + 1 == JC && half + 1 < NH) request_A(IC<0>{}, IC<half + 1>{});    // step 0 of the next pair
+          if constexpr (half == 0 && ph < MAXS) pf_slot(T, ph);
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int jw = 0; jw <= 2 - pc; ++jw)
+#pragma unroll
+            for (int nn = 0; nn < 2; ++nn)
+#pragma unroll
+              for (int t = 0; t < TY; ++t)
+                acc[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][nn][jw], Bq[ph & 1][t], acc[half * 2 + nn][t], 0, 0, 0);
+        });
+      }
+      static_assert(2 * JC >= MAXS, "two halo slots per K step");
     });
     if (ch != p.nchunk - 1) continue;
 
