@@ -170,9 +170,8 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
 // (Tried and WITHDRAWN in round 3: the channel-group count as a template parameter with the passes unrolled in batches of
 // four -- 2 % faster alone, but beside a wavefront of another kernel on the same SIMD (two depth maps in flight) the first
 // component of its 16-byte stores came out wrong in lanes 16-31 / 48-63; the same unrolled loop with scalar instead of packed
-// arithmetic was correct, as is this rolled form.  In its ISA the 16-byte store was split into global_store_dword v62 +
-// global_store_dwordx3 v[62:64] with v_mov_b32 v62, v63 a few instructions after the first: the data register of a store
-// in flight overwritten.  tests/test_gpu_pipeline.py::test_pipelined_inference_two_in_flight, ::test_small_kernels_beside_...)
+// arithmetic was correct, as is this rolled form (an unsplit 16-byte store or s_nop padding behind the store did not help: DESIGN.md
+// 6).  tests/test_gpu_pipeline.py::test_pipelined_inference_two_in_flight, ::test_small_kernels_beside_other_wavefronts.)
 template <int MODE>
 __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     const float* __restrict__ src, const float* __restrict__ Hmats, const float* __restrict__ ref,
