@@ -17,6 +17,17 @@ HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'atvsnet_hip.h')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result']
+# Kernels whose wavefronts can share a SIMD with another kernel's (two depth maps in flight, side streams) are built WITHOUT
+# compiler-formed packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): beside wavefronts of the bf16-MFMA
+# kernels such instructions produced wrong lane quarters (tests/test_gpu_pipeline.py).  The kernels that own
+# their SIMDs' whole register file keep the vectoriser.
+NO_PACKED_F32 = ('geometry', 'norm', 'pool', 'softargmin', 'aanet', 'fusion', 'api', 'conv', 'conv1x1', 'conv1x1_b',
+                 'conv2d_lds', 'conv2d_b', 'conv_tiled')
+
+
+def flags_for(src):
+    stem = os.path.splitext(os.path.basename(src))[0]
+    return FLAGS + (['-fno-slp-vectorize'] if stem in NO_PACKED_F32 else [])
 
 _lib = None
 
@@ -46,7 +57,7 @@ def build(force=False, verbose=False):
                 [os.path.getmtime(src), os.path.getmtime(HEADER)] +
                 [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))]):
             continue
-        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        cmd = [HIPCC] + flags_for(src) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
         procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -13,6 +13,7 @@ Differences from the reference, none of which changes a value:
 * optional keyword arguments let the caller pass feature-tower outputs it already has
   (the reference recomputes the reference tower for every source view).
 """
+import os
 import torch
 
 from .. import ops

@@ -165,13 +165,12 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
 // VALU instructions for one 16-byte store: the kernel was instruction-bound at 46 % of the HBM peak).  Here a workgroup
 // owns 256 pixels of one plane: phase 1, one pixel per thread -> taps and weights into LDS (48 bytes per pixel); phase 2,
 // C/4 passes in which thread t handles pixel pass * (256 / cg) + t / cg, channel group t % cg: two broadcast LDS reads,
-// four gathers, the blend in packed fp32 (two channels per instruction; the same IEEE operations in the same order as
-// blend4, so the result is bit-identical), one 16-byte store -- every pass writes 4 KB contiguous.
-// (Tried and WITHDRAWN in round 3: the channel-group count as a template parameter with the passes unrolled in batches of
-// four -- 2 % faster alone, but beside a wavefront of another kernel on the same SIMD (two depth maps in flight) the first
-// component of its 16-byte stores came out wrong in lanes 16-31 / 48-63; the same unrolled loop with scalar instead of packed
-// arithmetic was correct, as is this rolled form (an unsplit 16-byte store or s_nop padding behind the store did not help: DESIGN.md
-// 6).  tests/test_gpu_pipeline.py::test_pipelined_inference_two_in_flight, ::test_small_kernels_beside_other_wavefronts.)
+// four gathers, the blend (the same IEEE operations in the same order as blend4, so the result is bit-identical), one
+// 16-byte store -- every pass writes 4 KB contiguous.
+// (Round 3: an unrolled form of this kernel, and homographies_kernel, produced wrong lane quarters beside wavefronts of a
+// bf16-MFMA kernel on the same SIMD -- two depth maps in flight.  Common factor: compiler-formed packed fp32 arithmetic.  This
+// file is built with -fno-slp-vectorize (_lib.NO_PACKED_F32) and the blend below is scalar.  DESIGN.md 6;
+// tests/test_gpu_pipeline.py::test_small_kernels_beside_other_wavefronts, ::test_two_depth_maps_in_flight_fullsize.)
 template <int MODE>
 __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     const float* __restrict__ src, const float* __restrict__ Hmats, const float* __restrict__ ref,
@@ -224,10 +223,13 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     const float4 a = ld4(src + (size_t)__float_as_int(gi.x) * C + c), b = ld4(src + (size_t)__float_as_int(gi.y) * C + c);
     const float4 cc = ld4(src + (size_t)__float_as_int(gi.z) * C + c), dd = ld4(src + (size_t)__float_as_int(gi.w) * C + c);
     // ((wa a + wb b) + wc c) + wd d per component, two components per instruction
-    const f32x2 wa = {gw.x, gw.x}, wb = {gw.y, gw.y}, wc = {gw.z, gw.z}, wd = {gw.w, gw.w};
-    f32x2 lo = ((wa * (f32x2){a.x, a.y} + wb * (f32x2){b.x, b.y}) + wc * (f32x2){cc.x, cc.y}) + wd * (f32x2){dd.x, dd.y};
-    f32x2 hi = ((wa * (f32x2){a.z, a.w} + wb * (f32x2){b.z, b.w}) + wc * (f32x2){cc.z, cc.w}) + wd * (f32x2){dd.z, dd.w};
-    float4 o = make_float4(lo.x, lo.y, hi.x, hi.y);
+    // scalar arithmetic on purpose (the same IEEE operations in the same order as blend4): packed fp32 instructions gave wrong
+    // lane quarters beside another kernel's wavefronts on the SIMD
+    float4 o;
+    o.x = ((gw.x * a.x + gw.y * b.x) + gw.z * cc.x) + gw.w * dd.x;
+    o.y = ((gw.x * a.y + gw.y * b.y) + gw.z * cc.y) + gw.w * dd.y;
+    o.z = ((gw.x * a.z + gw.y * b.z) + gw.z * cc.z) + gw.w * dd.z;
+    o.w = ((gw.x * a.w + gw.y * b.w) + gw.z * cc.w) + gw.w * dd.w;
     if (MODE == 1) {
       const float valid = g[2].x;
       const float4 r = ld4(ref + (size_t)pix * C + c);
