@@ -532,8 +532,10 @@ def rank_main(args):
             t = torch.tensor([dtp], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dtp = float(t.item())
+        # every slot computed the captured inputs: all of them must hold the depth map the timed single-map path produced
+        same = all(bool(torch.equal(g.out, out)) for g in pipe.graphs)
         pipelined = {'value': round(n_groups * args.steps / dtp, 4), 'unit': 'depth-maps/sec', 'inflight': pipe.slots,
-                     'ms_per_step': round(1e3 * dtp / args.steps, 3),
+                     'ms_per_step': round(1e3 * dtp / args.steps, 3), 'equals_single_map_bitwise': same,
                      'note': '%d depth maps in flight (one captured graph + stream each, example.PipelinedInference): '
                              'throughput of independent depth maps of a scene, NOT the per-map rate `value` reports' % pipe.slots}
     if world > 1:
