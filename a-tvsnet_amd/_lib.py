@@ -15,19 +15,17 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('ATVS_LIB') or os.path.join(_HERE, 'libatvsnet_hip.so')   # ATVS_LIB: A/B a development build
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'atvsnet_hip.h')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
+# -fno-slp-vectorize: no COMPILER-FORMED packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Kernels whose
+# wavefronts shared a SIMD with wavefronts of a bf16-MFMA kernel (two depth maps in flight) produced wrong lane quarters with it
+# (tests/test_gpu_pipeline.py); building every file without the vectoriser costs nothing measurable (26.9 ms per
+# depth map either way).  Packed arithmetic written by hand (float2-typed code in the FMA kernels and epilogues) stays.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result']
-# Kernels whose wavefronts can share a SIMD with another kernel's (two depth maps in flight, side streams) are built WITHOUT
-# compiler-formed packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32): beside wavefronts of the bf16-MFMA
-# kernels such instructions produced wrong lane quarters (tests/test_gpu_pipeline.py).  The kernels that own
-# their SIMDs' whole register file keep the vectoriser.
-NO_PACKED_F32 = ('geometry', 'norm', 'pool', 'softargmin', 'aanet', 'fusion', 'api', 'conv', 'conv1x1', 'conv1x1_b',
-                 'conv2d_lds', 'conv2d_b', 'conv_tiled')
 
 
 def flags_for(src):
-    stem = os.path.splitext(os.path.basename(src))[0]
-    return FLAGS + (['-fno-slp-vectorize'] if stem in NO_PACKED_F32 else [])
+    return FLAGS
+
 
 _lib = None
 
