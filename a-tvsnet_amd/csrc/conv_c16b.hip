@@ -92,6 +92,9 @@ __device__ __forceinline__ void b16_split(const float4& v, bf16x4* p0, bf16x4* p
 
 template <int CIN, bool RELU>
 __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
+  // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
+  // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
+  asm volatile("" ::: "v255", "a255");
   using K = B16<CIN>;
   constexpr int TY = B16_TY, HY = B16_HY, MAXS = K::MAXS, JC = K::JC;
   constexpr int B16_IMG = K::IMG, B16_VB = K::VB, B16_ROWB = K::ROWB, B16_SLOTS = K::SLOTS;

@@ -106,6 +106,9 @@ __device__ __forceinline__ void ub_split(const float4& v, bf16x4* p0, bf16x4* p1
 // stay resident: the 64 -> 32 layer as two 16-channel launches)
 template <int COUT, bool STREAMW>
 __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
+  // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
+  // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
+  asm volatile("" ::: "v255", "a255");
   using U = UpB<COUT>;
   constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
