@@ -15,16 +15,19 @@ CSRC = os.path.join(_HERE, 'csrc')
 LIB_PATH = os.environ.get('ATVS_LIB') or os.path.join(_HERE, 'libatvsnet_hip.so')   # ATVS_LIB: A/B a development build
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'atvsnet_hip.h')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-# -fno-slp-vectorize: no COMPILER-FORMED packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32).  Kernels whose
-# wavefronts shared a SIMD with wavefronts of a bf16-MFMA kernel (two depth maps in flight) produced wrong lane quarters with it
-# (tests/test_gpu_pipeline.py); building every file without the vectoriser costs nothing measurable (26.9 ms per
-# depth map either way).  Packed arithmetic written by hand (float2-typed code in the FMA kernels and epilogues) stays.
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-fno-slp-vectorize', '-Wall',
+# -fno-slp-vectorize: no COMPILER-FORMED packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in kernels whose
+# wavefronts can share a SIMD with another kernel's: beside wavefronts of a bf16-MFMA kernel (two depth maps in flight) such
+# kernels produced wrong lane quarters, more often with packed arithmetic (tests/test_gpu_pipeline.py).  The
+# one-workgroup-per-CU bf16-MFMA kernels reserve their SIMDs' whole register file (nothing runs beside them) and keep the
+# vectoriser: their operand split is a fifth of a stage and runs 1.9 instead of 1.5 VALU instructions per MFMA without it.
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result']
+OWNS_ITS_SIMD = ('conv_xb', 'conv_c16b', 'conv3d_b', 'conv3d_s2b', 'deconv_up_b', 'aanet_fused')
 
 
 def flags_for(src):
-    return FLAGS
+    stem = os.path.splitext(os.path.basename(src))[0]
+    return FLAGS + ([] if stem in OWNS_ITS_SIMD else ['-fno-slp-vectorize'])
 
 
 _lib = None

@@ -168,8 +168,8 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
 // four gathers, the blend (the same IEEE operations in the same order as blend4, so the result is bit-identical), one
 // 16-byte store -- every pass writes 4 KB contiguous.
 // (Round 3: an unrolled form of this kernel, and homographies_kernel, produced wrong lane quarters beside wavefronts of a
-// bf16-MFMA kernel on the same SIMD -- two depth maps in flight.  Common factor: compiler-formed packed fp32 arithmetic.  The
-// library is built with -fno-slp-vectorize (_lib.FLAGS) and the blend below is scalar.  DESIGN.md 6;
+// bf16-MFMA kernel on the same SIMD -- two depth maps in flight.  Common factor: compiler-formed packed fp32 arithmetic.  This
+// file is built with -fno-slp-vectorize (_lib.flags_for) and the blend below is scalar.  DESIGN.md 6;
 // tests/test_gpu_pipeline.py::test_small_kernels_beside_other_wavefronts, ::test_two_depth_maps_in_flight_fullsize.)
 template <int MODE>
 __global__ __launch_bounds__(256) void warp_planes_shared_kernel(

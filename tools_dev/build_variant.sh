@@ -6,7 +6,7 @@ name=$1; stem=$2; shift 2
 root=$(cd $(dirname $0)/.. && pwd)
 src=$root/a-tvsnet_amd/csrc
 mkdir -p $root/tools_dev/_dbg
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-slp-vectorize -Wall -Wno-unused-function -Wno-unused-result "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result "$@" \
   -c $src/$stem.hip -o $root/tools_dev/_dbg/${stem}_$name.o || exit 1
 objs=$(ls $src/*.o | grep -v "/$stem.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/tools_dev/_dbg/lib_$name.so $objs $root/tools_dev/_dbg/${stem}_$name.o && echo built lib_$name.so
