@@ -14,6 +14,7 @@ namespace {
 
 constexpr int ST_TZ = 4, ST_TY = 8, ST_TX = 32;
 constexpr int ST_HZ = ST_TZ + 2, ST_HY = ST_TY + 2, ST_HX = ST_TX + 2;
+constexpr int RS_STG = 64 * 9;      // refine_stems: float4s of one wavefront's staging rows (64 voxels, 9 float4 pitch)
 
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict__ x, const float* __restrict__ w,
@@ -135,12 +136,9 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
                                                            const float* __restrict__ hull, const float* __restrict__ w,
                                                            float* __restrict__ y, double* __restrict__ stats, int D, int H,
                                                            int W, int tiles_y, int tiles_x, int tiles) {
-  __shared__ float4 tile[ST_HZ * ST_HY * ST_HX];          // (geo0, geo1, prob, hull) per halo voxel
+  // (geo0, geo1, prob, hull) per halo voxel; after the taps, each wavefront's staging rows for the stores
+  __shared__ float4 tile[ST_HZ * ST_HY * ST_HX > 4 * RS_STG ? ST_HZ * ST_HY * ST_HX : 4 * RS_STG];
   __shared__ double s_red[4][2][24];
-#ifdef ST_EXP_LDSW
-  __shared__ __attribute__((aligned(16))) float s_w[27 * 32];
-  for (int i = threadIdx.x; i < 27 * 32; i += 256) s_w[i] = w[i];
-#endif
   const int tid = threadIdx.x;
   const int grp = blockIdx.x / tiles, t = blockIdx.x - grp * tiles;
   const int x0 = (t % tiles_x) * ST_TX, y0 = ((t / tiles_x) % tiles_y) * ST_TY, z0 = (t / (tiles_x * tiles_y)) * ST_TZ;
@@ -177,11 +175,7 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
   for (int kd = 0; kd < 3; ++kd)
 #pragma unroll 1
     for (int j = 0; j < 9; ++j) {
-#ifdef ST_EXP_LDSW
-      const float* wk = s_w + (kd * 9 + j) * 32;                // broadcast LDS reads: in order with the fragment reads
-#else
       const float* wk = w + (kd * 9 + j) * 32;                  // uniform address: scalar loads
-#endif
       f32x2 wr[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) wr[k] = (f32x2){wk[2 * k], wk[2 * k + 1]};
@@ -213,31 +207,53 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
   float* yg = y + (size_t)grp * vol * 32;
   const float* phg = photo + (size_t)grp * vol * 8;
   const float* pbg = geo_pb ? geo_pb + (size_t)grp * H * W * 24 : nullptr;
+  // Stores go through LDS: a thread owns one voxel's 128-byte row, and written by its owner each store instruction would
+  // touch 64 rows with 16 bytes each (eight partial writes per line at the L2).  Each wavefront stages its 64 rows (two
+  // lines of 32 voxels; 144-byte pitch: conflict-free both ways) and writes them back as whole kilobytes per instruction.
+  __syncthreads();                                         // every wavefront is done with the halo tile
+  const int lane = tid & 63, wave = tid >> 6;
+  float4* stg = tile + wave * RS_STG;
 #pragma unroll
   for (int z = 0; z < ST_TZ; ++z) {
     const int zo = z0 + z;
-    if (!col_ok || zo >= D) continue;
+    if (zo >= D) continue;                                 // uniform over the workgroup
     float* a24 = acc[z];
     const size_t vox = ((size_t)zo * H + yo) * W + xo;
-    if (pbg) {
-      const float* pb = pbg + ((size_t)yo * W + xo) * 24 + plane_variant(zo - 1, D) * 8;
-      const float4 b0 = ld4(pb), b1 = ld4(pb + 4);
-      a24[0] += b0.x; a24[1] += b0.y; a24[2] += b0.z; a24[3] += b0.w;
-      a24[4] += b1.x; a24[5] += b1.y; a24[6] += b1.z; a24[7] += b1.w;
-    }
-    float* dst = yg + vox * 32;
-    st4(dst, ld4(phg + vox * 8));
-    st4(dst + 4, ld4(phg + vox * 8 + 4));
+    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
+    if (col_ok) {
+      if (pbg) {
+        const float* pb = pbg + ((size_t)yo * W + xo) * 24 + plane_variant(zo - 1, D) * 8;
+        const float4 b0 = ld4(pb), b1 = ld4(pb + 4);
+        a24[0] += b0.x; a24[1] += b0.y; a24[2] += b0.z; a24[3] += b0.w;
+        a24[4] += b1.x; a24[5] += b1.y; a24[6] += b1.z; a24[7] += b1.w;
+      }
+      p0 = ld4(phg + vox * 8);
+      p1 = ld4(phg + vox * 8 + 4);
 #pragma unroll
-    for (int k = 0; k < 24; k += 4) st4(dst + 8 + k, make_float4(a24[k], a24[k + 1], a24[k + 2], a24[k + 3]));
-#pragma unroll
-    for (int k = 0; k < 24; ++k) {
-      ssum[k] += a24[k];
-      ssq[k] += a24[k] * a24[k];
+      for (int k = 0; k < 24; ++k) {
+        ssum[k] += a24[k];
+        ssq[k] += a24[k] * a24[k];
+      }
     }
+    stg[lane * 9] = p0;
+    stg[lane * 9 + 1] = p1;
+#pragma unroll
+    for (int k = 0; k < 24; k += 4) stg[lane * 9 + 2 + k / 4] = make_float4(a24[k], a24[k + 1], a24[k + 2], a24[k + 3]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {                          // instruction i: line i / 4, voxels 8 (i % 4) .. + 7, 16 bytes per lane
+      const int r = i >> 2, xi = (i & 3) * 8 + (lane >> 3), c = lane & 7;
+      const float4 v = stg[(r * 32 + xi) * 9 + c];
+      const int yy = y0 + 2 * wave + r, xx = x0 + xi;
+      if (yy < H && xx < W) st4(yg + (((size_t)zo * H + yy) * W + xx) * 32 + c * 4, v);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (stats) {
-    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int k = 0; k < 24; ++k) {
       double a = (double)ssum[k], b = (double)ssq[k];
