@@ -14,6 +14,13 @@ namespace {
 
 constexpr int ST_TZ = 4, ST_TY = 8, ST_TX = 32;
 constexpr int ST_HZ = ST_TZ + 2, ST_HY = ST_TY + 2, ST_HX = ST_TX + 2;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ float rs_zeros[8];       // what a load outside the volume reads
+constexpr int RS_PF = (ST_HZ * ST_HY * ST_HX + 255) / 256;     // halo voxels per thread
+#ifndef RS_WAVES
+#define RS_WAVES 2
+#endif
+constexpr int RS_GRID = RS_WAVES * 256;   // persistent: RS_WAVES workgroups per CU (registers)
 constexpr int RS_STG = 64 * 9;      // refine_stems: float4s of one wavefront's staging rows (64 voxels, 9 float4 pitch)
 
 template <int CIN>
@@ -123,6 +130,19 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
   }
 }
 
+// one halving step of the statistics butterfly: HALF values kept of 2 * HALF
+template <int HALF>
+__device__ __forceinline__ void rs_halve(double* v, int o, int lane, int& c0) {
+  const bool up = lane & o;
+#pragma unroll
+  for (int i = 0; i < HALF; ++i) {
+    const double send = up ? v[i] : v[i + HALF];
+    const double keep = up ? v[i + HALF] : v[i];
+    v[i] = keep + __shfl_xor(send, o);
+  }
+  c0 += up ? HALF : 0;
+}
+
 // ---- the four stems of the refinement network as ONE pass over the 32-channel concat buffer -------------------------
 // CostVolRefineNet (cnn_wrapper/atvsnet.py:300-313) concatenates photo | geo | prob | vishull stems (8 channels each)
 // into the 32-channel input of its U-Net.  Written stem by stem, every launch touches 32 of the 128 bytes of each row
@@ -130,33 +150,57 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(const float* __restrict_
 // FMA stems (geo: 2 channels + depth-plane bias, prob: 1, vishull: 1) are computed together and stored, with the RAW
 // output of the photo stem (MFMA, dense 8-channel tensor) passed through, as whole 128-byte rows.
 //   w: [27 taps][4 input channels: geo0, geo1, prob, hull][8] floats (device);
-//   stats rows: [2][24] doubles (geo 0..7 | prob 8..15 | hull 16..23), one row per workgroup.
-__global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restrict__ photo, const float* __restrict__ geo,
+//   stats rows: [2][24] doubles (geo 0..7 | prob 8..15 | hull 16..23), one row per TILE (the workgroups are persistent).
+// Where its time goes (4 volumes of 192 x 128 x 160, by leaving phases out): taps 0.31 ms (packed FMAs at the rate the
+// SIMDs issue them), loads 0.28, stores 0.30, statistics 0.19 -> 0.06 with the halving butterfly; the phases add up
+// (two wavefronts per SIMD: 217 registers) whatever the start of the second workgroup of a CU is delayed by.
+__global__ __launch_bounds__(256, RS_WAVES) void refine_stems_kernel(const float* __restrict__ photo, const float* __restrict__ geo,
                                                            const float* __restrict__ geo_pb, const float* __restrict__ prob,
                                                            const float* __restrict__ hull, const float* __restrict__ w,
                                                            float* __restrict__ y, double* __restrict__ stats, int D, int H,
-                                                           int W, int tiles_y, int tiles_x, int tiles) {
+                                                           int W, int tiles_y, int tiles_x, int tiles, int groups) {
   // (geo0, geo1, prob, hull) per halo voxel; after the taps, each wavefront's staging rows for the stores
   __shared__ float4 tile[ST_HZ * ST_HY * ST_HX > 4 * RS_STG ? ST_HZ * ST_HY * ST_HX : 4 * RS_STG];
   __shared__ double s_red[4][2][24];
   const int tid = threadIdx.x;
-  const int grp = blockIdx.x / tiles, t = blockIdx.x - grp * tiles;
-  const int x0 = (t % tiles_x) * ST_TX, y0 = ((t / tiles_x) % tiles_y) * ST_TY, z0 = (t / (tiles_x * tiles_y)) * ST_TZ;
   const size_t vol = (size_t)D * H * W;
-  const float* gg = geo + (size_t)grp * vol * 2;
-  const float* pg = prob + (size_t)grp * vol;
-  const float* hg = hull + (size_t)grp * vol;
-  for (int s = tid; s < ST_HZ * ST_HY * ST_HX; s += 256) {
-    const int xx = s % ST_HX, yy = (s / ST_HX) % ST_HY, zz = s / (ST_HX * ST_HY);
-    const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
-    float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-    if ((unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) {
+  // PERSISTENT: workgroup b takes tiles b, b + gridDim.x, ...; the next tile's halo is requested (into registers) after the
+  // taps and lands in LDS after the stores and the statistics, so that its latency hides behind them and the resident
+  // workgroups of a CU drift apart (loads of one beside the FMAs of another) instead of marching phase by phase.
+  float4 pf[RS_PF];
+  auto request = [&](int id) {
+    const int grp = id / tiles, t = id - grp * tiles;
+    const int x0 = (t % tiles_x) * ST_TX, y0 = ((t / tiles_x) % tiles_y) * ST_TY, z0 = (t / (tiles_x * tiles_y)) * ST_TZ;
+    const float* gg = geo + (size_t)grp * vol * 2;
+    const float* pg = prob + (size_t)grp * vol;
+    const float* hg = hull + (size_t)grp * vol;
+#pragma unroll
+    for (int i = 0; i < RS_PF; ++i) {
+      const int s = tid + i * 256;
+      const int xx = s % ST_HX, yy = (s / ST_HX) % ST_HY, zz = s / (ST_HX * ST_HY);
+      const int gz = z0 + zz - 1, gy = y0 + yy - 1, gx = x0 + xx - 1;
+      // no branch around a load or a store anywhere in the tile loop (a join makes every later wait a wait for all):
+      // slots outside the volume read zeros from rs_zeros
+      const bool ok = s < ST_HZ * ST_HY * ST_HX && (unsigned)gz < (unsigned)D && (unsigned)gy < (unsigned)H &&
+                      (unsigned)gx < (unsigned)W;
       const size_t v = ((size_t)gz * H + gy) * W + gx;
-      const float2 g2 = *reinterpret_cast<const float2*>(gg + v * 2);
-      val = make_float4(g2.x, g2.y, pg[v], hg[v]);
+      const float2 g2 = *reinterpret_cast<const float2*>(ok ? gg + v * 2 : rs_zeros);
+      const float4 val = make_float4(g2.x, g2.y, *(ok ? pg + v : rs_zeros), *(ok ? hg + v : rs_zeros));
+      pf[i] = val;
     }
-    tile[s] = val;
-  }
+  };
+  auto land = [&]() {
+#pragma unroll
+    for (int i = 0; i < RS_PF; ++i)
+      if (tid + i * 256 < ST_HZ * ST_HY * ST_HX) tile[tid + i * 256] = pf[i];
+  };
+  const int total = tiles * groups;
+  request(blockIdx.x);                                     // gridDim.x <= total
+  for (int id = blockIdx.x; id < total; id += gridDim.x) {
+  const int grp = id / tiles, t = id - grp * tiles;
+  const int x0 = (t % tiles_x) * ST_TX, y0 = ((t / tiles_x) % tiles_y) * ST_TY, z0 = (t / (tiles_x * tiles_y)) * ST_TZ;
+  __syncthreads();                                         // the previous tile's staging rows and s_red are done with
+  land();
   __syncthreads();
   const int lx = tid & 31, ly = tid >> 5;
   const int xo = x0 + lx, yo = y0 + ly;
@@ -205,34 +249,50 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
 #pragma unroll
   for (int k = 0; k < 24; ++k) ssum[k] = ssq[k] = 0.f;
   float* yg = y + (size_t)grp * vol * 32;
+  // the tile's ST_TZ planes of y as a buffer (H * W * 512 bytes < 4 GB, checked by the caller)
+  const unsigned ybytes = (unsigned)((size_t)H * W * 128 * ST_TZ);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg + (size_t)z0 * H * W * 32, 0, ybytes, 0x00020000);
   const float* phg = photo + (size_t)grp * vol * 8;
   const float* pbg = geo_pb ? geo_pb + (size_t)grp * H * W * 24 : nullptr;
   // Stores go through LDS: a thread owns one voxel's 128-byte row, and written by its owner each store instruction would
   // touch 64 rows with 16 bytes each (eight partial writes per line at the L2).  Each wavefront stages its 64 rows (two
   // lines of 32 voxels; 144-byte pitch: conflict-free both ways) and writes them back as whole kilobytes per instruction.
   __syncthreads();                                         // every wavefront is done with the halo tile
+  // The loads of plane z + 1 (depth-plane bias, photo row) are issued BEFORE the stores of plane z, and the next tile's halo
+  // before all of them: memory operations retire in order, so that no wait of the plane loop covers a store.
+  float4 ph[2][2], bb[2][2];
+  auto fetch = [&](int z, float4* p, float4* q) {
+    const int zo = z0 + z;
+    const bool ok = col_ok && zo < D;
+    const float* pb = ok && pbg ? pbg + ((size_t)yo * W + xo) * 24 + plane_variant(zo - 1, D) * 8 : rs_zeros;
+    const float* pp = ok ? phg + (((size_t)zo * H + yo) * W + xo) * 8 : rs_zeros;
+    q[0] = ld4(pb);
+    q[1] = ld4(pb + 4);
+    p[0] = ld4(pp);
+    p[1] = ld4(pp + 4);
+  };
+  request(id + (int)gridDim.x < total ? id + gridDim.x : id);      // the last tile asks for itself again (never landed)
+  fetch(0, ph[0], bb[0]);
   const int lane = tid & 63, wave = tid >> 6;
   float4* stg = tile + wave * RS_STG;
 #pragma unroll
   for (int z = 0; z < ST_TZ; ++z) {
     const int zo = z0 + z;
-    if (zo >= D) continue;                                 // uniform over the workgroup
+    if (z + 1 < ST_TZ) fetch(z + 1, ph[(z + 1) & 1], bb[(z + 1) & 1]);
     float* a24 = acc[z];
-    const size_t vox = ((size_t)zo * H + yo) * W + xo;
-    float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0;
-    if (col_ok) {
-      if (pbg) {
-        const float* pb = pbg + ((size_t)yo * W + xo) * 24 + plane_variant(zo - 1, D) * 8;
-        const float4 b0 = ld4(pb), b1 = ld4(pb + 4);
+    const float4 p0 = ph[z & 1][0], p1 = ph[z & 1][1];
+    {
+      const float4 b0 = bb[z & 1][0], b1 = bb[z & 1][1];   // zeros without a depth-plane bias: x + 0.f == x for the statistics
+      if (pbg) {                                           // and the stores alike (a -0.f would become +0.f: pbg decides)
         a24[0] += b0.x; a24[1] += b0.y; a24[2] += b0.z; a24[3] += b0.w;
         a24[4] += b1.x; a24[5] += b1.y; a24[6] += b1.z; a24[7] += b1.w;
       }
-      p0 = ld4(phg + vox * 8);
-      p1 = ld4(phg + vox * 8 + 4);
+      const bool ok = col_ok && zo < D;
 #pragma unroll
       for (int k = 0; k < 24; ++k) {
-        ssum[k] += a24[k];
-        ssq[k] += a24[k] * a24[k];
+        const float a = ok ? a24[k] : 0.f;                 // x + 0.f leaves the sums as they were
+        ssum[k] += a;
+        ssq[k] += a * a;
       }
     }
     stg[lane * 9] = p0;
@@ -247,32 +307,48 @@ __global__ __launch_bounds__(256) void refine_stems_kernel(const float* __restri
       const int r = i >> 2, xi = (i & 3) * 8 + (lane >> 3), c = lane & 7;
       const float4 v = stg[(r * 32 + xi) * 9 + c];
       const int yy = y0 + 2 * wave + r, xx = x0 + xi;
-      if (yy < H && xx < W) st4(yg + (((size_t)zo * H + yy) * W + xx) * 32 + c * 4, v);
+      const bool ok = yy < H && xx < W && zo < D;
+      const u32x4 bits = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                          __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+      // a buffer store: lanes outside the volume get an offset past the descriptor's range and are dropped
+      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, ok ? (unsigned)(((z * H + yy) * W + xx) * 32 + c * 4) * 4u : ybytes, 0, 0);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (stats) {
+    // The wavefront's 48 sums as a butterfly that HALVES what a lane carries at each of its first four steps (lane bit
+    // set: keep the upper half and send the lower, else the reverse), then two plain steps on the three values left:
+    // the same additions in the same order as 48 full butterflies (a + b == b + a), with 51 exchanges instead of 288.
+    double v[48];
 #pragma unroll
     for (int k = 0; k < 24; ++k) {
-      double a = (double)ssum[k], b = (double)ssq[k];
+      v[k] = (double)ssum[k];
+      v[24 + k] = (double)ssq[k];
+    }
+    int c0 = 0;                                            // first of the channels this lane ends up holding
+    rs_halve<24>(v, 1, lane, c0);
+    rs_halve<12>(v, 2, lane, c0);
+    rs_halve<6>(v, 4, lane, c0);
+    rs_halve<3>(v, 8, lane, c0);
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        a += __shfl_xor(a, o);
-        b += __shfl_xor(b, o);
-      }
-      if (lane == 0) {
-        s_red[wave][0][k] = a;
-        s_red[wave][1][k] = b;
-      }
+    for (int i = 0; i < 3; ++i) {
+      v[i] += __shfl_xor(v[i], 16);
+      v[i] += __shfl_xor(v[i], 32);
+    }
+    if (lane < 16) {
+      double* row = &s_red[wave][0][0];                    // [2][24] = 48 in the order of v
+#pragma unroll
+      for (int i = 0; i < 3; ++i) row[c0 + i] = v[i];
     }
     __syncthreads();
     if (tid < 48) {
       const int which = tid / 24, col = tid % 24;
-      stats[((size_t)blockIdx.x * 2 + which) * 24 + col] =
+      stats[((size_t)id * 2 + which) * 24 + col] =
           (s_red[0][which][col] + s_red[1][which][col]) + (s_red[2][which][col] + s_red[3][which][col]);
     }
+  }
   }
 }
 
@@ -318,11 +394,13 @@ extern "C" int atvs_refine_stems_f32(const float* photo_raw, const float* geo, c
   if (!photo_raw || !geo || !prob || !hull || !w || !y) return ATVS_ERR_NULL;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
   if (geo_plane_bias && D < 2) return ATVS_ERR_ARG;
+  if ((double)H * W * 128.0 * ST_TZ >= 4294967296.0) return ATVS_ERR_SHAPE;       // a tile's planes are one buffer descriptor
   const int ty = (H + ST_TY - 1) / ST_TY, tx = (W + ST_TX - 1) / ST_TX;
   const long tiles = atvs_conv_stem_rows(D, H, W);
   if (tiles * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  hipLaunchKernelGGL(refine_stems_kernel, dim3((unsigned)(tiles * groups)), dim3(256), 0, as_stream(stream), photo_raw, geo,
-                     geo_plane_bias, prob, hull, w, y, stats_partial, D, H, W, ty, tx, (int)tiles);
+  const long total = tiles * groups;
+  hipLaunchKernelGGL(refine_stems_kernel, dim3((unsigned)(total < RS_GRID ? total : RS_GRID)), dim3(256), 0, as_stream(stream),
+                     photo_raw, geo, geo_plane_bias, prob, hull, w, y, stats_partial, D, H, W, ty, tx, (int)tiles, groups);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -7,6 +7,7 @@ import torch
 import atvsnet_amd
 from atvsnet_amd import ops, _lib
 dev = torch.device('cuda:0')
+torch.manual_seed(0)
 G, D, H, W = 4, 192, 128, 160
 photo = torch.randn(G, D, H, W, 8, device=dev)
 geo = torch.randn(G, D, H, W, 2, device=dev)
@@ -29,3 +30,5 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 print('refine_stems %.3f ms  checksum %.6e' % (e0.elapsed_time(e1) / 10, float(y.double().sum())))
+if len(sys.argv) > 1:          # dump for a bitwise A/B of two builds: python tools_dev/bench_stems.py out.pt
+    torch.save({'y': y[:, ::16].cpu(), 'st': st.cpu(), 'ysum': y.double().sum(dim=(1, 2, 3)).cpu()}, sys.argv[1])
