@@ -142,6 +142,39 @@ def test_stem_kernel_matches_oracle(cuda, cin, shape, G):
     assert float((y2.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize('shape,G,bias', [((9, 13, 35), 3, True), ((21, 50, 70), 5, True), ((4, 8, 32), 1, False),
+                                          ((6, 20, 33), 2, False)])
+def test_refine_stems_matches_oracle(cuda, shape, G, bias):
+    """refine_stems_kernel (conv_stem.hip): the geo | prob | vishull stems of CostVolRefineNet (reference
+    cnn_wrapper/atvsnet.py:300-313) written with the raw photo stem as whole rows of the 32-channel concat.  Ragged
+    sizes (depth not a multiple of the 4-plane tile, rows / columns cut by the 8 x 32 tile), more tiles than
+    persistent workgroups ((21, 50, 70) x 5 = 630 tiles against 512), with and without the depth-plane bias; values
+    and the per-sample moments of the 24 computed channels."""
+    from atvsnet_amd import ops
+    from oracle import tf_ops as T
+    D, H, W = shape
+    photo = _rand((G, D, H, W, 8), 41)
+    geo, prob, hull = _rand((G, D, H, W, 2), 42), _rand((G, D, H, W, 1), 43), _rand((G, D, H, W, 1), 44)
+    pb = _rand((G, H, W, 24), 45) if bias else None
+    wg, wp, wh = _rand((3, 3, 3, 2, 8), 46) * 0.3, _rand((3, 3, 3, 1, 8), 47) * 0.3, _rand((3, 3, 3, 1, 8), 48) * 0.3
+    buf, st = ops.refine_stems(photo.to(cuda), geo.to(cuda), pb.to(cuda) if bias else None, prob.to(cuda), hull.to(cuda),
+                               ('stems-test', shape, G, bias), wg.numpy(), wp.numpy(), wh.numpy())
+    g = T.conv(geo, wg, 1, 'SAME')
+    if bias:
+        for z in range(D):
+            v = 0 if z == 0 else (2 if z == D - 1 else 1)
+            g[:, z] += pb[..., v * 8:v * 8 + 8]
+    want = torch.cat([photo, g, T.conv(prob, wp, 1, 'SAME'), T.conv(hull, wh, 1, 'SAME')], dim=-1)
+    got = buf.cpu()
+    assert torch.equal(got[..., :8], photo)
+    assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    p = ops.bn_params(st, 24, buf).cpu().reshape(G, 3, 24)
+    for k in range(G):
+        flat = want[k, ..., 8:].reshape(-1, 24).double()
+        assert float((p[k, 0] - flat.mean(0)).abs().max()) <= 1e-5
+        assert float((p[k, 1] - 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
+
+
 def _pending(x, w, key, G, relu=True):
     """A raw convolution output with its pending training-mode batch norm (what conv_bn(defer_bn=True) hands on)."""
     from atvsnet_amd import ops
