@@ -143,7 +143,7 @@ def test_stem_kernel_matches_oracle(cuda, cin, shape, G):
 
 
 @pytest.mark.parametrize('shape,G,bias', [((9, 13, 35), 3, True), ((21, 50, 70), 5, True), ((4, 8, 32), 1, False),
-                                          ((6, 20, 33), 2, False)])
+                                          ((6, 20, 33), 2, False), ((2, 3, 5), 2, True), ((1, 9, 40), 1, False)])
 def test_refine_stems_matches_oracle(cuda, shape, G, bias):
     """refine_stems_kernel (conv_stem.hip): the geo | prob | vishull stems of CostVolRefineNet (reference
     cnn_wrapper/atvsnet.py:300-313) written with the raw photo stem as whole rows of the 32-channel concat.  Ragged
