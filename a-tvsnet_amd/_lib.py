@@ -6,6 +6,7 @@ to load, every op raises.
 """
 import ctypes
 import glob
+import hashlib
 import os
 import re
 import subprocess
@@ -30,6 +31,20 @@ def flags_for(src):
     return FLAGS + ([] if stem in OWNS_ITS_SIMD else ['-fno-slp-vectorize'])
 
 
+def _flags_stamp(src):
+    """What an object file was built WITH: a flags-only change (e.g. a new mitigation flag) must rebuild it although no
+    source is newer.  Kept next to the object as <stem>.flags."""
+    return hashlib.sha1(' '.join([HIPCC] + flags_for(src)).encode()).hexdigest()
+
+
+def _stamp_ok(src):
+    try:
+        with open(src[:-4] + '.flags') as f:
+            return f.read().strip() == _flags_stamp(src)
+    except OSError:
+        return False
+
+
 _lib = None
 
 
@@ -42,7 +57,7 @@ def _stale():
         return True
     t = os.path.getmtime(LIB_PATH)
     deps = sources() + glob.glob(os.path.join(CSRC, '*.h')) + [HEADER]
-    return any(os.path.getmtime(p) > t for p in deps)
+    return any(os.path.getmtime(p) > t for p in deps) or not all(_stamp_ok(s) for s in sources())
 
 
 def build(force=False, verbose=False):
@@ -54,18 +69,20 @@ def build(force=False, verbose=False):
     for src in sources():
         obj = src[:-4] + '.o'
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(
+        if not force and os.path.exists(obj) and _stamp_ok(src) and os.path.getmtime(obj) > max(
                 [os.path.getmtime(src), os.path.getmtime(HEADER)] +
                 [os.path.getmtime(h) for h in glob.glob(os.path.join(CSRC, '*.h'))]):
             continue
         cmd = [HIPCC] + flags_for(src) + ['-c', src, '-o', obj]
         if verbose:
             print(' '.join(cmd))
-        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
-    for cmd, p in procs:
+        procs.append((src, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, cmd, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError('hipcc failed: %s\n%s' % (' '.join(cmd), out.decode('utf-8', 'replace')))
+        with open(src[:-4] + '.flags', 'w') as f:
+            f.write(_flags_stamp(src) + '\n')
         if verbose and out:
             print(out.decode('utf-8', 'replace'))
     cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB_PATH] + objs

@@ -30,3 +30,15 @@ def test_plain_c_caller_loads_the_library(tmp_path):
     r = subprocess.run([exe, _lib.LIB_PATH], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode == 0, r.stdout.decode()
     assert ('abi %d ok' % _lib.header_abi_version()) in r.stdout.decode()
+
+
+def test_flags_only_change_marks_the_library_stale(monkeypatch):
+    """An object file carries a stamp of the hipcc flags it was built with (<stem>.flags): a flags-only change -- e.g. a
+    new mitigation flag in _lib.flags_for -- must rebuild it although no source is newer (round-3 advisor finding)."""
+    from atvsnet_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('library not built')
+    src = _lib.sources()[0]
+    assert _lib._stamp_ok(src) and not _lib._stale()
+    monkeypatch.setattr(_lib, 'FLAGS', _lib.FLAGS + ['-DSOMETHING_NEW'])
+    assert not _lib._stamp_ok(src) and _lib._stale()

@@ -6,7 +6,9 @@ name=$1; stem=$2; shift 2
 root=$(cd $(dirname $0)/.. && pwd)
 src=$root/a-tvsnet_amd/csrc
 mkdir -p $root/tools_dev/_dbg
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function -Wno-unused-result "$@" \
+# the product's own per-file flags (incl. -fno-slp-vectorize where _lib.flags_for sets it), then the extra ones
+flags=$(cd $root && python3 -c "import atvsnet_amd; from atvsnet_amd import _lib; print(' '.join(_lib.flags_for('$stem.hip')))") || exit 1
+/opt/rocm/bin/hipcc $flags "$@" \
   -c $src/$stem.hip -o $root/tools_dev/_dbg/${stem}_$name.o || exit 1
 objs=$(ls $src/*.o | grep -v "/$stem.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $root/tools_dev/_dbg/lib_$name.so $objs $root/tools_dev/_dbg/${stem}_$name.o && echo built lib_$name.so
