@@ -5,6 +5,9 @@ B = 1) as /root/reference/atvsnet/homography_warping.py; each function is one or
 launches through ``ops`` (include/atvsnet_hip.h).  ``FLAGS.inverse_depth`` is read
 where the reference reads it (:149,215,301,321,369,378).
 
+``get_pixel_grids`` and ``interpolate`` (reference :8-17, :31-104) are exported as functions too, although the warps
+have them folded into their kernels: a caller that brings its own sampling coordinates binds to ``interpolate``.
+
 Beyond the reference API, ``homography_warping`` accepts a whole (B,D,3,3) stack of
 homographies and returns the (B,D,H,W,C) stack of warps in one launch -- the form
 model.py's D-unrolled loops need.
@@ -24,6 +27,28 @@ def _cam(c):
 
 def _scalar(t):
     return t.reshape(-1)[:1].contiguous()
+
+
+def get_pixel_grids(height, width, device=None):
+    """Pixel-centre texture coordinates (reference :8-17): the flat (3*H*W,) tensor [x + 0.5 | y + 0.5 | 1].
+    `device` (not in the reference, whose graph has one device): defaults to the current HIP device."""
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    return ops.pixel_grids(torch.empty(0, device=dev), int(height), int(width))
+
+
+def interpolate(image, x, y, output_mask=False, method='bilinear'):
+    """Sample image (B,H,W,C) at flat texture coordinates x, y (B*H*W,) -> (B*H*W, C) [, bool mask (B*H*W,)]
+    (reference :31-104).  bilinear: points outside [0, W-1) x [0, H-1) (after the -0.5 shift) or NaN give 0; nearest:
+    tf.round, such points read pixel (0,0) un-masked (quirk C4).  B = 1 like every caller on the path."""
+    if method not in ('bilinear', 'nearest'):
+        raise ValueError('interpolate: unknown method %r' % (method,))
+    if image.shape[0] != 1:
+        raise ValueError('batch size must be 1 (FLAGS.batch_size)')
+    res = ops.interpolate(image[0].contiguous(), x.reshape(-1).contiguous(), y.reshape(-1).contiguous(),
+                          method=method, want_mask=output_mask)
+    if output_mask:
+        return res[0], res[1] > 0
+    return res
 
 
 def get_homographies(left_cam, right_cam, depth_num, depth_start, depth_interval):

@@ -504,6 +504,73 @@ extern "C" int atvs_warp_by_depth(const float* src, const float* left_cam, const
 }
 
 // ---------------------------------------------------------------------------
+// interpolate (homography_warping.py:31-104) with CALLER-supplied sampling coordinates: the function the warps above
+// have folded into them, exported for callers that bring their own x / y (B = 1: n = h*w points in the reference,
+// any n here).  get_pixel_grids (homography_warping.py:8-17): [x + 0.5 | y + 0.5 | 1], each h*w long, concatenated;
+// tf.linspace = start + i * step with step = (stop - start) / (num - 1) in fp32.
+// ---------------------------------------------------------------------------
+template <int NEAREST>
+__global__ __launch_bounds__(256) void interpolate_kernel(const float* __restrict__ src, const float* __restrict__ xs,
+                                                          const float* __restrict__ ys, float* __restrict__ out,
+                                                          float* __restrict__ mask_out, long n, int h, int w, int C) {
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= n * C) return;
+  long pt = gid / C;
+  int c = (int)(gid % C);
+  float xw = xs[pt], yw = ys[pt];
+  float o, valid;
+  if (NEAREST) {
+    int idx = nearest_tap(xw, yw, h, w, &valid);
+    if (xw != xw || yw != yw) { idx = 0; valid = 0.f; }   // comparisons with NaN are false already; kept explicit (:42-43)
+    o = src[(size_t)idx * C + c];
+  } else {
+    Tap4 t = bilinear_taps(xw, yw, h, w);
+    valid = t.valid;
+    o = ((t.wa * src[(size_t)t.i00 * C + c] + t.wb * src[(size_t)t.i01 * C + c]) + t.wc * src[(size_t)t.i10 * C + c]) +
+        t.wd * src[(size_t)t.i11 * C + c];
+  }
+  out[gid] = o;
+  if (mask_out && c == 0) mask_out[pt] = valid;
+}
+
+extern "C" int atvs_interpolate(const float* src, const float* x, const float* y, float* out, float* mask_out, long n,
+                                int h, int w, int C, int method, atvs_stream_t stream) {
+  if (!src || !x || !y || !out) return ATVS_ERR_NULL;
+  if (h <= 0 || w <= 0 || C <= 0 || n < 0) return ATVS_ERR_SHAPE;
+  if (method != 0 && method != 1) return ATVS_ERR_ARG;
+  if (n == 0) return ATVS_OK;
+  hipStream_t s = as_stream(stream);
+  long tot = n * C;
+  if (method == 0)
+    hipLaunchKernelGGL((interpolate_kernel<0>), dim3(cdiv(tot, 256)), dim3(256), 0, s, src, x, y, out, mask_out, n, h, w, C);
+  else
+    hipLaunchKernelGGL((interpolate_kernel<1>), dim3(cdiv(tot, 256)), dim3(256), 0, s, src, x, y, out, mask_out, n, h, w, C);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+__global__ __launch_bounds__(256) void pixel_grids_kernel(float* __restrict__ out, int h, int w) {
+  long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  long npix = (long)h * w;
+  if (gid >= npix) return;
+  int y = (int)(gid / w), x = (int)(gid % w);
+  // tf.linspace(0.5, n - 0.5, n): step = ((n - 0.5) - 0.5) / (n - 1)
+  float sx = (w > 1) ? (((float)w - 0.5f) - 0.5f) / (float)(w - 1) : 0.f;
+  float sy = (h > 1) ? (((float)h - 0.5f) - 0.5f) / (float)(h - 1) : 0.f;
+  out[gid] = 0.5f + sx * (float)x;
+  out[npix + gid] = 0.5f + sy * (float)y;
+  out[2 * npix + gid] = 1.f;
+}
+
+extern "C" int atvs_pixel_grids(float* out, int h, int w, atvs_stream_t stream) {
+  if (!out) return ATVS_ERR_NULL;
+  if (h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
+  hipLaunchKernelGGL(pixel_grids_kernel, dim3(cdiv((long)h * w, 256)), dim3(256), 0, as_stream(stream), out, h, w);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// ---------------------------------------------------------------------------
 // transform_depth (homography_warping.py:275-326): two global maxima (quirk C15)
 // -> three tiny passes.  ws: 2 floats (max of input, max of transformed z).
 // ---------------------------------------------------------------------------

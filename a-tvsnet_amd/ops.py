@@ -176,6 +176,30 @@ def warp_by_depth(src, left_cam, right_cam, depth, method='bilinear', inverse_de
     return out, mask
 
 
+def interpolate(src, x, y, method='bilinear', want_mask=False):
+    """src (h,w,C), x / y (n,) texture coordinates -> (n,C) [, mask (n,) of 1.f / 0.f] (atvs_interpolate)."""
+    h, w, C = src.shape
+    n = x.numel()
+    if y.numel() != n:
+        raise ValueError('interpolate: x and y must have the same number of points')
+    if method not in ('bilinear', 'nearest'):
+        raise ValueError('interpolate: unknown method %r' % (method,))
+    out = _new(src, (n, C))
+    mask = _new(src, (n,)) if want_mask else None
+    if _dev_ok(src, x, y):
+        _call('atvs_interpolate', _p(src), _p(x), _p(y), _p(out), _p(mask), ctypes.c_long(n), h, w, C,
+              1 if method == 'nearest' else 0, _stream())
+    return (out, mask) if want_mask else out
+
+
+def pixel_grids(ref, height, width):
+    """-> (3*height*width,) = [x + 0.5 | y + 0.5 | 1] on ref's device (atvs_pixel_grids)."""
+    out = _new(ref, (3 * int(height) * int(width),))
+    if _dev_ok(out):
+        _call('atvs_pixel_grids', _p(out), int(height), int(width), _stream())
+    return out
+
+
 def transform_depth(depth, left_cam, right_cam, inverse_depth=True):
     """depth (h,w) in left_cam -> same pixels, values expressed in right_cam's frame."""
     h, w = depth.shape[:2]

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 24
+#define ATVS_ABI_VERSION 25
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -95,6 +95,15 @@ int atvs_visual_hull(const float* ref_depth, const float* view_depth_in_ref, con
 int atvs_warp_by_depth(const float* src, const float* left_cam, const float* right_cam, const float* depth,
                        float* out, float* mask_out, float* pose_ws, int h, int w, int C, int method,
                        int inverse_depth, atvs_stream_t stream);
+
+/* interpolate, homography_warping.py:31-104, with caller-supplied coordinates: src (h,w,C), x / y (n) in the
+ * reference's texture coordinates (pixel centres at +0.5), out (n,C), mask_out (n) 1.f / 0.f or NULL.  method 0
+ * bilinear (invalid points give 0), 1 nearest (tf.round; invalid points read pixel (0,0), not masked). */
+int atvs_interpolate(const float* src, const float* x, const float* y, float* out, float* mask_out, long n,
+                     int h, int w, int C, int method, atvs_stream_t stream);
+
+/* get_pixel_grids, homography_warping.py:8-17: out (3*h*w) = [x + 0.5 | y + 0.5 | 1], row-major pixels. */
+int atvs_pixel_grids(float* out, int h, int w, atvs_stream_t stream);
 
 /* transform_depth, homography_warping.py:275-326.  ws14: 14 floats of scratch. */
 int atvs_transform_depth(const float* depth, const float* left_cam, const float* right_cam, float* out,

@@ -184,3 +184,64 @@ def test_softargmin_known_answers(cuda):
     assert torch.allclose(ops.softargmin(cost, ds, di).cpu(), torch.full((h, w), 0.1 + 5 * 0.02), rtol=1e-6)
     flat = torch.zeros(D, h, w, device=cuda)
     assert torch.allclose(ops.softargmin(flat, ds, di).cpu(), torch.full((h, w), 0.1 + 7.5 * 0.02), rtol=1e-6)
+
+
+def _query_points(h, w, n, seed):
+    """Texture coordinates around and beyond the image, with exact half-integers (tf.round ties), the borders of the
+    valid range and non-finite values."""
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.rand(n, generator=g) * (w + 6) - 3).float()
+    y = (torch.rand(n, generator=g) * (h + 6) - 3).float()
+    special = torch.tensor([0.5, 1.0, 1.5, 2.0, 2.5, w - 1.0, w - 0.5, w - 0.5 - 1e-4, 0.0, 0.49999, float('nan'),
+                            float('inf'), -float('inf')])
+    k = special.numel()
+    x[:k] = special
+    y[k:2 * k] = torch.where(special == w - 1.0, torch.tensor(h - 1.0), special)
+    y[2 * k] = h - 0.5
+    return x, y
+
+
+@pytest.mark.parametrize('method', ['bilinear', 'nearest'])
+@pytest.mark.parametrize('h,w,C', [(32, 40, 32), (17, 23, 3), (9, 11, 1)])
+def test_interpolate_bit_exact(cuda, method, h, w, C):
+    """interpolate with caller-supplied coordinates (reference homography_warping.py:31-104) against the oracle."""
+    from atvsnet_amd.atvsnet import homography_warping as HW
+    img = _feat(h, w, C, 5)
+    x, y = _query_points(h, w, h * w, 7)
+    want, wm = G.interpolate(img, x, y, output_mask=True, method=method)
+    got, gm = HW.interpolate(img.to(cuda), x.to(cuda), y.to(cuda), output_mask=True, method=method)
+    assert gm.dtype == torch.bool and torch.equal(gm.cpu(), wm)
+    got, want = got.cpu(), want
+    same = (got == want) | (torch.isnan(got) & torch.isnan(want))      # inf * 0 = NaN on both sides (tf.multiply)
+    assert bool(same.all())
+    only = HW.interpolate(img.to(cuda), x.to(cuda), y.to(cuda), method=method).cpu()
+    assert bool(((only == want) | (torch.isnan(only) & torch.isnan(want))).all())
+
+
+def test_interpolate_on_the_pixel_grid_is_the_identity_warp(cuda):
+    """get_pixel_grids -> interpolate = the image away from the last row / column (SURVEY 8c known answer 2)."""
+    from atvsnet_amd.atvsnet import homography_warping as HW
+    h, w, C = 12, 20, 4
+    img = _feat(h, w, C, 9)
+    grid = HW.get_pixel_grids(h, w)
+    gx, gy = G.get_pixel_grids(h, w)
+    assert grid.shape == (3 * h * w,)
+    assert torch.equal(grid.cpu(), torch.cat([gx, gy, torch.ones(h * w)]))
+    out = HW.interpolate(img.to(cuda), grid[:h * w], grid[h * w:2 * h * w]).cpu().reshape(h, w, C)
+    assert torch.equal(out[:-1, :-1], img[0, :-1, :-1])
+    assert bool((out[-1] == 0).all()) and bool((out[:, -1] == 0).all())
+    near = HW.interpolate(img.to(cuda), grid[:h * w], grid[h * w:2 * h * w], method='nearest').cpu().reshape(h, w, C)
+    assert torch.equal(near[:-1, :-1], img[0, :-1, :-1])
+    assert torch.equal(near[-1, 3], img[0, 0, 0])                      # invalid -> pixel (0,0), not masked
+
+
+def test_interpolate_refuses_what_the_reference_cannot_mean(cuda):
+    from atvsnet_amd.atvsnet import homography_warping as HW
+    img = _feat(4, 5, 2, 1).to(cuda)
+    z = torch.zeros(20, device=cuda)
+    with pytest.raises(ValueError):
+        HW.interpolate(img, z, z, method='bicubic')
+    with pytest.raises(ValueError):
+        HW.interpolate(img, z, z[:7])
+    with pytest.raises(RuntimeError):
+        HW.interpolate(img.cpu(), z.cpu(), z.cpu())
