@@ -116,10 +116,15 @@ def load_data(sample_list, data_index):
 
 
 class _Pipelines(object):
-    """One set of captured HIP graphs per input shape (scenes of one data set share it), two depth maps in flight:
-    submit() issues a depth map asynchronously, fetch() returns the oldest one's results as numpy arrays."""
+    """One set of captured HIP graphs per input shape (scenes of one data set share it), SLOTS depth maps queued:
+    submit() issues a depth map asynchronously, fetch() returns the oldest one's results as numpy arrays.
+    CO_RESIDENT = False: the GPU runs one depth map at a time (the reference's scene loop, eval_pointcloud.py:291-396, is
+    serial too); the second slot only lets the host load / submit the next view and write the previous one's files
+    meanwhile.  True runs both maps' kernels concurrently (+4.5 % maps/s) and stays off until the co-residency fault of
+    DESIGN.md appendix B is root-caused or a >= 10,000-map full-size soak is clean."""
 
     SLOTS = 2
+    CO_RESIDENT = False
 
     def __init__(self, device, use_graph=True):
         self.device, self.use_graph, self.cache = device, use_graph, {}
@@ -134,7 +139,8 @@ class _Pipelines(object):
         key = tuple(images.shape)
         p = self.cache.get(key)
         if p is None:
-            p = self.cache[key] = example.PipelinedInference(images, cams, FLAGS.max_d, slots=self.SLOTS, out_prob_map=True)
+            p = self.cache[key] = example.PipelinedInference(images, cams, FLAGS.max_d, slots=self.SLOTS,
+                                                                co_resident=self.CO_RESIDENT, out_prob_map=True)
         self.pending.append((p, p.submit(images, cams)))
 
     def room(self):
@@ -187,8 +193,8 @@ def run_eval_pc(savepath, image_infos, use_graph=True):
             write_cam(stem + '.txt', cams_data[0, 0])
             plt.imsave(stem + '.png', disp_up, cmap='viridis')
 
-        # the depth maps of a scene are independent: the next one is issued before the previous one's results are
-        # fetched and written (two in flight), so file I/O and the GPU's under-filled phases overlap
+        # the depth maps of a scene are independent: the next one is submitted before the previous one's results are
+        # fetched and written, so file I/O overlaps the GPU (which still runs one map at a time: _Pipelines.CO_RESIDENT)
         for current_i in range(len(mvs_list)):
             image_data_raw, images_data, cams_data, _depth, out_index = load_data(mvs_list, current_i)
             if not run.room():

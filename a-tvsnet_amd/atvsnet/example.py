@@ -265,21 +265,29 @@ class GraphedInference(object):
 
 
 class PipelinedInference(object):
-    """`slots` depth maps in flight: one captured graph (static buffers) and one HIP stream per slot.
+    """`slots` depth maps queued: one captured graph (static buffers) and one HIP stream per slot.
 
-    The depth maps of a scene are independent (one per reference view, reference eval_pointcloud.py:399-424), and a
-    single pipeline leaves the GPU under-filled in its low-resolution / 2-D phases; issuing the next depth map on a second
-    stream fills them (config 3 on MI355X: 35.7 -> 33.2 ms per depth map with 2 in flight, no gain from a third).
-    Every slot computes exactly what GraphedInference computes.
+    The depth maps of a scene are independent (one per reference view, reference eval_pointcloud.py:399-424).
+    `co_resident=False` (default): a slot's graph starts when the previously submitted one has finished -- the GPU runs
+    ONE depth map at a time, bit for bit the single-map path, and what the queue buys is that the host prepares and submits
+    the next map (and writes the previous one's files) meanwhile.
+    `co_resident=True`: the slots' graphs run concurrently on their streams; the second map's kernels fill the phases in
+    which one pipeline leaves the GPU under-filled (+4.5 % depth maps/s at config 3).  Opt-in only: wavefronts of different
+    kernels then share SIMDs, and on this pool's MI355X small kernels beside bf16-MFMA wavefronts have produced wrong lane
+    quarters (un-root-caused, defended by register-file reservation in the one-workgroup kernels
+    but not in conv2d_b / conv1x1_b).  bench.py measures it under `pipelined` and fails the run if a slot's output
+    differs from the single-map output.
 
         t = p.submit(images, cams)      # asynchronous: copies the inputs, replays the slot's graph on its stream
         out = p.result(t)               # waits for that depth map; the tensors are valid until the slot is re-used
     """
 
-    def __init__(self, images, cams, max_d=None, slots=2, **kw):
+    def __init__(self, images, cams, max_d=None, slots=2, co_resident=False, **kw):
         if slots < 1:
             raise ValueError('PipelinedInference: slots >= 1')
         self.device = images.device
+        self.co_resident = bool(co_resident)
+        self.last = None                 # slot of the most recent submission (its event orders the next one behind it)
         self.graphs = [GraphedInference(images, cams, max_d, **kw) for _ in range(slots)]
         self.streams = [torch.cuda.Stream(self.device) for _ in range(slots)]
         self.events = [torch.cuda.Event() for _ in range(slots)]
@@ -298,6 +306,8 @@ class PipelinedInference(object):
         self.next = (s + 1) % len(self.graphs)
         st = self.streams[s]
         st.wait_stream(torch.cuda.current_stream(self.device))      # inputs prepared on the caller's stream
+        if not self.co_resident and self.last is not None and self.last != s:
+            st.wait_event(self.events[self.last])                   # one depth map on the GPU at a time
         for t in (images, cams):
             # the copy into the slot's static buffers runs on the slot's stream, possibly long after this call returns:
             # tell the caching allocator, or the caller's next allocation could re-use the block while it is still read
@@ -307,6 +317,7 @@ class PipelinedInference(object):
             self.graphs[s](images, cams)
             self.events[s].record(st)
         self.busy[s] = True
+        self.last = s
         return s
 
     def result(self, ticket):
@@ -323,8 +334,12 @@ class PipelinedInference(object):
             st.wait_stream(torch.cuda.current_stream(self.device))
         for i in range(count):
             s = i % len(self.graphs)
+            if not self.co_resident and self.last is not None and self.last != s:
+                self.streams[s].wait_event(self.events[self.last])
             with torch.cuda.stream(self.streams[s]):
                 self.graphs[s].graph.replay()
+                self.events[s].record(self.streams[s])
+            self.last = s
         for st in self.streams:
             torch.cuda.current_stream(self.device).wait_stream(st)
 

@@ -5,7 +5,9 @@
 
 A step = one depth map through the whole example.py pipeline (towers -> 2x stacked 3-D U-Net per source ->
 AAM1 -> refinement per source -> AAM2 -> x4 upsample + soft-argmin), inputs resident in HBM, synthetic
-seeded images / cameras / weights, fp32 arithmetic (fp32 MFMA for every convolution).
+seeded images / cameras / weights, fp32 storage and accumulation; the heavy convolutions run on
+v_mfma_f32_16x16x32_bf16 with every fp32 operand split into three bf16 pieces (fp32-class results), the rest on
+the fp32 matrix cores; `split_bf16` times the all-fp32-MFMA path next to it.
 Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: 5 views
 (1 reference + 4 sources) of 640x512, D=192.  cfg2 = two-view 640x512x192, cfg4 = 9 views 928x480x256 (the
 8-source configuration quoted for 8 GPUs), cfg5 = two-view 1600x1184x256.
@@ -13,13 +15,15 @@ On one GPU the step is ONE replay of a HIP graph captured from the pipeline (eve
 over all its calls -- views, siamese directions -- stacked on the batch axis with per-call batch statistics);
 --eager issues every launch from Python instead.  `value` = K depth maps strictly one after the other (1 / wall
 time of one depth map).  --inflight N (default 2): a SECOND timed region issues K depth maps round-robin on N streams
-(one captured graph + static buffers each, example.PipelinedInference) -- the depth maps of a scene are independent (one
-per reference view) and a second one in flight fills the phases in which one pipeline leaves the GPU under-filled; that
-throughput is reported under `pipelined`, never as `value`.
+with their kernels CO-RESIDENT on the GPU (example.PipelinedInference(co_resident=True), opt-in in the product) -- the
+depth maps of a scene are independent (one per reference view) and a second one in flight fills the phases in which one
+pipeline leaves the GPU under-filled; that throughput is reported under `pipelined`, never as `value`, and the run FAILS
+(exit code 4, "ok": false) if any slot's depth map differs from the single-map output by one bit.
 
 --gpus N > 1: this process touches no GPU; it starts N ranks (one process per GPU, RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), prints ONE JSON line and exits non-zero if a rank of the primary
-measurement fails or if fewer than N devices are visible.  (Launched under torch.distributed.run -- WORLD_SIZE
+measurement fails (1), if fewer than N devices are visible (2), or if a secondary view-sharded measurement fails (3: the
+line is still printed, with "ok": false and the error inside the sub-object).  (Launched under torch.distributed.run -- WORLD_SIZE
 already in the environment -- it is a rank itself and measures the mode --parallel names.)  Two ways to use N GPUs
 (a-tvsnet_amd/parallel.py):
   --parallel maps   (primary; `value`): the unit of the metric is a depth map and the depth maps of a scene are
@@ -29,16 +33,18 @@ already in the environment -- it is a rank itself and measures the mode --parall
                     are sharded over groups of at most one rank per source and exchanged inside both AANet modules
                     over RCCL (all-to-all of voxel shards + all-gather) -- lower latency per depth map, fewer depth
                     maps per second than `maps` (DESIGN.md 5 has the model).  Measured by a second set of ranks after
-                    the primary result is safe; a failure there is reported in the line and on stderr.
+                    the primary result is safe; a failure there is reported in the line, on stderr and as exit code 3.
 With the default workload the launcher ALSO measures BASELINE configs[3] ("view_sharded_cfg4": 9 views 928x480x256, the 8
 sources dealt over the N ranks -- one per GPU at N = 8 -- with `source_views_per_sec`, the exchange's share, the parity
 against tests/golden/fullsize_cfg4.npz, and the same depth map on ONE rank measured in the same invocation, so that
 speed-up and fraction-of-linear come from one run).
 
-One JSON line on rank 0.  `roofline` = the dominant kernel (conv_xp.hip: the 3x3x3 convolution of the 32 warped
-channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch) against
-the fp32 MFMA peak, timed with HIP events on its launch stream; `roofline_hbm` = the plane-sweep warp
-(warp_planes_kernel) against the HBM peak, timed the same way; `kernels` = the top kernels of the committed
+One JSON line on rank 0.  `roofline` = the dominant kernel (conv_xb.hip: the 3x3x3 convolution of the 32 warped
+channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch): the bf16 MFMA
+FLOPs the launch ISSUES / its duration (HIP events on its launch stream, >= 10 eager launches) against the dense bf16
+MFMA peak (2.5 PF) -- the pipe it runs on; `fp32_equivalent` = the algorithmic fp32 convolution FLOPs against the fp32
+matrix peak, `mfma_busy` / `clock_GHz` from the committed PMC passes; `roofline_hbm` = the plane-sweep warp
+(warp_planes_shared_kernel) against the HBM peak, timed the same way; `kernels` = the top kernels of the committed
 rocprofv3 kernel trace of this command; `parity` = the output of the timed path against the oracle-generated
 fixture of this workload (tests/golden/fullsize_*.npz) and graph replay == eager bit for bit;
 `cpu_baseline` = the CPU oracle on the host cores.
@@ -66,8 +72,16 @@ WARP = ('warp', 0)                                 # atvs_warp_planes, bilinear 
 PEAK_F32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_BF16_MFMA_TFLOPS = 2500.0     # MI355X_MICROARCH.md, dense BF16 MFMA
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md, HBM3E peak (6.29 TB/s achievable by a float4 copy)
-PMC_FILE = os.path.join('profiles', 'round3_pmc_xpair.json')
-KERNEL_STATS_FILE = os.path.join('profiles', 'round3_bench_kernel_stats.csv')
+def _newest(*names):
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, 'profiles', n)):
+            return os.path.join('profiles', n)
+    return os.path.join('profiles', names[-1])
+
+
+PMC_FILE = _newest('round4_pmc_xpair.json', 'round3_pmc_xpair.json')
+KERNEL_STATS_FILE = _newest('round4_bench_kernel_stats.csv', 'round3_bench_kernel_stats.csv')
+EAGER_TIMING_PASSES = 10           # eager passes after the timed region: >= 10 event-timed launches of the dominant kernel
 
 
 def parse(argv=None):
@@ -214,12 +228,38 @@ def launch(args, argv):
             one, err1 = secondary(1, wl + ['--gpus', '1', '--workload', 'cfg4', '--inflight', '1', '--steps', '3', '--warmup', '1'], 900)
             shd, err2 = secondary(n, wl + ['--gpus', str(n), '--workload', 'cfg4', '--parallel', 'views', '--steps', '5', '--warmup', '2'], 900)
             line['view_sharded_cfg4'] = cfg4_entry(one, err1, shd, err2, n)
+        failed = []
         for key in ('view_sharded', 'view_sharded_cfg4'):
-            if isinstance(line.get(key), dict) and line[key].get('error'):
-                sys.stderr.write('bench.py: secondary measurement %s FAILED: %s\n' % (key, line[key]['error']))
+            if isinstance(line.get(key), dict) and not line[key].get('ok', False):
+                failed.append(key)
+                sys.stderr.write('bench.py: secondary measurement %s FAILED: %s\n' % (key, line[key].get('error')))
+        promote_view_sharded(line)
+        if failed:
+            line['ok'] = False
+            line['failed'] = failed
+            print(json.dumps(line))
+            sys.stdout.flush()
+            return 3
     print(json.dumps(line))
     sys.stdout.flush()
     return 0
+
+
+def promote_view_sharded(line):
+    """The north-star partition (BASELINE configs[3]: source views sharded one per GPU, exchange inside both AANets) next
+    to `value` at the top level of the N > 1 line, so that a SCALE record shows it and not only the replica mode."""
+    c4 = line.get('view_sharded_cfg4')
+    if isinstance(c4, dict) and c4.get('ok'):
+        line['view_sharded_cfg4_value'] = c4.get('value')
+        line['view_sharded_cfg4_ms_per_step'] = c4.get('ms_per_step')
+        line['view_sharded_cfg4_source_views_per_sec'] = c4.get('source_views_per_sec')
+        line['fraction_of_linear'] = c4.get('fraction_of_linear')
+        line['speedup_vs_single_gpu'] = c4.get('speedup_vs_single_gpu')
+        line['exchange'] = c4.get('exchange')
+    vs = line.get('view_sharded')
+    if isinstance(vs, dict) and vs.get('ok'):
+        line['view_sharded_value'] = vs.get('value')
+    return line
 
 
 def view_sharded_entry(l2, err):
@@ -256,11 +296,11 @@ def cfg4_entry(one, err1, shd, err2, n):
 # --------------------------------------------------------------------------------------------- CPU baseline
 
 def cpu_baseline(args):
-    """The CPU oracle (our restatement of the reference's TF-CPU path; TensorFlow 1.5 cannot be installed) timed
-    on the host cores at FULL size: BASELINE configs[0] (two-view 160x128, D=32) 1 warm-up + 3 runs, median;
-    the stages of the two-view pipeline at the benchmark's image size and depth count once each (one full
-    configs[1] pipeline), the AANet over the benchmark's source views once; `value` composes those full-size
-    stage times the way the benchmarked pipeline composes them."""
+    """The CPU oracle (our restatement of the reference's TF-CPU path; TensorFlow 1.5 cannot be installed) timed on the host
+    cores: BASELINE configs[0] (two-view 160x128, D=32) 1 warm-up + 3 runs, median; then the benchmark's OWN workload end
+    to end, once, at full size (configs[1] / configs[2]: about 12 s / 55 s on 32 threads of the GPU box's host) -- `value`
+    is that measured wall time, nothing composed.  For the larger workloads (cfg4 / cfg5: 5-7 minutes of CPU work) every
+    stage runs once at full size and `value` composes them the way the pipeline does (`measured_end_to_end`: false)."""
     import numpy as np
     import torch
     from atvsnet_amd import synthetic, variables
@@ -289,12 +329,31 @@ def cpu_baseline(args):
             OM.run_twoview(imgs, cams, W, 32)
             runs.append(time.time() - t)
     cfg1 = float(np.median(runs[1:]))
-    # the benchmark's size, stage by stage (= one two-view pipeline), each stage once
     D = args.depths
+    n_src = args.views - 1
+    base = {'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'port',
+            'kind_detail': 'restatement: the CPU oracle (torch-CPU / numpy restatement of the reference\'s TF-1.5 path, oracle/), '
+                           'NOT TensorFlow and not a build of the reference -- TensorFlow 1.5 cannot be installed here',
+            'host_cpus': ncpu, 'cpu_model': model_name,
+            'configs0_s': round(cfg1, 3), 'configs0_runs_s': [round(r, 3) for r in runs]}
+    if not args.custom and args.workload in ('cfg2', 'cfg3'):
+        imgs, cams = synthetic.make_inputs(args.views, args.height, args.width, D, seed=0)
+        imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
+        with torch.no_grad():
+            t = time.time()
+            out = OM.run_twoview(imgs, cams, W, D) if n_src == 1 else OM.run_multiview(imgs, cams, W, D)
+            per_map = time.time() - t
+        base.update(value=1.0 / per_map, measured_end_to_end=True, workload_s=round(per_map, 2),
+                    output_checksum=float(out.double().mean()),
+                    sample='CPU restatement (not TensorFlow): configs[0] (160x128, D=32 two-view) 1 warm-up + 3 runs, median %.2f s; '
+                           'then ONE depth map of the benchmarked workload end to end (%d views %dx%d, D=%d, the same seeded inputs '
+                           'and weights as the GPU run): %.1f s measured on %d threads; value = 1 / that; %.0f s of CPU work in all'
+                           % (cfg1, args.views, args.width, args.height, D, per_map, threads, time.time() - t_all))
+        return base
+    # the larger workloads, stage by stage (= one two-view pipeline), each stage once at full size
     imgs, cams = synthetic.make_inputs(2, args.height, args.width, D)
     imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
     ds, di = OM.depth_start_interval(cams)
-    n_src = args.views - 1
     T = {}
     with torch.no_grad():
         t = time.time()
@@ -323,18 +382,16 @@ def cpu_baseline(args):
         per_map = args.views * T['tower'] + n_src * (2 * (T['warp'] + T['unet']) + T['refine']) + 2 * T['aam']
     else:
         per_map = twoview
-    return {'value': 1.0 / per_map, 'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'port',
-            'kind_detail': 'restatement: the CPU oracle (torch-CPU / numpy restatement of the reference\'s TF-1.5 path); '
-                           'TensorFlow itself cannot be installed here',
-            'host_cpus': ncpu, 'cpu_model': model_name,
-            'configs0_s': round(cfg1, 3), 'configs0_runs_s': [round(r, 3) for r in runs],
-            'twoview_fullsize_s': round(twoview, 2), 'stage_s': {k: round(v, 2) for k, v in T.items()},
-            'sample': 'CPU restatement (not TensorFlow): configs[0] (160x128, D=32 two-view) 1 warm-up + 3 runs, median '
-                      '%.2f s; every stage of the pipeline once at FULL size %dx%d, D=%d (tower %.1f s, warp %.1f s, '
-                      'U-Net %.1f s, refinement %.1f s, AANet over %d views + head + upsample %.1f s); value = 1 / (%d '
-                      'towers + %d x (2 warps + 2 U-Nets + refinement) + 2 AAM) = 1 / %.1f s; %.0f s of CPU work in all'
-                      % (cfg1, args.width, args.height, D, T['tower'], T['warp'], T['unet'], T['refine'], n_src,
-                         T['aam'], args.views if n_src > 1 else 2, n_src, per_map, time.time() - t_all)}
+    base.update(value=1.0 / per_map, measured_end_to_end=False, twoview_fullsize_s=round(twoview, 2),
+                stage_s={k: round(v, 2) for k, v in T.items()},
+                sample='CPU restatement (not TensorFlow): configs[0] (160x128, D=32 two-view) 1 warm-up + 3 runs, median '
+                       '%.2f s; every stage of the pipeline once at FULL size %dx%d, D=%d (tower %.1f s, warp %.1f s, '
+                       'U-Net %.1f s, refinement %.1f s, AANet over %d views + head + upsample %.1f s); value = 1 / (%d '
+                       'towers + %d x (2 warps + 2 U-Nets + refinement) + 2 AAM) = 1 / %.1f s (composed, not measured end to '
+                       'end); %.0f s of CPU work in all'
+                       % (cfg1, args.width, args.height, D, T['tower'], T['warp'], T['unet'], T['refine'], n_src,
+                          T['aam'], args.views if n_src > 1 else 2, n_src, per_map, time.time() - t_all))
+    return base
 
 
 # --------------------------------------------------------------------------------------------- reporting helpers
@@ -354,6 +411,24 @@ def pmc_traffic(args, samples):
             return None
         return {'write': int(d['write_bytes']), 'fetch_raw': int(d['fetch_bytes_raw']), 'fetch_x2': 2 * int(d['fetch_bytes_raw']),
                 'source': PMC_FILE, 'measured_in_run': False}
+    except Exception:
+        return None
+
+
+def pmc_counters(args, samples):
+    """Matrix-pipe occupancy, held clock and VALU instructions per MFMA of the dominant launch from the committed PMC passes
+    (same validity conditions as pmc_traffic)."""
+    if (args.width, args.height, args.depths) != (640, 512, 192):
+        return None
+    try:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
+            d = json.load(f)['dominant']
+        from atvsnet_amd import ops
+        if int(d['volumes_per_launch']) != int(samples) or ('conv_%s_kernel' % ops._xkind()) not in d['kernel']:
+            return None
+        return {'mfma_busy': d.get('mfma_busy_fraction_of_simd_cycles'), 'clock_GHz': d.get('clock_GHz'),
+                'valu_per_mfma': d.get('valu_per_mfma'), 'kernel': d.get('kernel'),
+                'duration_ms': round(d['duration_ns_under_profiler'] / 1e6, 4)}
     except Exception:
         return None
 
@@ -442,6 +517,7 @@ def dry_rank(args):
 
 
 def rank_main(args):
+    failed = False
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -490,7 +566,7 @@ def rank_main(args):
             graphed = parallel.ShardedGraphedInference(imgs, cams, args.depths, group=group)
         else:
             # one HIP graph per depth map; `inflight` of them (own static buffers and stream each) for the timed region
-            pipe = ex.PipelinedInference(imgs, cams, args.depths, slots=max(1, args.inflight))
+            pipe = ex.PipelinedInference(imgs, cams, args.depths, slots=max(1, args.inflight), co_resident=True)
             graphed = pipe.graphs[0]
 
     def eager_step(view_streams=True):
@@ -535,8 +611,9 @@ def rank_main(args):
         # every slot computed the captured inputs: all of them must hold the depth map the timed single-map path produced
         same = all(bool(torch.equal(g.out, out)) for g in pipe.graphs)
         pipelined = {'value': round(n_groups * args.steps / dtp, 4), 'unit': 'depth-maps/sec', 'inflight': pipe.slots,
-                     'ms_per_step': round(1e3 * dtp / args.steps, 3), 'equals_single_map_bitwise': same,
-                     'note': '%d depth maps in flight (one captured graph + stream each, example.PipelinedInference): '
+                     'ms_per_step': round(1e3 * dtp / args.steps, 3), 'equals_single_map_bitwise': same, 'co_resident': True,
+                     'note': '%d depth maps in flight with their kernels co-resident on the GPU (example.PipelinedInference('
+                             'co_resident=True): opt-in, the product default runs one map at a time -- DESIGN.md appendix B): '
                              'throughput of independent depth maps of a scene, NOT the per-map rate `value` reports' % pipe.slots}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -576,11 +653,11 @@ def rank_main(args):
         finally:
             ops.use_bf16x3(default_on)
 
-    # the dominant kernel and the warp, timed by HIP events on their launch stream in two eager single-stream passes
+    # the dominant kernel and the warp, timed by HIP events on their launch stream in ten eager single-stream passes
     # of the same step right after the timed region (kernels inside a replayed graph cannot be bracketed by events;
     # single stream: no other kernel shares the GPU with the one being timed)
     ops.watch([DOMINANT, WARP])
-    for _ in range(2):
+    for _ in range(EAGER_TIMING_PASSES):
         eager_out = eager_step(view_streams=False)
     watched = ops.watch(None)
     assert torch.isfinite(out).all()
@@ -615,16 +692,45 @@ def rank_main(args):
                            'pieces, six products, fp32 accumulation)',
                      'xw': 'conv_xw_kernel<SIB> (x-pair rows x Winograd F(2,3) along y on v_mfma_f32_16x16x4_f32)',
                      'xp': 'conv_xp_kernel<C4=4,SIB> (x-pair rows on v_mfma_f32_16x16x4_f32)'}[kind]
-            roof = {'bound': 'mfma', 'kernel': '%s: conv_b0_0_1 (32 warped channels -> 8, 3x3x3, full resolution) + sibling conv_b0_1_0 '
-                                              '(-> 16, stride 2), %d volumes per launch' % (kdesc, int(samples)),
-                    'flops_convention': 'achieved = ALGORITHMIC (direct fp32 convolution, SURVEY 8d) FLOPs / time, priced against the '
-                                        'fp32 matrix peak the path is specified in; ' +
-                                        ('the kernel issues 6 x 4/3 = 8 bf16 MFMA FLOPs per algorithmic FLOP (six piece products, x-pair '
-                                         'rows): see `issued_bf16`' if kind == 'xb' else
-                                         'the kernel issues 8/9 of them as MFMA work (F(2,3): 2/3, x-pair rows: 4/3)' if kind == 'xw' else
-                                         'the kernel issues 4/3 of them as MFMA work (x-pair rows)'),
-                    'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+            pmc = pmc_counters(args, samples)
+            fp32_eq = {'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                       'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                       'note': 'ALGORITHMIC direct fp32 convolution FLOPs (SURVEY 8d) / time against the fp32 matrix peak the path is '
+                               'specified in: what an fp32-MFMA kernel would need to reach; exceeds 1.0 in principle on the bf16 pipe '
+                               '(ceiling 2500 / 8 / 157.3 = 1.99), so it is NOT the roofline fraction'}
+            if kind == 'xb':
+                # main: 9 steps x 6 products per (8-channel chunk, 16 pairs x row): 2*16*16*32 FLOP each = 8 x the useful
+                # fp32 FLOPs (x-pair zero taps 4/3, six products); sibling: 7 steps of 4 taps for 27 -> 28/27 x 6
+                main = 2.0 * 27 * 32 * 8 * vox * samples
+                sibf = (flops - main)
+                issued = main * 8.0 + sibf * 6.0 * 28.0 / 27.0
+                peak, pipe = PEAK_BF16_MFMA_TFLOPS, 'bf16'
+                conv = ('achieved = bf16 MFMA FLOPs the launch ISSUES (v_mfma_f32_16x16x32_bf16 count x 16384; 8 per algorithmic '
+                        'FLOP of the main convolution: six piece products x 4/3 x-pair rows; 6 x 28/27 for the sibling) / '
+                        'time, against the dense bf16 MFMA peak: the pipe the kernel runs on')
+            elif kind == 'xw':
+                issued, peak, pipe = flops * 8.0 / 9.0, PEAK_F32_MFMA_TFLOPS, 'fp32'
+                conv = 'achieved = fp32 MFMA FLOPs issued (F(2,3): 2/3, x-pair rows: 4/3 of the algorithmic FLOPs) / time'
+            else:
+                issued, peak, pipe = flops * 4.0 / 3.0, PEAK_F32_MFMA_TFLOPS, 'fp32'
+                conv = 'achieved = fp32 MFMA FLOPs issued (x-pair rows: 4/3 of the algorithmic FLOPs) / time'
+            iss = issued / (avg_ms * 1e-3) / 1e12
+            roof = {'bound': 'mfma', 'pipe': pipe,
+                    'kernel': '%s: conv_b0_0_1 (32 warped channels -> 8, 3x3x3, full resolution) + sibling conv_b0_1_0 '
+                              '(-> 16, stride 2), %d volumes per launch' % (kdesc, int(samples)),
+                    'flops_convention': conv,
+                    'achieved': round(iss, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(iss / peak, 4),
+                    'issued_flops_per_launch': issued,
+                    'useful_frac': round(flops * (6.0 if kind == 'xb' else 1.0) / (avg_ms * 1e-3) / 1e12 / peak, 4),
+                    'fp32_equivalent': fp32_eq,
+                    'mfma_busy': pmc.get('mfma_busy') if pmc else None,
+                    'clock_GHz': pmc.get('clock_GHz') if pmc else None,
+                    'valu_per_mfma': pmc.get('valu_per_mfma') if pmc else None,
+                    'pmc': ({'source': PMC_FILE, 'measured_in_run': False, 'kernel': pmc.get('kernel'),
+                             'duration_ms_under_profiler': pmc.get('duration_ms'),
+                             'note': 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); clock_GHz = '
+                                     'GRBM_GUI_ACTIVE / 8 / duration: the clock the chip holds under this kernel (2.4 GHz spec)'}
+                            if pmc else None),
                     'traffic': (tr['write'] + tr['fetch_x2']) if tr else None,
                     'traffic_detail': dict(tr, algorithmic=alg_bytes,
                                            ratio_raw=round((tr['write'] + tr['fetch_raw']) / alg_bytes, 3),
@@ -636,15 +742,6 @@ def rank_main(args):
                     if tr else None,
                     'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[DOMINANT]), 'volumes_per_launch': samples,
                     'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': alg_bytes}
-            if kind == 'xb':
-                # main: 9 steps x 6 products per (8-channel chunk, 16 pairs x row): 2*16*16*32 FLOP each = 8 x the useful
-                # fp32 FLOPs (x-pair zero taps 4/3, six products); sibling: 7 steps of 4 taps for 27 -> 28/27 x 6
-                main = 2.0 * 27 * 32 * 8 * vox * samples
-                sibf = (flops - main)
-                issued = main * 8.0 + sibf * 6.0 * 28.0 / 27.0
-                roof['issued_bf16'] = {'flops_per_launch': issued, 'achieved': round(issued / (avg_ms * 1e-3) / 1e12, 1),
-                                       'peak': PEAK_BF16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                       'frac': round(issued / (avg_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4)}
         if watched.get(WARP):
             # plane-sweep warp of the 32-channel source features into the D-varying half of the cost volume:
             # algorithmic bytes = write D*h*w*32*4 + read h*w*32*4
@@ -705,11 +802,22 @@ def rank_main(args):
                 line['cpu_baseline'] = cpu_baseline(args)
             except Exception as e:                        # the baseline must never hide the GPU number
                 line['cpu_baseline'] = {'error': repr(e)}
+        problems = []
+        if pipelined is not None and not pipelined['equals_single_map_bitwise']:
+            problems.append('pipelined: a slot of the co-resident run differs from the single-map output')
+        if isinstance(line.get('parity'), dict) and line['parity'].get('ok') is False:
+            problems.append('parity: rel-L1 above the bar')
+        if isinstance(line.get('parity'), dict) and line['parity'].get('graph_equals_eager_bitwise') is False:
+            problems.append('parity: graph replay differs from eager launch')
+        line['ok'] = not problems
+        if problems:
+            line['problems'] = problems
+            failed = True
         print(json.dumps(line))
         sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
-    return 0
+    return 4 if failed else 0
 
 
 def main(argv=None):

@@ -79,3 +79,58 @@ def test_secondary_entries_name_their_mode_and_failures():
     assert v == {'ok': False, 'error': 'timeout'}
     l2 = dict(shd, scaling='strong')
     assert bench.view_sharded_entry(l2, None)['ok'] is True
+
+
+def _fake_launch(monkeypatch, capsys, secondary_ok):
+    """bench.launch() with the ranks replaced by canned lines: the primary `maps` run succeeds; the view-sharded
+    secondaries succeed or fail."""
+    sys.path.insert(0, ROOT)
+    import bench
+    calls = []
+
+    def fake_run_ranks(n, argv, timeout_s):
+        calls.append((n, list(argv)))
+        if '--parallel' in argv and argv[argv.index('--parallel') + 1] == 'maps':
+            return json.dumps({'metric': 'm', 'value': 280.0, 'n_gpus': n, 'config': {}}) + '\n', [0] * n
+        if not secondary_ok:
+            return 'RuntimeError: NCCL error\n', [1] + [0] * (n - 1)
+        cfg4 = '--workload' in argv and argv[argv.index('--workload') + 1] == 'cfg4'
+        ms = (96.0 if n == 1 else 20.0) if cfg4 else 14.0
+        return json.dumps({'value': 1e3 / ms, 'unit': 'depth-maps/sec', 'ms_per_step': ms, 'scaling': 'strong',
+                           'source_views_per_sec': 8e3 / ms, 'exchange': {'graph_ms': ms - 3.0, 'comm_ms': 3.0},
+                           'parity': {'ok': True}, 'config': {'parallelism': 'p', 'groups': [list(range(n))]}}) + '\n', [0] * n
+
+    monkeypatch.setattr(bench, '_run_ranks', fake_run_ranks)
+    monkeypatch.setattr(bench, 'visible_gpus', lambda *a, **k: 8)
+    argv = ['--gpus', '8', '--steps', '3', '--warmup', '1']
+    rc = bench.launch(bench.parse(argv), argv)
+    out = capsys.readouterr()
+    lines = [ln for ln in out.out.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1                                   # ONE JSON line whatever happens
+    return rc, json.loads(lines[0]), out.err, calls
+
+
+def test_launcher_exits_3_when_the_view_sharded_path_breaks(monkeypatch, capsys):
+    """The north-star partition must not be able to break behind a green run: a failing secondary keeps the primary line
+    (value intact) but marks it ok: false and the launcher exits 3."""
+    rc, line, err, calls = _fake_launch(monkeypatch, capsys, secondary_ok=False)
+    assert rc == 3 and line['ok'] is False and line['value'] == 280.0
+    assert set(line['failed']) == {'view_sharded', 'view_sharded_cfg4'}
+    assert line['view_sharded']['ok'] is False and 'ranks returned' in line['view_sharded']['error']
+    assert line['view_sharded_cfg4']['ok'] is False
+    assert 'FAILED' in err and 'fraction_of_linear' not in line
+
+
+def test_launcher_promotes_the_view_sharded_numbers(monkeypatch, capsys):
+    """A SCALE record reads the top level of the line: the view-sharded configs[3] rate, its fraction of linear and the
+    exchange's share stand next to `value` (replica mode)."""
+    rc, line, err, calls = _fake_launch(monkeypatch, capsys, secondary_ok=True)
+    assert rc == 0 and 'ok' not in line or line.get('ok', True)
+    assert line['value'] == 280.0
+    assert line['view_sharded_cfg4_value'] == 50.0 and line['view_sharded_cfg4_ms_per_step'] == 20.0
+    assert line['speedup_vs_single_gpu'] == 4.8 and line['fraction_of_linear'] == 0.6
+    assert line['exchange'] == {'graph_ms': 17.0, 'comm_ms': 3.0}
+    assert line['view_sharded_cfg4_source_views_per_sec'] == 400.0
+    assert abs(line['view_sharded_value'] - 1e3 / 14.0) < 1e-9
+    # the three secondary runs: views at N, cfg4 on one rank, cfg4 view-sharded at N
+    assert [c[0] for c in calls] == [8, 8, 1, 8]

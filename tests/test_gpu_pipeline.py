@@ -184,9 +184,11 @@ def test_graft_entry_build_then_smoke_in_one_process(cuda):
     assert r.returncode == 0 and 'smoke ok' in out, out[-2000:]
 
 
-def test_pipelined_inference_two_in_flight(cuda, weights):
-    """example.PipelinedInference: two depth maps in flight (independent reference views of a scene, reference
-    eval_pointcloud.py:399-424) give, per depth map, exactly what one pipeline gives."""
+@pytest.mark.parametrize('co_resident', [False, True])
+def test_pipelined_inference_two_in_flight(cuda, weights, co_resident):
+    """example.PipelinedInference: two depth maps queued (independent reference views of a scene, reference
+    eval_pointcloud.py:399-424) give, per depth map, exactly what one pipeline gives -- with the GPU running one map at
+    a time (the default) and with both maps' kernels on the GPU at once (co_resident=True, opt-in)."""
     from atvsnet_amd.atvsnet import example as ex
     from atvsnet_amd import synthetic
     imgs, cams = _inputs(3)
@@ -195,7 +197,8 @@ def test_pipelined_inference_two_in_flight(cuda, weights):
     want1 = ex.infer_multiview(imgs, cams, 32).clone()
     want2 = ex.infer_multiview(imgs2, cams, 32).clone()
     assert not torch.equal(want1, want2)
-    p = ex.PipelinedInference(imgs, cams, 32, slots=2)
+    p = ex.PipelinedInference(imgs, cams, 32, slots=2, co_resident=co_resident)
+    assert ex.PipelinedInference.__init__.__defaults__[2] is False          # co-residency is opt-in
     t1 = p.submit(imgs, cams)
     t2 = p.submit(imgs2, cams)
     with pytest.raises(RuntimeError):
@@ -289,7 +292,7 @@ def test_two_depth_maps_in_flight_fullsize(cuda, weights):
 
     imgs, cams = inputs(0)
     imgs2, _ = inputs(7)
-    p = ex.PipelinedInference(imgs, cams, 192, slots=2)
+    p = ex.PipelinedInference(imgs, cams, 192, slots=2, co_resident=True)
     w1 = p.result(p.submit(imgs, cams)).clone()
     torch.cuda.synchronize()
     w2 = p.result(p.submit(imgs2, cams)).clone()
