@@ -333,18 +333,28 @@ class Network(object):
         wg = self._kernel(vg, (3, 3, 3, geo.shape[-1], filters))
         wpr = self._kernel('%s/conv3d/kernel' % n_prob, (3, 3, 3, 1, filters))
         wh = self._kernel('%s/conv3d/kernel' % n_hull, (3, 3, 3, 1, filters))
-        y_photo, st_photo = ops.conv_split(photo, vp, wp, want_stats=True)                 # dense raw (B,D,h,w,8)
         wg_var, planes_g = ops._fold_split_weights(vg, wg, geo.chan_map, geo.var.shape[-1], geo.const.shape[-1])
         pb_geo = ops.conv(geo.const, (vg, 'planes'), planes_g, groups=B)                   # (B,h,w,24)
-        buf, st24 = ops.refine_stems(y_photo, geo.var, pb_geo, self._bt(prob, n_prob), self._bt(hull, n_hull),
-                                     (vg, 'stems'), wg_var, wpr, wh)
+        dhw = tuple(int(v) for v in photo.shape[1:4])
+        planar = dhw if (ops.planar_concat_ok(dhw) and not photo.planar and photo.cv % 8 == 0) else None
+        if planar:
+            # the concat as four dense 8-channel planes: the photo stem writes plane 0, the FMA stems planes 1..3, and the
+            # consumer (3dconv0_1 | 3dconv1_0) stages 32-byte voxels per chunk instead of 32 of every 128 bytes
+            buf = torch.empty((B, 4, ops.planar_stride(*dhw)), dtype=torch.float32, device=pb_geo.device)
+            st_photo = ops.conv_split_into_plane(photo, vp, wp, buf, 0, planar)
+            buf, st24 = ops.refine_stems(None, geo.var, pb_geo, self._bt(prob, n_prob), self._bt(hull, n_hull),
+                                         (vg, 'stems'), wg_var, wpr, wh, planar_out=buf)
+        else:
+            y_photo, st_photo = ops.conv_split(photo, vp, wp, want_stats=True)             # dense raw (B,D,h,w,8)
+            buf, st24 = ops.refine_stems(y_photo, geo.var, pb_geo, self._bt(prob, n_prob), self._bt(hull, n_hull),
+                                         (vg, 'stems'), wg_var, wpr, wh)
         pshape = (3, 4 * filters) if B == 1 else (B, 3, 4 * filters)
         params = torch.empty(pshape, dtype=torch.float32, device=buf.device)
         ops.copy_channels(ops.bn_params(st_photo, filters, buf, None, BN_EPS), params, filters, 0, 0)
         ops.copy_channels(ops.bn_params(st24, 3 * filters, buf, None, BN_EPS), params, 3 * filters, 0, filters)
         # the batch norm + ReLU of the 32 channels stays pending: the concat's consumer (3dconv0_1 | 3dconv1_0) normalises
         # on load; anything else that asks for a stem or the concat gets the materialised tensor
-        out = ops.PendingBN(buf, params, True)
+        out = ops.PendingBN(buf, params, True, planar=planar)
         for i, name in enumerate((n_photo, n_geo, n_prob, n_hull)):
             self.layers[name] = ops.LazySlice(out, i * filters, (i + 1) * filters)
         self.layers[concat_name] = out

@@ -154,11 +154,16 @@ __device__ __forceinline__ void rs_halve(double* v, int o, int lane, int& c0) {
 // Where its time goes (4 volumes of 192 x 128 x 160, by leaving phases out): taps 0.31 ms (packed FMAs at the rate the
 // SIMDs issue them), loads 0.28, stores 0.30, statistics 0.19 -> 0.06 with the halving butterfly; the phases add up
 // (two wavefronts per SIMD: 217 registers) whatever the start of the second workgroup of a CU is delayed by.
+// PLANAR: y is chunk-planar per sample, four planes of [D][H][W][8] `pstride` floats apart (the layout the x-pair kernel
+// stages as dense 32-byte voxels: conv_xb.hip, x_planar).  The photo stem has written plane 0 itself, so nothing is passed
+// through: the kernel reads 16 and writes 96 bytes per voxel instead of 48 and 128, and every store instruction of a
+// wavefront covers ONE whole kilobyte of one plane (a line of 32 voxels).
+template <bool PLANAR>
 __global__ __launch_bounds__(256, RS_WAVES) void refine_stems_kernel(const float* __restrict__ photo, const float* __restrict__ geo,
                                                            const float* __restrict__ geo_pb, const float* __restrict__ prob,
                                                            const float* __restrict__ hull, const float* __restrict__ w,
                                                            float* __restrict__ y, double* __restrict__ stats, int D, int H,
-                                                           int W, int tiles_y, int tiles_x, int tiles, int groups) {
+                                                           int W, int tiles_y, int tiles_x, int tiles, int groups, long pstride) {
   // (geo0, geo1, prob, hull) per halo voxel; after the taps, each wavefront's staging rows for the stores
   __shared__ float4 tile[ST_HZ * ST_HY * ST_HX > 4 * RS_STG ? ST_HZ * ST_HY * ST_HX : 4 * RS_STG];
   __shared__ double s_red[4][2][24];
@@ -248,11 +253,13 @@ __global__ __launch_bounds__(256, RS_WAVES) void refine_stems_kernel(const float
   float ssum[24], ssq[24];
 #pragma unroll
   for (int k = 0; k < 24; ++k) ssum[k] = ssq[k] = 0.f;
-  float* yg = y + (size_t)grp * vol * 32;
-  // the tile's ST_TZ planes of y as a buffer (H * W * 512 bytes < 4 GB, checked by the caller)
-  const unsigned ybytes = (unsigned)((size_t)H * W * 128 * ST_TZ);
-  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg + (size_t)z0 * H * W * 32, 0, ybytes, 0x00020000);
-  const float* phg = photo + (size_t)grp * vol * 8;
+  float* yg = PLANAR ? y + (size_t)grp * 4 * pstride + pstride : y + (size_t)grp * vol * 32;
+  // the tile's ST_TZ planes of y as a buffer (H * W * 512 bytes < 4 GB, checked by the caller); PLANAR: one per channel plane
+  const unsigned ybytes = (unsigned)((size_t)H * W * (PLANAR ? 32 : 128) * ST_TZ);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg + (size_t)z0 * H * W * (PLANAR ? 8 : 32), 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc1 = __builtin_amdgcn_make_buffer_rsrc(yg + (PLANAR ? pstride : 0) + (size_t)z0 * H * W * 8, 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t yrsrc2 = __builtin_amdgcn_make_buffer_rsrc(yg + (PLANAR ? 2 * pstride : 0) + (size_t)z0 * H * W * 8, 0, ybytes, 0x00020000);
+  const float* phg = PLANAR ? nullptr : photo + (size_t)grp * vol * 8;
   const float* pbg = geo_pb ? geo_pb + (size_t)grp * H * W * 24 : nullptr;
   // Stores go through LDS: a thread owns one voxel's 128-byte row, and written by its owner each store instruction would
   // touch 64 rows with 16 bytes each (eight partial writes per line at the L2).  Each wavefront stages its 64 rows (two
@@ -265,11 +272,13 @@ __global__ __launch_bounds__(256, RS_WAVES) void refine_stems_kernel(const float
     const int zo = z0 + z;
     const bool ok = col_ok && zo < D;
     const float* pb = ok && pbg ? pbg + ((size_t)yo * W + xo) * 24 + plane_variant(zo - 1, D) * 8 : rs_zeros;
-    const float* pp = ok ? phg + (((size_t)zo * H + yo) * W + xo) * 8 : rs_zeros;
     q[0] = ld4(pb);
     q[1] = ld4(pb + 4);
-    p[0] = ld4(pp);
-    p[1] = ld4(pp + 4);
+    if (!PLANAR) {
+      const float* pp = ok ? phg + (((size_t)zo * H + yo) * W + xo) * 8 : rs_zeros;
+      p[0] = ld4(pp);
+      p[1] = ld4(pp + 4);
+    }
   };
   request(id + (int)gridDim.x < total ? id + gridDim.x : id);      // the last tile asks for itself again (never landed)
   fetch(0, ph[0], bb[0]);
@@ -295,13 +304,28 @@ __global__ __launch_bounds__(256, RS_WAVES) void refine_stems_kernel(const float
         ssq[k] += a * a;
       }
     }
-    stg[lane * 9] = p0;
-    stg[lane * 9 + 1] = p1;
+    if (!PLANAR) {
+      stg[lane * 9] = p0;
+      stg[lane * 9 + 1] = p1;
+    }
 #pragma unroll
     for (int k = 0; k < 24; k += 4) stg[lane * 9 + 2 + k / 4] = make_float4(a24[k], a24[k + 1], a24[k + 2], a24[k + 3]);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (PLANAR) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) {                        // instruction i: stem i / 2 (its plane), line i % 2: 32 voxels x 32 bytes
+        const int c = i >> 1, r = i & 1, xi = lane >> 1, hf = lane & 1;
+        const float4 v = stg[(r * 32 + xi) * 9 + 2 + c * 2 + hf];
+        const int yy = y0 + 2 * wave + r, xx = x0 + xi;
+        const bool ok = yy < H && xx < W && zo < D;
+        const u32x4 bits = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
+                            __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
+        const unsigned off = ok ? (unsigned)(((z * H + yy) * W + xx) * 8 + hf * 4) * 4u : ybytes;
+        __builtin_amdgcn_raw_buffer_store_b128(bits, c == 0 ? yrsrc : (c == 1 ? yrsrc1 : yrsrc2), off, 0, 0);
+      }
+    } else
 #pragma unroll
     for (int i = 0; i < 8; ++i) {                          // instruction i: line i / 4, voxels 8 (i % 4) .. + 7, 16 bytes per lane
       const int r = i >> 2, xi = (i & 3) * 8 + (lane >> 3), c = lane & 7;
@@ -388,19 +412,27 @@ extern "C" int atvs_conv_stem_f32(const float* x, const float* w, const float* p
 // (G,H,W,24) | conv(prob (G,D,H,W,1)) | conv(hull (G,D,H,W,1))] (no activation: the batch norm + ReLU of the concat
 // follows).  w: [27][geo0, geo1, prob, hull][8] floats on the device (atvs_refine_stems_pack arranges the three TF
 // kernels).  stats_partial: groups * atvs_conv_stem_rows rows of [2][24] doubles (the 24 computed channels) or NULL.
+// y_planar != 0: y is chunk-planar, (G, 4, y_planar) with planes of [D][H][W][8]; planes 1..3 are written (geo | prob | hull),
+// plane 0 belongs to the photo stem (atvs_conv_xb_f32 with y_group_stride) and photo_raw is not read (may be NULL).
 extern "C" int atvs_refine_stems_f32(const float* photo_raw, const float* geo, const float* geo_plane_bias, const float* prob,
                                      const float* hull, const float* w, float* y, double* stats_partial, int groups, int D,
-                                     int H, int W, atvs_stream_t stream) {
-  if (!photo_raw || !geo || !prob || !hull || !w || !y) return ATVS_ERR_NULL;
+                                     int H, int W, long y_planar, atvs_stream_t stream) {
+  if ((!photo_raw && !y_planar) || !geo || !prob || !hull || !w || !y) return ATVS_ERR_NULL;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
+  if (y_planar && y_planar < (long)D * H * W * 8) return ATVS_ERR_ARG;
   if (geo_plane_bias && D < 2) return ATVS_ERR_ARG;
   if ((double)H * W * 128.0 * ST_TZ >= 4294967296.0) return ATVS_ERR_SHAPE;       // a tile's planes are one buffer descriptor
   const int ty = (H + ST_TY - 1) / ST_TY, tx = (W + ST_TX - 1) / ST_TX;
   const long tiles = atvs_conv_stem_rows(D, H, W);
   if (tiles * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
   const long total = tiles * groups;
-  hipLaunchKernelGGL(refine_stems_kernel, dim3((unsigned)(total < RS_GRID ? total : RS_GRID)), dim3(256), 0, as_stream(stream),
-                     photo_raw, geo, geo_plane_bias, prob, hull, w, y, stats_partial, D, H, W, ty, tx, (int)tiles, groups);
+  const dim3 grid((unsigned)(total < RS_GRID ? total : RS_GRID));
+  if (y_planar)
+    hipLaunchKernelGGL(refine_stems_kernel<true>, grid, dim3(256), 0, as_stream(stream), photo_raw, geo, geo_plane_bias, prob,
+                       hull, w, y, stats_partial, D, H, W, ty, tx, (int)tiles, groups, y_planar);
+  else
+    hipLaunchKernelGGL(refine_stems_kernel<false>, grid, dim3(256), 0, as_stream(stream), photo_raw, geo, geo_plane_bias, prob,
+                       hull, w, y, stats_partial, D, H, W, ty, tx, (int)tiles, groups, 0L);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -608,15 +608,20 @@ extern "C" int atvs_conv_xb_pack_sibling(const float* w2, int Cin, unsigned char
 
 // Same contract as atvs_conv_xw_f32 (x_planar included), weights packed by atvs_conv_xb_pack[_sibling]; grid and statistics
 // rows = atvs_conv_xp_grid.  fp32-class results (split-bf16 operands, fp32 accumulation); rounding differs from the fp32 forms.
+// Beyond atvs_conv_xw_f32: x_planar may come WITH in_params (one pending batch norm, the refinement's chunk-planar concat;
+// not with x2), and y_group_stride != 0 = floats between the samples of y (default D*H*W*ldy): the photo stem writes
+// plane 0 of each sample's chunk-planar concat (ldy = 8, y_group_stride = 4 * plane stride).
 extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* plane_bias,
                                 float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
                                 int relu, const unsigned char* packed_w2, const float* plane_bias2, float* y2,
                                 double* stats_partial2, int ldy2, int y_coff2, const float* x2, const float* in_params,
-                                const float* in_params2, int in_relu, int in_relu2, long x_planar, atvs_stream_t stream) {
+                                const float* in_params2, int in_relu, int in_relu2, long x_planar, long y_group_stride,
+                                atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (in_params2 && !x2) return ATVS_ERR_ARG;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8)) return ATVS_ERR_SHAPE;
-  if (x_planar && (x2 || in_params || x_planar < (long)D * H * W * 8)) return ATVS_ERR_ARG;
+  if (x_planar && (x2 || x_planar < (long)D * H * W * 8)) return ATVS_ERR_ARG;
+  if (y_group_stride && y_group_stride < (long)D * H * W * ldy) return ATVS_ERR_ARG;
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if (plane_bias && D < 2) return ATVS_ERR_ARG;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
@@ -640,7 +645,7 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
   a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
   a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;
   a.wg = (int)atvs_conv_xp_grid(D, H, W, groups);
-  a.gx = x_planar ? x_planar * (Cin / 8) : (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
+  a.gx = x_planar ? x_planar * (Cin / 8) : (long)D * H * W * Cin; a.gy = y_group_stride ? y_group_stride : (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
   a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
   const long blocks = (long)a.wg * groups;
   hipStream_t st = as_stream(stream);

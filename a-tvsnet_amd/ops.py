@@ -776,7 +776,7 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
 
 
 def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None,
-                   prologue=None, planar=False):
+                   prologue=None, planar=False, ldy=None, y_gstride=0, y_off=0):
     """One atvs_conv_xp_f32 launch: x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
     sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5.
     prologue = (x2 | None, params | None, params2 | None, relu, relu2): the input is formed on load as
@@ -786,7 +786,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
         Cin = K * 8
     else:
         G, D, H, W, Cin = x5.shape
-    ldy = y.shape[-1]
+    ldy = y.shape[-1] if ldy is None else int(ldy)      # ldy / y_gstride given: y is a plane of a chunk-planar buffer (xb only)
     null = ctypes.c_void_p(0)
     sp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else null     # noqa: E731
     pk2, y2, y_coff2, sbuf2, pb2 = sibling if sibling is not None else (None, None, 0, None, None)
@@ -802,13 +802,19 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
         raise ValueError('conv_xp: the main and the sibling weights are packed for different kernels')
     if planar and not xw:
         raise ValueError('conv_xp: the chunk-planar input layout belongs to the Winograd kernel')
+    if (y_gstride or (planar and prologue is not None)) and kind != 'xb':
+        raise ValueError('conv_xp: a strided output / a prologue over a chunk-planar input belong to the split-bf16 kernel')
     if _dev_ok(x5, y, bias, plane_bias, y2, pb2, x2, ipa, ipb):
         with _Timed(pk.key, (D, H, W, Cin), pk.cout + (16 if pk2 is not None else 0), G):
-            args = [_p(x5), _p(pk.wp), _p(bias), _p(plane_bias), _p(y), sp(stats_buf), G, D, H, W, Cin,
+            yp = ctypes.c_void_p(y.data_ptr() + 4 * int(y_off))     # y_off: floats into a chunk-planar buffer (with ldy / y_gstride)
+            args = [_p(x5), _p(pk.wp), _p(bias), _p(plane_bias), yp, sp(stats_buf), G, D, H, W, Cin,
                     ldy, int(y_coff), int(bool(relu)), _p(pk2.wp) if pk2 is not None else null, _p(pb2), _p(y2),
                     sp(sbuf2), int(y2.shape[-1]) if y2 is not None else 0, int(y_coff2), _p(x2), _p(ipa), _p(ipb),
                     int(bool(relu_a)), int(bool(relu_b))]
-            if xw:
+            if kind == 'xb':
+                _call('atvs_conv_xb_f32', *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0),
+                                                    ctypes.c_long(int(y_gstride)), _stream()]))
+            elif xw:
                 _call('atvs_conv_%s_f32' % kind, *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0), _stream()]))
             else:
                 _call('atvs_conv_xp_f32', *(args + [_stream()]))
@@ -1407,13 +1413,58 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
                 groups=B)
 
 
-def refine_stems(photo_raw, geo_var, geo_plane_bias, prob, hull, key, w_geo, w_prob, w_hull):
+_USE_PLANAR_CONCAT = os.environ.get('ATVS_PLANAR_CONCAT', '1') != '0'
+
+
+def use_planar_concat(flag):
+    """Testing / A-B hook: the refinement's 32-channel concat as four dense 8-channel planes (chunk-planar) instead of
+    channel-last rows -- what its consumer, the x-pair launch of global_refine_3dconv0_1 | 1_0, stages per chunk."""
+    global _USE_PLANAR_CONCAT
+    _USE_PLANAR_CONCAT = bool(flag)
+
+
+def planar_concat_ok(shape):
+    """(D,h,w): should CostVolRefineNet's concat be chunk-planar?  Only when both its producer (the photo stem) and its
+    consumer run on the split-bf16 x-pair kernel, which writes / reads planes."""
+    D, h, w = (int(v) for v in shape)
+    return (_USE_PLANAR_CONCAT and _USE_PLANAR and _xkind() == 'xb' and _USE_PROLOGUE and _FORCE_IMPL is None
+            and siblings_ok((D, h, w), 32, 8, 16) and 4.0 * 4 * planar_stride(D, h, w) < 2.0 ** 40)
+
+
+def conv_split_into_plane(sv, key, w_host, buf, plane, planar):
+    """conv_split (8 output channels) written into plane `plane` of the chunk-planar buffer buf (B, K, planar_stride):
+    the photo stem of CostVolRefineNet as the producer of plane 0 of the concat.  -> Stats."""
+    D, H, W = planar
+    B, K, pstride = buf.shape
+    if sv.planar or sv.shape[0] != B or tuple(sv.shape[1:4]) != (D, H, W) or pstride != planar_stride(D, H, W) \
+            or not buf.is_contiguous() or int(w_host.shape[-1]) != 8 or sv.cv % 8:
+        raise ValueError('conv_split_into_plane: shapes')
+    cv, cc = sv.cv, sv.const.shape[-1]
+    wv, planes = _fold_split_weights(key, w_host, sv.chan_map, cv, cc)
+    pb = conv(sv.const, (key, 'planes'), planes, stride=1, groups=B)                   # (B, h, w, 24)
+    pk = pack_conv_xp((key, 'var'), wv, buf.device)
+    if pk.kind != 'xb':
+        raise ValueError('conv_split_into_plane: the split-bf16 x-pair kernel only')
+    blocks = xp_blocks(D, H, W, B)
+    sbuf = _stats_buffer(buf, blocks, 16, groups=B)
+    st = Stats()
+    st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 16, D * H * W, B
+    conv_xp_launch(sv.var, pk, buf, 0, None, False, sbuf, pb, ldy=8, y_gstride=K * pstride, y_off=int(plane) * pstride)
+    return st
+
+
+def refine_stems(photo_raw, geo_var, geo_plane_bias, prob, hull, key, w_geo, w_prob, w_hull, planar_out=None):
     """The geo | prob | vishull stems of CostVolRefineNet in one pass, stored with the raw photo-stem output as whole
     rows of the 32-channel concat buffer (atvs_refine_stems_f32).  photo_raw (B,D,h,w,8), geo_var (B,D,h,w,2),
     geo_plane_bias (B,h,w,24), prob / hull (B,D,h,w,1); w_*: TF kernels [3,3,3,Cin,8] (numpy, D-varying channels only).
-    -> (buffer (B,D,h,w,32) raw, Stats over the 24 computed channels)."""
+    -> (buffer (B,D,h,w,32) raw, Stats over the 24 computed channels).
+    planar_out = chunk-planar buffer (B, 4, planar_stride(D,h,w)) whose plane 0 the photo stem has written itself
+    (conv_split_into_plane): planes 1..3 are written here, photo_raw is None, the buffer is returned."""
     import numpy as np
-    B, D, H, W, _ = photo_raw.shape
+    B, D, H, W, _ = geo_var.shape
+    if planar_out is not None and (tuple(planar_out.shape) != (B, 4, planar_stride(D, H, W)) or not planar_out.is_contiguous()):
+        raise ValueError('refine_stems: planar_out must be a contiguous (B, 4, planar_stride(D,h,w)) buffer')
+    photo_raw = geo_var if planar_out is not None else photo_raw      # (device / meta reference below)
     ck = ('stems', key, str(photo_raw.device))
     pk = _pack_cache.get(ck)
     if pk is None:
@@ -1429,15 +1480,16 @@ def refine_stems(photo_raw, geo_var, geo_plane_bias, prob, hull, key, w_geo, w_p
         pk.key, pk.tab, pk.cin, pk.cout = key, None, 4, 24
         pk.wp = None if photo_raw.is_meta else torch.from_numpy(packed).to(photo_raw.device)
         _pack_cache[ck] = pk
-    buf = _new(photo_raw, (B, D, H, W, 32))
+    buf = _new(photo_raw, (B, D, H, W, 32)) if planar_out is None else planar_out
     rows = int(_lib.lib().atvs_conv_stem_rows(D, H, W))
     st = Stats()
     st.partial = torch.empty((B, rows, 2, 24), dtype=torch.float64, device=photo_raw.device)
     st.blocks, st.cpad, st.count, st.groups = rows, 24, D * H * W, B
     if _dev_ok(photo_raw, geo_var, geo_plane_bias, prob, hull, buf):
         with _Timed(key, (D, H, W, 4), 24, B):
-            _call('atvs_refine_stems_f32', _p(photo_raw), _p(geo_var), _p(geo_plane_bias), _p(prob), _p(hull), _p(pk.wp),
-                  _p(buf), ctypes.c_void_p(st.partial.data_ptr()), B, D, H, W, _stream())
+            _call('atvs_refine_stems_f32', _p(photo_raw if planar_out is None else None), _p(geo_var), _p(geo_plane_bias),
+                  _p(prob), _p(hull), _p(pk.wp), _p(buf), ctypes.c_void_p(st.partial.data_ptr()), B, D, H, W,
+                  ctypes.c_long(planar_stride(D, H, W) if planar_out is not None else 0), _stream())
     return buf, st
 
 
@@ -1466,12 +1518,15 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
     if isinstance(x, LAZY):
         if not siblings_prologue_ok(x):
             raise ValueError('conv_siblings: this lazy input must be materialised first')
+        if isinstance(x, PendingBN) and x.planar and x._final is None:
+            planar = x.planar          # the refinement's concat: chunk-planar raw buffer, batch norm + ReLU pending
         x, prologue = x.prologue()
     if planar:             # x: (G, Cin/8, planar_stride(D,H,W)) chunk-planar buffer, planar = (D,H,W); not the direct fp32 kernel
         D, H, W = planar
-        if prologue is not None or _xkind() == 'xp' or groups is None or x.dim() != 3 or not x.is_contiguous() \
-                or x.shape[2] != planar_stride(D, H, W):
-            raise ValueError('conv_siblings(planar=(D,H,W)): a contiguous (G, Cin/8, planar_stride) buffer, no prologue')
+        if (prologue is not None and _xkind() != 'xb') or _xkind() == 'xp' or groups is None or x.dim() != 3 \
+                or not x.is_contiguous() or x.shape[2] != planar_stride(D, H, W):
+            raise ValueError('conv_siblings(planar=(D,H,W)): a contiguous (G, Cin/8, planar_stride) buffer (a prologue only '
+                             'on the split-bf16 kernel)')
         G, K = x.shape[:2]
         x5, nsp, cin = x, 3, K * 8
     else:
@@ -1735,17 +1790,22 @@ class PendingBN(object):
     normalises on the fly (ops.bn_add).  Any other consumer calls materialize().  raw is batch-first
     (B, ..., C); params (3,C), or (B,3,C) for B independent samples."""
 
-    def __init__(self, raw, params, relu):
+    def __init__(self, raw, params, relu, planar=None):
+        # planar=(D,h,w): raw is a chunk-planar (B, C/8, planar_stride(D,h,w)) buffer (the refinement's concat); its one
+        # consumer that reads planes is conv_siblings, everything else gets the channel-last tensor from materialize()
         self.raw, self.params, self.relu = raw, params, bool(relu)
+        self.planar = tuple(int(v) for v in planar) if planar else None
         self._final = None
         self.device = raw.device
 
     @property
     def shape(self):
+        if self.planar:
+            return (self.raw.shape[0],) + self.planar + (self.raw.shape[1] * 8,)
         return tuple(self.raw.shape)
 
     def dim(self):
-        return self.raw.dim()
+        return 5 if self.planar else self.raw.dim()
 
     @property
     def is_meta(self):
@@ -1754,7 +1814,12 @@ class PendingBN(object):
     def materialize(self):
         """The normalised tensor (computed once, in place on the raw buffer)."""
         if self._final is None:
-            self._final = bn_apply(self.raw, self.params, self.relu)
+            raw = self.raw
+            if self.planar:
+                B, K = raw.shape[:2]
+                D, h, w = self.planar
+                raw = planar_view(raw, D, h, w).permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, K * 8).contiguous()
+            self._final = bn_apply(raw, self.params, self.relu)
         return self._final
 
     def prologue(self):

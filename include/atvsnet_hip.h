@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 25
+#define ATVS_ABI_VERSION 26
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -292,7 +292,9 @@ int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, c
  * (conv_xb.hip): every fp32 operand = three bf16 pieces, the six products x_i * w_j with i + j <= 2 accumulated in fp32 by
  * v_mfma_f32_16x16x32_bf16 (the arithmetic of atvs_conv_c16b_f32) -- fp32-class results, 9 K steps of 16-cycle instructions
  * per (8-channel chunk, kd, kh) row instead of 36 fp32 steps of 32 cycles.  Weights: atvs_conv_xb_pack / _pack_sibling
- * (HOST; sizes in BYTES). */
+ * (HOST; sizes in BYTES).  Beyond atvs_conv_xw_f32: x_planar may come with in_params (a pending batch norm over a
+ * chunk-planar input: the refinement's concat; not with x2); y_group_stride != 0 = floats between the samples of y
+ * (>= D*H*W*ldy; 0 = dense): with ldy = 8 the output lands in one 8-channel plane of each sample's chunk-planar buffer. */
 int atvs_conv_xb_pack_size(int Cin, long* packed_bytes);
 int atvs_conv_xb_pack(const float* w, int Cin, unsigned char* packed);
 int atvs_conv_xb_pack_sibling_size(int Cin, long* packed_bytes);
@@ -301,7 +303,7 @@ int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, const float*
                      double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const unsigned char* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
-                     int in_relu2, long x_planar, atvs_stream_t stream);
+                     int in_relu2, long x_planar, long y_group_stride, atvs_stream_t stream);
 
 /* 3x3 stride-1 SAME 2-D convolution (dilation 1, 2 or 4) of wide feature maps, LDS-tiled (conv2d_lds.hip): the
  * heavy layers of the feature towers -- the bottlenecks' conv2 (slim.conv2d, network.py:585-587), conv0_1 / conv0_2 /
@@ -415,11 +417,15 @@ int atvs_conv_stem_f32(const float* x, const float* w, const float* plane_bias, 
  * partial-line HBM writes): y (groups,D,H,W,32) = [photo_raw (..,8) | conv(geo (..,2)) + geo_plane_bias (groups,H,W,24) |
  * conv(prob (..,1)) | conv(hull (..,1))], no activation.  atvs_refine_stems_pack (HOST) arranges the three TF kernels
  * [3,3,3,Cin,8] as [27][geo0, geo1, prob, hull][8] (upload the 864 floats).  stats_partial: groups * atvs_conv_stem_rows
- * rows of [2][24] doubles over the 24 computed channels, or NULL. */
+ * rows of [2][24] doubles over the 24 computed channels, or NULL.
+ * y_planar != 0: y is chunk-planar instead, (groups, 4, y_planar) floats with planes of [D][H][W][8] (the layout
+ * atvs_conv_xb_f32 reads with x_planar): planes 1..3 = geo | prob | hull are written, plane 0 is the photo stem's own
+ * output (atvs_conv_xb_f32 with ldy = 8 and y_group_stride = 4 * y_planar) and photo_raw is not read (may be NULL):
+ * 16 B read + 96 B written per voxel instead of 48 + 128. */
 int atvs_refine_stems_pack(const float* w_geo, const float* w_prob, const float* w_hull, float* packed);
 int atvs_refine_stems_f32(const float* photo_raw, const float* geo, const float* geo_plane_bias, const float* prob,
                           const float* hull, const float* w, float* y, double* stats_partial, int groups, int D, int H,
-                          int W, atvs_stream_t stream);
+                          int W, long y_planar, atvs_stream_t stream);
 
 /* conv(3, 1, 1, relu=False) on an 8-channel volume: the probability heads conv_b2_6_2,
  * attention_prob_vol[_refine], global_refined_cost_vol (cnn_wrapper/atvsnet.py:192,213,220,226,
