@@ -375,3 +375,98 @@ def test_conv_c16_against_torch_and_the_tiled_kernel(cuda, G, shape, cin, cout):
     assert torch.equal(buf[..., 16:], torch.clamp(got + b.to(cuda), min=0)) or \
         float((buf[..., 16:] - torch.clamp(got + b.to(cuda), min=0)).abs().max()) <= 1e-6
     assert torch.all(buf[..., :16] == -7.0)
+
+
+@pytest.mark.parametrize('shape,G,bias', [((9, 13, 35), 3, True), ((21, 50, 70), 5, True), ((4, 8, 32), 1, False),
+                                          ((2, 3, 5), 2, True)])
+def test_refine_stems_planar_is_bitwise_the_channel_last_form(cuda, shape, G, bias):
+    """refine_stems_kernel<PLANAR>: planes 1..3 of the chunk-planar concat = channels 8..31 of the channel-last rows, bit for
+    bit, with the same statistics; plane 0 (the photo stem's) and the padding between the planes are not touched."""
+    from atvsnet_amd import ops
+    D, H, W = shape
+    photo = _rand((G, D, H, W, 8), 41).to(cuda)
+    geo, prob, hull = (_rand((G, D, H, W, c), 42 + i).to(cuda) for i, c in enumerate((2, 1, 1)))
+    pb = _rand((G, H, W, 24), 45).to(cuda) if bias else None
+    wg, wp, wh = _rand((3, 3, 3, 2, 8), 46) * 0.3, _rand((3, 3, 3, 1, 8), 47) * 0.3, _rand((3, 3, 3, 1, 8), 48) * 0.3
+    key = ('stems-planar-test', shape, G, bias)
+    cl, st = ops.refine_stems(photo, geo, pb, prob, hull, key, wg.numpy(), wp.numpy(), wh.numpy())
+    ps = ops.planar_stride(D, H, W)
+    buf = torch.full((G, 4, ps), 7.25, device=cuda)
+    out, st2 = ops.refine_stems(None, geo, pb, prob, hull, key, wg.numpy(), wp.numpy(), wh.numpy(), planar_out=buf)
+    assert out is buf
+    planes = ops.planar_view(buf, D, H, W)                       # (G,4,D,H,W,8)
+    for c in range(3):
+        assert torch.equal(planes[:, 1 + c], cl[..., 8 + 8 * c:16 + 8 * c])
+    assert bool((planes[:, 0] == 7.25).all()) and bool((buf[..., D * H * W * 8:] == 7.25).all())
+    assert torch.equal(st.partial, st2.partial)
+
+
+@pytest.mark.parametrize('shape,G', [((8, 16, 40), 2), ((6, 9, 33), 1), ((5, 24, 70), 3)])
+def test_photo_stem_into_plane_and_planar_concat_consumer_are_bitwise(cuda, shape, G):
+    """The photo stem written straight into plane 0 of the chunk-planar concat (atvs_conv_xb_f32 with y_group_stride) equals
+    conv_split's dense output, and the x-pair launch that normalises the concat on load gives the same bits from the four
+    planes as from the channel-last rows (reference cnn_wrapper/atvsnet.py:300-316)."""
+    from atvsnet_amd import ops
+    if ops._xkind() != 'xb':
+        pytest.skip('the planar concat belongs to the split-bf16 x-pair kernel')
+    D, H, W = shape
+    chan = 16
+    photo = ops.SplitVolume(_rand((G, D, H, W, chan), 20).to(cuda), _rand((G, H, W, 2 * chan), 21).to(cuda),
+                            [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
+    w = (_rand((3, 3, 3, 3 * chan, 8), 22) * 0.1).numpy()
+    y, st = ops.conv_split(photo, 'photo-plane-test', w, want_stats=True)
+    ps = ops.planar_stride(D, H, W)
+    buf = torch.full((G, 4, ps), -3.5, device=cuda)
+    st2 = ops.conv_split_into_plane(photo, 'photo-plane-test', w, buf, 0, (D, H, W))
+    planes = ops.planar_view(buf, D, H, W)
+    assert torch.equal(planes[:, 0], y.reshape(G, D, H, W, 8))
+    assert bool((planes[:, 1:] == -3.5).all()) and torch.equal(st.partial, st2.partial)
+    # the consumer: 32-channel concat, pending batch norm + ReLU, from planes and from rows
+    rest = _rand((G, D, H, W, 24), 23).to(cuda)
+    for c in range(3):
+        planes[:, 1 + c] = rest[..., 8 * c:8 * c + 8]
+    rows = torch.cat([y.reshape(G, D, H, W, 8), rest], -1).contiguous()
+    params = torch.stack([_rand((G, 32), 8) * 0.3, _rand((G, 32), 9).abs() + 0.5, _rand((G, 32), 10) + 0.7], 1).to(cuda)
+    params = params.contiguous() if G > 1 else params[0].contiguous()
+    w8, w16 = (_rand((3, 3, 3, 32, 8), 5) * 0.1).numpy(), (_rand((3, 3, 3, 32, 16), 6) * 0.1).numpy()
+    lazy_p = ops.PendingBN(buf, params, True, planar=(D, H, W))
+    assert lazy_p.shape == (G, D, H, W, 32) and lazy_p.dim() == 5
+    if not ops.siblings_ok((D, H, W), 32, 8, 16):
+        assert torch.equal(lazy_p.materialize(), ops.bn_apply(rows.clone(), params, True))
+        return
+    (a, sa), (a2, sa2) = ops.conv_siblings(lazy_p, 'pc8', w8, 'pc16', w16, groups=G)
+    assert lazy_p._final is None
+    (b, sb), (b2, sb2) = ops.conv_siblings(ops.PendingBN(rows.clone(), params, True), 'pc8', w8, 'pc16', w16, groups=G)
+    assert torch.equal(a, b) and torch.equal(a2, b2)
+    assert torch.equal(sa.partial, sb.partial) and torch.equal(sa2.partial, sb2.partial)
+    assert torch.equal(lazy_p.materialize(), ops.bn_apply(rows.clone(), params, True))     # any other consumer: rows
+
+
+def test_refinement_net_planar_concat_equals_channel_last_concat(cuda, weights):
+    """CostVolRefineNet with its concat as four dense planes (default) against the channel-last concat
+    (ops.use_planar_concat(False)): every output bit for bit, and the planar form really ran."""
+    from atvsnet_amd import ops
+    from atvsnet_amd.cnn_wrapper.atvsnet import CostVolRefineNet
+    if ops._xkind() != 'xb':
+        pytest.skip('the planar concat belongs to the split-bf16 x-pair kernel')
+    G, chan, shape = 2, 16, (16, 32, 48)
+    photo = ops.SplitVolume(_rand((G,) + shape + (chan,), 20).to(cuda), _rand((G, 32, 48, 2 * chan), 21).to(cuda),
+                            [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
+    geo = ops.SplitVolume(_rand((G,) + shape + (2,), 30).to(cuda), _rand((G, 32, 48, 2), 31).to(cuda),
+                          [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
+    prob, hull = _rand((G,) + shape + (1,), 40).to(cuda), _rand((G,) + shape + (1,), 41).to(cuda)
+    res = {}
+    for flag in (True, False):
+        ops.use_planar_concat(flag)
+        try:
+            ref = CostVolRefineNet({'photo_group': photo, 'geo_group': geo, 'prob_vol': prob, 'vis_hull': hull},
+                                   is_training=True, independent_samples=True)
+            concat = ref.layers['global_refine_concat']
+            assert isinstance(concat, ops.PendingBN) and bool(concat.planar) == flag
+            res[flag] = [ref.get_output().clone(), ref.get_output_by_name('global_refine_3dconv6_1').clone(),
+                         ref.get_output_by_name('global_refine_photo_3dconv').clone(),
+                         ref.get_output_by_name('global_refine_concat').clone()]
+        finally:
+            ops.use_planar_concat(True)
+    for a, b in zip(res[True], res[False]):
+        assert torch.equal(a, b)

@@ -8,6 +8,9 @@ in fp32 (a product of two bf16 values is exact in fp32) and summed.
     1 product : x0*w0                                   (plain bf16)
     3 products: x0*w0 + x0*w1 + x1*w0                   (error ~2^-16 per product)
     6 products: all xi*wj with i + j <= 2               (error ~2^-24 per product: fp32-class; 6/16 of the fp32 MFMA time)
+   16         : fp16 pieces, x = h0 + h1 / 2048 with h0 = f16(x), h1 = f16((x - h0) * 2048) (the residual scaled into the
+                normal range), w likewise; THREE products: h0*g0 + (h0*g1 + h1*g0) / 2048 (error ~2^-22 per product; the
+                cross terms accumulate apart and are scaled once)
 """
 import os
 import sys
@@ -41,8 +44,19 @@ def pairs(n):
     return {1: [(0, 0)], 3: [(0, 0), (0, 1), (1, 0)], 6: [(0, 0), (0, 1), (1, 0), (0, 2), (1, 1), (2, 0)]}[n]
 
 
+def f16_pieces(t):
+    h0 = t.to(torch.float16).to(torch.float32)
+    h1 = ((t - h0) * 2048.0).to(torch.float16).to(torch.float32)
+    return h0, h1
+
+
 def conv(x, w, stride=1, padding='SAME', dilation=1, bias=None, explicit_pad=None):
     n = FORM['n']
+    if n == 16:
+        (h0, h1), (g0, g1) = f16_pieces(x), f16_pieces(w)
+        cross = _plain(h0, g1, stride, padding, dilation, None, explicit_pad) + _plain(h1, g0, stride, padding, dilation, None, explicit_pad)
+        y = _plain(h0, g0, stride, padding, dilation, None, explicit_pad) + cross * (1.0 / 2048.0)
+        return y + bias if bias is not None else y
     k = {1: 1, 3: 2, 6: 3}[n]
     xs, ws = pieces(x, k), pieces(w, k)
     y = None
@@ -54,6 +68,9 @@ def conv(x, w, stride=1, padding='SAME', dilation=1, bias=None, explicit_pad=Non
 
 def conv_t(x, w, stride=2):
     n = FORM['n']
+    if n == 16:
+        (h0, h1), (g0, g1) = f16_pieces(x), f16_pieces(w)
+        return _plain_t(h0, g0, stride) + (_plain_t(h0, g1, stride) + _plain_t(h1, g0, stride)) * (1.0 / 2048.0)
     k = {1: 1, 3: 2, 6: 3}[n]
     xs, ws = pieces(x, k), pieces(w, k)
     y = None
