@@ -1,20 +1,27 @@
-// 3x3x3 SAME stride-1 convolution to EIGHT output channels in x-pair form on the bf16 matrix cores with SPLIT operands, one
+// 3x3x3 SAME stride-1 convolution to EIGHT output channels in x-pair form on the 16-bit matrix cores with SPLIT operands, one
 // wavefront per SIMD (gfx950): conv_xp.hip's layers (conv_b*_0_1, global_refine_3dconv0_1, the photo stem; stride-2 sibling
 // conv_b*_1_0 / 3dconv1_0 from the same staged image; /root/reference/cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet,
-// layer code network.py:165-215) with every fp32 operand split into three bf16 pieces (conv_c16b.hip has the arithmetic:
-// x = x0 + x1 + x2, the six products x_i * w_j with i + j <= 2, fp32 accumulation on v_mfma_f32_16x16x32_bf16 -- fp32-class
-// results for 6/16 of the fp32 matrix-core time).
+// layer code network.py:165-215).
+//
+// Arithmetic (round 4): every fp32 operand is split into TWO fp16 pieces, x = h0 + h1 / 2048 with h0 = f16(x) and
+// h1 = f16((x - h0) * 2048) (the residual scaled into fp16's normal range: 22 significant bits, no denormal loss), w = g0 + g1 /
+// 2048 likewise (split by the host packer); THREE products on v_mfma_f32_16x16x32_f16 with fp32 accumulation: h0 g0 into the
+// main accumulator, h0 g1 + h1 g0 into a second one that is scaled by 2^-11 once in the epilogue (the dropped h1 g1 is 2^-22 of
+// a product).  Measured on MI355X (tools_dev/micro/f16_split_probe.hip): error of a 864-term dot product against a double sum
+// 2.8e-7 of the output maximum, against 6.3e-7 for the fp32 matrix cores and 8.0e-7 for the round-3 form (three bf16 pieces, six
+// products): fewer accumulation steps.  fp16 DENORMAL inputs are honoured by the instruction (same probe).  Range: |x| or |w| >
+// 65504 becomes infinity and the output NaN (loud, not silent): the layers' inputs are batch-normalised activations / features,
+// |x| <= sqrt(voxels) + |beta|; the packer refuses such weights.
 //
 // One K = 32 instruction covers the FOUR x offsets a voxel pair touches x 8 channels: lane group q = x offset xl, so a
 // (kd, kh) tap row of an 8-channel chunk is ONE K step (36 fp32 16x16x4 steps of conv_xp become 9), rows = (x parity,
-// channel) as in conv_xp (3/4 of the MFMA work useful).  Per 8-channel chunk and 8 rows: 9 steps x 6 products x 8 = 432
-// instructions of 16 cycles against conv_xw's 384 of 32 (Winograd does not combine with split pieces: the transform of a
-// piece is not a bf16 number).
+// channel) as in conv_xp (3/4 of the MFMA work useful).  Per 8-channel chunk and 8 rows: 9 steps x 3 products x 8 = 216
+// instructions of 16 cycles (round 3: 432; conv_xw: 384 of 32 cycles).
 //
-// Structure: tile 4(z) x 8(y) x 32(x), wavefront w owns plane z0 + w (8 accumulator tiles); the input is staged in 8-channel
-// chunks as THREE piece images [6][10][even / odd x interleaved in runs of eight][8 bf16] (46 KB each, single-buffered: the next
+// Structure: tile 4(z) x 8(y) x 32(x), wavefront w owns plane z0 + w (8 + 8 accumulator tiles); the input is staged in 8-channel
+// chunks as TWO piece images [6][10][even / odd x interleaved in runs of eight][8 fp16] (46 KB each, single-buffered: the next
 // stage's halo waits in registers as in conv_xp, two barriers per stage); the split happens once per staged element, after
-// the optional prologue (batch norm + ReLU of the producers, skip add).  Weights (three pieces per step, split on the host)
+// the optional prologue (batch norm + ReLU of the producers, skip add).  Weights (two pieces per step, split on the host)
 // stream from L2 two steps ahead.  Sibling: K step i = taps 4 i + q of the 27 (7 steps), 2 rows per wavefront.
 #include <cstring>
 #include <type_traits>
@@ -43,16 +50,18 @@ constexpr int XB_MAXS = (XB_SLOTS + 255) / 256;             // 16 per thread
 constexpr int XB_JC = 9;                                    // main K steps per chunk: (kd, kh)
 constexpr int XB_J2 = 7;                                    // sibling K steps per chunk: taps 4 i + q
 constexpr int XB_LOOK = 2;                                  // weight look-ahead in K steps
-static_assert(XB_MAXS <= 3 * XB_JC, "one halo slot per phase of the main K loop");
-static_assert(2 * XB_IMG + (2 * XB_HY + 2 + XB_TY) * XB_ROWB < 3 * XB_IMG, "fragment reads stay inside the images");
+constexpr int XB_NP = 2;                                    // operand pieces
+constexpr float XB_RS = 2048.f, XB_IRS = 1.f / 2048.f;      // scale of the residual piece and its inverse (exact powers of two)
+static_assert(XB_MAXS <= XB_NP * XB_JC, "one halo slot per phase of the main K loop");
+static_assert((XB_NP - 1) * XB_IMG + (2 * XB_HY + 2 + XB_TY) * XB_ROWB < XB_NP * XB_IMG, "fragment reads stay inside the images");
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct XbArgs {
   const float* x;
-  const bf16x8* wp;      // packed weight pieces, see atvs_conv_xb_pack
+  const f16x8* wp;       // packed weight pieces, see atvs_conv_xb_pack
   const float* zeros;    // 16 bytes of zeros (tail of the packed weights)
   const float* bias;
   const float* pbias;    // (H, W, 24) or nullptr
@@ -63,7 +72,7 @@ struct XbArgs {
   int nchunk;
   int tiles_y, tiles_x, ntiles;
   int relu;
-  const bf16x8* wp2;     // packed sibling weight pieces (atvs_conv_xb_pack_sibling) or nullptr
+  const f16x8* wp2;      // packed sibling weight pieces (atvs_conv_xb_pack_sibling) or nullptr
   const float* pbias2;   // (Ho2, Wo2, 48) or nullptr
   float* y2;
   double* stats2;
@@ -87,18 +96,14 @@ struct XbArgs {
 // (PMC: half of the LDS cycles).
 __device__ __forceinline__ constexpr int xb_col(int par, int i) { return (i >> 3) * 256 + par * 128 + (i & 7) * 16; }
 
-// the three bf16 pieces of four fp32 values
-__device__ __forceinline__ void xb_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+// the two fp16 pieces of four fp32 values: h0 = f16(x), h1 = f16((x - h0) * 2^11)  (x - h0 is exact in fp32)
+__device__ __forceinline__ void xb_split(const float4& v, f16x4* p0, f16x4* p1) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
+    const _Float16 a = (_Float16)x[i];
     (*p0)[i] = a;
-    (*p1)[i] = b;
-    (*p2)[i] = (__bf16)r2;
+    (*p1)[i] = (_Float16)((x[i] - (float)a) * XB_RS);
   }
 }
 
@@ -116,9 +121,9 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
 
   // this lane's fragment (the 8 channels of one voxel of a piece image) of halo row 0 of the wavefront's plane at its x
   // offset xl = q; piece images XB_IMG apart (one base each: the displacements exceed the 16-bit immediate otherwise)
-  int fb[3];
+  int fb[XB_NP];
 #pragma unroll
-  for (int pc = 0; pc < 3; ++pc) fb[pc] = pc * XB_IMG + (wave * XB_HY) * XB_ROWB + xb_col(q & 1, (q >> 1) + r);
+  for (int pc = 0; pc < XB_NP; ++pc) fb[pc] = pc * XB_IMG + (wave * XB_HY) * XB_ROWB + xb_col(q & 1, (q >> 1) + r);
   // sibling: this lane's tap of step i is 4 i + q (taps past 26: zero weights, tap 26's fragment); per-step byte offsets
   int sd[SIB ? XB_J2 : 1];
   if (SIB) {
@@ -256,8 +261,8 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
   float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
   if (p.bias) bv = ld4(p.bias + (q & 1) * 4);
-  f32x4 acc[XB_TY];
-  f32x4 acc2[2];
+  f32x4 acc[XB_TY], accx[XB_TY];       // h0 g0 | (h0 g1 + h1 g0) * 2^11
+  f32x4 acc2[2], acc2x[2];
   float ssum2[4] = {0.f, 0.f, 0.f, 0.f}, ssq2[4] = {0.f, 0.f, 0.f, 0.f};
 
   if (nstage > 0) {
@@ -275,17 +280,17 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     XDBG(0)
     if (ch == 0) {
 #pragma unroll
-      for (int t = 0; t < XB_TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      acc2[0] = acc2[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int t = 0; t < XB_TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      acc2[0] = acc2[1] = acc2x[0] = acc2x[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // weight pieces of this chunk: [step][piece][lane]; those of the first steps are on their way while the images are written
-    const bf16x8* wch = p.wp + ((size_t)ch * JC * 3) * 64 + lane;
-    const bf16x8* wch2 = p.wp2 + ((size_t)ch * J2 * 3) * 64 + lane;
-    bf16x8 A[JC][3], A2[SIB ? XB_J2 : 1][3];
+    const f16x8* wch = p.wp + ((size_t)ch * JC * XB_NP) * 64 + lane;
+    const f16x8* wch2 = p.wp2 + ((size_t)ch * J2 * XB_NP) * 64 + lane;
+    f16x8 A[JC][XB_NP], A2[SIB ? XB_J2 : 1][XB_NP];
 #pragma unroll
     for (int s = 0; s < XB_LOOK; ++s)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) A[s][pc] = wch[(s * 3 + pc) * 64];
+      for (int pc = 0; pc < XB_NP; ++pc) A[s][pc] = wch[(s * XB_NP + pc) * 64];
 
     __syncthreads();                       // every wavefront is done reading the previous stage's images
     XDBG(5)
@@ -297,11 +302,10 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || last_live) {
-        bf16x4 p0, p1, p2;
-        xb_split(pf[i], &p0, &p1, &p2);
-        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
-        *reinterpret_cast<bf16x4*>(smem + XB_IMG + laddr[i]) = p1;
-        *reinterpret_cast<bf16x4*>(smem + 2 * XB_IMG + laddr[i]) = p2;
+        f16x4 p0, p1;
+        xb_split(pf[i], &p0, &p1);
+        *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<f16x4*>(smem + XB_IMG + laddr[i]) = p1;
       }
     XDBG(1)
     __syncthreads();
@@ -324,53 +328,55 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     const size_t erow2 = (size_t)p.Wo2 * p.ldy2;
     const size_t eo2 = (((size_t)zo2 * p.Ho2 + yo2) * p.Wo2 + xo2) * (size_t)p.ldy2 + p.ycoff2 + 4 * q;
 
-    // ---- main K loop: 9 steps (kd, kh) x 3 phases (input piece pc with the weight pieces jw <= 2 - pc: 24 / 16 / 8 MFMAs);
+    // ---- main K loop: 9 steps (kd, kh) x 2 phases (input piece h0 with both weight pieces: 16 MFMAs; h1 with g0: 8);
     // the fragments of ONE input piece are live at a time, requested one phase ahead
-    bf16x8 Bq[2][XB_TY], B2[2][3][2];
+    f16x8 Bq[2][XB_TY], B2[2][XB_NP][2];
     auto request_B = [&](int ph) __attribute__((always_inline)) {
-      const int s = ph / 3, pc = ph % 3;
+      const int s = ph / XB_NP, pc = ph % XB_NP;
       const int off = ((s / 3) * XB_HY + (s % 3)) * ROWB;
 #pragma unroll
-      for (int t = 0; t < XB_TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + fb[pc] + (off + t * ROWB));
+      for (int t = 0; t < XB_TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + fb[pc] + (off + t * ROWB));
     };
-    auto request_B2 = [&](int i) __attribute__((always_inline)) {         // the three pieces of sibling step i (12 MFMAs)
+    auto request_B2 = [&](int i) __attribute__((always_inline)) {         // the two pieces of sibling step i (6 MFMAs)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
+      for (int pc = 0; pc < XB_NP; ++pc)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
-          B2[i & 1][pc][t] = *reinterpret_cast<const bf16x8*>(smem + pc * XB_IMG + sd[i] + 2 * t * ROWB);
+          B2[i & 1][pc][t] = *reinterpret_cast<const f16x8*>(smem + pc * XB_IMG + sd[i] + 2 * t * ROWB);
     };
     request_B(0);
     asm volatile("" ::: "memory");
     XDBG(0)
 #pragma unroll
-    for (int ph = 0; ph < 3 * JC; ++ph) {
-      const int s = ph / 3, pc = ph % 3;
+    for (int ph = 0; ph < XB_NP * JC; ++ph) {
+      const int s = ph / XB_NP, pc = ph % XB_NP;
       if (pc == 0) {
         if (s + XB_LOOK < JC) {
 #pragma unroll
-          for (int w3 = 0; w3 < 3; ++w3) A[s + XB_LOOK][w3] = wch[((s + XB_LOOK) * 3 + w3) * 64];
+          for (int w3 = 0; w3 < XB_NP; ++w3) A[s + XB_LOOK][w3] = wch[((s + XB_LOOK) * XB_NP + w3) * 64];
         } else if (SIB) {
 #pragma unroll
-          for (int w3 = 0; w3 < 3; ++w3) A2[s + XB_LOOK - JC][w3] = wch2[((s + XB_LOOK - JC) * 3 + w3) * 64];
+          for (int w3 = 0; w3 < XB_NP; ++w3) A2[s + XB_LOOK - JC][w3] = wch2[((s + XB_LOOK - JC) * XB_NP + w3) * 64];
         }
       }
-      if (ph + 1 < 3 * JC) request_B(ph + 1);
+      if (ph + 1 < XB_NP * JC) request_B(ph + 1);
       else if (SIB) request_B2(0);
       if (ph < MAXS) pf_slot(T, ph);
-      if (!SIB && ph == 3 * JC - 6) {
+      if (!SIB && ph == XB_NP * JC - 4) {
         const bool use = last_chunk && pbg;
 #pragma unroll
         for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((use && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
       }
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      if (pc == 0) {
 #pragma unroll
-      for (int jw = 0; jw < 3; ++jw) {
-        if (jw > 2 - pc) continue;
+        for (int t = 0; t < XB_TY; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], Bq[ph & 1][t], acc[t], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < XB_TY; ++t)
-          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[s][jw], Bq[ph & 1][t], acc[t], 0, 0, 0);
+        for (int t = 0; t < XB_TY; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][1], Bq[ph & 1][t], accx[t], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int t = 0; t < XB_TY; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], Bq[ph & 1][t], accx[t], 0, 0, 0);
       }
     }
     XDBG(2)
@@ -380,7 +386,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
       for (int i = 0; i < J2; ++i) {
         if (i + XB_LOOK < J2) {
 #pragma unroll
-          for (int w3 = 0; w3 < 3; ++w3) A2[i + XB_LOOK][w3] = wch2[((i + XB_LOOK) * 3 + w3) * 64];
+          for (int w3 = 0; w3 < XB_NP; ++w3) A2[i + XB_LOOK][w3] = wch2[((i + XB_LOOK) * XB_NP + w3) * 64];
         }
         if (i + 1 < J2) request_B2(i + 1);
         if (i == J2 - 3) {            // the epilogues' depth-plane biases, behind the last weight request of the stage
@@ -395,14 +401,11 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
+        for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i][0], B2[i & 1][0][t], acc2[t], 0, 0, 0);
 #pragma unroll
-          for (int jw = 0; jw < 3; ++jw) {
-            if (jw > 2 - pc) continue;
+        for (int t = 0; t < 2; ++t) acc2x[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i][1], B2[i & 1][0][t], acc2x[t], 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-              acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2[i][jw], B2[i & 1][pc][t], acc2[t], 0, 0, 0);
-          }
+        for (int t = 0; t < 2; ++t) acc2x[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i][0], B2[i & 1][1][t], acc2x[t], 0, 0, 0);
       }
     }
     XDBG(3)
@@ -414,10 +417,10 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
       for (int t = 0; t < XB_TY; ++t) {
         if (!erow_ok(t)) continue;
         float4 v;
-        v.x = (acc[t][0] + bv.x) + epb[t].x;
-        v.y = (acc[t][1] + bv.y) + epb[t].y;
-        v.z = (acc[t][2] + bv.z) + epb[t].z;
-        v.w = (acc[t][3] + bv.w) + epb[t].w;
+        v.x = ((acc[t][0] + accx[t][0] * XB_IRS) + bv.x) + epb[t].x;
+        v.y = ((acc[t][1] + accx[t][1] * XB_IRS) + bv.y) + epb[t].y;
+        v.z = ((acc[t][2] + accx[t][2] * XB_IRS) + bv.z) + epb[t].z;
+        v.w = ((acc[t][3] + accx[t][3] * XB_IRS) + bv.w) + epb[t].w;
         if (decltype(relu_tag)::value) {          // NaN passes through, as in tf.nn.relu
           v.x = (v.x < 0.f) ? 0.f : v.x;
           v.y = (v.y < 0.f) ? 0.f : v.y;
@@ -435,7 +438,8 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (!erow2_ok(t)) continue;
-        const float4 v = make_float4(acc2[t][0] + epb2[t].x, acc2[t][1] + epb2[t].y, acc2[t][2] + epb2[t].z, acc2[t][3] + epb2[t].w);
+        const float4 v = make_float4((acc2[t][0] + acc2x[t][0] * XB_IRS) + epb2[t].x, (acc2[t][1] + acc2x[t][1] * XB_IRS) + epb2[t].y,
+                                     (acc2[t][2] + acc2x[t][2] * XB_IRS) + epb2[t].z, (acc2[t][3] + acc2x[t][3] * XB_IRS) + epb2[t].w);
         st4(y2g + (eo2 + (size_t)t * erow2), v);
         ssum2[0] += v.x; ssum2[1] += v.y; ssum2[2] += v.z; ssum2[3] += v.w;
         ssq2[0] += v.x * v.x; ssq2[1] += v.y * v.y; ssq2[2] += v.z * v.z; ssq2[3] += v.w * v.w;
@@ -512,7 +516,7 @@ long xb_ntiles(int D, int H, int W) {
 
 template <bool SIB, int PRO>
 int launch_xb(const XbArgs& a, long blocks, hipStream_t s) {
-  const size_t lds = 3 * (size_t)XB_IMG;
+  const size_t lds = XB_NP * (size_t)XB_IMG;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
@@ -526,25 +530,15 @@ int launch_xb(const XbArgs& a, long blocks, hipStream_t s) {
   return ATVS_OK;
 }
 
-// round-to-nearest-even bf16 of a finite float, as a float / its 16 bits
-float xb_round(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  float o;
-  std::memcpy(&o, &u, 4);
-  return o;
-}
-uint16_t xb_bits(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  return (uint16_t)(u >> 16);
-}
-void xb_put(uint16_t* out, size_t base, float v) {      // the three pieces of v at out[base + piece * 64 * 8]
-  const float p0 = xb_round(v), p1 = xb_round(v - p0), p2 = xb_round((v - p0) - p1);
-  out[base] = xb_bits(p0);
-  out[base + 64 * 8] = xb_bits(p1);
-  out[base + 2 * 64 * 8] = xb_bits(p2);
+// HOST: the two fp16 pieces of v (round to nearest even; the kernel's xb_split) at out[base + piece * 64 * 8]; false if v does
+// not fit fp16's range
+bool xb_put(uint16_t* out, size_t base, float v) {
+  const _Float16 h0 = (_Float16)v;
+  const _Float16 h1 = (_Float16)((v - (float)h0) * XB_RS);
+  std::memcpy(&out[base], &h0, 2);
+  std::memcpy(&out[base + 64 * 8], &h1, 2);
+  const float back = (float)h0;
+  return back - back == 0.f;                             // finite
 }
 
 }  // namespace
@@ -552,7 +546,7 @@ void xb_put(uint16_t* out, size_t base, float v) {      // the three pieces of v
 // Bytes of the packed form of a [3,3,3,Cin,8] kernel (Cin % 8 == 0) for atvs_conv_xb_f32, including 16 trailing zero bytes.
 extern "C" int atvs_conv_xb_pack_size(int Cin, long* packed_bytes) {
   if (Cin <= 0 || (Cin % 8) || !packed_bytes) return ATVS_ERR_SHAPE;
-  *packed_bytes = (long)(Cin / 8) * XB_JC * 3 * 1024 + 16;
+  *packed_bytes = (long)(Cin / 8) * XB_JC * XB_NP * 1024 + 16;
   return ATVS_OK;
 }
 
@@ -565,6 +559,7 @@ extern "C" int atvs_conv_xb_pack(const float* w, int Cin, unsigned char* packed)
   if (rc) return rc;
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
+  bool fits = true;
   for (int ch = 0; ch < Cin / 8; ++ch)
     for (int s = 0; s < XB_JC; ++s)
       for (int q = 0; q < 4; ++q)
@@ -573,15 +568,15 @@ extern "C" int atvs_conv_xb_pack(const float* w, int Cin, unsigned char* packed)
           if (kw < 0 || kw > 2) continue;
           for (int co = 0; co < 8; ++co)
             for (int e = 0; e < 8; ++e)
-              xb_put(out, ((((size_t)ch * XB_JC + s) * 3) * 64 + q * 16 + jx * 8 + co) * 8 + e,
-                     w[((((size_t)kd * 3 + kh) * 3 + kw) * Cin + ch * 8 + e) * 8 + co]);
+              fits &= xb_put(out, ((((size_t)ch * XB_JC + s) * XB_NP) * 64 + q * 16 + jx * 8 + co) * 8 + e,
+                             w[((((size_t)kd * 3 + kh) * 3 + kw) * Cin + ch * 8 + e) * 8 + co]);
         }
-  return ATVS_OK;
+  return fits ? ATVS_OK : ATVS_ERR_ARG;                  // a weight beyond fp16's range (|w| > 65504)
 }
 
 extern "C" int atvs_conv_xb_pack_sibling_size(int Cin, long* packed_bytes) {
   if (Cin <= 0 || (Cin % 8) || !packed_bytes) return ATVS_ERR_SHAPE;
-  *packed_bytes = (long)(Cin / 8) * XB_J2 * 3 * 1024;
+  *packed_bytes = (long)(Cin / 8) * XB_J2 * XB_NP * 1024;
   return ATVS_OK;
 }
 
@@ -594,6 +589,7 @@ extern "C" int atvs_conv_xb_pack_sibling(const float* w2, int Cin, unsigned char
   if (rc) return rc;
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
+  bool fits = true;
   for (int ch = 0; ch < Cin / 8; ++ch)
     for (int i = 0; i < XB_J2; ++i)
       for (int q = 0; q < 4; ++q) {
@@ -601,9 +597,10 @@ extern "C" int atvs_conv_xb_pack_sibling(const float* w2, int Cin, unsigned char
         if (tap > 26) continue;
         for (int co = 0; co < 16; ++co)
           for (int e = 0; e < 8; ++e)
-            xb_put(out, ((((size_t)ch * XB_J2 + i) * 3) * 64 + q * 16 + co) * 8 + e, w2[((size_t)tap * Cin + ch * 8 + e) * 16 + co]);
+            fits &= xb_put(out, ((((size_t)ch * XB_J2 + i) * XB_NP) * 64 + q * 16 + co) * 8 + e,
+                           w2[((size_t)tap * Cin + ch * 8 + e) * 16 + co]);
       }
-  return ATVS_OK;
+  return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
 // Same contract as atvs_conv_xw_f32 (x_planar included), weights packed by atvs_conv_xb_pack[_sibling]; grid and statistics
@@ -634,14 +631,14 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
   long pb;
   atvs_conv_xb_pack_size(Cin, &pb);
   XbArgs a;
-  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
   a.bias = bias; a.pbias = plane_bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff;
   a.nchunk = Cin / 8;
   a.tiles_y = (H + XB_TY - 1) / XB_TY; a.tiles_x = (W + XB_TXV - 1) / XB_TXV;
   a.ntiles = (int)xb_ntiles(D, H, W);
   a.relu = relu;
-  a.wp2 = reinterpret_cast<const bf16x8*>(packed_w2); a.pbias2 = plane_bias2; a.y2 = y2; a.stats2 = stats_partial2;
+  a.wp2 = reinterpret_cast<const f16x8*>(packed_w2); a.pbias2 = plane_bias2; a.y2 = y2; a.stats2 = stats_partial2;
   a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
   a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;
   a.wg = (int)atvs_conv_xp_grid(D, H, W, groups);

@@ -10,7 +10,7 @@ configurations on the seeded synthetic inputs and weights (the same ones bench.p
     cfg5    two-view 1600x1184, D=256              (BASELINE configs[4])
     cfg5f64 the float64-network evaluation of cfg5: NOT generated -- it needs more than the 62 GB of the build container
             (killed by the kernel), and a run on a GPU box's host took that box down; see cfg5h
-    cfg5h   configs[4] at HALF the image size: two-view 800x592, D=256, the same cameras scaled (synthetic.make_inputs)
+    cfg5h   configs[4] at HALF the image size: two-view 800x576 (the network needs multiples of 32), D=256, the same camera model (synthetic.make_inputs)
     cfg5hf64 its float64-network evaluation: the noise floor of the configs[4]-shaped case (D=256, two-view, wide
             images) that fits this container -- the HIP path is asserted to be no further from it than 1.5 x the float32
             oracle is (tests/test_gpu_fullsize.py::test_cfg5_halfsize_against_the_float64_floor)
@@ -43,7 +43,7 @@ CONFIGS = {            # name: (views, H, W, D)
     'cfg3': (5, 512, 640, 192),
     'cfg4': (9, 480, 928, 256),
     'cfg5': (2, 1184, 1600, 256),
-    'cfg5h': (2, 592, 800, 256),
+    'cfg5h': (2, 576, 800, 256),
 }
 
 
