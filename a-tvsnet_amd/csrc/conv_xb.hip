@@ -21,8 +21,12 @@
 // Structure: tile 4(z) x 8(y) x 32(x), wavefront w owns plane z0 + w (8 + 8 accumulator tiles); the input is staged in 8-channel
 // chunks as TWO piece images [6][10][even / odd x interleaved in runs of eight][8 fp16] (46 KB each, single-buffered: the next
 // stage's halo waits in registers as in conv_xp, two barriers per stage); the split happens once per staged element, after
-// the optional prologue (batch norm + ReLU of the producers, skip add).  Weights (two pieces per step, split on the host)
-// stream from L2 two steps ahead.  Sibling: K step i = taps 4 i + q of the 27 (7 steps), 2 rows per wavefront.
+// the optional prologue (batch norm + ReLU of the producers, skip add).  Weights (two pieces per step, split on the host): the
+// NEXT chunk's 32 KB are fetched at the top of the K loop (eight 16-byte loads per thread, L2 hits) and written into the other
+// of two LDS weight buffers a few phases later; the K loop reads its A fragments from LDS one step ahead.  (Round 3 streamed
+// them from L2 into registers inside the loop: vector-memory operations retire in order, so every weight request queued behind
+// the HBM halo loads of the phases before it and each K step waited for memory latency -- halving the MFMA count alone bought
+// 30 %, not 2 x.)  Sibling: K step i = taps 4 i + q of the 27 (7 steps), 2 rows per wavefront.
 #include <cstring>
 #include <type_traits>
 
@@ -49,15 +53,26 @@ constexpr int XB_SLOTS = XB_HZ * XB_HY * XB_HX * 2;         // float4 slots of t
 constexpr int XB_MAXS = (XB_SLOTS + 255) / 256;             // 16 per thread
 constexpr int XB_JC = 9;                                    // main K steps per chunk: (kd, kh)
 constexpr int XB_J2 = 7;                                    // sibling K steps per chunk: taps 4 i + q
-constexpr int XB_LOOK = 2;                                  // weight look-ahead in K steps
 constexpr int XB_NP = 2;                                    // operand pieces
+constexpr int XB_WMAIN = XB_JC * XB_NP * 1024;              // bytes of a chunk's main weight pieces: [step][piece][lane][8 fp16]
+constexpr int XB_WSIB = XB_J2 * XB_NP * 1024;               // ... of its sibling weight pieces
+constexpr int XB_WBUF = XB_WMAIN + XB_WSIB;                 // one LDS weight buffer (32 KB); two of them behind the images
+constexpr int XB_WOFF = XB_NP * XB_IMG;
+constexpr int XB_LDS = XB_WOFF + 2 * XB_WBUF;               // 157,696 of the CU's 163,840 bytes
+static_assert(XB_LDS <= 160 * 1024, "one workgroup per CU");
+static_assert((XB_WMAIN / 16) % 128 == 0 && (XB_WBUF / 16) % 256 == 0, "weight slots: whole wavefronts per source");
 constexpr float XB_RS = 2048.f, XB_IRS = 1.f / 2048.f;      // scale of the residual piece and its inverse (exact powers of two)
-static_assert(XB_MAXS <= XB_NP * XB_JC, "one halo slot per phase of the main K loop");
+static_assert(XB_MAXS <= 18, "three halo slots per phase of the main K loop");
 static_assert((XB_NP - 1) * XB_IMG + (2 * XB_HY + 2 + XB_TY) * XB_ROWB < XB_NP * XB_IMG, "fragment reads stay inside the images");
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// buffer_load_dwordx4 (offen).  hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 compiles to a ONE-dword load whose value is
+// splat over the four components (checked in the ISA), so the LLVM intrinsic is bound by name instead.
+__device__ f32x4 xb_buffer_load_x4(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
 
 struct XbArgs {
   const float* x;
@@ -116,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
   constexpr int MAXS = XB_MAXS, JC = XB_JC, J2 = SIB ? XB_J2 : 0, ROWB = XB_ROWB;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: a scalar (uniform branches)
   const int r = lane & 15, q = lane >> 4;
 
   // this lane's fragment (the 8 channels of one voxel of a piece image) of halo row 0 of the wavefront's plane at its x
@@ -148,7 +163,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     const int c4 = s & 1, v = s >> 1;
     const int xx = v % XB_HX, v2 = v / XB_HX;
     const int yy = v2 % XB_HY, zz = v2 / XB_HY;
-    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.vstride + c4 * 4;
+    goff[i] = (((zz * p.Hi + yy) * p.Wi + xx) * p.vstride + c4 * 4) * 4;       // BYTES from the halo's first voxel
     laddr[i] = (zz * XB_HY + yy) * XB_ROWB + xb_col(xx & 1, xx >> 1) + c4 * 8;
     pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
   }
@@ -209,14 +224,38 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
   };
   float4 pf[MAXS];
   float4 pf2[PRO == 2 ? MAXS : 1];
-  unsigned vmask = 0;
-  auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
-    const unsigned t1 = pg[i] - T.lo;
-    const unsigned t2 = T.hi1 + ~pg[i];
-    const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
-    pf[i] = ld4(ok ? (T.xb + (T.org + goff[i])) : p.zeros);
-    if (PRO >= 1) vmask = (vmask & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-    if (PRO == 2) pf2[i] = ld4(ok ? (T.xb2 + (T.org + goff[i])) : p.zeros);
+  // The halo of the next stage is fetched with BUFFER loads from a descriptor whose base is the halo's first voxel of the
+  // chunk (a scalar add per stage): a slot's address is then a per-kernel constant (goff) and a slot outside the volume gets
+  // an offset beyond the descriptor's range -- the load returns zeros, no pointer select.  Which slots are inside is a property
+  // of the TILE: the 16-bit mask is recomputed only when the prefetched stage starts a new tile (every nchunk-th stage).
+  // (Round 3 formed a 64-bit address and the bounds test per slot and stage: ~16 vector instructions per slot, 257 of the
+  // kernel's 480 per stage, against 240 MFMAs.)
+  unsigned vinv = 0;                     // bit i set: slot i of the prefetched stage lies OUTSIDE the volume
+  auto pf_mask = [&](const PfTile& T) __attribute__((always_inline)) {
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      const unsigned t1 = pg[i] - T.lo;
+      const unsigned t2 = T.hi1 + ~pg[i];
+      m |= ((((t1 & t2) & 0x808080u) == 0x808080u) ? 0u : 1u) << i;
+    }
+    return m;
+  };
+  auto pf_rsrc = [&](const float* base, int org) __attribute__((always_inline)) {
+#ifdef ATVS_XB_HOT       // development: every tile fetches the same halo (cache hits) -- is the launch bound by the memory path?
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (org & 1023)), 0, 0x7ffffff0, 0x00020000);
+#else
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base + org), 0, 0x7ffffff0, 0x00020000);
+#endif
+  };
+  auto pf_slot = [&](__amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb, int i) __attribute__((always_inline)) {
+    const unsigned voff = (unsigned)goff[i] | (unsigned)__builtin_amdgcn_sbfe(vinv, i, 1);      // all ones when outside
+    const f32x4 a = xb_buffer_load_x4(ra, (int)voff, 0, 0);
+    pf[i] = make_float4(a[0], a[1], a[2], a[3]);
+    if (PRO == 2) {
+      const f32x4 b = xb_buffer_load_x4(rb, (int)voff, 0, 0);
+      pf2[i] = make_float4(b[0], b[1], b[2], b[3]);
+    }
   };
 
   // prologue transform: arithmetic of bn_apply / bn_add (norm.hip), as conv_xp.hip / conv_xw.hip
@@ -244,7 +283,7 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     return t;
   };
   auto xform = [&](int i, const Par& P) __attribute__((always_inline)) {
-    const bool ok = (vmask >> i) & 1u;
+    const bool ok = !((vinv >> i) & 1u);            // vinv still describes the stage being staged: it is renewed in the K loop
     f32x2 lo = {pf[i].x, pf[i].y}, hi = {pf[i].z, pf[i].w};
     lo = bn2(lo, (f32x2){P.ma.x, P.ma.y}, (f32x2){P.sa.x, P.sa.y}, (f32x2){P.ba.x, P.ba.y}, floor_a, has_a);
     hi = bn2(hi, (f32x2){P.ma.z, P.ma.w}, (f32x2){P.sa.z, P.sa.w}, (f32x2){P.ba.z, P.ba.w}, floor_a, has_a);
@@ -265,10 +304,35 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
   f32x4 acc2[2], acc2x[2];
   float ssum2[4] = {0.f, 0.f, 0.f, 0.f}, ssq2[4] = {0.f, 0.f, 0.f, 0.f};
 
-  if (nstage > 0) {
-    const PfTile T0 = pf_tile(0);
+  // weight pieces of a chunk: global -> registers -> LDS buffer `buf` ([main steps][sibling steps], XB_WBUF bytes)
+  constexpr int NW = SIB ? XB_WBUF / 4096 : (XB_WMAIN + 4095) / 4096;        // float4 slots per thread: 8 | 5
+  float4 wreg[NW];
+  auto w_request = [&](int chunk) __attribute__((always_inline)) {
+    const unsigned char* gm = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)chunk * XB_WMAIN;
+    const unsigned char* gs = SIB ? reinterpret_cast<const unsigned char*>(p.wp2) + (size_t)chunk * XB_WSIB : nullptr;
 #pragma unroll
-    for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+    for (int j = 0; j < NW; ++j) {
+      const int idx = tid + 256 * j;                         // float4 index inside the buffer; main | sibling is wave-uniform
+      const unsigned char* src = idx < XB_WMAIN / 16 ? gm + (size_t)idx * 16
+                                                     : (SIB ? gs + (size_t)(idx - XB_WMAIN / 16) * 16 : reinterpret_cast<const unsigned char*>(p.zeros));
+      wreg[j] = ld4(reinterpret_cast<const float*>(src));
+    }
+  };
+  auto w_land = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+      const int idx = tid + 256 * j;
+      if (SIB || idx < XB_WMAIN / 16) *reinterpret_cast<float4*>(smem + XB_WOFF + buf * XB_WBUF + idx * 16) = wreg[j];
+    }
+  };
+  if (nstage > 0) {
+    w_request(0);
+    w_land(0);                             // read after the two barriers of stage 0
+    const PfTile T0 = pf_tile(0);
+    vinv = pf_mask(T0);
+    const __amdgpu_buffer_rsrc_t r0 = pf_rsrc(T0.xb, T0.org), r02 = pf_rsrc(PRO == 2 ? T0.xb2 : T0.xb, T0.org);
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) pf_slot(r0, r02, i);
   }
 
 #ifdef ATVS_XB_DEBUG
@@ -283,14 +347,10 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
       for (int t = 0; t < XB_TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       acc2[0] = acc2[1] = acc2x[0] = acc2x[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    // weight pieces of this chunk: [step][piece][lane]; those of the first steps are on their way while the images are written
-    const f16x8* wch = p.wp + ((size_t)ch * JC * XB_NP) * 64 + lane;
-    const f16x8* wch2 = p.wp2 + ((size_t)ch * J2 * XB_NP) * 64 + lane;
-    f16x8 A[JC][XB_NP], A2[SIB ? XB_J2 : 1][XB_NP];
-#pragma unroll
-    for (int s = 0; s < XB_LOOK; ++s)
-#pragma unroll
-      for (int pc = 0; pc < XB_NP; ++pc) A[s][pc] = wch[(s * XB_NP + pc) * 64];
+    // this chunk's weight pieces sit in LDS buffer wbuf (one chunk: resident in buffer 0 for the whole launch)
+    const bool wstream = p.nchunk > 1;
+    const int wbuf = wstream ? (stage & 1) : 0;
+    const int wb = XB_WOFF + wbuf * XB_WBUF + lane * 16;
 
     __syncthreads();                       // every wavefront is done reading the previous stage's images
     XDBG(5)
@@ -311,8 +371,16 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     __syncthreads();
     XDBG(6)
 
+    // The next stage's traffic goes out in the FIRST phases of the K loop: the next chunk's weights first (their write into the
+    // other LDS buffer, at phase 6, then waits for L2 hits only -- vector-memory operations retire in order), then two halo
+    // slots per phase (two or three instructions each) in phases 0..7, so that the last ones have ten phases and the sibling
+    // loop to arrive.  (One per phase up to phase 15, round 3: the next stage's split waited for HBM.  All 24 loads in one
+    // burst in front of the loop: the wavefronts stall issuing them, 2,700 cycles per stage.)
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
     const bool last_chunk = (ch == p.nchunk - 1);
+    if (last_chunk) vinv = pf_mask(T);                         // the prefetched stage starts a new tile
+    const __amdgpu_buffer_rsrc_t rsa = pf_rsrc(T.xb, T.org), rsb = pf_rsrc(PRO == 2 ? T.xb2 : T.xb, T.org);
+
     int tz0, ty0, tx0;
     tile_origin(k, &tz0, &ty0, &tx0);
     const int zo = tz0 + wave, xo = tx0 + 2 * r + (q >> 1), co = (q & 1) * 4;
@@ -328,14 +396,33 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
     const size_t erow2 = (size_t)p.Wo2 * p.ldy2;
     const size_t eo2 = (((size_t)zo2 * p.Ho2 + yo2) * p.Wo2 + xo2) * (size_t)p.ldy2 + p.ycoff2 + 4 * q;
 
-    // ---- main K loop: 9 steps (kd, kh) x 2 phases (input piece h0 with both weight pieces: 16 MFMAs; h1 with g0: 8);
-    // the fragments of ONE input piece are live at a time, requested one phase ahead
-    f16x8 Bq[2][XB_TY], B2[2][XB_NP][2];
-    auto request_B = [&](int ph) __attribute__((always_inline)) {
-      const int s = ph / XB_NP, pc = ph % XB_NP;
-      const int off = ((s / 3) * XB_HY + (s % 3)) * ROWB;
+    // ---- main K loop: per kd TWO phases -- the TEN halo rows of input piece h0 at depth kd serve the three kh steps x both
+    // weight pieces (48 MFMAs), then the ten rows of h1 serve kh x g0 (24 MFMAs): 20 fragment reads per kd instead of 48.
+    // Why: with a fragment read per MFMA the four wavefronts asked the LDS for 4 x 4 cycles of ds_read_b128 per 16-cycle MFMA
+    // -- the array was saturated in every h1 phase and each MFMA waited for its fragment (phase timers: 5,300 cycles for
+    // 3,456 of MFMA work; counters: LDS active 45 % of the launch ON AVERAGE, MFMA pipe 38 %).  Rows of one piece are requested
+    // during the other piece's phase (every second MFMA slot), the six weight fragments of the next kd during the h0 phase.
+    f16x8 Bq[XB_NP][XB_HY], B2[2][XB_NP][2], A[2][3][XB_NP], A2[2][XB_NP];
+    auto request_A = [&](int kd) __attribute__((always_inline)) {           // the weight fragments of steps 3 kd .. 3 kd + 2
+#ifdef ATVS_XB_BARE
+      if (kd > 0) return;
+#endif
 #pragma unroll
-      for (int t = 0; t < XB_TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + fb[pc] + (off + t * ROWB));
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int pc = 0; pc < XB_NP; ++pc)
+          A[kd & 1][kh][pc] = *reinterpret_cast<const f16x8*>(smem + wb + ((kd * 3 + kh) * XB_NP + pc) * 1024);
+    };
+    auto request_A2 = [&](int i) __attribute__((always_inline)) {
+#pragma unroll
+      for (int pc = 0; pc < XB_NP; ++pc) A2[i & 1][pc] = *reinterpret_cast<const f16x8*>(smem + wb + XB_WMAIN + (i * XB_NP + pc) * 1024);
+    };
+    auto request_B = [&](int kd, int pc) __attribute__((always_inline)) {
+#ifdef ATVS_XB_NOREAD      // development: what does the K loop cost without its fragment reads?
+      if (kd > 0 || pc > 0) return;
+#endif
+#pragma unroll
+      for (int y = 0; y < XB_HY; ++y) Bq[pc][y] = *reinterpret_cast<const f16x8*>(smem + fb[pc] + (kd * XB_HY + y) * ROWB);
     };
     auto request_B2 = [&](int i) __attribute__((always_inline)) {         // the two pieces of sibling step i (6 MFMAs)
 #pragma unroll
@@ -344,68 +431,96 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
         for (int t = 0; t < 2; ++t)
           B2[i & 1][pc][t] = *reinterpret_cast<const f16x8*>(smem + pc * XB_IMG + sd[i] + 2 * t * ROWB);
     };
-    request_B(0);
+    request_A(0);
+    request_B(0, 0);
     asm volatile("" ::: "memory");
     XDBG(0)
 #pragma unroll
-    for (int ph = 0; ph < XB_NP * JC; ++ph) {
-      const int s = ph / XB_NP, pc = ph % XB_NP;
+    for (int ph = 0; ph < 2 * 3; ++ph) {
+      const int kd = ph >> 1, pc = ph & 1;
       if (pc == 0) {
-        if (s + XB_LOOK < JC) {
+        request_B(kd, 1);
+        if (kd + 1 < 3) request_A(kd + 1);
+        else if (SIB) request_A2(0);
+      } else {
+        if (kd + 1 < 3) request_B(kd + 1, 0);
+        else if (SIB) request_B2(0);
+      }
+      // the next stage's traffic: the next chunk's weights first (their write into the other LDS buffer, two phases on, then
+      // waits for L2 hits only -- vector-memory operations retire in order), then three halo slots per phase.  Tried and
+      // dropped: all 24 loads in one burst in front of the loop (the wavefronts stall issuing them: +2,700 cycles per stage),
+      // one wavefront's 16 loads per phase, staggered (+700).  In-loop vector-memory instructions are what the K loop pays
+      // for: 5,000 cycles with them, 3,100 = the bare MFMA stream without (phase timers, development builds).
+      // (The two-source form -- one 8-channel chunk on the path, weights resident -- has no registers to hold them across phases.)
+#ifndef ATVS_XB_BARE       // development: the bare MFMA stream
+      if (ph == (PRO == 2 ? 2 : 0) && wstream) w_request(ch + 1 < p.nchunk ? ch + 1 : 0);
+      if (ph == 2 && wstream) w_land(wbuf ^ 1);
 #pragma unroll
-          for (int w3 = 0; w3 < XB_NP; ++w3) A[s + XB_LOOK][w3] = wch[((s + XB_LOOK) * XB_NP + w3) * 64];
-        } else if (SIB) {
+      for (int i = 3 * ph; i < 3 * ph + 3; ++i)
+        if (i < MAXS) pf_slot(rsa, rsb, i);
+#endif
+      if (!SIB && ph == 4 && last_chunk) {       // (uniform branch: only the tile's last stage has an epilogue)
 #pragma unroll
-          for (int w3 = 0; w3 < XB_NP; ++w3) A2[s + XB_LOOK - JC][w3] = wch2[((s + XB_LOOK - JC) * XB_NP + w3) * 64];
+        for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((pbg && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
+      }
+      if (pc == 0) {
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+#pragma unroll
+          for (int t = 0; t < XB_TY; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[kd & 1][kh][0], Bq[0][t + kh], acc[t], 0, 0, 0);
+#pragma unroll
+          for (int t = 0; t < XB_TY; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[kd & 1][kh][1], Bq[0][t + kh], accx[t], 0, 0, 0);
         }
-      }
-      if (ph + 1 < XB_NP * JC) request_B(ph + 1);
-      else if (SIB) request_B2(0);
-      if (ph < MAXS) pf_slot(T, ph);
-      if (!SIB && ph == XB_NP * JC - 4) {
-        const bool use = last_chunk && pbg;
-#pragma unroll
-        for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((use && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
-      }
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      if (pc == 0) {
-#pragma unroll
-        for (int t = 0; t < XB_TY; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], Bq[ph & 1][t], acc[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < XB_TY; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][1], Bq[ph & 1][t], accx[t], 0, 0, 0);
       } else {
 #pragma unroll
-        for (int t = 0; t < XB_TY; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[s][0], Bq[ph & 1][t], accx[t], 0, 0, 0);
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int t = 0; t < XB_TY; ++t) accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[kd & 1][kh][0], Bq[1][t + kh], accx[t], 0, 0, 0);
       }
+      // the phase's requests do not depend on its MFMAs: two MFMAs, then at most one LDS read / LDS write / global load and a
+      // few other vector instructions in their shadow (bunched in front of the MFMAs they left the matrix pipe dry)
+#pragma unroll
+      for (int g = 0; g < (pc == 0 ? 24 : 12); ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);      // MFMA
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);      // DS read
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);      // DS write
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);      // VALU
+      }
+      asm volatile("" ::: "memory");                            // this phase's requests stay in this phase
+      __builtin_amdgcn_sched_barrier(0);
     }
     XDBG(2)
     if (SIB) {
-      // one phase per step here: with two rows per wavefront a per-piece phase would be 2-6 MFMAs long
+      // 7 steps of 6 MFMAs, one phase per step (with two rows per wavefront a per-piece phase would be 2-4 MFMAs long)
 #pragma unroll
       for (int i = 0; i < J2; ++i) {
-        if (i + XB_LOOK < J2) {
-#pragma unroll
-          for (int w3 = 0; w3 < XB_NP; ++w3) A2[i + XB_LOOK][w3] = wch2[((i + XB_LOOK) * XB_NP + w3) * 64];
+        if (i + 1 < J2) {
+          request_A2(i + 1);
+          request_B2(i + 1);
         }
-        if (i + 1 < J2) request_B2(i + 1);
-        if (i == J2 - 3) {            // the epilogues' depth-plane biases, behind the last weight request of the stage
-          const bool use = last_chunk && pbg;
+        if (i == J2 - 3 && last_chunk) {   // the epilogues' depth-plane biases (uniform branch: the tile's last stage only)
 #pragma unroll
-          for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((use && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
-          const bool use2 = last_chunk && pb2g;
+          for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((pbg && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
           const size_t o = ((size_t)yo2 * p.Wo2 + xo2) * 48 + plane_variant(2 * zo2 - p.pbz, p.Di) * 16 + 4 * q;
 #pragma unroll
-          for (int t = 0; t < 2; ++t) epb2[t] = ld4((use2 && erow2_ok(t)) ? pb2g + (o + (size_t)t * p.Wo2 * 48) : p.zeros);
+          for (int t = 0; t < 2; ++t) epb2[t] = ld4((pb2g && erow2_ok(t)) ? pb2g + (o + (size_t)t * p.Wo2 * 48) : p.zeros);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i & 1][0], B2[i & 1][0][t], acc2[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc2x[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i & 1][1], B2[i & 1][0][t], acc2x[t], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) acc2x[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i & 1][0], B2[i & 1][1][t], acc2x[t], 0, 0, 0);
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i][0], B2[i & 1][0][t], acc2[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc2x[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i][1], B2[i & 1][0][t], acc2x[t], 0, 0, 0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) acc2x[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A2[i][0], B2[i & 1][1][t], acc2x[t], 0, 0, 0);
       }
     }
     XDBG(3)
@@ -516,7 +631,7 @@ long xb_ntiles(int D, int H, int W) {
 
 template <bool SIB, int PRO>
 int launch_xb(const XbArgs& a, long blocks, hipStream_t s) {
-  const size_t lds = XB_NP * (size_t)XB_IMG;
+  const size_t lds = XB_LDS;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
@@ -622,6 +737,7 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if (plane_bias && D < 2) return ATVS_ERR_ARG;
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
+  if (24.0 * ((double)H * W + W + 64) * (x_planar ? 8 : Cin) >= 2147483648.0) return ATVS_ERR_SHAPE;   // a halo's byte offsets (buffer loads)
   if (packed_w2) {
     if (!y2) return ATVS_ERR_NULL;
     if (y_coff2 < 0 || y_coff2 + 16 > ldy2 || (ldy2 % 4) || (y_coff2 % 4)) return ATVS_ERR_SHAPE;

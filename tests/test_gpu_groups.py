@@ -182,22 +182,23 @@ def _pending(x, w, key, G, relu=True):
     return ops.PendingBN(y, ops.bn_params(st, y.shape[-1], y), relu)
 
 
-@pytest.mark.parametrize('G,shape', [(1, (16, 32, 48)), (3, (12, 24, 40)), (2, (9, 21, 37))])
-def test_siblings_add_on_load_is_bitwise_the_materialised_sum(cuda, G, shape):
+@pytest.mark.parametrize('G,shape,C', [(1, (16, 32, 48), 8), (3, (12, 24, 40), 8), (2, (9, 21, 37), 8), (2, (8, 16, 40), 24)])
+def test_siblings_add_on_load_is_bitwise_the_materialised_sum(cuda, G, shape, C):
     """The U-Net's stack input I_b = bn_relu(conv_6_0) + bn_relu(conv_0_1) (reference cnn_wrapper/atvsnet.py:38-39,
-    network.py:695-697) formed inside the x-pair launch: same values as bn_add followed by the plain launch."""
+    network.py:695-697) formed inside the x-pair launch: same values as bn_add followed by the plain launch.  (C = 24: three
+    8-channel chunks, i.e. the two-source form with its weights streamed through the LDS buffers.)"""
     from atvsnet_amd import ops
-    xa, xb = _rand((G,) + shape + (8,), 1).to(cuda), _rand((G,) + shape + (8,), 2).to(cuda)
-    wa, wb = (_rand((3, 3, 3, 8, 8), 3) * 0.2).numpy(), (_rand((3, 3, 3, 8, 8), 4) * 0.2).numpy()
-    w8, w16 = (_rand((3, 3, 3, 8, 8), 5) * 0.1).numpy(), (_rand((3, 3, 3, 8, 16), 6) * 0.1).numpy()
+    xa, xb = _rand((G,) + shape + (8,), 1).to(cuda), _rand((G,) + shape + (C,), 2).to(cuda)
+    wa, wb = (_rand((3, 3, 3, 8, C), 3) * 0.2).numpy(), (_rand((3, 3, 3, C, C), 4) * 0.2).numpy()
+    w8, w16 = (_rand((3, 3, 3, C, 8), 5) * 0.1).numpy(), (_rand((3, 3, 3, C, 16), 6) * 0.1).numpy()
     for dense_second in (False, True):
-        a = _pending(xa, wa, ('pa', G), G)
-        b = xb.clone() if dense_second else _pending(xb, wb, ('pb', G), G)
+        a = _pending(xa, wa, ('pa', G, C), G)
+        b = xb.clone() if dense_second else _pending(xb, wb, ('pb', G, C), G)
         lazy = ops.PendingSum([a, b])
         assert ops.siblings_prologue_ok(lazy)
-        (y, st), (y2, st2) = ops.conv_siblings(lazy, 'pl8', w8, 'pl16', w16, groups=G)
+        (y, st), (y2, st2) = ops.conv_siblings(lazy, ('pl8', C), w8, ('pl16', C), w16, groups=G)
         dense = ops.PendingSum([a, b]).materialize()
-        (r, rt), (r2, rt2) = ops.conv_siblings(dense, 'pl8', w8, 'pl16', w16, groups=G)
+        (r, rt), (r2, rt2) = ops.conv_siblings(dense, ('pl8', C), w8, ('pl16', C), w16, groups=G)
         assert torch.equal(y, r) and torch.equal(y2, r2)
         assert torch.equal(ops.bn_params(st, 8, y), ops.bn_params(rt, 8, r))
         assert torch.equal(ops.bn_params(st2, 16, y2), ops.bn_params(rt2, 16, r2))

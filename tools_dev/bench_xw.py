@@ -37,10 +37,12 @@ def timed(name, fn, gf):
 V, V2 = D * H * W, (D // 2) * (H // 2) * (W // 2)
 # 1. dominant: 32 warped channels -> 8 | 16 (stride 2), plane biases, 8 volumes
 G = 8
-x = torch.randn(G, D, H, W, 32, device=dev)
+planar = kind != 'xp'          # as the pipeline launches it: the warped half of the cost volume chunk-planar
+x = torch.randn(G, 4, ops.planar_stride(D, H, W), device=dev) if planar else torch.randn(G, D, H, W, 32, device=dev)
 pb, pb2 = torch.randn(G, H, W, 24, device=dev), torch.randn(G, H // 2, W // 2, 48, device=dev)
 w8, w16 = wt(32, 8), wt(32, 16)
-timed('conv_b0_0_1|1_0  32->8|16  G=8 (dominant)', lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G),
+timed('conv_b0_0_1|1_0  32->8|16  G=8 (dominant%s)' % (', planar' if planar else ''),
+      lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W) if planar else False),
       G * (2.0 * 27 * 32 * 8 * V + 2.0 * 27 * 32 * 16 * V2) / 1e9)
 del x, pb, pb2
 # 2. stack inputs: two 8-channel sources, normalise + add on load, 8 volumes
@@ -58,9 +60,11 @@ timed('conv_b1_0_1|1_0  8+8->8|16 add-on-load G=8', stack, G * (2.0 * 27 * 8 * 8
 del xa, xb
 # 3. refinement: 32-channel concat, normalise on load, 4 volumes
 G = 4
-x = torch.randn(G, D, H, W, 32, device=dev)
+planar = kind == 'xb'
+x = torch.randn(G, 4, ops.planar_stride(D, H, W), device=dev) if planar else torch.randn(G, D, H, W, 32, device=dev)
 par = torch.stack([torch.randn(G, 32) * 0.1, torch.rand(G, 32) + 0.5, torch.randn(G, 32) * 0.1], 1).to(dev).contiguous()
-timed('3dconv0_1|1_0  32->8|16 normalise-on-load G=4', lambda: ops.conv_siblings(ops.PendingBN(x, par, True), 'c8', w8, 'c16', w16, groups=G),
+timed('3dconv0_1|1_0  32->8|16 normalise-on-load G=4%s' % (', planar' if planar else ''),
+      lambda: ops.conv_siblings(ops.PendingBN(x, par, True, planar=(D, H, W) if planar else None), 'c8', w8, 'c16', w16, groups=G),
       G * (2.0 * 27 * 32 * 8 * V + 2.0 * 27 * 32 * 16 * V2) / 1e9)
 del x
 # 4. photo stem: 16 -> 8, plane bias, 4 volumes

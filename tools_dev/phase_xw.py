@@ -18,6 +18,13 @@ if which == 'dominant':
     w8, w16 = wt(32, 8), wt(32, 16)
     run = lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G)   # noqa: E731
     mf = (384, 112)
+elif which == 'dominantp':           # as the pipeline launches it: the warped half chunk-planar
+    G = 8
+    x = torch.randn(G, 4, ops.planar_stride(D, H, W), device=dev)
+    pb, pb2 = torch.randn(G, H, W, 24, device=dev), torch.randn(G, H // 2, W // 2, 48, device=dev)
+    w8, w16 = wt(32, 8), wt(32, 16)
+    run = lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W))   # noqa: E731
+    mf = (384, 112)
 elif which == 'stack':
     G = 8
     xa, xb = torch.randn(G, D, H, W, 8, device=dev), torch.randn(G, D, H, W, 8, device=dev)
@@ -53,6 +60,6 @@ tot = b[:, :NP].sum(1).mean()
 print('%s: waves %d, stages per wave %.0f, mean cycles per stage %.0f (s_memtime ticks = 100 MHz x ? -- ratios matter)' % (which, len(b), ns, tot / ns))
 names = ['loop top (+acc zero)', 'stage setup (pf_tile, addresses)', 'main K loop (%d MFMAs)' % mf[0], 'sibling K loop (%d MFMAs)' % mf[1], 'epilogue (every nchunk-th stage)', 'barrier']
 if os.environ.get('XB'):
-    names = ['setup (tile, addresses, first fragments)', 'transform + split + LDS write', 'main K loop (432 MFMAs x 16 cyc)', 'sibling K loop (84 MFMAs x 16 cyc)', 'epilogue', 'barrier 1 (others done reading)', 'barrier 2 (images written)']
+    names = ['setup (tile, addresses, first fragments)', 'transform + split + LDS write', 'main K loop (216 MFMAs x 16 cyc)', 'sibling K loop (42 MFMAs x 16 cyc)', 'epilogue', 'barrier 1 (others done reading)', 'barrier 2 (images written)']
 for i, n in enumerate(names):
     print('%-40s %9.0f per stage (%.1f%%)' % (n, b[:, i].mean() / ns, 100 * b[:, i].mean() / tot))
