@@ -82,6 +82,33 @@ def twoview_f64(name):
                 return tuple(o.double() if o.dtype == torch.float32 else o for o in out)
             return out.double() if out.dtype == torch.float32 else out
         return wrapped
+    # torch's float64 conv3d on the CPU unfolds its input (27 x Cin doubles per voxel: 101 GB for the 64-channel cost volume
+    # of cfg5h): large float64 convolutions run slab by slab along the depth axis -- the same sums, a bounded footprint
+    plain_conv = T.conv
+
+    def slab_conv(x, w, stride=1, padding='SAME', dilation=1, bias=None, explicit_pad=None):
+        nsp = x.dim() - 2
+        cost = x.numel() * 8.0 * float(np.prod(w.shape[:nsp]))
+        if x.dtype != torch.float64 or nsp != 3 or cost < 6e9 or dilation != 1 or not isinstance(stride, int):
+            return plain_conv(x, w, stride, padding, dilation, bias, explicit_pad)
+        ks = w.shape[:3]
+        if explicit_pad is not None:
+            pads = list(explicit_pad)
+        elif padding == 'SAME':
+            pads = [T.same_pad(x.shape[1 + i], ks[i], stride)[:2] for i in range(3)]
+        else:
+            pads = [(0, 0)] * 3
+        n = x.shape[1]
+        out_d = (n + pads[0][0] + pads[0][1] - ks[0]) // stride + 1
+        step = max(1, int(out_d * 6e9 / cost))
+        outs = []
+        for o0 in range(0, out_d, step):
+            o1 = min(out_d, o0 + step)
+            lo, hi = o0 * stride - pads[0][0], (o1 - 1) * stride - pads[0][0] + ks[0]
+            sl = x[:, max(lo, 0):min(hi, n)]
+            outs.append(plain_conv(sl, w, stride, 'VALID', 1, bias, [(max(0, -lo), max(0, hi - n)), pads[1], pads[2]]))
+        return torch.cat(outs, 1)
+    T.conv = slab_conv
     saved = {}
     for fn in ('homography_warping', 'homography_warping_by_depth', 'transform_depth', 'get_visual_hull'):
         saved[fn] = getattr(G, fn)
@@ -94,6 +121,7 @@ def twoview_f64(name):
         for fn, f in saved.items():
             setattr(G, fn, f)
         T.linspace = orig_linspace
+        T.conv = plain_conv
     return {'depth64': d64[0, ..., 0].numpy().astype(np.float32)}
 
 
