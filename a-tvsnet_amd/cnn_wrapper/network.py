@@ -577,8 +577,6 @@ class Network(object):
         ws = self.store.get_host('%s/weight_shared' % scope, (3, 3, 3, c_in, c_in))
         key = scope + '/shared|unique'
         w16 = np.concatenate([ws, wu], axis=-1)
-        if stacked is not None and ops.aanet_fused_ok(stacked):
-            return ops.aanet_fused(stacked, key, w16).unsqueeze(0)       # scores never reach memory (csrc/aanet_fused.hip)
         if stacked is not None:
             sr = ops.conv(stacked, key, w16, relu=True, groups=stacked.shape[0])
             srs = [sr[n] for n in range(sr.shape[0])]

@@ -2,10 +2,11 @@
 // (gfx950): the quarter- and eighth-resolution layers of the 3-D U-Nets (conv_b*_2_1: 32 -> 32, conv_b*_3_1: 64 -> 64,
 // global_refine_3dconv{2,3}_1; /root/reference/cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, layer code
 // network.py:172-215), which ran on the fp32 matrix cores at 60-90 TFLOP/s (conv_c16.hip / conv_mfma.hip).  Arithmetic of
-// conv_c16b.hip: every fp32 operand = three bf16 pieces, the six products with i + j <= 2, fp32 accumulation.
+// conv_c16b.hip (round 4): every fp32 operand = two fp16 pieces (h0, h1 = f16((x - h0) * 2048)), three products on
+// v_mfma_f32_16x16x32_f16, the cross terms in a second accumulator scaled by 2^-11 in the epilogue.
 //
 // Structure = conv_c16b.hip's 16-channel form generalised: tile 4(z) x 8(y) x 16(x), wavefront w owns plane z0 + w, the input
-// is staged in 16-channel chunks as three piece images (34.5 KB each, single-buffered, the next stage's halo waits in
+// is staged in 16-channel chunks as two piece images (34.5 KB each, single-buffered, the next stage's halo waits in
 // registers), a K = 32 step = two taps x 16 channels (14 steps per chunk); the wavefront holds ALL output channels of its
 // voxels (2 or 4 accumulator tiles per row), computed two tiles at a time over the same staged image; weight pieces stream
 // from L2 one step ahead (they do not fit in LDS beside the images: 84 KB per chunk and pair of tiles).
@@ -27,18 +28,20 @@ constexpr int C3B_IMG = C3B_HZ * C3B_HY * C3B_ROWB;            // 34,560 bytes p
 constexpr int C3B_SLOTS = C3B_HZ * C3B_HY * C3B_HX * 4;        // float4 slots of the fp32 halo of a chunk
 constexpr int C3B_MAXS = (C3B_SLOTS + 255) / 256;              // 17 per thread
 constexpr int C3B_JC = 14;                                     // K steps per chunk: taps 2 j, 2 j + 1 (tap 27 = zero weights)
-static_assert(C3B_MAXS <= 3 * C3B_JC, "one halo slot per phase of the K loop");
+constexpr int C3B_NP = 2;                                      // operand pieces
+constexpr float C3B_RS = 2048.f, C3B_IRS = 1.f / 2048.f;
+static_assert(C3B_MAXS <= C3B_NP * C3B_JC, "one halo slot per phase of the K loop");
 constexpr int c3b_clamp26(int t) { return t < 26 ? t : 26; }
 constexpr int c3b_disp(int t) { return ((t / 9) * C3B_HY + (t / 3) % 3) * C3B_ROWB + (t % 3) * C3B_VB; }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct C3bArgs {
   const float* x;
-  const bf16x8* wp;            // packed bf16 pieces (atvs_conv3d_b_pack)
+  const f16x8* wp;             // packed fp16 pieces (atvs_conv3d_b_pack)
   const float* zeros;          // 16 zero bytes
   const float* bias;
   float* y;
@@ -50,6 +53,8 @@ struct C3bArgs {
   int wg;
   int relu;
   long gx, gy;
+  int nhalf;                   // 1: Cout = 32; 2: Cout = 64 as two 32-channel halves, blocks [0, bh) and [bh, 2 bh) of one launch
+  int bh;                      // blocks per half = wg * groups
 };
 
 template <int N>
@@ -63,21 +68,19 @@ __device__ __forceinline__ void c3b_static_for(F&& f) {
   c3b_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ void c3b_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+__device__ __forceinline__ void c3b_split(const float4& v, f16x4* p0, f16x4* p1) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
+    const _Float16 a = (_Float16)x[i];
     (*p0)[i] = a;
-    (*p1)[i] = b;
-    (*p2)[i] = (__bf16)r2;
+    (*p1)[i] = (_Float16)((x[i] - (float)a) * C3B_RS);
   }
 }
 
-// NT = Cout / 16 output tiles (2 or 4), computed in NT / 2 passes of two tiles over the staged chunk
+// NT = 2 output tiles (32 channels) per workgroup.  Cout = 64 runs as TWO 32-channel halves in one launch (blocks [bh, 2 bh)
+// compute channels 32..63: the input is staged twice, but four tiles' main + cross accumulators -- 256 registers -- do not
+// fit a wavefront (294 spilled registers), and at eighth resolution the launch had 192 tiles for 256 CUs anyway).
 template <int NT>
 __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
   // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
@@ -108,7 +111,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
   }
 
   const int G = p.wg;
-  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
+  const int hf = (int)blockIdx.x / p.bh, bidx = (int)blockIdx.x - hf * p.bh;      // output-channel half, block within it
+  const int NTT = NT * p.nhalf;                                                    // tiles in the packed weights
+  const int grp = bidx / p.wg, lbk = bidx - grp * p.wg;
   const int xcd = lbk & 7, tslot = lbk >> 3;
   const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
   float* __restrict__ yg = p.y + (size_t)grp * p.gy;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
     pf[i] = ld4(ok ? (xg + (T.org + goff[i])) : p.zeros);
   };
 
-  f32x4 acc[NT][TY];
+  f32x4 acc[NT][TY], accx[NT][TY];     // h0 g0 | (h0 g1 + h1 g0) * 2^11
   f32x2 ssum2[NT][2], ssq2[NT][2];
 #pragma unroll
   for (int n = 0; n < NT; ++n) ssum2[n][0] = ssum2[n][1] = ssq2[n][0] = ssq2[n][1] = (f32x2){0.f, 0.f};
@@ -171,49 +176,48 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
 #pragma unroll
       for (int n = 0; n < NT; ++n)
 #pragma unroll
-        for (int t = 0; t < TY; ++t) acc[n][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TY; ++t) acc[n][t] = accx[n][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // weight pieces of this chunk: [step][tile][piece][lane]; the first step's are on their way while the images are written
-    const bf16x8* wch = p.wp + ((size_t)ch * JC * NT * 3) * 64 + lane;
-    bf16x8 A[2][2][3];
+    const f16x8* wch = p.wp + (((size_t)ch * JC * NTT + hf * NT) * C3B_NP) * 64 + lane;
+    f16x8 A[2][2][C3B_NP];
 #pragma unroll
     for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) A[0][nn][pc] = wch[(nn * 3 + pc) * 64];
+      for (int pc = 0; pc < C3B_NP; ++pc) A[0][nn][pc] = wch[(nn * C3B_NP + pc) * 64];
 
     __syncthreads();                       // every wavefront is done reading the previous stage's images
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < C3B_SLOTS) {
-        bf16x4 p0, p1, p2;
-        c3b_split(pf[i], &p0, &p1, &p2);
-        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
-        *reinterpret_cast<bf16x4*>(smem + C3B_IMG + laddr[i]) = p1;
-        *reinterpret_cast<bf16x4*>(smem + 2 * C3B_IMG + laddr[i]) = p2;
+        f16x4 p0, p1;
+        c3b_split(pf[i], &p0, &p1);
+        *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<f16x4*>(smem + C3B_IMG + laddr[i]) = p1;
       }
     }
     __syncthreads();
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
 
-    // ---- K loops: per pair of output tiles 14 steps of two taps x 16 channels, each in three phases -- input piece pc with
-    // the weight pieces jw <= 2 - pc (48 / 32 / 16 MFMAs); fragments requested one phase ahead, weights one step ahead
-    bf16x8 Bq[2][TY];
+    // ---- K loops: per pair of output tiles 14 steps of two taps x 16 channels, each in two phases -- input piece h0 with both
+    // weight pieces (32 MFMAs), h1 with g0 (16); fragments requested one phase ahead, weights one step ahead
+    f16x8 Bq[2][TY];
     c3b_static_for<NH>([&](auto HF) __attribute__((always_inline)) {
       constexpr int half = decltype(HF)::value;
       auto request_B = [&](auto PH) __attribute__((always_inline)) {
-        constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
+        constexpr int ph = decltype(PH)::value, j = ph / C3B_NP, pc = ph % C3B_NP;
         constexpr int tA = c3b_clamp26(2 * j), tB = c3b_clamp26(2 * j + 1);
         const int a = fbase + ((q >> 1) ? c3b_disp(tB) : c3b_disp(tA));
 #pragma unroll
         for (int t = 0; t < TY; ++t)
-          Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * C3B_IMG + a + t * C3B_ROWB);
+          Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * C3B_IMG + a + t * C3B_ROWB);
       };
       auto request_B1 = [&](auto PH, auto TT) __attribute__((always_inline)) {      // row t of phase ph
-        constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3, t = decltype(TT)::value;
+        constexpr int ph = decltype(PH)::value, j = ph / C3B_NP, pc = ph % C3B_NP, t = decltype(TT)::value;
         constexpr int tA = c3b_clamp26(2 * j), tB = c3b_clamp26(2 * j + 1);
         const int a = fbase + ((q >> 1) ? c3b_disp(tB) : c3b_disp(tA));
-        Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * C3B_IMG + a + t * C3B_ROWB);
+        Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * C3B_IMG + a + t * C3B_ROWB);
       };
       static_assert(JC % 2 == 0, "step 0 of the next tile pair goes to slot 0 while the last step reads slot 1");
       request_B(IC<0>{});
@@ -222,19 +226,23 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
       // every memory instruction behind ONE MFMA (tools_dev/micro/mfma_bf16_rate.hip): MFMA m of a phase = (weight piece jw,
         // tile nn, row t); behind the first eight the next phase's fragments, then (first phase of a step) the six weight
         // registers of the next step, then a halo slot of the next stage
-        c3b_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
-          constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
-          c3b_static_for<(3 - pc) * 2 * TY>([&](auto M) __attribute__((always_inline)) {
+        c3b_static_for<C3B_NP * JC>([&](auto PH) __attribute__((always_inline)) {
+          constexpr int ph = decltype(PH)::value, j = ph / C3B_NP, pc = ph % C3B_NP;
+          c3b_static_for<(2 - pc) * 2 * TY>([&](auto M) __attribute__((always_inline)) {
             constexpr int m = decltype(M)::value, jw = m / (2 * TY), nn = (m / TY) % 2, t = m % TY;
-            acc[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][nn][jw], Bq[ph & 1][t], acc[half * 2 + nn][t], 0, 0, 0);
+            if constexpr (pc == 0 && jw == 0)
+              acc[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][0], Bq[ph & 1][t], acc[half * 2 + nn][t], 0, 0, 0);
+            else
+              accx[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][pc == 0 ? 1 : 0], Bq[ph & 1][t], accx[half * 2 + nn][t], 0, 0, 0);
             if constexpr (m < TY) {
-              if constexpr (ph + 1 < 3 * JC) request_B1(IC<ph + 1>{}, IC<m>{});
-            } else if constexpr (pc == 0 && m < TY + 6) {
-              constexpr int e = m - TY, en = e / 3, ep = e % 3;
-              if constexpr (j + 1 < JC) A[(j + 1) & 1][en][ep] = wch[(((j + 1) * NT + half * 2 + en) * 3 + ep) * 64];
-              else if constexpr (half + 1 < NH) A[0][en][ep] = wch[((0 * NT + (half + 1) * 2 + en) * 3 + ep) * 64];      // step 0 of the next pair
-            } else if constexpr (half == 0 && pc < 2 && m == TY + 8) {
-              if constexpr (2 * j + pc < MAXS) pf_slot(T, 2 * j + pc);
+              if constexpr (ph + 1 < C3B_NP * JC) request_B1(IC<ph + 1>{}, IC<m>{});
+            } else if constexpr (pc == 0 && m < TY + 2 * C3B_NP) {
+              constexpr int e = m - TY, en = e / C3B_NP, ep = e % C3B_NP;
+              if constexpr (j + 1 < JC) A[(j + 1) & 1][en][ep] = wch[(((j + 1) * NTT + half * 2 + en) * C3B_NP + ep) * 64];
+              else if constexpr (half + 1 < NH) A[0][en][ep] = wch[((0 * NTT + (half + 1) * 2 + en) * C3B_NP + ep) * 64];      // step 0 of the next pair
+            } else if constexpr (half == 0 && pc == 0 && (m == TY + 6 || m == TY + 10)) {
+              constexpr int slot = 2 * j + (m == TY + 10 ? 1 : 0);
+              if constexpr (slot < MAXS) pf_slot(T, slot);
             }
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
@@ -248,23 +256,31 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
 #pragma unroll
           for (int nn = 0; nn < 2; ++nn)
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc) A[j & 1][nn][pc] = wch[((j * NT + hh * 2 + nn) * 3 + pc) * 64];
+            for (int pc = 0; pc < C3B_NP; ++pc) A[j & 1][nn][pc] = wch[((j * NTT + hh * 2 + nn) * C3B_NP + pc) * 64];
         };
-        c3b_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
-          constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
-          if constexpr (ph + 1 < 3 * JC) request_B(IC<ph + 1>{});
+        c3b_static_for<C3B_NP * JC>([&](auto PH) __attribute__((always_inline)) {
+          constexpr int ph = decltype(PH)::value, j = ph / C3B_NP, pc = ph % C3B_NP;
+          if constexpr (ph + 1 < C3B_NP * JC) request_B(IC<ph + 1>{});
           if constexpr (pc == 0 && j + 1 < JC) request_A(IC<j + 1>{}, IC<half>{});
           if constexpr (pc == 0 && j + 1 == JC && half + 1 < NH) request_A(IC<0>{}, IC<half + 1>{});    // step 0 of the next pair
           if constexpr (half == 0 && ph < MAXS) pf_slot(T, ph);
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int jw = 0; jw <= 2 - pc; ++jw)
-#pragma unroll
-            for (int nn = 0; nn < 2; ++nn)
+          for (int nn = 0; nn < 2; ++nn) {
+            if constexpr (pc == 0) {
 #pragma unroll
               for (int t = 0; t < TY; ++t)
-                acc[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][nn][jw], Bq[ph & 1][t], acc[half * 2 + nn][t], 0, 0, 0);
+                acc[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][0], Bq[ph & 1][t], acc[half * 2 + nn][t], 0, 0, 0);
+#pragma unroll
+              for (int t = 0; t < TY; ++t)
+                accx[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][1], Bq[ph & 1][t], accx[half * 2 + nn][t], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int t = 0; t < TY; ++t)
+                accx[half * 2 + nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][0], Bq[ph & 1][t], accx[half * 2 + nn][t], 0, 0, 0);
+            }
+          }
         });
       }
       static_assert(2 * JC >= MAXS, "two halo slots per K step");
@@ -277,16 +293,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
     const int zo = tz0 + wave, xo = tx0 + r;
     const bool evox_ok = zo < p.Di && xo < p.Wi;
     const unsigned erow = (unsigned)p.Wi * p.ldy;
-    const unsigned eo = (((unsigned)zo * p.Hi + ty0) * p.Wi + xo) * p.ldy + p.ycoff + q * 4;
+    const unsigned eo = (((unsigned)zo * p.Hi + ty0) * p.Wi + xo) * p.ldy + p.ycoff + hf * (NT * 16) + q * 4;
     const unsigned vo_ok = evox_ok ? eo * 4u : ybytes;
     c3b_static_for<NT>([&](auto NN) __attribute__((always_inline)) {
       constexpr int n = decltype(NN)::value;
-      const float4 bv = p.bias ? ld4(p.bias + n * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 bv = p.bias ? ld4(p.bias + hf * (NT * 16) + n * 16 + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
       c3b_static_for<TY>([&](auto TT) __attribute__((always_inline)) {
         constexpr int t = decltype(TT)::value;
         const bool row_ok = ty0 + t < p.Hi;
         const bool ok = evox_ok && row_ok;
-        float a0 = acc[n][t][0] + bv.x, a1 = acc[n][t][1] + bv.y, a2 = acc[n][t][2] + bv.z, a3 = acc[n][t][3] + bv.w;
+        float a0 = (acc[n][t][0] + accx[n][t][0] * C3B_IRS) + bv.x, a1 = (acc[n][t][1] + accx[n][t][1] * C3B_IRS) + bv.y;
+        float a2 = (acc[n][t][2] + accx[n][t][2] * C3B_IRS) + bv.z, a3 = (acc[n][t][3] + accx[n][t][3] * C3B_IRS) + bv.w;
         if (p.relu) {
           a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
           a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
@@ -325,30 +342,17 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
     __syncthreads();
     if (tid < 2 * CO) {
       const int which = tid / CO, col = tid % CO;
-      p.stats[((size_t)blockIdx.x * 2 + which) * CO + col] =
+      p.stats[((size_t)bidx * 2 + which) * (CO * p.nhalf) + hf * CO + col] =
           (s_red[(0 * 2 + which) * CO + col] + s_red[(1 * 2 + which) * CO + col]) +
           (s_red[(2 * 2 + which) * CO + col] + s_red[(3 * 2 + which) * CO + col]);
     }
   }
 }
 
-float c3b_round(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  float o;
-  std::memcpy(&o, &u, 4);
-  return o;
-}
-uint16_t c3b_bits(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  return (uint16_t)(u >> 16);
-}
 
 template <int NT>
 int launch_c3b(const C3bArgs& a, long grid, hipStream_t s) {
-  const size_t lds = 3 * (size_t)C3B_IMG;
+  const size_t lds = C3B_NP * (size_t)C3B_IMG;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
@@ -358,7 +362,7 @@ int launch_c3b(const C3bArgs& a, long grid, hipStream_t s) {
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv3d_b_kernel<NT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3d_b_kernel<NT>), dim3((unsigned)(grid * a.nhalf)), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -372,13 +376,13 @@ extern "C" int atvs_conv3d_b_supported(int Cin, int Cout) {
 extern "C" int atvs_conv3d_b_pack_size(int Cin, int Cout, long* packed_bytes) {
   if (!packed_bytes) return ATVS_ERR_NULL;
   if (!atvs_conv3d_b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
-  *packed_bytes = (long)(Cin / 16) * C3B_JC * (Cout / 16) * 3 * 1024 + 16;
+  *packed_bytes = (long)(Cin / 16) * C3B_JC * (Cout / 16) * C3B_NP * 1024 + 16;
   return ATVS_OK;
 }
 
 // HOST function.  packed[chunk][step j][tile n][piece][lane = q*16 + co16][8 bf16] = piece of
-// w[tap = 2 j + (q >> 1)][ci = 16 chunk + 8 (q & 1) + e][co = 16 n + co16] (zero for tap 27); pieces w0 = bf16(w),
-// w1 = bf16(w - w0), w2 = bf16(w - w0 - w1), round to nearest even.
+// w[tap = 2 j + (q >> 1)][ci = 16 chunk + 8 (q & 1) + e][co = 16 n + co16] (zero for tap 27); pieces g0 = f16(w),
+// g1 = f16((w - g0) * 2048), round to nearest even; ATVS_ERR_ARG for a weight beyond fp16's range.
 extern "C" int atvs_conv3d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed) {
   if (!w || !packed) return ATVS_ERR_NULL;
   long pb;
@@ -387,6 +391,7 @@ extern "C" int atvs_conv3d_b_pack(const float* w, int Cin, int Cout, unsigned ch
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
   const int NT = Cout / 16;
+  bool fits = true;
   for (int ch = 0; ch < Cin / 16; ++ch)
     for (int j = 0; j < C3B_JC; ++j)
       for (int n = 0; n < NT; ++n)
@@ -397,13 +402,14 @@ extern "C" int atvs_conv3d_b_pack(const float* w, int Cin, int Cout, unsigned ch
             for (int e = 0; e < 8; ++e) {
               const int ci = ch * 16 + (q & 1) * 8 + e;
               const float v = w[((size_t)tap * Cin + ci) * Cout + n * 16 + co];
-              const float p0 = c3b_round(v), p1 = c3b_round(v - p0), p2 = c3b_round((v - p0) - p1);
-              const float pc[3] = {p0, p1, p2};
-              for (int k = 0; k < 3; ++k)
-                out[(((((size_t)ch * C3B_JC + j) * NT + n) * 3 + k) * 64 + q * 16 + co) * 8 + e] = c3b_bits(pc[k]);
+              const _Float16 g0 = (_Float16)v, g1 = (_Float16)((v - (float)g0) * C3B_RS);
+              std::memcpy(&out[(((((size_t)ch * C3B_JC + j) * NT + n) * C3B_NP + 0) * 64 + q * 16 + co) * 8 + e], &g0, 2);
+              std::memcpy(&out[(((((size_t)ch * C3B_JC + j) * NT + n) * C3B_NP + 1) * 64 + q * 16 + co) * 8 + e], &g1, 2);
+              const float back = (float)g0;
+              fits &= (back - back == 0.f);
             }
         }
-  return ATVS_OK;
+  return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
 // y (G,D,H,W,ldy)[..., y_coff : y_coff + Cout] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,Cout], stride 1, SAME) (+ bias, ReLU),
@@ -419,7 +425,7 @@ extern "C" int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, 
   C3bArgs a;
   long pb;
   atvs_conv3d_b_pack_size(Cin, Cout, &pb);
-  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
   a.bias = bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16; a.relu = relu;
   a.tiles_y = (H + C3B_TY - 1) / C3B_TY; a.tiles_x = (W + C3B_TX - 1) / C3B_TX;
@@ -430,7 +436,9 @@ extern "C" int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, 
   const long grid = blocks * groups;
   if (grid > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
-  int rc = (Cout == 32) ? launch_c3b<2>(a, grid, st) : launch_c3b<4>(a, grid, st);
+  a.nhalf = Cout / 32; a.bh = (int)grid;
+  if (grid * a.nhalf > 0x7fffffffL) return ATVS_ERR_SHAPE;
+  int rc = launch_c3b<2>(a, grid, st);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

@@ -31,14 +31,16 @@ constexpr int s2_xsel(int kw) { return kw == 0 ? 0 : kw == 1 ? (S2_TX + 1) * S2_
 constexpr int s2_disp(int t) { return ((t / 9) * S2_HY + (t / 3) % 3) * S2_ROWB + s2_xsel(t % 3); }
 __device__ __forceinline__ constexpr int s2_xcol(int xx) { return ((xx & 1) ? (S2_TX + 1) + (xx >> 1) : (xx >> 1)) * S2_VB; }
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int S2_NP = 2;                                       // operand pieces: x = h0 + h1 / 2048 (conv_c16b.hip, round 4)
+constexpr float S2_RS = 2048.f, S2_IRS = 1.f / 2048.f;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct S2Args {
   const float* x;
-  const bf16x8* wp;
+  const f16x8* wp;
   const float* zeros;
   const float* bias;
   float* y;
@@ -65,17 +67,13 @@ __device__ __forceinline__ void s2_static_for(F&& f) {
   s2_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ void s2_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+__device__ __forceinline__ void s2_split(const float4& v, f16x4* p0, f16x4* p1) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
+    const _Float16 a = (_Float16)x[i];
     (*p0)[i] = a;
-    (*p1)[i] = b;
-    (*p2)[i] = (__bf16)r2;
+    (*p1)[i] = (_Float16)((x[i] - (float)a) * S2_RS);
   }
 }
 
@@ -85,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
   // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
   asm volatile("" ::: "v255", "a255");
-  constexpr int TY = S2_TY, HY = S2_HY, MAXS = S2_MAXS, JC = S2_JC, NTW = NT / 2, NM = 6 * NTW * TY;
+  constexpr int TY = S2_TY, HY = S2_HY, MAXS = S2_MAXS, JC = S2_JC, NTW = NT / 2, NM = 3 * NTW * TY;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -155,7 +153,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     pf[i] = ld4(ok ? (xg + (T.org + goff[i])) : p.zeros);
   };
 
-  f32x4 acc[NTW][TY];
+  f32x4 acc[NTW][TY], accx[NTW][TY];   // h0 g0 | (h0 g1 + h1 g0) * 2^11
   f32x2 ssum2[NTW][2], ssq2[NTW][2];
 #pragma unroll
   for (int n = 0; n < NTW; ++n) ssum2[n][0] = ssum2[n][1] = ssq2[n][0] = ssq2[n][1] = (f32x2){0.f, 0.f};
@@ -174,25 +172,24 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
 #pragma unroll
       for (int n = 0; n < NTW; ++n)
 #pragma unroll
-        for (int t = 0; t < TY; ++t) acc[n][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < TY; ++t) acc[n][t] = accx[n][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // weight pieces of this chunk: [step][tile][piece][lane]
-    const bf16x8* wch = p.wp + ((size_t)ch * JC * NT * 3 + (size_t)wn * NTW * 3) * 64 + lane;
-    bf16x8 A[2][NTW][3], B[2][3][TY];
+    const f16x8* wch = p.wp + ((size_t)ch * JC * NT * S2_NP + (size_t)wn * NTW * S2_NP) * 64 + lane;
+    f16x8 A[2][NTW][S2_NP], B[2][S2_NP][TY];
 #pragma unroll
     for (int nn = 0; nn < NTW; ++nn)
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) A[0][nn][pc] = wch[(nn * 3 + pc) * 64];
+      for (int pc = 0; pc < S2_NP; ++pc) A[0][nn][pc] = wch[(nn * S2_NP + pc) * 64];
 
     __syncthreads();                       // every wavefront is done reading the previous stage's images
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < S2_SLOTS) {
-        bf16x4 p0, p1, p2;
-        s2_split(pf[i], &p0, &p1, &p2);
-        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
-        *reinterpret_cast<bf16x4*>(smem + S2_IMG + laddr[i]) = p1;
-        *reinterpret_cast<bf16x4*>(smem + 2 * S2_IMG + laddr[i]) = p2;
+        f16x4 p0, p1;
+        s2_split(pf[i], &p0, &p1);
+        *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<f16x4*>(smem + S2_IMG + laddr[i]) = p1;
       }
     }
     __syncthreads();
@@ -203,28 +200,29 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
       constexpr int j = decltype(JT)::value, pc = decltype(PC)::value, t = decltype(TT)::value;
       constexpr int tA = s2_clamp26(2 * j), tB = s2_clamp26(2 * j + 1);
       const int a = fbase + ((q >> 1) ? s2_disp(tB) : s2_disp(tA));
-      B[j & 1][pc][t] = *reinterpret_cast<const bf16x8*>(smem + pc * S2_IMG + a + 2 * t * S2_ROWB);
+      B[j & 1][pc][t] = *reinterpret_cast<const f16x8*>(smem + pc * S2_IMG + a + 2 * t * S2_ROWB);
     };
-    s2_static_for<3 * TY>([&](auto M) __attribute__((always_inline)) {
+    s2_static_for<S2_NP * TY>([&](auto M) __attribute__((always_inline)) {
       constexpr int m = decltype(M)::value;
       fragment(IC<0>{}, IC<m / TY>{}, IC<m % TY>{});
     });
     asm volatile("" ::: "memory");
-    // ---- K loop: 14 steps of two taps x 16 channels; MFMA m of a step = (piece pc, weight piece jw <= 2 - pc, tile nn, row t);
-    // behind MFMA m: m < 12 the next step's fragments, then its weights, then two halo slots of the next stage
+    // ---- K loop: 14 steps of two taps x 16 channels; MFMA m of a step = (product pr: h0 g0 | h0 g1 | h1 g0, tile nn, row t);
+    // behind MFMA m: m < 8 the next step's fragments, then its weights, then two halo slots of the next stage
     s2_static_for<JC>([&](auto JT) __attribute__((always_inline)) {
       constexpr int j = decltype(JT)::value;
       s2_static_for<NM>([&](auto M) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value, pr = m / (NTW * TY), nn = (m / TY) % NTW, t = m % TY;
-        constexpr int pc = pr < 3 ? 0 : pr < 5 ? 1 : 2, jw = pr - (pc == 0 ? 0 : pc == 1 ? 3 : 5);
-        acc[nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][nn][jw], B[j & 1][pc][t], acc[nn][t], 0, 0, 0);
-        if constexpr (m < 3 * TY) {
+        constexpr int pc = pr < 2 ? 0 : 1, jw = pr == 1 ? 1 : 0;
+        if constexpr (pr == 0) acc[nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][0], B[j & 1][0][t], acc[nn][t], 0, 0, 0);
+        else accx[nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][jw], B[j & 1][pc][t], accx[nn][t], 0, 0, 0);
+        if constexpr (m < S2_NP * TY) {
           if constexpr (j + 1 < JC) fragment(IC<j + 1>{}, IC<m / TY>{}, IC<m % TY>{});
-        } else if constexpr (m < 3 * TY + 3 * NTW) {
-          constexpr int e = m - 3 * TY;
-          if constexpr (j + 1 < JC) A[(j + 1) & 1][e / 3][e % 3] = wch[(((j + 1) * NT + e / 3) * 3 + e % 3) * 64];
-        } else if constexpr (m == 3 * TY + 3 * NTW || m == 3 * TY + 3 * NTW + 2) {
-          constexpr int s = 2 * j + (m - 3 * TY - 3 * NTW) / 2;
+        } else if constexpr (m < S2_NP * TY + S2_NP * NTW) {
+          constexpr int e = m - S2_NP * TY;
+          if constexpr (j + 1 < JC) A[(j + 1) & 1][e / S2_NP][e % S2_NP] = wch[(((j + 1) * NT + e / S2_NP) * S2_NP + e % S2_NP) * 64];
+        } else if constexpr (m == S2_NP * TY + S2_NP * NTW || m == S2_NP * TY + S2_NP * NTW + 1) {
+          constexpr int s = 2 * j + (m - S2_NP * TY - S2_NP * NTW);
           if constexpr (s < MAXS) pf_slot(T, s);
         }
         asm volatile("" ::: "memory");
@@ -248,7 +246,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
         constexpr int t = decltype(TT)::value;
         const bool row_ok = ty0 + t < p.Ho;
         const bool ok = evox_ok && row_ok;
-        float a0 = acc[n][t][0] + bv.x, a1 = acc[n][t][1] + bv.y, a2 = acc[n][t][2] + bv.z, a3 = acc[n][t][3] + bv.w;
+        float a0 = (acc[n][t][0] + accx[n][t][0] * S2_IRS) + bv.x, a1 = (acc[n][t][1] + accx[n][t][1] * S2_IRS) + bv.y;
+        float a2 = (acc[n][t][2] + accx[n][t][2] * S2_IRS) + bv.z, a3 = (acc[n][t][3] + accx[n][t][3] * S2_IRS) + bv.w;
         if (p.relu) {
           a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
           a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
@@ -293,23 +292,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   }
 }
 
-float s2_round(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  float o;
-  std::memcpy(&o, &u, 4);
-  return o;
-}
-uint16_t s2_bits(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  return (uint16_t)(u >> 16);
-}
-
 template <int NT>
 int launch_s2b(const S2Args& a, long grid, hipStream_t s) {
-  const size_t lds = 3 * (size_t)S2_IMG;
+  const size_t lds = S2_NP * (size_t)S2_IMG;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
@@ -347,7 +332,7 @@ extern "C" long atvs_conv3d_s2b_grid(int Do, int Ho, int Wo, int groups) {
 extern "C" int atvs_conv3d_s2b_pack_size(int Cin, int Cout, long* packed_bytes) {
   if (!packed_bytes) return ATVS_ERR_NULL;
   if (!atvs_conv3d_s2b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
-  *packed_bytes = (long)(Cin / 16) * S2_JC * (Cout / 16) * 3 * 1024 + 16;
+  *packed_bytes = (long)(Cin / 16) * S2_JC * (Cout / 16) * S2_NP * 1024 + 16;
   return ATVS_OK;
 }
 
@@ -361,6 +346,7 @@ extern "C" int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned 
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
   const int NT = Cout / 16;
+  bool fits = true;
   for (int ch = 0; ch < Cin / 16; ++ch)
     for (int j = 0; j < S2_JC; ++j)
       for (int n = 0; n < NT; ++n)
@@ -371,13 +357,14 @@ extern "C" int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned 
             for (int e = 0; e < 8; ++e) {
               const int ci = ch * 16 + (q & 1) * 8 + e;
               const float v = w[((size_t)tap * Cin + ci) * Cout + n * 16 + co];
-              const float p0 = s2_round(v), p1 = s2_round(v - p0), p2 = s2_round((v - p0) - p1);
-              const float pc[3] = {p0, p1, p2};
-              for (int k = 0; k < 3; ++k)
-                out[(((((size_t)ch * S2_JC + j) * NT + n) * 3 + k) * 64 + q * 16 + co) * 8 + e] = s2_bits(pc[k]);
+              const _Float16 g0 = (_Float16)v, g1 = (_Float16)((v - (float)g0) * S2_RS);
+              std::memcpy(&out[(((((size_t)ch * S2_JC + j) * NT + n) * S2_NP + 0) * 64 + q * 16 + co) * 8 + e], &g0, 2);
+              std::memcpy(&out[(((((size_t)ch * S2_JC + j) * NT + n) * S2_NP + 1) * 64 + q * 16 + co) * 8 + e], &g1, 2);
+              const float back = (float)g0;
+              fits &= (back - back == 0.f);
             }
         }
-  return ATVS_OK;
+  return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
 // y (G,Do,Ho,Wo,ldy)[..., y_coff : y_coff + Cout] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,Cout], stride 2, SAME) (+ bias, ReLU),
@@ -394,7 +381,7 @@ extern "C" int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w
   S2Args a;
   long pb;
   atvs_conv3d_s2b_pack_size(Cin, Cout, &pb);
-  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
   a.bias = bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
   a.pbz = (2 * (Do - 1) + 3 - D) / 2; a.pby = (2 * (Ho - 1) + 3 - H) / 2; a.pbx = (2 * (Wo - 1) + 3 - W) / 2;

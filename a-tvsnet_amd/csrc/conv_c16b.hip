@@ -1,16 +1,16 @@
-// The 8 / 16 -> 16 channel 3x3x3 convolutions of conv_c16.hip on the bf16 matrix
-// cores with SPLIT operands -- BASELINE.json configs[1] names "bf16 conv3d MFMA"; plain bf16 operands miss the 1e-3 depth
-// bar by a factor 200, so every fp32 operand is split into three bf16 pieces
-//     x = x0 + x1 + x2,   x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)        (24 mantissa bits kept)
-// and the six products x_i * w_j with i + j <= 2 are accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (a product of two
-// bf16 values is exact in fp32; dropped terms ~2^-24): fp32-class results (tools_dev/bf16_split_emulation.py: final depth
-// 1.2e-5 from the fp32 oracle at configs[0], 4.5e-4 from the float64 networks at configs[1] against the fp32 oracle's
-// 4.3e-4) for 6/16 of the fp32 MFMA time: one K = 32 instruction (16 cycles) covers two taps x 16 channels, which takes
-// eight 16x16x4 fp32 instructions (256 cycles); six of them = 96 cycles.
+// The 8 / 16 -> 16 channel 3x3x3 convolutions of conv_c16.hip on the 16-bit matrix cores with SPLIT operands -- BASELINE.json
+// configs[1] names "bf16 conv3d MFMA"; plain bf16 operands miss the 1e-3 depth bar by a factor 200.  Round 4:
+// every fp32 operand = TWO fp16 pieces,
+//     x = h0 + h1 / 2048,   h0 = f16(x), h1 = f16((x - h0) * 2048)        (22 significant bits; the residual scaled into fp16's
+//                                                                            normal range: no denormal loss)
+// and THREE products on v_mfma_f32_16x16x32_f16 with fp32 accumulation: h0 g0 into the main accumulator, h0 g1 + h1 g0 into a
+// second one scaled by 2^-11 in the epilogue (conv_xb.hip has the measurements: per-layer error against a double sum below
+// the fp32 matrix cores' and below round 3's three bf16 pieces / six products).  One K = 32 instruction (16 cycles) covers two
+// taps x 16 channels, which takes eight 16x16x4 fp32 instructions (256 cycles); three of them = 48 cycles.
 //
 // Structure = conv_c16.hip's 8-channel form (32-byte voxels, two taps per K step, lane half q >> 1 picks the tap): here a
-// voxel of one PIECE image is 16 channels x 2 bytes = 32 bytes, the three piece images lie IMG bytes apart, the split is
-// done once per staged element on its way into LDS, the packed weights (three pieces per K step, split on the host) are
+// voxel of one PIECE image is 16 channels x 2 bytes = 32 bytes, the two piece images lie IMG bytes apart, the split is
+// done once per staged element on its way into LDS, the packed weights (two pieces per K step, split on the host) are
 // resident in LDS.  Cout = 16, Cin = 16 (conv_b*_1_1, global_refine_3dconv1_1: two taps per K step) or Cin = 8 (the AANet
 // modules' shared | unique convolution: four taps per K step, 16-byte voxels).
 #include <cstring>
@@ -38,21 +38,23 @@ struct B16 {
   static constexpr int SLOTS = B16_HZ * B16_HY * B16_HX * C4;
   static constexpr int MAXS = (SLOTS + 255) / 256;              // 9 / 17 per thread
   static constexpr int JC = (27 + TPS - 1) / TPS;               // K steps: 7 / 14 (taps past 26 = zero weights)
-  static_assert(MAXS <= 3 * JC, "one halo slot per phase of the K loop");
+  static_assert(MAXS <= 2 * JC, "two halo slots per K step");
   // byte displacement of tap t from halo voxel (wave, 0, r): (kd, kh) rows + kw voxels
   static constexpr int clamp26(int t) { return t < 26 ? t : 26; }
   static constexpr int disp(int t) { return ((t / 9) * B16_HY + (t / 3) % 3) * ROWB + (t % 3) * VB; }
 };
-constexpr int B16_WSTEP = 3 * 1024;                           // bytes of packed weights per K step (3 pieces x 64 lanes x 16 B)
+constexpr int B16_NP = 2;                                     // operand pieces
+constexpr int B16_WSTEP = B16_NP * 1024;                      // bytes of packed weights per K step (2 pieces x 64 lanes x 16 B)
+constexpr float B16_RS = 2048.f, B16_IRS = 1.f / 2048.f;      // scale of the residual piece and its inverse
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct B16Args {
   const float* x;
-  const unsigned char* wp;     // packed bf16 pieces (atvs_conv_c16b_pack)
+  const unsigned char* wp;     // packed fp16 pieces (atvs_conv_c16b_pack)
   const float* zeros;          // 16 zero bytes
   const float* bias;
   float* y;
@@ -75,18 +77,14 @@ __device__ __forceinline__ void b16_static_for(F&& f) {
   b16_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// the three bf16 pieces of four fp32 values
-__device__ __forceinline__ void b16_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+// the two fp16 pieces of four fp32 values: h0 = f16(x), h1 = f16((x - h0) * 2^11)
+__device__ __forceinline__ void b16_split(const float4& v, f16x4* p0, f16x4* p1) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
+    const _Float16 a = (_Float16)x[i];
     (*p0)[i] = a;
-    (*p1)[i] = b;
-    (*p2)[i] = (__bf16)r2;
+    (*p1)[i] = (_Float16)((x[i] - (float)a) * B16_RS);
   }
 }
 
@@ -106,12 +104,12 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
   // packed weights -> LDS, once
   {
     const float4* src = reinterpret_cast<const float4*>(p.wp);
-    float4* dst = reinterpret_cast<float4*>(smem + 3 * B16_IMG);
+    float4* dst = reinterpret_cast<float4*>(smem + B16_NP * B16_IMG);
     for (int i = tid; i < JC * (B16_WSTEP / 16); i += 256) dst[i] = src[i];
   }
   // this lane's B fragment (8 consecutive channels of a voxel) at halo voxel (wave, 0, r), tap (0,0,0)
   const int fbase = ((wave * HY) * B16_HX + r) * B16_VB + (q % K::LPT) * 16;
-  const int wbase = 3 * B16_IMG + lane * 16;
+  const int wbase = B16_NP * B16_IMG + lane * 16;
 
   // halo slots: float4 = channels 4 c4 .. of a voxel -> 8 bytes at (voxel, c4) of each piece image
   int goff[MAXS], laddr[MAXS];
@@ -174,7 +172,7 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
 
   f32x2 ssum2[2], ssq2[2];
   ssum2[0] = ssum2[1] = ssq2[0] = ssq2[1] = (f32x2){0.f, 0.f};
-  f32x4 acc[TY];
+  f32x4 acc[TY], accx[TY];             // h0 g0 | (h0 g1 + h1 g0) * 2^11
   const float4 bv = p.bias ? ld4(p.bias + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   const unsigned ybytes = (unsigned)(p.gy * 4);
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
@@ -187,29 +185,28 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
 
   for (int k = 0; k < my_tiles; ++k) {
 #pragma unroll
-    for (int t = 0; t < TY; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();                       // every wavefront is done reading the previous tile's images
-    // split the staged fp32 halo into its three bf16 pieces on the way into LDS
+    // split the staged fp32 halo into its two fp16 pieces on the way into LDS
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < B16_SLOTS) {
-        bf16x4 p0, p1, p2;
-        b16_split(pf[i], &p0, &p1, &p2);
-        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
-        *reinterpret_cast<bf16x4*>(smem + B16_IMG + laddr[i]) = p1;
-        *reinterpret_cast<bf16x4*>(smem + 2 * B16_IMG + laddr[i]) = p2;
+        f16x4 p0, p1;
+        b16_split(pf[i], &p0, &p1);
+        *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<f16x4*>(smem + B16_IMG + laddr[i]) = p1;
       }
     }
     __syncthreads();
 
     const PfTile T = pf_tile(min(k + 1, my_tiles - 1));      // last tile: harmless re-read of its own halo
 
-    // ---- K loop: 14 steps of two taps x 16 channels, each in three phases -- input piece i = 0, 1, 2 with the weight
-    // pieces j <= 2 - i (24 / 16 / 8 MFMAs): the fragments of ONE input piece are live at a time (the next phase's are
-    // requested in front of this phase's MFMAs), the three weight pieces of a step are requested one step ahead
-    bf16x8 Bq[2][TY], A[2][3];
+    // ---- K loop: 14 steps of two taps x 16 channels, each in two phases -- input piece h0 with both weight pieces (16 MFMAs),
+    // h1 with g0 (8): the fragments of ONE input piece are live at a time (the next phase's are requested behind this
+    // phase's first MFMAs), the two weight pieces of a step are requested one step ahead
+    f16x8 Bq[2][TY], A[2][B16_NP];
     auto request_B = [&](auto PH) __attribute__((always_inline)) {
-      constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
+      constexpr int ph = decltype(PH)::value, j = ph / B16_NP, pc = ph % B16_NP;
       // this lane group's tap of the step (taps past 26 have zero weights: re-read tap 26's fragment)
       constexpr int tA = K::clamp26(K::TPS * j), tB = K::clamp26(K::TPS * j + 1), tC = K::clamp26(K::TPS * j + 2), tD = K::clamp26(K::TPS * j + 3);
       int a;
@@ -217,20 +214,20 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
       else a = fbase + ((q & 2) ? ((q & 1) ? K::disp(tD) : K::disp(tC)) : ((q & 1) ? K::disp(tB) : K::disp(tA)));
 #pragma unroll
       for (int t = 0; t < TY; ++t)
-        Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
+        Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
     };
     auto request_B1 = [&](auto PH, auto TT) __attribute__((always_inline)) {      // row t of phase ph
-      constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3, t = decltype(TT)::value;
+      constexpr int ph = decltype(PH)::value, j = ph / B16_NP, pc = ph % B16_NP, t = decltype(TT)::value;
       constexpr int tA = K::clamp26(K::TPS * j), tB = K::clamp26(K::TPS * j + 1), tC = K::clamp26(K::TPS * j + 2), tD = K::clamp26(K::TPS * j + 3);
       int a;
       if constexpr (K::TPS == 2) a = fbase + ((q >> 1) ? K::disp(tB) : K::disp(tA));
       else a = fbase + ((q & 2) ? ((q & 1) ? K::disp(tD) : K::disp(tC)) : ((q & 1) ? K::disp(tB) : K::disp(tA)));
-      Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
+      Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * B16_IMG + a + t * B16_ROWB);
     };
     auto request_A = [&](auto JT) __attribute__((always_inline)) {
       constexpr int j = decltype(JT)::value;
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) A[j & 1][pc] = *reinterpret_cast<const bf16x8*>(smem + wbase + j * B16_WSTEP + pc * 1024);
+      for (int pc = 0; pc < B16_NP; ++pc) A[j & 1][pc] = *reinterpret_cast<const f16x8*>(smem + wbase + j * B16_WSTEP + pc * 1024);
     };
     request_A(IC<0>{});
     request_B(IC<0>{});
@@ -238,17 +235,19 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     // every memory instruction behind ONE MFMA (tools_dev/micro/mfma_bf16_rate.hip: issued in a bunch at the top of a phase they
     // cost matrix-core time): MFMA m of a phase = (weight piece jw, row t); behind the first eight the next phase's fragments,
     // then (first phase of a step) the next step's weights, then a halo slot of the next stage
-    b16_static_for<3 * JC>([&](auto PH) __attribute__((always_inline)) {
-      constexpr int ph = decltype(PH)::value, j = ph / 3, pc = ph % 3;
-      b16_static_for<(3 - pc) * TY>([&](auto M) __attribute__((always_inline)) {
+    b16_static_for<B16_NP * JC>([&](auto PH) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH)::value, j = ph / B16_NP, pc = ph % B16_NP;
+      b16_static_for<(2 - pc) * TY>([&](auto M) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value, jw = m / TY, t = m % TY;
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[j & 1][jw], Bq[ph & 1][t], acc[t], 0, 0, 0);
+        if constexpr (pc == 0 && jw == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][0], Bq[ph & 1][t], acc[t], 0, 0, 0);
+        else accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][pc == 0 ? 1 : 0], Bq[ph & 1][t], accx[t], 0, 0, 0);
         if constexpr (m < TY) {
-          if constexpr (ph + 1 < 3 * JC) request_B1(IC<ph + 1>{}, IC<m>{});
-        } else if constexpr (pc == 0 && m < TY + 3) {
-          if constexpr (j + 1 < JC) A[(j + 1) & 1][m - TY] = *reinterpret_cast<const bf16x8*>(smem + wbase + (j + 1) * B16_WSTEP + (m - TY) * 1024);
-        } else if constexpr (m == TY + 4 && pc < 2) {
-          if constexpr (2 * j + pc < MAXS) pf_slot(T, 2 * j + pc);
+          if constexpr (ph + 1 < B16_NP * JC) request_B1(IC<ph + 1>{}, IC<m>{});
+        } else if constexpr (m < TY + B16_NP) {
+          if constexpr (j + 1 < JC) A[(j + 1) & 1][m - TY] = *reinterpret_cast<const f16x8*>(smem + wbase + (j + 1) * B16_WSTEP + (m - TY) * 1024);
+        } else if constexpr (m == TY + 3 || m == TY + 6) {
+          constexpr int slot = 2 * j + (m == TY + 6 ? 1 : 0);
+          if constexpr (slot < MAXS) pf_slot(T, slot);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
@@ -268,7 +267,8 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
       constexpr int t = decltype(TT)::value;
       const bool row_ok = ty0 + t < p.Hi;
       const bool ok = evox_ok && row_ok;
-      float a0 = acc[t][0] + bv.x, a1 = acc[t][1] + bv.y, a2 = acc[t][2] + bv.z, a3 = acc[t][3] + bv.w;
+      float a0 = (acc[t][0] + accx[t][0] * B16_IRS) + bv.x, a1 = (acc[t][1] + accx[t][1] * B16_IRS) + bv.y;
+      float a2 = (acc[t][2] + accx[t][2] * B16_IRS) + bv.z, a3 = (acc[t][3] + accx[t][3] * B16_IRS) + bv.w;
       if (RELU) {
         a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
         a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
@@ -310,20 +310,6 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
   }
 }
 
-// round-to-nearest-even bf16 of a finite float, as a float
-static float b16_round(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  float o;
-  std::memcpy(&o, &u, 4);
-  return o;
-}
-static uint16_t b16_bits(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  return (uint16_t)(u >> 16);
-}
 
 }  // namespace
 
@@ -336,8 +322,8 @@ extern "C" int atvs_conv_c16b_pack_size(int Cin, long* packed_bytes) {
 }
 
 // HOST function.  packed[step j][piece][lane = q*16 + co][8 bf16] = piece of w[tap = TPS*j + q / LPT][ci = (q % LPT)*8 + e][co]
-// (TPS = 32 / Cin taps per step, LPT = 4 / TPS lane groups per tap; zero for taps past 26), pieces w0 = bf16(w),
-// w1 = bf16(w - w0), w2 = bf16(w - w0 - w1), round to nearest even.
+// (TPS = 32 / Cin taps per step, LPT = 4 / TPS lane groups per tap; zero for taps past 26), pieces g0 = f16(w),
+// g1 = f16((w - g0) * 2048), round to nearest even.  ATVS_ERR_ARG if a weight does not fit fp16's range (|w| > 65504).
 extern "C" int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packed) {
   if (!w || !packed) return ATVS_ERR_NULL;
   long pb;
@@ -346,6 +332,7 @@ extern "C" int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packe
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
   const int TPS = 32 / Cin, LPT = 4 / TPS, JC = (27 + TPS - 1) / TPS;
+  bool fits = true;
   for (int j = 0; j < JC; ++j)
     for (int q = 0; q < 4; ++q) {
       const int tap = TPS * j + q / LPT;
@@ -354,19 +341,20 @@ extern "C" int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packe
         for (int e = 0; e < 8; ++e) {
           const int ci = (q % LPT) * 8 + e;
           const float v = w[((size_t)tap * Cin + ci) * 16 + co];
-          const float p0 = b16_round(v), p1 = b16_round(v - p0), p2 = b16_round((v - p0) - p1);
-          const float pc[3] = {p0, p1, p2};
-          for (int k = 0; k < 3; ++k)
-            out[(((size_t)j * 3 + k) * 64 + q * 16 + co) * 8 + e] = b16_bits(pc[k]);
+          const _Float16 g0 = (_Float16)v, g1 = (_Float16)((v - (float)g0) * B16_RS);
+          std::memcpy(&out[(((size_t)j * B16_NP + 0) * 64 + q * 16 + co) * 8 + e], &g0, 2);
+          std::memcpy(&out[(((size_t)j * B16_NP + 1) * 64 + q * 16 + co) * 8 + e], &g1, 2);
+          const float back = (float)g0;
+          fits &= (back - back == 0.f);
         }
     }
-  return ATVS_OK;
+  return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
 namespace {
 template <int CIN, bool RELU>
 int launch_c16b(const B16Args& a, long grid, hipStream_t s) {
-  const size_t lds = 3 * (size_t)B16<CIN>::IMG + (size_t)B16<CIN>::JC * B16_WSTEP;
+  const size_t lds = B16_NP * (size_t)B16<CIN>::IMG + (size_t)B16<CIN>::JC * B16_WSTEP;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;

@@ -2026,34 +2026,6 @@ def aanet_combine(srs, xs, out=None):
     return out
 
 
-_USE_AANET_FUSED = False       # measured: 27.87 against 27.83 ms per depth map at configs[2], 97.0 against 95.8 at configs[3]
-
-
-def use_aanet_fused(flag):
-    """The score convolution of every view and the cross-view combine in one launch (aanet_fused.hip): bit-identical to the
-    two launches, no [S | R] tensors in memory (1 GB at configs[2], 2.6 GB at configs[3]), not faster -- off by default."""
-    global _USE_AANET_FUSED
-    _USE_AANET_FUSED = bool(flag)
-
-
-def aanet_fused_ok(stacked):
-    """Can the AANet module of these stacked views (N,D,H,W,8) run as one launch?"""
-    return (_USE_AANET_FUSED and _USE_BF16X3 and _USE_C16 and _FORCE_IMPL is None and stacked.dim() == 5
-            and stacked.shape[-1] == 8 and stacked.is_contiguous() and stacked.shape[3] >= 12
-            and bool(_lib.lib().atvs_aanet_fused_supported(int(stacked.shape[0])))
-            and 32.0 * stacked[0].numel() < 2.0 ** 31)
-
-
-def aanet_fused(stacked, key, w16_host):
-    """AANet aggregation of the N views stacked (N,D,H,W,8): relu(conv3x3x3(x_n, [shared | unique])) and the cross-view
-    softmax + weighted sum in ONE launch (atvs_aanet_fused_f32) -> (D,H,W,8); bit-identical to conv + aanet_combine."""
-    N, D, H, W, _ = stacked.shape
-    pk = pack_conv_c16b(key, w16_host, stacked.device)
-    out = _new(stacked, (D, H, W, 8))
-    if _dev_ok(stacked, out):
-        with _Timed(key, (D, H, W, 8), 16, N):
-            _call('atvs_aanet_fused_f32', _p(stacked), _p(pk.wp), _p(out), int(N), int(D), int(H), int(W), _stream())
-    return out
 
 
 def aanet_partial(srs, xs, stage, ssum=None, umax=None):

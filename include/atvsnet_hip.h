@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 26
+#define ATVS_ABI_VERSION 27
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -394,15 +394,6 @@ int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned char* pack
 int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups, int D, int H,
                          int W, int Cin, int Cout, int ldy, int y_coff, int relu, int stats_ld, int stats_coff,
                          atvs_stream_t stream);
-
-/* AANet aggregation over nv source views in ONE launch (aanet_fused.hip; network.py:282-351, 378-408): the shared | unique
- * 3x3x3 8 -> 16 convolution of every view (split-bf16 operands, ReLU: atvs_conv_c16b_f32 with packed_w =
- * atvs_conv_c16b_pack(Cin = 8) of [shared | unique]) and atvs_aanet_combine's cross-view softmax + weighted sum, the scores staying
- * in registers.  x (nv,D,H,W,8) -> out (D,H,W,8), bit-identical to the two launches; nv: atvs_aanet_fused_supported (2, 3, 4, 8). */
-int atvs_aanet_fused_supported(int nv);
-int atvs_aanet_fused_f32(const float* x, const unsigned char* packed_w, float* out, int nv, int D, int H, int W,
-                         atvs_stream_t stream);
-
 /* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
  * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a
  * sliding register window along z, not MFMA (conv_stem.hip).  x (groups,D,H,W,Cin), Cin in {1,2}; w = the TF kernel

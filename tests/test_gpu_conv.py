@@ -511,32 +511,6 @@ def test_conv3d_s2b_stride2_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cou
         ops.clear_pack_cache()
 
 
-@pytest.mark.parametrize('nv', [2, 3, 4, 8])
-@pytest.mark.parametrize('D,H,W', [(8, 16, 32), (9, 19, 21), (5, 8, 12)])
-def test_aanet_fused_equals_two_launches(cuda, nv, D, H, W):
-    """The AANet module in one launch (aanet_fused.hip: score convolution of every view + cross-view softmax + weighted sum,
-    scores in registers) is BIT-identical to atvs_conv_c16b_f32 (ReLU) followed by atvs_aanet_combine, and matches the oracle's
-    attention_aggregation at the bar of tests/test_gpu_aanet.py."""
-    from atvsnet_amd import ops
-    from oracle import nets
-    x = _rand((nv, D, H, W, 8), 95)
-    w16 = _rand((3, 3, 3, 8, 16), 96, 0.15)
-    xd = x.to(cuda)
-    ops.clear_pack_cache()
-    ops.use_aanet_fused(True)
-    try:
-        assert ops.aanet_fused_ok(xd)
-    finally:
-        ops.use_aanet_fused(False)           # the default
-    got = ops.aanet_fused(xd, ('af', nv), w16.numpy())
-    sr = ops.conv(xd, ('af', nv), w16.numpy(), relu=True, groups=nv)
-    two = ops.aanet_combine([sr[n] for n in range(nv)], [xd[n] for n in range(nv)])
-    assert torch.equal(got, two)
-    W_ = {'a/attention_activation/weight_shared': w16[..., :8].contiguous(), 'a/attention_activation/weight_unique': w16[..., 8:].contiguous()}
-    want = nets.attention_aggregation(x.permute(1, 2, 3, 4, 0)[None].contiguous(), W_, 'a')[0]
-    assert float((got.cpu() - want).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
-
-
 def test_conv_split_siblings_match_dense(cuda):
     from atvsnet_amd import ops
     ops.clear_pack_cache()
