@@ -19,14 +19,16 @@ namespace {
 
 constexpr int C1B_PX = 128;                   // pixels per workgroup
 constexpr int C1B_PIMG = C1B_PX * 64;         // bytes of one piece image (32 channels x 2 B per pixel)
-constexpr int C1B_BUFB = 3 * C1B_PIMG;
+constexpr int C1B_NP = 2;                     // operand pieces: x = h0 + h1 / 2048 (conv_c16b.hip, round 4)
+constexpr float C1B_RS = 2048.f, C1B_IRS = 1.f / 2048.f;
+constexpr int C1B_BUFB = C1B_NP * C1B_PIMG;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct C1bArgs {
   const float* x;
-  const bf16x8* wp;
+  const f16x8* wp;
   const float* bias;
   const float* res;
   const float* in_params;
@@ -41,17 +43,13 @@ struct C1bArgs {
 
 __device__ __forceinline__ int c1b_swz(int a) { return a ^ (((a >> 9) & 1) << 5); }
 
-__device__ __forceinline__ void c1b_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+__device__ __forceinline__ void c1b_split(const float4& v, f16x4* p0, f16x4* p1) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
+    const _Float16 a = (_Float16)x[i];
     (*p0)[i] = a;
-    (*p1)[i] = b;
-    (*p2)[i] = (__bf16)r2;
+    (*p1)[i] = (_Float16)((x[i] - (float)a) * C1B_RS);
   }
 }
 
@@ -102,12 +100,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
       }
-      bf16x4 p0, p1, p2;
-      c1b_split(v, &p0, &p1, &p2);
+      f16x4 p0, p1;
+      c1b_split(v, &p0, &p1);
       unsigned char* d = smem + buf * C1B_BUFB + laddr[i];
-      *reinterpret_cast<bf16x4*>(d) = p0;
-      *reinterpret_cast<bf16x4*>(d + C1B_PIMG) = p1;
-      *reinterpret_cast<bf16x4*>(d + 2 * C1B_PIMG) = p2;
+      *reinterpret_cast<f16x4*>(d) = p0;
+      *reinterpret_cast<f16x4*>(d + C1B_PIMG) = p1;
     }
   };
 
@@ -115,44 +112,44 @@ __global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
   const int fb = c1b_swz(r * 64 + q * 16) + wr * TYW * 1024;
 
   // packed weight pieces: [chunk][NT tiles][3 pieces][64 lanes] bf16x8, one zero chunk at the end
-  const bf16x8* __restrict__ wl = p.wp + (size_t)(wn * NTW) * 3 * 64 + lane;
-  constexpr int WSTEP = NT * 3 * 64;
-  bf16x8 Aw[2][NTW][3];
+  const f16x8* __restrict__ wl = p.wp + (size_t)(wn * NTW) * C1B_NP * 64 + lane;
+  constexpr int WSTEP = NT * C1B_NP * 64;
+  f16x8 Aw[2][NTW][C1B_NP];
 #pragma unroll
   for (int n = 0; n < NTW; ++n)
 #pragma unroll
-    for (int w3 = 0; w3 < 3; ++w3) Aw[0][n][w3] = wl[(n * 3 + w3) * 64];
+    for (int w3 = 0; w3 < C1B_NP; ++w3) Aw[0][n][w3] = wl[(n * C1B_NP + w3) * 64];
 
-  f32x4 acc[TYW][NTW];
+  f32x4 acc[TYW][NTW], accx[TYW][NTW];  // h0 g0 | (h0 g1 + h1 g0) * 2^11
 #pragma unroll
   for (int t = 0; t < TYW; ++t)
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NTW; ++n) acc[t][n] = accx[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int i = 0; i < MAXS; ++i) pf_slot(i, 0);
   write_image(0, 0);
   __syncthreads();
 
-  bf16x8 Bq[2][TYW];
+  f16x8 Bq[2][TYW];
   auto chunk = [&](auto PAR, int ch) __attribute__((always_inline)) {
     constexpr int par = decltype(PAR)::value;                 // ch & 1: LDS buffer and weight slot of the chunk
     const unsigned char* lb = smem + par * C1B_BUFB;
     const bool more = ch + 1 < p.nchunk;
     auto request_b = [&](int pc) __attribute__((always_inline)) {
 #pragma unroll
-      for (int t = 0; t < TYW; ++t) Bq[pc & 1][t] = *reinterpret_cast<const bf16x8*>(lb + pc * C1B_PIMG + fb + t * 1024);
+      for (int t = 0; t < TYW; ++t) Bq[pc & 1][t] = *reinterpret_cast<const f16x8*>(lb + pc * C1B_PIMG + fb + t * 1024);
     };
     request_b(0);
 #pragma unroll
-    for (int pc = 0; pc < 3; ++pc) {
+    for (int pc = 0; pc < C1B_NP; ++pc) {
       if (pc == 0) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
-          for (int w3 = 0; w3 < 3; ++w3) Aw[par ^ 1][n][w3] = wl[(size_t)(ch + 1) * WSTEP + (n * 3 + w3) * 64];
+          for (int w3 = 0; w3 < C1B_NP; ++w3) Aw[par ^ 1][n][w3] = wl[(size_t)(ch + 1) * WSTEP + (n * C1B_NP + w3) * 64];
       }
-      if (pc + 1 < 3) request_b(pc + 1);
+      if (pc + 1 < C1B_NP) request_b(pc + 1);
       if (more) {
         if (pc == 0) { pf_slot(0, ch + 1); pf_slot(1, ch + 1); }
         if (pc == 1) { pf_slot(2, ch + 1); pf_slot(3, ch + 1); }
@@ -160,13 +157,16 @@ __global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int jw = 0; jw < 3; ++jw) {
-        if (jw > 2 - pc) continue;
+      for (int n = 0; n < NTW; ++n) {
+        if (pc == 0) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
+          for (int t = 0; t < TYW; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[par][n][0], Bq[pc & 1][t], acc[t][n], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TYW; ++t)
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Aw[par][n][jw], Bq[pc & 1][t], acc[t][n], 0, 0, 0);
+          for (int t = 0; t < TYW; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[par][n][1], Bq[pc & 1][t], accx[t][n], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < TYW; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[par][n][0], Bq[pc & 1][t], accx[t][n], 0, 0, 0);
+        }
       }
     }
     if (more) {
@@ -195,7 +195,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
       const int co = (wn * NTW + n) * 16 + 4 * q;
-      float4 v = make_float4(acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]);
+      float4 v = make_float4(acc[t][n][0] + accx[t][n][0] * C1B_IRS, acc[t][n][1] + accx[t][n][1] * C1B_IRS,
+                             acc[t][n][2] + accx[t][n][2] * C1B_IRS, acc[t][n][3] + accx[t][n][3] * C1B_IRS);
       if (p.bias) {
         const float4 bb = ld4(p.bias + co);
         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -258,19 +259,6 @@ int launch_c1b(const C1bArgs& a, int groups, hipStream_t s) {
   return ATVS_OK;
 }
 
-float c1b_round(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  float o;
-  std::memcpy(&o, &u, 4);
-  return o;
-}
-uint16_t c1b_bits(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  return (uint16_t)(u >> 16);
-}
 
 }  // namespace
 
@@ -284,7 +272,7 @@ extern "C" long atvs_conv1x1_b_rows(long pixels) { return (pixels + C1B_PX - 1) 
 extern "C" int atvs_conv1x1_b_pack_size(int Cin, int Cout, long* packed_bytes) {
   if (!packed_bytes) return ATVS_ERR_NULL;
   if (!atvs_conv1x1_b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
-  *packed_bytes = (long)(Cin / 32 + 1) * (Cout / 16) * 3 * 1024;
+  *packed_bytes = (long)(Cin / 32 + 1) * (Cout / 16) * C1B_NP * 1024;
   return ATVS_OK;
 }
 
@@ -298,17 +286,20 @@ extern "C" int atvs_conv1x1_b_pack(const float* w, int Cin, int Cout, unsigned c
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
   const int NT = Cout / 16;
+  bool fits = true;
   for (int ch = 0; ch < Cin / 32; ++ch)
     for (int n = 0; n < NT; ++n)
       for (int q = 0; q < 4; ++q)
         for (int co16 = 0; co16 < 16; ++co16)
           for (int e = 0; e < 8; ++e) {
             const float v = w[(size_t)(ch * 32 + q * 8 + e) * Cout + n * 16 + co16];
-            const float p0 = c1b_round(v), p1 = c1b_round(v - p0), p2 = c1b_round((v - p0) - p1);
-            const float pc[3] = {p0, p1, p2};
-            for (int k = 0; k < 3; ++k) out[((((size_t)ch * NT + n) * 3 + k) * 64 + q * 16 + co16) * 8 + e] = c1b_bits(pc[k]);
+            const _Float16 g0 = (_Float16)v, g1 = (_Float16)((v - (float)g0) * C1B_RS);
+            std::memcpy(&out[((((size_t)ch * NT + n) * C1B_NP + 0) * 64 + q * 16 + co16) * 8 + e], &g0, 2);
+            std::memcpy(&out[((((size_t)ch * NT + n) * C1B_NP + 1) * 64 + q * 16 + co16) * 8 + e], &g1, 2);
+            const float back = (float)g0;
+            fits &= (back - back == 0.f);
           }
-  return ATVS_OK;
+  return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
 // Same contract as atvs_conv1x1_f32 except the statistics rows (atvs_conv1x1_b_rows: 128 pixels per workgroup) and the weights
@@ -322,7 +313,7 @@ extern "C" int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w,
   if (residual && y_coff != 0) return ATVS_ERR_ARG;
   if ((double)pixels * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
   C1bArgs a;
-  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.bias = bias; a.res = residual; a.in_params = in_params;
+  a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.bias = bias; a.res = residual; a.in_params = in_params;
   a.y = y; a.stats = stats_partial;
   a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.ycoff = y_coff; a.relu = relu; a.in_relu = in_relu;
   a.rows = pixels; a.wgs = (int)atvs_conv1x1_b_rows(pixels); a.nchunk = Cin / 32;

@@ -22,12 +22,14 @@ constexpr int C2B_PITCH = 24;                 // pixels per LDS row (16 + 2 * 4)
 constexpr int C2B_ROWB = C2B_PITCH * 32;      // bytes per row of one piece image (16 channels x 2 B per pixel)
 constexpr int C2B_JS = 5;                     // K steps per 16-channel chunk: taps 2 j + (q >> 1) of the 9 (10th = zero)
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int C2B_NP = 2;                                      // operand pieces: x = h0 + h1 / 2048 (conv_c16b.hip, round 4)
+constexpr float C2B_RS = 2048.f, C2B_IRS = 1.f / 2048.f;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 struct C2bArgs {
   const float* x;
-  const bf16x8* wp;
+  const f16x8* wp;
   const float* bias;
   const float* res;
   const float* in_params;
@@ -42,17 +44,13 @@ struct C2bArgs {
   long total;
 };
 
-__device__ __forceinline__ void c2b_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+__device__ __forceinline__ void c2b_split(const float4& v, f16x4* p0, f16x4* p1) {
   const float x[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
+    const _Float16 a = (_Float16)x[i];
     (*p0)[i] = a;
-    (*p1)[i] = b;
-    (*p2)[i] = (__bf16)r2;
+    (*p1)[i] = (_Float16)((x[i] - (float)a) * C2B_RS);
   }
 }
 
@@ -66,11 +64,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
   constexpr int SLOTS = HR * HC * 4;
   constexpr int MAXS = (SLOTS + 255) / 256;
   constexpr int PIMG = HR * C2B_ROWB;          // bytes of one piece image
-  constexpr int BUFB = 3 * PIMG;
+  constexpr int BUFB = C2B_NP * PIMG;
   constexpr int WN = 4 / WR;
   constexpr int NT = NTW * WN;
   constexpr int JS = C2B_JS;
-  static_assert(MAXS <= 3 * JS, "one halo slot per phase");
+  static_assert(MAXS <= C2B_NP * JS, "one halo slot per phase");
   static_assert(HC <= C2B_PITCH, "row pitch");
 
   const int tid = threadIdx.x;
@@ -122,12 +120,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
       }
-      bf16x4 p0, p1, p2;
-      c2b_split(v, &p0, &p1, &p2);
+      f16x4 p0, p1;
+      c2b_split(v, &p0, &p1);
       unsigned char* d = smem + buf * BUFB + laddr[i];
-      *reinterpret_cast<bf16x4*>(d) = p0;
-      *reinterpret_cast<bf16x4*>(d + PIMG) = p1;
-      *reinterpret_cast<bf16x4*>(d + 2 * PIMG) = p2;
+      *reinterpret_cast<f16x4*>(d) = p0;
+      *reinterpret_cast<f16x4*>(d + PIMG) = p1;
     }
   };
 
@@ -145,59 +142,62 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
   // register slots, the pieces of step gs + 1 requested at the first phase of step gs (with two workgroups per CU the
   // other wavefront of the SIMD covers what is left of the L2 latency); a chunk has 5 steps, so the slot parity flips from
   // chunk to chunk: the chunk loop is unrolled by two (Cin / 16 is even for every shape the towers have).
-  const bf16x8* __restrict__ wl = p.wp + (size_t)(wn * NTW) * 3 * 64 + lane;
-  constexpr int WSTEP = NT * 3 * 64;
-  bf16x8 Aw[2][NTW][3];
+  const f16x8* __restrict__ wl = p.wp + (size_t)(wn * NTW) * C2B_NP * 64 + lane;
+  constexpr int WSTEP = NT * C2B_NP * 64;
+  f16x8 Aw[2][NTW][C2B_NP];
 #pragma unroll
   for (int n = 0; n < NTW; ++n)
 #pragma unroll
-    for (int w3 = 0; w3 < 3; ++w3) Aw[0][n][w3] = wl[(n * 3 + w3) * 64];
+    for (int w3 = 0; w3 < C2B_NP; ++w3) Aw[0][n][w3] = wl[(n * C2B_NP + w3) * 64];
 
-  f32x4 acc[TY][NTW];
+  f32x4 acc[TY][NTW], accx[TY][NTW];   // h0 g0 | (h0 g1 + h1 g0) * 2^11
 #pragma unroll
   for (int t = 0; t < TY; ++t)
 #pragma unroll
-    for (int n = 0; n < NTW; ++n) acc[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < NTW; ++n) acc[t][n] = accx[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #pragma unroll
   for (int i = 0; i < MAXS; ++i) pf_slot(i, 0);
   write_image(0, 0);
   __syncthreads();
 
-  bf16x8 Bq[2][TY];
+  f16x8 Bq[2][TY];
   auto chunk = [&](auto PAR, int ch) __attribute__((always_inline)) {
     constexpr int par = decltype(PAR)::value;                 // ch & 1: LDS buffer and weight-slot parity of the chunk
     const unsigned char* lb = smem + par * BUFB;
     const bool more = ch + 1 < p.nchunk;
-    const bf16x8* wc = wl + (size_t)ch * JS * WSTEP;
+    const f16x8* wc = wl + (size_t)ch * JS * WSTEP;
     auto request_b = [&](int ph) __attribute__((always_inline)) {
-      const int j = ph / 3, pc = ph % 3;
+      const int j = ph / C2B_NP, pc = ph % C2B_NP;
 #pragma unroll
-      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(lb + pc * PIMG + bd[j] + t * C2B_ROWB);
+      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(lb + pc * PIMG + bd[j] + t * C2B_ROWB);
     };
     request_b(0);
 #pragma unroll
-    for (int ph = 0; ph < 3 * JS; ++ph) {
-      const int j = ph / 3, pc = ph % 3;
+    for (int ph = 0; ph < C2B_NP * JS; ++ph) {
+      const int j = ph / C2B_NP, pc = ph % C2B_NP;
       const int slot = (par * JS + j) & 1;
       if (pc == 0) {
 #pragma unroll
         for (int n = 0; n < NTW; ++n)
 #pragma unroll
-          for (int w3 = 0; w3 < 3; ++w3) Aw[slot ^ 1][n][w3] = wc[(size_t)(j + 1) * WSTEP + (n * 3 + w3) * 64];
+          for (int w3 = 0; w3 < C2B_NP; ++w3) Aw[slot ^ 1][n][w3] = wc[(size_t)(j + 1) * WSTEP + (n * C2B_NP + w3) * 64];
       }
-      if (ph + 1 < 3 * JS) request_b(ph + 1);
+      if (ph + 1 < C2B_NP * JS) request_b(ph + 1);
       if (ph < MAXS && more) pf_slot(ph, ch + 1);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int jw = 0; jw < 3; ++jw) {
-        if (jw > 2 - pc) continue;
+      for (int n = 0; n < NTW; ++n) {
+        if (pc == 0) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
+          for (int t = 0; t < TY; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[slot][n][0], Bq[ph & 1][t], acc[t][n], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TY; ++t)
-            acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Aw[slot][n][jw], Bq[ph & 1][t], acc[t][n], 0, 0, 0);
+          for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[slot][n][1], Bq[ph & 1][t], accx[t][n], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[slot][n][0], Bq[ph & 1][t], accx[t][n], 0, 0, 0);
+        }
       }
     }
     if (more) {
@@ -227,7 +227,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
       const int co = (wn * NTW + n) * 16 + 4 * q;
-      float4 v = make_float4(acc[t][n][0], acc[t][n][1], acc[t][n][2], acc[t][n][3]);
+      float4 v = make_float4(acc[t][n][0] + accx[t][n][0] * C2B_IRS, acc[t][n][1] + accx[t][n][1] * C2B_IRS,
+                             acc[t][n][2] + accx[t][n][2] * C2B_IRS, acc[t][n][3] + accx[t][n][3] * C2B_IRS);
       if (p.bias) {
         const float4 bb = ld4(p.bias + co);
         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
@@ -286,25 +287,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
 template <int NTW, int WR, int TY, int DIL>
 int launch_c2b(const C2bArgs& a, hipStream_t s) {
   constexpr int R = TY * WR, HR = R + 2 * DIL;
-  size_t lds = (size_t)2 * 3 * HR * C2B_ROWB;
+  size_t lds = (size_t)2 * C2B_NP * HR * C2B_ROWB;
   const long blocks = ((a.total + 7) / 8) * 8;
   if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipLaunchKernelGGL((conv2d_b_kernel<NTW, WR, TY, DIL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;
-}
-
-float c2b_round(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  float o;
-  std::memcpy(&o, &u, 4);
-  return o;
-}
-uint16_t c2b_bits(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  return (uint16_t)(u >> 16);
 }
 
 }  // namespace
@@ -313,7 +300,7 @@ uint16_t c2b_bits(float v) {
 extern "C" int atvs_conv2d_b_pack_size(int Cin, int Cout, long* packed_bytes) {
   if (!packed_bytes) return ATVS_ERR_NULL;
   if (!atvs_conv2d_lds_supported(Cin, Cout, 1)) return ATVS_ERR_SHAPE;
-  *packed_bytes = (long)((Cin / 16) * C2B_JS + 1) * (Cout / 16) * 3 * 1024;
+  *packed_bytes = (long)((Cin / 16) * C2B_JS + 1) * (Cout / 16) * C2B_NP * 1024;
   return ATVS_OK;
 }
 
@@ -327,6 +314,7 @@ extern "C" int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned ch
   std::memset(packed, 0, (size_t)pb);
   uint16_t* out = reinterpret_cast<uint16_t*>(packed);
   const int NT = Cout / 16, nch = Cin / 16;
+  bool fits = true;
   for (int ch = 0; ch < nch; ++ch)
     for (int j = 0; j < C2B_JS; ++j)
       for (int n = 0; n < NT; ++n)
@@ -337,13 +325,14 @@ extern "C" int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned ch
             for (int e = 0; e < 8; ++e) {
               const int ci = ch * 16 + (q & 1) * 8 + e, co = n * 16 + co16;
               const float v = w[((size_t)tap * Cin + ci) * Cout + co];
-              const float p0 = c2b_round(v), p1 = c2b_round(v - p0), p2 = c2b_round((v - p0) - p1);
-              const float pc[3] = {p0, p1, p2};
-              for (int k = 0; k < 3; ++k)
-                out[(((((size_t)(ch * C2B_JS + j) * NT + n) * 3 + k) * 64) + q * 16 + co16) * 8 + e] = c2b_bits(pc[k]);
+              const _Float16 g0 = (_Float16)v, g1 = (_Float16)((v - (float)g0) * C2B_RS);
+              std::memcpy(&out[(((((size_t)(ch * C2B_JS + j) * NT + n) * C2B_NP + 0) * 64) + q * 16 + co16) * 8 + e], &g0, 2);
+              std::memcpy(&out[(((((size_t)(ch * C2B_JS + j) * NT + n) * C2B_NP + 1) * 64) + q * 16 + co16) * 8 + e], &g1, 2);
+              const float back = (float)g0;
+              fits &= (back - back == 0.f);
             }
         }
-  return ATVS_OK;
+  return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
 // Same contract as atvs_conv2d_lds_f32 (shapes, statistics rows = atvs_conv2d_lds_rows) with split-bf16 operands; weights from
@@ -358,7 +347,7 @@ extern "C" int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, 
   if (residual && y_coff != 0) return ATVS_ERR_ARG;
   if ((double)H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
   C2bArgs a;
-  a.x = x; a.wp = reinterpret_cast<const bf16x8*>(packed_w); a.bias = bias; a.res = residual; a.in_params = in_params;
+  a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.bias = bias; a.res = residual; a.in_params = in_params;
   a.y = y; a.stats = stats_partial;
   a.G = G; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16;
   const int R = (Cout == 32) ? 8 : 4;
