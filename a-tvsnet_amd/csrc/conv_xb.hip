@@ -262,39 +262,33 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
   struct Par { float4 ma, sa, ba, mb, sb, bb; };
   const bool has_a = PRO >= 1 && ipa != nullptr, has_b = PRO == 2 && ipb != nullptr;
   const float floor_a = p.relu_a ? 0.f : -__builtin_huge_valf(), floor_b = p.relu_b ? 0.f : -__builtin_huge_valf();
+  // a source WITHOUT a pending batch norm gets the identity (mean 0, scale 1, beta 0, no floor) once per chunk, not a select per
+  // staged value: (v - 0) * 1 + 0 == v (a -0 becomes +0: the same sums)
   auto load_par = [&](int chunk) __attribute__((always_inline)) {
     Par P;
     const int cch = chunk * 8 + c4t * 4;
-    const int sa = has_a ? p.Cin : 0, sb = has_b ? p.Cin : 0;
-    const float* a = has_a ? ipa + cch : p.zeros;
-    P.ma = ld4(a); P.sa = ld4(a + sa); P.ba = ld4(a + 2 * sa);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f), one = make_float4(1.f, 1.f, 1.f, 1.f);
+    P.ma = has_a ? ld4(ipa + cch) : zero; P.sa = has_a ? ld4(ipa + p.Cin + cch) : one; P.ba = has_a ? ld4(ipa + 2 * p.Cin + cch) : zero;
     if (PRO == 2) {
-      const float* b = has_b ? ipb + cch : p.zeros;
-      P.mb = ld4(b); P.sb = ld4(b + sb); P.bb = ld4(b + 2 * sb);
+      P.mb = has_b ? ld4(ipb + cch) : zero; P.sb = has_b ? ld4(ipb + p.Cin + cch) : one; P.bb = has_b ? ld4(ipb + 2 * p.Cin + cch) : zero;
     }
     return P;
   };
-  auto bn2 = [&](f32x2 v, f32x2 m, f32x2 sc, f32x2 be, float lo, bool has) __attribute__((always_inline)) {
-    f32x2 t = (v - m) * sc + be;
-    t.x = fmaxf(t.x, lo);
-    t.y = fmaxf(t.y, lo);
-    t.x = has ? t.x : v.x;
-    t.y = has ? t.y : v.y;
-    return t;
+  const float lo_a = has_a ? floor_a : -__builtin_huge_valf(), lo_b = has_b ? floor_b : -__builtin_huge_valf();
+  auto bn1 = [&](float v, float m, float sc, float be, float lo) __attribute__((always_inline)) {
+    return fmaxf((v - m) * sc + be, lo);               // bn_apply's arithmetic (norm.hip): sub, mul, add -- no contraction
   };
   auto xform = [&](int i, const Par& P) __attribute__((always_inline)) {
     const bool ok = !((vinv >> i) & 1u);            // vinv still describes the stage being staged: it is renewed in the K loop
-    f32x2 lo = {pf[i].x, pf[i].y}, hi = {pf[i].z, pf[i].w};
-    lo = bn2(lo, (f32x2){P.ma.x, P.ma.y}, (f32x2){P.sa.x, P.sa.y}, (f32x2){P.ba.x, P.ba.y}, floor_a, has_a);
-    hi = bn2(hi, (f32x2){P.ma.z, P.ma.w}, (f32x2){P.sa.z, P.sa.w}, (f32x2){P.ba.z, P.ba.w}, floor_a, has_a);
+    float4 v = pf[i];
+    v.x = bn1(v.x, P.ma.x, P.sa.x, P.ba.x, lo_a); v.y = bn1(v.y, P.ma.y, P.sa.y, P.ba.y, lo_a);
+    v.z = bn1(v.z, P.ma.z, P.sa.z, P.ba.z, lo_a); v.w = bn1(v.w, P.ma.w, P.sa.w, P.ba.w, lo_a);
     if (PRO == 2) {
-      f32x2 ul = {pf2[i].x, pf2[i].y}, uh = {pf2[i].z, pf2[i].w};
-      ul = bn2(ul, (f32x2){P.mb.x, P.mb.y}, (f32x2){P.sb.x, P.sb.y}, (f32x2){P.bb.x, P.bb.y}, floor_b, has_b);
-      uh = bn2(uh, (f32x2){P.mb.z, P.mb.w}, (f32x2){P.sb.z, P.sb.w}, (f32x2){P.bb.z, P.bb.w}, floor_b, has_b);
-      lo += ul;
-      hi += uh;
+      const float4 u = pf2[i];
+      v.x += bn1(u.x, P.mb.x, P.sb.x, P.bb.x, lo_b); v.y += bn1(u.y, P.mb.y, P.sb.y, P.bb.y, lo_b);
+      v.z += bn1(u.z, P.mb.z, P.sb.z, P.bb.z, lo_b); v.w += bn1(u.w, P.mb.w, P.sb.w, P.bb.w, lo_b);
     }
-    pf[i] = make_float4(ok ? lo.x : 0.f, ok ? lo.y : 0.f, ok ? hi.x : 0.f, ok ? hi.y : 0.f);
+    pf[i] = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
   };
 
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
@@ -532,10 +526,12 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
       for (int t = 0; t < XB_TY; ++t) {
         if (!erow_ok(t)) continue;
         float4 v;
-        v.x = ((acc[t][0] + accx[t][0] * XB_IRS) + bv.x) + epb[t].x;
-        v.y = ((acc[t][1] + accx[t][1] * XB_IRS) + bv.y) + epb[t].y;
-        v.z = ((acc[t][2] + accx[t][2] * XB_IRS) + bv.z) + epb[t].z;
-        v.w = ((acc[t][3] + accx[t][3] * XB_IRS) + bv.w) + epb[t].w;
+        // fmaf(cross, 2^-11, main): the product by a power of two is exact, i.e. the same value as main + cross * 2^-11 in one
+        // instruction
+        v.x = (__builtin_fmaf(accx[t][0], XB_IRS, acc[t][0]) + bv.x) + epb[t].x;
+        v.y = (__builtin_fmaf(accx[t][1], XB_IRS, acc[t][1]) + bv.y) + epb[t].y;
+        v.z = (__builtin_fmaf(accx[t][2], XB_IRS, acc[t][2]) + bv.z) + epb[t].z;
+        v.w = (__builtin_fmaf(accx[t][3], XB_IRS, acc[t][3]) + bv.w) + epb[t].w;
         if (decltype(relu_tag)::value) {          // NaN passes through, as in tf.nn.relu
           v.x = (v.x < 0.f) ? 0.f : v.x;
           v.y = (v.y < 0.f) ? 0.f : v.y;
@@ -553,8 +549,8 @@ __global__ __launch_bounds__(256, 1) void conv_xb_kernel(XbArgs p) {
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         if (!erow2_ok(t)) continue;
-        const float4 v = make_float4((acc2[t][0] + acc2x[t][0] * XB_IRS) + epb2[t].x, (acc2[t][1] + acc2x[t][1] * XB_IRS) + epb2[t].y,
-                                     (acc2[t][2] + acc2x[t][2] * XB_IRS) + epb2[t].z, (acc2[t][3] + acc2x[t][3] * XB_IRS) + epb2[t].w);
+        const float4 v = make_float4(__builtin_fmaf(acc2x[t][0], XB_IRS, acc2[t][0]) + epb2[t].x, __builtin_fmaf(acc2x[t][1], XB_IRS, acc2[t][1]) + epb2[t].y,
+                                     __builtin_fmaf(acc2x[t][2], XB_IRS, acc2[t][2]) + epb2[t].z, __builtin_fmaf(acc2x[t][3], XB_IRS, acc2[t][3]) + epb2[t].w);
         st4(y2g + (eo2 + (size_t)t * erow2), v);
         ssum2[0] += v.x; ssum2[1] += v.y; ssum2[2] += v.z; ssum2[3] += v.w;
         ssq2[0] += v.x * v.x; ssq2[1] += v.y * v.y; ssq2[2] += v.z * v.z; ssq2[3] += v.w * v.w;

@@ -6,8 +6,9 @@
 A step = one depth map through the whole example.py pipeline (towers -> 2x stacked 3-D U-Net per source ->
 AAM1 -> refinement per source -> AAM2 -> x4 upsample + soft-argmin), inputs resident in HBM, synthetic
 seeded images / cameras / weights, fp32 storage and accumulation; the heavy convolutions run on
-v_mfma_f32_16x16x32_bf16 with every fp32 operand split into three bf16 pieces (fp32-class results), the rest on
-the fp32 matrix cores; `split_bf16` times the all-fp32-MFMA path next to it.
+v_mfma_f32_16x16x32_f16 with every fp32 operand split into two fp16 pieces (three products, fp32-class results, DESIGN.md 8;
+the transposed convolutions: three bf16 pieces, six products), the rest on the fp32 matrix cores; `split_operands` times the
+all-fp32-MFMA path next to it.
 Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: 5 views
 (1 reference + 4 sources) of 640x512, D=192.  cfg2 = two-view 640x512x192, cfg4 = 9 views 928x480x256 (the
 8-source configuration quoted for 8 GPUs), cfg5 = two-view 1600x1184x256.
@@ -40,8 +41,8 @@ against tests/golden/fullsize_cfg4.npz, and the same depth map on ONE rank measu
 speed-up and fraction-of-linear come from one run).
 
 One JSON line on rank 0.  `roofline` = the dominant kernel (conv_xb.hip: the 3x3x3 convolution of the 32 warped
-channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch): the bf16 MFMA
-FLOPs the launch ISSUES / its duration (HIP events on its launch stream, >= 10 eager launches) against the dense bf16
+channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch): the 16-bit MFMA
+FLOPs the launch ISSUES / its duration (HIP events on its launch stream, >= 10 eager launches) against the dense bf16 / fp16
 MFMA peak (2.5 PF) -- the pipe it runs on; `fp32_equivalent` = the algorithmic fp32 convolution FLOPs against the fp32
 matrix peak, `mfma_busy` / `clock_GHz` from the committed PMC passes; `roofline_hbm` = the plane-sweep warp
 (warp_planes_shared_kernel) against the HBM peak, timed the same way; `kernels` = the top kernels of the committed
@@ -622,6 +623,7 @@ def rank_main(args):
     out = out.clone()
 
     # secondary: the same step with EVERY convolution on the fp32 matrix cores (ops.use_bf16x3(False)).  The default path runs
+    # its heavy layers on the 16-bit matrix cores with SPLIT operands (two fp16 pieces / three products since round 4):
     # the 8 / 16 -> 16 channel 3x3x3 layers (AANet shared | unique, conv_b*_1_1, global_refine_3dconv1_1) on
     # v_mfma_f32_16x16x32_bf16 with SPLIT operands -- x = x0 + x1 + x2, w = w0 + w1 + w2 in bf16 (24 mantissa bits kept),
     # the 6 products with i + j <= 2, fp32 accumulation: fp32-class results (per-layer error against float64 equal to the fp32
@@ -641,8 +643,10 @@ def rank_main(args):
             torch.cuda.synchronize()
             dt2 = time.perf_counter() - t2
             split = {'layers': 'the 3x3x3 layers with 8 / 16 / 32 input channels (conv_xb.hip, conv_c16b.hip) and the 3x3 / 1x1 tower '
-                               'layers with Cin % 32 == 0 (conv2d_b.hip, conv1x1_b.hip) on v_mfma_f32_16x16x32_bf16: '
-                               'x = x0 + x1 + x2, w = w0 + w1 + w2 in bf16, the 6 products with i + j <= 2, fp32 accumulation',
+                               'layers with Cin % 32 == 0 (conv2d_b.hip, conv1x1_b.hip) on v_mfma_f32_16x16x32_f16: '
+                               'x = h0 + h1 / 2048, w = g0 + g1 / 2048 in fp16 (h1 = f16((x - h0) * 2048)), the 3 products '
+                               'h0 g0 + (h0 g1 + h1 g0) / 2048, fp32 accumulation; the transposed convolutions (deconv_up_b.hip) '
+                               'keep three bf16 pieces / six products',
                      'in_value': bool(default_on),
                      'other_path': 'every convolution on the fp32 matrix cores' if default_on else 'split-bf16 layers enabled',
                      'other_ms_per_step': round(1e3 * dt2 / args.steps, 3), 'other_value': round(args.steps / dt2, 4),
@@ -688,26 +692,26 @@ def rank_main(args):
             ach = flops / (avg_ms * 1e-3) / 1e12
             tr = pmc_traffic(args, samples)
             kind = ops._xkind()
-            kdesc = {'xb': 'conv_xb_kernel<SIB> (x-pair rows on v_mfma_f32_16x16x32_bf16, every fp32 operand split into three bf16 '
-                           'pieces, six products, fp32 accumulation)',
+            kdesc = {'xb': 'conv_xb_kernel<SIB> (x-pair rows on v_mfma_f32_16x16x32_f16, every fp32 operand split into two fp16 '
+                           'pieces, three products, fp32 accumulation)',
                      'xw': 'conv_xw_kernel<SIB> (x-pair rows x Winograd F(2,3) along y on v_mfma_f32_16x16x4_f32)',
                      'xp': 'conv_xp_kernel<C4=4,SIB> (x-pair rows on v_mfma_f32_16x16x4_f32)'}[kind]
             pmc = pmc_counters(args, samples)
             fp32_eq = {'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                        'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
                        'note': 'ALGORITHMIC direct fp32 convolution FLOPs (SURVEY 8d) / time against the fp32 matrix peak the path is '
-                               'specified in: what an fp32-MFMA kernel would need to reach; exceeds 1.0 in principle on the bf16 pipe '
-                               '(ceiling 2500 / 8 / 157.3 = 1.99), so it is NOT the roofline fraction'}
+                               'specified in: what an fp32-MFMA kernel would need to reach; exceeds 1.0 on the 16-bit pipe '
+                               '(ceiling 2500 / 4 / 157.3 = 3.97), so it is NOT the roofline fraction'}
             if kind == 'xb':
-                # main: 9 steps x 6 products per (8-channel chunk, 16 pairs x row): 2*16*16*32 FLOP each = 8 x the useful
-                # fp32 FLOPs (x-pair zero taps 4/3, six products); sibling: 7 steps of 4 taps for 27 -> 28/27 x 6
+                # main: 9 steps x 3 products per (8-channel chunk, 16 pairs x row): 2*16*16*32 FLOP each = 4 x the useful
+                # fp32 FLOPs (x-pair zero taps 4/3, three products); sibling: 7 steps of 4 taps for 27 -> 28/27 x 3
                 main = 2.0 * 27 * 32 * 8 * vox * samples
                 sibf = (flops - main)
-                issued = main * 8.0 + sibf * 6.0 * 28.0 / 27.0
-                peak, pipe = PEAK_BF16_MFMA_TFLOPS, 'bf16'
-                conv = ('achieved = bf16 MFMA FLOPs the launch ISSUES (v_mfma_f32_16x16x32_bf16 count x 16384; 8 per algorithmic '
-                        'FLOP of the main convolution: six piece products x 4/3 x-pair rows; 6 x 28/27 for the sibling) / '
-                        'time, against the dense bf16 MFMA peak: the pipe the kernel runs on')
+                issued = main * 4.0 + sibf * 3.0 * 28.0 / 27.0
+                peak, pipe = PEAK_BF16_MFMA_TFLOPS, 'fp16'
+                conv = ('achieved = fp16 MFMA FLOPs the launch ISSUES (v_mfma_f32_16x16x32_f16 count x 16384; 4 per algorithmic '
+                        'FLOP of the main convolution: three piece products x 4/3 x-pair rows; 3 x 28/27 for the sibling) / '
+                        'time, against the dense fp16 / bf16 MFMA peak: the pipe the kernel runs on')
             elif kind == 'xw':
                 issued, peak, pipe = flops * 8.0 / 9.0, PEAK_F32_MFMA_TFLOPS, 'fp32'
                 conv = 'achieved = fp32 MFMA FLOPs issued (F(2,3): 2/3, x-pair rows: 4/3 of the algorithmic FLOPs) / time'
@@ -721,7 +725,7 @@ def rank_main(args):
                     'flops_convention': conv,
                     'achieved': round(iss, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(iss / peak, 4),
                     'issued_flops_per_launch': issued,
-                    'useful_frac': round(flops * (6.0 if kind == 'xb' else 1.0) / (avg_ms * 1e-3) / 1e12 / peak, 4),
+                    'useful_frac': round(flops * (3.0 if kind == 'xb' else 1.0) / (avg_ms * 1e-3) / 1e12 / peak, 4),
                     'fp32_equivalent': fp32_eq,
                     'mfma_busy': pmc.get('mfma_busy') if pmc else None,
                     'clock_GHz': pmc.get('clock_GHz') if pmc else None,
@@ -771,9 +775,11 @@ def rank_main(args):
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True,
             'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'precision': ('fp32 storage and fp32 accumulation everywhere; the heavy convolutions (3x3x3 with 8 / 16 / 32 input '
-                          'channels, 3x3 and 1x1 tower layers) split every fp32 operand into three bf16 pieces (24 mantissa bits '
-                          'kept) and form 6 of the 9 piece products: fp32-class, same parity bar; the other layers use fp32 MFMA '
-                          'operands; see `split_bf16` for the all-fp32-MFMA figure') if ops._USE_BF16X3 else 'fp32 MFMA operands, fp32 accumulation',
+                          'channels, 3x3 and 1x1 tower layers) split every fp32 operand into two fp16 pieces (22 significant bits, '
+                          'the residual piece scaled into the normal range; transposed convolutions: three bf16 pieces) '
+                          'and form 3 products with the cross terms accumulated apart: fp32-class (per-layer error against float64 '
+                          'below the fp32 matrix cores\'), same parity bar; the other layers use fp32 MFMA operands; see '
+                          '`split_operands` for the all-fp32-MFMA figure') if ops._USE_BF16X3 else 'fp32 MFMA operands, fp32 accumulation',
             'config': {'workload': '%d depth map(s) per step: %d views (1 ref + %d src) %dx%d, D=%d, example.py %s pipeline'
                                    % (n_groups, args.views, args.views - 1, args.width, args.height, args.depths,
                                       'two-view' if twoview else 'multi-view'),
@@ -787,7 +793,7 @@ def rank_main(args):
             'source_views_per_sec': round(n_groups * args.steps * (args.views - 1) / dt, 3),
             'latency_ms': round(1e3 * dt / args.steps, 3),
             'pipelined': pipelined,
-            'split_bf16': split,
+            'split_operands': split,
             'roofline': roof, 'roofline_hbm': roof_hbm, 'kernels': top_kernels(),
         }
         if comm is not None:
