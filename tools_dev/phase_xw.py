@@ -49,7 +49,7 @@ else:
 for _ in range(3):
     run()
 torch.cuda.synchronize()
-buf = np.zeros(4096 * 8, np.uint64)
+buf = np.zeros(8192 * 8, np.uint64)
 rc = _lib.lib().atvs_debug_read_xw(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 b = buf.reshape(-1, 8).astype(np.float64)
