@@ -1,4 +1,4 @@
-"""profiles/round3_pmc_kernels.json from the summary of tools_dev/pmc_bench.sh:  python tools_dev/make_pmc_table.py gpurun_out/pmc_<tag>"""
+"""profiles/round4_pmc_kernels.json from the summary of tools_dev/pmc_bench.sh:  python tools_dev/make_pmc_table.py gpurun_out/pmc_<tag>"""
 import json
 import os
 import sys
@@ -27,6 +27,6 @@ for k, v in list(d.items())[:40]:
         e['memory_TBps_raw'] = round((c.get('FETCH_SIZE', 0) + c.get('WRITE_SIZE', 0)) * 1024 / dur / 1e3, 2)
     e['lds_bank_conflict_cycles'] = int(c.get('SQ_LDS_BANK_CONFLICT', 0))
     out['kernels'][k] = e
-json.dump(out, open(os.path.join(root, 'profiles', 'round3_pmc_kernels.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(root, 'profiles', 'round4_pmc_kernels.json'), 'w'), indent=1)
 for k in list(out['kernels'])[:10]:
     print(k, out['kernels'][k])
