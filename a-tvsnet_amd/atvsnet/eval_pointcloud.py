@@ -149,7 +149,7 @@ class _Pipelines(object):
     def fetch(self):
         p, t = self.pending.pop(0)
         out = t if p is None else p.result(t)
-        return [o.cpu().numpy() for o in out]
+        return [example.check_finite(o.cpu().numpy(), 'a network output') for o in out]
 
     def __call__(self, images_data, cams_data):
         self.submit(images_data, cams_data)

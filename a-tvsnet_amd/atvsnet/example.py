@@ -398,6 +398,17 @@ def write_error_xlsx(path, error, view_num):
     workbook.close()
 
 
+def check_finite(arr, what='depth map'):
+    """The split-operand convolutions carry activations as two fp16 pieces: a value beyond +-65504 turns
+    into inf/NaN there instead of a silently wrong depth.  The host drivers call this on every result they copy back so that
+    the failure names its cause (ATVS_BF16X3=0 selects the fp32 matrix-core kernels, which have fp32's range)."""
+    if not np.isfinite(arr).all():
+        raise FloatingPointError('%s holds %d non-finite values: an activation or weight left the fp16 range of the split-operand '
+                                 'kernels (or the inputs were not finite); rerun with ATVS_BF16X3=0 for the fp32 kernels'
+                                 % (what, int((~np.isfinite(arr)).sum())))
+    return arr
+
+
 def _to_device(images_data, cams_data):
     torch.cuda.set_device(FLAGS.gpu_id)          # every kernel launches on the current device's stream
     dev = torch.device('cuda:%d' % FLAGS.gpu_id)
@@ -413,7 +424,7 @@ def run_test_multiview(savepath, images_data, cams_data, depth_gt=None):
     _load_weights()
     images, cams = _to_device(images_data, cams_data)
     print(Notify.INFO, 'running test......', Notify.ENDC)
-    out_depth_map = infer_multiview(images, cams, FLAGS.max_d).cpu().numpy()
+    out_depth_map = check_finite(infer_multiview(images, cams, FLAGS.max_d).cpu().numpy())
     out_disp_map = out_depth_map.copy()
     if FLAGS.inverse_depth:
         out_depth_map[out_depth_map < 1e-10] = float("inf")
@@ -428,7 +439,7 @@ def run_test_twoview(savepath, images_data, cams_data, depth_gt=None):
     _load_weights()
     images, cams = _to_device(images_data, cams_data)
     print(Notify.INFO, 'running test......', Notify.ENDC)
-    out_depth_map = infer_twoview(images, cams, FLAGS.max_d).cpu().numpy()
+    out_depth_map = check_finite(infer_twoview(images, cams, FLAGS.max_d).cpu().numpy())
     out_disp_map = out_depth_map.copy()
     if FLAGS.inverse_depth:
         out_depth_map[out_depth_map <= 0] = float("inf")

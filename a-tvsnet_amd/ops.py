@@ -1901,13 +1901,16 @@ def use_prologue(flag):
 
 def siblings_prologue_ok(src):
     """Can conv_siblings take this lazy input as it is (the kernel forms it while staging)?  Built forms: one pending
-    batch norm with Cin % 16 == 0 (the refinement's concat); a sum of two with Cin % 16 == 8 (the U-Net's stack inputs)."""
+    batch norm with Cin % 16 == 0 (the refinement's concat); a sum of two with Cin % 16 == 8 (the U-Net's stack inputs;
+    Cin == 8 on the split-operand kernel)."""
     if not _USE_PROLOGUE or _FORCE_IMPL is not None or not _USE_XP1W:
         return False
     if isinstance(src, PendingBN):
         return src._final is None and src.shape[-1] % 16 == 0 and src.raw.is_contiguous()
     if isinstance(src, PendingSum):
         if src._final is not None or src.shape[-1] % 16 != 8:
+            return False
+        if _xkind() == 'xb' and src.shape[-1] != 8:        # conv_xb's two-source form: one 8-channel chunk
             return False
         gs = set()
         for t in src.items:

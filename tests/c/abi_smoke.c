@@ -26,7 +26,7 @@ int main(int argc, char** argv) {
     return 5;
   }
   long bytes = 0;
-  if (pack_size(32, 32, &bytes) != ATVS_OK || bytes != 2L * 14 * 2 * 3 * 1024 + 16) return 6;
+  if (pack_size(32, 32, &bytes) != ATVS_OK || bytes != 2L * 14 * 2 * 2 * 1024 + 16) return 6;   /* 2 chunks x 14 steps x 2 tiles x 2 fp16 pieces */
   if (pack_size(8, 32, &bytes) != ATVS_ERR_SHAPE) return 7;
   if (stems(0, 0, 0, 0, 0, 0, 0, 0, 1, 8, 8, 32, 0) != ATVS_ERR_NULL) return 8;
   printf("abi %d ok\n", version());

@@ -167,6 +167,37 @@ def test_batch_norm_train(cuda, shape, beta):
     assert torch.allclose(raw.var(0, unbiased=False), v / (v + 1e-3), rtol=1e-4)
 
 
+@pytest.mark.parametrize('G,rows,C', [(1, 5 * 6 * 7, 8), (3, 4099, 16), (2, 1031, 24), (1, 4 * 1024 + 3, 128), (4, 777, 12),
+                                      (2, 9000, 32)])
+def test_elementwise_bn_passes_match_their_formula(cuda, G, rows, C):
+    """bn_apply / bn_add (norm.hip: a workgroup covers four spans of 1024 floats of ONE sample) on sizes that end inside a
+    span, channel counts that are and are not powers of two, several independent samples with their own parameters, a
+    channel slice of a wider buffer, two and three terms -- against the same expression in torch (exact up to the
+    fused-multiply-add contraction: 1e-6 relative)."""
+    from atvsnet_amd import ops
+    x = [_rand((G, rows, C), 200 + i, 2.0) for i in range(3)]
+    par = [torch.stack([_rand((G, C), 210 + i), torch.rand(G, C, generator=torch.Generator().manual_seed(220 + i)) + 0.5,
+                        _rand((G, C), 230 + i)], 1).contiguous() for i in range(3)]
+
+    def bn(i, relu):
+        y = (x[i] - par[i][:, 0][:, None]) * par[i][:, 1][:, None] + par[i][:, 2][:, None]
+        return torch.clamp(y, min=0) if relu else y
+    xd, pd = [t.to(cuda) for t in x], [t.to(cuda) for t in par]
+    for relu in (False, True):
+        _close(ops.bn_apply(xd[0], pd[0], relu=relu, out=torch.empty_like(xd[0])).cpu(), bn(0, relu), 1e-6)
+    # a channel slice of a buffer twice as wide, in place; the other channels untouched
+    wide = torch.full((G, rows, 2 * C + 4), -3.0, device=cuda)
+    wide[..., 4:4 + C] = xd[1]
+    ops.bn_apply(wide, pd[1], relu=True, C=C, c_off=4)
+    _close(wide[..., 4:4 + C].cpu(), bn(1, True), 1e-6)
+    assert float((wide[..., :4] + 3.0).abs().max()) == 0.0 and float((wide[..., 4 + C:] + 3.0).abs().max()) == 0.0
+    # two and three terms, pending and dense mixed
+    got2 = ops.bn_add([ops.PendingBN(xd[0], pd[0], True), ops.PendingBN(xd[1], pd[1], False)])
+    _close(got2.cpu(), bn(0, True) + bn(1, False), 1e-6)
+    got3 = ops.bn_add([ops.PendingBN(xd[0], pd[0], False), xd[2], ops.PendingBN(xd[1], pd[1], True)])
+    _close(got3.cpu(), (bn(0, False) + x[2]) + bn(1, True), 1e-6)
+
+
 def test_conv_bn_matches_oracle_layer(cuda):
     from atvsnet_amd import ops
     x = _rand((1, 6, 8, 10, 16), 18)
@@ -339,6 +370,39 @@ def test_conv_siblings_one_launch(cuda, xkernel, D, H, W, Cin):
     (y, _), (y2, _) = ops.conv_siblings(x[0].to(cuda), ('sib', D, H, W, Cin), w.numpy(), ('sib2', D, H, W, Cin), w2.numpy())
     _close(y2.cpu(), T.conv(x, w2, 2, 'SAME')[0])
     _close(y.cpu(), T.conv(x, w, 1, 'SAME')[0])
+
+
+def test_split_operand_kernels_fail_loudly_outside_the_fp16_range(cuda):
+    """Two fp16 pieces carry 22 significand bits but only fp16's exponent range: a weight beyond 65504 is
+    refused when it is packed, and an activation beyond it gives a NON-FINITE output where it is read -- never a finite wrong
+    value -- while values up to the limit stay exact to the usual tolerance."""
+    from atvsnet_amd import ops
+    ops.clear_pack_cache()
+    D, H, W, Cin = 4, 8, 32, 16
+    x = _rand((1, D, H, W, Cin), 70)
+    w = _rand((3, 3, 3, Cin, 8), 71, 0.2)
+    # large but representable: activations up to ~5e4 against 0.2-scale weights
+    big = x * (5.0e4 / float(x.abs().max()))
+    got = ops.conv(big[0].to(cuda), ('rng', 1), w.numpy())
+    _close(got.cpu(), T.conv(big, w, 1, 'SAME')[0])
+    # one activation beyond the range: every output that reads it is non-finite, and every FINITE output is the value from
+    # before (the x-pair form multiplies the neighbouring pair's window by structural zeros: inf * 0 widens the NaN region
+    # by a voxel along x, it never narrows it)
+    bad = big.clone()
+    bad[0, 2, 4, 16, 3] = 1.0e5
+    got2 = ops.conv(bad[0].to(cuda), ('rng', 1), w.numpy()).cpu()
+    touched = torch.zeros(D, H, W, dtype=torch.bool)
+    touched[1:4, 3:6, 15:18] = True
+    assert not torch.isfinite(got2[touched]).any()
+    fin = torch.isfinite(got2)
+    assert torch.equal(got2[fin], got.cpu()[fin])
+    assert int((~fin.all(-1)).sum()) <= 3 * 3 * 6
+    # a weight beyond the range is refused by the packer
+    wbad = w.clone()
+    wbad[1, 1, 1, 0, 0] = 7.0e4
+    with pytest.raises(RuntimeError):
+        ops.conv(x[0].to(cuda), ('rng', 2), wbad.numpy())
+    ops.clear_pack_cache()
 
 
 @pytest.mark.parametrize('B,D,h,w', [(1, 6, 16, 40), (2, 9, 19, 70)])

@@ -235,3 +235,16 @@ def test_weight_reload_drops_arranged_copies():
     store.set('conv_b1_1_1/conv3d/kernel', np.zeros_like(w))
     assert not ops._pack_cache and not ops._fold_cache and not ops._xp_cache and not ops._virt_cache
     store.set('conv_b1_1_1/conv3d/kernel', w)
+
+
+def test_results_outside_the_fp16_range_fail_loudly():
+    """The split-operand kernels turn an activation beyond +-65504 into inf/NaN; the host drivers refuse such a result by name
+    instead of writing it to disk (atvsnet/example.py check_finite)."""
+    from atvsnet_amd.atvsnet import example
+    ok = np.linspace(0.001, 0.01, 12, dtype=np.float32).reshape(3, 4)
+    assert example.check_finite(ok) is ok
+    bad = ok.copy()
+    bad[1, 2] = np.nan
+    bad[2, 0] = np.inf
+    with pytest.raises(FloatingPointError, match='2 non-finite.*ATVS_BF16X3=0'):
+        example.check_finite(bad)

@@ -1,6 +1,7 @@
-"""Host functions of the split-bf16 kernels (no GPU): the weight packers of include/atvsnet_hip.h that arrange a TF kernel as
-three bf16 pieces per weight in the lane order of v_mfma_f32_16x16x32_bf16, their size queries, and the argument checks the
-launch entry points make before they touch the HIP runtime."""
+"""Host functions of the split-operand kernels (no GPU): the weight packers of include/atvsnet_hip.h that arrange a TF kernel as
+two fp16 pieces per weight (w = g0 + g1 / 2048; the transposed convolution: three bf16 pieces) in the lane order of
+v_mfma_f32_16x16x32_{f16,bf16}, their size queries, and the argument checks the launch entry points make before they touch the
+HIP runtime."""
 import ctypes
 
 import numpy as np
@@ -27,13 +28,15 @@ def _pack(name, w, cin, cout):
 
 
 def _check_pieces(p, want):
-    """p: (..., 3 pieces, ...) decoded to float32 with the piece axis FIRST; want: the weights in the same arrangement."""
-    p0, p1, p2 = p.astype(np.float64)
-    # piece 0 is the round-to-nearest-even bf16 of the weight, the pieces descend, and their sum is the weight to 2^-24
-    rne = torch.from_numpy(want.astype(np.float32)).bfloat16().float().numpy()
-    assert np.array_equal(p0.astype(np.float32), rne)
-    assert np.all(np.abs(p1) <= np.abs(p0) * 2.0 ** -7 + 1e-45) and np.all(np.abs(p2) <= np.abs(p0) * 2.0 ** -15 + 1e-45)
-    assert np.abs((p0 + p1 + p2) - want).max() <= np.abs(want).max() * 2.0 ** -23
+    """p: (2 pieces, ...) fp16 with the piece axis FIRST; want: the weights (float32) in the same arrangement.
+    g0 = fp16(w) (round to nearest even), g1 = fp16((w - g0) * 2048) -- the kernels' own split (conv_xb.hip xb_split2) -- and
+    g0 + g1 / 2048 is the weight to 2^-22."""
+    g0, g1 = p
+    want = want.astype(np.float32)
+    assert np.array_equal(g0, want.astype(np.float16))
+    assert np.array_equal(g1, ((want - g0.astype(np.float32)) * np.float32(2048.0)).astype(np.float16))
+    back = g0.astype(np.float64) + g1.astype(np.float64) / 2048.0
+    assert np.abs(back - want).max() <= np.abs(want).max() * 2.0 ** -21
 
 
 @pytest.mark.parametrize('cin,cout', [(32, 32), (64, 128), (128, 64)])
@@ -43,7 +46,7 @@ def test_conv1x1_b_pack_layout(cin, cout):
     w = np.random.default_rng(cin + cout).standard_normal((cin, cout)).astype(np.float32)
     buf = _pack('atvs_conv1x1_b', w, cin, cout)
     nt = cout // 16
-    p = _f32(buf.view(np.uint16)).reshape(cin // 32 + 1, nt, 3, 4, 16, 8)       # chunk, n, piece, q, co16, e
+    p = buf.view(np.float16).reshape(cin // 32 + 1, nt, 2, 4, 16, 8)            # chunk, n, piece, q, co16, e
     assert not p[-1].any()
     want = w.reshape(cin // 32, 4, 8, nt, 16).transpose(0, 3, 1, 4, 2)              # chunk, n, q, co16, e
     _check_pieces(np.moveaxis(p[:-1], 2, 0), want)
@@ -58,7 +61,7 @@ def test_conv3d_b_pack_layout(name, cin, cout):
     buf = _pack(name, w, cin, cout)
     assert not buf[-16:].any()
     nt, nch = cout // 16, cin // 16
-    p = _f32(buf[:-16].view(np.uint16)).reshape(nch, 14, nt, 3, 2, 2, 16, 8)     # chunk, j, n, piece, tap half, ci half, co16, e
+    p = buf[:-16].view(np.float16).reshape(nch, 14, nt, 2, 2, 2, 16, 8)          # chunk, j, n, piece, tap half, ci half, co16, e
     w28 = np.concatenate([w.reshape(27, cin, cout), np.zeros((1, cin, cout), np.float32)])
     want = w28.reshape(14, 2, nch, 2, 8, nt, 16).transpose(2, 0, 5, 1, 3, 6, 4)    # chunk, j, n, tap half, ci half, co16, e
     _check_pieces(np.moveaxis(p, 3, 0), want)

@@ -46,20 +46,36 @@ else:
     u8 = wt(16, 8)
     run = lambda: ops.conv(x, 'd8', u8, want_stats=True, plane_bias=pb, groups=G)   # noqa: E731
     mf = (384, 0)
-for _ in range(3):
+for _ in range(int(os.environ.get('ITERS', 3))):
     run()
 torch.cuda.synchronize()
 buf = np.zeros(8192 * 8, np.uint64)
 rc = _lib.lib().atvs_debug_read_xw(buf.ctypes.data_as(ctypes.c_void_p))
 assert rc == 0
 b = buf.reshape(-1, 8).astype(np.float64)
+if os.environ.get('XB'):
+    # conv_xb.hip: 8 wavefronts per workgroup, rows (workgroup * 8 + wave); waves 0..3 multiply, 4..7 stage
+    b = b[:512 * 8].reshape(512, 8, 8)
+    b = b[b[:, 0, 7] > 0]
+    ns = b[:, 0, 7].mean()
+    cons, prod = b[:, :4].reshape(-1, 8), b[:, 4:].reshape(-1, 8)
+    raw = buf.reshape(-1, 8)[:512 * 8].reshape(512, 8, 8)[:, 0, 6]
+    raw = raw[raw > 0]
+    wall, cyc = (raw >> np.uint64(32)).astype(np.float64), (raw & np.uint64(0xffffffff)).astype(np.float64) * 256
+    print('%s: workgroups %d, stages per workgroup %.0f; shader clock during the launch %.2f GHz (%.3f ms)' % (which, len(b), ns, (cyc / (wall * 10.0)).mean(), wall.mean() / 1e5))
+    for nm, rows, names in (('consumer', cons, ['setup + first fragments', '-', 'main K loop (108 MFMAs x 16 cyc = 1728)', 'sibling K loop (21 MFMAs x 16 cyc = 336)', 'epilogue', 'barrier wait']),
+                            ('producer', prod, ['weights -> LDS, next weights / parameters requested', 'rest', 'next tile, mask, descriptors', 'slots: prologue + split + LDS write + next load', '-', 'barrier wait'])):
+        tot = rows[:, :6].sum(1).mean()
+        print('%s wavefronts: %.0f cycles per stage' % (nm, tot / ns))
+        for i, n in enumerate(names):
+            if n != '-':
+                print('   %-52s %8.0f per stage (%.1f%%)' % (n, rows[:, i].mean() / ns, 100 * rows[:, i].mean() / tot))
+    sys.exit(0)
 b = b[b[:, 7] > 0]
 ns = b[:, 7].mean()
-NP = 7 if os.environ.get('XB') else 6
+NP = 6
 tot = b[:, :NP].sum(1).mean()
 print('%s: waves %d, stages per wave %.0f, mean cycles per stage %.0f (s_memtime ticks = 100 MHz x ? -- ratios matter)' % (which, len(b), ns, tot / ns))
 names = ['loop top (+acc zero)', 'stage setup (pf_tile, addresses)', 'main K loop (%d MFMAs)' % mf[0], 'sibling K loop (%d MFMAs)' % mf[1], 'epilogue (every nchunk-th stage)', 'barrier']
-if os.environ.get('XB'):
-    names = ['setup (tile, addresses, first fragments)', 'transform + split + LDS write', 'main K loop (216 MFMAs x 16 cyc)', 'sibling K loop (42 MFMAs x 16 cyc)', 'epilogue', 'barrier 1 (others done reading)', 'barrier 2 (images written)']
 for i, n in enumerate(names):
     print('%-40s %9.0f per stage (%.1f%%)' % (n, b[:, i].mean() / ns, 100 * b[:, i].mean() / tot))
