@@ -96,6 +96,7 @@ def parse(argv=None):
     p.add_argument('--depths', type=int, default=None)
     p.add_argument('--views', type=int, default=None)
     p.add_argument('--no-cpu-baseline', action='store_true')
+    p.add_argument('--no-power', action='store_true', help='skip the ~2 s socket-power / shader-clock probe after the timed region')
     p.add_argument('--no-parity', action='store_true')
     p.add_argument('--no-split-bf16', action='store_true', help='skip the secondary measurement with the split-bf16 layers switched the other way')
     p.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
@@ -397,6 +398,55 @@ def cpu_baseline(args):
 
 # --------------------------------------------------------------------------------------------- reporting helpers
 
+def power_probe(step, seconds=2.0):
+    """Socket power and shader clock while `step` repeats for `seconds` (rocm-smi sampled from a second thread), AFTER the timed
+    region: does the workload run into the package's power management?  (It does: DESIGN.md 6.)  None where rocm-smi is not
+    usable."""
+    import shutil
+    import subprocess
+    import threading
+    if shutil.which('rocm-smi') is None:
+        return None
+    samples, stop = [], [False]
+
+    def sampler():
+        while not stop[0]:
+            try:
+                out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower', '--json'], stdout=subprocess.PIPE,
+                                     stderr=subprocess.DEVNULL, timeout=5).stdout.decode()
+                card = list(json.loads(out).values())[0]
+                pw = [float(v) for k, v in card.items() if 'Power' in k and 'Max' not in k]
+                cap = [float(v) for k, v in card.items() if 'Max' in k and 'Power' in k]
+                clk = [int(''.join(c for c in v.split('(')[-1] if c.isdigit())) for k, v in card.items() if k.startswith('sclk')]
+                if pw and clk:
+                    samples.append((time.perf_counter(), pw[0], clk[0], cap[0] if cap else None))
+            except Exception:                                # noqa: BLE001
+                pass
+            time.sleep(0.15)
+
+    th = threading.Thread(target=sampler, daemon=True)
+    t0 = time.perf_counter()
+    th.start()
+    n = 0
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(5):
+            step()
+        n += 5
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    stop[0] = True
+    th.join(timeout=6)
+    warm = [s_ for s_ in samples if s_[0] - t0 > 0.5 and s_[0] - t0 < dt]       # past the ramp
+    if not warm:
+        return None
+    return {'socket_W': round(float(np.mean([s_[1] for s_ in warm])), 1), 'cap_W': warm[0][3],
+            'sclk_MHz': int(round(float(np.mean([s_[2] for s_ in warm])))), 'peak_sclk_MHz': 2400, 'samples': len(warm),
+            'seconds': round(dt, 2), 'ms_per_step': round(1e3 * dt / n, 3),
+            'note': 'the timed step repeated for ~2 s after the timed region, rocm-smi sampled every 0.15 s (first 0.5 s dropped): the '
+                    'pipeline holds the package at its power cap and the firmware lowers the shader clock below the 2.4 GHz the MFMA '
+                    'peak is quoted at -- energy per depth map, not issue slots, is what the split-operand convolutions are bound by'}
+
+
 def pmc_traffic(args, samples):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes of THIS kernel as bench.py
     launches it (profiles/round3_pmc_xpair.json: the dominant x-pair launch, 8 volumes per launch, 640x512x192; only valid
@@ -657,6 +707,13 @@ def rank_main(args):
         finally:
             ops.use_bf16x3(default_on)
 
+    power = None
+    if world == 1 and not args.no_power:
+        try:
+            power = power_probe(step)
+        except Exception as e:                                # noqa: BLE001
+            power = {'error': repr(e)}
+
     # the dominant kernel and the warp, timed by HIP events on their launch stream in ten eager single-stream passes
     # of the same step right after the timed region (kernels inside a replayed graph cannot be bracketed by events;
     # single stream: no other kernel shares the GPU with the one being timed)
@@ -794,7 +851,7 @@ def rank_main(args):
             'latency_ms': round(1e3 * dt / args.steps, 3),
             'pipelined': pipelined,
             'split_operands': split,
-            'roofline': roof, 'roofline_hbm': roof_hbm, 'kernels': top_kernels(),
+            'roofline': roof, 'roofline_hbm': roof_hbm, 'power': power, 'kernels': top_kernels(),
         }
         if comm is not None:
             line['exchange'] = comm

@@ -7,7 +7,7 @@ src = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(src, 'summary.json')))
 out = {'note': 'rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only; tools_dev/pmc_bench.sh) over `bench.py --eager '
-               '--inflight 1` of the final round-3 library on MI355X: per-launch averages for the kernels of one depth map (config 3), '
+               '--inflight 1` of the round-4 library on MI355X: per-launch averages for the kernels of one depth map (config 3), '
                'sorted by total time.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); valu_per_mfma = '
                '(SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA; clock_GHz = GRBM_GUI_ACTIVE / 8 / duration; fetch / write = FETCH_SIZE / '
                'WRITE_SIZE (KB at the memory side of L2, Infinity-Cache hits included; wide coalesced reads count at half their bytes '
