@@ -398,52 +398,75 @@ def cpu_baseline(args):
 
 # --------------------------------------------------------------------------------------------- reporting helpers
 
-def power_probe(step, seconds=2.0):
-    """Socket power and shader clock while `step` repeats for `seconds` (rocm-smi sampled from a second thread), AFTER the timed
-    region: does the workload run into the package's power management?  (It does: DESIGN.md 6.)  None where rocm-smi is not
-    usable."""
-    import shutil
-    import subprocess
+def hwmon_dir(device=0):
+    """The hwmon directory (socket power, shader clock) of HIP device `device`: the drm card with the device's PCI bus id.
+    sysfs only -- no child process is started from the GPU-initialised benchmark process."""
+    import ctypes
+    import glob
+    try:
+        hip = ctypes.CDLL('libamdhip64.so')
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device)) != 0:
+            return None
+        bus = buf.value.decode().lower()
+    except OSError:
+        return None
+    for card in glob.glob('/sys/class/drm/card*/device'):
+        if os.path.basename(os.path.realpath(card)).lower() == bus:
+            hw = sorted(glob.glob(os.path.join(card, 'hwmon', 'hwmon*')))
+            return hw[0] if hw else None
+    return None
+
+
+def _read_int(path):
+    try:
+        with open(path) as f:
+            return int(f.read().strip())
+    except (OSError, ValueError):
+        return None
+
+
+def power_probe(step, seconds=2.0, device=0):
+    """Socket power and shader clock while `step` repeats for `seconds` (the amdgpu hwmon files of THIS device sampled from a
+    second thread), AFTER the timed region: does the workload run into the package's power management?  (It does: DESIGN.md
+    4.1, 6.)  None where the files are not readable."""
     import threading
-    if shutil.which('rocm-smi') is None:
+    import torch
+    hw = hwmon_dir(device)
+    if hw is None or _read_int(os.path.join(hw, 'power1_input')) is None:
         return None
     samples, stop = [], [False]
 
     def sampler():
         while not stop[0]:
-            try:
-                out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--showmaxpower', '--json'], stdout=subprocess.PIPE,
-                                     stderr=subprocess.DEVNULL, timeout=5).stdout.decode()
-                card = list(json.loads(out).values())[0]
-                pw = [float(v) for k, v in card.items() if 'Power' in k and 'Max' not in k]
-                cap = [float(v) for k, v in card.items() if 'Max' in k and 'Power' in k]
-                clk = [int(''.join(c for c in v.split('(')[-1] if c.isdigit())) for k, v in card.items() if k.startswith('sclk')]
-                if pw and clk:
-                    samples.append((time.perf_counter(), pw[0], clk[0], cap[0] if cap else None))
-            except Exception:                                # noqa: BLE001
-                pass
-            time.sleep(0.15)
+            pw, clk = _read_int(os.path.join(hw, 'power1_input')), _read_int(os.path.join(hw, 'freq1_input'))
+            if pw is not None and clk is not None:
+                samples.append((time.perf_counter(), pw / 1e6, clk / 1e6))
+            time.sleep(0.02)
 
     th = threading.Thread(target=sampler, daemon=True)
     t0 = time.perf_counter()
     th.start()
     n = 0
-    while time.perf_counter() - t0 < seconds:
-        for _ in range(5):
-            step()
-        n += 5
-        torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    stop[0] = True
-    th.join(timeout=6)
-    warm = [s_ for s_ in samples if s_[0] - t0 > 0.5 and s_[0] - t0 < dt]       # past the ramp
+    try:
+        while time.perf_counter() - t0 < seconds:
+            for _ in range(5):
+                step()
+            n += 5
+            torch.cuda.synchronize()
+    finally:
+        dt = time.perf_counter() - t0
+        stop[0] = True
+        th.join(timeout=2)
+    warm = [s_ for s_ in samples if 0.5 < s_[0] - t0 < dt]       # past the ramp
     if not warm:
         return None
-    return {'socket_W': round(float(np.mean([s_[1] for s_ in warm])), 1), 'cap_W': warm[0][3],
+    cap = _read_int(os.path.join(hw, 'power1_cap'))
+    return {'socket_W': round(float(np.mean([s_[1] for s_ in warm])), 1), 'cap_W': None if cap is None else cap / 1e6,
             'sclk_MHz': int(round(float(np.mean([s_[2] for s_ in warm])))), 'peak_sclk_MHz': 2400, 'samples': len(warm),
-            'seconds': round(dt, 2), 'ms_per_step': round(1e3 * dt / n, 3),
-            'note': 'the timed step repeated for ~2 s after the timed region, rocm-smi sampled every 0.15 s (first 0.5 s dropped): the '
-                    'pipeline holds the package at its power cap and the firmware lowers the shader clock below the 2.4 GHz the MFMA '
+            'seconds': round(dt, 2), 'ms_per_step': round(1e3 * dt / n, 3), 'source': 'amdgpu hwmon power1_input / freq1_input',
+            'note': 'the timed step repeated for ~2 s after the timed region, hwmon sampled every 20 ms (first 0.5 s dropped): the '
+                    'pipeline holds the package near its power cap and the firmware lowers the shader clock below the 2.4 GHz the MFMA '
                     'peak is quoted at -- energy per depth map, not issue slots, is what the split-operand convolutions are bound by'}
 
 

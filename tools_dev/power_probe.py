@@ -1,12 +1,8 @@
-"""Socket power and shader clock while ONE x-pair launch repeats for a few seconds (rocm-smi sampled from a second thread):
+"""Socket power and shader clock while ONE x-pair launch repeats for a few seconds (amdgpu hwmon sampled from a second thread):
 is the launch running into the package's power management?
     [ATVS_LIB=<variant .so>] python tools_dev/power_probe.py [dominantp|stack|refine|stem] [seconds]"""
-import json
 import os
-import subprocess
 import sys
-import threading
-import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -39,41 +35,10 @@ else:
     u8 = wt(16, 8)
     run = lambda: ops.conv(x, 'd8', u8, want_stats=True, plane_bias=pb, groups=G)   # noqa: E731
 
-samples, stop = [], False
-
-
-def sampler():
-    while not stop:
-        try:
-            out = subprocess.run(['rocm-smi', '--showpower', '--showclocks', '--json'], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
-                                 timeout=5).stdout.decode()
-            card = list(json.loads(out).values())[0]
-            pw = [float(v) for k, v in card.items() if 'Power' in k and 'W' in k]
-            sclk = [v for k, v in card.items() if k.startswith('sclk')]
-            samples.append((time.time(), pw[0] if pw else float('nan'), sclk[0] if sclk else '?'))
-        except Exception as e:          # noqa: BLE001
-            samples.append((time.time(), float('nan'), repr(e)))
-        time.sleep(0.2)
-
+import bench                                           # noqa: E402  (hwmon sampling: bench.power_probe)
 
 for _ in range(20):
     run()
 torch.cuda.synchronize()
-th = threading.Thread(target=sampler)
-th.start()
-t0 = time.time()
-n = 0
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-while time.time() - t0 < secs:
-    for _ in range(50):
-        run()
-    n += 50
-    torch.cuda.synchronize()
-e1.record()
-torch.cuda.synchronize()
-stop = True
-th.join()
-print('%s: %.3f ms per launch over %d launches (%.1f s, host loop included)' % (which, e0.elapsed_time(e1) / n, n, time.time() - t0))
-for t, pw, clk in samples:
-    print('   t = %4.1f s   %7.1f W   sclk %s' % (t - t0, pw, clk))
+r = bench.power_probe(run, secs)
+print(which, r if r is None else {k: v for k, v in r.items() if k != 'note'})
