@@ -431,6 +431,7 @@ def power_probe(step, seconds=2.0, device=0):
     second thread), AFTER the timed region: does the workload run into the package's power management?  (It does: DESIGN.md
     4.1, 6.)  None where the files are not readable."""
     import threading
+    import numpy as np
     import torch
     hw = hwmon_dir(device)
     if hw is None or _read_int(os.path.join(hw, 'power1_input')) is None:
@@ -465,9 +466,10 @@ def power_probe(step, seconds=2.0, device=0):
     return {'socket_W': round(float(np.mean([s_[1] for s_ in warm])), 1), 'cap_W': None if cap is None else cap / 1e6,
             'sclk_MHz': int(round(float(np.mean([s_[2] for s_ in warm])))), 'peak_sclk_MHz': 2400, 'samples': len(warm),
             'seconds': round(dt, 2), 'ms_per_step': round(1e3 * dt / n, 3), 'source': 'amdgpu hwmon power1_input / freq1_input',
-            'note': 'the timed step repeated for ~2 s after the timed region, hwmon sampled every 20 ms (first 0.5 s dropped): the '
-                    'pipeline holds the package near its power cap and the firmware lowers the shader clock below the 2.4 GHz the MFMA '
-                    'peak is quoted at -- energy per depth map, not issue slots, is what the split-operand convolutions are bound by'}
+            'note': 'the timed step repeated for ~2 s after the timed region, hwmon sampled every 20 ms (first 0.5 s dropped): the average '
+                    'over ALL kernels of the step.  The split-operand convolution launches alone hold the package AT its cap with the '
+                    'shader clock far below the 2.4 GHz the MFMA peak is quoted at (tools_dev/power_probe.py, DESIGN.md 4.1: dominant '
+                    'launch 1,370-1,400 W at 1.85-1.90 GHz) -- energy per launch, not issue slots, is what bounds them'}
 
 
 def pmc_traffic(args, samples):
