@@ -478,6 +478,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
     float* __restrict__ y2g = p.y2 + (size_t)grp * p.gy2;
     const float* __restrict__ pbg = p.pbias ? p.pbias + (size_t)grp * p.gpb : nullptr;
     const float* __restrict__ pb2g = p.pbias2 ? p.pbias2 + (size_t)grp * p.gpb2 : nullptr;
+    const bool any_pb = pbg != nullptr || pb2g != nullptr;
     float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) bv = ld4(p.bias + (q & 1) * 4);
     f32x4 acc[XB_TY], accx[XB_TY];       // h0 g0 | (h0 g1 + h1 g0) * 2^11
@@ -535,7 +536,12 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
       };
       request_A(0);
       request_B(0, 0);
-      if (last_chunk) {                          // the epilogue's depth-plane biases: a whole K loop to arrive (uniform branch)
+      // the epilogue's depth-plane biases: a whole K loop to arrive (uniform branches).  A launch WITHOUT plane biases issues no load
+      // here at all: loads and stores share one in-order counter, so a load of zeros would make every epilogue wait for the
+      // acknowledgement of the previous tile's stores (one-chunk launches: an HBM write round trip per stage).  (No zero
+      // initialisation in front of the loads either: the compiler turns "zero or loaded" into a select and waits for the load on
+      // the spot.)
+      if (last_chunk && any_pb) {
 #pragma unroll
         for (int t = 0; t < XB_TY; ++t) epb[t] = ld4((pbg && erow_ok(t)) ? pbg + (epb_off + (size_t)t * p.Wi * 24) : p.zeros);
         if (SIB) {
@@ -597,6 +603,20 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
       XDBG(3)
       if (last_chunk) {
         // ---- epilogue (conv_xp.hip): this lane holds channels co..co+3 of voxel xo for the 4 rows of plane zo
+        // Every loaded epilogue operand passes through an (empty) assembly statement FIRST: the compiler waits for them here,
+        // once.  Otherwise its loop-carried bookkeeping puts s_waitcnt vmcnt(0) in front of each row's first use of the bias --
+        // loads and stores share the counter, so every row waited for the previous row's store to be acknowledged (an HBM
+        // write round trip per row: 3,700-5,200 cycles per epilogue, phase timers).
+        asm volatile("" : "+v"(bv.x), "+v"(bv.y), "+v"(bv.z), "+v"(bv.w));
+        if (any_pb) {
+          asm volatile("" : "+v"(epb2.x), "+v"(epb2.y), "+v"(epb2.z), "+v"(epb2.w));
+#pragma unroll
+          for (int t = 0; t < XB_TY; ++t) asm volatile("" : "+v"(epb[t].x), "+v"(epb[t].y), "+v"(epb[t].z), "+v"(epb[t].w));
+        } else {                             // (+ 0 as a launch with all-zero biases adds it: the same bits, -0 included)
+#pragma unroll
+          for (int t = 0; t < XB_TY; ++t) epb[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+          epb2 = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         auto store_rows = [&](auto relu_tag) __attribute__((always_inline)) {
 #pragma unroll
           for (int t = 0; t < XB_TY; ++t) {
