@@ -1,7 +1,6 @@
-// 3x3x3 SAME stride-1 convolution to EIGHT output channels in x-pair form on the 16-bit matrix cores with SPLIT operands, one
-// wavefront per SIMD (gfx950): conv_xp.hip's layers (conv_b*_0_1, global_refine_3dconv0_1, the photo stem; stride-2 sibling
-// conv_b*_1_0 / 3dconv1_0 from the same staged image; /root/reference/cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet,
-// layer code network.py:165-215).
+// 3x3x3 SAME stride-1 convolution to EIGHT output channels in x-pair form on the 16-bit matrix cores with SPLIT operands (gfx950):
+// the layers conv_b*_0_1, global_refine_3dconv0_1, the photo stem, and from the same staged image their stride-2 sibling
+// conv_b*_1_0 / 3dconv1_0 (/root/reference/cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, layer code network.py:165-215).
 //
 // Arithmetic (round 4): every fp32 operand is split into TWO fp16 pieces, x = h0 + h1 / 2048 with h0 = f16(x) and
 // h1 = f16((x - h0) * 2048) (the residual scaled into fp16's normal range: 22 significant bits, no denormal loss), w = g0 + g1 /
@@ -14,19 +13,21 @@
 // |x| <= sqrt(voxels) + |beta|; the packer refuses such weights.
 //
 // One K = 32 instruction covers the FOUR x offsets a voxel pair touches x 8 channels: lane group q = x offset xl, so a
-// (kd, kh) tap row of an 8-channel chunk is ONE K step (36 fp32 16x16x4 steps of conv_xp become 9), rows = (x parity,
-// channel) as in conv_xp (3/4 of the MFMA work useful).  Per 8-channel chunk and 8 rows: 9 steps x 3 products x 8 = 216
-// instructions of 16 cycles (round 3: 432; conv_xw: 384 of 32 cycles).
+// (kd, kh) tap row of an 8-channel chunk is ONE K step, rows = (x parity, channel): 3/4 of the MFMA work useful.  Per 8-channel
+// chunk and 4 rows: 9 steps x 3 products x 4 = 108 instructions of 16 cycles per multiplying wavefront, + 21 for the sibling
+// (K step i = taps 4 i + q of the 27: 7 steps x 3 products on the wavefront's one sibling row).
 //
-// Structure: tile 4(z) x 8(y) x 32(x), wavefront w owns plane z0 + w (8 + 8 accumulator tiles); the input is staged in 8-channel
-// chunks as TWO piece images [6][10][even / odd x interleaved in runs of eight][8 fp16] (46 KB each, single-buffered: the next
-// stage's halo waits in registers as in conv_xp, two barriers per stage); the split happens once per staged element, after
-// the optional prologue (batch norm + ReLU of the producers, skip add).  Weights (two pieces per step, split on the host): the
-// NEXT chunk's 32 KB are fetched at the top of the K loop (eight 16-byte loads per thread, L2 hits) and written into the other
-// of two LDS weight buffers a few phases later; the K loop reads its A fragments from LDS one step ahead.  (Round 3 streamed
-// them from L2 into registers inside the loop: vector-memory operations retire in order, so every weight request queued behind
-// the HBM halo loads of the phases before it and each K step waited for memory latency -- halving the MFMA count alone bought
-// 30 %, not 2 x.)  Sibling: K step i = taps 4 i + q of the 27 (7 steps), 2 rows per wavefront.
+// Structure (round 4, second half): ONE workgroup of EIGHT wavefronts per CU, two roles.  Wavefronts 0..3 (one per SIMD) MULTIPLY:
+// wavefront w owns plane z0 + w of a 4(z) x 4(y) x 32(x) tile (4 main + 4 cross accumulator tiles) and sibling row (w >> 1, w & 1);
+// their loop holds LDS reads and MFMAs only.  Wavefronts 4..7 (the second wavefront of each SIMD) STAGE the next stage: the fp32
+// halo of an 8-channel chunk (6 x 6 x 34 voxels, buffer loads with out-of-volume slots addressed out of range = zeros), the
+// optional prologue (batch norm + ReLU of the producers, skip add), the split, the two piece images [6][6][even / odd x
+// interleaved in runs of eight][8 fp16] (23 KB each) of the OTHER of two image buffers, and the chunk's 32 KB of weight pieces
+// into the other of two weight buffers; the prologue's parameters of all chunks sit in the last 3.8 KB of LDS.  One barrier per
+// stage.  The staging wavefronts' loads are issued by inline assembly and waited for with exact s_waitcnt vmcnt counts (the
+// comment at the loads says why; tools_dev/check_xb_inflight.py checks that the compiler moves no loaded register).  Its vector
+// arithmetic is scalar fp32 (built with -fno-slp-vectorize): the staging wavefronts compute beside the kernel's own MFMA
+// wavefronts on every SIMD.  What bounds the launches is the package's power cap.
 #include <cstring>
 #include <type_traits>
 

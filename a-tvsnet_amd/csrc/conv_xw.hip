@@ -1,4 +1,5 @@
 // 3x3x3 SAME stride-1 convolution to EIGHT output channels: x-pair rows x Winograd F(2,3) along y, one wavefront per
+// (conv_xp.hip, referred to below, was this kernel's direct fp32 predecessor -- round 2, removed from the tree in round 4: git history.)
 // SIMD (gfx950).  Successor of conv_xp.hip for the widest layers of the stacked U-Nets / the refinement net
 // (conv_b*_0_1, global_refine_3dconv0_1, the photo stem: cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, layer
 // code /root/reference/cnn_wrapper/network.py:165-215).
@@ -567,6 +568,17 @@ int launch_xw(const XwArgs& a, long blocks, hipStream_t s) {
 
 }  // namespace
 
+// workgroups PER SAMPLE of an x-pair launch (atvs_conv_xw_f32 / atvs_conv_xb_f32) over `groups` independent samples (rows of the
+// statistics buffer = groups * this): one workgroup per CU in all, shared out among the samples, a multiple of 8 each
+extern "C" long atvs_conv_xp_grid(int D, int H, int W, int groups) {
+  if (groups < 1) groups = 1;
+  long nt = xw_ntiles(D, H, W);
+  long share = 256 / groups / 8 * 8;
+  if (share < 8) share = 8;
+  long g = nt < share ? nt : share;
+  return (g + 7) / 8 * 8;
+}
+
 // Floats of the packed form of a [3,3,3,Cin,8] kernel (Cin % 8 == 0), including 4 trailing zeros.
 extern "C" int atvs_conv_xw_pack_size(int Cin, long* packed_floats) {
   if (Cin <= 0 || (Cin % 8) || !packed_floats) return ATVS_ERR_SHAPE;
@@ -634,7 +646,7 @@ extern "C" int atvs_conv_xw_pack_sibling(const float* w2, int Cin, float* packed
 }
 
 // Same contract as atvs_conv_xp_f32 (include/atvsnet_hip.h) with weights packed by atvs_conv_xw_pack[_sibling]; grid and
-// statistics rows = atvs_conv_xp_grid.  Results differ from atvs_conv_xp_f32 by fp32 rounding only (F(2,3) along y).
+// statistics rows = atvs_conv_xp_grid.  Results differ from the direct sum by fp32 rounding only (F(2,3) along y).
 extern "C" int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias,
                                 float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
                                 int relu, const float* packed_w2, const float* plane_bias2, float* y2,

@@ -368,21 +368,20 @@ def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y, xpair
     return pk
 
 
-_USE_XW = True
 _USE_XB = os.environ.get('ATVS_BF16X3', '1') == '1'
 _USE_PLANAR = True
 
 
 def use_xb(flag):
-    """Testing / A-B hook: the split-bf16 form of the x-pair kernel (conv_xb.hip: three bf16 pieces per operand, six
-    products, fp32 accumulation) in front of the fp32 kernels (conv_xw.hip / conv_xp.hip)."""
+    """Testing / A-B hook: the split-operand form of the x-pair kernel (conv_xb.hip: two fp16 pieces per operand, three
+    products, fp32 accumulation) in front of the fp32 kernel (conv_xw.hip)."""
     global _USE_XB
     _USE_XB = bool(flag)
 
 
 def _xkind():
     """Which one-workgroup-per-CU x-pair kernel serves the 8-output-channel layers."""
-    return 'xb' if _USE_XB else ('xw' if _USE_XW else 'xp')
+    return 'xb' if _USE_XB else 'xw'
 
 
 def use_planar(flag):
@@ -406,19 +405,13 @@ def planar_view(buf, D, h, w):
 
 
 def planar_cost_volume_ok(shape, F):
-    """Should build_cost_volumes write the warped half chunk-planar?  Only when its one consumer -- the x-pair launch of
-    conv_b0_0_1 | conv_b0_1_0 -- is the Winograd kernel."""
-    return (_USE_PLANAR and _xkind() != 'xp' and F in (16, 32, 64) and siblings_ok(tuple(shape), F, 8, 16))
-
-
-def use_xw(flag):
-    """Testing / A-B hook: the Winograd F(2,3)-along-y form of the x-pair kernel (conv_xw.hip) instead of conv_xp.hip."""
-    global _USE_XW
-    _USE_XW = bool(flag)
+    """Should build_cost_volumes write the warped half chunk-planar?  When its one consumer is an x-pair launch of
+    conv_b0_0_1 | conv_b0_1_0 (both x-pair kernels read the layout)."""
+    return (_USE_PLANAR and F in (16, 32, 64) and siblings_ok(tuple(shape), F, 8, 16))
 
 
 def pack_conv_xp(key, w_host, device):
-    """Packed weights of the one-workgroup-per-CU x-pair kernel (atvs_conv_xp_f32 / atvs_conv_xw_f32); cached."""
+    """Packed weights of the one-workgroup-per-CU x-pair kernels (atvs_conv_xb_f32 / atvs_conv_xw_f32); cached."""
     import numpy as np
     kind = _xkind()
     xw = kind == 'xw'
@@ -777,7 +770,7 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
 
 def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None,
                    prologue=None, planar=False, ldy=None, y_gstride=0, y_off=0):
-    """One atvs_conv_xp_f32 launch: x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
+    """One x-pair launch (atvs_conv_xb_f32 / atvs_conv_xw_f32): x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
     sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5.
     prologue = (x2 | None, params | None, params2 | None, relu, relu2): the input is formed on load as
     act(bn(x5)) [+ act(bn(x2))] (include/atvsnet_hip.h)."""
@@ -797,11 +790,8 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
         if ip is not None and (ip.numel() != G * 3 * Cin or not ip.is_contiguous()):
             raise ValueError('conv_xp: prologue parameters must be (groups, 3, Cin)')
     kind = pk.kind
-    xw = kind in ('xw', 'xb')             # the kernels that take the chunk-planar layout
     if pk2 is not None and pk2.kind != kind:
         raise ValueError('conv_xp: the main and the sibling weights are packed for different kernels')
-    if planar and not xw:
-        raise ValueError('conv_xp: the chunk-planar input layout belongs to the Winograd kernel')
     if (y_gstride or (planar and prologue is not None)) and kind != 'xb':
         raise ValueError('conv_xp: a strided output / a prologue over a chunk-planar input belong to the split-bf16 kernel')
     if _dev_ok(x5, y, bias, plane_bias, y2, pb2, x2, ipa, ipb):
@@ -814,10 +804,8 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
             if kind == 'xb':
                 _call('atvs_conv_xb_f32', *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0),
                                                     ctypes.c_long(int(y_gstride)), _stream()]))
-            elif xw:
-                _call('atvs_conv_%s_f32' % kind, *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0), _stream()]))
             else:
-                _call('atvs_conv_xp_f32', *(args + [_stream()]))
+                _call('atvs_conv_xw_f32', *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0), _stream()]))
 
 
 def xp_blocks(D, H, W, groups=1):
@@ -1523,7 +1511,7 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
         x, prologue = x.prologue()
     if planar:             # x: (G, Cin/8, planar_stride(D,H,W)) chunk-planar buffer, planar = (D,H,W); not the direct fp32 kernel
         D, H, W = planar
-        if (prologue is not None and _xkind() != 'xb') or _xkind() == 'xp' or groups is None or x.dim() != 3 \
+        if (prologue is not None and _xkind() != 'xb') or groups is None or x.dim() != 3 \
                 or not x.is_contiguous() or x.shape[2] != planar_stride(D, H, W):
             raise ValueError('conv_siblings(planar=(D,H,W)): a contiguous (G, Cin/8, planar_stride) buffer (a prologue only '
                              'on the split-bf16 kernel)')
@@ -1565,7 +1553,7 @@ def conv_split_siblings(sv, key, w_host, key2, w2_host):
     wv2, planes2 = _fold_split_weights(key2, w2_host, sv.chan_map, cv, cc)
     pb = conv(sv.const, (key, 'planes'), planes, stride=1, groups=B)
     pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2, groups=B)
-    if sv.planar and _xkind() != 'xp':
+    if sv.planar:
         return conv_siblings(sv._var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B,
                              planar=sv.planar)
     return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B)

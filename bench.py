@@ -776,8 +776,7 @@ def rank_main(args):
             kind = ops._xkind()
             kdesc = {'xb': 'conv_xb_kernel<SIB> (x-pair rows on v_mfma_f32_16x16x32_f16, every fp32 operand split into two fp16 '
                            'pieces, three products, fp32 accumulation)',
-                     'xw': 'conv_xw_kernel<SIB> (x-pair rows x Winograd F(2,3) along y on v_mfma_f32_16x16x4_f32)',
-                     'xp': 'conv_xp_kernel<C4=4,SIB> (x-pair rows on v_mfma_f32_16x16x4_f32)'}[kind]
+                     'xw': 'conv_xw_kernel<SIB> (x-pair rows x Winograd F(2,3) along y on v_mfma_f32_16x16x4_f32)'}[kind]
             pmc = pmc_counters(args, samples)
             fp32_eq = {'achieved': round(ach, 3), 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                        'frac': round(ach / PEAK_F32_MFMA_TFLOPS, 4),
@@ -794,12 +793,9 @@ def rank_main(args):
                 conv = ('achieved = fp16 MFMA FLOPs the launch ISSUES (v_mfma_f32_16x16x32_f16 count x 16384; 4 per algorithmic '
                         'FLOP of the main convolution: three piece products x 4/3 x-pair rows; 3 x 28/27 for the sibling) / '
                         'time, against the dense fp16 / bf16 MFMA peak: the pipe the kernel runs on')
-            elif kind == 'xw':
+            else:
                 issued, peak, pipe = flops * 8.0 / 9.0, PEAK_F32_MFMA_TFLOPS, 'fp32'
                 conv = 'achieved = fp32 MFMA FLOPs issued (F(2,3): 2/3, x-pair rows: 4/3 of the algorithmic FLOPs) / time'
-            else:
-                issued, peak, pipe = flops * 4.0 / 3.0, PEAK_F32_MFMA_TFLOPS, 'fp32'
-                conv = 'achieved = fp32 MFMA FLOPs issued (x-pair rows: 4/3 of the algorithmic FLOPs) / time'
             iss = issued / (avg_ms * 1e-3) / 1e12
             roof = {'bound': 'mfma', 'pipe': pipe,
                     'kernel': '%s: conv_b0_0_1 (32 warped channels -> 8, 3x3x3, full resolution) + sibling conv_b0_1_0 '

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 27
+#define ATVS_ABI_VERSION 28
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -242,40 +242,32 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
 /* conv / conv_bn(3, 8, 1) on a full-resolution volume -- 3x3x3 SAME stride-1 convolution to EIGHT output
  * channels (conv_b*_0_1, global_refine_3dconv0_1, the refinement stems; cnn_wrapper/atvsnet.py, layer code
  * cnn_wrapper/network.py:165-215), Cin % 8 == 0.  x-pair form (two x-adjacent voxels fill the 16 MFMA rows),
- * ONE workgroup per CU with the whole register file and LDS, fully unrolled K loop (conv_xp.hip).
- *   atvs_conv_xp_pack_size / _pack   HOST: pack the TF kernel [3,3,3,Cin,8] (upload the result)
- *   atvs_conv_xp_grid                workgroups of a launch = rows of stats_partial ([2][16] doubles each,
- *                                    columns 0..7 = channels, the layout atvs_bn_finalize takes with cpad 16)
- *   atvs_conv_xp_f32                 y (D,H,W,ldy)[..., y_coff + co] = conv(x) (+ bias, + plane_bias (H,W,24), ReLU)
+ * ONE workgroup per CU with the whole register file and LDS.  Two kernels share the contract: conv_xb.hip (split fp16
+ * operands on the 16-bit matrix cores: the product's kernel) and conv_xw.hip (fp32 matrix cores, Winograd F(2,3) along y:
+ * the A/B form, ops.use_bf16x3(False)).
+ *   atvs_conv_x{w,b}_pack_size / _pack  HOST: pack the TF kernel [3,3,3,Cin,8] (upload the result)
+ *   atvs_conv_xp_grid                   workgroups of a launch PER SAMPLE = rows of stats_partial per sample ([2][16] doubles
+ *                                       each, columns 0..7 = channels, the layout atvs_bn_finalize takes with cpad 16)
+ *   atvs_conv_x{w,b}_f32                y (D,H,W,ldy)[..., y_coff + co] = conv(x) (+ bias, + plane_bias (H,W,24), ReLU)
  * Sibling: the U-Nets feed the same tensor to conv_b*_0_1 (8 channels, stride 1) and to the encoder branch
  * conv_b*_1_0 (16 channels, stride 2; cnn_wrapper/atvsnet.py StackedUNet, CostVolRefineNet 0_1 / 1_0).  With
- * packed_w2 != NULL (atvs_conv_xp_pack_sibling of the TF kernel [3,3,3,Cin,16]) the launch also writes
+ * packed_w2 != NULL (atvs_conv_x{w,b}_pack_sibling of the TF kernel [3,3,3,Cin,16]) the launch also writes
  * y2 (ceil(D/2), ceil(H/2), ceil(W/2), ldy2)[..., y_coff2 + co] = that stride-2 SAME convolution (+ plane_bias2
- * (Ho2, Wo2, 48)) from the tile already staged in LDS, and its moments into stats_partial2 (same rows). */
-int atvs_conv_xp_pack_size(int Cin, long* packed_floats);
-int atvs_conv_xp_pack(const float* w, int Cin, float* packed);
-int atvs_conv_xp_pack_sibling_size(int Cin, long* packed_floats);
-int atvs_conv_xp_pack_sibling(const float* w2, int Cin, float* packed);
-/* groups >= 1 independent samples stacked on the leading axis of every tensor; atvs_conv_xp_grid = workgroups PER SAMPLE.
+ * (Ho2, Wo2, 48)) from the tile already staged in LDS, and its moments into stats_partial2 (same rows).
+ * groups >= 1 independent samples stacked on the leading axis of every tensor.
  * Prologue (normalise-on-load / add-on-load): with in_params != NULL the convolution's input is relu?((x - mean) * rstd +
  * beta) per sample, parameters (groups, 3, Cin) -- the producer's training-mode batch norm, network.py:206-212 -- and with
  * x2 != NULL the SUM of two such terms (in_params2 for x2; either parameter block may be NULL = that term as is): the
  * U-Net's skip add (network.py:695-697) formed while the halo is staged.  Out-of-volume taps stay zero.  Built for the
- * shapes the path has: in_params with Cin % 16 == 0 and a sibling; x2 with Cin % 16 == 8 and a sibling (else ATVS_ERR_ARG). */
+ * shapes the path has: in_params with Cin % 16 == 0 and a sibling; x2 with a sibling and Cin % 16 == 8 (conv_xw) /
+ * Cin == 8 (conv_xb) -- else ATVS_ERR_ARG / ATVS_ERR_SHAPE. */
 long atvs_conv_xp_grid(int D, int H, int W, int groups);
-int atvs_conv_xp_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias, float* y,
-                     double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
-                     const float* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
-                     int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
-                     int in_relu2, atvs_stream_t stream);
 
-/* The same layers (same contract, grid and statistics rows as atvs_conv_xp_f32, every Cin % 8 == 0) on the
- * Winograd kernel conv_xw.hip: x-pair rows x minimal filtering F(2,3) along y -- two output rows from 4 products per
- * (kd, x offset, channel) instead of 6, i.e. 2/3 of the MFMAs of atvs_conv_xp_f32.  The filter transform
+/* The fp32 form, conv_xw.hip: x-pair rows x minimal filtering F(2,3) along y -- two output rows from 4 products per
+ * (kd, x offset, channel) instead of 6.  The filter transform
  * U = [g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2] is applied by the HOST packer in double; the input transform
  * [d0-d2, d1+d2, d2-d1, d1-d3] in registers from the raw rows staged in LDS (8-channel chunks, double-buffered image).
- * Results differ from the direct sum by fp32 rounding only (one 32 -> 8 layer: 7.7e-7 of the output maximum against
- * 4.2e-7 for atvs_conv_xp_f32).  Weights must be packed with atvs_conv_xw_pack / _pack_sibling (NOT the xp forms).
+ * Results differ from the direct sum by fp32 rounding only (one 32 -> 8 layer: 7.7e-7 of the output maximum).
  * x_planar != 0 (no prologue): x is chunk-planar per sample, Cin/8 planes of [D][H][W][8] x_planar floats apart, as
  * atvs_warp_planes writes it with the same `planar` (sample stride = x_planar * Cin / 8). */
 int atvs_conv_xw_pack_size(int Cin, long* packed_floats);
@@ -288,13 +280,15 @@ int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, c
                      int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
                      int in_relu2, long x_planar, atvs_stream_t stream);
 
-/* The same layers (same contract as atvs_conv_xw_f32, x_planar included) on the bf16 matrix cores with SPLIT operands
- * (conv_xb.hip): every fp32 operand = three bf16 pieces, the six products x_i * w_j with i + j <= 2 accumulated in fp32 by
- * v_mfma_f32_16x16x32_bf16 (the arithmetic of atvs_conv_c16b_f32) -- fp32-class results, 9 K steps of 16-cycle instructions
- * per (8-channel chunk, kd, kh) row instead of 36 fp32 steps of 32 cycles.  Weights: atvs_conv_xb_pack / _pack_sibling
- * (HOST; sizes in BYTES).  Beyond atvs_conv_xw_f32: x_planar may come with in_params (a pending batch norm over a
- * chunk-planar input: the refinement's concat; not with x2); y_group_stride != 0 = floats between the samples of y
- * (>= D*H*W*ldy; 0 = dense): with ldy = 8 the output lands in one 8-channel plane of each sample's chunk-planar buffer. */
+/* The same layers (same contract as atvs_conv_xw_f32, x_planar included) on the 16-bit matrix cores with SPLIT operands
+ * (conv_xb.hip): every fp32 operand = TWO fp16 pieces, x = h0 + h1 / 2048 (h1 = fp16((x - h0) * 2048)), the three products
+ * h0 g0 + (h0 g1 + h1 g0) / 2048 accumulated in fp32 by v_mfma_f32_16x16x32_f16 -- fp32-class results (22 significant bits per
+ * operand; |x| or |w| beyond 65504 gives inf / NaN, the packers return ATVS_ERR_ARG for such weights), 9 K steps of 16-cycle
+ * instructions per (8-channel chunk, kd, kh) row instead of 36 fp32 steps of 32 cycles.  Weights: atvs_conv_xb_pack /
+ * _pack_sibling (HOST; sizes in BYTES).  Beyond atvs_conv_xw_f32: x_planar may come with in_params (a pending batch norm
+ * over a chunk-planar input: the refinement's concat; not with x2); y_group_stride != 0 = floats between the samples of y
+ * (>= D*H*W*ldy; 0 = dense): with ldy = 8 the output lands in one 8-channel plane of each sample's chunk-planar buffer.
+ * x2 (two sources) needs Cin == 8; a prologue needs Cin <= 160 (its parameters live in LDS). */
 int atvs_conv_xb_pack_size(int Cin, long* packed_bytes);
 int atvs_conv_xb_pack(const float* w, int Cin, unsigned char* packed);
 int atvs_conv_xb_pack_sibling_size(int Cin, long* packed_bytes);
@@ -324,9 +318,10 @@ int atvs_conv2d_lds_f32(const float* x, const float* packed_w, const float* bias
                         const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H, int W,
                         int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
-/* The same layers (same contract, shapes with Cin % 32 == 0, statistics rows = atvs_conv2d_lds_rows) with split-bf16 operands
- * (conv2d_b.hip: every fp32 operand = three bf16 pieces, six products, fp32 accumulation on v_mfma_f32_16x16x32_bf16; the
- * arithmetic of atvs_conv_c16b_f32).  Weights: atvs_conv2d_b_pack (HOST; size in BYTES). */
+/* The same layers (same contract, shapes with Cin % 32 == 0, statistics rows = atvs_conv2d_lds_rows) with SPLIT operands
+ * (conv2d_b.hip: every fp32 operand = two fp16 pieces, three products, fp32 accumulation on v_mfma_f32_16x16x32_f16; the
+ * arithmetic of atvs_conv_c16b_f32).  Weights: atvs_conv2d_b_pack (HOST; size in BYTES; ATVS_ERR_ARG for a weight beyond
+ * fp16's range). */
 int atvs_conv2d_b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
 int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
@@ -349,9 +344,9 @@ int atvs_conv1x1_f32(const float* x, const float* packed_w, const float* bias, c
                      const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
                      int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
-/* The same layers (network.py:573-601) with SPLIT bf16 operands on the bf16 matrix cores (conv1x1_b.hip; the arithmetic of
+/* The same layers (network.py:573-601) with SPLIT fp16 operands on the 16-bit matrix cores (conv1x1_b.hip; the arithmetic of
  * atvs_conv_c16b_f32): Cin % 32 == 0, Cin <= 1024, Cout in {32, 64, 128}.  Same contract as atvs_conv1x1_f32 except the
- * packed weights (bytes of bf16 pieces) and the statistics rows (128 pixels per workgroup: atvs_conv1x1_b_rows). */
+ * packed weights (bytes of fp16 pieces) and the statistics rows (128 pixels per workgroup: atvs_conv1x1_b_rows). */
 int atvs_conv1x1_b_supported(int Cin, int Cout);
 int atvs_conv1x1_b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_conv1x1_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
@@ -361,8 +356,8 @@ int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w, const floa
                        int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* 3x3x3 SAME stride-1 convolutions with Cin % 16 == 0 and 32 / 64 output channels (conv_b*_2_1, conv_b*_3_1,
- * global_refine_3dconv{2,3}_1: cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, network.py:172-215) with SPLIT bf16
- * operands on the bf16 matrix cores (conv3d_b.hip; the arithmetic of atvs_conv_c16b_f32).  x (groups,D,H,W,Cin) ->
+ * global_refine_3dconv{2,3}_1: cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, network.py:172-215) with SPLIT fp16
+ * operands on the 16-bit matrix cores (conv3d_b.hip; the arithmetic of atvs_conv_c16b_f32).  x (groups,D,H,W,Cin) ->
  * y (groups,D,H,W,ldy)[..., y_coff : y_coff + Cout]; stats_partial: groups * atvs_conv_c16_grid rows of [2][Cout] doubles or NULL.
  * Weights: atvs_conv3d_b_pack (HOST; size in BYTES). */
 int atvs_conv3d_b_supported(int Cin, int Cout);
@@ -372,7 +367,7 @@ int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, const float
                       int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* The STRIDE-2 form (conv_b*_2_0: 16 -> 32, conv_b*_3_0: 32 -> 64, global_refine_3dconv{2,3}_0; network.py:172-215) with split
- * bf16 operands (conv3d_s2b.hip): x (groups,D,H,W,Cin) -> y (groups,Do,Ho,Wo,ldy)[..., y_coff : y_coff + Cout], Do = ceil(D / 2) ...,
+ * fp16 operands (conv3d_s2b.hip): x (groups,D,H,W,Cin) -> y (groups,Do,Ho,Wo,ldy)[..., y_coff : y_coff + Cout], Do = ceil(D / 2) ...,
  * TF SAME padding (pad_before = (2 (Do - 1) + 3 - D) / 2 per axis).  stats_partial: groups * atvs_conv3d_s2b_grid(Do,Ho,Wo,groups)
  * rows of [2][Cout] doubles or NULL.  Weights: atvs_conv3d_s2b_pack (HOST; size in BYTES). */
 int atvs_conv3d_s2b_supported(int Cin, int Cout);
@@ -382,8 +377,10 @@ int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned char* packe
 int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
                         int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
-/* atvs_deconv_up_f32's layers and contract (grid / statistics rows = atvs_deconv_up_grid) with SPLIT bf16 operands on the bf16
- * matrix cores (deconv_up_b.hip; the arithmetic of atvs_conv_c16b_f32).  The packed weights of all chunks stay in LDS beside
+/* atvs_deconv_up_f32's layers and contract (grid / statistics rows = atvs_deconv_up_grid) with SPLIT operands on the 16-bit
+ * matrix cores (deconv_up_b.hip; this kernel keeps round 3's arithmetic: THREE bf16 pieces per operand, x = x0 + x1 + x2, the six
+ * products x_i * w_j with i + j <= 2 on v_mfma_f32_16x16x32_bf16, one accumulator -- its 32 accumulator tiles leave no room for the
+ * second set the fp16 form needs).  The packed weights of all chunks stay in LDS beside
  * three piece images where they fit (Cout 8: Cin <= 48; Cout 16: Cin <= 32); Cout 16 with more input channels re-reads one chunk's
  * weights per stage (atvs_deconv_up_b_supported).  stats_ld / stats_coff: a statistics row is [2][stats_ld] doubles and this
  * launch's channels start at column stats_coff (16, 0 = atvs_deconv_up_f32's layout): a 32-channel layer (conv_b*_4_0) runs as two
@@ -541,10 +538,13 @@ int atvs_conv_c16_f32(const float* x, const float* packed_w, const float* bias, 
                       int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu,
                       atvs_stream_t stream);
 
-/* The 8 / 16 -> 16 channel forms of atvs_conv_c16_f32 on the bf16 matrix cores with SPLIT operands (conv_c16b.hip;
- * BASELINE.json configs[1] names "bf16 conv3d MFMA"): x = x0 + x1 + x2 and w = w0 + w1 + w2 in bf16 (24 mantissa bits kept),
- * the six products x_i * w_j with i + j <= 2 accumulated in fp32 by v_mfma_f32_16x16x32_bf16 -- fp32-class results (rounding
- * differs from the fp32 MFMA form), 6/16 of its matrix-core time.  Same grid / statistics rows as atvs_conv_c16_f32.
+/* The 8 / 16 -> 16 channel forms of atvs_conv_c16_f32 on the 16-bit matrix cores with SPLIT operands (conv_c16b.hip;
+ * BASELINE.json configs[1] names "bf16 conv3d MFMA"): x = h0 + h1 / 2048 and w = g0 + g1 / 2048 in fp16 (h0 = fp16(x),
+ * h1 = fp16((x - h0) * 2048): 22 significant bits, the residual piece scaled into fp16's normal range), the three products
+ * h0 g0 + (h0 g1 + h1 g0) / 2048 accumulated in fp32 by v_mfma_f32_16x16x32_f16, the cross terms in an accumulator of their
+ * own that is scaled once -- fp32-class results (per-layer error against float64 below the fp32 MFMA form's; rounding
+ * differs from it).  |x| or |w| beyond 65504 gives inf / NaN; the packers return ATVS_ERR_ARG for such weights.  Same grid /
+ * statistics rows as atvs_conv_c16_f32.
  *   atvs_conv_c16b_pack_size / _pack   HOST: split and pack the TF kernel [3,3,3,Cin,16], Cin 8 or 16 (bytes; upload the result) */
 int atvs_conv_c16b_pack_size(int Cin, long* packed_bytes);
 int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packed);

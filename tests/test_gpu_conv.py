@@ -277,17 +277,16 @@ def test_split_volume_conv_matches_dense(cuda, impl, stride):
     _close(s[0, :8].float(), want.reshape(-1, 8).double().sum(0).float(), 1e-5)
 
 
-@pytest.mark.parametrize('xp1w', ['xb', 'xw', 'xp', False])
+@pytest.mark.parametrize('xp1w', ['xb', 'xw', False])
 @pytest.mark.parametrize('D,H,W,Cin', [(9, 19, 70, 32), (4, 8, 32, 16), (6, 21, 45, 8), (13, 9, 33, 24), (2, 3, 24, 16)])
 def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
-    """The four x-pair kernels for the 8-output-channel layers (one workgroup per CU: split-bf16 form conv_xb.hip (default),
-    Winograd F(2,3)-along-y fp32 form conv_xw.hip, direct fp32 form conv_xp.hip / the tiled kernel's x-pair form): ragged sizes (odd H: a row pair that
+    """The x-pair kernels for the 8-output-channel layers (one workgroup per CU: split-operand form conv_xb.hip (default),
+    Winograd F(2,3)-along-y fp32 form conv_xw.hip; the tiled kernel's x-pair form): ragged sizes (odd H: a row pair that
     straddles the end), 16- and 8-channel chunks, with depth-plane bias + bias + residual + ReLU, written into a
     channel slice of a wider (concat) buffer, statistics of what was written."""
     from atvsnet_amd import ops
     ops.use_xp1w(bool(xp1w))
     ops.use_xb(xp1w == 'xb')
-    ops.use_xw(xp1w == 'xw')
     ops.clear_pack_cache()
     try:
         x = _rand((1, D, H, W, Cin), 50)
@@ -317,21 +316,18 @@ def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
     finally:
         ops.use_xp1w(True)
         ops.use_xb(True)
-        ops.use_xw(True)
         ops.clear_pack_cache()
 
 
-@pytest.fixture(params=['xb', 'xw', 'xp'])
+@pytest.fixture(params=['xb', 'xw'])
 def xkernel(request):
-    """Run a test on the three one-workgroup-per-CU x-pair kernels: conv_xb.hip (split bf16, default), conv_xw.hip (fp32
-    Winograd) and conv_xp.hip (fp32 direct)."""
+    """Run a test on both one-workgroup-per-CU x-pair kernels: conv_xb.hip (split fp16 operands, default) and conv_xw.hip
+    (fp32 Winograd)."""
     from atvsnet_amd import ops
     ops.use_xb(request.param == 'xb')
-    ops.use_xw(request.param == 'xw')
     ops.clear_pack_cache()
     yield request.param
     ops.use_xb(True)
-    ops.use_xw(True)
     ops.clear_pack_cache()
 
 
@@ -435,19 +431,15 @@ def test_planar_cost_volume_is_bitwise_the_channel_last_one(cuda, B, D, h, w):
     assert torch.equal(y, r) and torch.equal(y2, r2)
     assert torch.equal(st.partial, rt.partial) and torch.equal(st2.partial, rt2.partial)
     assert torch.equal(sv_pl.materialize(), sv_cl.materialize())
-    # the fp32 Winograd kernel reads the planar form too; a consumer without it (the direct x-pair kernel) gets the
-    # channel-last copy
+    # the fp32 Winograd kernel reads the planar form too
     try:
-        for xb, xw in ((False, True), (False, False)):
-            ops.use_xb(xb)
-            ops.use_xw(xw)
-            ops.clear_pack_cache()
-            (z, _), (z2, _) = ops.conv_split_siblings(sv_pl, 'pl8', w8, 'pl16', w16)
-            (q, _), (q2, _) = ops.conv_split_siblings(sv_cl, 'pl8', w8, 'pl16', w16)
-            assert torch.equal(z, q) and torch.equal(z2, q2)
+        ops.use_xb(False)
+        ops.clear_pack_cache()
+        (z, _), (z2, _) = ops.conv_split_siblings(sv_pl, 'pl8', w8, 'pl16', w16)
+        (q, _), (q2, _) = ops.conv_split_siblings(sv_cl, 'pl8', w8, 'pl16', w16)
+        assert torch.equal(z, q) and torch.equal(z2, q2)
     finally:
         ops.use_xb(True)
-        ops.use_xw(True)
         ops.clear_pack_cache()
 
 

@@ -1,5 +1,5 @@
 """The four x-pair launches of a depth map as bench.py issues them (batched), timed one by one with HIP events:
-usage: [ATVS_LIB=tools_dev/_dbg/lib_X.so] python tools_dev/bench_xw.py [reps] [xb|xw|xp]"""
+usage: [ATVS_LIB=tools_dev/_dbg/lib_X.so] python tools_dev/bench_xw.py [reps] [xb|xw]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,6 @@ from atvsnet_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 kind = sys.argv[2] if len(sys.argv) > 2 else 'xb'
 ops.use_xb(kind == 'xb')
-ops.use_xw(kind == 'xw')
 print('x-pair kernel:', kind)
 dev = torch.device('cuda:0')
 D, H, W = 192, 128, 160
@@ -37,7 +36,7 @@ def timed(name, fn, gf):
 V, V2 = D * H * W, (D // 2) * (H // 2) * (W // 2)
 # 1. dominant: 32 warped channels -> 8 | 16 (stride 2), plane biases, 8 volumes
 G = 8
-planar = kind != 'xp'          # as the pipeline launches it: the warped half of the cost volume chunk-planar
+planar = True                  # as the pipeline launches it: the warped half of the cost volume chunk-planar
 x = torch.randn(G, 4, ops.planar_stride(D, H, W), device=dev) if planar else torch.randn(G, D, H, W, 32, device=dev)
 pb, pb2 = torch.randn(G, H, W, 24, device=dev), torch.randn(G, H // 2, W // 2, 48, device=dev)
 w8, w16 = wt(32, 8), wt(32, 16)
