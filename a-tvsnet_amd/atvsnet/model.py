@@ -283,14 +283,17 @@ def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_inte
     # the warped half goes straight into the layout its one consumer reads best: chunk-planar (F/8, D, h, w, 8) for the
     # Winograd x-pair launch of conv_b0_0_1 | conv_b0_1_0 (dense 32-byte voxels per 8-channel chunk), else channel-last
     planar = ops.planar_cost_volume_ok((D, h, w), F)
+    # ... and, for the split-operand x-pair kernel, as the two fp16 PIECES of every value: the warp splits once per value, the
+    # consumer's staging wavefronts only move bytes (LDS-DMA)
+    pieces = planar and ops.planar_pieces_ok((D, h, w), F)
     var = torch.empty((B, F // 8, ops.planar_stride(D, h, w)) if planar else (B, D, h, w, F), dtype=torch.float32,
                       device=features.device)
     for b, (r, s) in enumerate(pairs):
         Hm = get_homographies(cams[:, r], cams[:, s], depth_num=D, depth_start=depth_start, depth_interval=depth_interval)
-        ops.warp_planes(features[fi(s)], Hm[0].contiguous(), out=var[b], planar=planar)
+        ops.warp_planes(features[fi(s)], Hm[0].contiguous(), out=var[b], planar=planar, pieces=pieces)
     const = torch.stack([features[fi(r)] for r, _ in pairs], 0) if B > 1 else features[fi(pairs[0][0]):fi(pairs[0][0]) + 1]
     return ops.SplitVolume(var, const.contiguous(), [('c', i) for i in range(F)] + [('v', i) for i in range(F)],
-                           planar=(D, h, w) if planar else False)
+                           planar=(D, h, w) if planar else False, pieces=pieces)
 
 
 def base_stage_batch(features, cams, depth_num, depth_start, depth_interval, fwd, rev, ref_i=0, feature_index=None):

@@ -84,6 +84,25 @@ __device__ __forceinline__ void homography_apply(const float* __restrict__ Hm, i
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// The two fp16 pieces of two fp32 values, packed: h0 = f16(x), h1 = f16((x - h0) * 2^11)  (x - h0 is exact in fp32), in FIVE
+// vector instructions: one packed conversion, two mixed-precision fused multiply-adds h0 * -1 + x that read the fp16 halves
+// directly, two that scale by 2^11 (rs = 2048.f in a scalar register) and round into the halves of the second piece (plain C
+// costs 8-9: the compiler converts h0 back to fp32 first and, with -ffp-contract=off, rewrites fma(h0, -1, x) as a subtraction).
+// Same values as the C form: every fma is exact before its one rounding; r * 2048 + 0 keeps r's zero (+0, as x - h0 gives it).
+// ONE definition for every producer of pieces: conv_xb.hip's staging wavefronts and the plane-sweep warp (geometry.hip) must
+// split bit-identically.
+__device__ __forceinline__ void atvs_split2_f16(float x0, float x1, float rs, unsigned* h0, unsigned* h1) {
+  float r0, r1;
+  unsigned a, b;
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(x0), "v"(x1));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
+  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(b) : "v"(r0), "s"(rs));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(b) : "v"(r1), "s"(rs));
+  *h0 = a;
+  *h1 = b;
+}
+
 __device__ __forceinline__ float4 blend4(const Tap4& t, float4 a, float4 b, float4 c, float4 d) {
   float4 o;
   o.x = ((t.wa * a.x + t.wb * b.x) + t.wc * c.x) + t.wd * d.x;

@@ -104,6 +104,7 @@ struct XbArgs {
   int sample_major;
   int vstride;           // floats between voxels / between 8-channel chunks of x (channel-last or chunk-planar: conv_xw.hip)
   long cstride;
+  long piece_bytes;      // x in pieces: bytes between the two piece planes of a chunk (D * H * W * 16)
 };
 
 // Byte offset inside an image row of the voxel with x parity `par` and index i = x / 2 (0..16): even and odd voxels
@@ -116,27 +117,14 @@ __device__ __forceinline__ constexpr int xb_col(int par, int i) {
   return i < 16 ? (i >> 3) * 256 + par * 128 + (i & 7) * 16 : 512 + par * 128;
 }
 
-// the two fp16 pieces of two fp32 values, packed: h0 = f16(x), h1 = f16((x - h0) * 2^11)  (x - h0 is exact in fp32), in FIVE
-// vector instructions: one packed conversion, two mixed-precision fused multiply-adds h0 * -1 + x that read the fp16 halves
-// directly, two that scale by 2^11 and round into the halves of the second piece (plain C costs 8-9: the compiler converts h0
-// back to fp32 first and, with -ffp-contract=off, rewrites fma(h0, -1, x) as a subtraction).  The staging wavefronts share their
-// SIMD's issue slots with the MFMA stream: instructions, not latency, are what the split costs.  Same values as the C form:
-// every fma is exact before its one rounding; r * 2048 + 0 keeps r's zero (+0, as x - h0 gives it).
-__device__ __forceinline__ void xb_split2(float x0, float x1, float rs, unsigned* h0, unsigned* h1) {
-  float r0, r1;
-  unsigned a, b;
-  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(a) : "v"(x0), "v"(x1));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(a), "v"(x0));
-  asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(a), "v"(x1));
-  asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(b) : "v"(r0), "s"(rs));
-  asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(b) : "v"(r1), "s"(rs));
-  *h0 = a;
-  *h1 = b;
-}
+// (the operand split itself: atvs_split2_f16, common.h -- five vector instructions per two values)
 
 // WS: the launch streams its weights (more than one 8-channel chunk); else the one chunk's pieces stay resident in buffer 0
-template <bool SIB, int PRO, bool WS>
+// PIECES: x already holds the two fp16 pieces of every value (atvs_warp_planes(pieces)): the staging wavefronts only MOVE them,
+// global -> LDS by LDS-DMA (no registers, no arithmetic); no prologue
+template <bool SIB, int PRO, bool WS, bool PIECES>
 __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
+  static_assert(!PIECES || PRO == 0, "pieces come finished: no prologue");
   // the workgroup's two wavefronts per SIMD take the SIMD's whole register file (256 each): no wavefront of ANOTHER kernel runs
   // beside this one's 16-bit MFMAs
   asm volatile("" ::: "v255");
@@ -205,7 +193,99 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
     }
     __syncthreads();
   }
-  if (producer) {
+  if (producer && PIECES) {
+    // ================= PRODUCER wavefronts, input in pieces: per stage 2 x 6 LDS-DMA instructions per wavefront copy the halo's
+    // records (16 bytes = the 8 fp16 of one voxel of one piece) from the chunk's two piece planes straight into the two piece
+    // images, 8 more the weight pieces.  An image is a sequence of 16-byte records in LDS order (41 per row: xb_col); a DMA
+    // instruction fills 64 consecutive records, each lane FETCHING the voxel its record holds (the gather is on the global
+    // side; holes of the row layout and voxels outside the volume get an out-of-range offset = zeros).  Stage t is requested at
+    // the start of the iteration in which the multiplying wavefronts work on stage t - 1 and must have landed at that iteration's
+    // barrier: a whole stage of their time, nothing to keep in registers.
+    const int pw = wave - 4;
+    constexpr int RPR = XB_ROWB / 16;                      // records per image row (41)
+    constexpr int NREC = XB_HZ * XB_HY * RPR;              // 1,476 per piece image
+    constexpr int NCHK = (NREC + 63) / 64;                 // 24 instructions per piece image
+    constexpr int CPW = (NCHK + 3) / 4;                    // 6 per wavefront
+    int goffp[CPW];
+    unsigned pgp[CPW];
+#pragma unroll
+    for (int j = 0; j < CPW; ++j) {
+      const int rec = (pw + 4 * j) * 64 + lane;
+      const int row = min(rec / RPR, XB_HZ * XB_HY - 1), pos = rec % RPR;
+      const int zz = row / XB_HY, yy = row % XB_HY;
+      // inverse of xb_col: records 0..31 = two runs of (8 even, 8 odd) voxels, record 32 = voxel 32, record 40 = voxel 33
+      const int xx = pos < 32 ? 2 * ((pos >> 4) * 8 + (pos & 7)) + ((pos >> 3) & 1) : (pos == 32 ? 32 : 33);
+      const bool voxel = rec < NREC && (pos <= 32 || pos == 40);
+      goffp[j] = ((zz * p.Hi + yy) * p.Wi + xx) * 16;                         // BYTES from the halo's first voxel in a piece plane
+      pgp[j] = 0x808080u | (unsigned)(voxel ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+    }
+    const unsigned char* __restrict__ xgb = reinterpret_cast<const unsigned char*>(p.x) + (size_t)grp * p.gx * 4;
+    auto w_dma = [&](int chunk, int buf) __attribute__((always_inline)) {
+      const unsigned char* gm = reinterpret_cast<const unsigned char*>(p.wp) + (size_t)chunk * XB_WMAIN + lane * 16;
+      const unsigned char* gs = SIB ? reinterpret_cast<const unsigned char*>(p.wp2) + (size_t)chunk * XB_WSIB + lane * 16 : gm;
+      constexpr int NWP = SIB ? XB_WBUF / 1024 / 4 : (XB_WMAIN / 1024 + 3) / 4;        // 8 | 5 kilobyte pieces per wavefront
+#pragma unroll
+      for (int j = 0; j < NWP; ++j) {
+        const int pk = pw + 4 * j;                             // wave-uniform
+        if (!SIB && pk >= XB_WMAIN / 1024) continue;
+        const unsigned char* src = pk < XB_WMAIN / 1024 ? gm + pk * 1024 : gs + (pk - XB_WMAIN / 1024) * 1024;
+        __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1)))*)src,
+                                         (void __attribute__((address_space(3)))*)(smem + XB_WOFF + buf * XB_WBUF + pk * 1024), 16, 0, 0);
+      }
+    };
+    TileWalk twn = tw0;
+    int chn = 0, tiles_left = my_tiles;
+    unsigned vmask = 0;
+    for (int t = 0; t < nstage; ++t) {
+      const int gz0 = twn.bz * XB_TZ - 1, gy0 = twn.by * XB_TY - 1, gx0 = twn.bx * XB_TXV - 1;
+      if (chn == 0) {                                          // a new tile: which records lie outside the volume
+        const unsigned lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+        const unsigned hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+                             ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+        vmask = 0;
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+          const unsigned t1 = pgp[j] - lo, t2 = hi1 + ~pgp[j];
+          vmask |= ((((t1 & t2) & 0x808080u) == 0x808080u) ? 0u : 1u) << j;
+        }
+      }
+      const long org = ((long)(gz0 * p.Hi + gy0) * p.Wi + gx0) * 16;       // bytes; the halo's first voxel (may lie in front of the plane)
+      const unsigned char* base = xgb + (size_t)chn * p.cstride * 4 + org;
+      const int ib = (t & 1) * XB_IBUF;
+      XDBG(2)
+#pragma unroll
+      for (int pc = 0; pc < XB_NP; ++pc) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(base + (size_t)pc * p.piece_bytes), 0,
+                                                                             0x7ffffff0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < CPW; ++j) {
+          const int c = pw + 4 * j;                            // wave-uniform: this instruction's 64 records
+          if (c >= NCHK) continue;
+          const unsigned voff = (unsigned)goffp[j] | (unsigned)__builtin_amdgcn_sbfe(vmask, j, 1);
+          if (c * 64 + lane < NREC)                            // (the last instruction of an image: 4 records)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (void __attribute__((address_space(3)))*)(smem + ib + pc * XB_IMG + c * 1024), 16,
+                                                     (int)voff, 0, 0, 0);
+        }
+      }
+      // the weight pieces BEHIND the halo: L2 hits, they land while the halo's HBM round trip is still under way (in front of
+      // it: the same time, measured)
+      if (WS || t == 0) w_dma(chn, WS ? (t & 1) : 0);
+      XDBG(3)
+      // -> stage t + 1
+      if (chn + 1 < p.nchunk) {
+        ++chn;
+      } else if (tiles_left > 1) {
+        --tiles_left;
+        chn = 0;
+        tile_next(&twn);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // stage t has landed
+      XDBG(1)
+      __syncthreads();
+      XDBG(5)
+    }
+    __syncthreads();                                           // the consumers' last stage
+  } else if (producer) {
     // ================= PRODUCER wavefronts (4..7): global -> (prologue, split) -> the piece images and weight buffers of the
     // NEXT stage, while the consumers multiply the current one.  One barrier per stage.
     const int ptid = tid - 256;
@@ -341,8 +421,8 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
       }
       if (i < MAXS - 1 || last_live) {
         uint2 p0, p1;
-        xb_split2(v.x, v.y, XB_RS, &p0.x, &p1.x);
-        xb_split2(v.z, v.w, XB_RS, &p0.y, &p1.y);
+        atvs_split2_f16(v.x, v.y, XB_RS, &p0.x, &p1.x);
+        atvs_split2_f16(v.z, v.w, XB_RS, &p0.y, &p1.y);
         *reinterpret_cast<uint2*>(smem + ib + laddr[i]) = p0;
         *reinterpret_cast<uint2*>(smem + ib + XB_IMG + laddr[i]) = p1;
       }
@@ -724,19 +804,19 @@ long xb_ntiles(int D, int H, int W) {
   return (long)((D + XB_TZ - 1) / XB_TZ) * ((H + XB_TY - 1) / XB_TY) * ((W + XB_TXV - 1) / XB_TXV);
 }
 
-template <bool SIB, int PRO, bool WS>
+template <bool SIB, int PRO, bool WS, bool PIECES = false>
 int launch_xb(const XbArgs& a, long blocks, hipStream_t s) {
   const size_t lds = XB_LDS;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<SIB, PRO, WS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<SIB, PRO, WS, PIECES>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv_xb_kernel<SIB, PRO, WS>), dim3((unsigned)blocks), dim3(512), lds, s, a);
+  hipLaunchKernelGGL((conv_xb_kernel<SIB, PRO, WS, PIECES>), dim3((unsigned)blocks), dim3(512), lds, s, a);
   return ATVS_OK;
 }
 
@@ -823,12 +903,13 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
                                 int relu, const unsigned char* packed_w2, const float* plane_bias2, float* y2,
                                 double* stats_partial2, int ldy2, int y_coff2, const float* x2, const float* in_params,
                                 const float* in_params2, int in_relu, int in_relu2, long x_planar, long y_group_stride,
-                                atvs_stream_t stream) {
+                                int x_pieces, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (in_params2 && !x2) return ATVS_ERR_ARG;
   if (x2 && Cin != 8) return ATVS_ERR_SHAPE;             // the two-source form: one 8-channel chunk (resident weights)
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || Cin <= 0 || (Cin % 8)) return ATVS_ERR_SHAPE;
   if (x_planar && (x2 || x_planar < (long)D * H * W * 8)) return ATVS_ERR_ARG;
+  if (x_pieces && (!x_planar || in_params || x2)) return ATVS_ERR_ARG;      // pieces: chunk-planar, finished values (no prologue)
   if (y_group_stride && y_group_stride < (long)D * H * W * ldy) return ATVS_ERR_ARG;
   if (y_coff < 0 || y_coff + 8 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if (plane_bias && D < 2) return ATVS_ERR_ARG;
@@ -863,10 +944,13 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
   a.x2 = x2; a.in_pa = in_params; a.in_pb = in_params2; a.relu_a = in_relu; a.relu_b = in_relu2;
   a.vstride = x_planar ? 8 : Cin;
   a.cstride = x_planar ? x_planar : 8;
+  a.piece_bytes = (long)D * H * W * 16;
   const int pro = x2 ? 2 : (in_params ? 1 : 0);
   int rc;
   const bool ws = a.nchunk > 1;
-  if (pro == 0 && packed_w2) rc = ws ? launch_xb<true, 0, true>(a, blocks, st) : launch_xb<true, 0, false>(a, blocks, st);
+  if (x_pieces && packed_w2) rc = ws ? launch_xb<true, 0, true, true>(a, blocks, st) : launch_xb<true, 0, false, true>(a, blocks, st);
+  else if (x_pieces) rc = ws ? launch_xb<false, 0, true, true>(a, blocks, st) : launch_xb<false, 0, false, true>(a, blocks, st);
+  else if (pro == 0 && packed_w2) rc = ws ? launch_xb<true, 0, true>(a, blocks, st) : launch_xb<true, 0, false>(a, blocks, st);
   else if (pro == 0) rc = ws ? launch_xb<false, 0, true>(a, blocks, st) : launch_xb<false, 0, false>(a, blocks, st);
   else if (pro == 1 && packed_w2) rc = ws ? launch_xb<true, 1, true>(a, blocks, st) : launch_xb<true, 1, false>(a, blocks, st);
   else if (pro == 2 && packed_w2) rc = launch_xb<true, 2, false>(a, blocks, st);

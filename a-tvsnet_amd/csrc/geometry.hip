@@ -171,10 +171,14 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
 // bf16-MFMA kernel on the same SIMD -- two depth maps in flight.  Common factor: compiler-formed packed fp32 arithmetic.  This
 // file is built with -fno-slp-vectorize (_lib.flags_for) and the blend below is scalar.  DESIGN.md 6;
 // tests/test_gpu_pipeline.py::test_small_kernels_beside_other_wavefronts, ::test_two_depth_maps_in_flight_fullsize.)
-template <int MODE>
+// PIECES (chunk-planar output only): every value leaves as its two fp16 pieces (atvs_split2_f16: the split conv_xb.hip's staging
+// wavefronts would otherwise perform, once per value instead of once per halo copy) -- a chunk plane is then
+// [2 pieces][D][h][w][8 fp16], the same bytes as [D][h][w][8 fp32]; piece_bytes = D * h * w * 16.
+template <int MODE, bool PIECES>
 __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     const float* __restrict__ src, const float* __restrict__ Hmats, const float* __restrict__ ref,
-    float* __restrict__ out, float* __restrict__ mask_out, int h, int w, int C, int ld, int c_off, long plane_stride) {
+    float* __restrict__ out, float* __restrict__ mask_out, int h, int w, int C, int ld, int c_off, long plane_stride,
+    long piece_bytes) {
   typedef float f32x2 __attribute__((ext_vector_type(2)));
   __shared__ __attribute__((aligned(16))) float s_geo[256 * 12];
   const int d = blockIdx.y;
@@ -238,17 +242,39 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
       o.z = fabsf(o.z - r.z) * valid;
       o.w = fabsf(o.w - r.w) * valid;
     }
-    // plane_stride > 0: chunk-planar output [C/8][D][h][w][8] (the layout atvs_conv_xw_f32 reads with x_planar)
-    if (plane_stride > 0) st4(out + (size_t)(c >> 3) * (size_t)plane_stride + ((size_t)d * npix + pix) * 8 + (c & 7), o);
-    else st4(out + ((size_t)d * npix + pix) * (size_t)ld + c_off + c, o);
+    if (PIECES) {
+      // The lane pair (tid, tid ^ 1) holds channels 0..3 | 4..7 of one voxel's chunk.  After the split the even lane keeps its h0
+      // and takes the partner's, the odd lane keeps its h1 and takes the partner's (two DPP moves): each lane stores ONE 16-byte
+      // record -- the voxel's eight h0 into the chunk's first piece plane, its eight h1 into the second -- so a store
+      // instruction still writes whole lines (32 consecutive voxels per piece plane).
+      unsigned h0a, h1a, h0b, h1b;
+      atvs_split2_f16(o.x, o.y, 2048.f, &h0a, &h1a);
+      atvs_split2_f16(o.z, o.w, 2048.f, &h0b, &h1b);
+      const bool hi = (c & 4) != 0;                   // this lane holds channels 4..7 (it is the odd lane of its pair)
+      const unsigned s0 = hi ? h0a : h1a, s1 = hi ? h0b : h1b;
+      const unsigned r0 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s0, 0xB1, 0xF, 0xF, true);     // quad_perm [1,0,3,2]
+      const unsigned r1 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)s1, 0xB1, 0xF, 0xF, true);
+      uint4 rec;
+      if (hi) rec = make_uint4(r0, r1, h1a, h1b);     // h1 of channels 0..3 (partner's) | 4..7 (own)
+      else rec = make_uint4(h0a, h0b, r0, r1);        // h0 of channels 0..3 (own) | 4..7 (partner's)
+      unsigned char* dst = reinterpret_cast<unsigned char*>(out + (size_t)(c >> 3) * (size_t)plane_stride) +
+                           (hi ? (size_t)piece_bytes : (size_t)0) + ((size_t)d * npix + pix) * 16;
+      *reinterpret_cast<uint4*>(dst) = rec;
+    } else if (plane_stride > 0) {
+      // chunk-planar output [C/8][D][h][w][8] (the layout atvs_conv_xw_f32 reads with x_planar)
+      st4(out + (size_t)(c >> 3) * (size_t)plane_stride + ((size_t)d * npix + pix) * 8 + (c & 7), o);
+    } else {
+      st4(out + ((size_t)d * npix + pix) * (size_t)ld + c_off + c, o);
+    }
   }
 }
 
 extern "C" int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
                                 const float* depth_start, const float* depth_interval, float* out, float* mask_out,
                                 int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, long planar,
-                                atvs_stream_t stream) {
+                                int pieces, atvs_stream_t stream) {
   if (!src || !homographies || !out) return ATVS_ERR_NULL;
+  if (pieces && !planar) return ATVS_ERR_ARG;
   if (planar && (mode != 0 || (C != 16 && C != 32 && C != 64) || ld_out != C || c_off != 0)) return ATVS_ERR_ARG;
   if (planar && planar < (long)D * h * w * 8) return ATVS_ERR_ARG;
   const long plane_stride = planar;       // floats between the 8-channel chunk planes (>= D*h*w*8; callers pad it)
@@ -264,12 +290,16 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
   if (vec && mode < 2 && (C == 16 || C == 32 || C == 64)) {
     // geometry once per pixel, shared by its channel-group lanes
     dim3 g2(cdiv((long)h * w, 256), D);
-    if (mode == 0)
-      hipLaunchKernelGGL((warp_planes_shared_kernel<0>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
-                         ld_out, c_off, plane_stride);
+    const long piece_bytes = (long)D * h * w * 16;
+    if (mode == 0 && pieces)
+      hipLaunchKernelGGL((warp_planes_shared_kernel<0, true>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
+                         ld_out, c_off, plane_stride, piece_bytes);
+    else if (mode == 0)
+      hipLaunchKernelGGL((warp_planes_shared_kernel<0, false>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
+                         ld_out, c_off, plane_stride, 0L);
     else
-      hipLaunchKernelGGL((warp_planes_shared_kernel<1>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
-                         ld_out, c_off, 0L);
+      hipLaunchKernelGGL((warp_planes_shared_kernel<1, false>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
+                         ld_out, c_off, 0L, 0L);
     ATVS_LAUNCH_CHECK();
     return ATVS_OK;
   }

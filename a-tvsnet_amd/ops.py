@@ -93,13 +93,18 @@ WARP_NEAREST = 3      # atvs_warp_planes mode: nearest-neighbour sampling (inclu
 
 
 def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=None, depth_start=None,
-                depth_interval=None, rep=1, want_mask=False, planar=False):
+                depth_interval=None, rep=1, want_mask=False, planar=False, pieces=False):
     """src (h,w,C), homographies (D,3,3) -> out (D,h,w,ld_out) [, mask (D,h,w)].
     planar=True (plain warp, C in {16,32,64}): out is chunk-planar, a PlanarVolume-shaped (C/8, plane_floats(D,h,w)) buffer
-    whose rows hold (D,h,w,8) -- the layout the x-pair kernels read as dense 32-byte voxels (SplitVolume(planar=True))."""
+    whose rows hold (D,h,w,8) -- the layout the x-pair kernels read as dense 32-byte voxels (SplitVolume(planar=True)).
+    pieces=True (with planar): every value is written as its two fp16 pieces (the operand split of the split-operand
+    convolutions, done once by this producer); a row of `out` then holds [2 pieces][D][h][w][8 fp16] -- the same bytes, to be
+    read by conv_xb only (SplitVolume(pieces=True); planar_pieces_decode() for anything else)."""
     h, w, C = src.shape
     D = homographies.shape[0]
     width = rep if mode == 2 else C
+    if pieces and not planar:
+        raise ValueError('warp_planes(pieces=True) needs planar=True')
     if planar:
         if mode != 0 or C not in (16, 32, 64) or c_off != 0:
             raise ValueError('warp_planes(planar=True): plain warp of 16 / 32 / 64 channels')
@@ -119,7 +124,7 @@ def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=N
         with _Timed(('warp', int(mode)), (D, h, w, C), width):
             _call('atvs_warp_planes', _p(src), _p(homographies), _p(ref), _p(depth_start), _p(depth_interval),
                   _p(out), _p(mask), D, h, w, C, int(ld_out), int(c_off), int(mode), int(rep),
-                  ctypes.c_long(planar_stride(D, h, w) if planar else 0), _stream())
+                  ctypes.c_long(planar_stride(D, h, w) if planar else 0), int(bool(pieces)), _stream())
     return (out, mask) if want_mask else out
 
 
@@ -402,6 +407,28 @@ def planar_stride(D, h, w):
 def planar_view(buf, D, h, w):
     """(.., K, planar_stride) chunk-planar buffer -> the (.., K, D, h, w, 8) view of its planes."""
     return buf[..., :D * h * w * 8].unflatten(-1, (D, h, w, 8))
+
+
+_USE_PIECES = os.environ.get('ATVS_PIECES', '1') == '1'
+
+
+def use_pieces(flag):
+    """Testing / A-B hook: the warped half of the cost volume as fp16 PIECES (the producer splits, conv_xb stages by LDS-DMA)."""
+    global _USE_PIECES
+    _USE_PIECES = bool(flag)
+
+
+def planar_pieces_ok(shape, F):
+    """Should build_cost_volumes write the warped half as pieces?  Only the split-operand x-pair kernel reads them."""
+    return _USE_PIECES and _xkind() == 'xb' and planar_cost_volume_ok(shape, F)
+
+
+def planar_pieces_decode(buf, D, h, w):
+    """(.., K, planar_stride) buffer written with pieces=True -> (.., K, D, h, w, 8) float32 values h0 + h1 / 2048 (what the
+    products of the split-operand kernels see: equal to the fp32 value to 2^-22 relative; tests and fallbacks)."""
+    n = D * h * w * 8
+    halves = buf[..., :n].contiguous().view(torch.float16).unflatten(-1, (2, D, h, w, 8)).float()
+    return halves[..., 0, :, :, :, :] + halves[..., 1, :, :, :, :] / 2048.0
 
 
 def planar_cost_volume_ok(shape, F):
@@ -769,7 +796,7 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
 
 
 def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None,
-                   prologue=None, planar=False, ldy=None, y_gstride=0, y_off=0):
+                   prologue=None, planar=False, ldy=None, y_gstride=0, y_off=0, pieces=False):
     """One x-pair launch (atvs_conv_xb_f32 / atvs_conv_xw_f32): x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].
     sibling = (pk2, y2, y_coff2, stats_buf2, plane_bias2): the stride-2 16-channel convolution of the same x5.
     prologue = (x2 | None, params | None, params2 | None, relu, relu2): the input is formed on load as
@@ -803,7 +830,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
                     int(bool(relu_a)), int(bool(relu_b))]
             if kind == 'xb':
                 _call('atvs_conv_xb_f32', *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0),
-                                                    ctypes.c_long(int(y_gstride)), _stream()]))
+                                                    ctypes.c_long(int(y_gstride)), int(bool(pieces)), _stream()]))
             else:
                 _call('atvs_conv_xw_f32', *(args + [ctypes.c_long(planar_stride(D, H, W) if planar else 0), _stream()]))
 
@@ -1308,8 +1335,11 @@ class SplitVolume(object):
     (warp_planes(planar=True)): conv_split_siblings hands it to the x-pair kernel as it is, every other consumer gets the
     channel-last copy var_cl() makes."""
 
-    def __init__(self, var, const, chan_map, planar=False):
+    def __init__(self, var, const, chan_map, planar=False, pieces=False):
         self.planar = tuple(int(v) for v in planar) if planar else False
+        self.pieces = bool(pieces)               # (with planar) the buffer holds fp16 pieces: warp_planes(pieces=True)
+        if self.pieces and not self.planar:
+            raise ValueError('SplitVolume(pieces=True) needs planar=(D,h,w)')
         if var.dim() == (2 if self.planar else 4):
             var, const = var.unsqueeze(0), const.unsqueeze(0)
         self._var, self.const, self.chan_map = var, const, list(chan_map)
@@ -1327,7 +1357,8 @@ class SplitVolume(object):
         if self._cl is None:
             B, K = self._var.shape[:2]
             D, h, w = self.planar
-            self._cl = planar_view(self._var, D, h, w).permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, K * 8).contiguous()
+            pv = planar_pieces_decode(self._var, D, h, w) if self.pieces else planar_view(self._var, D, h, w)
+            self._cl = pv.permute(0, 2, 3, 4, 1, 5).reshape(B, D, h, w, K * 8).contiguous()
         return self._cl
 
     @property
@@ -1496,7 +1527,7 @@ def use_siblings(flag):
     _USE_SIBLINGS = bool(flag)
 
 
-def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None, groups=None, planar=False):
+def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None, groups=None, planar=False, pieces=False):
     """The U-Net's two convolutions of one input in ONE launch: y = conv3x3x3(x, w) (8 channels, stride 1) and
     y2 = conv3x3x3(x, w2) (16 channels, stride 2, SAME), each with the partial moments of its output.
     x (D,H,W,Cin) (groups=G: (G,D,H,W,Cin)), Cin % 8 == 0.  Returns (y, Stats), (y2, Stats).
@@ -1540,8 +1571,10 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
         raise ValueError('conv_siblings %s: plane_bias2 %s' % (key2, tuple(plane_bias2.shape)))
     if prologue is not None and prologue[0] is not None:
         prologue = (_to5(prologue[0], groups, 'conv_siblings second source')[0],) + tuple(prologue[1:])
+    if pieces and (not planar or prologue is not None or _xkind() != 'xb'):
+        raise ValueError('conv_siblings(pieces=True): a chunk-planar input without a prologue, on the split-operand kernel')
     conv_xp_launch(x5, pk, y, 0, None, False, sbuf, plane_bias, sibling=(pk2, y2, 0, sbuf2, plane_bias2),
-                   prologue=prologue, planar=planar)
+                   prologue=prologue, planar=planar, pieces=pieces)
     return (y, st), (y2, st2)
 
 
@@ -1553,9 +1586,9 @@ def conv_split_siblings(sv, key, w_host, key2, w2_host):
     wv2, planes2 = _fold_split_weights(key2, w2_host, sv.chan_map, cv, cc)
     pb = conv(sv.const, (key, 'planes'), planes, stride=1, groups=B)
     pb2 = conv(sv.const, (key2, 'planes'), planes2, stride=2, groups=B)
-    if sv.planar:
+    if sv.planar and (not sv.pieces or _xkind() == 'xb'):
         return conv_siblings(sv._var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B,
-                             planar=sv.planar)
+                             planar=sv.planar, pieces=sv.pieces)
     return conv_siblings(sv.var, (key, 'var'), wv, (key2, 'var'), wv2, plane_bias=pb, plane_bias2=pb2, groups=B)
 
 

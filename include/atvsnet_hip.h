@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 28
+#define ATVS_ABI_VERSION 29
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -65,10 +65,14 @@ int atvs_get_homographies(const float* left_cam, const float* right_cam, const f
  *   planar != 0 (mode 0, C in {16, 32, 64}, ld_out == C, c_off == 0): out is written chunk-planar,
  *           [C/8] planes of [D][h][w][8], `planar` floats apart (>= D*h*w*8; pad it so that the planes do not start
  *           on the same HBM channel) -- the layout atvs_conv_xw_f32 / _xb_f32 read with x_planar (dense 32-byte
- *           voxels per 8-channel chunk); same values, another place. */
+ *           voxels per 8-channel chunk); same values, another place.
+ *   pieces != 0 (with planar): every value is written as its two fp16 pieces, h0 = fp16(x), h1 = fp16((x - h0) * 2048) -- the
+ *           operand split of the split-operand convolutions, done once by the producer: a chunk plane then holds
+ *           [2 pieces][D][h][w][8 fp16] (the same D*h*w*32 bytes), which atvs_conv_xb_f32 reads with x_pieces and stages
+ *           by LDS-DMA. */
 int atvs_warp_planes(const float* src, const float* homographies, const float* ref,
                      const float* depth_start, const float* depth_interval, float* out, float* mask_out,
-                     int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, long planar,
+                     int D, int h, int w, int C, int ld_out, int c_off, int mode, int rep, long planar, int pieces,
                      atvs_stream_t stream);
 
 /* build_cost_volume, model.py:157-200: tf.tile(ref) ++ stack_d(warp_d(view)) ->
@@ -288,7 +292,9 @@ int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, c
  * _pack_sibling (HOST; sizes in BYTES).  Beyond atvs_conv_xw_f32: x_planar may come with in_params (a pending batch norm
  * over a chunk-planar input: the refinement's concat; not with x2); y_group_stride != 0 = floats between the samples of y
  * (>= D*H*W*ldy; 0 = dense): with ldy = 8 the output lands in one 8-channel plane of each sample's chunk-planar buffer.
- * x2 (two sources) needs Cin == 8; a prologue needs Cin <= 160 (its parameters live in LDS). */
+ * x2 (two sources) needs Cin == 8; a prologue needs Cin <= 160 (its parameters live in LDS).
+ * x_pieces != 0 (with x_planar, no prologue): the chunk planes hold the two fp16 pieces of every value, [2][D][H][W][8 fp16] as
+ * atvs_warp_planes(pieces) writes them; the launch then only moves them into LDS (LDS-DMA), the same products follow. */
 int atvs_conv_xb_pack_size(int Cin, long* packed_bytes);
 int atvs_conv_xb_pack(const float* w, int Cin, unsigned char* packed);
 int atvs_conv_xb_pack_sibling_size(int Cin, long* packed_bytes);
@@ -297,7 +303,7 @@ int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, const float*
                      double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
                      const unsigned char* packed_w2, const float* plane_bias2, float* y2, double* stats_partial2, int ldy2,
                      int y_coff2, const float* x2, const float* in_params, const float* in_params2, int in_relu,
-                     int in_relu2, long x_planar, long y_group_stride, atvs_stream_t stream);
+                     int in_relu2, long x_planar, long y_group_stride, int x_pieces, atvs_stream_t stream);
 
 /* 3x3 stride-1 SAME 2-D convolution (dilation 1, 2 or 4) of wide feature maps, LDS-tiled (conv2d_lds.hip): the
  * heavy layers of the feature towers -- the bottlenecks' conv2 (slim.conv2d, network.py:585-587), conv0_1 / conv0_2 /

@@ -443,6 +443,52 @@ def test_planar_cost_volume_is_bitwise_the_channel_last_one(cuda, B, D, h, w):
         ops.clear_pack_cache()
 
 
+@pytest.mark.parametrize('B,D,h,w,F', [(1, 6, 16, 40, 32), (2, 9, 19, 70, 32), (1, 5, 9, 33, 16), (1, 4, 8, 32, 64)])
+def test_cost_volume_in_pieces_is_bitwise_the_planar_one(cuda, B, D, h, w, F):
+    """atvs_warp_planes(pieces): the warped half of the cost volume leaves the warp as the two fp16 pieces of every value --
+    bit for bit the split the convolution's staging wavefronts perform (h0 = fp16(x), h1 = fp16((x - h0) * 2048)), laid out
+    [chunk][piece][D][h][w][8] -- and conv_xb stages them by LDS-DMA (x_pieces): both convolutions and their statistics equal the
+    planar-fp32 launch bit for bit (ragged sizes: rows that end inside a DMA instruction's 64 records, volume borders)."""
+    from atvsnet_amd import ops
+    from oracle import homography_warping as G
+    from oracle import model as OM
+    ops.clear_pack_cache()
+    cams = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'example2_0_cam.npy')))[None, None]
+    cam2 = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'example2_1_cam.npy')))[None, None]
+    cams = torch.cat([cams, cam2], 1).float()
+    ds, di = OM.depth_start_interval(cams)
+    Hm = G.get_homographies(cams[:, 0], cams[:, 1], D, ds, di)[0].to(cuda)
+    feats = (_rand((B, h, w, F), 95) * 3.0).to(cuda)
+    const = _rand((B, h, w, F), 96).to(cuda)
+    pl = torch.stack([ops.warp_planes(feats[b], Hm, planar=True) for b in range(B)])
+    pc = torch.stack([ops.warp_planes(feats[b], Hm, planar=True, pieces=True) for b in range(B)])
+    assert pc.shape == pl.shape and pc.dtype == torch.float32
+    # the pieces, bit for bit (numpy's float32 -> float16 conversion rounds to nearest even as the hardware does)
+    n = D * h * w * 8
+    x = ops.planar_view(pl, D, h, w).cpu().numpy()                                   # (B, K, D, h, w, 8)
+    got = pc[..., :n].contiguous().view(torch.float16).cpu().numpy().reshape(B, F // 8, 2, D, h, w, 8)
+    h0 = x.astype(np.float16)
+    h1 = ((x - h0.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    assert np.array_equal(got[:, :, 0].view(np.uint16), h0.view(np.uint16))
+    assert np.array_equal(got[:, :, 1].view(np.uint16), h1.view(np.uint16))
+    dec = ops.planar_pieces_decode(pc, D, h, w).cpu().numpy()
+    assert np.abs(dec - x).max() <= np.abs(x).max() * 2.0 ** -21
+    # the launches
+    cmap = [('c', i) for i in range(F)] + [('v', i) for i in range(F)]
+    sv_pl = ops.SplitVolume(pl, const, cmap, planar=(D, h, w))
+    sv_pc = ops.SplitVolume(pc, const, cmap, planar=(D, h, w), pieces=True)
+    w8, w16 = (_rand((3, 3, 3, 2 * F, 8), 97) * 0.1).numpy(), (_rand((3, 3, 3, 2 * F, 16), 98) * 0.1).numpy()
+    (y, st), (y2, st2) = ops.conv_split_siblings(sv_pc, 'pc8', w8, 'pc16', w16)
+    (r, rt), (r2, rt2) = ops.conv_split_siblings(sv_pl, 'pc8', w8, 'pc16', w16)
+    assert torch.equal(y, r) and torch.equal(y2, r2)
+    assert torch.equal(st.partial, rt.partial) and torch.equal(st2.partial, rt2.partial)
+    # any other consumer gets the decoded channel-last values (fp32 kernels, tests): close to the planar ones, not bitwise
+    assert float((sv_pc.var - sv_pl.var).abs().max()) <= float(sv_pl.var.abs().max()) * 2.0 ** -21
+    with pytest.raises(ValueError):
+        ops.warp_planes(feats[0], Hm, pieces=True)                                   # pieces need the planar layout
+    ops.clear_pack_cache()
+
+
 @pytest.mark.parametrize('cin', [16, 8])
 @pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 37), (2, 5, 8, 12)])
 def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W, cin):

@@ -43,7 +43,8 @@ def _against_fp32(ops, run, first):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 
 
-@pytest.mark.parametrize('form', ['streamed weights, plane biases (dominant launch)', 'normalise on load (refinement)',
+@pytest.mark.parametrize('form', ['streamed weights, plane biases (dominant launch)', 'input in pieces, staged by LDS-DMA (dominant launch)',
+                                  'normalise on load (refinement)',
                                   'two sources, add on load (stack inputs)', 'no sibling (photo stem)'])
 def test_every_repetition_of_a_full_size_launch_is_bitwise_the_first(form):
     from atvsnet_amd import ops
@@ -51,14 +52,20 @@ def test_every_repetition_of_a_full_size_launch_is_bitwise_the_first(form):
     torch.manual_seed(5)
     rng = np.random.default_rng(5)
     ops.clear_pack_cache()
-    if form.startswith('streamed'):
+    if form.startswith('streamed') or form.startswith('input in pieces'):
         G = 8
+        pieces = form.startswith('input in pieces')
         x = torch.randn(G, 4, ops.planar_stride(D, H, W), device=dev)
+        if pieces:                       # any fp16 bit patterns are valid pieces: finite ones, as a warp would write them
+            n = D * H * W * 8
+            half = (torch.randn(G, 4, 2 * n, device=dev) * 2.0).half()
+            x[..., :n] = half.view(torch.float32)
         pb, pb2 = torch.randn(G, H, W, 24, device=dev), torch.randn(G, H // 2, W // 2, 48, device=dev)
         w8, w16 = _wt(rng, 32, 8), _wt(rng, 32, 16)
 
         def run():
-            (y, st), (y2, st2) = ops.conv_siblings(x, 'sk8', w8, 'sk16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W))
+            (y, st), (y2, st2) = ops.conv_siblings(x, 'sk8', w8, 'sk16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W),
+                                                   pieces=pieces)
             return y, y2, st.partial, st2.partial
     elif form.startswith('normalise'):
         G = 4
@@ -89,5 +96,6 @@ def test_every_repetition_of_a_full_size_launch_is_bitwise_the_first(form):
             y, st = ops.conv(x, 'sp8', w8, want_stats=True, plane_bias=pb, groups=G)
             return y, st.partial
     first = _repeat_bitwise(run)
-    _against_fp32(ops, lambda: run()[:2 if len(first) == 4 else 1], first[:2 if len(first) == 4 else 1])
+    if not form.startswith('input in pieces'):           # (the fp32 kernel does not read pieces; test_gpu_conv.py ties them to the planar form)
+        _against_fp32(ops, lambda: run()[:2 if len(first) == 4 else 1], first[:2 if len(first) == 4 else 1])
     ops.clear_pack_cache()

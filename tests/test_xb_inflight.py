@@ -20,5 +20,12 @@ def test_no_loaded_register_is_moved_or_spilled_while_in_flight(capsys):
     rc = mod.main()
     out = capsys.readouterr().out
     assert rc == 0, out
-    # every instantiation was seen and has inline loads and waits
-    assert out.count('inline loads') == 7 and ' 0 inline loads' not in out and ' 0 inline waits' not in out, out
+    # every instantiation was seen; the forms that split in the kernel have inline loads and waits, the four that take their input
+    # in pieces (last template argument true: LDS-DMA through builtins, nothing in registers) have none
+    lines = [ln for ln in out.splitlines() if 'inline loads' in ln]
+    assert len(lines) == 11, out
+    for ln in lines:
+        if 'ELb1EEEvNS' in ln:
+            assert ': 0 inline loads' in ln, ln
+        else:
+            assert ': 0 inline loads' not in ln and ' 0 inline waits' not in ln, ln

@@ -15,15 +15,16 @@ cams4[:, 1, :2, :3] /= 4.0          # intrinsics of the quarter-resolution featu
 ds, di = cams[0, 1, 3, 0:1].contiguous(), cams[0, 1, 3, 1:2].contiguous()
 Hm = ops.get_homographies(cams4[0], cams4[1], ds, di, D)
 out = torch.empty(C // 8, ops.planar_stride(D, h, w), device=dev)
-run = lambda: ops.warp_planes(src, Hm, out=out, planar=True)      # noqa: E731
-for _ in range(3):
-    run()
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(20):
-    run()
-e1.record()
-torch.cuda.synchronize()
-ms = e0.elapsed_time(e1) / 20
-print('warp %.4f ms  %.2f TB/s written' % (ms, 4.0 * D * h * w * C / 1e9 / ms))
+for pieces in (False, True, False, True):
+    run = lambda: ops.warp_planes(src, Hm, out=out, planar=True, pieces=pieces)      # noqa: E731
+    for _ in range(10):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(100):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 100
+    print('warp (%s) %.4f ms  %.2f TB/s written' % ('fp16 pieces' if pieces else 'fp32 planar', ms, 4.0 * D * h * w * C / 1e9 / ms))

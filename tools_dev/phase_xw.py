@@ -18,12 +18,12 @@ if which == 'dominant':
     w8, w16 = wt(32, 8), wt(32, 16)
     run = lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G)   # noqa: E731
     mf = (384, 112)
-elif which == 'dominantp':           # as the pipeline launches it: the warped half chunk-planar
+elif which in ('dominantp', 'dominantpc'):           # as the pipeline launches it: the warped half chunk-planar (dominantpc: as fp16 pieces)
     G = 8
     x = torch.randn(G, 4, ops.planar_stride(D, H, W), device=dev)
     pb, pb2 = torch.randn(G, H, W, 24, device=dev), torch.randn(G, H // 2, W // 2, 48, device=dev)
     w8, w16 = wt(32, 8), wt(32, 16)
-    run = lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W))   # noqa: E731
+    run = lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W), pieces=(which == 'dominantpc'))   # noqa: E731
     mf = (384, 112)
 elif which == 'stack':
     G = 8

@@ -16,12 +16,12 @@ dev = torch.device('cuda:0')
 D, H, W = 192, 128, 160
 rng = np.random.default_rng(0)
 wt = lambda cin, cout: (rng.standard_normal((3, 3, 3, cin, cout)) * 0.1).astype(np.float32)   # noqa: E731
-if which == 'dominantp':
+if which in ('dominantp', 'dominantpc'):          # dominantpc: the input as fp16 pieces (staged by LDS-DMA)
     G = 8
     x = torch.randn(G, 4, ops.planar_stride(D, H, W), device=dev)
     pb, pb2 = torch.randn(G, H, W, 24, device=dev), torch.randn(G, H // 2, W // 2, 48, device=dev)
     w8, w16 = wt(32, 8), wt(32, 16)
-    run = lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W))   # noqa: E731
+    run = lambda: ops.conv_siblings(x, 'a8', w8, 'a16', w16, plane_bias=pb, plane_bias2=pb2, groups=G, planar=(D, H, W), pieces=(which == 'dominantpc'))   # noqa: E731
 elif which == 'stack':
     G = 8
     xa, xb = torch.randn(G, D, H, W, 8, device=dev), torch.randn(G, D, H, W, 8, device=dev)
