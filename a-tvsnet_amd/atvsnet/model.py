@@ -161,7 +161,8 @@ def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_ca
     photo_err = ops.absdiff_mask(wfeat, rf, mphoto)
     wdep, mgeo = ops.warp_by_depth(dvt, rc, vc, dref, 'nearest', FLAGS.inverse_depth)
     geo_err = ops.absdiff_mask(wdep, dref.reshape(h, w, 1), mgeo)
-    ops.warp_planes(vf, Hm, out=photo_var[b], mode=1, ref=rf)                              # (D,h,w,chan)
+    pieces = photo_var.dim() == 3            # (B, chan/8, planar_stride): chunk-planar fp16 pieces for the photo stem (ops.photo_pieces_ok)
+    ops.warp_planes(vf, Hm, out=photo_var[b], mode=1, ref=rf, planar=pieces, pieces=pieces)    # (D,h,w,chan)
     ops.copy_channels(photo_err, photo_const[b], chan, 0, 0)
     ops.copy_channels(rf, photo_const[b], chan, 0, chan)
     ops.geo_ref_planes(dref, ds, di, geo_var[b], 0)
@@ -191,7 +192,11 @@ def _hull_view(ref_id):
 
 def _refine_net(bufs, prob_vol, chan, independent):
     photo_var, photo_const, geo_var, geo_const, hull = bufs
-    photo = ops.SplitVolume(photo_var, photo_const, [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
+    cmap = [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)]
+    if photo_var.dim() == 3:
+        photo = ops.SplitVolume(photo_var, photo_const, cmap, planar=tuple(geo_var.shape[1:4]), pieces=True)
+    else:
+        photo = ops.SplitVolume(photo_var, photo_const, cmap)
     geo = ops.SplitVolume(geo_var, geo_const, [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
     tower = CostVolRefineNet({'photo_group': photo, 'geo_group': geo, 'prob_vol': prob_vol, 'vis_hull': hull},
                              is_training=True, reuse=AUTO_REUSE, independent_samples=independent)
@@ -200,7 +205,8 @@ def _refine_net(bufs, prob_vol, chan, independent):
 
 def _refinement_buffers(B, D, h, w, chan, like):
     e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=like.device)     # noqa: E731
-    return (e(B, D, h, w, chan), e(B, h, w, 2 * chan), e(B, D, h, w, 2), e(B, h, w, 2), e(B, D, h, w, 1))
+    photo_var = e(B, chan // 8, ops.planar_stride(D, h, w)) if ops.photo_pieces_ok((D, h, w), chan) else e(B, D, h, w, chan)
+    return (photo_var, e(B, h, w, 2 * chan), e(B, D, h, w, 2), e(B, h, w, 2), e(B, D, h, w, 1))
 
 
 def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, images, prob_vol, ref_id, view_id,

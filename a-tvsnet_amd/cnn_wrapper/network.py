@@ -336,7 +336,7 @@ class Network(object):
         wg_var, planes_g = ops._fold_split_weights(vg, wg, geo.chan_map, geo.var.shape[-1], geo.const.shape[-1])
         pb_geo = ops.conv(geo.const, (vg, 'planes'), planes_g, groups=B)                   # (B,h,w,24)
         dhw = tuple(int(v) for v in photo.shape[1:4])
-        planar = dhw if (ops.planar_concat_ok(dhw) and not photo.planar and photo.cv % 8 == 0) else None
+        planar = dhw if (ops.planar_concat_ok(dhw) and (not photo.planar or photo.pieces) and photo.cv % 8 == 0) else None
         if planar:
             # the concat as four dense 8-channel planes: the photo stem writes plane 0, the FMA stems planes 1..3, and the
             # consumer (3dconv0_1 | 3dconv1_0) stages 32-byte voxels per chunk instead of 32 of every 128 bytes

@@ -275,7 +275,7 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
                                 int pieces, atvs_stream_t stream) {
   if (!src || !homographies || !out) return ATVS_ERR_NULL;
   if (pieces && !planar) return ATVS_ERR_ARG;
-  if (planar && (mode != 0 || (C != 16 && C != 32 && C != 64) || ld_out != C || c_off != 0)) return ATVS_ERR_ARG;
+  if (planar && ((mode != 0 && mode != 1) || (C != 16 && C != 32 && C != 64) || ld_out != C || c_off != 0)) return ATVS_ERR_ARG;
   if (planar && planar < (long)D * h * w * 8) return ATVS_ERR_ARG;
   const long plane_stride = planar;       // floats between the 8-channel chunk planes (>= D*h*w*8; callers pad it)
   if (D <= 0 || h <= 0 || w <= 0 || C <= 0 || ld_out < C || c_off < 0) return ATVS_ERR_SHAPE;
@@ -291,15 +291,12 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
     // geometry once per pixel, shared by its channel-group lanes
     dim3 g2(cdiv((long)h * w, 256), D);
     const long piece_bytes = (long)D * h * w * 16;
-    if (mode == 0 && pieces)
-      hipLaunchKernelGGL((warp_planes_shared_kernel<0, true>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
-                         ld_out, c_off, plane_stride, piece_bytes);
-    else if (mode == 0)
-      hipLaunchKernelGGL((warp_planes_shared_kernel<0, false>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
-                         ld_out, c_off, plane_stride, 0L);
-    else
-      hipLaunchKernelGGL((warp_planes_shared_kernel<1, false>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C,
-                         ld_out, c_off, 0L, 0L);
+#define SHARED(M, P)                                                                                                       \
+  hipLaunchKernelGGL((warp_planes_shared_kernel<M, P>), g2, block, 0, s, src, homographies, ref, out, mask_out, h, w, C, ld_out, \
+                     c_off, plane_stride, (P) ? piece_bytes : 0L)
+    if (mode == 0) { if (pieces) SHARED(0, true); else SHARED(0, false); }
+    else { if (pieces) SHARED(1, true); else SHARED(1, false); }
+#undef SHARED
     ATVS_LAUNCH_CHECK();
     return ATVS_OK;
   }

@@ -106,8 +106,8 @@ def warp_planes(src, homographies, out=None, ld_out=None, c_off=0, mode=0, ref=N
     if pieces and not planar:
         raise ValueError('warp_planes(pieces=True) needs planar=True')
     if planar:
-        if mode != 0 or C not in (16, 32, 64) or c_off != 0:
-            raise ValueError('warp_planes(planar=True): plain warp of 16 / 32 / 64 channels')
+        if mode not in (0, 1) or C not in (16, 32, 64) or c_off != 0:
+            raise ValueError('warp_planes(planar=True): plain warp / photo volume of 16 / 32 / 64 channels')
         pstride = planar_stride(D, h, w)
         if out is None:
             out = _new(src, (C // 8, pstride))
@@ -1450,12 +1450,19 @@ def planar_concat_ok(shape):
             and siblings_ok((D, h, w), 32, 8, 16) and 4.0 * 4 * planar_stride(D, h, w) < 2.0 ** 40)
 
 
+def photo_pieces_ok(shape, chan):
+    """(D,h,w), D-varying channels: should the refinement's photo volume be written as fp16 pieces?  When its one consumer is
+    the photo stem on the split-operand x-pair kernel writing a plane of the chunk-planar concat (conv_split_into_plane)."""
+    return _USE_PIECES and chan in (16, 32, 64) and planar_concat_ok(shape)
+
+
 def conv_split_into_plane(sv, key, w_host, buf, plane, planar):
     """conv_split (8 output channels) written into plane `plane` of the chunk-planar buffer buf (B, K, planar_stride):
-    the photo stem of CostVolRefineNet as the producer of plane 0 of the concat.  -> Stats."""
+    the photo stem of CostVolRefineNet as the producer of plane 0 of the concat.  -> Stats.
+    sv: channel-last D-varying part, or chunk-planar fp16 pieces (SplitVolume(planar, pieces): warp_planes(mode=1, pieces))."""
     D, H, W = planar
     B, K, pstride = buf.shape
-    if sv.planar or sv.shape[0] != B or tuple(sv.shape[1:4]) != (D, H, W) or pstride != planar_stride(D, H, W) \
+    if (sv.planar and (not sv.pieces or sv.planar != (D, H, W))) or sv.shape[0] != B or tuple(sv.shape[1:4]) != (D, H, W) or pstride != planar_stride(D, H, W) \
             or not buf.is_contiguous() or int(w_host.shape[-1]) != 8 or sv.cv % 8:
         raise ValueError('conv_split_into_plane: shapes')
     cv, cc = sv.cv, sv.const.shape[-1]
@@ -1468,7 +1475,11 @@ def conv_split_into_plane(sv, key, w_host, buf, plane, planar):
     sbuf = _stats_buffer(buf, blocks, 16, groups=B)
     st = Stats()
     st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 16, D * H * W, B
-    conv_xp_launch(sv.var, pk, buf, 0, None, False, sbuf, pb, ldy=8, y_gstride=K * pstride, y_off=int(plane) * pstride)
+    if sv.pieces:
+        conv_xp_launch(sv._var, pk, buf, 0, None, False, sbuf, pb, ldy=8, y_gstride=K * pstride, y_off=int(plane) * pstride,
+                       planar=sv.planar, pieces=True)
+    else:
+        conv_xp_launch(sv.var, pk, buf, 0, None, False, sbuf, pb, ldy=8, y_gstride=K * pstride, y_off=int(plane) * pstride)
     return st
 
 

@@ -62,7 +62,7 @@ int atvs_get_homographies(const float* left_cam, const float* right_cam, const f
  *           channels (geo view volume, reference quirk: 16 identical channels).
  *   mode 3: nearest-neighbour warp (homography_warping.py:45-56: tf.round half-to-even,
  *           out-of-range pixels read source pixel (0,0) and are NOT zeroed; mask_out tells).
- *   planar != 0 (mode 0, C in {16, 32, 64}, ld_out == C, c_off == 0): out is written chunk-planar,
+ *   planar != 0 (mode 0 or 1, C in {16, 32, 64}, ld_out == C, c_off == 0): out is written chunk-planar,
  *           [C/8] planes of [D][h][w][8], `planar` floats apart (>= D*h*w*8; pad it so that the planes do not start
  *           on the same HBM channel) -- the layout atvs_conv_xw_f32 / _xb_f32 read with x_planar (dense 32-byte
  *           voxels per 8-channel chunk); same values, another place.

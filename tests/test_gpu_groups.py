@@ -448,6 +448,46 @@ def test_photo_stem_into_plane_and_planar_concat_consumer_are_bitwise(cuda, shap
     assert torch.equal(lazy_p.materialize(), ops.bn_apply(rows.clone(), params, True))     # any other consumer: rows
 
 
+@pytest.mark.parametrize('D,h,w', [(6, 16, 40), (5, 9, 33)])
+def test_photo_volume_in_pieces_feeds_the_photo_stem_bitwise(cuda, D, h, w):
+    """The refinement's photo volume |warp_d(view) - ref| * mask (reference model.py:270-280) written by the warp as chunk-planar
+    fp16 pieces (atvs_warp_planes mode 1, planar, pieces) and staged by the photo stem's launch with LDS-DMA: the pieces are
+    bit for bit the split of the channel-last volume, and the stem's plane of the concat and its statistics are the same bits."""
+    from atvsnet_amd import ops
+    from oracle import homography_warping as G_
+    from oracle import model as OM
+    if ops._xkind() != 'xb':
+        pytest.skip('pieces belong to the split-operand x-pair kernel')
+    import os
+    import numpy as np
+    ops.clear_pack_cache()
+    chan = 16
+    gd = os.path.join(os.path.dirname(__file__), 'golden')
+    cams = torch.stack([torch.from_numpy(np.load(os.path.join(gd, 'example2_%d_cam.npy' % i))) for i in range(2)])[None].float()
+    ds, di = OM.depth_start_interval(cams)
+    Hm = G_.get_homographies(cams[:, 0], cams[:, 1], D, ds, di)[0].to(cuda)
+    vf, rf = (_rand((h, w, chan), 40) * 2.0).to(cuda), (_rand((h, w, chan), 41) * 2.0).to(cuda)
+    cl = ops.warp_planes(vf, Hm, mode=1, ref=rf)                                              # (D,h,w,16)
+    pc = ops.warp_planes(vf, Hm, mode=1, ref=rf, planar=True, pieces=True)                    # (2, planar_stride)
+    n = D * h * w * 8
+    x = cl.cpu().numpy().reshape(D, h, w, 2, 8).transpose(3, 0, 1, 2, 4)                      # (chunk, D, h, w, 8)
+    got = pc[:, :n].contiguous().view(torch.float16).cpu().numpy().reshape(2, 2, D, h, w, 8)
+    h0 = x.astype(np.float16)
+    h1 = ((x - h0.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    assert np.array_equal(got[:, 0].view(np.uint16), h0.view(np.uint16)) and np.array_equal(got[:, 1].view(np.uint16), h1.view(np.uint16))
+    const = _rand((1, h, w, 2 * chan), 42).to(cuda)
+    cmap = [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)]
+    sv_cl = ops.SplitVolume(cl[None], const, cmap)
+    sv_pc = ops.SplitVolume(pc[None], const, cmap, planar=(D, h, w), pieces=True)
+    wgt = (_rand((3, 3, 3, 3 * chan, 8), 43) * 0.1).numpy()
+    ps = ops.planar_stride(D, h, w)
+    buf_a, buf_b = torch.full((1, 4, ps), -3.5, device=cuda), torch.full((1, 4, ps), -3.5, device=cuda)
+    st_a = ops.conv_split_into_plane(sv_cl, 'photo-pieces-test', wgt, buf_a, 0, (D, h, w))
+    st_b = ops.conv_split_into_plane(sv_pc, 'photo-pieces-test', wgt, buf_b, 0, (D, h, w))
+    assert torch.equal(buf_a, buf_b) and torch.equal(st_a.partial, st_b.partial)
+    ops.clear_pack_cache()
+
+
 def test_refinement_net_planar_concat_equals_channel_last_concat(cuda, weights):
     """CostVolRefineNet with its concat as four dense planes (default) against the channel-last concat
     (ops.use_planar_concat(False)): every output bit for bit, and the planar form really ran."""
