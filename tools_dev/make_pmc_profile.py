@@ -10,13 +10,13 @@ S = json.load(open(os.path.join(ROOT, 'gpurun_out', 'pmc_' + tag, 'summary.json'
 V, V2 = 192 * 128 * 160, 96 * 64 * 80
 KERN = sys.argv[3] if len(sys.argv) > 3 else 'conv_xb_kernel'
 FORMS = {   # kernel name -> (description, volumes per launch, algorithmic FLOP, algorithmic read bytes, write bytes)
-    KERN + '<true, 0, true>': ('conv_b0_0_1 | conv_b0_1_0: 32 warped channels -> 8 | 16 (stride 2), plane biases', 8,
+    KERN + '<true, 0, true, true>': ('conv_b0_0_1 | conv_b0_1_0: 32 warped channels -> 8 | 16 (stride 2), plane biases', 8,
                                 2.0 * 27 * 32 * 8 * V + 2.0 * 27 * 32 * 16 * V2, 4.0 * 32 * V, 4.0 * (8 * V + 16 * V2)),
-    KERN + '<true, 2, false>': ('conv_b{1,2}_0_1 | 1_0: two 8-channel sources, batch norm + ReLU + add on load -> 8 | 16', 8,
+    KERN + '<true, 2, false, false>': ('conv_b{1,2}_0_1 | 1_0: two 8-channel sources, batch norm + ReLU + add on load -> 8 | 16', 8,
                                 2.0 * 27 * 8 * 8 * V + 2.0 * 27 * 8 * 16 * V2, 4.0 * 16 * V, 4.0 * (8 * V + 16 * V2)),
-    KERN + '<true, 1, true>': ('global_refine_3dconv0_1 | 1_0: 32-channel concat, batch norm + ReLU on load -> 8 | 16', 4,
+    KERN + '<true, 1, true, false>': ('global_refine_3dconv0_1 | 1_0: 32-channel concat, batch norm + ReLU on load -> 8 | 16', 4,
                                 2.0 * 27 * 32 * 8 * V + 2.0 * 27 * 32 * 16 * V2, 4.0 * 32 * V, 4.0 * (8 * V + 16 * V2)),
-    KERN + '<false, 0, true>': ('photo stem: 16 D-varying channels -> 8, plane bias', 4, 2.0 * 27 * 16 * 8 * V, 4.0 * 16 * V, 4.0 * 8 * V),
+    KERN + '<false, 0, true, true>': ('photo stem: 16 D-varying channels -> 8, plane bias', 4, 2.0 * 27 * 16 * 8 * V, 4.0 * 16 * V, 4.0 * 8 * V),
 }
 res = {'note': 'rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only) over `bench.py --eager --inflight 1` on '
                'MI355X (tools_dev/pmc_bench.sh): the launches of the timed graph, per-launch averages.  mfma_busy = '
@@ -48,7 +48,7 @@ for name, (desc, vols, flop, rd, wr) in FORMS.items():
     e['traffic_ratio_raw'] = round((e['write_bytes'] + e['fetch_bytes_raw']) / alg, 3)
     e['traffic_ratio_fetch_x2'] = round((e['write_bytes'] + 2 * e['fetch_bytes_raw']) / alg, 3)
     res['kernels'][name] = e
-res['dominant'] = dict(res['kernels'][KERN + '<true, 0, true>'], kernel=KERN + '<true, 0, true>')
+res['dominant'] = dict(res['kernels'][KERN + '<true, 0, true, true>'], kernel=KERN + '<true, 0, true, true>')
 others = {}
 for name, k in S.items():
     if name in FORMS or 'total_ms_under_profiler' not in k or k['total_ms_under_profiler'] < 0.5:
