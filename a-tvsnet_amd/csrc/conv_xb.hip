@@ -800,6 +800,9 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
 }
 
 
+#undef XB_PF_WAIT
+#undef XB_W_WAIT
+
 long xb_ntiles(int D, int H, int W) {
   return (long)((D + XB_TZ - 1) / XB_TZ) * ((H + XB_TY - 1) / XB_TY) * ((W + XB_TXV - 1) / XB_TXV);
 }
