@@ -1,29 +1,42 @@
-// 3x3x3 stride-2 SAME transposed convolution to 8 or 16 output channels on the bf16 matrix cores with SPLIT operands (gfx950):
+// 3x3x3 stride-2 SAME transposed convolution to 8 or 16 output channels on the 16-bit matrix cores with SPLIT operands (gfx950):
 // deconv_up.hip's layers (conv_b*_6_0, global_refine_3dconv6_0: 16 -> 8, full-resolution output; conv_b*_5_0,
-// global_refine_3dconv5_0: 32 -> 16; /root/reference/cnn_wrapper/network.py:510-550) with every fp32 operand split into three
-// bf16 pieces, six products, fp32 accumulation (conv_c16b.hip has the arithmetic).
+// global_refine_3dconv5_0: 32 -> 16; /root/reference/cnn_wrapper/network.py:510-550) with every fp32 operand split into TWO fp16
+// pieces, three products, fp32 accumulation (conv_xb.hip has the arithmetic: x = h0 + h1 / 2048, the cross terms in an
+// accumulator of their own that is scaled once; atvs_split2_f16).  (Rounds 3 / 4 first half: three bf16 pieces, six products,
+// one accumulator set of 32 tiles per wavefront -- a second set did not fit beside it; the tile is now half as tall.)
 //
 // Form of deconv_up.hip: per input voxel M = 8 parity classes x Cout rows, K = 8 offsets x Cin; here a K = 32 instruction
 // covers the TWO x offsets of an (oz, oy) pair x 16 channels (lane group q: ox = q >> 1, channels 8 (q & 1) ..), so
-//   Cout =  8: tile m = (pz, py), rows = (px, channel): 9 (tile, oz, oy) steps (18 fp32 blocks of four 32-cycle MFMAs become
-//              9 steps of six 16-cycle ones);
+//   Cout =  8: tile m = (pz, py), rows = (px, channel): 9 (tile, oz, oy) steps of three 16-cycle MFMAs;
 //   Cout = 16: tile m = (pz, py, px), rows = channel: 18 steps (the odd-px tiles use only the ox = 0 half of K).
-// Steps are issued in GROUPS of up to four tiles that share (oz, oy), hence the input fragments; a group runs in three phases
-// (input piece pc with the weight pieces jw <= 2 - pc), fragments requested one phase ahead, the group's weights (from LDS,
-// resident for the launch) one group ahead.  Tile 4(z) x TY(y) x 16(x) input voxels, TY = 8 / 4; one-sided halo 5 x (TY+1) x 17;
-// three piece images of 32-byte voxels (no swizzle needed: 16 lanes read 16 consecutive voxels, the channel half shifts by 16
-// bytes); branch-free buffer stores as in deconv_up.hip.
+// Steps are issued in GROUPS of up to four tiles that share (oz, oy), hence the input fragments; a group runs in two phases
+// (input piece h0 with both weight pieces, then h1 with g0), fragments requested one phase ahead, the group's weights (from LDS,
+// resident for the launch) one group ahead.  Tile 4(z) x TY(y) x 16(x) input voxels, TY = 4 / 2 (16 output tiles x two accumulator
+// sets per wavefront); one-sided halo 5 x (TY+1) x 17; two piece images of 32-byte voxels (no swizzle needed: 16 lanes read 16
+// consecutive voxels, the channel half shifts by 16 bytes); branch-free buffer stores as in deconv_up.hip.
+// At most 256 registers per wavefront and (for the product's shapes) under 80 KB of LDS: TWO workgroups share a CU, one's
+// epilogue stores and staging run beside the other's K loop.  Scalar fp32 arithmetic only (-fno-slp-vectorize: wavefronts of
+// the two workgroups share SIMDs).
 #include <cstring>
 #include <type_traits>
 #include <utility>
 
 #include "conv_common.h"
 
-extern "C" long atvs_deconv_up_grid(int D, int H, int W, int Cout, int groups);
 
 namespace {
 
 constexpr int UB_TZ = 4, UB_TX = 16;
+constexpr int UB_NP = 2;                               // operand pieces
+#ifndef ATVS_UB_WGS8
+#define ATVS_UB_WGS8 1
+#endif
+#define UB_WGS_PER_CU(COUT) ((COUT) == 8 ? ATVS_UB_WGS8 : 2)
+#ifndef ATVS_UB_GRID8
+#define ATVS_UB_GRID8 ATVS_UB_WGS8
+#endif
+#define UB_GRID_PER_CU(COUT) ((COUT) == 8 ? ATVS_UB_GRID8 : 2)
+constexpr float UB_RS = 2048.f, UB_IRS = 1.f / 2048.f; // scale of the residual piece and its inverse
 constexpr int UB_HZ = UB_TZ + 1, UB_HX = UB_TX + 1;
 constexpr int UB_VB = 32;
 constexpr int UB_ROWB = UB_HX * UB_VB;                 // 544
@@ -32,11 +45,11 @@ template <int COUT>
 struct UpB {
   static_assert(COUT == 8 || COUT == 16, "built for 8 and 16 output channels");
   static constexpr int NT = (COUT == 8) ? 4 : 8;
-  static constexpr int TY = 32 / NT;
+  static constexpr int TY = 16 / NT;                   // 16 output tiles per wavefront x (main, cross) accumulators
   static constexpr int HY = TY + 1;
   static constexpr int IMG = UB_HZ * HY * UB_ROWB;     // bytes of one piece image
   static constexpr int SLOTS = UB_HZ * HY * UB_HX * 4;
-  static constexpr int MAXS = (SLOTS + 255) / 256;     // 12 / 7
+  static constexpr int MAXS = (SLOTS + 255) / 256;     // 7 / 4
   static constexpr int NG = (COUT == 8) ? 4 : 5;       // groups
   // group g: its (oz, oy) pair o2 = oz * 2 + oy, its tiles
   static constexpr int o2_of(int g) { return (COUT == 8) ? g : (g < 2 ? 0 : g - 1); }
@@ -52,14 +65,12 @@ struct UpB {
     return n;
   }
   static constexpr int NSTEP = first_step(NG);
-  static constexpr int WCH = NSTEP * 3 * 1024;         // bytes of packed weights per chunk
+  static constexpr int WCH = NSTEP * UB_NP * 1024;     // bytes of packed weights per chunk
 };
 static_assert(UpB<8>::NSTEP == 9 && UpB<16>::NSTEP == 18, "(tile, oz, oy) steps");
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct UpBArgs {
   const float* x;
@@ -88,27 +99,10 @@ __device__ __forceinline__ void ub_static_for(F&& f) {
   ub_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-__device__ __forceinline__ void ub_split(const float4& v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
-  const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const __bf16 a = (__bf16)x[i];
-    const float r1 = x[i] - (float)a;
-    const __bf16 b = (__bf16)r1;
-    const float r2 = r1 - (float)b;
-    (*p0)[i] = a;
-    (*p1)[i] = b;
-    (*p2)[i] = (__bf16)r2;
-  }
-}
-
 // STREAMW: the packed weights of ONE chunk live in LDS and are re-read from L2 at every stage (Cin too large for all chunks to
 // stay resident: the 64 -> 32 layer as two 16-channel launches)
 template <int COUT, bool STREAMW>
-__global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
-  // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
-  // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
-  asm volatile("" ::: "v255", "a255");
+__global__ __launch_bounds__(256, UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(UpBArgs p) {
   using U = UpB<COUT>;
   constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -119,12 +113,12 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
   // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
   if (!STREAMW) {
     const float4* src = reinterpret_cast<const float4*>(p.wp);
-    float4* dst = reinterpret_cast<float4*>(smem + 3 * U::IMG);
+    float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
     for (int i = tid; i < p.nchunk * (U::WCH / 16); i += 256) dst[i] = src[i];
   }
   // this lane's fragment at halo voxel (wave, 0, r + 1 - ox), ox = q >> 1: offset (-1, -1, ox) of row 0 of the wavefront's plane
   const int fbase = ((wave * HY) * UB_HX + r + 1 - (q >> 1)) * UB_VB + (q & 1) * 16;
-  const int wbase = 3 * U::IMG + lane * 16;
+  const int wbase = UB_NP * U::IMG + lane * 16;
 
   int goff[MAXS], laddr[MAXS];
   unsigned pg[MAXS];
@@ -188,8 +182,8 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
     pf[i] = ld4(ok ? (T.xb + (T.org + goff[i])) : p.zeros);
   };
 
-  f32x2 ssum2[2] = {{0.f, 0.f}, {0.f, 0.f}}, ssq2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-  f32x4 acc[TY][NT];
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};       // scalar on purpose (two workgroups share a CU)
+  f32x4 acc[TY][NT], accx[TY][NT];       // h0 g0 | (h0 g1 + h1 g0) * 2^11
   const unsigned ybytes = (unsigned)(p.gy * 4);
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
 
@@ -205,65 +199,84 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
 #pragma unroll
       for (int t = 0; t < TY; ++t)
 #pragma unroll
-        for (int m = 0; m < NT; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int m = 0; m < NT; ++m) acc[t][m] = accx[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();                       // every wavefront is done reading the previous stage's images (and weights)
     if (STREAMW) {
       const float4* src = reinterpret_cast<const float4*>(p.wp + (size_t)ch * U::WCH);
-      float4* dst = reinterpret_cast<float4*>(smem + 3 * U::IMG);
+      float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
       for (int i = tid; i < U::WCH / 16; i += 256) dst[i] = src[i];
     }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) {
-        bf16x4 p0, p1, p2;
-        ub_split(pf[i], &p0, &p1, &p2);
-        *reinterpret_cast<bf16x4*>(smem + laddr[i]) = p0;
-        *reinterpret_cast<bf16x4*>(smem + U::IMG + laddr[i]) = p1;
-        *reinterpret_cast<bf16x4*>(smem + 2 * U::IMG + laddr[i]) = p2;
+        uint2 p0, p1;
+        atvs_split2_f16(pf[i].x, pf[i].y, UB_RS, &p0.x, &p1.x);
+        atvs_split2_f16(pf[i].z, pf[i].w, UB_RS, &p0.y, &p1.y);
+        *reinterpret_cast<uint2*>(smem + laddr[i]) = p0;
+        *reinterpret_cast<uint2*>(smem + U::IMG + laddr[i]) = p1;
       }
     __syncthreads();
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
     const int wb = wbase + (STREAMW ? 0 : ch * U::WCH);
 
-    // ---- K loop: groups of tiles sharing (oz, oy), three phases each
-    bf16x8 Bq[2][TY], A[2][4][3];
+    // ---- K loop: groups of tiles sharing (oz, oy), two phases each: input piece h0 with the weight pieces g0 (main) and g1
+    // (cross), then h1 with g0 (cross)
+    // A0: the g0 weight fragments of a group, double-buffered (needed in both phases: the next group's are requested during
+    // this group's first phase); A1: the g1 fragments, needed in the first phase only -- the next group's are requested during
+    // the second phase into the same registers (a wavefront has 256: two workgroups share a CU)
+    f16x8 Bq[2][TY], A0[2][4], A1[4];
     auto request_B = [&](auto PH) __attribute__((always_inline)) {
-      constexpr int ph = decltype(PH)::value, g = ph / 3, pc = ph % 3, o2 = U::o2_of(g), oz = o2 >> 1, oy = o2 & 1;
+      constexpr int ph = decltype(PH)::value, g = ph / UB_NP, pc = ph % UB_NP, o2 = U::o2_of(g), oz = o2 >> 1, oy = o2 & 1;
       constexpr int disp = ((1 - oz) * HY + (1 - oy)) * UB_ROWB;
 #pragma unroll
-      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const bf16x8*>(smem + pc * U::IMG + fbase + (disp + t * UB_ROWB));
+      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * U::IMG + fbase + (disp + t * UB_ROWB));
     };
-    auto request_A = [&](auto GT) __attribute__((always_inline)) {
+    auto request_A0 = [&](auto GT) __attribute__((always_inline)) {
       constexpr int g = decltype(GT)::value;
       ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
         constexpr int i = decltype(IT)::value;
-#pragma unroll
-        for (int pc = 0; pc < 3; ++pc)
-          A[g & 1][i][pc] = *reinterpret_cast<const bf16x8*>(smem + wb + ((U::first_step(g) + i) * 3 + pc) * 1024);
+        A0[g & 1][i] = *reinterpret_cast<const f16x8*>(smem + wb + ((U::first_step(g) + i) * UB_NP + 0) * 1024);
       });
     };
-    request_A(IC<0>{});
+    auto request_A1 = [&](auto GT) __attribute__((always_inline)) {
+      constexpr int g = decltype(GT)::value;
+      ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
+        constexpr int i = decltype(IT)::value;
+        A1[i] = *reinterpret_cast<const f16x8*>(smem + wb + ((U::first_step(g) + i) * UB_NP + 1) * 1024);
+      });
+    };
+    request_A0(IC<0>{});
+    request_A1(IC<0>{});
     request_B(IC<0>{});
     asm volatile("" ::: "memory");
-    ub_static_for<3 * NG>([&](auto PH) __attribute__((always_inline)) {
-      constexpr int ph = decltype(PH)::value, g = ph / 3, pc = ph % 3;
-      if constexpr (ph + 1 < 3 * NG) request_B(IC<ph + 1>{});
-      if constexpr (pc == 1 && g + 1 < NG) request_A(IC<g + 1>{});
+    ub_static_for<UB_NP * NG>([&](auto PH) __attribute__((always_inline)) {
+      constexpr int ph = decltype(PH)::value, g = ph / UB_NP, pc = ph % UB_NP;
+      if constexpr (ph + 1 < UB_NP * NG) request_B(IC<ph + 1>{});
+      if constexpr (pc == 0 && g + 1 < NG) request_A0(IC<g + 1>{});
       if constexpr (ph < MAXS) pf_slot(T, ph);
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
+      ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
+        constexpr int i = decltype(IT)::value, m = U::tile(g, i);
+        if constexpr (pc == 0) {
 #pragma unroll
-      for (int jw = 0; jw <= 2 - pc; ++jw)
-        ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
-          constexpr int i = decltype(IT)::value, m = U::tile(g, i);
+          for (int t = 0; t < TY; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0[g & 1][i], Bq[ph & 1][t], acc[t][m], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TY; ++t)
-            acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[g & 1][i][jw], Bq[ph & 1][t], acc[t][m], 0, 0, 0);
-        });
+          for (int t = 0; t < TY; ++t) accx[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[i], Bq[ph & 1][t], accx[t][m], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < TY; ++t) accx[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0[g & 1][i], Bq[ph & 1][t], accx[t][m], 0, 0, 0);
+        }
+      });
+      if constexpr (pc == 0 && g + 1 < NG) {     // behind the MFMAs that read A1: the next group's g1 fragments
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        request_A1(IC<g + 1>{});
+      }
     });
-    static_assert(3 * NG >= MAXS, "every halo slot is requested inside the K loop");
+    static_assert(UB_NP * NG >= MAXS, "every halo slot is requested inside the K loop");
     if (ch != p.nchunk - 1) continue;
 
     // ---- epilogue (deconv_up.hip): this lane holds, of tile m,
@@ -284,7 +297,9 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
         constexpr int m = decltype(MT)::value, t = decltype(TT)::value;
         constexpr int pz = (COUT == 8) ? (m >> 1) : (m >> 2), py = (COUT == 8) ? (m & 1) : ((m >> 1) & 1);
         constexpr int px = (COUT == 8) ? 0 : (m & 1);
-        float a0 = acc[t][m][0], a1 = acc[t][m][1], a2 = acc[t][m][2], a3 = acc[t][m][3];
+        // fmaf(cross, 2^-11, main): the product by a power of two is exact
+        float a0 = __builtin_fmaf(accx[t][m][0], UB_IRS, acc[t][m][0]), a1 = __builtin_fmaf(accx[t][m][1], UB_IRS, acc[t][m][1]);
+        float a2 = __builtin_fmaf(accx[t][m][2], UB_IRS, acc[t][m][2]), a3 = __builtin_fmaf(accx[t][m][3], UB_IRS, acc[t][m][3]);
         if (p.relu) {
           a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
           a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
@@ -295,11 +310,10 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
         const bool row_ok = ty0 + t < p.Hi;
         __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, soff, 0);
         const bool ok = evox_ok && row_ok;
-        f32x2 lo = {ok ? a0 : 0.f, ok ? a1 : 0.f}, hi = {ok ? a2 : 0.f, ok ? a3 : 0.f};
-        ssum2[0] += lo;
-        ssum2[1] += hi;
-        ssq2[0] = __builtin_elementwise_fma(lo, lo, ssq2[0]);
-        ssq2[1] = __builtin_elementwise_fma(hi, hi, ssq2[1]);
+        const float b0 = ok ? a0 : 0.f, b1 = ok ? a1 : 0.f, b2 = ok ? a2 : 0.f, b3 = ok ? a3 : 0.f;
+        ssum[0] += b0; ssum[1] += b1; ssum[2] += b2; ssum[3] += b3;
+        ssq[0] = __builtin_fmaf(b0, b0, ssq[0]); ssq[1] = __builtin_fmaf(b1, b1, ssq[1]);
+        ssq[2] = __builtin_fmaf(b2, b2, ssq[2]); ssq[3] = __builtin_fmaf(b3, b3, ssq[3]);
       });
     });
   }
@@ -310,7 +324,7 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
     double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      double a = (double)ssum2[kk >> 1][kk & 1], bq = (double)ssq2[kk >> 1][kk & 1];
+      double a = (double)ssum[kk], bq = (double)ssq[kk];
 #pragma unroll
       for (int o = 1; o < 16; o <<= 1) {
         a += __shfl_xor(a, o);
@@ -338,22 +352,20 @@ __global__ __launch_bounds__(256, 1) void deconv_up_b_kernel(UpBArgs p) {
   }
 }
 
-float ub_round(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-  float o;
-  std::memcpy(&o, &u, 4);
-  return o;
-}
-uint16_t ub_bits(float v) {
-  uint32_t u;
-  std::memcpy(&u, &v, 4);
-  return (uint16_t)(u >> 16);
+// HOST: the two fp16 pieces of v (round to nearest even; the kernel's atvs_split2_f16) at out[base + piece * 64 * 8]; false if v
+// does not fit fp16's range
+bool ub_put(uint16_t* out, size_t base, float v) {
+  const _Float16 h0 = (_Float16)v;
+  const _Float16 h1 = (_Float16)((v - (float)h0) * UB_RS);
+  std::memcpy(&out[base], &h0, 2);
+  std::memcpy(&out[base + 64 * 8], &h1, 2);
+  const float back = (float)h0;
+  return back - back == 0.f;                             // finite
 }
 
 size_t ub_lds(int Cin, int Cout) {
-  return Cout == 8 ? 3 * (size_t)UpB<8>::IMG + (size_t)(Cin / 16) * UpB<8>::WCH : 3 * (size_t)UpB<16>::IMG + (size_t)(Cin / 16) * UpB<16>::WCH;
+  return Cout == 8 ? UB_NP * (size_t)UpB<8>::IMG + (size_t)(Cin / 16) * UpB<8>::WCH
+                   : UB_NP * (size_t)UpB<16>::IMG + (size_t)(Cin / 16) * UpB<16>::WCH;
 }
 // all chunks resident if they fit, else one chunk at a time (Cout 16 only)
 bool ub_stream(int Cin, int Cout) { return Cout == 16 && ub_lds(Cin, Cout) > 160 * 1024; }
@@ -374,7 +386,8 @@ int launch_upb(const UpBArgs& a, long grid, size_t lds, hipStream_t s) {
 }
 
 template <int COUT>
-void pack_upb(const float* w, int Cin, uint16_t* out) {
+bool pack_upb(const float* w, int Cin, uint16_t* out) {
+  bool fits = true;
   using U = UpB<COUT>;
   auto kof = [](int par, int off) { return par ? (off ? -1 : 1) : (off ? 2 : 0); };
   for (int ch = 0; ch < Cin / 16; ++ch)
@@ -392,13 +405,11 @@ void pack_upb(const float* w, int Cin, uint16_t* out) {
             for (int e = 0; e < 8; ++e) {
               const int ci = ch * 16 + (q & 1) * 8 + e;
               const float v = w[((((size_t)kd * 3 + kh) * 3 + kw) * COUT + co) * Cin + ci];
-              const float p0 = ub_round(v), p1 = ub_round(v - p0), p2 = ub_round((v - p0) - p1);
-              const float pc[3] = {p0, p1, p2};
-              for (int k = 0; k < 3; ++k)
-                out[((((size_t)ch * U::NSTEP + step) * 3 + k) * 64 + q * 16 + row) * 8 + e] = ub_bits(pc[k]);
+              fits &= ub_put(out, ((((size_t)ch * U::NSTEP + step) * UB_NP) * 64 + q * 16 + row) * 8 + e, v);
             }
           }
       }
+  return fits;
 }
 
 }  // namespace
@@ -427,12 +438,24 @@ extern "C" int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned
   int rc = atvs_deconv_up_b_pack_size(Cin, Cout, &pb);
   if (rc) return rc;
   std::memset(packed, 0, (size_t)pb);
-  if (Cout == 8) pack_upb<8>(w, Cin, reinterpret_cast<uint16_t*>(packed));
-  else pack_upb<16>(w, Cin, reinterpret_cast<uint16_t*>(packed));
-  return ATVS_OK;
+  const bool fits = (Cout == 8) ? pack_upb<8>(w, Cin, reinterpret_cast<uint16_t*>(packed)) : pack_upb<16>(w, Cin, reinterpret_cast<uint16_t*>(packed));
+  return fits ? ATVS_OK : ATVS_ERR_ARG;                  // a weight beyond fp16's range (|w| > 65504)
 }
 
-// Contract of atvs_deconv_up_f32 (grid / statistics rows = atvs_deconv_up_grid) with split-bf16 operands (fp32-class results).
+// workgroups PER SAMPLE of a launch over `groups` independent samples (rows of the statistics buffer = groups * this): the
+// workgroups that fit the GPU at once (UB_WGS_PER_CU per CU), shared out among the samples, a multiple of 8 each
+extern "C" long atvs_deconv_up_b_grid(int D, int H, int W, int Cout, int groups) {
+  if (groups < 1) groups = 1;
+  if (Cout != 8 && Cout != 16) return 0;
+  const int ty = (Cout == 8) ? UpB<8>::TY : UpB<16>::TY;
+  const long nt = (long)((D + UB_TZ - 1) / UB_TZ) * ((H + ty - 1) / ty) * ((W + UB_TX - 1) / UB_TX);
+  long share = 256 * UB_GRID_PER_CU(Cout) / groups / 8 * 8;
+  if (share < 8) share = 8;
+  const long g = nt < share ? nt : share;
+  return (g + 7) / 8 * 8;
+}
+
+// Contract of atvs_deconv_up_f32 with split operands (fp32-class results); grid / statistics rows = atvs_deconv_up_b_grid.
 // stats_ld / stats_coff: a statistics row is [2][stats_ld] doubles and this launch's channels start at column stats_coff
 // (16 / 0 = atvs_deconv_up_f32's layout; a wider layer computed 16 channels per launch passes its width and 0, 16, ...).
 extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups,
@@ -454,13 +477,13 @@ extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_
   const int ty = (Cout == 8) ? UpB<8>::TY : UpB<16>::TY;
   a.tiles_y = (H + ty - 1) / ty; a.tiles_x = (W + UB_TX - 1) / UB_TX;
   a.ntiles = ((D + UB_TZ - 1) / UB_TZ) * a.tiles_y * a.tiles_x;
-  const long blocks = atvs_deconv_up_grid(D, H, W, Cout, groups);
+  const long blocks = atvs_deconv_up_b_grid(D, H, W, Cout, groups);
   a.wg = (int)blocks;
   a.gx = (long)D * H * W * Cin; a.gy = 8L * D * H * W * ldy;
   if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
   const bool stream_w = ub_stream(Cin, Cout);
-  const size_t lds = stream_w ? 3 * (size_t)UpB<16>::IMG + UpB<16>::WCH : ub_lds(Cin, Cout);
+  const size_t lds = stream_w ? UB_NP * (size_t)UpB<16>::IMG + UpB<16>::WCH : ub_lds(Cin, Cout);
   int rc = (Cout == 8) ? launch_upb<8, false>(a, blocks * groups, lds, st)
                        : stream_w ? launch_upb<16, true>(a, blocks * groups, lds, st) : launch_upb<16, false>(a, blocks * groups, lds, st);
   if (rc) return rc;

@@ -1647,7 +1647,8 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
         # all 8 parity classes from one staged input tile, one workgroup per CU (csrc/deconv_up.hip)
         split = split_on('upb') and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), int(cout)))     # deconv_up_b.hip
         pk = pack_deconv_up(key, w_host, x.device, '_b' if split else '')
-        blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), int(cout), int(G)))
+        grid_fn = _lib.lib().atvs_deconv_up_b_grid if split else _lib.lib().atvs_deconv_up_grid
+        blocks = int(grid_fn(int(D), int(H), int(W), int(cout), int(G)))
         st, sbuf = None, None
         if want_stats:
             sbuf = _stats_buffer(x, blocks, 16, groups=G)
@@ -1666,7 +1667,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
             and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), 16)):
         # the 64 -> 32 layer (conv_b*_4_0) as two 16-channel launches of the split-bf16 kernel into the halves of y
         import numpy as np
-        blocks = int(_lib.lib().atvs_deconv_up_grid(int(D), int(H), int(W), 16, int(G)))
+        blocks = int(_lib.lib().atvs_deconv_up_b_grid(int(D), int(H), int(W), 16, int(G)))
         st, sbuf = None, None
         if want_stats:
             sbuf = _stats_buffer(x, blocks, 32, groups=G)

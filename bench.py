@@ -6,8 +6,8 @@
 A step = one depth map through the whole example.py pipeline (towers -> 2x stacked 3-D U-Net per source ->
 AAM1 -> refinement per source -> AAM2 -> x4 upsample + soft-argmin), inputs resident in HBM, synthetic
 seeded images / cameras / weights, fp32 storage and accumulation; the heavy convolutions run on
-v_mfma_f32_16x16x32_f16 with every fp32 operand split into two fp16 pieces (three products, fp32-class results, DESIGN.md 8;
-the transposed convolutions: three bf16 pieces, six products), the rest on the fp32 matrix cores; `split_operands` times the
+v_mfma_f32_16x16x32_f16 with every fp32 operand split into two fp16 pieces (three products, fp32-class results),
+the rest on the fp32 matrix cores; `split_operands` times the
 all-fp32-MFMA path next to it.
 Default workload = BASELINE.json configs[2], the configuration the metric is quoted on: 5 views
 (1 reference + 4 sources) of 640x512, D=192.  cfg2 = two-view 640x512x192, cfg4 = 9 views 928x480x256 (the
@@ -720,8 +720,7 @@ def rank_main(args):
             split = {'layers': 'the 3x3x3 layers with 8 / 16 / 32 input channels (conv_xb.hip, conv_c16b.hip) and the 3x3 / 1x1 tower '
                                'layers with Cin % 32 == 0 (conv2d_b.hip, conv1x1_b.hip) on v_mfma_f32_16x16x32_f16: '
                                'x = h0 + h1 / 2048, w = g0 + g1 / 2048 in fp16 (h1 = f16((x - h0) * 2048)), the 3 products '
-                               'h0 g0 + (h0 g1 + h1 g0) / 2048, fp32 accumulation; the transposed convolutions (deconv_up_b.hip) '
-                               'keep three bf16 pieces / six products',
+                               'h0 g0 + (h0 g1 + h1 g0) / 2048, fp32 accumulation; the transposed convolutions (deconv_up_b.hip) likewise',
                      'in_value': bool(default_on),
                      'other_path': 'every convolution on the fp32 matrix cores' if default_on else 'split-bf16 layers enabled',
                      'other_ms_per_step': round(1e3 * dt2 / args.steps, 3), 'other_value': round(args.steps / dt2, 4),
@@ -854,7 +853,7 @@ def rank_main(args):
             'scaling': 'strong' if sharded else 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'precision': ('fp32 storage and fp32 accumulation everywhere; the heavy convolutions (3x3x3 with 8 / 16 / 32 input '
                           'channels, 3x3 and 1x1 tower layers) split every fp32 operand into two fp16 pieces (22 significant bits, '
-                          'the residual piece scaled into the normal range; transposed convolutions: three bf16 pieces) '
+                          'the residual piece scaled into the normal range) '
                           'and form 3 products with the cross terms accumulated apart: fp32-class (per-layer error against float64 '
                           'below the fp32 matrix cores\'), same parity bar; the other layers use fp32 MFMA operands; see '
                           '`split_operands` for the all-fp32-MFMA figure') if ops._USE_BF16X3 else 'fp32 MFMA operands, fp32 accumulation',

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 29
+#define ATVS_ABI_VERSION 30
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -383,14 +383,15 @@ int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned char* packe
 int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
                         int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
-/* atvs_deconv_up_f32's layers and contract (grid / statistics rows = atvs_deconv_up_grid) with SPLIT operands on the 16-bit
- * matrix cores (deconv_up_b.hip; this kernel keeps round 3's arithmetic: THREE bf16 pieces per operand, x = x0 + x1 + x2, the six
- * products x_i * w_j with i + j <= 2 on v_mfma_f32_16x16x32_bf16, one accumulator -- its 32 accumulator tiles leave no room for the
- * second set the fp16 form needs).  The packed weights of all chunks stay in LDS beside
- * three piece images where they fit (Cout 8: Cin <= 48; Cout 16: Cin <= 32); Cout 16 with more input channels re-reads one chunk's
- * weights per stage (atvs_deconv_up_b_supported).  stats_ld / stats_coff: a statistics row is [2][stats_ld] doubles and this
+/* atvs_deconv_up_f32's layers and contract with SPLIT operands on the 16-bit matrix cores (deconv_up_b.hip; the arithmetic of
+ * atvs_conv_c16b_f32: two fp16 pieces per operand, three products, the cross terms in an accumulator of their own).  Grid /
+ * statistics rows = atvs_deconv_up_b_grid (two workgroups per CU; NOT atvs_deconv_up_grid).  The packed weights of all chunks
+ * stay in LDS beside two piece images where they fit; Cout 16 with more input channels re-reads one chunk's weights per stage
+ * (atvs_deconv_up_b_supported).  stats_ld / stats_coff: a statistics row is [2][stats_ld] doubles and this
  * launch's channels start at column stats_coff (16, 0 = atvs_deconv_up_f32's layout): a 32-channel layer (conv_b*_4_0) runs as two
- * 16-channel launches with y_coff / stats_coff 0 and 16, ldy = stats_ld = 32.  Weights: atvs_deconv_up_b_pack (HOST; size in BYTES). */
+ * 16-channel launches with y_coff / stats_coff 0 and 16, ldy = stats_ld = 32.  Weights: atvs_deconv_up_b_pack (HOST; size in BYTES;
+ * ATVS_ERR_ARG for a weight beyond fp16's range). */
+long atvs_deconv_up_b_grid(int D, int H, int W, int Cout, int groups);
 int atvs_deconv_up_b_supported(int Cin, int Cout);
 int atvs_deconv_up_b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);

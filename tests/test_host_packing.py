@@ -69,17 +69,21 @@ def test_conv3d_b_pack_layout(name, cin, cout):
 
 @pytest.mark.parametrize('cin,cout', [(16, 8), (32, 16), (64, 16)])
 def test_deconv_up_b_pack_holds_every_weight_once(cin, cout):
-    """atvs_deconv_up_b_pack: whatever the order (output classes x fragment steps), the three piece images are aligned, piece 0
-    is the bf16 of a weight, and every weight of the [3,3,3,Cout,Cin] kernel appears at least once (classes re-use taps), zeros
-    elsewhere, 16 zero bytes behind."""
+    """atvs_deconv_up_b_pack: whatever the order (output classes x fragment steps), the two piece images are aligned, piece 0
+    is the fp16 of a weight, piece 1 the fp16 of its scaled residual, and every weight of the [3,3,3,Cout,Cin] kernel appears at
+    least once (classes re-use taps), zeros elsewhere, 16 zero bytes behind."""
     w = np.random.default_rng(cin + 7 * cout).standard_normal((3, 3, 3, cout, cin)).astype(np.float32)
     buf = _pack('atvs_deconv_up_b', w, cin, cout)
     assert not buf[-16:].any()
-    vals = _f32(buf[:-16].view(np.uint16))
-    rne = torch.from_numpy(w).bfloat16().float().numpy().ravel()
-    packed_set = set(np.unique(vals).tolist())
-    assert set(np.unique(rne).tolist()) <= packed_set          # every weight's leading piece is there
-    assert np.count_nonzero(vals) >= 2 * w.size                 # and at least two more images' worth of pieces
+    vals = buf[:-16].view(np.float16).reshape(-1, 2, 64, 8)          # (chunk x step, piece, lane, e)
+    g0 = w.astype(np.float16)
+    g1 = ((w - g0.astype(np.float32)) * np.float32(2048.0)).astype(np.float16)
+    assert set(np.unique(g0.view(np.uint16)).tolist()) <= set(np.unique(vals[:, 0].view(np.uint16)).tolist())
+    # piece 1 sits where piece 0 sits, and is the residual of THAT weight
+    pairs = set(zip(g0.view(np.uint16).ravel().tolist(), g1.view(np.uint16).ravel().tolist())) | {(0, 0)}
+    got = set(zip(vals[:, 0].view(np.uint16).ravel().tolist(), vals[:, 1].view(np.uint16).ravel().tolist()))
+    assert got <= pairs
+    assert np.count_nonzero(vals[:, 0]) >= w.size
 
 
 def test_split_bf16_entry_points_check_their_arguments_first():
