@@ -31,11 +31,14 @@ constexpr int UB_NP = 2;                               // operand pieces
 #ifndef ATVS_UB_WGS8
 #define ATVS_UB_WGS8 1
 #endif
-#define UB_WGS_PER_CU(COUT) ((COUT) == 8 ? ATVS_UB_WGS8 : 2)
+#ifndef ATVS_UB_WGS16
+#define ATVS_UB_WGS16 2
+#endif
+#define UB_WGS_PER_CU(COUT) ((COUT) == 8 ? ATVS_UB_WGS8 : ATVS_UB_WGS16)
 #ifndef ATVS_UB_GRID8
 #define ATVS_UB_GRID8 ATVS_UB_WGS8
 #endif
-#define UB_GRID_PER_CU(COUT) ((COUT) == 8 ? ATVS_UB_GRID8 : 2)
+#define UB_GRID_PER_CU(COUT) ((COUT) == 8 ? ATVS_UB_GRID8 : ATVS_UB_WGS16)
 constexpr float UB_RS = 2048.f, UB_IRS = 1.f / 2048.f; // scale of the residual piece and its inverse
 constexpr int UB_HZ = UB_TZ + 1, UB_HX = UB_TX + 1;
 constexpr int UB_VB = 32;
