@@ -1,12 +1,12 @@
-// 1x1 convolution of feature maps (a tall GEMM Y[p, co] = sum_ci X[p, ci] W[ci, co]) on the bf16 matrix cores with SPLIT operands
+// 1x1 convolution of feature maps (a tall GEMM Y[p, co] = sum_ci X[p, ci] W[ci, co]) on the 16-bit matrix cores with SPLIT operands
 // (gfx950): conv1x1.hip's layers (the bottlenecks' conv1 / conv3 / shortcut and fusion1 of the 2-D towers,
-// /root/reference/cnn_wrapper/network.py:552-602, cnn_wrapper/atvsnet.py:254-292) with every fp32 operand split into three bf16
-// pieces, six products, fp32 accumulation (conv_c16b.hip has the arithmetic).  At 128 -> 128 the fp32 MFMA form is as much
-// matrix-core- as HBM-bound (32 FLOP per byte); with the products 2.7x cheaper the layer is HBM-bound.
+// /root/reference/cnn_wrapper/network.py:552-602, cnn_wrapper/atvsnet.py:254-292) with every fp32 operand split into TWO fp16
+// pieces, three products, fp32 accumulation (conv_c16b.hip / conv_xb.hip have the arithmetic; round 3: three bf16 pieces, six products).  At 128 -> 128 the fp32 MFMA form is as much
+// matrix-core- as HBM-bound (32 FLOP per byte); with the products 5x cheaper the layer is HBM-bound.
 //
 // Structure = conv2d_b.hip without a halo: one workgroup per 128 consecutive pixels of one image, the WAVES SPLIT THE OUTPUT
-// CHANNELS and share the pixels, K loop in chunks of 32 input channels = ONE K = 32 step (lane group q = channels 8 q ..), three
-// phases per step; two LDS buffers of three piece images [128 pixels][32 channels] (64-byte pixels, bit 5 of the byte address
+// CHANNELS and share the pixels, K loop in chunks of 32 input channels = ONE K = 32 step (lane group q = channels 8 q ..), two
+// phases per step (h0 with both weight pieces, h1 with g0); two LDS buffers of two piece images [128 pixels][32 channels] (64-byte pixels, bit 5 of the byte address
 // XOR-ed with bit 9: conflict-free ds_read_b128); the next chunk's pixels are fetched during the phases and split + written after
 // them; weight pieces streamed from L2 one step ahead (two register slots, the chunk loop unrolled by two); optional
 // normalise-on-load; epilogue as conv1x1.hip (bias, residual, ReLU, per-(image, workgroup) moments).

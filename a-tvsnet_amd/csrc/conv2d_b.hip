@@ -1,15 +1,16 @@
-// 3x3 (dilated) stride-1 SAME 2-D convolution of wide feature maps on the bf16 matrix cores with SPLIT operands (gfx950):
+// 3x3 (dilated) stride-1 SAME 2-D convolution of wide feature maps on the 16-bit matrix cores with SPLIT operands (gfx950):
 // conv2d_lds.hip's layers (the bottlenecks' conv2, conv0_1 / conv0_2, fusion0 of the 2-D feature towers,
-// /root/reference/cnn_wrapper/atvsnet.py:254-292, network.py:198-200,585-587) with every fp32 operand split into three bf16
-// pieces, the six products x_i * w_j (i + j <= 2) accumulated in fp32 by v_mfma_f32_16x16x32_bf16 (conv_c16b.hip has the
-// arithmetic and its error measurements: fp32-class).
+// /root/reference/cnn_wrapper/atvsnet.py:254-292, network.py:198-200,585-587) with every fp32 operand split into TWO fp16
+// pieces (x = h0 + h1 / 2048), the three products h0 g0 + (h0 g1 + h1 g0) / 2048 accumulated in fp32 by v_mfma_f32_16x16x32_f16, the
+// cross terms in an accumulator of their own (conv_c16b.hip / conv_xb.hip have the arithmetic and its error measurements:
+// fp32-class; round 3: three bf16 pieces, six products).
 //
 // Structure = conv2d_lds.hip (one workgroup per tile of R x 16 pixels of one image, the WAVES SPLIT THE OUTPUT CHANNELS and share
 // the pixels, two LDS buffers, the next 16-channel chunk's halo fetched one slot per phase and written after the loop, optional
 // normalise-on-load, same epilogue / statistics rows) with: a K = 32 step = two taps x 16 channels (lane half q >> 1 picks the
-// tap: 5 steps per chunk, the 10th tap has zero weights); three piece images per buffer (32-byte pixels, row pitch 768 B:
-// conflict-free ds_read_b128 without a swizzle); the split done once per staged element on its way into LDS; three phases per
-// step (input piece pc with the weight pieces jw <= 2 - pc), the weight pieces (three per step and output tile, split by the
+// tap: 5 steps per chunk, the 10th tap has zero weights); two piece images per buffer (32-byte pixels, row pitch 768 B:
+// conflict-free ds_read_b128 without a swizzle); the split done once per staged element on its way into LDS; two phases per
+// step (h0 with both weight pieces, h1 with g0), the weight pieces (two per step and output tile, split by the
 // host packer) streamed from L2 one step ahead.
 #include <cstring>
 #include <type_traits>

@@ -454,7 +454,7 @@ def pack_conv_xp(key, w_host, device):
     rc = size_fn(cin, ctypes.byref(pf))
     if rc:
         raise RuntimeError('atvs_conv_%s_pack_size failed (%d) for Cin=%d' % (kind, rc, cin))
-    packed = np.empty(pf.value, np.uint8 if kind == 'xb' else np.float32)      # xb: bytes (bf16 pieces)
+    packed = np.empty(pf.value, np.uint8 if kind == 'xb' else np.float32)      # xb: bytes (fp16 pieces)
     rc = pack_fn(w.ctypes.data_as(ctypes.c_void_p), cin, packed.ctypes.data_as(ctypes.c_void_p))
     if rc:
         raise RuntimeError('atvs_conv_%s_pack failed (%d)' % (kind, rc))
@@ -470,7 +470,7 @@ def pack_conv_xp(key, w_host, device):
 
 def pack_deconv_up(key, w_host, device, kind=''):
     """Packed weights of the 8- / 16-channel transposed-convolution kernels (atvs_deconv_up_f32; kind '_b': the split-bf16
-    atvs_deconv_up_b_f32, bytes of bf16 pieces); cached."""
+    atvs_deconv_up_b_f32, bytes of fp16 pieces); cached."""
     import numpy as np
     ck = ('up' + kind, key, str(device))
     pk = _pack_cache.get(ck)
@@ -543,7 +543,8 @@ def split_off(*names):
 
 
 def use_bf16x3(flag):
-    """The split-bf16 kernels (x = x0 + x1 + x2, six products, fp32 accumulation; default) or their fp32-MFMA forms: the
+    """The split-operand kernels (x = h0 + h1 / 2048 in fp16, three products, fp32 accumulation; default -- the name is
+    round 3's, when the split was three bf16 pieces) or their fp32-MFMA forms: the
     8 / 16 -> 16 channel 3x3x3 convolutions (conv_c16b.hip | conv_c16.hip) and the 8-output-channel x-pair layers
     (conv_xb.hip | conv_xw.hip; use_xb switches those alone).  Default on since
     every full-size oracle fixture passes with it at the unchanged 1e-3 bar and its per-layer error against a float64
@@ -553,7 +554,7 @@ def use_bf16x3(flag):
 
 
 def pack_conv_c16b(key, w_host, device):
-    """Packed bf16 pieces of a [3,3,3,Cin,16] kernel (Cin 8 or 16) for atvs_conv_c16b_f32; cached."""
+    """Packed fp16 pieces of a [3,3,3,Cin,16] kernel (Cin 8 or 16) for atvs_conv_c16b_f32; cached."""
     import numpy as np
     ck = ('c16b', key, str(device))
     pk = _pack_cache.get(ck)
@@ -582,7 +583,7 @@ _USE_C16 = True
 
 
 def pack_conv3d_b(key, w_host, device, kind='b'):
-    """Packed bf16 pieces of a [3,3,3,Cin,Cout] kernel (Cin % 16 == 0, Cout 32 / 64) for atvs_conv3d_b_f32 (kind 'b') or the
+    """Packed fp16 pieces of a [3,3,3,Cin,Cout] kernel (Cin % 16 == 0, Cout 32 / 64) for atvs_conv3d_b_f32 (kind 'b') or the
     stride-2 atvs_conv3d_s2b_f32 (kind 's2b'); cached."""
     import numpy as np
     ck = ('c3' + kind, key, str(device))
@@ -771,7 +772,7 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
         rc = getattr(lib, 'atvs_conv1x1%s_pack_size' % kind)(cin, cout, ctypes.byref(pf))
         if rc:
             raise RuntimeError('atvs_conv1x1%s_pack_size failed (%d) for Cin=%d Cout=%d' % (kind, rc, cin, cout))
-        packed = np.empty(pf.value, np.uint8 if kind else np.float32)       # split kernel: bytes of bf16 pieces
+        packed = np.empty(pf.value, np.uint8 if kind else np.float32)       # split kernel: bytes of fp16 pieces
         rc = getattr(lib, 'atvs_conv1x1%s_pack' % kind)(w.ctypes.data_as(ctypes.c_void_p), cin, cout,
                                                         packed.ctypes.data_as(ctypes.c_void_p))
         if rc:

@@ -492,8 +492,8 @@ def test_cost_volume_in_pieces_is_bitwise_the_planar_one(cuda, B, D, h, w, F):
 @pytest.mark.parametrize('cin', [16, 8])
 @pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 37), (2, 5, 8, 12)])
 def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W, cin):
-    """Split-bf16 form of the 8 / 16 -> 16 channel convolution (conv_c16b.hip: three bf16 pieces per operand, six
-    products, fp32 accumulation on v_mfma_f32_16x16x32_bf16) against the oracle at the UNCHANGED fp32 bar (2e-5 of the
+    """Split-operand form of the 8 / 16 -> 16 channel convolution (conv_c16b.hip: two fp16 pieces per operand, three
+    products, fp32 accumulation on v_mfma_f32_16x16x32_f16) against the oracle at the UNCHANGED fp32 bar (2e-5 of the
     maximum), and no further from a float64 evaluation than the fp32 MFMA kernel is (x 2): bias + ReLU into a channel
     slice, statistics, ragged sizes, per-sample groups equal to single launches bit for bit."""
     from atvsnet_amd import ops

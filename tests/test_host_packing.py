@@ -1,6 +1,6 @@
 """Host functions of the split-operand kernels (no GPU): the weight packers of include/atvsnet_hip.h that arrange a TF kernel as
-two fp16 pieces per weight (w = g0 + g1 / 2048; the transposed convolution: three bf16 pieces) in the lane order of
-v_mfma_f32_16x16x32_{f16,bf16}, their size queries, and the argument checks the launch entry points make before they touch the
+two fp16 pieces per weight (w = g0 + g1 / 2048) in the lane order of
+v_mfma_f32_16x16x32_f16, their size queries, and the argument checks the launch entry points make before they touch the
 HIP runtime."""
 import ctypes
 
