@@ -111,14 +111,17 @@ __global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
   // this lane's fragment (channels 8 q .. of pixel r of a 16-pixel tile); tiles are 1024 bytes apart
   const int fb = c1b_swz(r * 64 + q * 16) + wr * TYW * 1024;
 
-  // packed weight pieces: [chunk][NT tiles][3 pieces][64 lanes] bf16x8, one zero chunk at the end
+  // packed weight pieces: [chunk][NT tiles][2 pieces][64 lanes] f16x8, one zero chunk at the end
   const f16x8* __restrict__ wl = p.wp + (size_t)(wn * NTW) * C1B_NP * 64 + lane;
   constexpr int WSTEP = NT * C1B_NP * 64;
-  f16x8 Aw[2][NTW][C1B_NP];
+  // g0 fragments double-buffered (both phases of a chunk read them; the next chunk's are requested in the first phase), g1
+  // fragments single (read in the first phase only; the next chunk's are requested behind it into the same registers)
+  f16x8 Aw0[2][NTW], Aw1[NTW];
 #pragma unroll
-  for (int n = 0; n < NTW; ++n)
-#pragma unroll
-    for (int w3 = 0; w3 < C1B_NP; ++w3) Aw[0][n][w3] = wl[(n * C1B_NP + w3) * 64];
+  for (int n = 0; n < NTW; ++n) {
+    Aw0[0][n] = wl[(n * C1B_NP + 0) * 64];
+    Aw1[n] = wl[(n * C1B_NP + 1) * 64];
+  }
 
   f32x4 acc[TYW][NTW], accx[TYW][NTW];  // h0 g0 | (h0 g1 + h1 g0) * 2^11
 #pragma unroll
@@ -145,9 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
     for (int pc = 0; pc < C1B_NP; ++pc) {
       if (pc == 0) {
 #pragma unroll
-        for (int n = 0; n < NTW; ++n)
-#pragma unroll
-          for (int w3 = 0; w3 < C1B_NP; ++w3) Aw[par ^ 1][n][w3] = wl[(size_t)(ch + 1) * WSTEP + (n * C1B_NP + w3) * 64];
+        for (int n = 0; n < NTW; ++n) Aw0[par ^ 1][n] = wl[(size_t)(ch + 1) * WSTEP + (n * C1B_NP + 0) * 64];
       }
       if (pc + 1 < C1B_NP) request_b(pc + 1);
       if (more) {
@@ -160,13 +161,19 @@ __global__ __launch_bounds__(256, 2) void conv1x1_b_kernel(C1bArgs p) {
       for (int n = 0; n < NTW; ++n) {
         if (pc == 0) {
 #pragma unroll
-          for (int t = 0; t < TYW; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[par][n][0], Bq[pc & 1][t], acc[t][n], 0, 0, 0);
+          for (int t = 0; t < TYW; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw0[par][n], Bq[pc & 1][t], acc[t][n], 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < TYW; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[par][n][1], Bq[pc & 1][t], accx[t][n], 0, 0, 0);
+          for (int t = 0; t < TYW; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw1[n], Bq[pc & 1][t], accx[t][n], 0, 0, 0);
         } else {
 #pragma unroll
-          for (int t = 0; t < TYW; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[par][n][0], Bq[pc & 1][t], accx[t][n], 0, 0, 0);
+          for (int t = 0; t < TYW; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw0[par][n], Bq[pc & 1][t], accx[t][n], 0, 0, 0);
         }
+      }
+      if (pc == 0) {                          // behind the MFMAs that read Aw1: the next chunk's g1 fragments
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NTW; ++n) Aw1[n] = wl[(size_t)(ch + 1) * WSTEP + (n * C1B_NP + 1) * 64];
       }
     }
     if (more) {
