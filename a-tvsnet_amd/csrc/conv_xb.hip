@@ -401,7 +401,9 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
       }
       return P;
     };
-    const float lo_a = has_a ? floor_a : -__builtin_huge_valf(), lo_b = has_b ? floor_b : -__builtin_huge_valf();
+    // (canonical once: fmaxf below then needs no per-use quieting of its bound)
+    const float lo_a = __builtin_canonicalizef(has_a ? floor_a : -__builtin_huge_valf()),
+                lo_b = __builtin_canonicalizef(has_b ? floor_b : -__builtin_huge_valf());
     auto bn1 = [&](float v, float m, float sc, float be, float lo) __attribute__((always_inline)) {
       return fmaxf((v - m) * sc + be, lo);               // bn_apply's arithmetic (norm.hip): sub, mul, add -- no contraction
     };
@@ -409,7 +411,6 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
     auto stage_slot = [&](int i, const Par& P, unsigned vmask, int ib) __attribute__((always_inline)) {
       float4 v = make_float4(pf[i][0], pf[i][1], pf[i][2], pf[i][3]);
       if (PRO >= 1) {
-        const bool ok = !((vmask >> i) & 1u);
         v.x = bn1(v.x, P.ma.x, P.sa.x, P.ba.x, lo_a); v.y = bn1(v.y, P.ma.y, P.sa.y, P.ba.y, lo_a);
         v.z = bn1(v.z, P.ma.z, P.sa.z, P.ba.z, lo_a); v.w = bn1(v.w, P.ma.w, P.sa.w, P.ba.w, lo_a);
         if (PRO == 2) {
@@ -417,12 +418,17 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
           v.x += bn1(u.x, P.mb.x, P.sb.x, P.bb.x, lo_b); v.y += bn1(u.y, P.mb.y, P.sb.y, P.bb.y, lo_b);
           v.z += bn1(u.z, P.mb.z, P.sb.z, P.bb.z, lo_b); v.w += bn1(u.w, P.mb.w, P.sb.w, P.bb.w, lo_b);
         }
-        v = make_float4(ok ? v.x : 0.f, ok ? v.y : 0.f, ok ? v.z : 0.f, ok ? v.w : 0.f);
       }
       if (i < MAXS - 1 || last_live) {
         uint2 p0, p1;
         atvs_split2_f16(v.x, v.y, XB_RS, &p0.x, &p1.x);
         atvs_split2_f16(v.z, v.w, XB_RS, &p0.y, &p1.y);
+        if (PRO >= 1) {
+          // a slot OUTSIDE the volume must stage zeros (the transform of the zeros the load returned is not zero): the four
+          // packed words are masked (pieces of 0 are 0) -- one bit-field extract + four ANDs instead of selects on the values
+          const unsigned keep = ~(unsigned)__builtin_amdgcn_sbfe(vmask, i, 1);
+          p0.x &= keep; p0.y &= keep; p1.x &= keep; p1.y &= keep;
+        }
         *reinterpret_cast<uint2*>(smem + ib + laddr[i]) = p0;
         *reinterpret_cast<uint2*>(smem + ib + XB_IMG + laddr[i]) = p1;
       }

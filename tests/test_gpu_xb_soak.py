@@ -3,6 +3,8 @@ fail deterministically -- it would read a register a little too early, sometimes
 few hundred times at full size (every tile of a 192 x 128 x 160 volume, 256 workgroups busy, memory latency as in the product)
 and demand that EVERY repetition is bitwise the first one, which itself is checked against the fp32 kernel of the same layer
 (different arithmetic: tolerance 2e-5 of the maximum)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -10,7 +12,7 @@ import torch
 pytestmark = pytest.mark.gpu
 
 D, H, W = 192, 128, 160
-REPS = 200
+REPS = int(os.environ.get('ATVS_SOAK_REPS', 200))
 
 
 def _wt(rng, cin, cout):
