@@ -8,6 +8,12 @@
 // consecutive output); the small source map (h x w x C) is gathered through L2.
 #include "common.h"
 
+// buffer_load_dwordx4 (offen).  hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 compiles to a ONE-dword load whose value is
+// splat over the four components (checked in the ISA), so the LLVM intrinsic is bound by name instead.
+typedef float geo_f32x4 __attribute__((ext_vector_type(4)));
+__device__ geo_f32x4 atvs_buffer_load_x4(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
+
 // ---------------------------------------------------------------------------
 // 3x3 helpers, fixed operation order (matches oracle mm3 / inv3)
 // ---------------------------------------------------------------------------
@@ -201,7 +207,10 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
       if (mask_out) mask_out[(size_t)d * npix + pix] = t.valid;
     }
     float4* g = reinterpret_cast<float4*>(s_geo + tid * 12);
-    g[0] = make_float4(__int_as_float(t.i00), __int_as_float(t.i01), __int_as_float(t.i10), __int_as_float(t.i11));
+    // the taps as BYTE offsets of the pixels in src (32 bits: checked by the host): the channel-group lanes of phase 2 then add
+    // their own constant and gather through a buffer descriptor -- one vector instruction per gather address instead of seven
+    const int pixb = C * 4;
+    g[0] = make_float4(__int_as_float(t.i00 * pixb), __int_as_float(t.i01 * pixb), __int_as_float(t.i10 * pixb), __int_as_float(t.i11 * pixb));
     g[1] = make_float4(t.wa, t.wb, t.wc, t.wd);
     g[2] = make_float4(t.valid, 0.f, 0.f, 0.f);
   }
@@ -218,14 +227,18 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
     lp = ((tid >> (cgs + 2)) << 2) | ((i >> 1) & 3);
     c = (((i >> 3) << 1) | (i & 1)) * 4;
   }
+  const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(src), 0, (int)(npix * C * 4), 0x00020000);
+  const int cb = c * 4;                  // this lane's channel group, in bytes
   for (int pass = 0; pass < cg; ++pass) {
     const int pl = pass * ppp + lp;
     const long pix = pix0 + pl;
     if (pix >= npix) break;              // pixels ascend with the pass
     const float4* g = reinterpret_cast<const float4*>(s_geo + pl * 12);
     const float4 gi = g[0], gw = g[1];
-    const float4 a = ld4(src + (size_t)__float_as_int(gi.x) * C + c), b = ld4(src + (size_t)__float_as_int(gi.y) * C + c);
-    const float4 cc = ld4(src + (size_t)__float_as_int(gi.z) * C + c), dd = ld4(src + (size_t)__float_as_int(gi.w) * C + c);
+    const geo_f32x4 ga = atvs_buffer_load_x4(srs, __float_as_int(gi.x) + cb, 0, 0), gb = atvs_buffer_load_x4(srs, __float_as_int(gi.y) + cb, 0, 0);
+    const geo_f32x4 gc = atvs_buffer_load_x4(srs, __float_as_int(gi.z) + cb, 0, 0), gd = atvs_buffer_load_x4(srs, __float_as_int(gi.w) + cb, 0, 0);
+    const float4 a = make_float4(ga[0], ga[1], ga[2], ga[3]), b = make_float4(gb[0], gb[1], gb[2], gb[3]);
+    const float4 cc = make_float4(gc[0], gc[1], gc[2], gc[3]), dd = make_float4(gd[0], gd[1], gd[2], gd[3]);
     // ((wa a + wb b) + wc c) + wd d per component, two components per instruction
     // scalar arithmetic on purpose (the same IEEE operations in the same order as blend4): packed fp32 instructions gave wrong
     // lane quarters beside another kernel's wavefronts on the SIMD
@@ -287,8 +300,8 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
   long lanes = (long)h * w * (mode == 2 ? 1 : (vec ? C / 4 : C));
   dim3 grid(cdiv(lanes, 256), D), block(256);
   hipStream_t s = as_stream(stream);
-  if (vec && mode < 2 && (C == 16 || C == 32 || C == 64)) {
-    // geometry once per pixel, shared by its channel-group lanes
+  if (vec && mode < 2 && (C == 16 || C == 32 || C == 64) && (double)h * w * C * 4.0 < 2147483648.0) {
+    // geometry once per pixel, shared by its channel-group lanes (31-bit byte offsets into src)
     dim3 g2(cdiv((long)h * w, 256), D);
     const long piece_bytes = (long)D * h * w * 16;
 #define SHARED(M, P)                                                                                                       \
