@@ -401,10 +401,10 @@ def write_error_xlsx(path, error, view_num):
 def check_finite(arr, what='depth map'):
     """The split-operand convolutions carry activations as two fp16 pieces: a value beyond +-65504 turns
     into inf/NaN there instead of a silently wrong depth.  The host drivers call this on every result they copy back so that
-    the failure names its cause (ATVS_BF16X3=0 selects the fp32 matrix-core kernels, which have fp32's range)."""
+    the failure names its cause (ATVS_SPLIT16=0 selects the fp32 matrix-core kernels, which have fp32's range)."""
     if not np.isfinite(arr).all():
         raise FloatingPointError('%s holds %d non-finite values: an activation or weight left the fp16 range of the split-operand '
-                                 'kernels (or the inputs were not finite); rerun with ATVS_BF16X3=0 for the fp32 kernels'
+                                 'kernels (or the inputs were not finite); rerun with ATVS_SPLIT16=0 for the fp32 kernels'
                                  % (what, int((~np.isfinite(arr)).sum())))
     return arr
 

@@ -314,7 +314,7 @@ class Network(object):
         under their names; the terminal becomes the concat."""
         (s_photo, n_photo), (s_geo, n_geo), (s_prob, n_prob), (s_hull, n_hull) = stems
         photo, geo, prob, hull = (self.layers[k] for k in (s_photo, s_geo, s_prob, s_hull))
-        fused = (self.training and filters == 8 and ops._USE_STEM and ops._FORCE_IMPL is None
+        fused = (self.training and filters == 8 and ops.cfg.stem and ops.cfg.force_impl is None
                  and isinstance(photo, ops.SplitVolume) and isinstance(geo, ops.SplitVolume)
                  and geo.var.shape[-1] == 2 and not isinstance(prob, (ops.SplitVolume, ops.PendingBN))
                  and not isinstance(hull, (ops.SplitVolume, ops.PendingBN)) and prob.dim() == 5 and hull.dim() == 5

@@ -17,6 +17,89 @@ from . import _lib
 _ERR = {-1: 'null pointer', -2: 'bad shape', -3: 'bad argument', -4: 'launch failed'}
 
 
+class Config(object):
+    """Every dispatch switch of this module in ONE object (`ops.cfg`).  The product never changes them: the defaults below
+    are what runs; tests and A/B measurements use `with ops.configure(name=value, ...):`, which restores the previous
+    values on exit (also on an exception).  Unknown names raise.
+
+    split16        the split-operand kernels (x = h0 + h1 / 2048 in fp16, three products on v_mfma_f32_16x16x32_f16, fp32
+                   accumulation) in front of their fp32-MFMA forms.  Setting it sets `xb` too.  ATVS_SPLIT16=0 in
+                   the environment: every convolution on the fp32 matrix cores.
+    split_off      kernel families (c16b, c3b, s2b, upb, c2b, c1b, btl) kept on the fp32 matrix cores while split16 is on
+    xb             the split-operand x-pair kernel (conv_xb.hip) in front of the fp32 one (conv_xw.hip)
+    planar         the warped half of the cost volume chunk-planar;  pieces: ... as fp16 pieces written by the warp
+    planar_concat  the refinement's 32-channel concat as four dense 8-channel planes
+    conv_c16, deconv_up, stem, conv2d_lds, conv1x1, xp1w, xpair, siblings, bottleneck
+                   the dedicated kernel of that layer family in front of the generic ones
+    prologue       normalise-on-load / add-on-load in the consumers (else pending batch norms / sums are materialised first)
+    force_impl     None (automatic) | 'tiled' | 'gather': the generic convolution kernel to use
+    fused_finalize batch-norm moments finished inside the convolution launch (measured slower: off)
+    side_streams   independent small launches of one layer on side streams (parallel branches of a captured graph)
+    """
+    _DEFAULTS = dict(
+        split16=os.environ.get('ATVS_SPLIT16', '1') == '1',
+        split_off=frozenset(v for v in os.environ.get('ATVS_SPLIT_OFF', '').split(',') if v),
+        xb=os.environ.get('ATVS_SPLIT16', '1') == '1',
+        planar=True,
+        pieces=os.environ.get('ATVS_PIECES', '1') == '1',
+        planar_concat=os.environ.get('ATVS_PLANAR_CONCAT', '1') != '0',
+        conv_c16=True, deconv_up=True, stem=True, conv2d_lds=True, conv1x1=True, xp1w=True, xpair=True, siblings=True,
+        bottleneck=os.environ.get('ATVS_BOTTLENECK', '1') != '0',
+        prologue=True, force_impl=None, fused_finalize=False, side_streams=True)
+
+    def __init__(self):
+        for k, v in self._DEFAULTS.items():
+            object.__setattr__(self, k, v)
+
+    def __setattr__(self, name, value):
+        if name not in self._DEFAULTS:
+            raise AttributeError('ops.cfg has no switch %r (known: %s)' % (name, ', '.join(sorted(self._DEFAULTS))))
+        if name == 'split_off':
+            value = frozenset(value)
+        elif name == 'force_impl':
+            if value not in (None, 'tiled', 'gather'):
+                raise ValueError('force_impl: None | "tiled" | "gather"')
+        else:
+            value = bool(value)
+        object.__setattr__(self, name, value)
+        if name == 'split16':
+            object.__setattr__(self, 'xb', value)
+
+    def snapshot(self):
+        return {k: getattr(self, k) for k in self._DEFAULTS}
+
+
+cfg = Config()
+
+
+class configure(object):
+    """`with ops.configure(split16=False, clear_pack_cache=True): ...` -- set switches of `ops.cfg` for the block and restore
+    them afterwards.  clear_pack_cache=True also drops the arranged-weight cache on entry and exit (for tests that reuse a
+    weight key under two kernel families)."""
+
+    def __init__(self, clear_pack_cache=False, **switches):
+        for k in switches:
+            if k not in Config._DEFAULTS:
+                raise AttributeError('ops.cfg has no switch %r' % k)
+        self._new, self._clear = switches, clear_pack_cache
+
+    def __enter__(self):
+        self._old = cfg.snapshot()
+        # split16 first: it drags xb along, an explicit xb= in the same call wins
+        for k in sorted(self._new, key=lambda n: n != 'split16'):
+            setattr(cfg, k, self._new[k])
+        if self._clear:
+            clear_pack_cache()
+        return cfg
+
+    def __exit__(self, *exc):
+        for k, v in self._old.items():
+            object.__setattr__(cfg, k, v)
+        if self._clear:
+            clear_pack_cache()
+        return False
+
+
 def _dev_ok(*ts):
     """True if the kernels must be launched, False for meta tensors.  Device tensors must live on the CURRENT
     device (torch.cuda.set_device / FLAGS.gpu_id): the launch goes to that device's current stream."""
@@ -50,14 +133,9 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-_SIDE_STREAMS = True
 _side_pool = {}
 
 
-def use_side_streams(flag):
-    """Testing / A-B hook: independent small launches of one layer on side streams (parallel branches of a captured graph)."""
-    global _SIDE_STREAMS
-    _SIDE_STREAMS = bool(flag)
 
 
 def _side_stream(device, i):
@@ -373,26 +451,15 @@ def pack_conv_weights_tiled(key, w_host, taps, transposed, device, tile_y, xpair
     return pk
 
 
-_USE_XB = os.environ.get('ATVS_BF16X3', '1') == '1'
-_USE_PLANAR = True
 
 
-def use_xb(flag):
-    """Testing / A-B hook: the split-operand form of the x-pair kernel (conv_xb.hip: two fp16 pieces per operand, three
-    products, fp32 accumulation) in front of the fp32 kernel (conv_xw.hip)."""
-    global _USE_XB
-    _USE_XB = bool(flag)
 
 
 def _xkind():
     """Which one-workgroup-per-CU x-pair kernel serves the 8-output-channel layers."""
-    return 'xb' if _USE_XB else 'xw'
+    return 'xb' if cfg.xb else 'xw'
 
 
-def use_planar(flag):
-    """Testing / A-B hook: the chunk-planar warped half of the cost volume (dense halo rows for conv_xw.hip)."""
-    global _USE_PLANAR
-    _USE_PLANAR = bool(flag)
 
 
 PLANAR_PAD = int(os.environ.get('ATVS_PLANAR_PAD', 4096 + 64))         # floats between chunk planes beyond D*h*w*8: 16.25 KiB, so that the C/8 write streams of the
@@ -409,18 +476,13 @@ def planar_view(buf, D, h, w):
     return buf[..., :D * h * w * 8].unflatten(-1, (D, h, w, 8))
 
 
-_USE_PIECES = os.environ.get('ATVS_PIECES', '1') == '1'
 
 
-def use_pieces(flag):
-    """Testing / A-B hook: the warped half of the cost volume as fp16 PIECES (the producer splits, conv_xb stages by LDS-DMA)."""
-    global _USE_PIECES
-    _USE_PIECES = bool(flag)
 
 
 def planar_pieces_ok(shape, F):
     """Should build_cost_volumes write the warped half as pieces?  Only the split-operand x-pair kernel reads them."""
-    return _USE_PIECES and _xkind() == 'xb' and planar_cost_volume_ok(shape, F)
+    return cfg.pieces and _xkind() == 'xb' and planar_cost_volume_ok(shape, F)
 
 
 def planar_pieces_decode(buf, D, h, w):
@@ -434,7 +496,7 @@ def planar_pieces_decode(buf, D, h, w):
 def planar_cost_volume_ok(shape, F):
     """Should build_cost_volumes write the warped half chunk-planar?  When its one consumer is an x-pair launch of
     conv_b0_0_1 | conv_b0_1_0 (both x-pair kernels read the layout)."""
-    return (_USE_PLANAR and F in (16, 32, 64) and siblings_ok(tuple(shape), F, 8, 16))
+    return (cfg.planar and F in (16, 32, 64) and siblings_ok(tuple(shape), F, 8, 16))
 
 
 def pack_conv_xp(key, w_host, device):
@@ -524,33 +586,18 @@ def pack_conv_c16(key, w_host, device):
     return pk
 
 
-_USE_BF16X3 = os.environ.get('ATVS_BF16X3', '1') == '1'      # ATVS_BF16X3=0: every convolution on the fp32 matrix cores
 
 
-_SPLIT_OFF = set(v for v in os.environ.get('ATVS_SPLIT_OFF', '').split(',') if v)
 
 
 def split_on(name):
-    """Is the split-bf16 kernel family `name` enabled?  (c16b, c3b, s2b, upb, c2b, c1b; `ops.split_off(...)` / ATVS_SPLIT_OFF=a,b
-    keep single families on the fp32 matrix cores -- testing / A-B hook; conv_xb has ops.use_xb.)"""
-    return _USE_BF16X3 and name not in _SPLIT_OFF
+    """Is the split-operand kernel family `name` enabled?  (c16b, c3b, s2b, upb, c2b, c1b, btl; `ops.configure(split_off=(...))` /
+    ATVS_SPLIT_OFF=a,b keep single families on the fp32 matrix cores -- testing / A-B hook; conv_xb has cfg.xb.)"""
+    return cfg.split16 and name not in cfg.split_off
 
 
-def split_off(*names):
-    """Testing / A-B hook: exactly these split-bf16 kernel families off (see split_on)."""
-    _SPLIT_OFF.clear()
-    _SPLIT_OFF.update(names)
 
 
-def use_bf16x3(flag):
-    """The split-operand kernels (x = h0 + h1 / 2048 in fp16, three products, fp32 accumulation; default -- the name is
-    round 3's, when the split was three bf16 pieces) or their fp32-MFMA forms: the
-    8 / 16 -> 16 channel 3x3x3 convolutions (conv_c16b.hip | conv_c16.hip) and the 8-output-channel x-pair layers
-    (conv_xb.hip | conv_xw.hip; use_xb switches those alone).  Default on since
-    every full-size oracle fixture passes with it at the unchanged 1e-3 bar and its per-layer error against a float64
-    evaluation equals the fp32 MFMA kernel's (tests/test_gpu_conv.py::test_conv_c16b_split_bf16_matches_oracle)."""
-    global _USE_BF16X3, _USE_XB
-    _USE_BF16X3 = _USE_XB = bool(flag)
 
 
 def pack_conv_c16b(key, w_host, device):
@@ -579,7 +626,6 @@ def pack_conv_c16b(key, w_host, device):
     return pk
 
 
-_USE_C16 = True
 
 
 def pack_conv3d_b(key, w_host, device, kind='b'):
@@ -609,23 +655,14 @@ def pack_conv3d_b(key, w_host, device, kind='b'):
     return pk
 
 
-def use_conv_c16(flag):
-    """Testing / A-B hook: the one-workgroup-per-CU kernel for 3x3x3 convolutions to 16 / 32 channels."""
-    global _USE_C16
-    _USE_C16 = bool(flag)
 
 
-_USE_DECONV_UP = True
 
 
-def use_deconv_up(flag):
-    """Testing / A-B hook: the one-workgroup-per-CU transposed-convolution kernel for Cout 8 / 16."""
-    global _USE_DECONV_UP
-    _USE_DECONV_UP = bool(flag)
 
 
 def deconv_up_ok(cin, cout):
-    return _USE_DECONV_UP and _FORCE_IMPL is None and cout in (8, 16) and cin % 16 == 0 and 0 < cin <= 64
+    return cfg.deconv_up and cfg.force_impl is None and cout in (8, 16) and cin % 16 == 0 and 0 < cin <= 64
 
 
 def pack_conv_xp_sibling(key, w_host, device):
@@ -663,24 +700,14 @@ def pack_conv_xp_sibling(key, w_host, device):
 
 def conv2d_lds_ok(cin, cout, dilation, H, W):
     """Is the LDS-tiled 2-D kernel (atvs_conv2d_lds_f32) used for a 3x3 stride-1 SAME convolution of this shape?"""
-    return (_FORCE_IMPL != 'gather' and _USE_CONV2D_LDS and H >= 8 and W >= 16
+    return (cfg.force_impl != 'gather' and cfg.conv2d_lds and H >= 8 and W >= 16
             and bool(_lib.lib().atvs_conv2d_lds_supported(int(cin), int(cout), int(dilation))))
 
 
-_USE_CONV2D_LDS = True
-_USE_STEM = True
 
 
-def use_stem(flag):
-    """Testing / A-B hook for the FMA kernel of the 1-2 channel refinement stems."""
-    global _USE_STEM
-    _USE_STEM = bool(flag)
 
 
-def use_conv2d_lds(flag):
-    """Testing / A-B hook for the LDS-tiled 2-D convolution of the feature towers."""
-    global _USE_CONV2D_LDS
-    _USE_CONV2D_LDS = bool(flag)
 
 
 def pack_conv2d_lds(key, w_host, device):
@@ -741,17 +768,12 @@ def conv2d_lds(x, key, w_host, dilation=1, bias=None, residual=None, relu=False,
 def conv1x1_ok(cin, cout):
     """Is a GEMM kernel (atvs_conv1x1_b_f32 / atvs_conv1x1_f32) used for a stride-1 1x1 convolution of these channel counts?"""
     lib = _lib.lib()
-    return (_FORCE_IMPL != 'gather' and _USE_CONV1X1 and
+    return (cfg.force_impl != 'gather' and cfg.conv1x1 and
             bool((split_on('c1b') and lib.atvs_conv1x1_b_supported(int(cin), int(cout))) or lib.atvs_conv1x1_supported(int(cin), int(cout))))
 
 
-_USE_CONV1X1 = True
 
 
-def use_conv1x1(flag):
-    """Testing / A-B hook for the 1x1 GEMM kernel of the feature towers."""
-    global _USE_CONV1X1
-    _USE_CONV1X1 = bool(flag)
 
 
 def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=False, out=None, y_coff=0, in_params=None,
@@ -841,23 +863,18 @@ def xp_blocks(D, H, W, groups=1):
     return int(_lib.lib().atvs_conv_xp_grid(int(D), int(H), int(W), int(groups)))
 
 
-_USE_XP1W = True
 
 
-def use_xp1w(flag):
-    """Testing / A-B hook: the one-workgroup-per-CU x-pair kernel for Cout == 8, Cin % 8 == 0."""
-    global _USE_XP1W
-    _USE_XP1W = bool(flag)
 
 
 def tiled_tile_y(H, W, cout):
     """tile_y for the LDS-tiled kernel, or 0 when the gather kernel should be used."""
-    if _FORCE_IMPL == 'gather':
+    if cfg.force_impl == 'gather':
         return 0
     nt = 1
     while nt * 16 < cout:
         nt *= 2
-    if W < 12 and _FORCE_IMPL != 'tiled':
+    if W < 12 and cfg.force_impl != 'tiled':
         return 0
     if nt <= 2 and H >= 16:
         return 8
@@ -866,26 +883,16 @@ def tiled_tile_y(H, W, cout):
     return 0
 
 
-_FORCE_IMPL = None
 
 
-def force_conv_impl(impl):
-    """Testing hook: 'tiled' | 'gather' | None (automatic)."""
-    global _FORCE_IMPL
-    _FORCE_IMPL = impl
 
 
 _fin_pool = {}
 # Measured on MI355X (cfg3 pipeline, HIP-graph replay): 51.4 ms/depth-map with the separate 5-us finalize
 # launches, 54.5 ms with the in-launch last-arriver finalize (the arrival drains every workgroup's output
 # stores and the reducing workgroup runs alone at the tail) -> off by default, kept and tested.
-_FUSED_FINALIZE = False
 
 
-def fused_finalize(flag):
-    """Testing / A-B hook: finish the batch-norm moments inside the convolution launch."""
-    global _FUSED_FINALIZE
-    _FUSED_FINALIZE = bool(flag)
 
 
 def _fin_counter(device):
@@ -963,13 +970,8 @@ def _xpair_virtual_kernel(key, w_host):
 
 XPAIR_TAPS = tuple(((kd * 3 + kh) * 4 + oi, kd - 1, kh - 1, oi - 1) for kd in range(3) for kh in range(3)
                    for oi in range(4))
-_USE_XPAIR = True
 
 
-def use_xpair(flag):
-    """Testing / A-B hook for the x-pair form of the Cout == 8 convolutions."""
-    global _USE_XPAIR
-    _USE_XPAIR = bool(flag)
 
 
 def clear_pack_cache():
@@ -1183,7 +1185,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
 
     # ---- 3-D, 3x3x3, 1-2 input channels -> 8: the refinement stems, HBM-bound FMA kernel
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) and cout == 8 \
-            and cin <= 2 and bias is None and residual is None and _USE_STEM and _FORCE_IMPL is None \
+            and cin <= 2 and bias is None and residual is None and cfg.stem and cfg.force_impl is None \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
         import numpy as np
         ck = ('stem', key, str(x.device))
@@ -1214,7 +1216,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     b3 = split_on('c3b') and cin % 16 == 0 and cout in (32, 64) and bool(_lib.lib().atvs_conv3d_b_supported(int(cin), int(cout)))
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
             and ((cout == 16 and cin in (8, 16, 32)) or (cout == 32 and cin in (16, 32, 48, 64)) or b3) \
-            and residual is None and plane_bias is None and _USE_C16 and _FORCE_IMPL is None \
+            and residual is None and plane_bias is None and cfg.conv_c16 and cfg.force_impl is None \
             and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
         b16 = split_on('c16b') and cin in (8, 16) and cout == 16
@@ -1244,7 +1246,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
 
     # ---- 3-D, 3x3x3, stride 2, SAME, 16 k -> 32 / 64 channels: the U-Net encoders below half resolution on split-bf16 operands
     if nsp == 3 and stride == 2 and dilation == 1 and ks == (3, 3, 3) and padding == 'SAME' and explicit_pad is None \
-            and split_on('s2b') and _USE_C16 and _FORCE_IMPL is None and residual is None and plane_bias is None \
+            and split_on('s2b') and cfg.conv_c16 and cfg.force_impl is None and residual is None and plane_bias is None \
             and bool(_lib.lib().atvs_conv3d_s2b_supported(int(cin), int(cout))) and outs[2] >= 8 \
             and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
@@ -1268,9 +1270,9 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
             and tuple(outs) == ins:
         tile_y = tiled_tile_y(ins[1], ins[2], cout)
-    xpair = bool(tile_y) and _USE_XPAIR and cout == 8 and (ins[2] >= 24 or _FORCE_IMPL == 'tiled') \
+    xpair = bool(tile_y) and cfg.xpair and cout == 8 and (ins[2] >= 24 or cfg.force_impl == 'tiled') \
         and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0))
-    xp1w = xpair and _USE_XP1W and cin % 8 == 0 and residual is None
+    xp1w = xpair and cfg.xp1w and cin % 8 == 0 and residual is None
     if xp1w:
         pk = pack_conv_xp(key, w_host, x.device)
     elif xpair:
@@ -1299,7 +1301,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         conv_xp_launch(x5, pk, y5, y_coff, bias, relu, sbuf, plane_bias)
     elif tile_y:
         fin = None
-        if want_stats and _FUSED_FINALIZE and pk.cout <= 64 and not x.is_meta and G == 1:
+        if want_stats and cfg.fused_finalize and pk.cout <= 64 and not x.is_meta and G == 1:
             fin = Fin()
             fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, pk.cout)), sbuf
             fin.rows, fin.arrivals, fin.channels, fin.fold, fin.count = blocks, blocks, pk.cout, 1, M
@@ -1433,28 +1435,22 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
                 groups=B)
 
 
-_USE_PLANAR_CONCAT = os.environ.get('ATVS_PLANAR_CONCAT', '1') != '0'
 
 
-def use_planar_concat(flag):
-    """Testing / A-B hook: the refinement's 32-channel concat as four dense 8-channel planes (chunk-planar) instead of
-    channel-last rows -- what its consumer, the x-pair launch of global_refine_3dconv0_1 | 1_0, stages per chunk."""
-    global _USE_PLANAR_CONCAT
-    _USE_PLANAR_CONCAT = bool(flag)
 
 
 def planar_concat_ok(shape):
     """(D,h,w): should CostVolRefineNet's concat be chunk-planar?  Only when both its producer (the photo stem) and its
     consumer run on the split-bf16 x-pair kernel, which writes / reads planes."""
     D, h, w = (int(v) for v in shape)
-    return (_USE_PLANAR_CONCAT and _USE_PLANAR and _xkind() == 'xb' and _USE_PROLOGUE and _FORCE_IMPL is None
+    return (cfg.planar_concat and cfg.planar and _xkind() == 'xb' and cfg.prologue and cfg.force_impl is None
             and siblings_ok((D, h, w), 32, 8, 16) and 4.0 * 4 * planar_stride(D, h, w) < 2.0 ** 40)
 
 
 def photo_pieces_ok(shape, chan):
     """(D,h,w), D-varying channels: should the refinement's photo volume be written as fp16 pieces?  When its one consumer is
     the photo stem on the split-operand x-pair kernel writing a plane of the chunk-planar concat (conv_split_into_plane)."""
-    return _USE_PIECES and chan in (16, 32, 64) and planar_concat_ok(shape)
+    return cfg.pieces and chan in (16, 32, 64) and planar_concat_ok(shape)
 
 
 def conv_split_into_plane(sv, key, w_host, buf, plane, planar):
@@ -1526,17 +1522,12 @@ def refine_stems(photo_raw, geo_var, geo_plane_bias, prob, hull, key, w_geo, w_p
 
 def siblings_ok(shape, cin, cout, cout2):
     """Can conv(8 channels, stride 1) and conv(16 channels, stride 2) of one (D,H,W,cin) input share a launch?"""
-    return (_USE_XP1W and _USE_XPAIR and _USE_SIBLINGS and _FORCE_IMPL != 'gather' and len(shape) == 3 and cout == 8
-            and cout2 == 16 and cin % 8 == 0 and (shape[2] >= 24 or _FORCE_IMPL == 'tiled'))
+    return (cfg.xp1w and cfg.xpair and cfg.siblings and cfg.force_impl != 'gather' and len(shape) == 3 and cout == 8
+            and cout2 == 16 and cin % 8 == 0 and (shape[2] >= 24 or cfg.force_impl == 'tiled'))
 
 
-_USE_SIBLINGS = True
 
 
-def use_siblings(flag):
-    """Testing / A-B hook for the fused stride-2 sibling of the x-pair kernel."""
-    global _USE_SIBLINGS
-    _USE_SIBLINGS = bool(flag)
 
 
 def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=None, groups=None, planar=False, pieces=False):
@@ -1664,7 +1655,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
                     _call('atvs_deconv_up_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
                           int(bool(relu)), _stream())
         return (y, st) if want_stats else y
-    if cout == 32 and _USE_DECONV_UP and split_on('upb') and _FORCE_IMPL is None and 32.0 * M * cout < 2.0 ** 32 \
+    if cout == 32 and cfg.deconv_up and split_on('upb') and cfg.force_impl is None and 32.0 * M * cout < 2.0 ** 32 \
             and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), 16)):
         # the 64 -> 32 layer (conv_b*_4_0) as two 16-channel launches of the split-bf16 kernel into the halves of y
         import numpy as np
@@ -1683,7 +1674,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
                           int(bool(relu)), 32, 16 * h, _stream())
         return (y, st) if want_stats else y
     classes = [(a, b, c) for a in (0, 1) for b in (0, 1) for c in (0, 1)]
-    fused = _FORCE_IMPL != 'gather' and cout % 4 == 0 and cout <= 64 and (W >= 12 or _FORCE_IMPL == 'tiled')
+    fused = cfg.force_impl != 'gather' and cout % 4 == 0 and cout <= 64 and (W >= 12 or cfg.force_impl == 'tiled')
     if fused:
         per = min(8, 128 // cout)                     # classes per launch (N <= 128 virtual channels)
         wv = _deconv_virtual_kernel(key, w_host)
@@ -1704,14 +1695,14 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
             st.partial, st.blocks, st.cpad, st.count, st.fold, st.groups = sall, blocks * nl, nt * 16, 8 * M, per, G
             sbufs = [_stats_buffer(x, blocks, nt * 16, groups=G) for _ in range(nl)] if (nl > 1 and G > 1) else None
         fin = None
-        if st is not None and _FUSED_FINALIZE and cout <= 64 and not x.is_meta and G == 1:
+        if st is not None and cfg.fused_finalize and cout <= 64 and not x.is_meta and G == 1:
             fin = Fin()
             fin.counter, fin.params, fin.stats = _fin_counter(x.device), _new(x, (3, cout)), st.partial
             fin.rows, fin.arrivals, fin.channels, fin.fold, fin.count = blocks * nl, blocks * nl, cout, per, 8 * M
             st.params = fin.params
         # the class groups are independent launches that each fill only part of the chip at the resolutions this path serves
         # (eighth resolution: 384 tiles): launches after the first go to side streams (parallel branches of a captured graph)
-        main = torch.cuda.current_stream() if (nl > 1 and _SIDE_STREAMS and x.is_cuda) else None
+        main = torch.cuda.current_stream() if (nl > 1 and cfg.side_streams and x.is_cuda) else None
         sides = []
         for i in range(nl):
             wpart = wv[:, :, i * per * cout:(i + 1) * per * cout]
@@ -1924,20 +1915,15 @@ class LazySlice(object):
 
 LAZY = (PendingBN, PendingSum, LazySlice)
 
-_USE_PROLOGUE = True
 
 
-def use_prologue(flag):
-    """Testing / A-B hook: normalise-on-load / add-on-load in the x-pair convolution (else the inputs are materialised)."""
-    global _USE_PROLOGUE
-    _USE_PROLOGUE = bool(flag)
 
 
 def siblings_prologue_ok(src):
     """Can conv_siblings take this lazy input as it is (the kernel forms it while staging)?  Built forms: one pending
     batch norm with Cin % 16 == 0 (the refinement's concat); a sum of two with Cin % 16 == 8 (the U-Net's stack inputs;
     Cin == 8 on the split-operand kernel)."""
-    if not _USE_PROLOGUE or _FORCE_IMPL is not None or not _USE_XP1W:
+    if not cfg.prologue or cfg.force_impl is not None or not cfg.xp1w:
         return False
     if isinstance(src, PendingBN):
         return src._final is None and src.shape[-1] % 16 == 0 and src.raw.is_contiguous()

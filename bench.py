@@ -41,10 +41,12 @@ against tests/golden/fullsize_cfg4.npz, and the same depth map on ONE rank measu
 speed-up and fraction-of-linear come from one run).
 
 One JSON line on rank 0.  `roofline` = the dominant kernel (conv_xb.hip: the 3x3x3 convolution of the 32 warped
-channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch): the 16-bit MFMA
-FLOPs the launch ISSUES / its duration (HIP events on its launch stream, >= 10 eager launches) against the dense bf16 / fp16
-MFMA peak (2.5 PF) -- the pipe it runs on; `fp32_equivalent` = the algorithmic fp32 convolution FLOPs against the fp32
-matrix peak, `mfma_busy` / `clock_GHz` from the committed PMC passes; `roofline_hbm` = the plane-sweep warp
+channels of conv_b0_0_1 at full resolution together with its stride-2 sibling conv_b0_1_0, one launch): its ALGORITHMIC
+convolution FLOPs / its duration (HIP events on its launch stream, >= 10 eager launches) against the dense bf16 /
+fp16 MFMA peak (2.5 PF) -- `frac` = `algorithmic_frac`; `emulation_ceiling_frac` = the same against peak / 3 (three products per
+fp32-accurate product); `mfma_pipe_utilisation` = the MFMA FLOPs the launch ISSUES against the peak (how busy the pipe is, not how
+much useful work it does); `fp32_equivalent` = the algorithmic FLOPs against the fp32 matrix peak, `mfma_busy` / `clock_GHz` from the
+committed PMC passes; `roofline_hbm` = the plane-sweep warp
 (warp_planes_shared_kernel) against the HBM peak, timed the same way; `kernels` = the top kernels of the committed
 rocprofv3 kernel trace of this command; `parity` = the output of the timed path against the oracle-generated
 fixture of this workload (tests/golden/fullsize_*.npz) and graph replay == eager bit for bit;
@@ -80,8 +82,18 @@ def _newest(*names):
     return os.path.join('profiles', names[-1])
 
 
-PMC_FILE = _newest('round4_pmc_xpair.json', 'round3_pmc_xpair.json')
-KERNEL_STATS_FILE = _newest('round4_bench_kernel_stats.csv', 'round3_bench_kernel_stats.csv')
+PMC_FILE = _newest('round5_pmc_xpair.json', 'round4_pmc_xpair.json', 'round3_pmc_xpair.json')
+KERNEL_STATS_FILE = _newest('round5_bench_kernel_stats.csv', 'round4_bench_kernel_stats.csv', 'round3_bench_kernel_stats.csv')
+
+
+def profile_head(path):
+    """The `git rev-parse HEAD` a committed profile was measured at (tools_dev/final_run.sh writes profiles/<name>.head next to
+    every summary it copies; None for the profiles of earlier rounds)."""
+    try:
+        with open(os.path.join(ROOT, os.path.splitext(path)[0] + '.head')) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
 EAGER_TIMING_PASSES = 10           # eager passes after the timed region: >= 10 event-timed launches of the dominant kernel
 
 
@@ -98,7 +110,8 @@ def parse(argv=None):
     p.add_argument('--no-cpu-baseline', action='store_true')
     p.add_argument('--no-power', action='store_true', help='skip the ~2 s socket-power / shader-clock probe after the timed region')
     p.add_argument('--no-parity', action='store_true')
-    p.add_argument('--no-split-bf16', action='store_true', help='skip the secondary measurement with the split-bf16 layers switched the other way')
+    p.add_argument('--no-fp32-path', '--no-split-bf16', dest='no_fp32_path', action='store_true',
+                   help='skip the secondary measurement of the same step with every convolution on the fp32 matrix cores')
     p.add_argument('--eager', action='store_true', help='issue every launch from Python instead of replaying a HIP graph')
     p.add_argument('--inflight', type=int, default=2,
                    help='depth maps in flight per GPU (streams with one captured graph each); 1 = strictly one after the other')
@@ -249,15 +262,17 @@ def launch(args, argv):
 
 def promote_view_sharded(line):
     """The north-star partition (BASELINE configs[3]: source views sharded one per GPU, exchange inside both AANets) next
-    to `value` at the top level of the N > 1 line, so that a SCALE record shows it and not only the replica mode."""
+    to `value` at the top level of the N > 1 line, so that a SCALE record shows it and not only the replica mode.  Every
+    promoted key carries the `view_sharded_cfg4_` / `view_sharded_` prefix: they belong to another mode and workload than `value`."""
     c4 = line.get('view_sharded_cfg4')
     if isinstance(c4, dict) and c4.get('ok'):
         line['view_sharded_cfg4_value'] = c4.get('value')
         line['view_sharded_cfg4_ms_per_step'] = c4.get('ms_per_step')
         line['view_sharded_cfg4_source_views_per_sec'] = c4.get('source_views_per_sec')
-        line['fraction_of_linear'] = c4.get('fraction_of_linear')
-        line['speedup_vs_single_gpu'] = c4.get('speedup_vs_single_gpu')
-        line['exchange'] = c4.get('exchange')
+        line['view_sharded_cfg4_fraction_of_linear'] = c4.get('fraction_of_linear')
+        line['view_sharded_cfg4_speedup_vs_single_gpu'] = c4.get('speedup_vs_single_gpu')
+        line['view_sharded_cfg4_exchange'] = c4.get('exchange')
+        line['view_sharded_cfg4_rccl_ranks'] = c4.get('rccl_ranks')
     vs = line.get('view_sharded')
     if isinstance(vs, dict) and vs.get('ok'):
         line['view_sharded_value'] = vs.get('value')
@@ -270,7 +285,8 @@ def view_sharded_entry(l2, err):
         return {'ok': False, 'error': err}
     out = {k: l2.get(k) for k in ('value', 'unit', 'ms_per_step', 'scaling', 'source_views_per_sec', 'exchange', 'parity')}
     out.update(ok=True, mode='views (source views of one depth map sharded inside a group, RCCL exchange in AAM1/AAM2)',
-               parallelism=l2['config']['parallelism'], groups=l2['config']['groups'])
+               parallelism=l2['config']['parallelism'], groups=l2['config']['groups'], rccl=l2['config'].get('rccl'),
+               rccl_ranks=l2['config'].get('rccl_ranks'))
     return out
 
 
@@ -287,7 +303,8 @@ def cfg4_entry(one, err1, shd, err2, n):
         return out
     out.update(ok=True, value=shd.get('value'), unit=shd.get('unit'), ms_per_step=shd.get('ms_per_step'),
                scaling='strong', source_views_per_sec=shd.get('source_views_per_sec'), exchange=shd.get('exchange'),
-               parity=shd.get('parity'), parallelism=shd['config']['parallelism'], groups=shd['config']['groups'])
+               parity=shd.get('parity'), parallelism=shd['config']['parallelism'], groups=shd['config']['groups'],
+               rccl=shd['config'].get('rccl'), rccl_ranks=shd['config'].get('rccl_ranks'))
     if one is not None and one.get('ms_per_step') and shd.get('ms_per_step'):
         speedup = one['ms_per_step'] / shd['ms_per_step']
         out['speedup_vs_single_gpu'] = round(speedup, 3)
@@ -308,8 +325,6 @@ def cpu_baseline(args):
     from atvsnet_amd import synthetic, variables
     from oracle import model as OM, nets
     ncpu = os.cpu_count() or 1
-    threads = min(ncpu, 32)      # oneDNN scales badly past a few dozen threads on these sizes
-    torch.set_num_threads(threads)
     W = {k: torch.from_numpy(v) for k, v in variables.default_store().host.items()}
     model_name = ''
     try:
@@ -321,6 +336,20 @@ def cpu_baseline(args):
     except OSError:
         pass
     t_all = time.time()
+    # how many threads: measured, not asserted -- a mid-size two-view scene (320x256, D=96: 1/8 of configs[1], ~1-2 s) once per
+    # candidate count, the fastest count runs everything below
+    sweep = {}
+    imgs, cams = synthetic.make_inputs(2, 256, 320, 96)
+    imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
+    for n in sorted({min(ncpu, c) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            OM.run_twoview(imgs, cams, W, 96) if not sweep else None      # first call also warms the allocator / oneDNN caches
+            t = time.time()
+            OM.run_twoview(imgs, cams, W, 96)
+            sweep[n] = round(time.time() - t, 3)
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     # configs[0]: full pipeline, 1 warm-up + 3 runs
     imgs, cams = synthetic.make_inputs(2, 128, 160, 32)
     imgs, cams = torch.from_numpy(imgs), torch.from_numpy(cams)
@@ -333,8 +362,10 @@ def cpu_baseline(args):
     cfg1 = float(np.median(runs[1:]))
     D = args.depths
     n_src = args.views - 1
-    base = {'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'port',
-            'kind_detail': 'restatement: the CPU oracle (torch-CPU / numpy restatement of the reference\'s TF-1.5 path, oracle/), '
+    base = {'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'restatement',
+            'thread_sweep_s': {str(k): v for k, v in sorted(sweep.items())},
+            'thread_sweep_sample': 'two-view 320x256, D=96 (1/8 of configs[1]) once per thread count; the fastest count is `cores`',
+            'kind_detail': 'restatement ("port" in the contract\'s vocabulary): the CPU oracle (torch-CPU / numpy restatement of the reference\'s TF-1.5 path, oracle/), '
                            'NOT TensorFlow and not a build of the reference -- TensorFlow 1.5 cannot be installed here',
             'host_cpus': ncpu, 'cpu_model': model_name,
             'configs0_s': round(cfg1, 3), 'configs0_runs_s': [round(r, 3) for r in runs]}
@@ -697,17 +728,16 @@ def rank_main(args):
         dt = float(t.item())
     out = out.clone()
 
-    # secondary: the same step with EVERY convolution on the fp32 matrix cores (ops.use_bf16x3(False)).  The default path runs
-    # its heavy layers on the 16-bit matrix cores with SPLIT operands (two fp16 pieces / three products since round 4):
-    # the 8 / 16 -> 16 channel 3x3x3 layers (AANet shared | unique, conv_b*_1_1, global_refine_3dconv1_1) on
-    # v_mfma_f32_16x16x32_bf16 with SPLIT operands -- x = x0 + x1 + x2, w = w0 + w1 + w2 in bf16 (24 mantissa bits kept),
-    # the 6 products with i + j <= 2, fp32 accumulation: fp32-class results (per-layer error against float64 equal to the fp32
-    # MFMA kernel's; BASELINE configs[1] names "bf16 conv3d MFMA") -- so the all-fp32-MFMA figure is printed next to it.
+    # secondary: the same step with EVERY convolution on the fp32 matrix cores (`ops.configure(split16=False)`).  The default path runs
+    # its heavy layers on v_mfma_f32_16x16x32_f16 with SPLIT operands: x = h0 + h1 / 2048, w = g0 + g1 / 2048 in fp16 (22
+    # significant bits), the three products h0 g0 + (h0 g1 + h1 g0) / 2048, fp32 accumulation: fp32-class results
+    # (per-layer error against float64 below the fp32 MFMA kernel's; BASELINE configs[1] names "bf16 conv3d MFMA") -- so the
+    # all-fp32-MFMA figure is printed next to it.
     split = None
-    if world == 1 and graphed is not None and not args.no_split_bf16:
+    if world == 1 and graphed is not None and not args.no_fp32_path:
         try:
-            default_on = ops._USE_BF16X3
-            ops.use_bf16x3(not default_on)
+            default_on = ops.cfg.split16
+            ops.cfg.split16 = not default_on
             g2 = ex.GraphedInference(imgs, cams, args.depths)
             for _ in range(args.warmup):
                 g2()
@@ -722,14 +752,14 @@ def rank_main(args):
                                'x = h0 + h1 / 2048, w = g0 + g1 / 2048 in fp16 (h1 = f16((x - h0) * 2048)), the 3 products '
                                'h0 g0 + (h0 g1 + h1 g0) / 2048, fp32 accumulation; the transposed convolutions (deconv_up_b.hip) likewise',
                      'in_value': bool(default_on),
-                     'other_path': 'every convolution on the fp32 matrix cores' if default_on else 'split-bf16 layers enabled',
+                     'other_path': 'every convolution on the fp32 matrix cores' if default_on else 'split-operand layers enabled',
                      'other_ms_per_step': round(1e3 * dt2 / args.steps, 3), 'other_value': round(args.steps / dt2, 4),
                      'unit': 'depth-maps/sec', 'other_parity': None if args.no_parity else parity_check(args, o2.clone(), None)}
             del g2
         except Exception as e:
             split = {'error': repr(e)}
         finally:
-            ops.use_bf16x3(default_on)
+            ops.cfg.split16 = default_on
 
     power = None
     if world == 1 and not args.no_power:
@@ -758,7 +788,7 @@ def rank_main(args):
         # conv_b0_0_1 (3x3x3, 64 -> 8, stride 1, SAME) and conv_b0_1_0 (3x3x3, 64 -> 16, stride 2, SAME) read the same
         # cost volume and run as ONE launch.  Their 32 D-constant input channels (the tiled reference features) are
         # per-plane biases, so the launch convolves the 32 warped channels: 2*27*32*8 FLOP per voxel + 2*27*32*16 FLOP
-        # per half-resolution voxel.  Without the sibling (ops.use_siblings(False)) only the first term applies.
+        # per half-resolution voxel.  Without the sibling (`ops.configure(siblings=False)`) only the first term applies.
         vox2 = ((args.depths + 1) // 2) * ((h + 1) // 2) * ((w + 1) // 2)
         sib = ops.siblings_ok((args.depths, h, w), 32, 8, 16)
         flops = 2.0 * 27 * 32 * 8 * vox + (2.0 * 27 * 32 * 16 * vox2 if sib else 0.0)
@@ -789,20 +819,31 @@ def rank_main(args):
                 sibf = (flops - main)
                 issued = main * 4.0 + sibf * 3.0 * 28.0 / 27.0
                 peak, pipe = PEAK_BF16_MFMA_TFLOPS, 'fp16'
-                conv = ('achieved = fp16 MFMA FLOPs the launch ISSUES (v_mfma_f32_16x16x32_f16 count x 16384; 4 per algorithmic '
+                conv = ('fp16 MFMA FLOPs the launch ISSUES (v_mfma_f32_16x16x32_f16 count x 16384; 4 per algorithmic '
                         'FLOP of the main convolution: three piece products x 4/3 x-pair rows; 3 x 28/27 for the sibling) / '
                         'time, against the dense fp16 / bf16 MFMA peak: the pipe the kernel runs on')
             else:
                 issued, peak, pipe = flops * 8.0 / 9.0, PEAK_F32_MFMA_TFLOPS, 'fp32'
-                conv = 'achieved = fp32 MFMA FLOPs issued (F(2,3): 2/3, x-pair rows: 4/3 of the algorithmic FLOPs) / time'
+                conv = 'fp32 MFMA FLOPs issued (F(2,3): 2/3, x-pair rows: 4/3 of the algorithmic FLOPs) / time'
             iss = issued / (avg_ms * 1e-3) / 1e12
+            # achieved = ALGORITHMIC convolution FLOPs of the launch / its duration, against the dense 16-bit MFMA
+            # peak of the pipe it runs on.  What the pipe is busy with (three piece products, x-pair zero rows) is NOT in
+            # `frac`: it is reported apart as `mfma_pipe_utilisation` (a kernel that issued redundant MFMAs would score higher
+            # there, never here).  `emulation_ceiling_frac`: against peak / 3 -- the most an fp32-accurate three-product scheme
+            # can reach on this pipe.
+            products = 3.0 if kind == 'xb' else 1.0
             roof = {'bound': 'mfma', 'pipe': pipe,
                     'kernel': '%s: conv_b0_0_1 (32 warped channels -> 8, 3x3x3, full resolution) + sibling conv_b0_1_0 '
                               '(-> 16, stride 2), %d volumes per launch' % (kdesc, int(samples)),
-                    'flops_convention': conv,
-                    'achieved': round(iss, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(iss / peak, 4),
-                    'issued_flops_per_launch': issued,
-                    'useful_frac': round(flops * (3.0 if kind == 'xb' else 1.0) / (avg_ms * 1e-3) / 1e12 / peak, 4),
+                    'flops_convention': 'achieved = algorithmic direct-convolution FLOPs of the launch (2*27*Cin*Cout per output voxel, '
+                                        'SURVEY 8d) / its duration from HIP events in this run; peak = dense fp16 / bf16 MFMA',
+                    'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                    'algorithmic_frac': round(ach / peak, 4),
+                    'emulation_ceiling_frac': round(ach * products / peak, 4),
+                    'emulation_ceiling_TFLOPs': round(peak / products, 1),
+                    'mfma_pipe_utilisation': {'achieved': round(iss, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(iss / peak, 4),
+                                              'issued_flops_per_launch': issued, 'convention': conv,
+                                              'note': 'ISSUED MFMA work, not useful work: a utilisation of the pipe, not a roofline fraction'},
                     'fp32_equivalent': fp32_eq,
                     'mfma_busy': pmc.get('mfma_busy') if pmc else None,
                     'clock_GHz': pmc.get('clock_GHz') if pmc else None,
@@ -856,7 +897,7 @@ def rank_main(args):
                           'the residual piece scaled into the normal range) '
                           'and form 3 products with the cross terms accumulated apart: fp32-class (per-layer error against float64 '
                           'below the fp32 matrix cores\'), same parity bar; the other layers use fp32 MFMA operands; see '
-                          '`split_operands` for the all-fp32-MFMA figure') if ops._USE_BF16X3 else 'fp32 MFMA operands, fp32 accumulation',
+                          '`split_operands` for the all-fp32-MFMA figure') if ops.cfg.split16 else 'fp32 MFMA operands, fp32 accumulation',
             'config': {'workload': '%d depth map(s) per step: %d views (1 ref + %d src) %dx%d, D=%d, example.py %s pipeline'
                                    % (n_groups, args.views, args.views - 1, args.width, args.height, args.depths,
                                       'two-view' if twoview else 'multi-view'),
@@ -864,6 +905,8 @@ def rank_main(args):
                        'feature_hw': [h, w], 'voxels': vox, 'parallelism': par, 'world_size': world,
                        'groups': groups if world > 1 else None,
                        'rccl': '.'.join(str(v) for v in torch.cuda.nccl.version()) if world > 1 else None,
+                       # ranks of the communicator the DATA PATH uses: 0 in maps mode (no data-path collective)
+                       'rccl_ranks': gsize if sharded else 0,
                        'launch': 'eager' if graphed is None else ('HIP graph replay, batched per-view networks' if not sharded else
                                                                    'HIP graphs between the exchanges'),
                        'inflight': 1},

@@ -248,7 +248,7 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
  * cnn_wrapper/network.py:165-215), Cin % 8 == 0.  x-pair form (two x-adjacent voxels fill the 16 MFMA rows),
  * ONE workgroup per CU with the whole register file and LDS.  Two kernels share the contract: conv_xb.hip (split fp16
  * operands on the 16-bit matrix cores: the product's kernel) and conv_xw.hip (fp32 matrix cores, Winograd F(2,3) along y:
- * the A/B form, ops.use_bf16x3(False)).
+ * the A/B form, ops.configure(split16=False)).
  *   atvs_conv_x{w,b}_pack_size / _pack  HOST: pack the TF kernel [3,3,3,Cin,8] (upload the result)
  *   atvs_conv_xp_grid                   workgroups of a launch PER SAMPLE = rows of stats_partial per sample ([2][16] doubles
  *                                       each, columns 0..7 = channels, the layout atvs_bn_finalize takes with cpad 16)

@@ -8,8 +8,10 @@ configurations on the seeded synthetic inputs and weights (the same ones bench.p
     cfg3    5 views 640x512, D=192, multi-view     (BASELINE configs[2], the metric's configuration)
     cfg4    9 views 928x480, D=256, multi-view     (BASELINE configs[3]: 8 sources)
     cfg5    two-view 1600x1184, D=256              (BASELINE configs[4])
-    cfg5f64 the float64-network evaluation of cfg5: NOT generated -- it needs more than the 62 GB of the build container
-            (killed by the kernel), and a run on a GPU box's host took that box down; see cfg5h
+    cfg5f64 the float64-network evaluation of cfg5.  The plain oracle call keeps both 15.5 GB float64 cost volumes and every
+            U-Net layer alive at once (more than the 62 GB of the build container: killed by the kernel); `twoview_f64(lean=True)`
+            evaluates the SAME graph with the oracle's own layer functions but builds each cost volume in place and drops every
+            volume after its last consumer (checked bit-for-bit against the plain call on a small scene before the big run)
     cfg5h   configs[4] at HALF the image size: two-view 800x576 (the network needs multiples of 32), D=256, the same camera model (synthetic.make_inputs)
     cfg5hf64 its float64-network evaluation: the noise floor of the configs[4]-shaped case (D=256, two-view, wide
             images) that fits this container -- the HIP path is asserted to be no further from it than 1.5 x the float32
@@ -69,9 +71,90 @@ def twoview(name):
             'filtered_cost_mid': S['filtered_cost_volume'][0, mid].numpy()}
 
 
-def twoview_f64(name):
+def lean_cost_volume(ref_feature, view_feature, cams, depth_num, depth_start, depth_interval, ref_id, view_id):
+    """oracle.model.build_cost_volume written into ONE preallocated tensor (no list of planes + stack + cat)."""
+    H = G.get_homographies(cams[:, ref_id], cams[:, view_id], depth_num, depth_start, depth_interval)
+    B, h, w, F = ref_feature.shape
+    cv = torch.empty((B, depth_num, h, w, 2 * F), dtype=ref_feature.dtype)
+    cv[..., :F] = ref_feature.unsqueeze(1)
+    for d in range(depth_num):
+        cv[:, d, :, :, F:] = G.homography_warping(view_feature, H[:, d])
+    return cv
+
+
+def lean_stacked_unet_prob(box, W):
+    """oracle.nets.stacked_unet_prob (cnn_wrapper/atvsnet.py:100-192) with the same layer functions in the same order;
+    `box` = [cost volume] is emptied after the volume's two consumers and every layer is dropped after its last use."""
+    from oracle import nets
+    bf = 8
+    L = {}
+    for b in range(3):
+        p = 'conv_b%d_' % b
+        if b == 0:
+            inp = box.pop()
+        else:
+            q = 'conv_b%d_' % (b - 1)
+            inp = L.pop(q + '6_0') + L.pop(q + '0_1')
+        L[p + '1_0'] = nets.conv_bn(inp, W, p + '1_0', bf * 2, 2)
+        L[p + '0_1'] = nets.conv_bn(inp, W, p + '0_1', bf, 1)
+        del inp
+        L[p + '2_0'] = nets.conv_bn(L[p + '1_0'], W, p + '2_0', bf * 4, 2)
+        L[p + '3_0'] = nets.conv_bn(L[p + '2_0'], W, p + '3_0', bf * 8, 2)
+        if b == 0:
+            i11, i21 = L.pop(p + '1_0'), L.pop(p + '2_0')
+        else:
+            i11 = L.pop(p + '1_0') + L.pop(q + '5_0')
+            i21 = L.pop(p + '2_0') + L.pop(q + '4_0')
+        L[p + '1_1'] = nets.conv_bn(i11, W, p + '1_1', bf * 2, 1)
+        L[p + '2_1'] = nets.conv_bn(i21, W, p + '2_1', bf * 4, 1)
+        del i11, i21
+        L[p + '3_1'] = nets.conv_bn(L.pop(p + '3_0'), W, p + '3_1', bf * 8, 1)
+        L[p + '4_0'] = nets.deconv_bn(L.pop(p + '3_1'), W, p + '4_0', bf * 4)
+        if b == 0:
+            i50 = L[p + '4_0'] + L[p + '2_1']
+        else:
+            i50 = L[p + '4_0'] + L.pop(p + '2_1') + L['conv_b0_2_1']
+        L[p + '5_0'] = nets.deconv_bn(i50, W, p + '5_0', bf * 2)
+        del i50
+        if b == 0:
+            i60 = L[p + '5_0'] + L[p + '1_1']
+        else:
+            i60 = L[p + '5_0'] + L.pop(p + '1_1') + L['conv_b0_1_1']
+        L[p + '6_0'] = nets.deconv_bn(i60, W, p + '6_0', bf)
+        del i60
+    c61 = L.pop('conv_b2_6_0') + L.pop('conv_b2_0_1')
+    L.clear()
+    return nets.conv(c61, W, 'conv_b2_6_2', 1, 1, relu=False), c61
+
+
+def lean_run_twoview(images, cams, W, max_d):
+    """oracle.model.run_twoview / TVSNet (model.py:346-377, example.py:219-272) with nothing kept beyond its last use."""
+    from oracle import nets
+    ds, di = OM.depth_start_interval(cams)
+    ref_f = nets.resnet_ds2_spp(images[:, 0], W)
+    view_f = nets.resnet_ds2_spp(images[:, 1], W)
+    box = [lean_cost_volume(view_f, ref_f, cams, max_d, ds, di, 1, 0)]
+    pv_view, _ = lean_stacked_unet_prob(box, W)
+    depth_view = OM.prob2depth(pv_view.squeeze(-1), max_d, ds, di)
+    del pv_view, _
+    box = [lean_cost_volume(ref_f, view_f, cams, max_d, ds, di, 0, 1)]
+    del ref_f, view_f
+    pv_b2, filt = lean_stacked_unet_prob(box, W)
+    del filt
+    pv_b2 = pv_b2.squeeze(-1)
+    depth_b2 = OM.prob2depth(pv_b2, max_d, ds, di)
+    init = torch.stack([depth_b2, depth_view], 1)
+    _, prob_res = OM.refinement(init, cams, max_d, ds, di, images, pv_b2, W, ref_id=0, view_id=1, num_depths=2,
+                                depth_ref_id=0, depth_view_id=1)
+    refined = pv_b2 + prob_res
+    del pv_b2, prob_res
+    _, depth_refined = OM.prob2depth_upsample(refined, max_d, ds, di)
+    return depth_refined
+
+
+def twoview_f64(name, lean=False, scene=None):
     """The float64-network evaluation (see tests/golden/make_truth64_golden.py for the idea)."""
-    imgs, cams, D = inputs(name)
+    imgs, cams, D = scene if scene is not None else inputs(name)
     W64 = {k: v.double() for k, v in weights().items()}
 
     def f32_boundary(fn):
@@ -116,7 +199,7 @@ def twoview_f64(name):
     orig_linspace = T.linspace
     T.linspace = lambda a, b, n: orig_linspace(float(a), float(b), n).double()
     try:
-        d64 = OM.run_twoview(imgs.double(), cams, W64, D)
+        d64 = (lean_run_twoview if lean else OM.run_twoview)(imgs.double(), cams, W64, D)
     finally:
         for fn, f in saved.items():
             setattr(G, fn, f)
@@ -141,7 +224,15 @@ def main(argv):
     for name in argv:
         t0 = time.time()
         with torch.no_grad():
-            if name.endswith('f64'):
+            if name == 'cfg5f64':
+                # the lean evaluation is the plain one, bit for bit (a small scene), before it is trusted at full size
+                im, cm = synthetic.make_inputs(2, 128, 160, 32, seed=0)
+                small = (torch.from_numpy(im), torch.from_numpy(cm), 32)
+                a, b = twoview_f64(None, False, small)['depth64'], twoview_f64(None, True, small)['depth64']
+                assert np.array_equal(a, b), 'lean float64 evaluation differs from the plain one'
+                out = twoview_f64('cfg5', lean=True)
+                out['lean_equals_plain_on_160x128x32'] = np.bool_(True)
+            elif name.endswith('f64'):
                 out = twoview_f64(name[:-3])
             elif CONFIGS[name][0] == 2:
                 out = twoview(name)

@@ -98,7 +98,8 @@ def _fake_launch(monkeypatch, capsys, secondary_ok):
         ms = (96.0 if n == 1 else 20.0) if cfg4 else 14.0
         return json.dumps({'value': 1e3 / ms, 'unit': 'depth-maps/sec', 'ms_per_step': ms, 'scaling': 'strong',
                            'source_views_per_sec': 8e3 / ms, 'exchange': {'graph_ms': ms - 3.0, 'comm_ms': 3.0},
-                           'parity': {'ok': True}, 'config': {'parallelism': 'p', 'groups': [list(range(n))]}}) + '\n', [0] * n
+                           'parity': {'ok': True}, 'config': {'parallelism': 'p', 'groups': [list(range(n))], 'rccl': '2.26.6',
+                                                              'rccl_ranks': n}}) + '\n', [0] * n
 
     monkeypatch.setattr(bench, '_run_ranks', fake_run_ranks)
     monkeypatch.setattr(bench, 'visible_gpus', lambda *a, **k: 8)
@@ -118,7 +119,7 @@ def test_launcher_exits_3_when_the_view_sharded_path_breaks(monkeypatch, capsys)
     assert set(line['failed']) == {'view_sharded', 'view_sharded_cfg4'}
     assert line['view_sharded']['ok'] is False and 'ranks returned' in line['view_sharded']['error']
     assert line['view_sharded_cfg4']['ok'] is False
-    assert 'FAILED' in err and 'fraction_of_linear' not in line
+    assert 'FAILED' in err and not any('fraction_of_linear' in k for k in line)
 
 
 def test_launcher_promotes_the_view_sharded_numbers(monkeypatch, capsys):
@@ -128,8 +129,11 @@ def test_launcher_promotes_the_view_sharded_numbers(monkeypatch, capsys):
     assert rc == 0 and 'ok' not in line or line.get('ok', True)
     assert line['value'] == 280.0
     assert line['view_sharded_cfg4_value'] == 50.0 and line['view_sharded_cfg4_ms_per_step'] == 20.0
-    assert line['speedup_vs_single_gpu'] == 4.8 and line['fraction_of_linear'] == 0.6
-    assert line['exchange'] == {'graph_ms': 17.0, 'comm_ms': 3.0}
+    # promoted keys are prefixed: they belong to another mode / workload than `value`
+    assert line['view_sharded_cfg4_speedup_vs_single_gpu'] == 4.8 and line['view_sharded_cfg4_fraction_of_linear'] == 0.6
+    assert line['view_sharded_cfg4_exchange'] == {'graph_ms': 17.0, 'comm_ms': 3.0}
+    assert line['view_sharded_cfg4_rccl_ranks'] == 8
+    assert not {'fraction_of_linear', 'speedup_vs_single_gpu', 'exchange'} & set(line)
     assert line['view_sharded_cfg4_source_views_per_sec'] == 400.0
     assert abs(line['view_sharded_value'] - 1e3 / 14.0) < 1e-9
     # the three secondary runs: views at N, cfg4 on one rank, cfg4 view-sharded at N

@@ -44,11 +44,8 @@ CONV3D = [
 @pytest.fixture(params=['gather', 'tiled', None])
 def impl(request):
     from atvsnet_amd import ops
-    ops.force_conv_impl(request.param)
-    ops.clear_pack_cache()
-    yield request.param
-    ops.force_conv_impl(None)
-    ops.clear_pack_cache()
+    with ops.configure(force_impl=request.param, clear_pack_cache=True):
+        yield request.param
 
 
 @pytest.mark.parametrize('D,H,W,Cin,Cout,stride', CONV3D + [(9, 17, 35, 64, 8, 1), (5, 20, 40, 48, 8, 1),
@@ -285,10 +282,7 @@ def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
     straddles the end), 16- and 8-channel chunks, with depth-plane bias + bias + residual + ReLU, written into a
     channel slice of a wider (concat) buffer, statistics of what was written."""
     from atvsnet_amd import ops
-    ops.use_xp1w(bool(xp1w))
-    ops.use_xb(xp1w == 'xb')
-    ops.clear_pack_cache()
-    try:
+    with ops.configure(xp1w=bool(xp1w), xb=xp1w == 'xb', clear_pack_cache=True):
         x = _rand((1, D, H, W, Cin), 50)
         w = _rand((3, 3, 3, Cin, 8), 51, 0.2)
         b = _rand((8,), 52)
@@ -313,10 +307,6 @@ def test_conv_xpair_kernels(cuda, xp1w, D, H, W, Cin):
         got2 = ops.conv(x[0].to(cuda), ('xp', D, H, W, Cin), w.numpy(), bias=b.to(cuda), residual=res.to(cuda),
                         plane_bias=pb.to(cuda))
         _close(got2.cpu(), want + res)
-    finally:
-        ops.use_xp1w(True)
-        ops.use_xb(True)
-        ops.clear_pack_cache()
 
 
 @pytest.fixture(params=['xb', 'xw'])
@@ -324,11 +314,8 @@ def xkernel(request):
     """Run a test on both one-workgroup-per-CU x-pair kernels: conv_xb.hip (split fp16 operands, default) and conv_xw.hip
     (fp32 Winograd)."""
     from atvsnet_amd import ops
-    ops.use_xb(request.param == 'xb')
-    ops.clear_pack_cache()
-    yield request.param
-    ops.use_xb(True)
-    ops.clear_pack_cache()
+    with ops.configure(xb=request.param == 'xb', clear_pack_cache=True):
+        yield request.param
 
 
 @pytest.mark.parametrize('D,H,W,Cin', [(8, 16, 64, 32), (9, 19, 70, 16), (6, 21, 45, 8), (5, 8, 33, 24), (4, 7, 32, 8)])
@@ -432,15 +419,10 @@ def test_planar_cost_volume_is_bitwise_the_channel_last_one(cuda, B, D, h, w):
     assert torch.equal(st.partial, rt.partial) and torch.equal(st2.partial, rt2.partial)
     assert torch.equal(sv_pl.materialize(), sv_cl.materialize())
     # the fp32 Winograd kernel reads the planar form too
-    try:
-        ops.use_xb(False)
-        ops.clear_pack_cache()
+    with ops.configure(xb=False, clear_pack_cache=True):
         (z, _), (z2, _) = ops.conv_split_siblings(sv_pl, 'pl8', w8, 'pl16', w16)
         (q, _), (q2, _) = ops.conv_split_siblings(sv_cl, 'pl8', w8, 'pl16', w16)
         assert torch.equal(z, q) and torch.equal(z2, q2)
-    finally:
-        ops.use_xb(True)
-        ops.clear_pack_cache()
 
 
 @pytest.mark.parametrize('B,D,h,w,F', [(1, 6, 16, 40, 32), (2, 9, 19, 70, 32), (1, 5, 9, 33, 16), (1, 4, 8, 32, 64)])
@@ -491,7 +473,7 @@ def test_cost_volume_in_pieces_is_bitwise_the_planar_one(cuda, B, D, h, w, F):
 
 @pytest.mark.parametrize('cin', [16, 8])
 @pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 37), (2, 5, 8, 12)])
-def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W, cin):
+def test_conv_c16b_split16_matches_oracle(cuda, G, D, H, W, cin):
     """Split-operand form of the 8 / 16 -> 16 channel convolution (conv_c16b.hip: two fp16 pieces per operand, three
     products, fp32 accumulation on v_mfma_f32_16x16x32_f16) against the oracle at the UNCHANGED fp32 bar (2e-5 of the
     maximum), and no further from a float64 evaluation than the fp32 MFMA kernel is (x 2): bias + ReLU into a channel
@@ -502,12 +484,9 @@ def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W, cin):
     b = _rand((16,), 72)
     want = torch.clamp(T.conv(x, w, 1, 'SAME', bias=b), min=0)
     ref64 = torch.clamp(T.conv(x.double(), w.double(), 1, 'SAME', bias=b.double()), min=0)
-    ops.clear_pack_cache()
-    try:
-        outs = {}
-        for flag in (False, True):
-            ops.use_bf16x3(flag)
-            ops.clear_pack_cache()
+    outs = {}
+    for flag in (False, True):
+        with ops.configure(split16=flag, clear_pack_cache=True):
             buf = torch.full((G, D, H, W, 24), -3.0, device=cuda)
             got, st = ops.conv(x.to(cuda), ('c16b', G, D, H, W, cin), w.numpy(), bias=b.to(cuda), relu=True, want_stats=True,
                                out=buf, y_coff=4, groups=G)
@@ -522,18 +501,15 @@ def test_conv_c16b_split_bf16_matches_oracle(cuda, G, D, H, W, cin):
             if flag:
                 one = ops.conv(x[1 % G].to(cuda), ('c16b', G, D, H, W, cin), w.numpy(), bias=b.to(cuda), relu=True)
                 assert torch.equal(one.cpu(), y[1 % G, ..., 4:20])
-        e32 = float((outs[False] - ref64).abs().max())
-        e16 = float((outs[True] - ref64).abs().max())
-        print('max abs error vs float64: fp32 MFMA %.3e, split bf16 %.3e' % (e32, e16))
-        assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
-    finally:
-        ops.use_bf16x3(True)             # the default
-        ops.clear_pack_cache()
+    e32 = float((outs[False] - ref64).abs().max())
+    e16 = float((outs[True] - ref64).abs().max())
+    print('max abs error vs float64: fp32 MFMA %.3e, split fp16 %.3e' % (e32, e16))
+    assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
 
 
 @pytest.mark.parametrize('cin,cout', [(32, 32), (64, 64), (16, 32), (48, 64)])
 @pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 21), (2, 5, 8, 12)])
-def test_conv3d_b_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cout):
+def test_conv3d_b_split16_matches_oracle(cuda, G, D, H, W, cin, cout):
     """Split-bf16 form of the 16 k -> 32 / 64 channel 3x3x3 convolutions (conv3d_b.hip: several 16-channel chunks, two or
     four output tiles per wavefront, weights streamed) against the oracle at the fp32 bar, and no further from a float64
     evaluation than the fp32 kernel the layer used before (x 2): bias + ReLU into a channel slice, statistics, ragged
@@ -544,11 +520,9 @@ def test_conv3d_b_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cout):
     b = _rand((cout,), 82)
     want = torch.clamp(T.conv(x, w, 1, 'SAME', bias=b), min=0)
     ref64 = torch.clamp(T.conv(x.double(), w.double(), 1, 'SAME', bias=b.double()), min=0)
-    try:
-        outs = {}
-        for flag in (False, True):
-            ops.use_bf16x3(flag)
-            ops.clear_pack_cache()
+    outs = {}
+    for flag in (False, True):
+        with ops.configure(split16=flag, clear_pack_cache=True):
             buf = torch.full((G, D, H, W, cout + 8), -3.0, device=cuda)
             got, st = ops.conv(x.to(cuda), ('c3b', G, D, H, W, cin, cout), w.numpy(), bias=b.to(cuda), relu=True,
                                want_stats=True, out=buf, y_coff=4, groups=G)
@@ -563,18 +537,15 @@ def test_conv3d_b_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cout):
             if flag:
                 one = ops.conv(x[1 % G].to(cuda), ('c3b', G, D, H, W, cin, cout), w.numpy(), bias=b.to(cuda), relu=True)
                 assert torch.equal(one.cpu(), y[1 % G, ..., 4:4 + cout])
-        e32 = float((outs[False] - ref64).abs().max())
-        e16 = float((outs[True] - ref64).abs().max())
-        print('max abs error vs float64: fp32 MFMA %.3e, split bf16 %.3e' % (e32, e16))
-        assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
-    finally:
-        ops.use_bf16x3(True)             # the default
-        ops.clear_pack_cache()
+    e32 = float((outs[False] - ref64).abs().max())
+    e16 = float((outs[True] - ref64).abs().max())
+    print('max abs error vs float64: fp32 MFMA %.3e, split fp16 %.3e' % (e32, e16))
+    assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
 
 
 @pytest.mark.parametrize('cin,cout', [(16, 32), (32, 64), (48, 32)])
 @pytest.mark.parametrize('G,D,H,W', [(1, 8, 16, 32), (3, 9, 19, 21), (2, 6, 8, 17), (1, 5, 7, 33)])
-def test_conv3d_s2b_stride2_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cout):
+def test_conv3d_s2b_stride2_split16_matches_oracle(cuda, G, D, H, W, cin, cout):
     """Split-bf16 stride-2 3x3x3 convolutions (conv3d_s2b.hip: even | odd de-interleaved halo rows, waves split z plane and
     output-channel half) against the oracle at the fp32 bar and against a float64 evaluation (no further than the gather kernel
     x 2): TF SAME padding for even and odd sizes on every axis, bias + ReLU into a channel slice, statistics, groups."""
@@ -585,11 +556,9 @@ def test_conv3d_s2b_stride2_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cou
     want = torch.clamp(T.conv(x, w, 2, 'SAME', bias=b), min=0)
     ref64 = torch.clamp(T.conv(x.double(), w.double(), 2, 'SAME', bias=b.double()), min=0)
     Do, Ho, Wo = want.shape[1:4]
-    try:
-        outs = {}
-        for flag in (False, True):
-            ops.use_bf16x3(flag)
-            ops.clear_pack_cache()
+    outs = {}
+    for flag in (False, True):
+        with ops.configure(split16=flag, clear_pack_cache=True):
             buf = torch.full((G, Do, Ho, Wo, cout + 8), -3.0, device=cuda)
             got, st = ops.conv(x.to(cuda), ('s2b', G, D, H, W, cin, cout), w.numpy(), stride=2, bias=b.to(cuda), relu=True,
                                want_stats=True, out=buf, y_coff=4, groups=G)
@@ -604,13 +573,10 @@ def test_conv3d_s2b_stride2_split_bf16_matches_oracle(cuda, G, D, H, W, cin, cou
             if flag:
                 one = ops.conv(x[1 % G].to(cuda), ('s2b', G, D, H, W, cin, cout), w.numpy(), stride=2, bias=b.to(cuda), relu=True)
                 assert torch.equal(one.cpu(), y[1 % G, ..., 4:4 + cout])
-        e32 = float((outs[False] - ref64).abs().max())
-        e16 = float((outs[True] - ref64).abs().max())
-        print('max abs error vs float64: fp32 MFMA %.3e, split bf16 %.3e' % (e32, e16))
-        assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
-    finally:
-        ops.use_bf16x3(True)             # the default
-        ops.clear_pack_cache()
+    e32 = float((outs[False] - ref64).abs().max())
+    e16 = float((outs[True] - ref64).abs().max())
+    print('max abs error vs float64: fp32 MFMA %.3e, split fp16 %.3e' % (e32, e16))
+    assert e16 <= 2.0 * e32 + 1e-7 * float(ref64.abs().max())
 
 
 def test_conv_split_siblings_match_dense(cuda):
@@ -649,24 +615,20 @@ def test_in_launch_finalize_matches_separate_finalize(cuda, shape, cin, cout):
     D, H, W = shape
     x = _rand((D, H, W, cin), 50).to(cuda)
     w = _rand((3, 3, 3, cin, cout), 51, 0.2).numpy()
-    ops.fused_finalize(True)
-    ops.use_xp1w(False)           # the in-launch finalize lives in the tiled kernel
-    ops.use_conv_c16(False)
     ref = None
-    for it in range(12):
-        y, st = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
-        assert st.params is not None
-        fused = st.params.clone()
-        st.params = None
-        sep = ops.bn_params(st, cout, y)
-        assert torch.allclose(fused[:2], sep[:2], rtol=1e-6, atol=1e-7) and torch.all(fused[2] == 0)
-        if ref is None:
-            ref = fused
-        assert torch.equal(fused, ref)
-    ops.fused_finalize(False)
-    y2, st2 = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
-    ops.use_xp1w(True)
-    ops.use_conv_c16(True)
+    with ops.configure(xp1w=False, conv_c16=False):           # the in-launch finalize lives in the tiled kernel
+        with ops.configure(fused_finalize=True):
+            for it in range(12):
+                y, st = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
+                assert st.params is not None
+                fused = st.params.clone()
+                st.params = None
+                sep = ops.bn_params(st, cout, y)
+                assert torch.allclose(fused[:2], sep[:2], rtol=1e-6, atol=1e-7) and torch.all(fused[2] == 0)
+                if ref is None:
+                    ref = fused
+                assert torch.equal(fused, ref)
+        y2, st2 = ops.conv(x, ('fin', shape, cin, cout), w, want_stats=True)
     assert st2.params is None and torch.equal(y2, y)
 
 
@@ -704,22 +666,19 @@ def test_tensor_on_another_device_is_refused(cuda):
         ops.channel_stats(x)
 
 
-@pytest.fixture(params=['split-bf16', 'fp32'])
+@pytest.fixture(params=['split16', 'fp32'])
 def towerkernel(request):
-    """Run a test on both 3x3 tower kernels: conv2d_b.hip (split-bf16 operands, default) and conv2d_lds.hip (fp32 MFMA)."""
+    """Run a test on both 3x3 tower kernels: conv2d_b.hip (split-fp16 operands, default) and conv2d_lds.hip (fp32 MFMA)."""
     from atvsnet_amd import ops
-    ops.use_bf16x3(request.param == 'split-bf16')
-    ops.clear_pack_cache()
-    yield request.param
-    ops.use_bf16x3(True)
-    ops.clear_pack_cache()
+    with ops.configure(split16=request.param == 'split16', clear_pack_cache=True):
+        yield request.param
 
 
 @pytest.mark.parametrize('cin,cout,dil,H,W,G', [
     (128, 128, 2, 32, 48, 1), (128, 128, 4, 30, 44, 2), (64, 128, 1, 17, 33, 3), (320, 128, 1, 16, 32, 1),
     (64, 64, 1, 24, 40, 2), (32, 32, 1, 36, 52, 2), (32, 64, 1, 9, 16, 1)])
 def test_conv2d_lds_matches_oracle(cuda, towerkernel, cin, cout, dil, H, W, G):
-    """The LDS-tiled 2-D convolutions of the feature towers (conv2d_b.hip: split-bf16 operands; conv2d_lds.hip: fp32 MFMA):
+    """The LDS-tiled 2-D convolutions of the feature towers (conv2d_b.hip: split-fp16 operands; conv2d_lds.hip: fp32 MFMA):
     every instantiation, ragged edges, several independent images per launch, bias / residual / ReLU and the per-image
     moments, both at the same fp32 bar."""
     from atvsnet_amd import ops
@@ -768,7 +727,7 @@ def test_conv2d_lds_normalise_on_load(cuda, towerkernel):
 @pytest.mark.parametrize('cin,cout,H,W,G', [(128, 128, 16, 20, 2), (64, 128, 9, 13, 3), (32, 64, 7, 11, 1), (128, 32, 16, 16, 2),
                                             (64, 64, 5, 50, 2), (320, 128, 12, 11, 1), (96, 32, 3, 5, 2)])
 def test_conv1x1_matches_oracle(cuda, towerkernel, cin, cout, H, W, G):
-    """The 1x1 GEMM kernels of the towers (conv1x1_b.hip: split-bf16 operands, default; conv1x1.hip: fp32 MFMA): bias / residual /
+    """The 1x1 GEMM kernels of the towers (conv1x1_b.hip: split-fp16 operands, default; conv1x1.hip: fp32 MFMA): bias / residual /
     ReLU / per-image moments, ragged pixel counts, and the bottleneck's pre-activation applied on load -- same bars for both."""
     from atvsnet_amd import ops
     g = torch.Generator().manual_seed(cin + cout)

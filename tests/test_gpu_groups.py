@@ -134,11 +134,8 @@ def test_stem_kernel_matches_oracle(cuda, cin, shape, G):
         flat = want[g].reshape(-1, 8).double()
         assert float((p[g, 0] - flat.mean(0)).abs().max()) <= 1e-5
         assert float((p[g, 1] - 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
-    ops.use_stem(False)
-    try:
+    with ops.configure(stem=False):
         y2 = ops.conv(x.to(cuda), ('stem-mfma', cin, shape), w.numpy(), relu=True, plane_bias=pb.to(cuda), groups=G)
-    finally:
-        ops.use_stem(True)
     assert float((y2.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
 
 
@@ -235,7 +232,7 @@ def test_siblings_normalise_on_load_is_bitwise_the_materialised_input(cuda, G, s
 
 def test_networks_with_prologue_equal_materialised_inputs(cuda, weights):
     """StackedUNet_prob and CostVolRefineNet with add- / normalise-on-load against the same networks with the inputs
-    materialised first (ops.use_prologue(False)): every output bit for bit."""
+    materialised first (ops.configure(prologue=False)): every output bit for bit."""
     from atvsnet_amd import ops
     from atvsnet_amd.cnn_wrapper.atvsnet import StackedUNet_prob, CostVolRefineNet
     G = 2
@@ -247,8 +244,7 @@ def test_networks_with_prologue_equal_materialised_inputs(cuda, weights):
                           [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
     res = {}
     for flag in (True, False):
-        ops.use_prologue(flag)
-        try:
+        with ops.configure(prologue=flag):
             net = StackedUNet_prob({'data': cost}, is_training=True, independent_samples=True)
             ref = CostVolRefineNet({'photo_group': photo, 'geo_group': geo,
                                     'prob_vol': _rand((G, 16, 32, 48, 1), 40).to(cuda),
@@ -257,15 +253,13 @@ def test_networks_with_prologue_equal_materialised_inputs(cuda, weights):
             res[flag] = [net.get_output_by_name('conv_b2_6_1').clone(), net.get_output_by_name('conv_b2_6_2').clone(),
                          ref.get_output().clone(), ref.get_output_by_name('global_refine_geo_3dconv').clone(),
                          ref.get_output_by_name('global_refine_concat').clone()]
-        finally:
-            ops.use_prologue(True)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
 
 
 @pytest.mark.parametrize('G,shape,cin', [(2, (6, 8, 20), 64), (1, (5, 9, 18), 32), (3, (3, 4, 17), 48)])
 def test_deconv_32_channels_as_two_split_launches(cuda, G, shape, cin):
-    """conv_b*_4_0 (64 -> 32 at eighth resolution) as two 16-channel launches of the split-bf16 transposed-convolution kernel
+    """conv_b*_4_0 (64 -> 32 at eighth resolution) as two 16-channel launches of the split-fp16 transposed-convolution kernel
     (weights of one chunk re-read per stage, channel halves of y and of the statistics rows): against torch, its moments, its
     grouped form against single launches, and against the class-fused fp32 form."""
     from oracle import tf_ops as T
@@ -287,13 +281,8 @@ def test_deconv_32_channels_as_two_split_launches(cuda, G, shape, cin):
         rstd = 1.0 / torch.sqrt(want.reshape(-1, cout).double().var(0, unbiased=False) + 1e-3)
         assert float((pg[0].cpu().double() - mean).abs().max()) <= 1e-5
         assert float((pg[1].cpu().double() - rstd).abs().max()) <= 1e-4 * float(rstd.abs().max())
-    ops.use_bf16x3(False)
-    ops.clear_pack_cache()
-    try:
+    with ops.configure(split16=False, clear_pack_cache=True):
         ref, _ = ops.conv3d_transpose_s2(x.to(cuda), ('up32', cin), w.numpy(), want_stats=True, groups=G)
-    finally:
-        ops.use_bf16x3(True)
-        ops.clear_pack_cache()
     assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max())
 
 
@@ -303,19 +292,14 @@ def test_deconv_32_channels_as_two_split_launches(cuda, G, shape, cin):
 @pytest.mark.parametrize('split', [True, False])
 def test_deconv_up_against_torch_and_the_class_fused_form(cuda, G, shape, cin, cout, split):
     """The 8- / 16-channel transposed convolutions (conv_b*_6_0, conv_b*_5_0, reference cnn_wrapper/network.py:510-550) on their own
-    kernels (csrc/deconv_up_b.hip: split-bf16 operands, default where its weights fit LDS; csrc/deconv_up.hip: fp32 MFMA): against tf.layers.conv3d_transpose restated with torch (tolerance 2e-5 of the output scale: a
+    kernels (csrc/deconv_up_b.hip: split-fp16 operands, default where its weights fit LDS; csrc/deconv_up.hip: fp32 MFMA): against tf.layers.conv3d_transpose restated with torch (tolerance 2e-5 of the output scale: a
     different accumulation order), and its statistics / grouped form against the separate calls."""
     from oracle import tf_ops as T
     from atvsnet_amd import ops
     x = _rand((G,) + shape + (cin,), 21)
     w = _rand((3, 3, 3, cout, cin), 22) * 0.2
-    ops.use_bf16x3(split)
-    ops.clear_pack_cache()
-    try:
+    with ops.configure(split16=split, clear_pack_cache=True):
         _deconv_up_checks(cuda, ops, T, x, w, G, shape, cin, cout)
-    finally:
-        ops.use_bf16x3(True)
-        ops.clear_pack_cache()
 
 
 def _deconv_up_checks(cuda, ops, T, x, w, G, shape, cin, cout):
@@ -335,11 +319,8 @@ def _deconv_up_checks(cuda, ops, T, x, w, G, shape, cin, cout):
         assert float((pg - p1).abs().max()) <= 1e-6 * float(p1.abs().max())
         mean = want.reshape(-1, cout).double().mean(0)
         assert float((pg[0].cpu().double() - mean).abs().max()) <= 1e-5
-    ops.use_deconv_up(False)
-    try:
+    with ops.configure(deconv_up=False):
         ref, _ = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin, cout), w.numpy(), want_stats=True, groups=G)
-    finally:
-        ops.use_deconv_up(True)
     assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max())
     relu = ops.conv3d_transpose_s2(x.to(cuda), ('up', cin, cout), w.numpy(), relu=True, groups=G)
     assert torch.equal(relu, torch.clamp(got, min=0))
@@ -369,11 +350,8 @@ def test_conv_c16_against_torch_and_the_tiled_kernel(cuda, G, shape, cin, cout):
         pg = params[g] if G > 1 else params
         assert float((pg - ops.bn_params(st1, cout, one)).abs().max()) <= 1e-6 * float(pg.abs().max())
         assert float((pg[0].cpu().double() - want.reshape(-1, cout).double().mean(0)).abs().max()) <= 1e-5
-    ops.use_conv_c16(False)
-    try:
+    with ops.configure(conv_c16=False):
         ref = ops.conv(x.to(cuda), ('c16', cin, cout), w.numpy(), groups=G)
-    finally:
-        ops.use_conv_c16(True)
     assert float((ref - got).abs().max()) <= 2e-5 * float(ref.abs().max())
     b = _rand((cout,), 33)
     buf = torch.full((G,) + shape + (16 + cout,), -7.0, device=cuda)
@@ -414,7 +392,7 @@ def test_photo_stem_into_plane_and_planar_concat_consumer_are_bitwise(cuda, shap
     planes as from the channel-last rows (reference cnn_wrapper/atvsnet.py:300-316)."""
     from atvsnet_amd import ops
     if ops._xkind() != 'xb':
-        pytest.skip('the planar concat belongs to the split-bf16 x-pair kernel')
+        pytest.skip('the planar concat belongs to the split-fp16 x-pair kernel')
     D, H, W = shape
     chan = 16
     photo = ops.SplitVolume(_rand((G, D, H, W, chan), 20).to(cuda), _rand((G, H, W, 2 * chan), 21).to(cuda),
@@ -490,11 +468,11 @@ def test_photo_volume_in_pieces_feeds_the_photo_stem_bitwise(cuda, D, h, w):
 
 def test_refinement_net_planar_concat_equals_channel_last_concat(cuda, weights):
     """CostVolRefineNet with its concat as four dense planes (default) against the channel-last concat
-    (ops.use_planar_concat(False)): every output bit for bit, and the planar form really ran."""
+    (ops.configure(planar_concat=False)): every output bit for bit, and the planar form really ran."""
     from atvsnet_amd import ops
     from atvsnet_amd.cnn_wrapper.atvsnet import CostVolRefineNet
     if ops._xkind() != 'xb':
-        pytest.skip('the planar concat belongs to the split-bf16 x-pair kernel')
+        pytest.skip('the planar concat belongs to the split-fp16 x-pair kernel')
     G, chan, shape = 2, 16, (16, 32, 48)
     photo = ops.SplitVolume(_rand((G,) + shape + (chan,), 20).to(cuda), _rand((G, 32, 48, 2 * chan), 21).to(cuda),
                             [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)])
@@ -503,8 +481,7 @@ def test_refinement_net_planar_concat_equals_channel_last_concat(cuda, weights):
     prob, hull = _rand((G,) + shape + (1,), 40).to(cuda), _rand((G,) + shape + (1,), 41).to(cuda)
     res = {}
     for flag in (True, False):
-        ops.use_planar_concat(flag)
-        try:
+        with ops.configure(planar_concat=flag):
             ref = CostVolRefineNet({'photo_group': photo, 'geo_group': geo, 'prob_vol': prob, 'vis_hull': hull},
                                    is_training=True, independent_samples=True)
             concat = ref.layers['global_refine_concat']
@@ -512,7 +489,5 @@ def test_refinement_net_planar_concat_equals_channel_last_concat(cuda, weights):
             res[flag] = [ref.get_output().clone(), ref.get_output_by_name('global_refine_3dconv6_1').clone(),
                          ref.get_output_by_name('global_refine_photo_3dconv').clone(),
                          ref.get_output_by_name('global_refine_concat').clone()]
-        finally:
-            ops.use_planar_concat(True)
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)

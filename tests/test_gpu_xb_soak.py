@@ -34,13 +34,8 @@ def _repeat_bitwise(run):
 
 
 def _against_fp32(ops, run, first):
-    ops.use_bf16x3(False)
-    ops.clear_pack_cache()
-    try:
+    with ops.configure(split16=False, clear_pack_cache=True):
         ref = run()
-    finally:
-        ops.use_bf16x3(True)
-        ops.clear_pack_cache()
     for a, b in zip(first, ref):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max())
 

@@ -246,5 +246,5 @@ def test_results_outside_the_fp16_range_fail_loudly():
     bad = ok.copy()
     bad[1, 2] = np.nan
     bad[2, 0] = np.inf
-    with pytest.raises(FloatingPointError, match='2 non-finite.*ATVS_BF16X3=0'):
+    with pytest.raises(FloatingPointError, match='2 non-finite.*ATVS_SPLIT16=0'):
         example.check_finite(bad)

@@ -86,7 +86,7 @@ def test_deconv_up_b_pack_holds_every_weight_once(cin, cout):
     assert np.count_nonzero(vals[:, 0]) >= w.size
 
 
-def test_split_bf16_entry_points_check_their_arguments_first():
+def test_split16_entry_points_check_their_arguments_first():
     """supported() truth tables, size queries and NULL / shape checks (all return before any launch)."""
     L = _lib.lib()
     pb = ctypes.c_long()

@@ -19,7 +19,7 @@ from atvsnet_amd import _lib
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 # kernels that reserve the whole register file of their SIMD (asm volatile("" ::: "v255", "a255")): nothing runs beside them
 OWNS_ITS_SIMD = ('conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel')
-# fp32-MFMA predecessors (A/B path, ops.use_bf16x3(False)): one workgroup per CU with 450-512 registers; packed fp32 by design
+# fp32-MFMA predecessors (A/B path, ops.configure(split16=False)): one workgroup per CU with 450-512 registers; packed fp32 by design
 FP32_ONE_WORKGROUP = ('conv_xw_kernel', 'deconv_up_kernel', 'conv_c16_kernel')
 # FMA-bound kernels with hand-written packed FMAs that share their SIMDs: the reason PipelinedInference(co_resident=True) is opt-in
 KNOWN_EXPOSED = ('conv3d_8to1_kernel', 'refine_stems_kernel', 'probability_map_kernel')
@@ -54,7 +54,7 @@ def test_packed_fp32_only_where_it_is_accounted_for(tmp_path):
     strangers = sorted(k for k in counts if not any(a in k for a in allowed))
     assert not strangers, ('kernels with packed fp32 arithmetic that neither own their SIMD nor are listed as exposed: %s -- build '
                            'their source with -fno-slp-vectorize / scalar arithmetic, or reserve the register file' % strangers)
-    # the split-bf16 tower kernels run two workgroups per CU (they cannot own a SIMD): they must stay free of packed fp32
+    # the split-fp16 tower kernels run two workgroups per CU (they cannot own a SIMD): they must stay free of packed fp32
     for k in counts:
         assert 'conv2d_b_kernel' not in k and 'conv1x1_b_kernel' not in k, k
     # conv_xb's staging wavefronts compute (batch norm, operand split) beside its own MFMA wavefronts on the same SIMD: scalar fp32 only

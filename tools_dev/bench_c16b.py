@@ -14,7 +14,7 @@ for cin, G, D, H, W in ((16, 8, 96, 64, 80), (8, 4, 192, 128, 160)):
   w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, 16)) * 0.1).astype(np.float32)
   ref = T.conv(x[:1, :12].cpu().double(), torch.from_numpy(w).double(), 1, 'SAME')[0, 1:-1]
   for name, flag in (('fp32 MFMA (conv_c16)', False), ('split bf16 x3 (conv_c16b)', True)):
-    ops.use_bf16x3(flag)
+    ops.cfg.split16 = flag
     ops.clear_pack_cache()
     run = lambda: ops.conv(x, ('b', cin), w, want_stats=True, groups=G, relu=(cin == 8))      # noqa: E731
     for _ in range(3):
@@ -31,4 +31,4 @@ for cin, G, D, H, W in ((16, 8, 96, 64, 80), (8, 4, 192, 128, 160)):
     r = ref.clamp(min=0) if cin == 8 else ref
     err = float((y[0, 1:11].cpu().double() - r).abs().max() / r.abs().max())
     print('%-28s %.3f ms  %.1f TF/s (fp32-equivalent)  max err / max vs float64: %.2e' % (name, ms, gf / ms, err), flush=True)
-ops.use_bf16x3(True)
+ops.cfg.split16 = True

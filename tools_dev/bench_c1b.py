@@ -11,7 +11,7 @@ for cin, cout in ((128, 128), (128, 32), (32, 128), (64, 128), (64, 64), (32, 64
     x = torch.randn(G, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((1, 1, cin, cout)) * 0.05).astype(np.float32)
     for name, flag in (('fp32', False), ('split-bf16', True)):
-        ops.use_bf16x3(flag)
+        ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv1x1(x, ('b', cin, cout), w, want_stats=True)      # noqa: E731
         for _ in range(3):
@@ -26,4 +26,4 @@ for cin, cout in ((128, 128), (128, 32), (32, 128), (64, 128), (64, 64), (32, 64
         ms = e0.elapsed_time(e1) / 20
         gb = 4.0 * (cin + cout) * G * H * W / 1e9
         print('%3d -> %3d  %-10s %.4f ms  %.2f TB/s' % (cin, cout, name, ms, gb / ms), flush=True)
-ops.use_bf16x3(True)
+ops.cfg.split16 = True

@@ -11,7 +11,7 @@ for cin, cout, dil in ((128, 128, 2), (128, 128, 4), (320, 128, 1), (64, 64, 1),
     x = torch.randn(G, H * (2 if cout == 32 else 1), W * (2 if cout == 32 else 1), cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
     for name, flag in (('fp32', False), ('split-bf16', True)):
-        ops.use_bf16x3(flag)
+        ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv2d_lds(x, ('b', cin, cout, dil), w, dil, want_stats=True)      # noqa: E731
         for _ in range(3):
@@ -26,4 +26,4 @@ for cin, cout, dil in ((128, 128, 2), (128, 128, 4), (320, 128, 1), (64, 64, 1),
         ms = e0.elapsed_time(e1) / 10
         gf = 2.0 * 9 * cin * cout * x.shape[0] * x.shape[1] * x.shape[2] / 1e9
         print('%3d -> %3d dil %d  %-10s %.3f ms  %.1f TF/s' % (cin, cout, dil, name, ms, gf / ms), flush=True)
-ops.use_bf16x3(True)
+ops.cfg.split16 = True

@@ -10,7 +10,7 @@ for G, D, H, W, cin, cout in ((8, 48, 32, 40, 32, 32), (4, 48, 32, 40, 32, 32), 
     x = torch.randn(G, D, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, cout)) * 0.05).astype(np.float32)
     for name, flag in (('fp32', False), ('split-bf16', True)):
-        ops.use_bf16x3(flag)
+        ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv(x, ('b', cin, cout), w, want_stats=True, groups=G)      # noqa: E731
         for _ in range(3):
@@ -29,7 +29,7 @@ for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 32), (4, 96, 64, 80, 16, 32), 
     x = torch.randn(G, D, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, cout)) * 0.05).astype(np.float32)
     for name, flag in (('fp32', False), ('split-bf16', True)):
-        ops.use_bf16x3(flag)
+        ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv(x, ('s', cin, cout), w, stride=2, want_stats=True, groups=G)      # noqa: E731
         for _ in range(3):
@@ -44,4 +44,4 @@ for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 32), (4, 96, 64, 80, 16, 32), 
         ms = e0.elapsed_time(e1) / 20
         gf = 2.0 * 27 * cin * cout * G * D * H * W / 8 / 1e9
         print('stride 2  G=%d %dx%dx%d %3d -> %3d  %-10s %.4f ms  %.1f TF/s' % (G, D, H, W, cin, cout, name, ms, gf / ms), flush=True)
-ops.use_bf16x3(True)
+ops.cfg.split16 = True

@@ -10,7 +10,7 @@ for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 8), (4, 96, 64, 80, 16, 8), (8
     x = torch.randn(G, D, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, 3, cout, cin)) * 0.05).astype(np.float32)
     for name, flag in (('fp32', False), ('split-bf16', True)):
-        ops.use_bf16x3(flag)
+        ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv3d_transpose_s2(x, ('u', cin, cout), w, want_stats=True, groups=G)      # noqa: E731
         for _ in range(3):
@@ -25,4 +25,4 @@ for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 8), (4, 96, 64, 80, 16, 8), (8
         ms = e0.elapsed_time(e1) / 20
         gb = 4.0 * G * D * H * W * (cin + 8 * cout) / 1e9
         print('G=%d %dx%dx%d %3d -> %3d  %-10s %.4f ms  %.2f TB/s' % (G, D, H, W, cin, cout, name, ms, gb / ms), flush=True)
-ops.use_bf16x3(True)
+ops.cfg.split16 = True

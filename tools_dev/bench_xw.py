@@ -8,7 +8,7 @@ import atvsnet_amd
 from atvsnet_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 kind = sys.argv[2] if len(sys.argv) > 2 else 'xb'
-ops.use_xb(kind == 'xb')
+ops.cfg.xb = kind == 'xb'
 print('x-pair kernel:', kind)
 dev = torch.device('cuda:0')
 D, H, W = 192, 128, 160
