@@ -17,10 +17,10 @@ LIB_PATH = os.environ.get('ATVS_LIB') or os.path.join(_HERE, 'libatvsnet_hip.so'
 HEADER = os.path.join(os.path.dirname(_HERE), 'include', 'atvsnet_hip.h')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 # -fno-slp-vectorize: no COMPILER-FORMED packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32) in kernels whose
-# wavefronts can share a SIMD with another kernel's: beside wavefronts of a bf16-MFMA kernel (two depth maps in flight) such
-# kernels produced wrong lane quarters, more often with packed arithmetic (tests/test_gpu_pipeline.py).  The
-# one-workgroup-per-CU bf16-MFMA kernels reserve their SIMDs' whole register file (nothing runs beside them) and keep the
-# vectoriser: their operand split is a fifth of a stage and runs 1.9 instead of 1.5 VALU instructions per MFMA without it.
+# wavefronts can share a SIMD with another kernel's: beside wavefronts issuing 16x16x32 MFMAs (two depth maps in flight) such
+# kernels produced wrong lane quarters (tests/test_gpu_pipeline.py, tests/test_packed_fp32_census.py).
+# The one-workgroup-per-CU split-operand kernels listed below fill their SIMDs' register file (nothing runs beside them) and
+# keep the vectoriser: their operand split is a fifth of a stage and runs 1.9 instead of 1.5 VALU instructions per MFMA without.
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall',
          '-Wno-unused-function', '-Wno-unused-result']
 # conv_xb (round 4, second half) is not in the list although it owns its SIMDs: its STAGING wavefronts run beside its own MFMA
@@ -144,6 +144,7 @@ def lib():
         _lib.atvs_conv_stem_rows.restype = ctypes.c_long
         _lib.atvs_conv1x1_rows.restype = ctypes.c_long
         _lib.atvs_conv1x1_b_rows.restype = ctypes.c_long
+        _lib.atvs_bottleneck_b_rows.restype = ctypes.c_long
         _lib.atvs_conv3d_s2b_grid.restype = ctypes.c_long
         _lib.atvs_deconv_up_grid.restype = ctypes.c_long
         _lib.atvs_conv_c16_grid.restype = ctypes.c_long

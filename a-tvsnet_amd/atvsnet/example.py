@@ -273,10 +273,12 @@ class PipelinedInference(object):
     the next map (and writes the previous one's files) meanwhile.
     `co_resident=True`: the slots' graphs run concurrently on their streams; the second map's kernels fill the phases in
     which one pipeline leaves the GPU under-filled (+4.5 % depth maps/s at config 3).  Opt-in only: wavefronts of different
-    kernels then share SIMDs, and on this pool's MI355X small kernels beside bf16-MFMA wavefronts have produced wrong lane
-    quarters (un-root-caused, defended by register-file reservation in the one-workgroup kernels
-    but not in conv2d_b / conv1x1_b).  bench.py measures it under `pipelined` and fails the run if a slot's output
-    differs from the single-map output.
+    kernels then share SIMDs, and on this pool's MI355X kernels with compiler-formed packed fp32 arithmetic on dwordx2-loaded
+    operands have produced wrong lane quarters beside another kernel's 16x16x32 MFMA wavefronts (narrowed
+    to that instruction form, cause not established; the kernels that still contain packed fp32 are pinned by
+    tests/test_packed_fp32_census.py, and conv2d_b / conv1x1_b / bottleneck_b / deconv_up_b run two workgroups per CU, so
+    nothing reserves their SIMDs).  bench.py measures it under `pipelined` and fails the run if a slot's output differs from
+    the single-map output.
 
         t = p.submit(images, cams)      # asynchronous: copies the inputs, replays the slot's graph on its stream
         out = p.result(t)               # waits for that depth map; the tensors are valid until the slot is re-used

@@ -424,6 +424,18 @@ class Network(object):
             if st_in is None:
                 st_in = ops.channel_stats(x, groups=G)
             pre_params = ops.bn_params(st_in, depth_in, x, beta, BN_EPS)
+        if self.training and depth == depth_in and stride == 1 and kernel_size == 3 \
+                and ops.bottleneck_ok(depth, rate, x.shape[1], x.shape[2]):
+            # identity-shortcut unit: nothing global between the pre-activation's moments and the output -> ONE launch
+            # (bottleneck_b.hip); r1 and r2 never leave the CU
+            out, st = ops.bottleneck(
+                x, pre_params, tuple(scope + '/%s/weights' % c for c in ('conv1', 'conv2', 'conv3')),
+                self._kernel('%s/conv1/weights' % scope, (1, 1, depth, depth)), self._vec('%s/conv1/biases' % scope, depth, x),
+                self._kernel('%s/conv2/weights' % scope, (3, 3, depth, depth)), self._vec('%s/conv2/biases' % scope, depth, x),
+                self._kernel('%s/conv3/weights' % scope, (1, 1, depth, depth)), self._vec('%s/conv3/biases' % scope, depth, x),
+                dilation=rate)
+            out._atvs_stats = st
+            return out
         on_load = self.training and ops.conv1x1_ok(depth_in, depth)
         if depth == depth_in:
             if stride == 1:

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void warp_planes_kernel(
 // 16-byte store -- every pass writes 4 KB contiguous.
 // (Round 3: an unrolled form of this kernel, and homographies_kernel, produced wrong lane quarters beside wavefronts of a
 // bf16-MFMA kernel on the same SIMD -- two depth maps in flight.  Common factor: compiler-formed packed fp32 arithmetic.  This
-// file is built with -fno-slp-vectorize (_lib.flags_for) and the blend below is scalar.  DESIGN.md 6;
+// file is built with -fno-slp-vectorize (_lib.flags_for) and the blend below is scalar.  DESIGN.md appendix B;
 // tests/test_gpu_pipeline.py::test_small_kernels_beside_other_wavefronts, ::test_two_depth_maps_in_flight_fullsize.)
 // PIECES (chunk-planar output only): every value leaves as its two fp16 pieces (atvs_split2_f16: the split conv_xb.hip's staging
 // wavefronts would otherwise perform, once per value instead of once per halo copy) -- a chunk plane is then
@@ -313,6 +313,9 @@ extern "C" int atvs_warp_planes(const float* src, const float* homographies, con
     ATVS_LAUNCH_CHECK();
     return ATVS_OK;
   }
+  // the gather kernel below writes channel-last fp32 only: a chunk-planar / pieces request the shared kernel cannot take (a
+  // source map of 2 GiB or more) is refused, never silently written in another layout
+  if (planar || pieces) return ATVS_ERR_SHAPE;
 #define LAUNCH(M, V)                                                                                            \
   hipLaunchKernelGGL((warp_planes_kernel<M, V>), grid, block, 0, s, src, homographies, ref, depth_start,        \
                      depth_interval, out, mask_out, D, h, w, C, ld_out, c_off, rep)

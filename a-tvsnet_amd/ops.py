@@ -776,16 +776,13 @@ def conv1x1_ok(cin, cout):
 
 
 
-def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=False, out=None, y_coff=0, in_params=None,
-            in_relu=False):
-    """1x1 stride-1 convolution of x (G, ..., Cin) -> (G, ..., Cout) (any spatial axes between) on the GEMM kernel.
-    in_params (G,3,Cin): batch norm (+ ReLU if in_relu) of x applied on load."""
+def pack_conv1x1(key, w_host, cin, device):
+    """Packed weights of the 1x1 GEMM kernels for a TF kernel [1,1,Cin,Cout] (or [Cin,Cout]); cached.  pk.kind: '_b' = fp16
+    pieces for conv1x1_b.hip (and the 1x1 stages of bottleneck_b.hip), '' = fp32 for conv1x1.hip."""
     import numpy as np
-    G, cin = x.shape[0], x.shape[-1]
-    pixels = x.numel() // G // cin
     lib = _lib.lib()
     kind = '_b' if (split_on('c1b') and lib.atvs_conv1x1_b_supported(int(cin), int(np.asarray(w_host).size // cin))) else ''
-    ck = ('c1' + kind, key, str(x.device))
+    ck = ('c1' + kind, key, str(device))
     pk = _pack_cache.get(ck)
     if pk is None:
         w = np.ascontiguousarray(w_host, dtype=np.float32).reshape(cin, -1)
@@ -801,8 +798,20 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
             raise RuntimeError('atvs_conv1x1%s_pack failed (%d)' % (kind, rc))
         pk = _Packed()
         pk.key, pk.tab, pk.cin, pk.cout, pk.ntiles, pk.kind = key, None, cin, cout, cout // 16, kind
-        pk.wp = None if x.is_meta else torch.from_numpy(packed).to(x.device)
+        pk.wp = None if torch.device(device).type == 'meta' else torch.from_numpy(packed).to(device)
         _pack_cache[ck] = pk
+    return pk
+
+
+def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=False, out=None, y_coff=0, in_params=None,
+            in_relu=False):
+    """1x1 stride-1 convolution of x (G, ..., Cin) -> (G, ..., Cout) (any spatial axes between) on the GEMM kernel.
+    in_params (G,3,Cin): batch norm (+ ReLU if in_relu) of x applied on load."""
+    G, cin = x.shape[0], x.shape[-1]
+    pixels = x.numel() // G // cin
+    lib = _lib.lib()
+    pk = pack_conv1x1(key, w_host, cin, x.device)
+    kind = pk.kind
     y = _new(x, tuple(x.shape[:-1]) + (pk.cout,)) if out is None else out
     st, sbuf = None, None
     if want_stats:
@@ -815,6 +824,40 @@ def conv1x1(x, key, w_host, bias=None, residual=None, relu=False, want_stats=Fal
             _call('atvs_conv1x1%s_f32' % kind, _p(x), _p(pk.wp), _p(bias), _p(residual), _p(in_params), int(bool(in_relu)),
                   _p(y), ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G,
                   ctypes.c_long(pixels), cin, pk.cout, int(y.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+    return (y, st) if want_stats else y
+
+
+def bottleneck_ok(C, dilation, H, W):
+    """Is the identity-shortcut residual unit of this shape ONE launch (atvs_bottleneck_b_f32)?"""
+    return (cfg.bottleneck and cfg.force_impl is None and cfg.conv1x1 and cfg.conv2d_lds and split_on('btl') and split_on('c1b')
+            and split_on('c2b') and H >= 8 and W >= 16 and bool(_lib.lib().atvs_bottleneck_b_supported(int(C), int(dilation))))
+
+
+def bottleneck(x, in_params, keys, w1, b1, w2, b2, w3, b3, dilation=1, want_stats=True):
+    """Network.bottleneck with an identity shortcut (reference cnn_wrapper/network.py:552-602) in one launch:
+    y = x + conv3(relu(conv2(relu(conv1(relu(bn(x))) + b1)) + b2)) + b3 for x (G,H,W,C); in_params (G,3,C) = the pre-activation
+    batch norm's parameters (bn_params of x's moments with the unit's beta).  keys = the pack-cache keys of the three kernels
+    (the unfused path's: the arranged weights are shared).  Returns (y, Stats of y) -- the next unit's moments."""
+    G, H, W, C = x.shape
+    k1, k2, k3 = keys
+    p1, p3 = pack_conv1x1(k1, w1, C, x.device), pack_conv1x1(k3, w3, C, x.device)
+    p2 = pack_conv2d_lds(k2, w2, x.device)
+    if p1.kind != '_b' or p3.kind != '_b' or p2.kind != 'b' or (p1.cout, p2.cout, p3.cout) != (C, C, C):
+        raise ValueError('bottleneck: the fused unit takes the split-operand packs of three C -> C kernels')
+    y = _new(x, x.shape)
+    st, sbuf = None, None
+    if want_stats:
+        rows = int(_lib.lib().atvs_bottleneck_b_rows(int(H), int(W)))
+        sbuf = torch.empty((G, rows, 2, C), dtype=torch.float64, device=x.device)
+        st = Stats()
+        st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, C, H * W, G
+    if _dev_ok(x, y, in_params, b1, b2, b3):
+        if in_params.numel() != G * 3 * C:
+            raise ValueError('bottleneck: in_params must be (groups, 3, C)')
+        with _Timed(k2, (1, H, W, C), C, G):
+            _call('atvs_bottleneck_b_f32', _p(x), _p(in_params), _p(p1.wp), _p(b1), _p(p2.wp), _p(b2), _p(p3.wp), _p(b3), _p(y),
+                  ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, H, W, C, int(dilation),
+                  _stream())
     return (y, st) if want_stats else y
 
 
@@ -1837,7 +1880,8 @@ class PendingBN(object):
         return self.raw.is_meta
 
     def materialize(self):
-        """The normalised tensor (computed once, in place on the raw buffer)."""
+        """The normalised channel-last tensor (computed once; in place on the raw buffer, or on a channel-last copy of it when
+        the raw buffer is chunk-planar)."""
         if self._final is None:
             raw = self.raw
             if self.planar:
@@ -1861,7 +1905,8 @@ class PendingSum(object):
     def __init__(self, items):
         if len(items) != 2 or any(tuple(t.shape) != tuple(items[0].shape) for t in items):
             raise ValueError('PendingSum: two items of one shape')
-        self.items = list(items)
+        # a chunk-planar raw buffer is not a channel-last operand: such an item enters the sum materialised
+        self.items = [t.materialize() if isinstance(t, PendingBN) and t.planar else t for t in items]
         self._final = None
         self.device = items[0].device
 
@@ -1947,7 +1992,7 @@ def bn_add(items):
     """Sum of 2 or 3 items, each a dense tensor or a PendingBN (normalised on the fly); dims without batch."""
     xs, ps, mask = [], [], 0
     for i, it in enumerate(items):
-        if isinstance(it, PendingBN) and it._final is None:
+        if isinstance(it, PendingBN) and it._final is None and not it.planar:
             xs.append(it.raw)
             ps.append(it.params)
             mask |= (1 << i) if it.relu else 0

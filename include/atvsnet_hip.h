@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 30
+#define ATVS_ABI_VERSION 31
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -360,6 +360,21 @@ long atvs_conv1x1_b_rows(long pixels);
 int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
                        const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
                        int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* One launch per pre-activation residual unit (bottleneck_b.hip; replaces Network.bottleneck, reference
+ * cnn_wrapper/network.py:552-602, for depth == depth_in, stride 1 -- the identity-shortcut units of res_block, :604-616):
+ *   y = x + conv3_1x1(relu(conv2_3x3_dil(relu(conv1_1x1(relu(bn(x))) + b1)) + b2)) + b3
+ * for G images (H,W,C) channel-last fp32.  The unit has ONE global reduction (the moments of x, in_params (G,3,C) from
+ * atvs_bn_finalize); conv1 is evaluated for the tile and its dilation halo, r1 and r2 stay in LDS as fp16 pieces.  Split fp16
+ * operands, the K order and packed weights of the unfused kernels: w1 / w3 = atvs_conv1x1_b_pack of [C][C], w2 =
+ * atvs_conv2d_b_pack of [3][3][C][C]; y is bit for bit what atvs_conv1x1_b_f32 -> atvs_conv2d_b_f32 -> atvs_conv1x1_b_f32 give.
+ * stats_partial: NULL or (G, atvs_bottleneck_b_rows(H, W), 2, C) doubles: per-workgroup moments of y (the next unit's batch
+ * norm).  x and y may not alias.  Shapes: atvs_bottleneck_b_supported (C in {32, 64}, dilation 1). */
+int atvs_bottleneck_b_supported(int C, int dilation);
+long atvs_bottleneck_b_rows(int H, int W);
+int atvs_bottleneck_b_f32(const float* x, const float* in_params, const unsigned char* w1, const float* b1,
+                          const unsigned char* w2, const float* b2, const unsigned char* w3, const float* b3, float* y,
+                          double* stats_partial, int G, int H, int W, int C, int dilation, atvs_stream_t stream);
 
 /* 3x3x3 SAME stride-1 convolutions with Cin % 16 == 0 and 32 / 64 output channels (conv_b*_2_1, conv_b*_3_1,
  * global_refine_3dconv{2,3}_1: cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, network.py:172-215) with SPLIT fp16

@@ -762,3 +762,72 @@ def test_conv1x1_matches_oracle(cuda, towerkernel, cin, cout, H, W, G):
     # one image, legacy (unbatched) call form
     y1 = ops.conv(x[0].to(cuda), ('p', cin, cout), w.numpy())
     assert float((y1.cpu() - T.conv(x[:1], w, 1, 'SAME')[0]).abs().max()) <= 2e-5 * float(want.abs().max())
+
+
+@pytest.mark.parametrize('C,H,W,G', [(64, 128, 160, 5), (64, 13, 37, 2), (64, 8, 16, 1), (32, 256, 320, 5), (32, 21, 50, 3),
+                                     (32, 9, 17, 1), (64, 40, 32, 2)])
+def test_bottleneck_fused_is_bitwise_the_three_launches(cuda, C, H, W, G):
+    """bottleneck_b.hip: an identity-shortcut pre-activation residual unit (reference cnn_wrapper/network.py:552-602) as ONE
+    launch -- conv1 over the tile and its halo, r1 / r2 in LDS as fp16 pieces.  Same K order and packed weights as the three
+    launches it replaces (conv1x1_b -> conv2d_b -> conv1x1_b): the output must be THEIR bits, on full tower sizes and ragged
+    ones (rows / columns cut by the 8 x 16 tile, images smaller than a tile row); against the oracle's bottleneck at the
+    convolution bar; the moments it hands to the next unit against the output's own."""
+    from atvsnet_amd import ops
+    from oracle import nets
+    g = torch.Generator().manual_seed(100 + C + H)
+    x = torch.randn(G, H, W, C, generator=g) * 1.5 + 0.3
+    W_ = {'u/preact/beta': torch.randn(C, generator=g) * 0.1}
+    for name, shape, sc in (('conv1', (1, 1, C, C), (1.0 / C) ** 0.5), ('conv2', (3, 3, C, C), (1.0 / (9 * C)) ** 0.5),
+                            ('conv3', (1, 1, C, C), (1.0 / C) ** 0.5)):
+        W_['u/%s/weights' % name] = torch.randn(*shape, generator=g) * sc
+        W_['u/%s/biases' % name] = torch.randn(C, generator=g) * 0.1
+    xd = x.to(cuda)
+    assert ops.bottleneck_ok(C, 1, H, W)
+    params = ops.bn_params(ops.channel_stats(xd, groups=G), C, xd, W_['u/preact/beta'].to(cuda))
+    keys = tuple(('btl', C, H, W, n) for n in ('conv1', 'conv2', 'conv3'))
+    wb = [(W_['u/%s/weights' % n].numpy(), W_['u/%s/biases' % n].to(cuda)) for n in ('conv1', 'conv2', 'conv3')]
+    y, st = ops.bottleneck(xd, params, keys, wb[0][0], wb[0][1], wb[1][0], wb[1][1], wb[2][0], wb[2][1])
+    # the three launches
+    r = ops.conv(xd, keys[0], wb[0][0], bias=wb[0][1], relu=True, groups=G, in_params=params, in_relu=True)
+    r = ops.conv(r, keys[1], wb[1][0], bias=wb[1][1], relu=True, groups=G)
+    ref, st_ref = ops.conv(r, keys[2], wb[2][0], bias=wb[2][1], residual=xd, want_stats=True, groups=G)
+    assert torch.equal(y, ref)
+    # the oracle (per image: batch statistics per call)
+    want = torch.cat([nets.bottleneck(x[i:i + 1], W_, 'u', 3, C) for i in range(G)])
+    assert float((y.cpu() - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    # the moments of y for the next unit: the fused rows against the unfused rows (other grouping, same sums) and torch
+    p, p_ref = ops.bn_params(st, C, y).reshape(G, 3, C), ops.bn_params(st_ref, C, ref).reshape(G, 3, C)
+    assert float((p - p_ref).abs().max()) <= 1e-6 * float(p_ref.abs().max())
+    for i in range(G):
+        flat = y[i].reshape(-1, C).double()
+        assert float((p[i, 0].double() - flat.mean(0)).abs().max()) <= 1e-5
+        assert float((p[i, 1].double() - 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
+
+
+def test_residual_block_with_fused_units_equals_unfused(cuda, weights):
+    """res_block conv1_x of ResNetDS2SPP (8 units: one strided projection unit, seven identity units) through the operator API with
+    the fused unit (default) and without (`ops.configure(bottleneck=False)`): the first identity unit sees identical inputs and
+    moments -> identical bits; behind it the moments come from differently grouped partial sums, so the whole block is compared
+    at 1e-6 of its scale; and the fused units really ran (launch watch)."""
+    from atvsnet_amd import ops
+    from atvsnet_amd.cnn_wrapper.network import Network
+
+    class Block(Network):
+        def setup(self):
+            (self.feed('data').res_block(3, 64, num_block=8, stride=2, name='conv1_x'))
+
+    x = torch.randn(2, 64, 96, 32, generator=torch.Generator().manual_seed(3)).to(cuda)
+    outs, launches = {}, {}
+    for fused in (True, False):
+        with ops.configure(bottleneck=fused):
+            ops.watch('*')
+            net = Block({'data': x}, is_training=True, independent_samples=True)
+            launches[fused] = [str(k[0]) for k in ops.watch(None)]
+            outs[fused] = net.get_output().clone()
+    a, b = outs[True], outs[False]
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    # one launch per identity unit instead of three; the strided projection unit keeps its four
+    unit = lambda ls, scope: sum(1 for k in ls if k.startswith(scope + '/'))      # noqa: E731
+    assert unit(launches[True], 'conv1_x_1') == 1 and unit(launches[False], 'conv1_x_1') == 3
+    assert unit(launches[True], 'conv1_x') == 1 and unit(launches[True], 'conv1_x_0') == 4
+    assert len(launches[False]) - len(launches[True]) == 2 * 7
