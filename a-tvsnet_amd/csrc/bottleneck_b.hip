@@ -28,6 +28,15 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr float BT_RS = 2048.f, BT_IRS = 1.f / 2048.f;
 
+// Development build (-DATVS_BT_DEBUG): per-wavefront tick counts of the phases, read back with atvs_debug_read_bt
+// (tools_dev/phase_bt.py).
+#ifdef ATVS_BT_DEBUG
+__device__ unsigned long long atvs_dbg_bt[4096 * 8];
+#define BDBG(i) { unsigned long long t_ = clock64(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; }
+#else
+#define BDBG(i)
+#endif
+
 struct BtArgs {
   const float* x;
   const float* in_params;     // (G, 3, C): mean | 1 / sqrt(var + eps) | beta of the pre-activation batch norm
@@ -44,13 +53,44 @@ struct BtArgs {
   long total;
 };
 
+// the two fp16 pieces of four / eight values: atvs_split2_f16 (common.h: five vector instructions per two values, the values of
+// the C form `h0 = f16(x); h1 = f16((x - h0) * 2048)` the unfused kernels use)
+union BtQ { unsigned u[2]; f16x4 h; };
+union BtO { unsigned u[4]; f16x8 h; };
 __device__ __forceinline__ void bt_split(const float v[4], f16x4* p0, f16x4* p1) {
+  BtQ a, b;
+  atvs_split2_f16(v[0], v[1], BT_RS, &a.u[0], &b.u[0]);
+  atvs_split2_f16(v[2], v[3], BT_RS, &a.u[1], &b.u[1]);
+  *p0 = a.h;
+  *p1 = b.h;
+}
+__device__ __forceinline__ void bt_split8(const float v[8], f16x8* p0, f16x8* p1) {
+  BtO a, b;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const _Float16 a = (_Float16)v[i];
-    (*p0)[i] = a;
-    (*p1)[i] = (_Float16)((v[i] - (float)a) * BT_RS);
-  }
+  for (int i = 0; i < 4; ++i) atvs_split2_f16(v[2 * i], v[2 * i + 1], BT_RS, &a.u[i], &b.u[i]);
+  *p0 = a.h;
+  *p1 = b.h;
+}
+
+// Workgroup barrier for LDS hand-offs that leaves global loads IN FLIGHT: __syncthreads() drains vmcnt too, which would turn every
+// prefetch issued in front of it into an exposed round trip.  LDS traffic is all the barriers of this kernel order.
+__device__ __forceinline__ void bt_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Sum of a double over the 16 lanes of a row (every lane ends with the row's sum), by DPP instead of four ds_bpermute round trips:
+// quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror -- the partners hold equal partial sums, so the values are
+// those of the xor butterfly.
+template <int CTRL>
+__device__ __forceinline__ double bt_dpp_add(double a) {
+  const long long b = __builtin_bit_cast(long long, a);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return a + __builtin_bit_cast(double, ((long long)hi << 32) | (long long)(unsigned)lo);
+}
+__device__ __forceinline__ double bt_row_sum(double a) {
+  a = bt_dpp_add<0xB1>(a);
+  a = bt_dpp_add<0x4E>(a);
+  a = bt_dpp_add<0x141>(a);
+  return bt_dpp_add<0x140>(a);
 }
 
 // C channels, dilation DIL, TH x 16 output pixels per workgroup; P2 / P4: WN waves across the channels x WR across the rows.
@@ -80,6 +120,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
   const int g = (int)(lin / p.tiles), tile = (int)(lin % p.tiles);
   const int y0 = (tile / p.tiles_x) * TH, x0 = (tile % p.tiles_x) * 16;
   const float* __restrict__ xg = p.x + (size_t)g * p.H * p.W * C;
+#ifdef ATVS_BT_DEBUG
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
 
   // ------------------------------------------------------------------ P1: conv1 over tile + halo, pixels split over the waves
   {
@@ -109,7 +153,28 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
       for (int n = 0; n < NT; ++n)
 #pragma unroll
         for (int w = 0; w < 2; ++w) A1[ch][n][w] = p.w1[((size_t)(ch * NT + n) * 2 + w) * 64 + lane];
+    // the pre-activation's parameters of this lane's eight channels per chunk and conv1's bias: ONCE, in front of the groups (inside
+    // the loop the compiler re-issued them per group and chunk: 72 loads and as many waits per tile)
     const float* ip = p.in_params + (size_t)g * 3 * C + q * 8;
+    float mm[NCH32][8], ss[NCH32][8], cc[NCH32][8];
+#pragma unroll
+    for (int ch = 0; ch < NCH32; ++ch) {
+      const float4 m0 = ld4(ip + ch * 32), m1 = ld4(ip + ch * 32 + 4);
+      const float4 s0 = ld4(ip + C + ch * 32), s1 = ld4(ip + C + ch * 32 + 4);
+      const float4 c0 = ld4(ip + 2 * C + ch * 32), c1 = ld4(ip + 2 * C + ch * 32 + 4);
+      const float m_[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+      const float s_[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+      const float c_[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { mm[ch][e] = m_[e]; ss[ch][e] = s_[e]; cc[ch][e] = c_[e]; }
+    }
+    float4 b1v[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) b1v[n] = ld4(p.b1 + n * 16 + 4 * q);
+#ifdef ATVS_BT_DEBUG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    BDBG(0)
+#endif
 #pragma unroll
     for (int i = 0; i < G1W; ++i) {
       if (wave + 4 * i >= NG1) continue;                 // wave-uniform
@@ -120,20 +185,10 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
       for (int ch = 0; ch < NCH32; ++ch) {
         // pre-activation (conv1x1_b's normalise-on-load: (v - mean) * scale + beta, ReLU), then the split
         float v[8] = {xa[i][ch].x, xa[i][ch].y, xa[i][ch].z, xa[i][ch].w, xb[i][ch].x, xb[i][ch].y, xb[i][ch].z, xb[i][ch].w};
-        const float4 m0 = ld4(ip + ch * 32), m1 = ld4(ip + ch * 32 + 4);
-        const float4 s0 = ld4(ip + C + ch * 32), s1 = ld4(ip + C + ch * 32 + 4);
-        const float4 c0 = ld4(ip + 2 * C + ch * 32), c1 = ld4(ip + 2 * C + ch * 32 + 4);
-        const float mm[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
-        const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
-        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
         f16x8 h0, h1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          float t = in[i] ? fmaxf((v[e] - mm[e]) * ss[e] + cc[e], 0.f) : 0.f;
-          const _Float16 a = (_Float16)t;
-          h0[e] = a;
-          h1[e] = (_Float16)((t - (float)a) * BT_RS);
-        }
+        for (int e = 0; e < 8; ++e) v[e] = in[i] ? fmaxf((v[e] - mm[ch][e]) * ss[ch][e] + cc[ch][e], 0.f) : 0.f;
+        bt_split8(v, &h0, &h1);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
           acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[ch][n][0], h0, acc[n], 0, 0, 0);
@@ -146,8 +201,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
       unsigned char* d = smem + hp[i] * PITCH + q * 8;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
-        const float4 bb = ld4(p.b1 + n * 16 + 4 * q);
-        const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+        const float bv[4] = {b1v[n].x, b1v[n].y, b1v[n].z, b1v[n].w};
         float v[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -162,7 +216,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
       }
     }
   }
-  __syncthreads();
+  BDBG(1)
+  bt_lds_barrier();
+  BDBG(2)
 
   // ------------------------------------------------------------------ P2: conv2 from the r1 image
   f32x4 acc[TY][NTW], accx[TY][NTW];
@@ -170,6 +226,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
   for (int t = 0; t < TY; ++t)
 #pragma unroll
     for (int n = 0; n < NTW; ++n) acc[t][n] = accx[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 b2v[NTW];                   // in front of P2: vector-memory results return in order, a load issued behind P3's prefetches
+#pragma unroll                       // would wait for all of them
+  for (int n = 0; n < NTW; ++n) b2v[n] = ld4(p.b2 + (wn * NTW + n) * 16 + 4 * q);
   {
     // fragment of step j: tap 2 j + (q >> 1) (the 10th tap has zero weights: the 9th tap's data), channels (q & 1) * 8 .. of the
     // 16-channel chunk; row 0 of this wave's rows
@@ -183,49 +242,82 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
     // packed weights: [K step = chunk * 5 + j][NT tiles][2 pieces][64 lanes], one zero step of padding at the end
     const f16x8* __restrict__ wl = p.w2 + (size_t)(wn * NTW) * 2 * 64 + lane;
     constexpr int WSTEP = NT * 2 * 64;
-    f16x8 Aw[2][NTW][2];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n)
-#pragma unroll
-      for (int w = 0; w < 2; ++w) Aw[0][n][w] = wl[(n * 2 + w) * 64];
-#pragma unroll
-    for (int s = 0; s < NCH16 * JS; ++s) {
-      const int ch = s / JS, j = s % JS, cur = s & 1;
+    // weights two K steps ahead (three register slots: an L2 round trip is longer than one step's 12 * NTW MFMAs), fragments one
+    // step ahead (two slots); the requests of a step are pinned in front of its MFMAs
+    constexpr int S2 = NCH16 * JS;
+    f16x8 Aw[3][NTW][2];
+    auto request_a = [&](int slot, int step) __attribute__((always_inline)) {
 #pragma unroll
       for (int n = 0; n < NTW; ++n)
 #pragma unroll
-        for (int w = 0; w < 2; ++w) Aw[cur ^ 1][n][w] = wl[(size_t)(s + 1) * WSTEP + (n * 2 + w) * 64];
-      f16x8 B0[TY], B1[TY];
+        for (int w = 0; w < 2; ++w) Aw[slot][n][w] = wl[(size_t)step * WSTEP + (n * 2 + w) * 64];
+    };
+    f16x8 Bq[2][2][TY];
+    auto request_b = [&](int slot, int step) __attribute__((always_inline)) {
+      const int ch = step / JS, j = step % JS;
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
         const unsigned char* a = smem + bd[j] + t * (HC * PITCH) + ch * 32;
-        B0[t] = *reinterpret_cast<const f16x8*>(a);
-        B1[t] = *reinterpret_cast<const f16x8*>(a + PIMG);
+        Bq[slot][0][t] = *reinterpret_cast<const f16x8*>(a);
+        Bq[slot][1][t] = *reinterpret_cast<const f16x8*>(a + PIMG);
       }
+    };
+    request_a(0, 0);
+    request_a(1, 1);
+    request_b(0, 0);
+#pragma unroll
+    for (int s = 0; s < S2; ++s) {
+      const int cur = s % 3, bc = s & 1;
+      if (s + 2 <= S2) request_a((s + 2) % 3, s + 2);          // step S2 = the pack's zero padding step: never multiplied
+      if (s + 1 < S2) request_b(bc ^ 1, s + 1);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int n = 0; n < NTW; ++n) {
 #pragma unroll
-        for (int t = 0; t < TY; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[cur][n][0], B0[t], acc[t][n], 0, 0, 0);
+        for (int t = 0; t < TY; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[cur][n][0], Bq[bc][0][t], acc[t][n], 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[cur][n][1], B0[t], accx[t][n], 0, 0, 0);
+        for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[cur][n][1], Bq[bc][0][t], accx[t][n], 0, 0, 0);
       }
 #pragma unroll
       for (int n = 0; n < NTW; ++n)
 #pragma unroll
-        for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[cur][n][0], B1[t], accx[t][n], 0, 0, 0);
+        for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(Aw[cur][n][0], Bq[bc][1][t], accx[t][n], 0, 0, 0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
-  __syncthreads();                              // every wave has read its last r1 fragment
+  BDBG(3)
+  bt_lds_barrier();                             // every wave has read its last r1 fragment
 
   // ------------------------------------------------------------------ P3: r2 = relu(. + b2) as pieces over the r1 image
+  // conv3's weight pieces, the identity shortcut and b3: requested HERE, a whole phase in front of their use (inside P4 every one
+  // of them cost an exposed L2 / HBM round trip)
+  const int xo = x0 + r;
+  float4 rr[TY][NTW], b3v[NTW];
+#pragma unroll
+  for (int n = 0; n < NTW; ++n) b3v[n] = ld4(p.b3 + (wn * NTW + n) * 16 + 4 * q);
+#pragma unroll
+  for (int t = 0; t < TY; ++t) {
+    const int yo = y0 + wr * TY + t;
+    const bool ok = yo < p.H && xo < p.W;
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+      rr[t][n] = ok ? ld4(xg + ((size_t)yo * p.W + xo) * C + (wn * NTW + n) * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  f16x8 A3[NCH32][NTW][2];
+#pragma unroll
+  for (int ch = 0; ch < NCH32; ++ch)
+#pragma unroll
+    for (int n = 0; n < NTW; ++n)
+#pragma unroll
+      for (int w = 0; w < 2; ++w) A3[ch][n][w] = p.w3[((size_t)(ch * NT + wn * NTW + n) * 2 + w) * 64 + lane];
 #pragma unroll
   for (int t = 0; t < TY; ++t) {
     unsigned char* d = smem + ((wr * TY + t) * 16 + r) * PITCH + q * 8;
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
-      const int co = (wn * NTW + n) * 16 + 4 * q;
-      const float4 bb = ld4(p.b2 + co);
-      const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+      const float bv[4] = {b2v[n].x, b2v[n].y, b2v[n].z, b2v[n].w};
       float v[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -239,7 +331,8 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
       *reinterpret_cast<f16x4*>(d + (wn * NTW + n) * 32 + PIMG) = p1;
     }
   }
-  __syncthreads();
+  bt_lds_barrier();
+  BDBG(4)
 
   // ------------------------------------------------------------------ P4: conv3 + b3 + x, moments of y
 #pragma unroll
@@ -248,11 +341,6 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
     for (int n = 0; n < NTW; ++n) acc[t][n] = accx[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int ch = 0; ch < NCH32; ++ch) {
-    f16x8 A3[NTW][2];
-#pragma unroll
-    for (int n = 0; n < NTW; ++n)
-#pragma unroll
-      for (int w = 0; w < 2; ++w) A3[n][w] = p.w3[((size_t)(ch * NT + wn * NTW + n) * 2 + w) * 64 + lane];
     f16x8 B0[TY], B1[TY];
 #pragma unroll
     for (int t = 0; t < TY; ++t) {
@@ -263,17 +351,17 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
 #pragma unroll
-      for (int t = 0; t < TY; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[n][0], B0[t], acc[t][n], 0, 0, 0);
+      for (int t = 0; t < TY; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[ch][n][0], B0[t], acc[t][n], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[n][1], B0[t], accx[t][n], 0, 0, 0);
+      for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[ch][n][1], B0[t], accx[t][n], 0, 0, 0);
     }
 #pragma unroll
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
-      for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[n][0], B1[t], accx[t][n], 0, 0, 0);
+      for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[ch][n][0], B1[t], accx[t][n], 0, 0, 0);
   }
 
-  const int xo = x0 + r;
+  BDBG(5)
   float ssum[NTW][4], ssq[NTW][4];
 #pragma unroll
   for (int n = 0; n < NTW; ++n)
@@ -290,10 +378,9 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
       const int co = (wn * NTW + n) * 16 + 4 * q;
       float4 v = make_float4(acc[t][n][0] + accx[t][n][0] * BT_IRS, acc[t][n][1] + accx[t][n][1] * BT_IRS,
                              acc[t][n][2] + accx[t][n][2] * BT_IRS, acc[t][n][3] + accx[t][n][3] * BT_IRS);
-      const float4 bb = ld4(p.b3 + co);
+      const float4 bb = b3v[n];
       v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
-      const float4 rr = ld4(xg + rowb + co);                   // the identity shortcut
-      v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+      v.x += rr[t][n].x; v.y += rr[t][n].y; v.z += rr[t][n].z; v.w += rr[t][n].w;       // the identity shortcut
       st4(yg + rowb + co, v);
       ssum[n][0] += v.x; ssum[n][1] += v.y; ssum[n][2] += v.z; ssum[n][3] += v.w;
       ssq[n][0] += v.x * v.x; ssq[n][1] += v.y * v.y; ssq[n][2] += v.z * v.z; ssq[n][3] += v.w * v.w;
@@ -308,12 +395,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        double a = (double)ssum[n][k], bq = (double)ssq[n][k];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          a += __shfl_xor(a, o);
-          bq += __shfl_xor(bq, o);
-        }
+        const double a = bt_row_sum((double)ssum[n][k]), bq = bt_row_sum((double)ssq[n][k]);
         if (r == 0) {
           const int c = (wn * NTW + n) * 16 + 4 * q + k;
           if (WR == 1) {
@@ -335,6 +417,13 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
       }
     }
   }
+#ifdef ATVS_BT_DEBUG
+  BDBG(6)
+  if (lane == 0 && blockIdx.x < 1024) {
+    dbg_acc[7] = 1;
+    for (int i = 0; i < 8; ++i) atvs_dbg_bt[(blockIdx.x * 4 + wave) * 8 + i] = dbg_acc[i];
+  }
+#endif
 }
 
 template <int C, int DIL, int TH, int WN, int WR>
@@ -351,16 +440,22 @@ int launch_bt(BtArgs a, hipStream_t s) {
   return ATVS_OK;
 }
 
-constexpr int BT_TH = 8;
+constexpr int bt_th(int C) { return C == 32 ? 16 : 8; }      // rows of a tile: 16 x 16 pixels at 32 channels, 8 x 16 at 64
 
 }  // namespace
+
+#ifdef ATVS_BT_DEBUG
+extern "C" int atvs_debug_read_bt(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(atvs_dbg_bt), sizeof(atvs_dbg_bt));
+}
+#endif
 
 // Shapes the fused unit is built for: depth 32 / 64 (conv0_x, conv1_x of ResNetDS2SPP), dilation 1.  The 128-channel units
 // (dilation 2 / 4) keep their three launches: their r1 tile + halo does not fit LDS next to a useful tile.
 extern "C" int atvs_bottleneck_b_supported(int C, int dilation) { return ((C == 32 || C == 64) && dilation == 1) ? 1 : 0; }
 
-// workgroups per image = rows per image of stats_partial ([2][C] doubles each): tiles of 8 x 16 pixels
-extern "C" long atvs_bottleneck_b_rows(int H, int W) { return (long)((H + BT_TH - 1) / BT_TH) * ((W + 15) / 16); }
+// workgroups per image = rows per image of stats_partial ([2][C] doubles each): tiles of 8 x 16 (C = 64) / 16 x 16 (C = 32) pixels
+extern "C" long atvs_bottleneck_b_rows(int C, int H, int W) { return (long)((H + bt_th(C) - 1) / bt_th(C)) * ((W + 15) / 16); }
 
 // y = x + conv3(relu(conv2(relu(conv1(relu(bn(x))) + b1)) + b2)) + b3 for G images (H, W, C), channel-last fp32.
 // in_params (G,3,C): the pre-activation batch norm (atvs_bn_finalize rows mean | scale | beta).  w1 / w3: atvs_conv1x1_b_pack of
@@ -381,8 +476,8 @@ extern "C" int atvs_bottleneck_b_f32(const float* x, const float* in_params, con
   a.tiles_x = a.tiles = 0; a.total = 0;
   hipStream_t s = as_stream(stream);
   int rc;
-  if (C == 64) rc = launch_bt<64, 1, BT_TH, 2, 2>(a, s);
-  else rc = launch_bt<32, 1, BT_TH, 1, 4>(a, s);
+  if (C == 64) rc = launch_bt<64, 1, bt_th(64), 2, 2>(a, s);
+  else rc = launch_bt<32, 1, bt_th(32), 1, 4>(a, s);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

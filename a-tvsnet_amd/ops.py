@@ -847,7 +847,7 @@ def bottleneck(x, in_params, keys, w1, b1, w2, b2, w3, b3, dilation=1, want_stat
     y = _new(x, x.shape)
     st, sbuf = None, None
     if want_stats:
-        rows = int(_lib.lib().atvs_bottleneck_b_rows(int(H), int(W)))
+        rows = int(_lib.lib().atvs_bottleneck_b_rows(int(C), int(H), int(W)))
         sbuf = torch.empty((G, rows, 2, C), dtype=torch.float64, device=x.device)
         st = Stats()
         st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, C, H * W, G

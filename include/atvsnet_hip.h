@@ -368,10 +368,10 @@ int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w, const floa
  * atvs_bn_finalize); conv1 is evaluated for the tile and its dilation halo, r1 and r2 stay in LDS as fp16 pieces.  Split fp16
  * operands, the K order and packed weights of the unfused kernels: w1 / w3 = atvs_conv1x1_b_pack of [C][C], w2 =
  * atvs_conv2d_b_pack of [3][3][C][C]; y is bit for bit what atvs_conv1x1_b_f32 -> atvs_conv2d_b_f32 -> atvs_conv1x1_b_f32 give.
- * stats_partial: NULL or (G, atvs_bottleneck_b_rows(H, W), 2, C) doubles: per-workgroup moments of y (the next unit's batch
+ * stats_partial: NULL or (G, atvs_bottleneck_b_rows(C, H, W), 2, C) doubles: per-workgroup moments of y (the next unit's batch
  * norm).  x and y may not alias.  Shapes: atvs_bottleneck_b_supported (C in {32, 64}, dilation 1). */
 int atvs_bottleneck_b_supported(int C, int dilation);
-long atvs_bottleneck_b_rows(int H, int W);
+long atvs_bottleneck_b_rows(int C, int H, int W);
 int atvs_bottleneck_b_f32(const float* x, const float* in_params, const unsigned char* w1, const float* b1,
                           const unsigned char* w2, const float* b2, const unsigned char* w3, const float* b3, float* y,
                           double* stats_partial, int G, int H, int W, int C, int dilation, atvs_stream_t stream);
