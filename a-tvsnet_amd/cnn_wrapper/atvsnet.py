@@ -43,7 +43,7 @@ def _stacked_unet(net, with_prob_head):
         skip2 = [n('4_0'), n('2_1')] + ([] if b == 0 else ['conv_b0_2_1'])
         net.feed(*skip2).add(name=n('4_1')).deconv_bn(3, f * 2, 2, name=n('5_0'), defer_bn=True)
         skip1 = [n('5_0'), n('1_1')] + ([] if b == 0 else ['conv_b0_1_1'])
-        net.feed(*skip1).add(name=n('5_1')).deconv_bn(3, f, 2, name=n('6_0'), defer_bn=True)
+        net.feed(*skip1).add(name=n('5_1'), defer=True).deconv_bn(3, f, 2, name=n('6_0'), defer_bn=True)     # summed on load
     net.feed('conv_b2_6_0', 'conv_b2_0_1').add(name='conv_b2_6_1')
     if with_prob_head:
         net.conv(3, 1, 1, relu=False, name='conv_b2_6_2')
@@ -174,7 +174,7 @@ class CostVolRefineNet(Network):
              .add(name=g + '3dconv4_1')
              .deconv_bn(3, f * 2, 2, name=g + '3dconv5_0', defer_bn=True))
         (self.feed(g + '3dconv5_0', g + '3dconv1_1')
-             .add(name=g + '3dconv5_1')
+             .add(name=g + '3dconv5_1', defer=True)          # summed on load by the transposed convolution
              .deconv_bn(3, f, 2, name=g + '3dconv6_0', defer_bn=True))
         (self.feed(g + '3dconv6_0', g + '3dconv0_1')
              .add(name=g + '3dconv6_1')

@@ -380,7 +380,10 @@ class Network(object):
         if rank != 5 or kernel_size != 3 or strides != 2 or padding != 'SAME' or biased:
             raise NotImplementedError('deconv_bn: only the 3-D k=3, stride-2, SAME, unbiased form used by '
                                       'cnn_wrapper/atvsnet.py is built')
-        x = self._bt(input, name)
+        if isinstance(input, ops.PendingSum) and self.training and (input.shape[0] == 1 or self.independent_samples):
+            x = input                          # a deferred skip sum: formed inside the launch where the kernel can (ops.deconv_sum_ok)
+        else:
+            x = self._bt(input, name)
         G = x.shape[0]
         vname = '%s/conv3d_transpose/kernel' % name
         w = self._kernel(vname, (3, 3, 3, filters, x.shape[-1]))
@@ -536,10 +539,10 @@ class Network(object):
     @layer
     def add(self, inputs, name, defer=False):
         '''tf.add_n (reference network.py:695-697).  Inputs whose batch norm is still pending (conv_bn /
-        deconv_bn with defer_bn=True) are normalised inside the add kernel.  defer=True (extension): a sum of two
-        whose consumer can add on load (conv_bn_siblings) is handed over unformed.'''
+        deconv_bn with defer_bn=True) are normalised inside the add kernel.  defer=True (extension): a sum of two or three
+        whose consumer can add on load (conv_bn_siblings, deconv_bn) is handed over unformed.'''
         inputs = [t.materialize() if isinstance(t, (ops.PendingSum, ops.LazySlice)) else t for t in inputs]
-        if defer and self.training and len(inputs) == 2 and all(t.dim() == 5 for t in inputs):
+        if defer and self.training and len(inputs) in (2, 3) and all(t.dim() == 5 for t in inputs):
             return ops.PendingSum([t if isinstance(t, ops.PendingBN) else self._bt(t, name) for t in inputs])
         if len(inputs) in (2, 3) and any(isinstance(t, ops.PendingBN) for t in inputs) \
                 and inputs[0].shape[-1] % 4 == 0:

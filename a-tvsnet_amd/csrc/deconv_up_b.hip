@@ -77,6 +77,14 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct UpBArgs {
   const float* x;
+  // PRO form: the input is the U-Net's skip SUM, formed while the halo is staged (the bn_add pass it replaces, norm.hip):
+  //   x_in = t(x, pa, bit 0) + t(x2, pb, bit 1) [+ t(x3, pc, bit 2)],  t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v
+  const float* x2;
+  const float* x3;            // null: two terms
+  const float* pa;            // (groups, 3, Cin) or null (that term is a finished tensor)
+  const float* pb;
+  const float* pc;
+  int relu_mask;
   const unsigned char* wp;
   const float* zeros;
   float* y;
@@ -104,8 +112,10 @@ __device__ __forceinline__ void ub_static_for(F&& f) {
 
 // STREAMW: the packed weights of ONE chunk live in LDS and are re-read from L2 at every stage (Cin too large for all chunks to
 // stay resident: the 64 -> 32 layer as two 16-channel launches)
-template <int COUT, bool STREAMW>
-__global__ __launch_bounds__(256, UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(UpBArgs p) {
+// PRO: the skip sum formed on load (Cin = 16: one chunk; one workgroup per CU -- the three sources of a stage are in flight in
+// 84 registers, which two workgroups per CU do not have)
+template <int COUT, bool STREAMW, bool PRO>
+__global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(UpBArgs p) {
   using U = UpB<COUT>;
   constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -151,6 +161,20 @@ __global__ __launch_bounds__(256, UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(U
     if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
   }
   const int nstage = my_tiles * p.nchunk;
+  // PRO: the other sources and the batch-norm rows of this thread's four channels (c4 = tid & 3 in every slot; one chunk)
+  const float* __restrict__ xg2 = PRO ? p.x2 + (size_t)grp * p.gx : nullptr;
+  const float* __restrict__ xg3 = (PRO && p.x3) ? p.x3 + (size_t)grp * p.gx : nullptr;
+  float4 bnm[3], bns[3], bnb[3];
+  if (PRO) {
+    const float* pr[3] = {p.pa, p.pb, p.pc};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      const float* q3 = pr[k] ? pr[k] + (size_t)grp * 3 * p.Cin + (tid & 3) * 4 : nullptr;
+      bnm[k] = q3 ? ld4(q3) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bns[k] = q3 ? ld4(q3 + p.Cin) : make_float4(1.f, 1.f, 1.f, 1.f);
+      bnb[k] = q3 ? ld4(q3 + 2 * p.Cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
   auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
     int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
     int bx = tl % p.tiles_x;
@@ -177,12 +201,32 @@ __global__ __launch_bounds__(256, UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(U
             ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
     return T;
   };
-  float4 pf[MAXS];
+  float4 pf[MAXS], pf2[PRO ? MAXS : 1], pf3[PRO ? MAXS : 1];
+  unsigned okm_next = 0;                   // PRO: which slots of the stage being fetched lie inside the volume (a term of 0 is not 0 after its batch norm)
   auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
     const unsigned t1 = pg[i] - T.lo;
     const unsigned t2 = T.hi1 + ~pg[i];
     const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
     pf[i] = ld4(ok ? (T.xb + (T.org + goff[i])) : p.zeros);
+    if (PRO) {
+      pf2[i] = ld4(ok ? (xg2 + (T.xb - xg) + (T.org + goff[i])) : p.zeros);
+      if (xg3) pf3[i] = ld4(ok ? (xg3 + (T.xb - xg) + (T.org + goff[i])) : p.zeros);
+      okm_next = (okm_next & ~(1u << i)) | ((ok ? 1u : 0u) << i);
+    }
+  };
+  // one term of the sum: bn_add_kernel's arithmetic (norm.hip), term k of this thread's channel group
+  auto pro_term = [&](const float4& v, int k, const float* par) __attribute__((always_inline)) {
+    float4 o = v;
+    if (par) {
+      o.x = (v.x - bnm[k].x) * bns[k].x + bnb[k].x;
+      o.y = (v.y - bnm[k].y) * bns[k].y + bnb[k].y;
+      o.z = (v.z - bnm[k].z) * bns[k].z + bnb[k].z;
+      o.w = (v.w - bnm[k].w) * bns[k].w + bnb[k].w;
+      if ((p.relu_mask >> k) & 1) {
+        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+      }
+    }
+    return o;
   };
 
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};       // scalar on purpose (two workgroups share a CU)
@@ -210,9 +254,21 @@ __global__ __launch_bounds__(256, UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(U
       float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
       for (int i = tid; i < U::WCH / 16; i += 256) dst[i] = src[i];
     }
+    const unsigned okm = okm_next;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) {
+        if (PRO) {
+          float4 a = pro_term(pf[i], 0, p.pa);
+          const float4 b = pro_term(pf2[i], 1, p.pb);
+          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+          if (xg3) {
+            const float4 d = pro_term(pf3[i], 2, p.pc);
+            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+          }
+          const bool in = (okm >> i) & 1u;
+          pf[i] = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
+        }
         uint2 p0, p1;
         atvs_split2_f16(pf[i].x, pf[i].y, UB_RS, &p0.x, &p1.x);
         atvs_split2_f16(pf[i].z, pf[i].w, UB_RS, &p0.y, &p1.y);
@@ -373,18 +429,18 @@ size_t ub_lds(int Cin, int Cout) {
 // all chunks resident if they fit, else one chunk at a time (Cout 16 only)
 bool ub_stream(int Cin, int Cout) { return Cout == 16 && ub_lds(Cin, Cout) > 160 * 1024; }
 
-template <int COUT, bool STREAMW>
+template <int COUT, bool STREAMW, bool PRO = false>
 int launch_upb(const UpBArgs& a, long grid, size_t lds, hipStream_t s) {
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_up_b_kernel<COUT, STREAMW>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_up_b_kernel<COUT, STREAMW, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((deconv_up_b_kernel<COUT, STREAMW>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((deconv_up_b_kernel<COUT, STREAMW, PRO>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -461,9 +517,42 @@ extern "C" long atvs_deconv_up_b_grid(int D, int H, int W, int Cout, int groups)
 // Contract of atvs_deconv_up_f32 with split operands (fp32-class results); grid / statistics rows = atvs_deconv_up_b_grid.
 // stats_ld / stats_coff: a statistics row is [2][stats_ld] doubles and this launch's channels start at column stats_coff
 // (16 / 0 = atvs_deconv_up_f32's layout; a wider layer computed 16 channels per launch passes its width and 0, 16, ...).
+namespace {
+int upb_launch(const float* x, const float* x2, const float* x3, const float* pa, const float* pb, const float* pc, int relu_mask,
+               bool pro, const unsigned char* packed_w, float* y, double* stats_partial, int groups, int D, int H, int W, int Cin,
+               int Cout, int ldy, int y_coff, int relu, int stats_ld, int stats_coff, atvs_stream_t stream);
+}
+
 extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups,
                                     int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, int stats_ld,
                                     int stats_coff, atvs_stream_t stream) {
+  return upb_launch(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, false, packed_w, y, stats_partial, groups, D, H, W, Cin, Cout,
+                    ldy, y_coff, relu, stats_ld, stats_coff, stream);
+}
+
+// The same transposed convolution of the SUM of two or three volumes that is never written: x_in = t(x0, params0, bit 0) +
+// t(x1, params1, bit 1) [+ t(x2, params2, bit 2)] with t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v -- exactly
+// atvs_bn_add's arithmetic and order, formed per staged halo voxel (the U-Net's skip adds in front of conv_b*_6_0 /
+// global_refine_3dconv6_0, reference cnn_wrapper/atvsnet.py:156-158,186-188,332-334).  params_i: (groups,3,Cin) or NULL (a
+// finished tensor); x2 NULL: two terms.  Built for Cin = 16, Cout = 8 (atvs_deconv_up_b_sum_supported); results bit for bit
+// those of atvs_bn_add followed by atvs_deconv_up_b_f32.
+extern "C" int atvs_deconv_up_b_sum_supported(int Cin, int Cout) { return (Cin == 16 && Cout == 8) ? 1 : 0; }
+
+extern "C" int atvs_deconv_up_b_sum_f32(const float* x0, const float* params0, const float* x1, const float* params1,
+                                        const float* x2, const float* params2, int relu_mask, const unsigned char* packed_w,
+                                        float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout,
+                                        int ldy, int y_coff, int relu, int stats_ld, int stats_coff, atvs_stream_t stream) {
+  if (!x0 || !x1) return ATVS_ERR_NULL;
+  if (!atvs_deconv_up_b_sum_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
+  if (!x2 && params2) return ATVS_ERR_ARG;
+  return upb_launch(x0, x1, x2, params0, params1, params2, relu_mask, true, packed_w, y, stats_partial, groups, D, H, W, Cin, Cout,
+                    ldy, y_coff, relu, stats_ld, stats_coff, stream);
+}
+
+namespace {
+int upb_launch(const float* x, const float* x2, const float* x3, const float* pa, const float* pb, const float* pc, int relu_mask,
+               bool pro, const unsigned char* packed_w, float* y, double* stats_partial, int groups, int D, int H, int W, int Cin,
+               int Cout, int ldy, int y_coff, int relu, int stats_ld, int stats_coff, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (stats_ld < 16 || stats_coff < 0 || stats_coff + (stats_ld == 16 ? 16 : Cout) > stats_ld) return ATVS_ERR_ARG;
   if (!atvs_deconv_up_b_supported(Cin, Cout) || groups <= 0 || D <= 0 || H <= 0 || W <= 0) return ATVS_ERR_SHAPE;
@@ -471,9 +560,10 @@ extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_
   if ((double)D * H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
   if (8.0 * D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;
   UpBArgs a;
-  long pb;
-  atvs_deconv_up_b_pack_size(Cin, Cout, &pb);
-  a.x = x; a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  long pbytes;
+  atvs_deconv_up_b_pack_size(Cin, Cout, &pbytes);
+  a.x = x; a.x2 = x2; a.x3 = x3; a.pa = pa; a.pb = pb; a.pc = pc; a.relu_mask = relu_mask;
+  a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pbytes - 16));
   a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16; a.relu = relu;
   a.stats_ld = stats_ld; a.stats_coff = stats_coff;
@@ -487,9 +577,11 @@ extern "C" int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_
   hipStream_t st = as_stream(stream);
   const bool stream_w = ub_stream(Cin, Cout);
   const size_t lds = stream_w ? UB_NP * (size_t)UpB<16>::IMG + UpB<16>::WCH : ub_lds(Cin, Cout);
-  int rc = (Cout == 8) ? launch_upb<8, false>(a, blocks * groups, lds, st)
-                       : stream_w ? launch_upb<16, true>(a, blocks * groups, lds, st) : launch_upb<16, false>(a, blocks * groups, lds, st);
+  int rc = pro ? launch_upb<8, false, true>(a, blocks * groups, lds, st)
+               : (Cout == 8) ? launch_upb<8, false>(a, blocks * groups, lds, st)
+                             : stream_w ? launch_upb<16, true>(a, blocks * groups, lds, st) : launch_upb<16, false>(a, blocks * groups, lds, st);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
+}  // namespace

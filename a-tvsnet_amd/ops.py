@@ -32,6 +32,8 @@ class Config(object):
     conv_c16, deconv_up, stem, conv2d_lds, conv1x1, xp1w, xpair, siblings, bottleneck
                    the dedicated kernel of that layer family in front of the generic ones
     prologue       normalise-on-load / add-on-load in the consumers (else pending batch norms / sums are materialised first)
+    sum_on_load    the U-Net's skip sums formed inside their consumer's staging (transposed convolution, 16-channel convolution)
+                   instead of a bn_add pass (needs prologue)
     force_impl     None (automatic) | 'tiled' | 'gather': the generic convolution kernel to use
     fused_finalize batch-norm moments finished inside the convolution launch (measured slower: off)
     side_streams   independent small launches of one layer on side streams (parallel branches of a captured graph)
@@ -45,7 +47,8 @@ class Config(object):
         planar_concat=os.environ.get('ATVS_PLANAR_CONCAT', '1') != '0',
         conv_c16=True, deconv_up=True, stem=True, conv2d_lds=True, conv1x1=True, xp1w=True, xpair=True, siblings=True,
         bottleneck=os.environ.get('ATVS_BOTTLENECK', '1') != '0',
-        prologue=True, force_impl=None, fused_finalize=False, side_streams=True)
+        prologue=True, sum_on_load=os.environ.get('ATVS_SUM_ON_LOAD', '1') != '0', force_impl=None, fused_finalize=False,
+        side_streams=True)
 
     def __init__(self):
         for k, v in self._DEFAULTS.items():
@@ -1665,12 +1668,41 @@ def _deconv_virtual_kernel(key, w_host):
     return hit
 
 
+def deconv_sum_ok(src, cout, groups=None):
+    """Can conv3d_transpose_s2 take this PendingSum as it is (atvs_deconv_up_b_sum_f32 forms it while staging)?"""
+    if not (cfg.prologue and cfg.sum_on_load and cfg.force_impl is None and cfg.deconv_up and split_on('upb')) or src._final is not None:
+        return False
+    shape = tuple(src.shape)
+    if len(shape) != (5 if groups is not None else 4):
+        return False
+    cin = shape[-1]
+    if not (deconv_up_ok(cin, cout) and _lib.lib().atvs_deconv_up_b_sum_supported(int(cin), int(cout))):
+        return False
+    gs = set()
+    for t in src.items:
+        raw = t.raw if isinstance(t, PendingBN) else t
+        if isinstance(t, PendingBN) and (t.planar or (t._final is None and t.params.numel() != (groups or 1) * 3 * cin)):
+            return False
+        if not raw.is_contiguous():
+            return False
+    return True
+
+
 def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=None):
     """tf.layers.conv3d_transpose(3, stride 2, SAME): (D,H,W,Cin) -> (2D,2H,2W,Cout) (groups=G: G samples).
 
     w_host: TF layout [3,3,3,Cout,Cin].  LDS-tiled path: all 8 output parity classes from one staged
     input tile per workgroup (N axis = class x channel); fallback: one gather launch per class.
     """
+    terms = None
+    if isinstance(x, PendingSum):
+        # the skip sum formed inside the launch where the kernel is built for it (deconv_sum_ok), else formed first
+        if x._final is None and deconv_sum_ok(x, int(w_host.shape[-2]), groups):
+            terms = [(t.raw, t.params, t.relu) if (isinstance(t, PendingBN) and t._final is None)
+                     else ((t.materialize() if isinstance(t, PendingBN) else t), None, False) for t in x.items]
+            x = terms[0][0]
+        else:
+            x = x.materialize()
     x5, nsp = _to5(x, groups, 'conv3d_transpose input')
     G, D, H, W, Cin = x5.shape
     cout = int(w_host.shape[-2])
@@ -1689,9 +1721,17 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
             sbuf = _stats_buffer(x, blocks, 16, groups=G)
             st = Stats()
             st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, blocks, 16, 8 * M, G
-        if _dev_ok(x5, y5):
+        if terms is not None and not split:
+            raise RuntimeError('deconv_sum_ok admitted a sum the split-operand kernel does not take')
+        if _dev_ok(x5, y5, *[t for tr in (terms or []) for t in tr[:2]]):
             with _Timed(key, x5.shape[1:], cout, G):
-                if split:
+                if terms is not None:
+                    (xa, pa, ra), (xb, pb, rb) = terms[0], terms[1]
+                    xc, pc, rc = terms[2] if len(terms) > 2 else (None, None, False)
+                    _call('atvs_deconv_up_b_sum_f32', _p(xa), _p(pa), _p(xb), _p(pb), _p(xc), _p(pc),
+                          int(bool(ra)) | (int(bool(rb)) << 1) | (int(bool(rc)) << 2), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W,
+                          Cin, cout, cout, 0, int(bool(relu)), 16, 0, _stream())
+                elif split:
                     _call('atvs_deconv_up_b_f32', _p(x5), _p(pk.wp), _p(y5), _p(sbuf), G, D, H, W, Cin, cout, cout, 0,
                           int(bool(relu)), 16, 0, _stream())
                 else:
@@ -1899,12 +1939,13 @@ class PendingBN(object):
 
 
 class PendingSum(object):
-    """tf.add_n of two items (dense tensors or PendingBNs) that has not been formed yet: a consumer that can add on
-    load (conv_siblings) takes the items, any other consumer calls materialize() (= ops.bn_add / add_n)."""
+    """tf.add_n of two or three items (dense tensors or PendingBNs) that has not been formed yet: a consumer that can add on
+    load (conv_siblings: two items; conv3d_transpose_s2: two or three) takes the items, any other consumer calls
+    materialize() (= ops.bn_add / add_n)."""
 
     def __init__(self, items):
-        if len(items) != 2 or any(tuple(t.shape) != tuple(items[0].shape) for t in items):
-            raise ValueError('PendingSum: two items of one shape')
+        if len(items) not in (2, 3) or any(tuple(t.shape) != tuple(items[0].shape) for t in items):
+            raise ValueError('PendingSum: two or three items of one shape')
         # a chunk-planar raw buffer is not a channel-last operand: such an item enters the sum materialised
         self.items = [t.materialize() if isinstance(t, PendingBN) and t.planar else t for t in items]
         self._final = None
@@ -1932,6 +1973,8 @@ class PendingSum(object):
     def prologue(self):
         if self._final is not None:
             return self._final, None
+        if len(self.items) != 2:
+            raise ValueError('PendingSum.prologue: the x-pair kernels add two items on load')
         (a, pa), (b, pb) = (t.prologue() if isinstance(t, PendingBN) else (t, None) for t in self.items)
         return a, (b, pa[1] if pa else None, pb[1] if pb else None, bool(pa and pa[3]), bool(pb and pb[3]))
 
@@ -1973,7 +2016,7 @@ def siblings_prologue_ok(src):
     if isinstance(src, PendingBN):
         return src._final is None and src.shape[-1] % 16 == 0 and src.raw.is_contiguous()
     if isinstance(src, PendingSum):
-        if src._final is not None or src.shape[-1] % 16 != 8:
+        if src._final is not None or src.shape[-1] % 16 != 8 or len(src.items) != 2:
             return False
         if _xkind() == 'xb' and src.shape[-1] != 8:        # conv_xb's two-source form: one 8-channel chunk
             return False

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 31
+#define ATVS_ABI_VERSION 32
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -413,6 +413,19 @@ int atvs_deconv_up_b_pack(const float* w, int Cin, int Cout, unsigned char* pack
 int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y, double* stats_partial, int groups, int D, int H,
                          int W, int Cin, int Cout, int ldy, int y_coff, int relu, int stats_ld, int stats_coff,
                          atvs_stream_t stream);
+
+/* atvs_deconv_up_b_f32 over the SUM of two or three volumes that is never written (the U-Net's skip adds in front of
+ * conv_b*_6_0 / global_refine_3dconv6_0, reference cnn_wrapper/atvsnet.py:156-158,186-188,332-334):
+ *   x_in = t(x0, params0, bit 0) + t(x1, params1, bit 1) [+ t(x2, params2, bit 2)],
+ *   t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v                  (relu = that bit of relu_mask)
+ * -- atvs_bn_add's arithmetic and order, formed per staged halo voxel; params_i (groups,3,Cin) or NULL (a finished tensor),
+ * x2 NULL: two terms.  Bit for bit atvs_bn_add followed by atvs_deconv_up_b_f32.  Shapes: atvs_deconv_up_b_sum_supported
+ * (Cin = 16, Cout = 8: the full-resolution decoder; one workgroup per CU). */
+int atvs_deconv_up_b_sum_supported(int Cin, int Cout);
+int atvs_deconv_up_b_sum_f32(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
+                             const float* params2, int relu_mask, const unsigned char* packed_w, float* y, double* stats_partial,
+                             int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, int stats_ld,
+                             int stats_coff, atvs_stream_t stream);
 /* conv_bn(3, 8, 1) on a volume with ONE or TWO channels: the probability / visual-hull / geometric stems of the
  * refinement network (cnn_wrapper/atvsnet.py:300-311).  HBM-bound (432 FLOP per 36 B at one channel): FMA kernel with a
  * sliding register window along z, not MFMA (conv_stem.hip).  x (groups,D,H,W,Cin), Cin in {1,2}; w = the TF kernel

@@ -491,3 +491,37 @@ def test_refinement_net_planar_concat_equals_channel_last_concat(cuda, weights):
                          ref.get_output_by_name('global_refine_concat').clone()]
     for a, b in zip(res[True], res[False]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('G,shape,nterms', [(2, (6, 10, 20), 3), (1, (9, 17, 33), 2), (3, (4, 4, 16), 3), (2, (5, 7, 37), 2)])
+def test_deconv_sums_its_inputs_on_load_bitwise(cuda, G, shape, nterms):
+    """The full-resolution decoder conv_b*_6_0 (16 -> 8, reference cnn_wrapper/atvsnet.py:156-158,186-188) with its skip sum formed
+    while the halo is staged (atvs_deconv_up_b_sum_f32) against the same layer behind the bn_add pass it replaces: pending batch
+    norms with and without ReLU, a finished tensor among the terms, two and three terms, ragged tiles -- every bit and the
+    moments; and the sum really was not formed."""
+    from atvsnet_amd import ops
+    cin, cout = 16, 8
+    w = _rand((3, 3, 3, cout, cin), 5) * 0.2
+
+    def terms(seed):
+        ts = []
+        for k in range(nterms):
+            raw = _rand((G,) + shape + (cin,), seed + k).to(cuda)
+            if k == 1 and nterms == 3:
+                ts.append(raw)                                        # a finished tensor
+            else:
+                par = torch.stack([_rand((G, cin), seed + 10 + k) * 0.1, _rand((G, cin), seed + 30 + k).abs() + 0.5,
+                                   _rand((G, cin), seed + 20 + k) * 0.1], 1).to(cuda).contiguous()
+                ts.append(ops.PendingBN(raw, par, relu=(k != 2)))
+        return ts
+    s_on = ops.PendingSum(terms(40))
+    assert ops.deconv_sum_ok(s_on, cout, G)
+    got, st = ops.conv3d_transpose_s2(s_on, ('up-sum', cin), w.numpy(), want_stats=True, groups=G)
+    assert s_on._final is None                                        # never materialised
+    with ops.configure(prologue=False):
+        s_off = ops.PendingSum(terms(40))
+        assert not ops.deconv_sum_ok(s_off, cout, G)
+        ref, st_ref = ops.conv3d_transpose_s2(s_off, ('up-sum', cin), w.numpy(), want_stats=True, groups=G)
+        assert s_off._final is not None
+    assert torch.equal(got, ref)
+    assert torch.equal(ops.bn_params(st, cout, got), ops.bn_params(st_ref, cout, ref))
