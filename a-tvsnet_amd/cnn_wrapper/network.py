@@ -463,6 +463,13 @@ class Network(object):
             r = ops.conv(preact(), scope + '/conv1/weights', w1, bias=b1, relu=True, groups=G)
         w2 = self._kernel('%s/conv2/weights' % scope, (kernel_size, kernel_size, depth, depth))
         b2 = self._vec('%s/conv2/biases' % scope, depth, x)
+        if stride == 1 and self.training and kernel_size == 3 and ops.conv2d_tail_ok(depth, rate, r.shape[1], r.shape[2]):
+            # conv2 and conv3 in one launch (the 128-channel dilated units: their conv1 halo does not fit the fully fused unit)
+            out, st = ops.conv2d_tail(r, (scope + '/conv2/weights', scope + '/conv3/weights'), w2, b2,
+                                      self._kernel('%s/conv3/weights' % scope, (1, 1, depth, depth)),
+                                      self._vec('%s/conv3/biases' % scope, depth, x), residual=shortcut, dilation=rate)
+            out._atvs_stats = st
+            return out
         if stride == 1:
             r = ops.conv(r, scope + '/conv2/weights', w2, dilation=rate, bias=b2, relu=True, groups=G)
         else:

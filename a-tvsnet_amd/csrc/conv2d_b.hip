@@ -34,6 +34,9 @@ struct C2bArgs {
   const float* bias;
   const float* res;
   const float* in_params;
+  // TAIL form (a residual unit's conv2 AND conv3 in one launch): y = conv3_1x1(relu(conv2(x) + bias)) + b3 + res
+  const f16x8* w3;            // atvs_conv1x1_b_pack of conv3 [Cout][Cout]
+  const float* b3;
   float* y;
   double* stats;
   int G, H, W, Cin, Cout;
@@ -57,7 +60,15 @@ __device__ __forceinline__ void c2b_split(const float4& v, f16x4* p0, f16x4* p1)
 
 // NTW = 16-channel output tiles per wave, WR = row groups across the waves (4 / WR waves split the channels),
 // TY = rows per wave, DIL = dilation.  Cout = 16 * NTW * (4 / WR); tile = (TY * WR) rows x 16 columns.
-template <int NTW, int WR, int TY, int DIL>
+// Workgroup barrier for LDS hand-offs that leaves global loads in flight (bottleneck_b.hip)
+__device__ __forceinline__ void c2b_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// TAIL: the 1x1 convolution that follows in a residual unit (conv3, reference cnn_wrapper/network.py:598-601) runs in the same
+// launch: r2 = relu(conv2 + bias) leaves the accumulators as fp16 pieces into the (dead) image buffers -- conv3 needs all
+// channels of a pixel as K, and they are spread over the four waves -- and each wave multiplies its own output channels; bias b3,
+// the shortcut `res` and the moments of the unit's output in the common epilogue.  K order and packed weights of conv1x1_b.hip:
+// bit for bit conv2d_b followed by conv1x1_b.
+template <int NTW, int WR, int TY, int DIL, bool TAIL = false>
 __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int R = TY * WR;
@@ -211,6 +222,68 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
     chunk(std::integral_constant<int, 1>{}, ch + 1);
   }
 
+  if constexpr (TAIL) {
+    constexpr int XP = NT * 32 + 16;           // bytes per pixel of an exchange piece image (16 pixels x 16 B cover all banks)
+    constexpr int XIMG = R * 16 * XP;
+    // (the launch sizes LDS for the larger of the two image buffers and the two exchange images)
+    static_assert(NT % 2 == 0, "conv3 runs in 32-channel chunks");
+    // conv3's weight pieces of this wave's output tiles, b3 and the shortcut: requested in front of the exchange
+    f16x8 A3[NT / 2][NTW][C2B_NP];
+#pragma unroll
+    for (int ch = 0; ch < NT / 2; ++ch)
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int w3 = 0; w3 < C2B_NP; ++w3) A3[ch][n][w3] = p.w3[((size_t)(ch * NT + wn * NTW + n) * C2B_NP + w3) * 64 + lane];
+    float4 b2v[NTW];
+#pragma unroll
+    for (int n = 0; n < NTW; ++n) b2v[n] = p.bias ? ld4(p.bias + (wn * NTW + n) * 16 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+    c2b_lds_barrier();                         // every wave has read its last fragment of the images
+#pragma unroll
+    for (int t = 0; t < TY; ++t) {
+      unsigned char* d = smem + ((wr * TY + t) * 16 + r) * XP + q * 8;
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+        float4 v = make_float4(acc[t][n][0] + accx[t][n][0] * C2B_IRS, acc[t][n][1] + accx[t][n][1] * C2B_IRS,
+                               acc[t][n][2] + accx[t][n][2] * C2B_IRS, acc[t][n][3] + accx[t][n][3] * C2B_IRS);
+        if (p.bias) { v.x += b2v[n].x; v.y += b2v[n].y; v.z += b2v[n].z; v.w += b2v[n].w; }
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+        f16x4 p0, p1;
+        c2b_split(v, &p0, &p1);
+        *reinterpret_cast<f16x4*>(d + (wn * NTW + n) * 32) = p0;
+        *reinterpret_cast<f16x4*>(d + (wn * NTW + n) * 32 + XIMG) = p1;
+      }
+    }
+    c2b_lds_barrier();
+#pragma unroll
+    for (int t = 0; t < TY; ++t)
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) acc[t][n] = accx[t][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NT / 2; ++ch) {
+      f16x8 B0[TY], B1[TY];
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        const unsigned char* a = smem + ((wr * TY + t) * 16 + r) * XP + ch * 64 + q * 16;
+        B0[t] = *reinterpret_cast<const f16x8*>(a);
+        B1[t] = *reinterpret_cast<const f16x8*>(a + XIMG);
+      }
+#pragma unroll
+      for (int n = 0; n < NTW; ++n) {
+#pragma unroll
+        for (int t = 0; t < TY; ++t) acc[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[ch][n][0], B0[t], acc[t][n], 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[ch][n][1], B0[t], accx[t][n], 0, 0, 0);
+      }
+#pragma unroll
+      for (int n = 0; n < NTW; ++n)
+#pragma unroll
+        for (int t = 0; t < TY; ++t) accx[t][n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A3[ch][n][0], B1[t], accx[t][n], 0, 0, 0);
+    }
+  }
+  const float* ebias = TAIL ? p.b3 : p.bias;
+  const bool erelu = TAIL ? false : (p.relu != 0);
+
   // ---- epilogue: lane holds channels co..co+3 of pixel (y0 + wr*TY + t, x0 + r)
   const int xo = x0 + r;
   float ssum[NTW][4], ssq[NTW][4];
@@ -230,15 +303,15 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
       const int co = (wn * NTW + n) * 16 + 4 * q;
       float4 v = make_float4(acc[t][n][0] + accx[t][n][0] * C2B_IRS, acc[t][n][1] + accx[t][n][1] * C2B_IRS,
                              acc[t][n][2] + accx[t][n][2] * C2B_IRS, acc[t][n][3] + accx[t][n][3] * C2B_IRS);
-      if (p.bias) {
-        const float4 bb = ld4(p.bias + co);
+      if (ebias) {
+        const float4 bb = ld4(ebias + co);
         v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
       }
       if (rg) {
         const float4 rr = ld4(rg + rowb + co);
         v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
       }
-      if (p.relu) {
+      if (erelu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
       st4(yg + rowb + co, v);
@@ -251,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
     // a column of row groups (combined through LDS).
     double* row = p.stats + (size_t)lin * 2 * p.Cout;
     double* s_red = reinterpret_cast<double*>(smem);           // [wr][2][Cout], the images are dead
-    if (WR > 1) __syncthreads();
+    if (WR > 1 || TAIL) __syncthreads();       // s_red lies over the images / the exchange images
 #pragma unroll
     for (int n = 0; n < NTW; ++n)
 #pragma unroll
@@ -285,13 +358,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
   }
 }
 
-template <int NTW, int WR, int TY, int DIL>
+template <int NTW, int WR, int TY, int DIL, bool TAIL = false>
 int launch_c2b(const C2bArgs& a, hipStream_t s) {
   constexpr int R = TY * WR, HR = R + 2 * DIL;
   size_t lds = (size_t)2 * C2B_NP * HR * C2B_ROWB;
+  if (TAIL) {
+    constexpr size_t xch = (size_t)2 * R * 16 * ((NTW * (4 / WR)) * 32 + 16);
+    if (xch > lds) lds = xch;
+  }
   const long blocks = ((a.total + 7) / 8) * 8;
   if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  hipLaunchKernelGGL((conv2d_b_kernel<NTW, WR, TY, DIL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv2d_b_kernel<NTW, WR, TY, DIL, TAIL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -338,10 +415,10 @@ extern "C" int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned ch
 
 // Same contract as atvs_conv2d_lds_f32 (shapes, statistics rows = atvs_conv2d_lds_rows) with split-bf16 operands; weights from
 // atvs_conv2d_b_pack.  fp32-class results; rounding differs from the fp32 MFMA form.
-extern "C" int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
-                                 const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H,
-                                 int W, int Cin, int Cout, int dilation, int ldy, int y_coff, int relu,
-                                 atvs_stream_t stream) {
+namespace {
+int c2b_run(const float* x, const unsigned char* packed_w, const float* bias, const float* residual, const float* in_params,
+            int in_relu, const unsigned char* packed_w3, const float* b3, float* y, double* stats_partial, int G, int H, int W,
+            int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (G <= 0 || H <= 0 || W <= 0 || !atvs_conv2d_lds_supported(Cin, Cout, dilation) || (Cin % 32)) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
@@ -349,6 +426,7 @@ extern "C" int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, 
   if ((double)H * W * Cin >= 2147483648.0) return ATVS_ERR_SHAPE;
   C2bArgs a;
   a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.bias = bias; a.res = residual; a.in_params = in_params;
+  a.w3 = reinterpret_cast<const f16x8*>(packed_w3); a.b3 = b3;
   a.y = y; a.stats = stats_partial;
   a.G = G; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16;
   const int R = (Cout == 32) ? 8 : 4;
@@ -359,7 +437,10 @@ extern "C" int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, 
   a.total = (long)G * a.tiles;
   hipStream_t s = as_stream(stream);
   int rc = ATVS_ERR_ARG;
-  if (Cout == 128) {
+  if (packed_w3) {
+    if (dilation == 2) rc = launch_c2b<2, 1, 4, 2, true>(a, s);
+    else rc = launch_c2b<2, 1, 4, 4, true>(a, s);
+  } else if (Cout == 128) {
     if (dilation == 1) rc = launch_c2b<2, 1, 4, 1>(a, s);
     else if (dilation == 2) rc = launch_c2b<2, 1, 4, 2>(a, s);
     else rc = launch_c2b<2, 1, 4, 4>(a, s);
@@ -371,4 +452,30 @@ extern "C" int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, 
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
+}
+}  // namespace
+
+extern "C" int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
+                                 const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H,
+                                 int W, int Cin, int Cout, int dilation, int ldy, int y_coff, int relu,
+                                 atvs_stream_t stream) {
+  return c2b_run(x, packed_w, bias, residual, in_params, in_relu, nullptr, nullptr, y, stats_partial, G, H, W, Cin, Cout, dilation,
+                 ldy, y_coff, relu, stream);
+}
+
+// A residual unit's conv2 and conv3 in ONE launch (reference cnn_wrapper/network.py:585-601):
+//   y = conv3_1x1(relu(conv2_3x3_dil(x) + b2)) + b3 + residual
+// x (G,H,W,C) = r1, the unit's conv1 output; packed_w2 = atvs_conv2d_b_pack of [3][3][C][C], packed_w3 = atvs_conv1x1_b_pack of
+// [C][C]; residual (G,H,W,C) = the shortcut (identity or projection) or NULL; stats_partial: the moments of y, rows as
+// atvs_conv2d_lds_rows.  Built for the 128-channel dilated units (atvs_conv2d_b_tail_supported: C = 128, dilation 2 / 4) -- the
+// ones whose conv1 halo does not fit a fully fused unit (atvs_bottleneck_b_f32).  Bit for bit atvs_conv2d_b_f32 followed by
+// atvs_conv1x1_b_f32.
+extern "C" int atvs_conv2d_b_tail_supported(int C, int dilation) { return (C == 128 && (dilation == 2 || dilation == 4)) ? 1 : 0; }
+
+extern "C" int atvs_conv2d_b_tail_f32(const float* x, const unsigned char* packed_w2, const float* b2,
+                                      const unsigned char* packed_w3, const float* b3, const float* residual, float* y,
+                                      double* stats_partial, int G, int H, int W, int C, int dilation, atvs_stream_t stream) {
+  if (!packed_w3 || !b2 || !b3) return ATVS_ERR_NULL;
+  if (!atvs_conv2d_b_tail_supported(C, dilation)) return ATVS_ERR_SHAPE;
+  return c2b_run(x, packed_w2, b2, residual, nullptr, 0, packed_w3, b3, y, stats_partial, G, H, W, C, C, dilation, C, 0, 1, stream);
 }

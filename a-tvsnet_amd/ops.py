@@ -864,6 +864,34 @@ def bottleneck(x, in_params, keys, w1, b1, w2, b2, w3, b3, dilation=1, want_stat
     return (y, st) if want_stats else y
 
 
+def conv2d_tail_ok(C, dilation, H, W):
+    """Do a residual unit's conv2 (3x3, dilated) and conv3 (1x1) of this shape run as ONE launch (atvs_conv2d_b_tail_f32)?"""
+    return (cfg.bottleneck and cfg.force_impl is None and cfg.conv1x1 and cfg.conv2d_lds and split_on('btl') and split_on('c1b')
+            and split_on('c2b') and H >= 8 and W >= 16 and bool(_lib.lib().atvs_conv2d_b_tail_supported(int(C), int(dilation))))
+
+
+def conv2d_tail(x, keys, w2, b2, w3, b3, residual=None, dilation=1, want_stats=True):
+    """y = conv3_1x1(relu(conv2_3x3_dil(x) + b2)) + b3 [+ residual] for x (G,H,W,C): conv2 and conv3 of Network.bottleneck
+    (reference cnn_wrapper/network.py:585-601) in one launch.  keys = the pack-cache keys of the two kernels (the unfused path's).
+    Returns (y, Stats of y)."""
+    G, H, W, C = x.shape
+    p2, p3 = pack_conv2d_lds(keys[0], w2, x.device), pack_conv1x1(keys[1], w3, C, x.device)
+    if p2.kind != 'b' or p3.kind != '_b' or (p2.cout, p3.cout) != (C, C):
+        raise ValueError('conv2d_tail: the split-operand packs of two C -> C kernels')
+    y = _new(x, x.shape)
+    st, sbuf = None, None
+    if want_stats:
+        rows = int(_lib.lib().atvs_conv2d_lds_rows(H, W, C))
+        sbuf = torch.empty((G, rows, 2, C), dtype=torch.float64, device=x.device)
+        st = Stats()
+        st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, C, H * W, G
+    if _dev_ok(x, y, b2, b3, residual):
+        with _Timed(keys[0], (1, H, W, C), C, G):
+            _call('atvs_conv2d_b_tail_f32', _p(x), _p(p2.wp), _p(b2), _p(p3.wp), _p(b3), _p(residual), _p(y),
+                  ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, H, W, C, int(dilation), _stream())
+    return (y, st) if want_stats else y
+
+
 def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, plane_bias=None, sibling=None,
                    prologue=None, planar=False, ldy=None, y_gstride=0, y_off=0, pieces=False):
     """One x-pair launch (atvs_conv_xb_f32 / atvs_conv_xw_f32): x5 (G,D,H,W,Cin) -> y (G,D,H,W,ldy)[..., y_coff:y_coff+8].

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 32
+#define ATVS_ABI_VERSION 33
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -333,6 +333,18 @@ int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed)
 int atvs_conv2d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
                       const float* in_params, int in_relu, float* y, double* stats_partial, int G, int H, int W, int Cin,
                       int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream);
+
+/* A residual unit's conv2 AND conv3 in one launch (reference cnn_wrapper/network.py:585-601; conv2d_b.hip, TAIL form):
+ *   y = conv3_1x1(relu(conv2_3x3_dil(x) + b2)) + b3 + residual
+ * x (G,H,W,C) = the unit's conv1 output; packed_w2 = atvs_conv2d_b_pack of [3][3][C][C], packed_w3 = atvs_conv1x1_b_pack of
+ * [C][C]; residual (G,H,W,C) = the shortcut or NULL; stats_partial: moments of y (rows: atvs_conv2d_lds_rows) or NULL.  r2 crosses
+ * the wavefronts through LDS as fp16 pieces.  For the 128-channel dilated units (atvs_conv2d_b_tail_supported: C = 128, dilation
+ * 2 / 4), whose conv1 halo does not fit the fully fused unit (atvs_bottleneck_b_f32).  Bit for bit atvs_conv2d_b_f32 followed by
+ * atvs_conv1x1_b_f32. */
+int atvs_conv2d_b_tail_supported(int C, int dilation);
+int atvs_conv2d_b_tail_f32(const float* x, const unsigned char* packed_w2, const float* b2, const unsigned char* packed_w3,
+                           const float* b3, const float* residual, float* y, double* stats_partial, int G, int H, int W, int C,
+                           int dilation, atvs_stream_t stream);
 
 /* 1x1 convolution of feature maps (the bottlenecks' conv1 / conv3 / shortcut, fusion1: slim.conv2d 1x1,
  * network.py:573-601; cnn_wrapper/atvsnet.py:254-292) as a tall GEMM: weights staged once per workgroup in LDS, pixels

@@ -831,3 +831,34 @@ def test_residual_block_with_fused_units_equals_unfused(cuda, weights):
     assert unit(launches[True], 'conv1_x_1') == 1 and unit(launches[False], 'conv1_x_1') == 3
     assert unit(launches[True], 'conv1_x') == 1 and unit(launches[True], 'conv1_x_0') == 4
     assert len(launches[False]) - len(launches[True]) == 2 * 7
+
+
+@pytest.mark.parametrize('dil,H,W,G,proj', [(2, 128, 160, 5, False), (4, 128, 160, 5, False), (4, 13, 37, 2, True), (2, 9, 17, 1, False),
+                                            (4, 40, 32, 2, True)])
+def test_conv2_and_conv3_of_a_unit_in_one_launch_bitwise(cuda, dil, H, W, G, proj):
+    """conv2d_b.hip's TAIL form: conv2 (3x3, dilation 2 / 4) and conv3 (1x1) + shortcut of a 128-channel residual unit (reference
+    cnn_wrapper/network.py:585-601) in one launch -- r2 crosses the wavefronts through LDS as fp16 pieces.  Bit for bit the two
+    launches it replaces, at the tower's size and ragged ones, with the identity shortcut and a separate (projection) tensor;
+    against the oracle's convolutions; its moments against the output's own."""
+    from atvsnet_amd import ops
+    C = 128
+    g = torch.Generator().manual_seed(7 * dil + H)
+    r1 = torch.clamp(torch.randn(G, H, W, C, generator=g), min=0)
+    sc = torch.randn(G, H, W, C, generator=g)
+    w2 = torch.randn(3, 3, C, C, generator=g) * (1.0 / (9 * C)) ** 0.5
+    w3 = torch.randn(1, 1, C, C, generator=g) * (1.0 / C) ** 0.5
+    b2, b3 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    assert ops.conv2d_tail_ok(C, dil, H, W)
+    keys = (('tail', dil, H, 2), ('tail', dil, H, 3))
+    rd, scd = r1.to(cuda), (sc.to(cuda) if proj else r1.to(cuda))
+    y, st = ops.conv2d_tail(rd, keys, w2.numpy(), b2.to(cuda), w3.numpy(), b3.to(cuda), residual=scd, dilation=dil)
+    r2 = ops.conv(rd, keys[0], w2.numpy(), dilation=dil, bias=b2.to(cuda), relu=True, groups=G)
+    ref, st_ref = ops.conv(r2, keys[1], w3.numpy(), bias=b3.to(cuda), residual=scd, want_stats=True, groups=G)
+    assert torch.equal(y, ref)
+    want = T.conv(torch.clamp(T.conv(r1, w2, 1, 'SAME', dil, bias=b2), min=0), w3, 1, 'SAME', bias=b3) + (sc if proj else r1)
+    assert float((y.cpu() - want).abs().max()) <= 3e-5 * float(want.abs().max())
+    # the moments: rows per 4 x 16 tile here, per 128 pixels in conv1x1_b -- the same sums in another grouping
+    p, p_ref = ops.bn_params(st, C, y), ops.bn_params(st_ref, C, ref)
+    assert float((p - p_ref).abs().max()) <= 1e-6 * float(p_ref.abs().max())
+    flat = y.reshape(G, -1, C).double()
+    assert float((p.reshape(G, 3, C)[:, 0].double() - flat.mean(1)).abs().max()) <= 1e-5
