@@ -263,6 +263,13 @@ class GraphedInference(object):
         self.graph.replay()
         return self.out
 
+    def checked(self, images=None, cams=None):
+        """__call__, then wait for the depth map and raise FloatingPointError if a batch norm of this replay saw non-finite
+        moments (an fp16-range overflow of the split-operand kernels; check_device)."""
+        out = self(images, cams)
+        check_device(out.device)
+        return out
+
 
 class PipelinedInference(object):
     """`slots` depth maps queued: one captured graph (static buffers) and one HIP stream per slot.
@@ -327,6 +334,7 @@ class PipelinedInference(object):
             raise RuntimeError('PipelinedInference: nothing in flight on slot %d' % ticket)
         self.events[ticket].synchronize()
         self.busy[ticket] = False
+        check_device(self.device)                 # an fp16-range overflow of the split-operand kernels is reported, not returned
         return self.graphs[ticket].out
 
     def run(self, count):
@@ -400,10 +408,27 @@ def write_error_xlsx(path, error, view_num):
     workbook.close()
 
 
+_RANGE_HINT = ('an activation or weight left the fp16 range of the split-operand kernels (or the inputs were not finite); rerun with '
+               'ATVS_SPLIT16=0 for the fp32 kernels')
+
+
+def check_device(device=None):
+    """Raise if a batch norm on `device` saw a non-finite moment since the last check (the sticky flag atvs_bn_finalize sets,
+    ops.nonfinite_seen): catches an fp16-range overflow of the split-operand kernels even where a later ReLU swallowed the NaN
+    before it could reach the depth map.  Synchronises with the device; GraphedInference.checked() / PipelinedInference.result()
+    and the host drivers call it on every result they hand out."""
+    from .. import ops
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+    if ops.nonfinite_seen(device):
+        raise FloatingPointError('a batch norm saw non-finite moments: ' + _RANGE_HINT)
+
+
 def check_finite(arr, what='depth map'):
-    """The split-operand convolutions carry activations as two fp16 pieces (DESIGN.md section 4): a value beyond +-65504 turns
+    """The split-operand convolutions carry activations as two fp16 pieces (DESIGN.md section 8): a value beyond +-65504 turns
     into inf/NaN there instead of a silently wrong depth.  The host drivers call this on every result they copy back so that
     the failure names its cause (ATVS_SPLIT16=0 selects the fp32 matrix-core kernels, which have fp32's range)."""
+    if torch.cuda.is_available() and torch.cuda.is_initialized():
+        check_device()
     if not np.isfinite(arr).all():
         raise FloatingPointError('%s holds %d non-finite values: an activation or weight left the fp16 range of the split-operand '
                                  'kernels (or the inputs were not finite); rerun with ATVS_SPLIT16=0 for the fp32 kernels'

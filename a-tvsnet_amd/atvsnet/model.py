@@ -297,7 +297,7 @@ def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_inte
     for b, (r, s) in enumerate(pairs):
         Hm = get_homographies(cams[:, r], cams[:, s], depth_num=D, depth_start=depth_start, depth_interval=depth_interval)
         ops.warp_planes(features[fi(s)], Hm[0].contiguous(), out=var[b], planar=planar, pieces=pieces)
-    const = torch.stack([features[fi(r)] for r, _ in pairs], 0) if B > 1 else features[fi(pairs[0][0]):fi(pairs[0][0]) + 1]
+    const = ops.stack([features[fi(r)] for r, _ in pairs], 0) if B > 1 else features[fi(pairs[0][0]):fi(pairs[0][0]) + 1]
     return ops.SplitVolume(var, const.contiguous(), [('c', i) for i in range(F)] + [('v', i) for i in range(F)],
                            planar=(D, h, w) if planar else False, pieces=pieces)
 
@@ -340,7 +340,7 @@ def TVSNet(images, cams, depth_num, depth_start, depth_interval, view_i, ref_i=0
     prob_vol_b2, _ = cost_volume_reasoning(cost_vol, output_filtered_cost=True)
     del cost_vol
     depth_b2 = prob2depth(prob_vol_b2, depth_num, depth_start, depth_interval)
-    init_depth_images = torch.stack([depth_b2, depth_view], dim=1)
+    init_depth_images = ops.stack([depth_b2, depth_view], dim=1)
     _, prob_residual = refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, images, prob_vol_b2,
                                   ref_id=ref_i, view_id=view_i, view_homographies=None, num_depths=2, depth_ref_id=0,
                                   depth_view_id=1)
@@ -405,7 +405,7 @@ def TVSNet_refine(depth_b2, depth_view, prob_vol_b2, filtered_cost_volume, image
                   depth_interval, view_i, ref_i=0, shallow_features=None):
     """Refinement of one source view against the aggregated estimate (reference :428-441) ->
     (refined_prob_vol (B,D,h,w), refined_cost_volume (B,D,h,w,8))."""
-    init_depth_images = torch.stack([depth_b2, depth_view], dim=1)
+    init_depth_images = ops.stack([depth_b2, depth_view], dim=1)
     cost_residual, prob_residual = refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, images,
                                               prob_vol_b2, ref_id=ref_i, view_id=view_i, view_homographies=None,
                                               num_depths=2, depth_ref_id=0, depth_view_id=1,

@@ -14,7 +14,7 @@
 // floats = mean, rsqrt(var+eps), beta.
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ partials, long nblocks, int cpad,
                                                           double count, const float* __restrict__ beta, float eps,
-                                                          float* __restrict__ params, int C, int fold) {
+                                                          float* __restrict__ params, int C, int fold, int* __restrict__ flag) {
   __shared__ double sm[2][256];
   const int c = blockIdx.x;
   // blockIdx.y = independent sample (group): its own rows of partial sums, its own (3, C) parameter block
@@ -40,6 +40,9 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     double mean = sm[0][0] / count;
     double var = sm[1][0] / count - mean * mean;
     if (var < 0.0) var = 0.0;
+    // a non-finite moment = an activation left the fp16 range of a split-operand kernel upstream (or the input was not finite): the
+    // sticky device flag lets the host name the cause even where a later ReLU (fmaxf) swallows the NaN
+    if (flag && !(mean - mean == 0.0 && var - var == 0.0)) atomicOr(flag, 1);
     params[c] = (float)mean;
     params[C + c] = (float)(1.0 / sqrt(var + (double)eps));
     params[2 * C + c] = beta ? beta[c] : 0.f;
@@ -47,12 +50,12 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
 }
 
 extern "C" int atvs_bn_finalize(const double* stats_partial, int groups, long num_blocks, int cpad, int fold, long count,
-                                const float* beta, float eps, float* params, int C, atvs_stream_t stream) {
+                                const float* beta, float eps, float* params, int C, int* nonfinite_flag, atvs_stream_t stream) {
   if (!stats_partial || !params) return ATVS_ERR_NULL;
   if (groups <= 0 || groups > 65535 || num_blocks <= 0 || C <= 0 || fold < 1 || cpad < C * fold || count <= 0)
     return ATVS_ERR_SHAPE;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(C, groups), dim3(256), 0, as_stream(stream), stats_partial, num_blocks, cpad,
-                     (double)count, beta, eps, params, C, fold);
+                     (double)count, beta, eps, params, C, fold, nonfinite_flag);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -136,3 +136,28 @@ extern "C" int atvs_copy_channels(const float* src, float* dst, long rows, int C
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
+
+// dst[i] = *srcs[i] (i < n), each `elems` floats: torch.stack along a new leading axis for up to 16 tensors in ONE launch (the
+// per-pair reference features of a batch of cost volumes, model.py:186; the two initial depth maps of the refinement, :289)
+struct StackPtrs { const float* p[16]; };
+__global__ __launch_bounds__(256) void stack_kernel(StackPtrs s, float* __restrict__ dst, long elems4) {
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(s.p[blockIdx.y]);
+  float4* __restrict__ d = reinterpret_cast<float4*>(dst) + (size_t)blockIdx.y * elems4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < elems4; i += (long)gridDim.x * blockDim.x) d[i] = src[i];
+}
+
+extern "C" int atvs_stack(const float* const* srcs, int n, long elems, float* dst, atvs_stream_t stream) {
+  if (!srcs || !dst) return ATVS_ERR_NULL;
+  if (n <= 0 || n > 16 || elems <= 0 || (elems % 4)) return ATVS_ERR_SHAPE;
+  StackPtrs s;
+  for (int i = 0; i < 16; ++i) {
+    s.p[i] = srcs[i < n ? i : 0];
+    if (!s.p[i] || (reinterpret_cast<uintptr_t>(s.p[i]) & 15)) return ATVS_ERR_ARG;
+  }
+  if (reinterpret_cast<uintptr_t>(dst) & 15) return ATVS_ERR_ARG;
+  long blocks = (elems / 4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(stack_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(256), 0, as_stream(stream), s, dst, elems / 4);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}

@@ -1877,6 +1877,29 @@ def channel_stats(x, groups=None):
     return st
 
 
+_flag_pool = {}
+
+
+def nonfinite_flag(device):
+    """The device word atvs_bn_finalize ORs with 1 when a batch-norm moment is not finite (one per device, sticky)."""
+    key = str(torch.device(device))
+    f = _flag_pool.get(key)
+    if f is None:
+        f = _flag_pool[key] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+def nonfinite_seen(device, reset=True):
+    """Did any batch norm since the last reset see a non-finite moment?  (Synchronises with the device.)"""
+    f = _flag_pool.get(str(torch.device(device)))
+    if f is None:
+        return False
+    seen = bool(int(f.item()))
+    if seen and reset:
+        f.zero_()
+    return seen
+
+
 def bn_params(st, C, ref, beta=None, eps=1e-3):
     """Stats -> params (3,C) = (mean, rstd, beta); (G,3,C) for the G independent samples of a grouped tensor."""
     if st.params is not None and beta is None and abs(eps - 1e-3) < 1e-12:
@@ -1885,7 +1908,8 @@ def bn_params(st, C, ref, beta=None, eps=1e-3):
     params = _new(ref, (3, C) if G == 1 else (G, 3, C))
     if _dev_ok(ref, beta):
         _call('atvs_bn_finalize', ctypes.c_void_p(st.partial.data_ptr()), int(G), ctypes.c_long(st.blocks), st.cpad,
-              int(st.fold), ctypes.c_long(st.count), _p(beta), ctypes.c_float(eps), _p(params), C, _stream())
+              int(st.fold), ctypes.c_long(st.count), _p(beta), ctypes.c_float(eps), _p(params), C,
+              ctypes.c_void_p(nonfinite_flag(ref.device).data_ptr()), _stream())
     return params
 
 
@@ -2133,6 +2157,24 @@ def copy_channels(src, dst, C, src_off=0, dst_off=0):
         _call('atvs_copy_channels', _p(src), _p(dst), ctypes.c_long(rows), int(C), src.shape[-1], int(src_off),
               dst.shape[-1], int(dst_off), _stream())
     return dst
+
+
+def stack(tensors, dim=0):
+    """tf.stack / torch.stack of up to 16 same-shaped tensors along a new axis `dim`, where every axis in front of `dim` has
+    extent 1 (so that the result is the tensors laid end to end): one launch of the library's own copy kernel."""
+    shape = tuple(tensors[0].shape)
+    if any(tuple(t.shape) != shape for t in tensors) or any(int(v) != 1 for v in shape[:dim]):
+        raise ValueError('ops.stack: same shapes, and only unit axes in front of the new one')
+    out = _new(tensors[0], shape[:dim] + (len(tensors),) + shape[dim:])
+    n = tensors[0].numel()
+    if len(tensors) > 16 or n % 4:
+        for i, t in enumerate(tensors):
+            copy_channels(t.reshape(1, -1), out.reshape(len(tensors), -1)[i:i + 1], n)
+        return out
+    if _dev_ok(out, *tensors):
+        arr = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+        _call('atvs_stack', arr, len(tensors), ctypes.c_long(n), _p(out), _stream())
+    return out
 
 
 def concat_channels(tensors):

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 33
+#define ATVS_ABI_VERSION 34
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -480,9 +480,11 @@ int atvs_conv3d_8to1(const float* x, const float* w, float* y, int groups, int D
  * params [groups][3][C] = (mean, rsqrt(var+eps), beta): the moments of
  * tf.layers.batch_normalization(training=True) / slim.batch_norm, network.py:206-212,
  * 541-547, 570-571.  count = elements per channel of one sample.  beta (C, shared) or NULL.  fold >= 1: channel c
- * also sums columns c + C, c + 2C, ... (fold of them). */
+ * also sums columns c + C, c + 2C, ... (fold of them).  nonfinite_flag: NULL or a device word that is OR-ed with 1 when a
+ * moment is not finite -- the layers upstream carried a value beyond the fp16 range of the split-operand kernels (or a
+ * non-finite input); sticky, the host reads and clears it (a later ReLU can swallow the NaN, the flag keeps it). */
 int atvs_bn_finalize(const double* stats_partial, int groups, long num_blocks, int cpad, int fold, long count,
-                     const float* beta, float eps, float* params, int C, atvs_stream_t stream);
+                     const float* beta, float eps, float* params, int C, int* nonfinite_flag, atvs_stream_t stream);
 
 /* Partial sums of an arbitrary (groups, rows, C) tensor, C <= 256, in the layout above with
  * cpad = C and atvs_channel_stats_num_blocks(rows) blocks per sample. */
@@ -519,6 +521,11 @@ int atvs_resize_bilinear(const float* x, float* y, int groups, int H, int W, int
  * dst[r, dst_off + c] = src[r, src_off + c], c < C. */
 int atvs_copy_channels(const float* src, float* dst, long rows, int C, int ld_src, int src_off, int ld_dst,
                        int dst_off, atvs_stream_t stream);
+
+/* tf.stack along a new leading axis (model.py:186,289: the per-pair reference features of a batch of cost volumes, the two
+ * initial depth maps of the refinement): dst[i] = *srcs[i], i < n <= 16, each `elems` floats (a multiple of 4, 16-byte aligned).
+ * srcs: HOST array of n device pointers. */
+int atvs_stack(const float* const* srcs, int n, long elems, float* dst, atvs_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  * AANet aggregation over views  (cnn_wrapper/network.py:282-351, 378-408)
