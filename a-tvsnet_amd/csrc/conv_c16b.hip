@@ -1,8 +1,9 @@
 // The 8 / 16 -> 16 channel 3x3x3 convolutions of conv_c16.hip on the 16-bit matrix cores with SPLIT operands -- BASELINE.json
 // configs[1] names "bf16 conv3d MFMA"; plain bf16 operands miss the 1e-3 depth bar by a factor 200.  Round 4:
 // every fp32 operand = TWO fp16 pieces,
-//     x = h0 + h1 / 2048,   h0 = f16(x), h1 = f16((x - h0) * 2048)        (22 significant bits; the residual scaled into fp16's
-//                                                                            normal range: no denormal loss)
+//     x = h0 + h1 / 2048,   h0 = f16(x), h1 = f16((x - h0) * 2048)        (22 significant bits for |x| >= 2^-14; the residual is
+//                                                                            scaled towards fp16's normal range -- below 2^-14 both
+//                                                                            pieces are fp16 subnormals: 2^-36 absolute)
 // and THREE products on v_mfma_f32_16x16x32_f16 with fp32 accumulation: h0 g0 into the main accumulator, h0 g1 + h1 g0 into a
 // second one scaled by 2^-11 in the epilogue (conv_xb.hip has the measurements: per-layer error against a double sum below
 // the fp32 matrix cores' and below round 3's three bf16 pieces / six products).  One K = 32 instruction (16 cycles) covers two

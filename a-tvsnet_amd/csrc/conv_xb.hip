@@ -3,7 +3,8 @@
 // conv_b*_1_0 / 3dconv1_0 (/root/reference/cnn_wrapper/atvsnet.py StackedUNet / CostVolRefineNet, layer code network.py:165-215).
 //
 // Arithmetic (round 4): every fp32 operand is split into TWO fp16 pieces, x = h0 + h1 / 2048 with h0 = f16(x) and
-// h1 = f16((x - h0) * 2048) (the residual scaled into fp16's normal range: 22 significant bits, no denormal loss), w = g0 + g1 /
+// h1 = f16((x - h0) * 2048) (the residual scaled towards fp16's normal range: 22 significant bits for |x| >= 2^-14; smaller values
+// keep an ABSOLUTE precision of 2^-36 -- both pieces are then fp16 subnormals, which the instruction honours), w = g0 + g1 /
 // 2048 likewise (split by the host packer); THREE products on v_mfma_f32_16x16x32_f16 with fp32 accumulation: h0 g0 into the
 // main accumulator, h0 g1 + h1 g0 into a second one that is scaled by 2^-11 once in the epilogue (the dropped h1 g1 is 2^-22 of
 // a product).  Measured on MI355X (tools_dev/micro/f16_split_probe.hip): error of a 864-term dot product against a double sum

@@ -551,11 +551,11 @@ def top_kernels(k=5):
         return None
     rows = []
     with open(path) as f:
-        for r in csv.DictReader(f):
+        for r in csv.DictReader(ln for ln in f if not ln.startswith('#')):
             rows.append((r['Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0],
                          int(r['Calls']), float(r['AverageNs']) / 1e3, float(r['Percentage'])))
     rows.sort(key=lambda t: -t[3])
-    return {'source': KERNEL_STATS_FILE, 'measured_in_run': False, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --inflight 1',
+    return {'source': KERNEL_STATS_FILE, 'head': profile_head(KERNEL_STATS_FILE), 'measured_in_run': False, 'command': 'rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --inflight 1',
             'top': [{'kernel': n, 'calls': c, 'avg_us': round(a, 1), 'pct': round(p, 2)} for n, c, a, p in rows[:k]]}
 
 
@@ -567,7 +567,7 @@ def profiled_avg_us(substr):
         return None
     tot = calls = 0
     with open(path) as f:
-        for r in csv.DictReader(f):
+        for r in csv.DictReader(ln for ln in f if not ln.startswith('#')):
             if substr in r['Name']:
                 tot += float(r['AverageNs']) * int(r['Calls'])
                 calls += int(r['Calls'])
@@ -848,7 +848,7 @@ def rank_main(args):
                     'mfma_busy': pmc.get('mfma_busy') if pmc else None,
                     'clock_GHz': pmc.get('clock_GHz') if pmc else None,
                     'valu_per_mfma': pmc.get('valu_per_mfma') if pmc else None,
-                    'pmc': ({'source': PMC_FILE, 'measured_in_run': False, 'kernel': pmc.get('kernel'),
+                    'pmc': ({'source': PMC_FILE, 'head': profile_head(PMC_FILE), 'measured_in_run': False, 'kernel': pmc.get('kernel'),
                              'duration_ms_under_profiler': pmc.get('duration_ms'),
                              'note': 'mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024 SIMDs); clock_GHz = '
                                      'GRBM_GUI_ACTIVE / 8 / duration: the clock the chip holds under this kernel (2.4 GHz spec)'}
@@ -875,9 +875,9 @@ def rank_main(args):
                         'timing': 'HIP events around eager launches in this run (includes launch gaps of ~10 us)',
                         'avg_launch_ms': round(avg_ms, 4), 'launches': len(watched[WARP]),
                         'algorithmic_bytes_per_launch': wb, 'traffic': None}
-            prof_us = profiled_avg_us('warp_planes_shared_kernel<0>')
+            prof_us = profiled_avg_us('warp_planes_shared_kernel<0,')
             if prof_us and (args.width, args.height, args.depths) == (640, 512, 192):
-                roof_hbm['profile'] = {'source': KERNEL_STATS_FILE, 'measured_in_run': False, 'avg_launch_ms': round(prof_us / 1e3, 4),
+                roof_hbm['profile'] = {'source': KERNEL_STATS_FILE, 'head': profile_head(KERNEL_STATS_FILE), 'measured_in_run': False, 'avg_launch_ms': round(prof_us / 1e3, 4),
                                        'achieved': round(wb / (prof_us * 1e-6) / 1e9, 1),
                                        'frac': round(wb / (prof_us * 1e-6) / 1e9 / PEAK_HBM_GBS, 4)}
         par = 'single GPU'

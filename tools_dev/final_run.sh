@@ -1,11 +1,25 @@
-# Round-end validation on the GPU box: full -m gpu suite, smoke, default bench (+ other workloads), kernel trace, PMC passes.
-#   bash tools_dev/final_run.sh <tag>
-tag=${1:-final}
-mkdir -p gpurun_out/$tag
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > gpurun_out/$tag/gputests.log
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/$tag/smoke.log
-python bench.py > gpurun_out/$tag/bench_default.log 2>&1
-for w in cfg2 cfg4 cfg5; do python bench.py --workload $w --no-cpu-baseline --no-fp32-path > gpurun_out/$tag/bench_$w.log 2>&1; done
-bash tools_dev/prof_bench3.sh $tag > gpurun_out/$tag/prof.log 2>&1
-bash tools_dev/pmc_bench.sh $tag > gpurun_out/$tag/pmc.log 2>&1
-cat gpurun_out/$tag/gputests.log gpurun_out/$tag/smoke.log; for f in default cfg2 cfg4 cfg5; do tail -1 gpurun_out/$tag/bench_$f.log | cut -c1-200; done
+#!/bin/bash
+# Round-end measurement of HEAD, run from the BUILD container:   bash tools_dev/final_run.sh [tag]
+#   1. refuses to run on a dirty tree (what is measured must be a commit);
+#   2. writes `git rev-parse HEAD` to profiles/.measured_head (git-ignored; it travels to the GPU box with the snapshot, which
+#      carries no .git) and sends tools_dev/final_box.sh to an MI355X: the full -m gpu suite, smoke(), the default bench line, the
+#      other workloads, a rocprofv3 kernel trace of the bench and the PMC passes (one counter group per pass);
+#   3. tools_dev/collect_profiles.py copies the summaries into profiles/round5_* -- every JSON carries "head", every CSV a first
+#      line "# head <hash>", and <name>.head sits beside each file -- ready to be committed as the round's LAST commit (that commit
+#      touches profiles/ and documents only: the measured tree is its parent).
+set -e
+tag=${1:-r5final}
+root=$(cd $(dirname $0)/.. && pwd)
+cd $root
+if [ -n "$(git status --porcelain)" ]; then
+  echo "final_run.sh: the tree is dirty -- commit first, the profiles must name the commit they measured" >&2
+  git status --short >&2
+  exit 1
+fi
+head=$(git rev-parse HEAD)
+echo $head > profiles/.measured_head
+python3 -c "import __graft_entry__ as g; g.build()"
+/usr/local/graft/bin/gpurun --timeout 3300 -- "bash tools_dev/final_box.sh $tag"
+python3 tools_dev/collect_profiles.py $tag $head
+rm -f profiles/.measured_head
+echo "measured $head; now: git add profiles && git commit"

@@ -1,4 +1,4 @@
-"""profiles/round4_pmc_kernels.json from the summary of tools_dev/pmc_bench.sh:  python tools_dev/make_pmc_table.py gpurun_out/pmc_<tag>"""
+"""profiles/<name>.json from the summary of tools_dev/pmc_bench.sh:  python tools_dev/make_pmc_table.py gpurun_out/pmc_<tag> [profiles/name.json]"""
 import json
 import os
 import sys
@@ -7,7 +7,7 @@ src = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 d = json.load(open(os.path.join(src, 'summary.json')))
 out = {'note': 'rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only; tools_dev/pmc_bench.sh) over `bench.py --eager '
-               '--inflight 1` of the round-4 library on MI355X: per-launch averages for the kernels of one depth map (config 3), '
+               '--inflight 1` on MI355X: per-launch averages for the kernels of one depth map (config 3), '
                'sorted by total time.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); valu_per_mfma = '
                '(SQ_INSTS_VALU - SQ_INSTS_MFMA) / SQ_INSTS_MFMA; clock_GHz = GRBM_GUI_ACTIVE / 8 / duration; fetch / write = FETCH_SIZE / '
                'WRITE_SIZE (KB at the memory side of L2, Infinity-Cache hits included; wide coalesced reads count at half their bytes '
@@ -27,6 +27,6 @@ for k, v in list(d.items())[:40]:
         e['memory_TBps_raw'] = round((c.get('FETCH_SIZE', 0) + c.get('WRITE_SIZE', 0)) * 1024 / dur / 1e3, 2)
     e['lds_bank_conflict_cycles'] = int(c.get('SQ_LDS_BANK_CONFLICT', 0))
     out['kernels'][k] = e
-json.dump(out, open(os.path.join(root, 'profiles', 'round4_pmc_kernels.json'), 'w'), indent=1)
+json.dump(out, open(os.path.join(root, sys.argv[2] if len(sys.argv) > 2 else 'profiles/round4_pmc_kernels.json'), 'w'), indent=1)
 for k in list(out['kernels'])[:10]:
     print(k, out['kernels'][k])
