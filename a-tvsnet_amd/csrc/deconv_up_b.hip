@@ -24,6 +24,17 @@
 #include "conv_common.h"
 
 
+// Development build (-DATVS_UB_DEBUG): per-wavefront tick counts of the phases (tools_dev/phase_ub.py)
+#ifdef ATVS_UB_DEBUG
+__device__ unsigned long long atvs_dbg_ub[4096 * 8];
+extern "C" int atvs_debug_read_ub(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(atvs_dbg_ub), sizeof(atvs_dbg_ub));
+}
+#define UDBG(i) { unsigned long long t_ = clock64(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; }
+#else
+#define UDBG(i)
+#endif
+
 namespace {
 
 constexpr int UB_TZ = 4, UB_TX = 16;
@@ -122,6 +133,11 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
+#ifdef ATVS_UB_DEBUG
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+  const unsigned long long dbg_w0 = wall_clock64();
+#endif
 
   // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
   if (!STREAMW) {
@@ -240,8 +256,10 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
   }
 
+  UDBG(6)
   for (int stage = 0; stage < nstage; ++stage) {
     const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    UDBG(0)
     if (ch == 0) {
 #pragma unroll
       for (int t = 0; t < TY; ++t)
@@ -249,6 +267,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         for (int m = 0; m < NT; ++m) acc[t][m] = accx[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();                       // every wavefront is done reading the previous stage's images (and weights)
+    UDBG(1)
     if (STREAMW) {
       const float4* src = reinterpret_cast<const float4*>(p.wp + (size_t)ch * U::WCH);
       float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
@@ -275,7 +294,9 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         *reinterpret_cast<uint2*>(smem + laddr[i]) = p0;
         *reinterpret_cast<uint2*>(smem + U::IMG + laddr[i]) = p1;
       }
+    UDBG(2)
     __syncthreads();
+    UDBG(3)
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
     const int wb = wbase + (STREAMW ? 0 : ch * U::WCH);
@@ -336,6 +357,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
       }
     });
     static_assert(UB_NP * NG >= MAXS, "every halo slot is requested inside the K loop");
+    UDBG(4)
     if (ch != p.nchunk - 1) continue;
 
     // ---- epilogue (deconv_up.hip): this lane holds, of tile m,
@@ -375,8 +397,18 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         ssq[2] = __builtin_fmaf(b2, b2, ssq[2]); ssq[3] = __builtin_fmaf(b3, b3, ssq[3]);
       });
     });
+    UDBG(5)
   }
 
+#ifdef ATVS_UB_DEBUG
+  UDBG(5)
+  if (lane == 0 && blockIdx.x < 1024) {
+    // slot 7: stages | wall-clock ticks (100 MHz) from entry to here << 16
+    dbg_acc[7] = (unsigned long long)nstage | ((wall_clock64() - dbg_w0) << 16);
+    dbg_acc[0] = dbg_w0;                     // absolute start (100 MHz): dispatch skew across the workgroups
+    for (int i = 0; i < 8; ++i) atvs_dbg_ub[(blockIdx.x * 4 + wave) * 8 + i] = dbg_acc[i];
+  }
+#endif
   // ---- per-workgroup partial moments -> row blockIdx of stats: [2][16] doubles (Cout 8: columns 8..15 = 0)
   if (p.stats) {
     __syncthreads();
@@ -426,8 +458,13 @@ size_t ub_lds(int Cin, int Cout) {
   return Cout == 8 ? UB_NP * (size_t)UpB<8>::IMG + (size_t)(Cin / 16) * UpB<8>::WCH
                    : UB_NP * (size_t)UpB<16>::IMG + (size_t)(Cin / 16) * UpB<16>::WCH;
 }
-// all chunks resident if they fit, else one chunk at a time (Cout 16 only)
-bool ub_stream(int Cin, int Cout) { return Cout == 16 && ub_lds(Cin, Cout) > 160 * 1024; }
+// Cout 16: all chunks resident only while TWO workgroups still fit the CU's 160 KB (one chunk: 52 KB) -- with two chunks resident
+// (88 KB, the 32 -> 16 layer) one workgroup ran per CU whatever __launch_bounds__ says (measured: the second half of the grid
+// started when the first had finished); else one chunk at a time, re-read from L2 at every stage (~500 cycles of a ~6,000 cycle stage)
+#ifndef ATVS_UB_RESIDENT_MAX
+#define ATVS_UB_RESIDENT_MAX (80 * 1024)
+#endif
+bool ub_stream(int Cin, int Cout) { return Cout == 16 && ub_lds(Cin, Cout) > ATVS_UB_RESIDENT_MAX; }
 
 template <int COUT, bool STREAMW, bool PRO = false>
 int launch_upb(const UpBArgs& a, long grid, size_t lds, hipStream_t s) {
