@@ -507,11 +507,16 @@ class Network(object):
         return ops.avg_pool_same(x, pool_size, strides, groups=x.shape[0])
 
     @layer
-    def image_resize(self, input, size, name, align_corners=True, method='bilinear'):
-        '''tf.image.resize_images: always bilinear (reference network.py:649-655, quirk C14).'''
+    def image_resize(self, input, size, name, align_corners=True, method='bilinear', out_slice=None):
+        '''tf.image.resize_images: always bilinear (reference network.py:649-655, quirk C14).  out_slice=(concat name, channel
+        offset) (extension): the result is written into that slice of a pre-allocated concat buffer (concat_buffer).'''
         if not align_corners:
             raise NotImplementedError('image_resize: only align_corners=True is built')
         x = self._bt(input, name)
+        if out_slice is not None:
+            buf, c_off = self._concat_bufs[out_slice[0]], int(out_slice[1])
+            ops.resize_bilinear(x, (int(size[0]), int(size[1])), out=buf, c_off=c_off, groups=x.shape[0])
+            return self._slice_out(buf, out_slice, x.shape[-1])
         return ops.resize_bilinear(x, (int(size[0]), int(size[1])), groups=x.shape[0])
 
     @layer
@@ -541,6 +546,16 @@ class Network(object):
                     assert len(relus) == 1 and sum(pc[1] for pc in pend) == off
                     ops.bn_apply(buf, params, relus.pop())
                 return buf
+        buf = getattr(self, '_concat_bufs', {}).get(name)
+        if buf is not None and sum(t.shape[-1] for t in inputs) == buf.shape[-1] \
+                and not getattr(self, '_pending_bn', {}).get(id(buf)):
+            # some inputs were written in place: copy the others into their slices
+            off = 0
+            for t, tg in zip(inputs, tags):
+                if not (tg is not None and tg[0] == name and tg[1] == off):
+                    ops.copy_channels(self._bt(t, name), buf, t.shape[-1], 0, off)
+                off += t.shape[-1]
+            return buf
         return ops.concat_channels([self._bt(t, name) for t in inputs])
 
     @layer

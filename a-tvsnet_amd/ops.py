@@ -48,7 +48,7 @@ class Config(object):
         conv_c16=True, deconv_up=True, stem=True, conv2d_lds=True, conv1x1=True, xp1w=True, xpair=True, siblings=True,
         bottleneck=os.environ.get('ATVS_BOTTLENECK', '1') != '0',
         prologue=True, sum_on_load=os.environ.get('ATVS_SUM_ON_LOAD', '1') != '0', force_impl=None, fused_finalize=False,
-        side_streams=True)
+        side_streams=os.environ.get('ATVS_SIDE_STREAMS', '1') != '0')
 
     def __init__(self):
         for k, v in self._DEFAULTS.items():
