@@ -40,6 +40,7 @@ struct C2bArgs {
   float* y;
   double* stats;
   int G, H, W, Cin, Cout;
+  int Ho, Wo;                 // output grid (= H, W at stride 1)
   int ldy, ycoff;
   int nchunk;
   int tiles_x, tiles;
@@ -68,20 +69,27 @@ __device__ __forceinline__ void c2b_lds_barrier() { asm volatile("s_waitcnt lgkm
 // channels of a pixel as K, and they are spread over the four waves -- and each wave multiplies its own output channels; bias b3,
 // the shortcut `res` and the moments of the unit's output in the common epilogue.  K order and packed weights of conv1x1_b.hip:
 // bit for bit conv2d_b followed by conv1x1_b.
-template <int NTW, int WR, int TY, int DIL, bool TAIL = false>
+// STRIDE 2 (dilation 1): the strided conv2 of a residual unit's first block (explicit symmetric padding 1 + VALID, taps centred on
+// pixel 2 i: reference cnn_wrapper/network.py:588-595, quirk C17).  Halo (2 R + 1) x 33 pixels; even and odd columns of a row
+// are stored apart (odd | even halves of the row), so that the 16 lanes of a fragment read -- input columns 2 r + kx -- still
+// touch 16 consecutive 32-byte pixels.
+template <int NTW, int WR, int TY, int DIL, bool TAIL = false, int STRIDE = 1>
 __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  static_assert(STRIDE == 1 || (STRIDE == 2 && DIL == 1 && !TAIL), "stride 2: dilation 1, no tail");
   constexpr int R = TY * WR;
-  constexpr int HR = R + 2 * DIL, HC = 16 + 2 * DIL;
+  constexpr int HR = (R - 1) * STRIDE + 1 + 2 * DIL, HC = 15 * STRIDE + 1 + 2 * DIL;
   constexpr int SLOTS = HR * HC * 4;
   constexpr int MAXS = (SLOTS + 255) / 256;
-  constexpr int PIMG = HR * C2B_ROWB;          // bytes of one piece image
+  constexpr int PITCH = (STRIDE == 1) ? C2B_PITCH : 34;          // pixels per LDS row (stride 2: 17 odd + 17 even columns)
+  constexpr int ROWB = PITCH * 32;
+  constexpr int PIMG = HR * ROWB;              // bytes of one piece image
   constexpr int BUFB = C2B_NP * PIMG;
   constexpr int WN = 4 / WR;
   constexpr int NT = NTW * WN;
   constexpr int JS = C2B_JS;
   static_assert(MAXS <= C2B_NP * JS, "one halo slot per phase");
-  static_assert(HC <= C2B_PITCH, "row pitch");
+  static_assert(HC <= PITCH, "row pitch");
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -105,10 +113,12 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
     s = min(s, SLOTS - 1);
     const int c4 = s & 3, v = s >> 2;
     const int xx = v % HC, yy = v / HC;
-    const int gy = y0 - DIL + yy, gxx = x0 - DIL + xx;
+    const int gy = y0 * STRIDE - DIL + yy, gxx = x0 * STRIDE - DIL + xx;
     const bool ok = live && (unsigned)gy < (unsigned)p.H && (unsigned)gxx < (unsigned)p.W;
     goff[i] = ok ? ((gy * p.W + gxx) * p.Cin + c4 * 4) : 0;
-    laddr[i] = live ? ((yy * C2B_PITCH + xx) * 32 + c4 * 8) : -1;
+    // stride 2: halo column xx = 2 x0 - 1 + ... : odd xx are EVEN input offsets; columns of one parity sit together
+    const int lx = (STRIDE == 1) ? xx : ((xx & 1) * 17 + (xx >> 1));
+    laddr[i] = live ? ((yy * PITCH + lx) * 32 + c4 * 8) : -1;
     valid |= (ok ? 1u : 0u) << i;
   }
   float4 pf[MAXS];
@@ -147,7 +157,9 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
   for (int j = 0; j < JS; ++j) {
     const int tap = min(2 * j + (q >> 1), 8);
     const int ky = tap / 3, kx = tap % 3;
-    bd[j] = ((wr * TY + ky * DIL) * C2B_PITCH + r + kx * DIL) * 32 + (q & 1) * 16;
+    // stride 2: output pixel (t, r) reads halo pixel (2 t + ky, 2 r + kx), stored at column (kx & 1) * 17 + r + (kx >> 1)
+    bd[j] = (STRIDE == 1) ? ((wr * TY + ky * DIL) * PITCH + r + kx * DIL) * 32 + (q & 1) * 16
+                          : ((wr * TY * 2 + ky) * PITCH + (kx & 1) * 17 + r + (kx >> 1)) * 32 + (q & 1) * 16;
   }
 
   // ---- packed weight pieces: [K step = chunk * 5 + j][NT tiles][3 pieces][64 lanes] bf16x8, zero steps at the end.  Two
@@ -182,7 +194,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
     auto request_b = [&](int ph) __attribute__((always_inline)) {
       const int j = ph / C2B_NP, pc = ph % C2B_NP;
 #pragma unroll
-      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(lb + pc * PIMG + bd[j] + t * C2B_ROWB);
+      for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(lb + pc * PIMG + bd[j] + t * (STRIDE * ROWB));
     };
     request_b(0);
 #pragma unroll
@@ -296,8 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
 #pragma unroll
   for (int t = 0; t < TY; ++t) {
     const int yo = y0 + wr * TY + t;
-    if (yo >= p.H || xo >= p.W) continue;
-    const size_t rowb = ((size_t)yo * p.W + xo) * p.ldy + p.ycoff;
+    if (yo >= p.Ho || xo >= p.Wo) continue;
+    const size_t rowb = ((size_t)yo * p.Wo + xo) * p.ldy + p.ycoff;
 #pragma unroll
     for (int n = 0; n < NTW; ++n) {
       const int co = (wn * NTW + n) * 16 + 4 * q;
@@ -358,17 +370,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
   }
 }
 
-template <int NTW, int WR, int TY, int DIL, bool TAIL = false>
+template <int NTW, int WR, int TY, int DIL, bool TAIL = false, int STRIDE = 1>
 int launch_c2b(const C2bArgs& a, hipStream_t s) {
-  constexpr int R = TY * WR, HR = R + 2 * DIL;
-  size_t lds = (size_t)2 * C2B_NP * HR * C2B_ROWB;
+  constexpr int R = TY * WR, HR = (R - 1) * STRIDE + 1 + 2 * DIL;
+  size_t lds = (size_t)2 * C2B_NP * HR * (STRIDE == 1 ? C2B_ROWB : 34 * 32);
   if (TAIL) {
     constexpr size_t xch = (size_t)2 * R * 16 * ((NTW * (4 / WR)) * 32 + 16);
     if (xch > lds) lds = xch;
   }
   const long blocks = ((a.total + 7) / 8) * 8;
   if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  hipLaunchKernelGGL((conv2d_b_kernel<NTW, WR, TY, DIL, TAIL>), dim3((unsigned)blocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv2d_b_kernel<NTW, WR, TY, DIL, TAIL, STRIDE>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -418,8 +430,9 @@ extern "C" int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned ch
 namespace {
 int c2b_run(const float* x, const unsigned char* packed_w, const float* bias, const float* residual, const float* in_params,
             int in_relu, const unsigned char* packed_w3, const float* b3, float* y, double* stats_partial, int G, int H, int W,
-            int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream) {
+            int Cin, int Cout, int dilation, int ldy, int y_coff, int relu, atvs_stream_t stream, int stride = 1) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
+  if (stride != 1 && (stride != 2 || dilation != 1 || Cout != 64 || packed_w3 || (H % 2) || (W % 2))) return ATVS_ERR_SHAPE;
   if (G <= 0 || H <= 0 || W <= 0 || !atvs_conv2d_lds_supported(Cin, Cout, dilation) || (Cin % 32)) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if (residual && y_coff != 0) return ATVS_ERR_ARG;
@@ -429,15 +442,18 @@ int c2b_run(const float* x, const unsigned char* packed_w, const float* bias, co
   a.w3 = reinterpret_cast<const f16x8*>(packed_w3); a.b3 = b3;
   a.y = y; a.stats = stats_partial;
   a.G = G; a.H = H; a.W = W; a.Cin = Cin; a.Cout = Cout; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16;
+  a.Ho = H / stride; a.Wo = W / stride;
   const int R = (Cout == 32) ? 8 : 4;
-  a.tiles_x = (W + 15) / 16;
-  a.tiles = ((H + R - 1) / R) * a.tiles_x;
+  a.tiles_x = (a.Wo + 15) / 16;
+  a.tiles = ((a.Ho + R - 1) / R) * a.tiles_x;
   a.relu = relu; a.in_relu = in_relu;
-  a.gx = (long)H * W * Cin; a.gy = (long)H * W * ldy;
+  a.gx = (long)H * W * Cin; a.gy = (long)a.Ho * a.Wo * ldy;
   a.total = (long)G * a.tiles;
   hipStream_t s = as_stream(stream);
   int rc = ATVS_ERR_ARG;
-  if (packed_w3) {
+  if (stride == 2) {
+    rc = launch_c2b<1, 1, 4, 1, false, 2>(a, s);
+  } else if (packed_w3) {
     if (dilation == 2) rc = launch_c2b<2, 1, 4, 2, true>(a, s);
     else rc = launch_c2b<2, 1, 4, 4, true>(a, s);
   } else if (Cout == 128) {
@@ -478,4 +494,17 @@ extern "C" int atvs_conv2d_b_tail_f32(const float* x, const unsigned char* packe
   if (!packed_w3 || !b2 || !b3) return ATVS_ERR_NULL;
   if (!atvs_conv2d_b_tail_supported(C, dilation)) return ATVS_ERR_SHAPE;
   return c2b_run(x, packed_w2, b2, residual, nullptr, 0, packed_w3, b3, y, stats_partial, G, H, W, C, C, dilation, C, 0, 1, stream);
+}
+
+// The strided conv2 of a residual unit's first block (reference cnn_wrapper/network.py:588-595: explicit symmetric padding 1,
+// VALID, stride 2 -- taps centred on input pixel 2 i, quirk C17) on the split-operand kernel: x (G,H,W,Cin) with H, W even ->
+// y (G,H/2,W/2,Cout).  Built for 64 output channels (conv1_x_0/conv2 of ResNetDS2SPP; atvs_conv2d_b_s2_supported); weights
+// atvs_conv2d_b_pack; stats_partial rows = atvs_conv2d_lds_rows(H/2, W/2, Cout).  Same arithmetic as atvs_conv2d_b_f32.
+extern "C" int atvs_conv2d_b_s2_supported(int Cin, int Cout) { return (Cout == 64 && Cin > 0 && Cin % 32 == 0 && Cin <= 512) ? 1 : 0; }
+
+extern "C" int atvs_conv2d_b_s2_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
+                                    double* stats_partial, int G, int H, int W, int Cin, int Cout, int relu, atvs_stream_t stream) {
+  if (!atvs_conv2d_b_s2_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
+  return c2b_run(x, packed_w, bias, nullptr, nullptr, 0, nullptr, nullptr, y, stats_partial, G, H, W, Cin, Cout, 1, Cout, 0, relu,
+                 stream, 2);
 }

@@ -1246,6 +1246,29 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         y4, st = r if want_stats else (r, None)
         y = out if out is not None else _from5(y4.unsqueeze(1), nsp, groups)
         return (y, st) if want_stats else y
+    # ---- 2-D, 3x3, stride 2 behind explicit symmetric padding 1 (the strided conv2 of a residual unit's first block)
+    if nsp == 2 and stride == 2 and dilation == 1 and ks == (1, 3, 3) and explicit_pad is not None \
+            and tuple(tuple(int(v) for v in pr) for pr in explicit_pad) == ((1, 1), (1, 1)) and ins[1] % 2 == 0 and ins[2] % 2 == 0 \
+            and residual is None and plane_bias is None and in_params is None and y5 is None and cfg.force_impl is None \
+            and cfg.conv2d_lds and split_on('c2b') and ins[1] >= 16 and ins[2] >= 32 \
+            and bool(_lib.lib().atvs_conv2d_b_s2_supported(int(cin), int(cout))):
+        pk = pack_conv2d_lds(key, w_host, x.device)
+        if pk.kind == 'b':
+            Ho, Wo = ins[1] // 2, ins[2] // 2
+            y4 = _new(x, (G, Ho, Wo, cout))
+            st, sbuf = None, None
+            if want_stats:
+                rows = int(_lib.lib().atvs_conv2d_lds_rows(Ho, Wo, cout))
+                sbuf = torch.empty((G, rows, 2, cout), dtype=torch.float64, device=x.device)
+                st = Stats()
+                st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, cout, Ho * Wo, G
+            if _dev_ok(x5, y4, bias):
+                with _Timed(key, (1, ins[1], ins[2], cin), cout, G):
+                    _call('atvs_conv2d_b_s2_f32', _p(x5), _p(pk.wp), _p(bias), _p(y4),
+                          ctypes.c_void_p(sbuf.data_ptr()) if sbuf is not None else ctypes.c_void_p(0), G, ins[1], ins[2], cin, cout,
+                          int(bool(relu)), _stream())
+            y = _from5(y4.unsqueeze(1), nsp, groups)
+            return (y, st) if want_stats else y
     # ---- 2-D 1x1, stride 1: the LDS-staged GEMM kernel
     if nsp == 2 and stride == 1 and ks == (1, 1, 1) and plane_bias is None and conv1x1_ok(cin, cout) \
             and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):

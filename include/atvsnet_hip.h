@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 34
+#define ATVS_ABI_VERSION 35
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -345,6 +345,14 @@ int atvs_conv2d_b_tail_supported(int C, int dilation);
 int atvs_conv2d_b_tail_f32(const float* x, const unsigned char* packed_w2, const float* b2, const unsigned char* packed_w3,
                            const float* b3, const float* residual, float* y, double* stats_partial, int G, int H, int W, int C,
                            int dilation, atvs_stream_t stream);
+
+/* The strided conv2 of a residual unit's first block (reference cnn_wrapper/network.py:588-595: explicit symmetric padding 1 +
+ * VALID, stride 2 -- taps centred on input pixel 2 i, quirk C17) on the split-operand kernel (conv2d_b.hip, STRIDE form):
+ * x (G,H,W,Cin), H and W even -> y (G,H/2,W/2,Cout) (+ bias, ReLU).  Built for Cout = 64, Cin % 32 == 0 (conv1_x_0/conv2 of
+ * ResNetDS2SPP); weights atvs_conv2d_b_pack; stats_partial: rows atvs_conv2d_lds_rows(H/2, W/2, Cout) or NULL. */
+int atvs_conv2d_b_s2_supported(int Cin, int Cout);
+int atvs_conv2d_b_s2_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial, int G,
+                         int H, int W, int Cin, int Cout, int relu, atvs_stream_t stream);
 
 /* 1x1 convolution of feature maps (the bottlenecks' conv1 / conv3 / shortcut, fusion1: slim.conv2d 1x1,
  * network.py:573-601; cnn_wrapper/atvsnet.py:254-292) as a tall GEMM: weights staged once per workgroup in LDS, pixels

@@ -862,3 +862,29 @@ def test_conv2_and_conv3_of_a_unit_in_one_launch_bitwise(cuda, dil, H, W, G, pro
     assert float((p - p_ref).abs().max()) <= 1e-6 * float(p_ref.abs().max())
     flat = y.reshape(G, -1, C).double()
     assert float((p.reshape(G, 3, C)[:, 0].double() - flat.mean(1)).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize('G,H,W,cin', [(5, 256, 320, 64), (2, 18, 34, 64), (1, 16, 32, 32), (3, 42, 70, 64)])
+def test_strided_unit_conv2_on_the_split_kernel(cuda, G, H, W, cin):
+    """conv2d_b.hip's stride-2 form: the 3x3 stride-2 convolution behind explicit symmetric padding 1 of a residual unit's first
+    block (reference cnn_wrapper/network.py:588-595, quirk C17: taps centred on pixel 2 i) -- conv1_x_0/conv2 of ResNetDS2SPP at
+    its size and ragged ones: against the oracle's convolution, the generic kernel it replaces, and its moments."""
+    from atvsnet_amd import ops
+    cout = 64
+    g = torch.Generator().manual_seed(H + cin)
+    x = torch.clamp(torch.randn(G, H, W, cin, generator=g), min=0)
+    w = torch.randn(3, 3, cin, cout, generator=g) * (1.0 / (9 * cin)) ** 0.5
+    b = torch.randn(cout, generator=g) * 0.1
+    pad = [(1, 1), (1, 1)]
+    y, st = ops.conv(x.to(cuda), ('s2', H, cin), w.numpy(), stride=2, explicit_pad=pad, bias=b.to(cuda), relu=True,
+                     want_stats=True, groups=G)
+    want = torch.clamp(T.conv(x, w, 2, 'VALID', bias=b, explicit_pad=pad), min=0)
+    assert tuple(y.shape) == tuple(want.shape) == (G, H // 2, W // 2, cout)
+    assert float((y.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    with ops.configure(split_off=('c2b',), clear_pack_cache=True):
+        ref = ops.conv(x.to(cuda), ('s2', H, cin), w.numpy(), stride=2, explicit_pad=pad, bias=b.to(cuda), relu=True, groups=G)
+    assert float((y - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    p = ops.bn_params(st, cout, y).reshape(G, 3, cout)
+    flat = y.reshape(G, -1, cout).double()
+    assert float((p[:, 0].double() - flat.mean(1)).abs().max()) <= 1e-5
+    assert float((p[:, 1].double() - 1.0 / torch.sqrt(flat.var(1, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
