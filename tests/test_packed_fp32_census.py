@@ -59,7 +59,7 @@ def test_packed_fp32_only_where_it_is_accounted_for(tmp_path):
                            'their source with -fno-slp-vectorize / scalar arithmetic, or reserve the register file' % strangers)
     # the split-fp16 tower kernels run two workgroups per CU (they cannot own a SIMD): they must stay free of packed fp32
     for k in counts:
-        assert 'conv2d_b_kernel' not in k and 'conv1x1_b_kernel' not in k, k
+        assert 'conv2d_b_kernel' not in k and 'conv1x1_b_kernel' not in k and 'bottleneck_b_kernel' not in k, k
     # conv_xb's staging wavefronts compute (batch norm, operand split) beside its own MFMA wavefronts on the same SIMD: scalar fp32 only
     assert not any('conv_xb_kernel' in k for k in counts), [k for k in counts if 'conv_xb_kernel' in k]
     # deconv_up_b: two workgroups per CU, wavefronts of the same kernel share SIMDs
