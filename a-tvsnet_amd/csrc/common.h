@@ -83,6 +83,30 @@ __device__ __forceinline__ void homography_apply(const float* __restrict__ Hm, i
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// 16-byte store of data its producer does not read again (large volumes consumed by a LATER kernel): the non-temporal hint
+// keeps the line out of the way of what the L2 is holding for reuse.  -DATVS_NO_NT_STORES: plain stores (A/B).
+// cache-policy operand of raw buffer stores for the same purpose (gfx940+: bit 1 = nt)
+#ifdef ATVS_NO_NT_STORES
+#define ATVS_BUF_NT 0
+#else
+#define ATVS_BUF_NT 2
+#endif
+typedef float atvs_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned atvs_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_stream(float* p, float4 v) {
+#ifdef ATVS_NO_NT_STORES
+  *reinterpret_cast<float4*>(p) = v;
+#else
+  __builtin_nontemporal_store((atvs_f32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<atvs_f32x4*>(p));
+#endif
+}
+__device__ __forceinline__ void st4u_stream(void* p, uint4 v) {
+#ifdef ATVS_NO_NT_STORES
+  *reinterpret_cast<uint4*>(p) = v;
+#else
+  __builtin_nontemporal_store((atvs_u32x4){v.x, v.y, v.z, v.w}, reinterpret_cast<atvs_u32x4*>(p));
+#endif
+}
 
 // The two fp16 pieces of two fp32 values, packed: h0 = f16(x), h1 = f16((x - h0) * 2^11)  (x - h0 is exact in fp32), in FIVE
 // vector instructions: one packed conversion, two mixed-precision fused multiply-adds h0 * -1 + x that read the fp16 halves

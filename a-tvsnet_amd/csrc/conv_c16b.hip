@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
       }
       const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
                           __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
-      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, (t * erow) * 4u, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, (t * erow) * 4u, ATVS_BUF_NT);
       f32x2 lo = {ok ? a0 : 0.f, ok ? a1 : 0.f}, hi = {ok ? a2 : 0.f, ok ? a3 : 0.f};
       ssum2[0] += lo;
       ssum2[1] += hi;

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, RS_WAVES) void refine_stems_kernel(const float
         const u32x4 bits = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
                             __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
         const unsigned off = ok ? (unsigned)(((z * H + yy) * W + xx) * 8 + hf * 4) * 4u : ybytes;
-        __builtin_amdgcn_raw_buffer_store_b128(bits, c == 0 ? yrsrc : (c == 1 ? yrsrc1 : yrsrc2), off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(bits, c == 0 ? yrsrc : (c == 1 ? yrsrc1 : yrsrc2), off, 0, ATVS_BUF_NT);
       }
     } else
 #pragma unroll
@@ -335,7 +335,7 @@ __global__ __launch_bounds__(256, RS_WAVES) void refine_stems_kernel(const float
       const u32x4 bits = {__builtin_bit_cast(unsigned, v.x), __builtin_bit_cast(unsigned, v.y),
                           __builtin_bit_cast(unsigned, v.z), __builtin_bit_cast(unsigned, v.w)};
       // a buffer store: lanes outside the volume get an offset past the descriptor's range and are dropped
-      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, ok ? (unsigned)(((z * H + yy) * W + xx) * 32 + c * 4) * 4u : ybytes, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, ok ? (unsigned)(((z * H + yy) * W + xx) * 32 + c * 4) * 4u : ybytes, 0, ATVS_BUF_NT);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -722,7 +722,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
               v.z = (v.z < 0.f) ? 0.f : v.z;
               v.w = (v.w < 0.f) ? 0.f : v.w;
             }
-            st4(yg + (eo + (size_t)t * erow), v);
+            st4_stream(yg + (eo + (size_t)t * erow), v);
             ssum[0] += v.x; ssum[1] += v.y; ssum[2] += v.z; ssum[3] += v.w;
             ssq[0] += v.x * v.x; ssq[1] += v.y * v.y; ssq[2] += v.z * v.z; ssq[3] += v.w * v.w;
           }
@@ -732,7 +732,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
         if (SIB && e2_ok) {
           const float4 v = make_float4(__builtin_fmaf(acc2x[0], XB_IRS, acc2[0]) + epb2.x, __builtin_fmaf(acc2x[1], XB_IRS, acc2[1]) + epb2.y,
                                        __builtin_fmaf(acc2x[2], XB_IRS, acc2[2]) + epb2.z, __builtin_fmaf(acc2x[3], XB_IRS, acc2[3]) + epb2.w);
-          st4(y2g + eo2, v);
+          st4_stream(y2g + eo2, v);
           ssum2[0] += v.x; ssum2[1] += v.y; ssum2[2] += v.z; ssum2[3] += v.w;
           ssq2[0] += v.x * v.x; ssq2[1] += v.y * v.y; ssq2[2] += v.z * v.z; ssq2[3] += v.w * v.w;
         }

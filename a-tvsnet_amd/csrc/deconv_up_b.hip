@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
                             __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
         const bool row_ok = ty0 + t < p.Hi;
-        __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, soff, ATVS_BUF_NT);
         const bool ok = evox_ok && row_ok;
         const float b0 = ok ? a0 : 0.f, b1 = ok ? a1 : 0.f, b2 = ok ? a2 : 0.f, b3 = ok ? a3 : 0.f;
         ssum[0] += b0; ssum[1] += b1; ssum[2] += b2; ssum[3] += b3;

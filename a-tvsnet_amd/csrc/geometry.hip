@@ -272,7 +272,7 @@ __global__ __launch_bounds__(256) void warp_planes_shared_kernel(
       else rec = make_uint4(h0a, h0b, r0, r1);        // h0 of channels 0..3 (own) | 4..7 (partner's)
       unsigned char* dst = reinterpret_cast<unsigned char*>(out + (size_t)(c >> 3) * (size_t)plane_stride) +
                            (hi ? (size_t)piece_bytes : (size_t)0) + ((size_t)d * npix + pix) * 16;
-      *reinterpret_cast<uint4*>(dst) = rec;
+      st4u_stream(dst, rec);
     } else if (plane_stride > 0) {
       // chunk-planar output [C/8][D][h][w][8] (the layout atvs_conv_xw_f32 reads with x_planar)
       st4(out + (size_t)(c >> 3) * (size_t)plane_stride + ((size_t)d * npix + pix) * 8 + (c & 7), o);

@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void bn_add_kernel(const float* __restrict__ x
     float4 d = term(x2, p2, relu_mask & 4);
     a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
   }
-  st4(y + i, a);
+  st4_stream(y + i, a);
 }
 
 extern "C" int atvs_bn_add(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
