@@ -482,13 +482,17 @@ __device__ __forceinline__ void relative_pose(const float* left_cam, const float
   for (int i = 0; i < 3; ++i) vec[i] = v1[i] + v2[i];
 }
 
-// pose (12 floats: mat row-major, vec) computed once by a 1-thread kernel
-__global__ void relative_pose_kernel(const float* left_cam, const float* right_cam, float* pose) {
-  M3 mat;
-  float vec[3];
-  relative_pose(left_cam, right_cam, &mat, vec);
-  for (int i = 0; i < 9; ++i) pose[i] = mat.m[i];
-  for (int i = 0; i < 3; ++i) pose[9 + i] = vec[i];
+// pose (12 floats: mat row-major, vec) computed by thread 0 of every workgroup into LDS (round 5: it was a 1-thread launch of its
+// own in front of every consumer, 15 launches of 4.6 us per depth map; the same function, the same values)
+__device__ __forceinline__ void workgroup_pose(const float* left_cam, const float* right_cam, float* pose_s) {
+  if (threadIdx.x == 0) {
+    M3 mat;
+    float vec[3];
+    relative_pose(left_cam, right_cam, &mat, vec);
+    for (int i = 0; i < 9; ++i) pose_s[i] = mat.m[i];
+    for (int i = 0; i < 3; ++i) pose_s[9 + i] = vec[i];
+  }
+  __syncthreads();
 }
 
 // ---------------------------------------------------------------------------
@@ -496,10 +500,13 @@ __global__ void relative_pose_kernel(const float* left_cam, const float* right_c
 // method 0 bilinear / 1 nearest; mask written when mask_out != nullptr.
 // ---------------------------------------------------------------------------
 template <int NEAREST>
-__global__ __launch_bounds__(256) void warp_by_depth_kernel(const float* __restrict__ src, const float* __restrict__ pose,
+__global__ __launch_bounds__(256) void warp_by_depth_kernel(const float* __restrict__ src, const float* __restrict__ left_cam,
+                                                            const float* __restrict__ right_cam,
                                                             const float* __restrict__ depth, float* __restrict__ out,
                                                             float* __restrict__ mask_out, int h, int w, int C,
                                                             int inverse_depth) {
+  __shared__ float pose[12];
+  workgroup_pose(left_cam, right_cam, pose);
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long npix = (long)h * w;
   if (gid >= npix * C) return;
@@ -534,12 +541,11 @@ extern "C" int atvs_warp_by_depth(const float* src, const float* left_cam, const
   if (!src || !left_cam || !right_cam || !depth || !out || !pose_ws) return ATVS_ERR_NULL;
   if (h <= 0 || w <= 0 || C <= 0) return ATVS_ERR_SHAPE;
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(relative_pose_kernel, dim3(1), dim3(1), 0, s, left_cam, right_cam, pose_ws);
   long n = (long)h * w * C;
   if (method == 0)
-    hipLaunchKernelGGL((warp_by_depth_kernel<0>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, pose_ws, depth, out, mask_out, h, w, C, inverse_depth);
+    hipLaunchKernelGGL((warp_by_depth_kernel<0>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out, mask_out, h, w, C, inverse_depth);
   else if (method == 1)
-    hipLaunchKernelGGL((warp_by_depth_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, pose_ws, depth, out, mask_out, h, w, C, inverse_depth);
+    hipLaunchKernelGGL((warp_by_depth_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out, mask_out, h, w, C, inverse_depth);
   else
     return ATVS_ERR_ARG;
   ATVS_LAUNCH_CHECK();
@@ -647,9 +653,12 @@ __global__ __launch_bounds__(256) void max_kernel(const float* __restrict__ x, l
 }
 
 template <int PASS>
-__global__ __launch_bounds__(256) void transform_depth_kernel(const float* __restrict__ depth, const float* __restrict__ pose,
+__global__ __launch_bounds__(256) void transform_depth_kernel(const float* __restrict__ depth, const float* __restrict__ left_cam,
+                                                              const float* __restrict__ right_cam,
                                                               float* __restrict__ out, float* __restrict__ ws, int h, int w,
                                                               int inverse_depth) {
+  __shared__ float pose[12];
+  workgroup_pose(left_cam, right_cam, pose);
   long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
   long npix = (long)h * w;
   float z = -INFINITY;
@@ -686,12 +695,10 @@ extern "C" int atvs_transform_depth(const float* depth, const float* left_cam, c
   if (h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
   hipStream_t s = as_stream(stream);
   long npix = (long)h * w;
-  float* pose = ws14 + 2;
   hipLaunchKernelGGL(fill_neg_inf_kernel, dim3(1), dim3(1), 0, s, ws14);
-  hipLaunchKernelGGL(relative_pose_kernel, dim3(1), dim3(1), 0, s, left_cam, right_cam, pose);
   hipLaunchKernelGGL(max_kernel, dim3(min(cdiv(npix, 256), 1024)), dim3(256), 0, s, depth, npix, ws14);
-  hipLaunchKernelGGL((transform_depth_kernel<0>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, pose, out, ws14, h, w, inverse_depth);
-  hipLaunchKernelGGL((transform_depth_kernel<1>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, pose, out, ws14, h, w, inverse_depth);
+  hipLaunchKernelGGL((transform_depth_kernel<0>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, left_cam, right_cam, out, ws14, h, w, inverse_depth);
+  hipLaunchKernelGGL((transform_depth_kernel<1>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, left_cam, right_cam, out, ws14, h, w, inverse_depth);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
