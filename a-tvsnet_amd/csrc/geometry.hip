@@ -499,12 +499,15 @@ __device__ __forceinline__ void workgroup_pose(const float* left_cam, const floa
 // Per-pixel-depth warp (homography_warping.py:108-176): p' ~ M p + v * delta(p).
 // method 0 bilinear / 1 nearest; mask written when mask_out != nullptr.
 // ---------------------------------------------------------------------------
-template <int NEAREST>
+// ERR: out[pix, c_off + c] (rows of ld floats) = |warp - ref[pix, c]| * valid -- the warp, tf.abs(. - ref) * mask and the copy into
+// the tiled-channel buffer of the refinement's photo_err / geo_err (model.py:309-316) as one launch
+template <int NEAREST, bool ERR = false>
 __global__ __launch_bounds__(256) void warp_by_depth_kernel(const float* __restrict__ src, const float* __restrict__ left_cam,
                                                             const float* __restrict__ right_cam,
                                                             const float* __restrict__ depth, float* __restrict__ out,
                                                             float* __restrict__ mask_out, int h, int w, int C,
-                                                            int inverse_depth) {
+                                                            int inverse_depth, const float* __restrict__ ref = nullptr,
+                                                            int ld = 0, int c_off = 0) {
   __shared__ float pose[12];
   workgroup_pose(left_cam, right_cam, pose);
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -531,7 +534,11 @@ __global__ __launch_bounds__(256) void warp_by_depth_kernel(const float* __restr
     o = ((t.wa * src[(size_t)t.i00 * C + c] + t.wb * src[(size_t)t.i01 * C + c]) + t.wc * src[(size_t)t.i10 * C + c]) +
         t.wd * src[(size_t)t.i11 * C + c];
   }
-  out[gid] = o;
+  if (ERR) {
+    out[(size_t)pix * ld + c_off + c] = fabsf(o - ref[gid]) * valid;
+  } else {
+    out[gid] = o;
+  }
   if (mask_out && c == 0) mask_out[pix] = valid;
 }
 
@@ -546,6 +553,28 @@ extern "C" int atvs_warp_by_depth(const float* src, const float* left_cam, const
     hipLaunchKernelGGL((warp_by_depth_kernel<0>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out, mask_out, h, w, C, inverse_depth);
   else if (method == 1)
     hipLaunchKernelGGL((warp_by_depth_kernel<1>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out, mask_out, h, w, C, inverse_depth);
+  else
+    return ATVS_ERR_ARG;
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// |homography_warping_by_depth(src) - ref| * mask written into channels [c_off, c_off + C) of out (h, w, ld): photo_err / geo_err
+// of the refinement (model.py:309-316: the warp, tf.abs(warped - ref) * mask) straight into the tiled-channel buffer.  The same
+// operations in the same order as atvs_warp_by_depth followed by atvs_absdiff_mask.
+extern "C" int atvs_warp_by_depth_err(const float* src, const float* ref, const float* left_cam, const float* right_cam,
+                                      const float* depth, float* out, int ld_out, int c_off, int h, int w, int C, int method,
+                                      int inverse_depth, atvs_stream_t stream) {
+  if (!src || !ref || !left_cam || !right_cam || !depth || !out) return ATVS_ERR_NULL;
+  if (h <= 0 || w <= 0 || C <= 0 || c_off < 0 || c_off + C > ld_out) return ATVS_ERR_SHAPE;
+  hipStream_t s = as_stream(stream);
+  long n = (long)h * w * C;
+  if (method == 0)
+    hipLaunchKernelGGL((warp_by_depth_kernel<0, true>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out,
+                       (float*)nullptr, h, w, C, inverse_depth, ref, ld_out, c_off);
+  else if (method == 1)
+    hipLaunchKernelGGL((warp_by_depth_kernel<1, true>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out,
+                       (float*)nullptr, h, w, C, inverse_depth, ref, ld_out, c_off);
   else
     return ATVS_ERR_ARG;
   ATVS_LAUNCH_CHECK();
