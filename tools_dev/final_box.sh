@@ -5,7 +5,7 @@ root=$PWD
 out=$root/gpurun_out/$tag
 mkdir -p $out
 cp profiles/.measured_head $out/head 2>/dev/null
-timeout 1500 python -m pytest tests -q -m gpu 2>&1 | tail -5 > $out/gputests.log
+timeout 1500 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $out/gputests.log
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 > $out/smoke.log
 python bench.py > $out/bench_default.log 2>&1
 for w in cfg2 cfg4 cfg5; do python bench.py --workload $w --no-cpu-baseline --no-fp32-path --no-power > $out/bench_$w.log 2>&1; done
