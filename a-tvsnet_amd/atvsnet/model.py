@@ -258,7 +258,7 @@ def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_st
         _refinement_volumes(b, bufs, depth_ref, depth_views[v], cams[:, ref_id], view_cam, hull_cam,
                             shallow[si(ref_id):si(ref_id) + 1], shallow[si(v):si(v) + 1], D, ds, di, depth_start,
                             depth_interval)
-    pv = prob_vol.unsqueeze(-1).expand(S, -1, -1, -1, -1).contiguous() if S > 1 else prob_vol.unsqueeze(-1)
+    pv = ops.stack([prob_vol[0].unsqueeze(-1)] * S, 0) if S > 1 else prob_vol.unsqueeze(-1)      # the shared volume, once per sample
     return _refine_net(bufs, pv, chan, True)
 
 
