@@ -715,7 +715,10 @@ def pack_conv_xp_sibling(key, w_host, device):
 
 def conv2d_lds_ok(cin, cout, dilation, H, W):
     """Is the LDS-tiled 2-D kernel (atvs_conv2d_lds_f32) used for a 3x3 stride-1 SAME convolution of this shape?"""
-    return (cfg.force_impl != 'gather' and cfg.conv2d_lds and H >= 8 and W >= 16
+    # tiny maps (the pyramid branches' pooled maps, 2 x 3 ... 8 x 10 pixels): the split-operand kernel covers them with one masked
+    # tile per image in ~20 us; the generic gather kernel needs ~49 us for its serial 9 x Cin K loop
+    tiny_ok = split_on('c2b') and cin % 32 == 0 and H >= 2 and W >= 2
+    return (cfg.force_impl != 'gather' and cfg.conv2d_lds and ((H >= 8 and W >= 16) or tiny_ok)
             and bool(_lib.lib().atvs_conv2d_lds_supported(int(cin), int(cout), int(dilation))))
 
 

@@ -888,3 +888,23 @@ def test_strided_unit_conv2_on_the_split_kernel(cuda, G, H, W, cin):
     flat = y.reshape(G, -1, cout).double()
     assert float((p[:, 0].double() - flat.mean(1)).abs().max()) <= 1e-5
     assert float((p[:, 1].double() - 1.0 / torch.sqrt(flat.var(1, unbiased=False) + 1e-3)).abs().max()) <= 1e-4
+
+
+@pytest.mark.parametrize('G,H,W', [(5, 2, 3), (5, 4, 5), (2, 8, 10), (1, 3, 17), (3, 9, 2)])
+def test_tower_3x3_on_tiny_maps(cuda, G, H, W):
+    """The pyramid branches' 3x3 convolutions (128 -> 32) on their pooled maps of 2 x 3 ... 8 x 10 pixels (reference
+    cnn_wrapper/atvsnet.py:271-286) run on conv2d_b.hip with one masked tile per image: against the oracle's convolution and
+    the moments of what was written (as few as 6 samples per image, quirk C16)."""
+    from atvsnet_amd import ops
+    cin, cout = 128, 32
+    g = torch.Generator().manual_seed(H * 31 + W)
+    x = torch.randn(G, H, W, cin, generator=g)
+    w = torch.randn(3, 3, cin, cout, generator=g) * (1.0 / (9 * cin)) ** 0.5
+    assert ops.conv2d_lds_ok(cin, cout, 1, H, W)
+    y, st = ops.conv(x.to(cuda), ('tiny', H, W), w.numpy(), want_stats=True, groups=G)
+    want = T.conv(x, w, 1, 'SAME')
+    assert float((y.cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    p = ops.bn_params(st, cout, y).reshape(G, 3, cout)
+    flat = want.reshape(G, -1, cout).double()
+    assert float((p[:, 0].cpu().double() - flat.mean(1)).abs().max()) <= 1e-5
+    assert float((p[:, 1].cpu().double() - 1.0 / torch.sqrt(flat.var(1, unbiased=False) + 1e-3)).abs().max()) <= 1e-3
