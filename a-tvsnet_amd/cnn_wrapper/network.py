@@ -613,6 +613,9 @@ class Network(object):
         wu = self.store.get_host('%s/weight_unique' % scope, (3, 3, 3, c_in, c_in))
         ws = self.store.get_host('%s/weight_shared' % scope, (3, 3, 3, c_in, c_in))
         key = scope + '/shared|unique'
+        if ops.aanet_fused_ok(xs):
+            # the whole module in one launch: [S|R] of every view stays in registers (aanet_b.hip)
+            return ops.aanet_fused(xs, key, ws, wu).unsqueeze(0)
         w16 = np.concatenate([ws, wu], axis=-1)
         if stacked is not None:
             sr = ops.conv(stacked, key, w16, relu=True, groups=stacked.shape[0])

@@ -29,7 +29,7 @@ class Config(object):
     xb             the split-operand x-pair kernel (conv_xb.hip) in front of the fp32 one (conv_xw.hip)
     planar         the warped half of the cost volume chunk-planar;  pieces: ... as fp16 pieces written by the warp
     planar_concat  the refinement's 32-channel concat as four dense 8-channel planes
-    conv_c16, deconv_up, stem, conv2d_lds, conv1x1, xp1w, xpair, siblings, bottleneck
+    conv_c16, deconv_up, stem, conv2d_lds, conv1x1, xp1w, xpair, siblings, bottleneck, aanet_fused
                    the dedicated kernel of that layer family in front of the generic ones
     prologue       normalise-on-load / add-on-load in the consumers (else pending batch norms / sums are materialised first)
     sum_on_load    the U-Net's skip sums formed inside their consumer's staging (transposed convolution, 16-channel convolution)
@@ -46,6 +46,7 @@ class Config(object):
         pieces=os.environ.get('ATVS_PIECES', '1') == '1',
         planar_concat=os.environ.get('ATVS_PLANAR_CONCAT', '1') != '0',
         conv_c16=True, deconv_up=True, stem=True, conv2d_lds=True, conv1x1=True, xp1w=True, xpair=True, siblings=True,
+        aanet_fused=os.environ.get('ATVS_AANET_FUSED', '1') != '0',
         bottleneck=os.environ.get('ATVS_BOTTLENECK', '1') != '0',
         prologue=True, sum_on_load=os.environ.get('ATVS_SUM_ON_LOAD', '1') != '0', force_impl=None, fused_finalize=False,
         side_streams=os.environ.get('ATVS_SIDE_STREAMS', '1') != '0')
@@ -2245,6 +2246,43 @@ def aanet_combine(srs, xs, out=None):
     return out
 
 
+
+
+def aanet_fused_ok(xs):
+    """Does the whole AANet module over these views run as ONE launch (atvs_aanet_b_f32)?"""
+    return (cfg.aanet_fused and cfg.conv_c16 and cfg.force_impl is None and split_on('c16b') and xs[0].dim() == 4
+            and xs[0].shape[-1] == 8 and xs[0].shape[2] >= 12 and all(t.is_contiguous() and tuple(t.shape) == tuple(xs[0].shape) for t in xs)
+            and bool(_lib.lib().atvs_aanet_b_supported(8, len(xs))))
+
+
+def aanet_fused(xs, key, w_shared, w_unique):
+    """AANet over the views xs (list of (D,H,W,8)): score convolutions + cross-view softmax + weighted sum in one launch ->
+    (D,H,W,8).  w_shared / w_unique: host TF kernels [3,3,3,8,8]; key: pack-cache key."""
+    import numpy as np
+    dev = xs[0].device
+    ck = ('aanet_b', key, str(dev))
+    pk = _pack_cache.get(ck)
+    if pk is None:
+        L = _lib.lib()
+        pf = ctypes.c_long()
+        L.atvs_aanet_b_pack_size(ctypes.byref(pf))
+        packed = np.empty(pf.value, np.uint8)
+        ws = np.ascontiguousarray(w_shared, dtype=np.float32)
+        wu = np.ascontiguousarray(w_unique, dtype=np.float32)
+        rc = L.atvs_aanet_b_pack(ws.ctypes.data_as(ctypes.c_void_p), wu.ctypes.data_as(ctypes.c_void_p),
+                                 packed.ctypes.data_as(ctypes.c_void_p))
+        if rc:
+            raise RuntimeError('atvs_aanet_b_pack failed (%d)' % rc)
+        pk = _Packed()
+        pk.key, pk.tab = key, None
+        pk.wp = None if dev.type == 'meta' else torch.from_numpy(packed).to(dev)
+        _pack_cache[ck] = pk
+    D, H, W, _ = xs[0].shape
+    out = _new(xs[0], xs[0].shape)
+    if _dev_ok(out, *xs):
+        with _Timed(key, (D, H, W, 8), 16, len(xs)):
+            _call('atvs_aanet_b_f32', _ptr_array(xs), len(xs), _p(pk.wp), _p(out), D, H, W, _stream())
+    return out
 
 
 def aanet_partial(srs, xs, stage, ssum=None, umax=None):

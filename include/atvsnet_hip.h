@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 36
+#define ATVS_ABI_VERSION 37
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -550,6 +550,18 @@ int atvs_stack(const float* const* srcs, int n, long elems, float* dst, atvs_str
  * out (V,8) = sum_n softmax_n(R_n - S_n + sum_m S_m) * X_n. */
 int atvs_aanet_combine(const float* const* sr_ptrs, const float* const* x_ptrs, int nv, float* out, long V,
                        atvs_stream_t stream);
+
+/* The whole AANet module in ONE launch (aanet_b.hip, round 5): the shared | unique 3x3x3 score convolutions of every view (split
+ * fp16 operands, conv_c16b's stage) with their results kept in registers, then the cross-view softmax and weighted sum --
+ *   out (D,H,W,8) = sum_n softmax_n((R_n - S_n) + sum_m S_m) * X_n,   S_n | R_n = relu(conv3d(X_n, W_shared | W_unique, SAME))
+ * (reference cnn_wrapper/network.py:282-351,378-408).  x: HOST array of nv <= 4 device pointers (D,H,W,8) (atvs_aanet_b_supported; more views: the two-launch form); packed_w:
+ * atvs_aanet_b_pack(w_shared, w_unique) (HOST; [3,3,3,8,8] each; size in BYTES).  [S|R] is never written: bit for bit
+ * atvs_conv_c16b_f32 (ReLU) per view followed by atvs_aanet_combine. */
+int atvs_aanet_b_supported(int C, int nv);
+int atvs_aanet_b_pack_size(long* packed_bytes);
+int atvs_aanet_b_pack(const float* w_shared, const float* w_unique, unsigned char* packed);
+int atvs_aanet_b_f32(const float* const* x, int nv, const unsigned char* packed_w, float* out, int D, int H, int W,
+                     atvs_stream_t stream);
 
 /* The same arithmetic split at its three reductions over views, for views sharded
  * across GPUs (all-reduce SUM / MAX / SUM between stages):

@@ -525,3 +525,24 @@ def test_deconv_sums_its_inputs_on_load_bitwise(cuda, G, shape, nterms):
         assert s_off._final is not None
     assert torch.equal(got, ref)
     assert torch.equal(ops.bn_params(st, cout, got), ops.bn_params(st_ref, cout, ref))
+
+
+@pytest.mark.parametrize('nv,shape', [(4, (16, 24, 40)), (2, (9, 13, 35)), (3, (4, 8, 16)), (1, (6, 10, 20)), (4, (5, 9, 17))])
+def test_aanet_module_in_one_launch_bitwise(cuda, weights, nv, shape):
+    """aanet_b.hip: the shared | unique score convolutions of every view and the cross-view softmax + weighted sum (reference
+    cnn_wrapper/network.py:282-351,378-408) as ONE launch with [S|R] in registers -- against the two-launch form (conv_c16b per
+    view + aanet_combine) bit for bit, and against the oracle's attention_aggregation; ragged tiles, 1 to 4 views."""
+    from atvsnet_amd import ops
+    from atvsnet_amd.cnn_wrapper.atvsnet import AttAggregation_keepchannel
+    from oracle import nets
+    xs = [_rand(shape + (8,), 70 + n) for n in range(nv)]
+    stacked = torch.stack(xs, 0).to(cuda)
+    assert ops.aanet_fused_ok([stacked[n] for n in range(nv)])
+    outs = {}
+    for fused in (True, False):
+        with ops.configure(aanet_fused=fused):
+            net = AttAggregation_keepchannel({'data': stacked}, is_training=True)
+            outs[fused] = net.get_output().clone()
+    assert torch.equal(outs[True], outs[False])
+    want = nets.attention_aggregation(torch.stack(xs, -1)[None], weights, 'attention_aggregate')
+    assert float((outs[True].cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())

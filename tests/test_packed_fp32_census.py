@@ -21,7 +21,7 @@ from atvsnet_amd import _lib
 
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 # kernels that reserve the whole register file of their SIMD (asm volatile("" ::: "v255", "a255")): nothing runs beside them
-OWNS_ITS_SIMD = ('conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel')
+OWNS_ITS_SIMD = ('conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel', 'aanet_b_kernel')
 # fp32-MFMA predecessors (A/B path, ops.configure(split16=False)): one workgroup per CU with 450-512 registers; packed fp32 by design
 FP32_ONE_WORKGROUP = ('conv_xw_kernel', 'deconv_up_kernel', 'conv_c16_kernel')
 # FMA-bound kernels with hand-written packed FMAs that share their SIMDs: the reason PipelinedInference(co_resident=True) is opt-in
