@@ -248,3 +248,56 @@ def test_results_outside_the_fp16_range_fail_loudly():
     bad[2, 0] = np.inf
     with pytest.raises(FloatingPointError, match='2 non-finite.*ATVS_SPLIT16=0'):
         example.check_finite(bad)
+
+
+def test_config_object_and_context_manager():
+    """ops.cfg holds every dispatch switch; ops.configure sets them for a block and restores them -- also on an exception;
+    unknown names raise; split16 drags the x-pair kernel choice along unless xb is given in the same call."""
+    from atvsnet_amd import ops
+    before = ops.cfg.snapshot()
+    with ops.configure(split16=False, prologue=False):
+        assert not ops.cfg.split16 and not ops.cfg.xb and not ops.cfg.prologue
+        with ops.configure(split16=True, xb=False):
+            assert ops.cfg.split16 and not ops.cfg.xb
+        assert not ops.cfg.split16 and not ops.cfg.xb
+    assert ops.cfg.snapshot() == before
+    with pytest.raises(ZeroDivisionError):
+        with ops.configure(bottleneck=False, split_off=('c2b', 'btl')):
+            assert ops.cfg.split_off == frozenset(('c2b', 'btl')) and not ops.split_on('c2b') and ops.split_on('c16b')
+            1 / 0
+    assert ops.cfg.snapshot() == before
+    with pytest.raises(AttributeError):
+        ops.configure(no_such_switch=True)
+    with pytest.raises(AttributeError):
+        ops.cfg.no_such_switch = True
+    with pytest.raises(ValueError):
+        ops.cfg.force_impl = 'fastest'
+    assert sum(1 for ln in open(ops.__file__) if ln.startswith('def use_')) == 0
+
+
+def test_deferred_sums_on_meta_tensors():
+    """A deferred skip sum (2 or 3 terms) reaches the transposed convolution unformed where the kernel takes it (16 -> 8) and is
+    materialised everywhere else; the x-pair siblings only take two-term sums.  Host logic only (meta tensors: no launch)."""
+    import torch
+    from atvsnet_amd import ops
+    G, shape = 2, (4, 8, 16)
+    mk = lambda c: torch.empty((G,) + shape + (c,), dtype=torch.float32, device='meta')      # noqa: E731
+    par = lambda c: torch.empty((G, 3, c), dtype=torch.float32, device='meta')               # noqa: E731
+    three = ops.PendingSum([ops.PendingBN(mk(16), par(16), True), mk(16), ops.PendingBN(mk(16), par(16), False)])
+    assert ops.deconv_sum_ok(three, 8, G) and not ops.deconv_sum_ok(three, 16, G)
+    assert not ops.siblings_prologue_ok(ops.PendingSum([ops.PendingBN(mk(8), par(8), True)] * 3))
+    with pytest.raises(ValueError):
+        ops.PendingSum([mk(16)])
+    with pytest.raises(ValueError):
+        three.prologue()
+    with ops.configure(sum_on_load=False):
+        assert not ops.deconv_sum_ok(three, 8, G)
+    w = np.zeros((3, 3, 3, 8, 16), np.float32)
+    y, st = ops.conv3d_transpose_s2(three, ('meta-up', 16), w, want_stats=True, groups=G)
+    assert tuple(y.shape) == (G, 8, 16, 32, 8) and three._final is None and st.groups == G
+    # a planar pending batch norm enters a sum materialised (its raw buffer is not a channel-last operand)
+    D, h, w_ = 4, 8, 32
+    planar = ops.PendingBN(torch.empty((1, 1, ops.planar_stride(D, h, w_)), dtype=torch.float32, device='meta'),
+                           torch.empty((3, 8), dtype=torch.float32, device='meta'), True, planar=(D, h, w_))
+    s2 = ops.PendingSum([planar, torch.empty((1, D, h, w_, 8), dtype=torch.float32, device='meta')])
+    assert all(not isinstance(t, ops.PendingBN) for t in s2.items)
