@@ -131,8 +131,8 @@ class ResNetDS2SPP(Network):
     def setup(self):
         f = 32
         (self.feed('data')
-             .conv_bn(3, f, 2, name='conv0_0')
-             .conv_bn(3, f, 1, name='conv0_1')
+             .conv_bn(3, f, 2, name='conv0_0', defer_bn=True)      # normalised while conv0_1 / conv0_2 / fusion1 stage their input
+             .conv_bn(3, f, 1, name='conv0_1', defer_bn=True)
              .conv_bn(3, f, 1, name='conv0_2')
              .res_block(3, f, num_block=3, stride=1, rate=1, name='conv0_x')
              .res_block(3, f * 2, num_block=8, stride=2, rate=1, name='conv1_x')
@@ -150,7 +150,7 @@ class ResNetDS2SPP(Network):
                                out_slice=('concat_feature', (6 + i) * f)))      # straight into its slice of the concat
         (self.feed('conv1_x', 'conv3_x', 'branch_0', 'branch_1', 'branch_2', 'branch_3')
              .concat(axis=-1, name='concat_feature')
-             .conv_bn(3, f * 4, 1, relu=True, name='fusion0')
+             .conv_bn(3, f * 4, 1, relu=True, name='fusion0', defer_bn=True)
              .conv(1, f, 1, relu=False, name='fusion1'))
 
 

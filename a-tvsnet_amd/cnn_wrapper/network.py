@@ -198,6 +198,14 @@ class Network(object):
         rank = input.dim()
         if rank not in (4, 5):
             raise ValueError('Improper input rank for layer: ' + name)
+        if rank == 4 and padding == 'SAME' and ops.norm_on_load_2d_ok(input, kernel_size, filters, strides, rate) \
+                and (input.shape[0] == 1 or self.independent_samples):
+            # a pending batch norm (+ ReLU) applied while the kernel stages its input: the normalised tensor is never written
+            raw, (_, params, _, in_relu, _) = input.prologue()
+            w = self._kernel('%s/kernel' % name, (kernel_size,) * 2 + (raw.shape[-1], filters))
+            bias = self._vec('%s/bias' % name, filters, raw) if biased else None
+            return ops.conv(raw, name + '/kernel', w, stride=1, dilation=rate, padding='SAME', bias=bias, relu=relu,
+                            groups=raw.shape[0], in_params=params, in_relu=in_relu)
         x = self._bt(input, name)
         G, cin = x.shape[0], x.shape[-1]
         if rank == 5 and kernel_size == 3 and filters == 1 and cin == 8 and strides == 1 and rate == 1 \
@@ -233,7 +241,14 @@ class Network(object):
                 return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None),
                                                 c_off=c_off), out_slice, filters)
             input = input.materialize()
-        x = self._bt(input, name)
+        in_params, in_relu = None, False
+        if rank == 4 and padding == 'SAME' and self.training and buf is None \
+                and ops.norm_on_load_2d_ok(input, kernel_size, filters, strides, rate) \
+                and (input.shape[0] == 1 or self.independent_samples):
+            # the producer's batch norm (+ ReLU) is applied while this convolution stages its input
+            x, (_, in_params, _, in_relu, _) = input.prologue()
+        else:
+            x = self._bt(input, name)
         G, cin = x.shape[0], x.shape[-1]
         kind = 'conv2d' if rank == 4 else 'conv3d'
         vname = '%s/%s/kernel' % (name, kind)
@@ -242,11 +257,11 @@ class Network(object):
         if self.training and defer_bn and buf is None and not center and filters % 4 == 0:
             # extension: the layer's consumers are adds only -> hand them the raw output + the moments
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
-                             groups=G)
+                             groups=G, in_params=in_params, in_relu=in_relu)
             return ops.PendingBN(y, ops.bn_params(st, filters, y, None, BN_EPS), relu)
         if self.training:
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
-                             out=buf, y_coff=c_off, groups=G)
+                             out=buf, y_coff=c_off, groups=G, in_params=in_params, in_relu=in_relu)
         else:
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, out=buf,
                              y_coff=c_off, groups=G), None

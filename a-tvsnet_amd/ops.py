@@ -714,6 +714,20 @@ def pack_conv_xp_sibling(key, w_host, device):
     return pk
 
 
+def norm_on_load_2d_ok(src, ksize, filters, stride=1, rate=1):
+    """Can a 2-D convolution of this shape take a pending batch norm (PendingBN, channel-last) as it is -- the kernel
+    normalises (+ ReLU) while staging (conv2d_b.hip / conv1x1_b.hip `in_params`)?"""
+    if not (cfg.prologue and isinstance(src, PendingBN) and src._final is None and not src.planar and src.dim() == 4
+            and src.raw.is_contiguous() and stride == 1):
+        return False
+    G, H, W, cin = src.shape
+    if ksize == 3:
+        return conv2d_lds_ok(cin, filters, rate, H, W) and split_on('c2b') and cin % 32 == 0
+    if ksize == 1:
+        return rate == 1 and conv1x1_ok(cin, filters)
+    return False
+
+
 def conv2d_lds_ok(cin, cout, dilation, H, W):
     """Is the LDS-tiled 2-D kernel (atvs_conv2d_lds_f32) used for a 3x3 stride-1 SAME convolution of this shape?"""
     # tiny maps (the pyramid branches' pooled maps, 2 x 3 ... 8 x 10 pixels): the split-operand kernel covers them with one masked
