@@ -15,6 +15,17 @@
 
 #include "conv_common.h"
 
+// Development build (-DATVS_S2_DEBUG): per-wavefront tick counts of the phases (tools_dev/phase_s2.py)
+#ifdef ATVS_S2_DEBUG
+__device__ unsigned long long atvs_dbg_s2[4096 * 8];
+extern "C" int atvs_debug_read_s2(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(atvs_dbg_s2), sizeof(atvs_dbg_s2));
+}
+#define SDBG(i) { unsigned long long t_ = clock64(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; }
+#else
+#define SDBG(i)
+#endif
+
 namespace {
 
 constexpr int S2_TZ = 2, S2_TY = 4, S2_TX = 16;
@@ -77,8 +88,12 @@ __device__ __forceinline__ void s2_split(const float4& v, f16x4* p0, f16x4* p1) 
   }
 }
 
-// NT = Cout / 16 (2 or 4); a wavefront owns NTW = NT / 2 output tiles of one z plane
-template <int NT>
+// NT = Cout / 16 (2 or 4); a wavefront owns NTW = NT / 2 output tiles of one z plane.
+// WLDS: the packed weights of every chunk are copied into LDS once (16 -> 32: 56 KB beside the 95 KB of images) and the K loop
+// takes its weight fragments from there.  Streamed from L2 one step ahead (rounds 3-4) a step's 12 MFMAs = 192 cycles could not
+// cover the L2 round trip: every one of the 14 steps of a stage waited for its weights (round 5).  Where the weights do not fit
+// (32 -> 64) they are requested TWO steps ahead (three register slots).
+template <int NT, bool WLDS>
 __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
   // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
@@ -92,6 +107,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
 
   // this lane's fragment (channels 8 (q & 1) ..) of output (wz, row 0, r) at tap (0,0,0); lane half q >> 1 = tap of the step
   const int fbase = (2 * wz * HY) * S2_ROWB + r * S2_VB + (q & 1) * 16;
+  const f16x8* wsrc = p.wp;
+  if (WLDS) {
+    const float4* src = reinterpret_cast<const float4*>(p.wp);
+    float4* dst = reinterpret_cast<float4*>(smem + S2_NP * S2_IMG);
+    for (int i = tid; i < p.nchunk * JC * NT * S2_NP * 64; i += 256) dst[i] = src[i];
+    __syncthreads();
+    wsrc = reinterpret_cast<const f16x8*>(smem + S2_NP * S2_IMG);
+  }
 
   int goff[MAXS], laddr[MAXS];
   unsigned pg[MAXS];
@@ -166,8 +189,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
   }
 
+#ifdef ATVS_S2_DEBUG
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
   for (int stage = 0; stage < nstage; ++stage) {
     const int k = stage / p.nchunk, ch = stage - k * p.nchunk;
+    SDBG(0)
     if (ch == 0) {
 #pragma unroll
       for (int n = 0; n < NTW; ++n)
@@ -175,14 +203,22 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
         for (int t = 0; t < TY; ++t) acc[n][t] = accx[n][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     // weight pieces of this chunk: [step][tile][piece][lane]
-    const f16x8* wch = p.wp + ((size_t)ch * JC * NT * S2_NP + (size_t)wn * NTW * S2_NP) * 64 + lane;
-    f16x8 A[2][NTW][S2_NP], B[2][S2_NP][TY];
+    const f16x8* wch = wsrc + ((size_t)ch * JC * NT * S2_NP + (size_t)wn * NTW * S2_NP) * 64 + lane;
+    constexpr int AHEAD = WLDS ? 1 : 2, NA = AHEAD + 1;          // weight fragments requested AHEAD steps early, NA register slots
+    f16x8 A[NA][NTW][S2_NP], B[2][S2_NP][TY];
 #pragma unroll
-    for (int nn = 0; nn < NTW; ++nn)
+    for (int j0 = 0; j0 < AHEAD; ++j0)
 #pragma unroll
-      for (int pc = 0; pc < S2_NP; ++pc) A[0][nn][pc] = wch[(nn * S2_NP + pc) * 64];
+      for (int nn = 0; nn < NTW; ++nn)
+#pragma unroll
+        for (int pc = 0; pc < S2_NP; ++pc) A[j0][nn][pc] = wch[((j0 * NT + nn) * S2_NP + pc) * 64];
 
     __syncthreads();                       // every wavefront is done reading the previous stage's images
+    SDBG(1)
+#ifdef ATVS_S2_DEBUG
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    SDBG(2)
+#endif
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < S2_SLOTS) {
@@ -192,7 +228,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
         *reinterpret_cast<f16x4*>(smem + S2_IMG + laddr[i]) = p1;
       }
     }
+    SDBG(3)
     __syncthreads();
+    SDBG(4)
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
 
@@ -214,13 +252,13 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
       s2_static_for<NM>([&](auto M) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value, pr = m / (NTW * TY), nn = (m / TY) % NTW, t = m % TY;
         constexpr int pc = pr < 2 ? 0 : 1, jw = pr == 1 ? 1 : 0;
-        if constexpr (pr == 0) acc[nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][0], B[j & 1][0][t], acc[nn][t], 0, 0, 0);
-        else accx[nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][nn][jw], B[j & 1][pc][t], accx[nn][t], 0, 0, 0);
+        if constexpr (pr == 0) acc[nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j % NA][nn][0], B[j & 1][0][t], acc[nn][t], 0, 0, 0);
+        else accx[nn][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j % NA][nn][jw], B[j & 1][pc][t], accx[nn][t], 0, 0, 0);
         if constexpr (m < S2_NP * TY) {
           if constexpr (j + 1 < JC) fragment(IC<j + 1>{}, IC<m / TY>{}, IC<m % TY>{});
         } else if constexpr (m < S2_NP * TY + S2_NP * NTW) {
           constexpr int e = m - S2_NP * TY;
-          if constexpr (j + 1 < JC) A[(j + 1) & 1][e / S2_NP][e % S2_NP] = wch[(((j + 1) * NT + e / S2_NP) * S2_NP + e % S2_NP) * 64];
+          if constexpr (j + AHEAD < JC) A[(j + AHEAD) % NA][e / S2_NP][e % S2_NP] = wch[(((j + AHEAD) * NT + e / S2_NP) * S2_NP + e % S2_NP) * 64];
         } else if constexpr (m == S2_NP * TY + S2_NP * NTW || m == S2_NP * TY + S2_NP * NTW + 1) {
           constexpr int s = 2 * j + (m - S2_NP * TY - S2_NP * NTW);
           if constexpr (s < MAXS) pf_slot(T, s);
@@ -229,6 +267,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
         __builtin_amdgcn_sched_barrier(0);
       });
     });
+    SDBG(5)
     if (ch != p.nchunk - 1) continue;
 
     // ---- epilogue: this lane holds channels 16 (wn NTW + nn) + 4 q .. + 3 of output voxel (z0 + wz, y0 + t, x0 + r)
@@ -262,7 +301,14 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
         ssq2[n][1] = __builtin_elementwise_fma(hi, hi, ssq2[n][1]);
       });
     });
+    SDBG(6)
   }
+#ifdef ATVS_S2_DEBUG
+  if (lane == 0 && blockIdx.x < 1024) {
+    dbg_acc[7] = (unsigned long long)nstage;
+    for (int i = 0; i < 8; ++i) atvs_dbg_s2[(blockIdx.x * 4 + wave) * 8 + i] = dbg_acc[i];
+  }
+#endif
 
   if (p.stats) {
     constexpr int CO = NT * 16;
@@ -292,19 +338,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   }
 }
 
-template <int NT>
+template <int NT, bool WLDS>
 int launch_s2b(const S2Args& a, long grid, hipStream_t s) {
-  const size_t lds = S2_NP * (size_t)S2_IMG;
+  const size_t lds = S2_NP * (size_t)S2_IMG + (WLDS ? (size_t)a.nchunk * S2_JC * NT * S2_NP * 1024 : 0);
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_s2b_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_s2b_kernel<NT, WLDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv3d_s2b_kernel<NT>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3d_s2b_kernel<NT, WLDS>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -394,7 +440,10 @@ extern "C" int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w
   const long grid = blocks * groups;
   if (grid > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
-  int rc = (Cout == 32) ? launch_s2b<2>(a, grid, st) : launch_s2b<4>(a, grid, st);
+  // all chunks' weights resident in LDS where they fit beside the two piece images
+  const bool wlds = S2_NP * (size_t)S2_IMG + (size_t)a.nchunk * S2_JC * (Cout / 16) * S2_NP * 1024 <= 160 * 1024;
+  int rc = (Cout == 32) ? (wlds ? launch_s2b<2, true>(a, grid, st) : launch_s2b<2, false>(a, grid, st))
+                        : (wlds ? launch_s2b<4, true>(a, grid, st) : launch_s2b<4, false>(a, grid, st));
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
