@@ -127,6 +127,12 @@ __device__ __forceinline__ void atvs_split2_f16(float x0, float x1, float rs, un
   *h1 = b;
 }
 
+// ... of a float4: two 8-byte records (h0 of the four values | h1 of the four values), residual scale 2^11
+__device__ __forceinline__ void atvs_split4_f16(const float4& v, uint2* h0, uint2* h1) {
+  atvs_split2_f16(v.x, v.y, 2048.f, &h0->x, &h1->x);
+  atvs_split2_f16(v.z, v.w, 2048.f, &h0->y, &h1->y);
+}
+
 __device__ __forceinline__ float4 blend4(const Tap4& t, float4 a, float4 b, float4 c, float4 d) {
   float4 o;
   o.x = ((t.wa * a.x + t.wb * b.x) + t.wc * c.x) + t.wd * d.x;
