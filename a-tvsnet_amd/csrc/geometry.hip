@@ -718,12 +718,72 @@ __global__ __launch_bounds__(256) void transform_depth_kernel(const float* __res
   }
 }
 
+// The whole of transform_depth for a small map (<= 64 pixels per thread of ONE workgroup of 1,024): max of the input, the
+// transformed z and its max, the clip -- the four launches of the general form as one (round 5: a dependent launch costs ~4.7 us
+// of dispatch latency in a replayed graph, the map of configs[2] has 20,480 pixels).  The same operations per pixel; a maximum
+// is order-independent: identical bits.
+__device__ __forceinline__ float block_max_1024(float v, float* sm) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float m = sm[0];
+  for (int i = 1; i < 16; ++i) m = fmaxf(m, sm[i]);
+  return m;
+}
+
+__global__ __launch_bounds__(1024) void transform_depth_small_kernel(const float* __restrict__ depth, const float* __restrict__ left_cam,
+                                                                     const float* __restrict__ right_cam, float* __restrict__ out,
+                                                                     int h, int w, int inverse_depth) {
+  __shared__ float pose[12];
+  __shared__ float sm[16];
+  workgroup_pose(left_cam, right_cam, pose);
+  const long npix = (long)h * w;
+  float v = -INFINITY;
+  for (long i = threadIdx.x; i < npix; i += 1024) v = fmaxf(v, depth[i]);
+  const float dmax = block_max_1024(v, sm);
+  auto zof = [&](long pix, float* valid) __attribute__((always_inline)) {
+    float d = depth[pix];
+    *valid = 0.f;
+    if (inverse_depth) {
+      *valid = (d > 1e-10f) ? 1.f : 0.f;
+      d = fminf(fmaxf(d, 1e-10f), dmax);
+      d = 1.0f / d;
+      d = d * *valid;
+    }
+    const int y = (int)(pix / w), x = (int)(pix % w);
+    const float gx = ((float)x + 0.5f) * d, gy = ((float)y + 0.5f) * d;
+    return ((pose[6] * gx + pose[7] * gy) + pose[8] * d) + pose[11];
+  };
+  float zm = -INFINITY;
+  for (long i = threadIdx.x; i < npix; i += 1024) {
+    float valid;
+    zm = fmaxf(zm, zof(i, &valid));
+  }
+  const float zmax = block_max_1024(zm, sm);
+  for (long i = threadIdx.x; i < npix; i += 1024) {
+    float valid;
+    float z = zof(i, &valid);
+    if (inverse_depth) {
+      z = fminf(fmaxf(z, 1e-10f), zmax);
+      z = 1.0f / z;
+      z = z * valid;
+    }
+    out[i] = z;
+  }
+}
+
 extern "C" int atvs_transform_depth(const float* depth, const float* left_cam, const float* right_cam, float* out,
                                     float* ws14, int h, int w, int inverse_depth, atvs_stream_t stream) {
   if (!depth || !left_cam || !right_cam || !out || !ws14) return ATVS_ERR_NULL;
   if (h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
   hipStream_t s = as_stream(stream);
   long npix = (long)h * w;
+  if (npix <= 64 * 1024) {
+    hipLaunchKernelGGL(transform_depth_small_kernel, dim3(1), dim3(1024), 0, s, depth, left_cam, right_cam, out, h, w, inverse_depth);
+    ATVS_LAUNCH_CHECK();
+    return ATVS_OK;
+  }
   hipLaunchKernelGGL(fill_neg_inf_kernel, dim3(1), dim3(1), 0, s, ws14);
   hipLaunchKernelGGL(max_kernel, dim3(min(cdiv(npix, 256), 1024)), dim3(256), 0, s, depth, npix, ws14);
   hipLaunchKernelGGL((transform_depth_kernel<0>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, left_cam, right_cam, out, ws14, h, w, inverse_depth);
