@@ -507,7 +507,7 @@ __global__ __launch_bounds__(256) void warp_by_depth_kernel(const float* __restr
                                                             const float* __restrict__ depth, float* __restrict__ out,
                                                             float* __restrict__ mask_out, int h, int w, int C,
                                                             int inverse_depth, const float* __restrict__ ref = nullptr,
-                                                            int ld = 0, int c_off = 0) {
+                                                            int ld = 0, int c_off = 0, int copy_ref = 0) {
   __shared__ float pose[12];
   workgroup_pose(left_cam, right_cam, pose);
   long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -535,7 +535,9 @@ __global__ __launch_bounds__(256) void warp_by_depth_kernel(const float* __restr
         t.wd * src[(size_t)t.i11 * C + c];
   }
   if (ERR) {
-    out[(size_t)pix * ld + c_off + c] = fabsf(o - ref[gid]) * valid;
+    const float rv = ref[gid];
+    out[(size_t)pix * ld + c_off + c] = fabsf(o - rv) * valid;
+    if (copy_ref) out[(size_t)pix * ld + c_off + C + c] = rv;      // the tiled reference map that follows the error map in the buffer
   } else {
     out[gid] = o;
   }
@@ -560,21 +562,22 @@ extern "C" int atvs_warp_by_depth(const float* src, const float* left_cam, const
 }
 
 // |homography_warping_by_depth(src) - ref| * mask written into channels [c_off, c_off + C) of out (h, w, ld): photo_err / geo_err
-// of the refinement (model.py:309-316: the warp, tf.abs(warped - ref) * mask) straight into the tiled-channel buffer.  The same
+// of the refinement (model.py:309-316: the warp, tf.abs(warped - ref) * mask) straight into the tiled-channel buffer; copy_ref: ref
+// itself goes to the C channels behind (the tiled reference features / depth that follow the error map, model.py:329-334).  The same
 // operations in the same order as atvs_warp_by_depth followed by atvs_absdiff_mask.
 extern "C" int atvs_warp_by_depth_err(const float* src, const float* ref, const float* left_cam, const float* right_cam,
                                       const float* depth, float* out, int ld_out, int c_off, int h, int w, int C, int method,
-                                      int inverse_depth, atvs_stream_t stream) {
+                                      int inverse_depth, int copy_ref, atvs_stream_t stream) {
   if (!src || !ref || !left_cam || !right_cam || !depth || !out) return ATVS_ERR_NULL;
-  if (h <= 0 || w <= 0 || C <= 0 || c_off < 0 || c_off + C > ld_out) return ATVS_ERR_SHAPE;
+  if (h <= 0 || w <= 0 || C <= 0 || c_off < 0 || c_off + (copy_ref ? 2 : 1) * C > ld_out) return ATVS_ERR_SHAPE;
   hipStream_t s = as_stream(stream);
   long n = (long)h * w * C;
   if (method == 0)
     hipLaunchKernelGGL((warp_by_depth_kernel<0, true>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out,
-                       (float*)nullptr, h, w, C, inverse_depth, ref, ld_out, c_off);
+                       (float*)nullptr, h, w, C, inverse_depth, ref, ld_out, c_off, copy_ref);
   else if (method == 1)
     hipLaunchKernelGGL((warp_by_depth_kernel<1, true>), dim3(cdiv(n, 256)), dim3(256), 0, s, src, left_cam, right_cam, depth, out,
-                       (float*)nullptr, h, w, C, inverse_depth, ref, ld_out, c_off);
+                       (float*)nullptr, h, w, C, inverse_depth, ref, ld_out, c_off, copy_ref);
   else
     return ATVS_ERR_ARG;
   ATVS_LAUNCH_CHECK();
@@ -752,7 +755,9 @@ __global__ __launch_bounds__(1024) void transform_depth_small_kernel(const float
       d = d * *valid;
     }
     const int y = (int)(pix / w), x = (int)(pix % w);
-    const float gx = ((float)x + 0.5f) * d, gy = ((float)y + 0.5f) * d;
+    float gx = ((float)x + 0.5f) * d;
+    asm volatile("" : "+v"(gx));             // keeps the two products apart: no v_pk_mul_f32 here (Appendix B; tests/test_packed_fp32_census.py)
+    const float gy = ((float)y + 0.5f) * d;
     return ((pose[6] * gx + pose[7] * gy) + pose[8] * d) + pose[11];
   };
   float zm = -INFINITY;

@@ -263,15 +263,16 @@ def warp_by_depth(src, left_cam, right_cam, depth, method='bilinear', inverse_de
     return out, mask
 
 
-def warp_by_depth_err(src, ref, left_cam, right_cam, depth, out, c_off=0, method='bilinear', inverse_depth=True):
+def warp_by_depth_err(src, ref, left_cam, right_cam, depth, out, c_off=0, method='bilinear', inverse_depth=True, copy_ref=False):
     """|warp_by_depth(src) - ref| * mask written into out[..., c_off:c_off + C] (out: (h,w,ld)): the refinement's photo_err /
-    geo_err (warp, absolute difference, mask and the copy into the tiled-channel buffer) as one launch."""
+    geo_err (warp, absolute difference, mask and the copy into the tiled-channel buffer) as one launch; copy_ref: ref itself goes
+    to the C channels behind."""
     h, w, C = src.shape
     if tuple(ref.shape) != (h, w, C) or tuple(out.shape[:2]) != (h, w):
         raise ValueError('warp_by_depth_err: src / ref (h,w,C), out (h,w,ld)')
     if _dev_ok(src, ref, left_cam, right_cam, depth, out):
         _call('atvs_warp_by_depth_err', _p(src), _p(ref), _p(left_cam), _p(right_cam), _p(depth), _p(out), int(out.shape[-1]),
-              int(c_off), h, w, C, 1 if method == 'nearest' else 0, int(bool(inverse_depth)), _stream())
+              int(c_off), h, w, C, 1 if method == 'nearest' else 0, int(bool(inverse_depth)), int(bool(copy_ref)), _stream())
     return out
 
 

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 37
+#define ATVS_ABI_VERSION 38
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -101,10 +101,11 @@ int atvs_warp_by_depth(const float* src, const float* left_cam, const float* rig
                        int inverse_depth, atvs_stream_t stream);
 
 /* |homography_warping_by_depth(src) - ref| * mask into channels [c_off, c_off + C) of out (h,w,ld_out): photo_err / geo_err of the
- * refinement (model.py:309-316) in one launch; the operations and order of atvs_warp_by_depth + atvs_absdiff_mask. */
+ * refinement (model.py:309-316) in one launch; the operations and order of atvs_warp_by_depth + atvs_absdiff_mask.
+ * copy_ref != 0: ref itself is written to the C channels behind the error map (the tiled map that follows it, :329-334). */
 int atvs_warp_by_depth_err(const float* src, const float* ref, const float* left_cam, const float* right_cam,
                            const float* depth, float* out, int ld_out, int c_off, int h, int w, int C, int method,
-                           int inverse_depth, atvs_stream_t stream);
+                           int inverse_depth, int copy_ref, atvs_stream_t stream);
 
 /* interpolate, homography_warping.py:31-104, with caller-supplied coordinates: src (h,w,C), x / y (n) in the
  * reference's texture coordinates (pixel centres at +0.5), out (n,C), mask_out (n) 1.f / 0.f or NULL.  method 0
