@@ -24,18 +24,20 @@ def _stacked_unet(net, with_prob_head):
         else:
             src = n('0_0')
             net.feed(p('6_0'), p('0_1')).add(name=src, defer=True)     # formed on load by the siblings below
-        # defer_bn: these layers are consumed by `add`s only, which normalise them on the fly.
+        # defer_bn: the layer's batch norm (+ ReLU) is left to its consumers -- `add`s, which normalise on the fly, and the
+        # convolutions that normalise while they stage their halo (ops.norm_on_load_3d_ok); anything else materialises it.
         # conv_b*_0_1 and the encoder branch conv_b*_1_0 read the same tensor: issued as siblings (one launch)
         (net.feed(src)
             .conv_bn_siblings(dict(kernel_size=3, filters=f, strides=1, name=n('0_1'), defer_bn=True),
-                              dict(kernel_size=3, filters=f * 2, strides=2, name=n('1_0')))
-            .conv_bn(3, f * 4, 2, name=n('2_0'))
-            .conv_bn(3, f * 8, 2, name=n('3_0')))
+                              dict(kernel_size=3, filters=f * 2, strides=2, name=n('1_0'), defer_bn=True))
+            .conv_bn(3, f * 4, 2, name=n('2_0'), defer_bn=True)
+            .conv_bn(3, f * 8, 2, name=n('3_0'), defer_bn=True))
         if b == 0:
             net.feed(n('1_0')).conv_bn(3, f * 2, 1, name=n('1_1'), defer_bn=True)
             net.feed(n('2_0')).conv_bn(3, f * 4, 1, name=n('2_1'), defer_bn=True)
         else:
-            net.feed(n('1_0'), p('5_0')).add(name=n('1_1_concat')).conv_bn(3, f * 2, 1, name=n('1_1'), defer_bn=True)
+            # (the half-resolution skip sum is formed on load by conv_b*_1_1's kernel)
+            net.feed(n('1_0'), p('5_0')).add(name=n('1_1_concat'), defer=True).conv_bn(3, f * 2, 1, name=n('1_1'), defer_bn=True)
             net.feed(n('2_0'), p('4_0')).add(name=n('2_1_concat')).conv_bn(3, f * 4, 1, name=n('2_1'), defer_bn=True)
         (net.feed(n('3_0'))
             .conv_bn(3, f * 8, 1, name=n('3_1'))
@@ -166,9 +168,9 @@ class CostVolRefineNet(Network):
         (self.refine_stems(g + 'concat', [('photo_group', g + 'photo_3dconv'), ('geo_group', g + 'geo_3dconv'),
                                           ('prob_vol', g + 'prob_3dconv'), ('vis_hull', g + 'vishull_3dconv')], f)
              .conv_bn_siblings(dict(kernel_size=3, filters=f, strides=1, name=g + '3dconv0_1', defer_bn=True),
-                               dict(kernel_size=3, filters=f * 2, strides=2, name=g + '3dconv1_0'))
-             .conv_bn(3, f * 4, 2, name=g + '3dconv2_0')
-             .conv_bn(3, f * 8, 2, name=g + '3dconv3_0'))
+                               dict(kernel_size=3, filters=f * 2, strides=2, name=g + '3dconv1_0', defer_bn=True))
+             .conv_bn(3, f * 4, 2, name=g + '3dconv2_0', defer_bn=True)
+             .conv_bn(3, f * 8, 2, name=g + '3dconv3_0', defer_bn=True))
         self.feed(g + '3dconv1_0').conv_bn(3, f * 2, 1, name=g + '3dconv1_1', defer_bn=True)
         self.feed(g + '3dconv2_0').conv_bn(3, f * 4, 1, name=g + '3dconv2_1', defer_bn=True)
         (self.feed(g + '3dconv3_0')

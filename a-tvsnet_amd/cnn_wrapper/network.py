@@ -241,12 +241,22 @@ class Network(object):
                 return self._slice_out(self._bn(y, st, name, center, relu, C=(filters if buf is not None else None),
                                                 c_off=c_off), out_slice, filters)
             input = input.materialize()
-        in_params, in_relu = None, False
+        in_params, in_relu, in_sum = None, False, None
         if rank == 4 and padding == 'SAME' and self.training and buf is None \
                 and ops.norm_on_load_2d_ok(input, kernel_size, filters, strides, rate) \
                 and (input.shape[0] == 1 or self.independent_samples):
             # the producer's batch norm (+ ReLU) is applied while this convolution stages its input
             x, (_, in_params, _, in_relu, _) = input.prologue()
+        elif rank == 5 and padding == 'SAME' and self.training and buf is None and isinstance(input, ops.LAZY) \
+                and ops.norm_on_load_3d_ok(input, kernel_size, filters, strides, rate) \
+                and (input.shape[0] == 1 or self.independent_samples):
+            # 3-D: a pending batch norm, or the U-Net's skip sum of two, formed while the halo is staged
+            x, pro = input.prologue()
+            if pro is not None and isinstance(input, ops.PendingSum):
+                x1, in_params, p1, in_relu, r1 = pro
+                in_sum = (x1, p1, r1)
+            elif pro is not None:
+                in_params, in_relu = pro[1], pro[3]
         else:
             x = self._bt(input, name)
         G, cin = x.shape[0], x.shape[-1]
@@ -257,11 +267,11 @@ class Network(object):
         if self.training and defer_bn and buf is None and not center and filters % 4 == 0:
             # extension: the layer's consumers are adds only -> hand them the raw output + the moments
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
-                             groups=G, in_params=in_params, in_relu=in_relu)
+                             groups=G, in_params=in_params, in_relu=in_relu, in_sum=in_sum)
             return ops.PendingBN(y, ops.bn_params(st, filters, y, None, BN_EPS), relu)
         if self.training:
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, want_stats=True,
-                             out=buf, y_coff=c_off, groups=G, in_params=in_params, in_relu=in_relu)
+                             out=buf, y_coff=c_off, groups=G, in_params=in_params, in_relu=in_relu, in_sum=in_sum)
         else:
             y, st = ops.conv(x, vname, w, stride=strides, dilation=rate, padding=padding, bias=bias, out=buf,
                              y_coff=c_off, groups=G), None
@@ -284,7 +294,7 @@ class Network(object):
                            and d.get('out_slice') is None)
         shape = tuple(src.shape)
         fusable = (self.training and len(shape) == 5 and (shape[0] == 1 or self.independent_samples) and plain(a)
-                   and plain(b) and a['strides'] == 1 and b['strides'] == 2 and not b.get('defer_bn', False))
+                   and plain(b) and a['strides'] == 1 and b['strides'] == 2)
         if fusable and isinstance(src, ops.LAZY) and not ops.siblings_prologue_ok(src):
             src = src.materialize()        # a lazy input the kernel cannot form on load
         if fusable:
@@ -313,7 +323,10 @@ class Network(object):
             out_a = ops.PendingBN(ya, ops.bn_params(sa, a['filters'], ya, None, BN_EPS), a.get('relu', True))
         else:
             out_a = self._bn(ya, sa, a['name'], False, a.get('relu', True))
-        out_b = self._bn(yb, sb, b['name'], False, b.get('relu', True))
+        if b.get('defer_bn', False):
+            out_b = ops.PendingBN(yb, ops.bn_params(sb, b['filters'], yb, None, BN_EPS), b.get('relu', True))
+        else:
+            out_b = self._bn(yb, sb, b['name'], False, b.get('relu', True))
         self.layers[a['name']] = out_a
         self.layers[b['name']] = out_b
         self.feed(out_b)

@@ -41,6 +41,11 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct C3bArgs {
   const float* x;
+  // NORM form: x is a raw convolution output whose batch norm [+ ReLU] is applied while the halo is staged (atvs_bn_apply's
+  // arithmetic: relu?((v - mean) * scale + beta)); in_par (groups, 3, Cin).  (A two-term skip sum on load as conv_c16b.hip has
+  // it -- a second halo in flight -- spilled 158 registers here: two output tiles' accumulators fill the file.)
+  const float* in_par;
+  int in_relu;
   const f16x8* wp;             // packed fp16 pieces (atvs_conv3d_b_pack)
   const float* zeros;          // 16 zero bytes
   const float* bias;
@@ -79,7 +84,7 @@ __device__ __forceinline__ void c3b_split(const float4& v, f16x4* p0, f16x4* p1)
 // NT = 2 output tiles (32 channels) per workgroup.  Cout = 64 runs as TWO 32-channel halves in one launch (blocks [bh, 2 bh)
 // compute channels 32..63: the input is staged twice, but four tiles' main + cross accumulators -- 256 registers -- do not
 // fit a wavefront (294 spilled registers), and at eighth resolution the launch had 192 tiles for 256 CUs anyway).
-template <int NT>
+template <int NT, bool NORM>
 __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
   // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
   // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
@@ -154,6 +159,11 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
     const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
     pf[i] = ld4(ok ? (xg + (T.org + goff[i])) : p.zeros);
   };
+  // NORM: the (3, Cin) batch-norm rows of this sample behind the images in LDS (visible after the first stage's barrier); a
+  // thread reads the rows of its four channels (c4 = tid & 3 in every slot) of the chunk being staged
+  float* s_par = reinterpret_cast<float*>(smem + C3B_NP * C3B_IMG);
+  if (NORM)
+    for (int i = tid; i < 3 * p.Cin; i += 256) s_par[i] = p.in_par[(size_t)grp * 3 * p.Cin + i];
 
   f32x4 acc[NT][TY], accx[NT][TY];     // h0 g0 | (h0 g1 + h1 g0) * 2^11
   f32x2 ssum2[NT][2], ssq2[NT][2];
@@ -185,9 +195,30 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
       for (int pc = 0; pc < C3B_NP; ++pc) A[0][nn][pc] = wch[(nn * C3B_NP + pc) * 64];
 
     __syncthreads();                       // every wavefront is done reading the previous stage's images
+    const PfTile Tc = pf_tile(stage);      // NORM: which slots lie inside the volume (a padding zero is not zero after its batch norm)
+    float4 bnm, bns, bnb;
+    const float nfloor = p.in_relu ? 0.f : -INFINITY;
+    if (NORM) {
+      const float* q3 = s_par + ch * 16 + (tid & 3) * 4;
+      bnm = *reinterpret_cast<const float4*>(q3);
+      bns = *reinterpret_cast<const float4*>(q3 + p.Cin);
+      bnb = *reinterpret_cast<const float4*>(q3 + 2 * p.Cin);
+    }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < C3B_SLOTS) {
+        if (NORM) {
+          float4 a = pf[i];
+          a.x = (a.x - bnm.x) * bns.x + bnb.x;
+          a.y = (a.y - bnm.y) * bns.y + bnb.y;
+          a.z = (a.z - bnm.z) * bns.z + bnb.z;
+          a.w = (a.w - bnm.w) * bns.w + bnb.w;
+          a.x = fmaxf(a.x, nfloor); a.y = fmaxf(a.y, nfloor); a.z = fmaxf(a.z, nfloor); a.w = fmaxf(a.w, nfloor);     // ReLU or nothing
+          const unsigned t1 = pg[i] - Tc.lo;
+          const unsigned t2 = Tc.hi1 + ~pg[i];
+          const bool in = ((t1 & t2) & 0x808080u) == 0x808080u;
+          pf[i] = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
+        }
         f16x4 p0, p1;
         c3b_split(pf[i], &p0, &p1);
         *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
@@ -348,19 +379,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
 }
 
 
-template <int NT>
+template <int NT, bool NORM>
 int launch_c3b(const C3bArgs& a, long grid, hipStream_t s) {
-  const size_t lds = C3B_NP * (size_t)C3B_IMG;
+  const size_t lds = C3B_NP * (size_t)C3B_IMG + (NORM ? 3 * (size_t)a.Cin * 4 : 0);
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_b_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_b_kernel<NT, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv3d_b_kernel<NT>), dim3((unsigned)(grid * a.nhalf)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3d_b_kernel<NT, NORM>), dim3((unsigned)(grid * a.nhalf)), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -410,20 +441,19 @@ extern "C" int atvs_conv3d_b_pack(const float* w, int Cin, int Cout, unsigned ch
   return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
-// y (G,D,H,W,ldy)[..., y_coff : y_coff + Cout] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,Cout], stride 1, SAME) (+ bias, ReLU),
-// Cin % 16 == 0, Cout 32 or 64, split-bf16 operands (fp32-class results).  Grid / statistics rows = atvs_conv_c16_grid
-// ([2][Cout] doubles per row).
-extern "C" int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
-                                 double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff,
-                                 int relu, atvs_stream_t stream) {
+namespace {
+int c3b_launch(const float* x, const float* in_par, int in_relu, const unsigned char* packed_w, const float* bias, float* y,
+               double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu,
+               atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || !atvs_conv3d_b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if ((double)D * H * W * Cin >= 2147483648.0 || (double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;
   C3bArgs a;
-  long pb;
-  atvs_conv3d_b_pack_size(Cin, Cout, &pb);
-  a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  long pbytes;
+  atvs_conv3d_b_pack_size(Cin, Cout, &pbytes);
+  a.x = x; a.in_par = in_par; a.in_relu = in_relu;
+  a.wp = reinterpret_cast<const f16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pbytes - 16));
   a.bias = bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.ldy = ldy; a.ycoff = y_coff; a.nchunk = Cin / 16; a.relu = relu;
   a.tiles_y = (H + C3B_TY - 1) / C3B_TY; a.tiles_x = (W + C3B_TX - 1) / C3B_TX;
@@ -436,8 +466,28 @@ extern "C" int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, 
   hipStream_t st = as_stream(stream);
   a.nhalf = Cout / 32; a.bh = (int)grid;
   if (grid * a.nhalf > 0x7fffffffL) return ATVS_ERR_SHAPE;
-  int rc = launch_c3b<2>(a, grid, st);
+  int rc = in_par ? launch_c3b<2, true>(a, grid, st) : launch_c3b<2, false>(a, grid, st);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
+}
+}  // namespace
+
+// y (G,D,H,W,ldy)[..., y_coff : y_coff + Cout] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,Cout], stride 1, SAME) (+ bias, ReLU),
+// Cin % 16 == 0, Cout 32 or 64, split-fp16 operands (fp32-class results).  Grid / statistics rows = atvs_conv_c16_grid
+// ([2][Cout] doubles per row).
+extern "C" int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
+                                 double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff,
+                                 int relu, atvs_stream_t stream) {
+  return c3b_launch(x, nullptr, 0, packed_w, bias, y, stats_partial, groups, D, H, W, Cin, Cout, ldy, y_coff, relu, stream);
+}
+
+// The same convolution of relu?((x - mean) * scale + beta), x a raw convolution output and in_params (groups,3,Cin) its pending
+// batch norm (conv_b*_{2,3}_1 read conv_b*_{2,3}_0, reference cnn_wrapper/atvsnet.py:20-26): formed per staged halo voxel, the
+// normalised tensor is never written.  Bit for bit atvs_bn_apply followed by atvs_conv3d_b_f32.
+extern "C" int atvs_conv3d_b_norm_f32(const float* x, const float* in_params, int in_relu, const unsigned char* packed_w,
+                                      const float* bias, float* y, double* stats_partial, int groups, int D, int H, int W, int Cin,
+                                      int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream) {
+  if (!in_params) return ATVS_ERR_NULL;
+  return c3b_launch(x, in_params, in_relu, packed_w, bias, y, stats_partial, groups, D, H, W, Cin, Cout, ldy, y_coff, relu, stream);
 }

@@ -51,6 +51,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct S2Args {
   const float* x;
+  // NORM form: x is a raw convolution output whose batch norm [+ ReLU] is applied while the halo is staged (atvs_bn_apply's
+  // arithmetic: relu?((v - mean) * scale + beta)); in_par (groups, 3, Cin)
+  const float* in_par;
+  int in_relu;
   const f16x8* wp;
   const float* zeros;
   const float* bias;
@@ -91,7 +95,7 @@ __device__ __forceinline__ void s2_split(const float4& v, f16x4* p0, f16x4* p1) 
 // takes its weight fragments from there.  Streamed from L2 one step ahead (rounds 3-4) a step's 12 MFMAs = 192 cycles could not
 // cover the L2 round trip: every one of the 14 steps of a stage waited for its weights (round 5).  Where the weights do not fit
 // (32 -> 64) they are requested TWO steps ahead (three register slots).
-template <int NT, bool WLDS>
+template <int NT, bool WLDS, bool NORM>
 __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
   // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
@@ -174,6 +178,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     pf[i] = ld4(ok ? (xg + (T.org + goff[i])) : p.zeros);
   };
 
+  // NORM: the batch-norm rows of this thread's four channels (c4 = tid & 3 in every slot) of the chunk being staged, and of
+  // the next stage's chunk (requested in front of the K loop)
+  float4 bnm, bns, bnb, nbnm, nbns, nbnb;
+  auto norm_rows = [&](int ch) __attribute__((always_inline)) {
+    const float* q3 = p.in_par + (size_t)grp * 3 * p.Cin + ch * 16 + (tid & 3) * 4;
+    nbnm = ld4(q3); nbns = ld4(q3 + p.Cin); nbnb = ld4(q3 + 2 * p.Cin);
+  };
+  if (NORM) norm_rows(0);
+
   f32x4 acc[NTW][TY], accx[NTW][TY];   // h0 g0 | (h0 g1 + h1 g0) * 2^11
   f32x2 ssum2[NTW][2], ssq2[NTW][2];
 #pragma unroll
@@ -181,10 +194,10 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   const unsigned ybytes = (unsigned)(p.gy * 4);
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
 
+  PfTile Tn = pf_tile(0);                  // the stage whose halo is in flight
   if (nstage > 0) {
-    const PfTile T0 = pf_tile(0);
 #pragma unroll
-    for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+    for (int i = 0; i < MAXS; ++i) pf_slot(Tn, i);
   }
 
 #ifdef ATVS_S2_DEBUG
@@ -217,9 +230,28 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SDBG(2)
 #endif
+    const PfTile Tc = Tn;                 // NORM: which slots lie inside the volume (a padding zero is not zero after its batch norm)
+    const bool edge = Tc.lo != 0u || (Tc.hi1 & 0xffu) < (unsigned)S2_HZ || ((Tc.hi1 >> 8) & 0xffu) < (unsigned)HY || ((Tc.hi1 >> 16) & 0xffu) < (unsigned)S2_HX;
+    if (NORM) { bnm = nbnm; bns = nbns; bnb = nbnb; }
+    const float nfloor = p.in_relu ? 0.f : -INFINITY;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < S2_SLOTS) {
+        if (NORM) {
+          float4 a = pf[i];
+          a.x = (a.x - bnm.x) * bns.x + bnb.x;
+          a.y = (a.y - bnm.y) * bns.y + bnb.y;
+          a.z = (a.z - bnm.z) * bns.z + bnb.z;
+          a.w = (a.w - bnm.w) * bns.w + bnb.w;
+          a.x = fmaxf(a.x, nfloor); a.y = fmaxf(a.y, nfloor); a.z = fmaxf(a.z, nfloor); a.w = fmaxf(a.w, nfloor);     // ReLU or nothing
+          if (edge) {                        // (uniform) a halo that leaves the volume: its padding stays zero
+            const unsigned t1 = pg[i] - Tc.lo;
+            const unsigned t2 = Tc.hi1 + ~pg[i];
+            const bool in = ((t1 & t2) & 0x808080u) == 0x808080u;
+            a = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
+          }
+          pf[i] = a;
+        }
         f16x4 p0, p1;
         s2_split(pf[i], &p0, &p1);
         *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
@@ -230,7 +262,9 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     __syncthreads();
     SDBG(4)
 
-    const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
+    Tn = pf_tile(min(stage + 1, nstage - 1));
+    const PfTile T = Tn;      // last stage: harmless re-read of its own halo
+    if (NORM && p.nchunk > 1) norm_rows((stage + 1) % p.nchunk);
 
     auto fragment = [&](auto JT, auto PC, auto TT) __attribute__((always_inline)) {       // step j, piece pc, row t
       constexpr int j = decltype(JT)::value, pc = decltype(PC)::value, t = decltype(TT)::value;
@@ -336,19 +370,19 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   }
 }
 
-template <int NT, bool WLDS>
+template <int NT, bool WLDS, bool NORM>
 int launch_s2b(const S2Args& a, long grid, hipStream_t s) {
   const size_t lds = S2_NP * (size_t)S2_IMG + (WLDS ? (size_t)a.nchunk * S2_JC * NT * S2_NP * 1024 : 0);
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_s2b_kernel<NT, WLDS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_s2b_kernel<NT, WLDS, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv3d_s2b_kernel<NT, WLDS>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv3d_s2b_kernel<NT, WLDS, NORM>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 
@@ -411,12 +445,10 @@ extern "C" int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned 
   return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
-// y (G,Do,Ho,Wo,ldy)[..., y_coff : y_coff + Cout] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,Cout], stride 2, SAME) (+ bias, ReLU),
-// Do = ceil(D / 2) ...; Cin % 16 == 0, Cout 32 or 64, split-bf16 operands (fp32-class results).  stats_partial: groups *
-// atvs_conv3d_s2b_grid(Do,Ho,Wo,groups) rows of [2][Cout] doubles or NULL.
-extern "C" int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
-                                   double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff,
-                                   int relu, atvs_stream_t stream) {
+namespace {
+int s2b_launch(const float* x, const float* in_par, int in_relu, const unsigned char* packed_w, const float* bias, float* y,
+               double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu,
+               atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || !atvs_conv3d_s2b_supported(Cin, Cout)) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + Cout > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
@@ -425,7 +457,8 @@ extern "C" int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w
   S2Args a;
   long pb;
   atvs_conv3d_s2b_pack_size(Cin, Cout, &pb);
-  a.x = x; a.wp = reinterpret_cast<const f16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  a.x = x; a.in_par = in_par; a.in_relu = in_relu;
+  a.wp = reinterpret_cast<const f16x8*>(packed_w); a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
   a.bias = bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.Cin = Cin; a.Do = Do; a.Ho = Ho; a.Wo = Wo;
   a.pbz = (2 * (Do - 1) + 3 - D) / 2; a.pby = (2 * (Ho - 1) + 3 - H) / 2; a.pbx = (2 * (Wo - 1) + 3 - W) / 2;
@@ -440,9 +473,34 @@ extern "C" int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w
   hipStream_t st = as_stream(stream);
   // all chunks' weights resident in LDS where they fit beside the two piece images
   const bool wlds = S2_NP * (size_t)S2_IMG + (size_t)a.nchunk * S2_JC * (Cout / 16) * S2_NP * 1024 <= 160 * 1024;
-  int rc = (Cout == 32) ? (wlds ? launch_s2b<2, true>(a, grid, st) : launch_s2b<2, false>(a, grid, st))
-                        : (wlds ? launch_s2b<4, true>(a, grid, st) : launch_s2b<4, false>(a, grid, st));
+  int rc;
+  if (in_par)
+    rc = (Cout == 32) ? (wlds ? launch_s2b<2, true, true>(a, grid, st) : launch_s2b<2, false, true>(a, grid, st))
+                      : (wlds ? launch_s2b<4, true, true>(a, grid, st) : launch_s2b<4, false, true>(a, grid, st));
+  else
+    rc = (Cout == 32) ? (wlds ? launch_s2b<2, true, false>(a, grid, st) : launch_s2b<2, false, false>(a, grid, st))
+                      : (wlds ? launch_s2b<4, true, false>(a, grid, st) : launch_s2b<4, false, false>(a, grid, st));
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
+}
+}  // namespace
+
+// y (G,Do,Ho,Wo,ldy)[..., y_coff : y_coff + Cout] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,Cout], stride 2, SAME) (+ bias, ReLU),
+// Do = ceil(D / 2) ...; Cin % 16 == 0, Cout 32 or 64, split-fp16 operands (fp32-class results).  stats_partial: groups *
+// atvs_conv3d_s2b_grid(Do,Ho,Wo,groups) rows of [2][Cout] doubles or NULL.
+extern "C" int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
+                                   double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff,
+                                   int relu, atvs_stream_t stream) {
+  return s2b_launch(x, nullptr, 0, packed_w, bias, y, stats_partial, groups, D, H, W, Cin, Cout, ldy, y_coff, relu, stream);
+}
+
+// The same convolution of relu?((x - mean) * scale + beta), x a raw convolution output and in_params (groups,3,Cin) its pending
+// batch norm (the encoders conv_b*_{2,3}_0 read conv_b*_{1,2}_0, reference cnn_wrapper/atvsnet.py:10-12): formed per staged halo
+// voxel, the normalised tensor is never written.  Bit for bit atvs_bn_apply followed by atvs_conv3d_s2b_f32.
+extern "C" int atvs_conv3d_s2b_norm_f32(const float* x, const float* in_params, int in_relu, const unsigned char* packed_w,
+                                        const float* bias, float* y, double* stats_partial, int groups, int D, int H, int W,
+                                        int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream) {
+  if (!in_params) return ATVS_ERR_NULL;
+  return s2b_launch(x, in_params, in_relu, packed_w, bias, y, stats_partial, groups, D, H, W, Cin, Cout, ldy, y_coff, relu, stream);
 }

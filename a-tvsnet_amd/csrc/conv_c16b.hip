@@ -55,6 +55,14 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct B16Args {
   const float* x;
+  // PRO forms: the input is formed while the halo is staged, never written --
+  //   1: x_in = t(x, pa, bit 0)                     (a pending batch norm [+ ReLU]: atvs_bn_apply's arithmetic)
+  //   2: x_in = t(x, pa, bit 0) + t(x2, pb, bit 1)  (the U-Net's skip sum: atvs_bn_add's arithmetic and order)
+  // with t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v
+  const float* x2;
+  const float* pa;             // (groups, 3, Cin) or null (that term is a finished tensor)
+  const float* pb;
+  int relu_mask;
   const unsigned char* wp;     // packed fp16 pieces (atvs_conv_c16b_pack)
   const float* zeros;          // 16 zero bytes
   const float* bias;
@@ -87,7 +95,7 @@ __device__ __forceinline__ void b16_split(const float4& v, f16x4* p0, f16x4* p1)
   *p1 = __builtin_bit_cast(f16x4, b);
 }
 
-template <int CIN, bool RELU>
+template <int CIN, bool RELU, int PRO>
 __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
   // own the SIMD's whole register file (512 per lane): no wavefront of ANOTHER kernel runs beside this one's bf16 MFMAs --
   // beside them other kernels' wavefronts computed wrong lane quarters (tools_dev/micro/pk_beside_mfma.hip)
@@ -161,12 +169,38 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
             ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
     return T;
   };
-  float4 pf[MAXS];
+  float4 pf[MAXS], pf2[PRO == 2 ? MAXS : 1];
+  const float* __restrict__ xg2 = (PRO == 2) ? p.x2 + (size_t)grp * p.gx : nullptr;
   auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
     const unsigned t1 = pg[i] - T.lo;
     const unsigned t2 = T.hi1 + ~pg[i];
     const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
     pf[i] = ld4(ok ? (xg + (T.org + goff[i])) : p.zeros);
+    if (PRO == 2) pf2[i] = ld4(ok ? (xg2 + (T.org + goff[i])) : p.zeros);
+  };
+  // PRO: the batch-norm rows of this thread's four channels (c4 = tid % C4 in every slot)
+  float4 bnm[2], bns[2], bnb[2];
+  if (PRO) {
+    const float* pr[2] = {p.pa, p.pb};
+#pragma unroll
+    for (int k = 0; k < (PRO == 2 ? 2 : 1); ++k) {
+      const float* q3 = pr[k] ? pr[k] + (size_t)grp * 3 * CIN + (tid % K::C4) * 4 : nullptr;
+      bnm[k] = q3 ? ld4(q3) : make_float4(0.f, 0.f, 0.f, 0.f);
+      bns[k] = q3 ? ld4(q3 + CIN) : make_float4(1.f, 1.f, 1.f, 1.f);
+      bnb[k] = q3 ? ld4(q3 + 2 * CIN) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  auto pro_term = [&](const float4& v, int k, const float* par) __attribute__((always_inline)) {
+    float4 o = v;
+    if (par) {
+      o.x = (v.x - bnm[k].x) * bns[k].x + bnb[k].x;
+      o.y = (v.y - bnm[k].y) * bns[k].y + bnb[k].y;
+      o.z = (v.z - bnm[k].z) * bns[k].z + bnb[k].z;
+      o.w = (v.w - bnm[k].w) * bns[k].w + bnb[k].w;
+      const float fl = ((p.relu_mask >> k) & 1) ? 0.f : -INFINITY;      // ReLU or nothing, branch-free
+      o.x = fmaxf(o.x, fl); o.y = fmaxf(o.y, fl); o.z = fmaxf(o.z, fl); o.w = fmaxf(o.w, fl);
+    }
+    return o;
   };
 
   f32x2 ssum2[2], ssq2[2];
@@ -176,10 +210,10 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
   const unsigned ybytes = (unsigned)(p.gy * 4);
   const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
 
+  PfTile Tn = pf_tile(0);                  // the tile whose halo is in flight
   if (my_tiles > 0) {
-    const PfTile T0 = pf_tile(0);
 #pragma unroll
-    for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+    for (int i = 0; i < MAXS; ++i) pf_slot(Tn, i);
   }
 
   for (int k = 0; k < my_tiles; ++k) {
@@ -187,9 +221,25 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     for (int t = 0; t < TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();                       // every wavefront is done reading the previous tile's images
     // split the staged fp32 halo into its two fp16 pieces on the way into LDS
+    const PfTile Tc = Tn;                     // PRO: which slots lie inside the volume (a padding zero is not zero after its batch norm)
+    const bool edge = Tc.lo != 0u || (Tc.hi1 & 0xffu) < (unsigned)B16_HZ || ((Tc.hi1 >> 8) & 0xffu) < (unsigned)HY || ((Tc.hi1 >> 16) & 0xffu) < (unsigned)B16_HX;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < B16_SLOTS) {
+        if (PRO) {
+          float4 a = pro_term(pf[i], 0, p.pa);
+          if (PRO == 2) {
+            const float4 b = pro_term(pf2[i], 1, p.pb);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+          }
+          if (edge) {                        // (uniform) a halo that leaves the volume: its padding stays zero
+            const unsigned t1 = pg[i] - Tc.lo;
+            const unsigned t2 = Tc.hi1 + ~pg[i];
+            const bool in = ((t1 & t2) & 0x808080u) == 0x808080u;
+            a = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
+          }
+          pf[i] = a;
+        }
         f16x4 p0, p1;
         b16_split(pf[i], &p0, &p1);
         *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
@@ -198,7 +248,8 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     }
     __syncthreads();
 
-    const PfTile T = pf_tile(min(k + 1, my_tiles - 1));      // last tile: harmless re-read of its own halo
+    Tn = pf_tile(min(k + 1, my_tiles - 1));
+    const PfTile T = Tn;      // last tile: harmless re-read of its own halo
 
     // ---- K loop: 14 steps of two taps x 16 channels, each in two phases -- input piece h0 with both weight pieces (16 MFMAs),
     // h1 with g0 (8): the fragments of ONE input piece are live at a time (the next phase's are requested behind this
@@ -351,37 +402,36 @@ extern "C" int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packe
 }
 
 namespace {
-template <int CIN, bool RELU>
+template <int CIN, bool RELU, int PRO = 0>
 int launch_c16b(const B16Args& a, long grid, hipStream_t s) {
   const size_t lds = B16_NP * (size_t)B16<CIN>::IMG + (size_t)B16<CIN>::JC * B16_WSTEP;
   static bool attr_set[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
   if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16b_kernel<CIN, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16b_kernel<CIN, RELU, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             160 * 1024) != hipSuccess)
       return ATVS_ERR_LAUNCH;
     attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((conv_c16b_kernel<CIN, RELU>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((conv_c16b_kernel<CIN, RELU, PRO>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }
 }  // namespace
 
-// y (G,D,H,W,ldy)[..., y_coff : y_coff + 16] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,16], stride 1, SAME) (+ bias, ReLU), Cin 8
-// or 16, with split-bf16 operands (fp32-class results; rounding differs from atvs_conv_c16_f32).  Grid / statistics rows =
-// atvs_conv_c16_grid.
-extern "C" int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
-                                  double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
-                                  atvs_stream_t stream) {
+namespace {
+int c16b_launch(const float* x, const float* x2, const float* pa, const float* pb, int relu_mask, int pro,
+                const unsigned char* packed_w, const float* bias, float* y, double* stats_partial, int groups, int D, int H,
+                int W, int Cin, int ldy, int y_coff, int relu, atvs_stream_t stream) {
   if (!x || !packed_w || !y) return ATVS_ERR_NULL;
   if (groups <= 0 || D <= 0 || H <= 0 || W <= 0 || (Cin != 8 && Cin != 16)) return ATVS_ERR_SHAPE;
   if (y_coff < 0 || y_coff + 16 > ldy || (ldy % 4) || (y_coff % 4)) return ATVS_ERR_SHAPE;
   if ((double)D * H * W * Cin >= 2147483648.0 || (double)D * H * W * ldy * 4.0 >= 4294967296.0) return ATVS_ERR_SHAPE;
   B16Args a;
-  long pb;
-  atvs_conv_c16b_pack_size(Cin, &pb);
-  a.x = x; a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
+  long pb_;
+  atvs_conv_c16b_pack_size(Cin, &pb_);
+  a.x = x; a.x2 = x2; a.pa = pa; a.pb = pb; a.relu_mask = relu_mask;
+  a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb_ - 16));
   a.bias = bias; a.y = y; a.stats = stats_partial;
   a.Di = D; a.Hi = H; a.Wi = W; a.ldy = ldy; a.ycoff = y_coff;
   a.tiles_y = (H + B16_TY - 1) / B16_TY; a.tiles_x = (W + B16_TX - 1) / B16_TX;
@@ -393,9 +443,42 @@ extern "C" int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w,
   if (grid > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
   int rc;
-  if (Cin == 8) rc = relu ? launch_c16b<8, true>(a, grid, st) : launch_c16b<8, false>(a, grid, st);
+  if (pro == 1) rc = relu ? launch_c16b<16, true, 1>(a, grid, st) : launch_c16b<16, false, 1>(a, grid, st);
+  else if (pro == 2) rc = relu ? launch_c16b<16, true, 2>(a, grid, st) : launch_c16b<16, false, 2>(a, grid, st);
+  else if (Cin == 8) rc = relu ? launch_c16b<8, true>(a, grid, st) : launch_c16b<8, false>(a, grid, st);
   else rc = relu ? launch_c16b<16, true>(a, grid, st) : launch_c16b<16, false>(a, grid, st);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
+}
+}  // namespace
+
+// y (G,D,H,W,ldy)[..., y_coff : y_coff + 16] = conv3d(x (G,D,H,W,Cin), w [3,3,3,Cin,16], stride 1, SAME) (+ bias, ReLU), Cin 8
+// or 16, with split-fp16 operands (fp32-class results; rounding differs from atvs_conv_c16_f32).  Grid / statistics rows =
+// atvs_conv_c16_grid.
+extern "C" int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y,
+                                  double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                                  atvs_stream_t stream) {
+  return c16b_launch(x, nullptr, nullptr, nullptr, 0, 0, packed_w, bias, y, stats_partial, groups, D, H, W, Cin, ldy, y_coff, relu,
+                     stream);
+}
+
+// The same convolution (Cin = 16) of an input that is never written: x_in = t(x0, params0, bit 0) [+ t(x1, params1, bit 1)] with
+// t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v -- atvs_bn_apply's arithmetic for one term (a pending batch norm
+// applied while the halo is staged), atvs_bn_add's arithmetic and order for two (the U-Net's skip sum in front of
+// conv_b{1,2}_1_1: conv_b*_1_1_concat, reference cnn_wrapper/atvsnet.py:45-46,75-76,140-141,170-171).  params_i:
+// (groups,3,16) or NULL (that term is a finished tensor); x1 NULL: one term.  Results bit for bit those of atvs_bn_apply /
+// atvs_bn_add followed by atvs_conv_c16b_f32.
+extern "C" int atvs_conv_c16b_sum_supported(int Cin) { return Cin == 16 ? 1 : 0; }
+
+extern "C" int atvs_conv_c16b_sum_f32(const float* x0, const float* params0, const float* x1, const float* params1, int relu_mask,
+                                      const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
+                                      int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu,
+                                      atvs_stream_t stream) {
+  if (!x0) return ATVS_ERR_NULL;
+  if (!atvs_conv_c16b_sum_supported(Cin)) return ATVS_ERR_SHAPE;
+  if (!x1 && params1) return ATVS_ERR_ARG;
+  if (!x1 && !params0) return ATVS_ERR_ARG;          // nothing to form: atvs_conv_c16b_f32
+  return c16b_launch(x0, x1, params0, params1, relu_mask, x1 ? 2 : 1, packed_w, bias, y, stats_partial, groups, D, H, W, Cin, ldy,
+                     y_coff, relu, stream);
 }

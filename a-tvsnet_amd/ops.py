@@ -34,6 +34,8 @@ class Config(object):
     prologue       normalise-on-load / add-on-load in the consumers (else pending batch norms / sums are materialised first)
     sum_on_load    the U-Net's skip sums formed inside their consumer's staging (transposed convolution, 16-channel convolution)
                    instead of a bn_add pass (needs prologue)
+    norm3d         pending batch norms / two-term skip sums formed while conv_c16b, conv3d_b, conv3d_s2b stage their halo instead of
+                   a bn_apply / bn_add pass (needs sum_on_load)
     force_impl     None (automatic) | 'tiled' | 'gather': the generic convolution kernel to use
     fused_finalize batch-norm moments finished inside the convolution launch (measured slower: off)
     side_streams   independent small launches of one layer on side streams (parallel branches of a captured graph)
@@ -48,7 +50,8 @@ class Config(object):
         conv_c16=True, deconv_up=True, stem=True, conv2d_lds=True, conv1x1=True, xp1w=True, xpair=True, siblings=True,
         aanet_fused=os.environ.get('ATVS_AANET_FUSED', '1') != '0',
         bottleneck=os.environ.get('ATVS_BOTTLENECK', '1') != '0',
-        prologue=True, sum_on_load=os.environ.get('ATVS_SUM_ON_LOAD', '1') != '0', force_impl=None, fused_finalize=False,
+        prologue=True, sum_on_load=os.environ.get('ATVS_SUM_ON_LOAD', '1') != '0',
+        norm3d=os.environ.get('ATVS_NORM3D', '1') != '0', force_impl=None, fused_finalize=False,
         side_streams=os.environ.get('ATVS_SIDE_STREAMS', '1') != '0')
 
     def __init__(self):
@@ -729,6 +732,35 @@ def norm_on_load_2d_ok(src, ksize, filters, stride=1, rate=1):
     return False
 
 
+def norm_on_load_3d_ok(src, ksize, filters, stride=1, rate=1):
+    """Can a 3-D convolution take this lazy input as it is (its batch norm / its skip sum formed while the kernel stages
+    the halo)?  Built forms: a pending batch norm in front of conv_c16b (16 -> 16), conv3d_b (Cin % 16 == 0 -> 32 / 64) and
+    the stride-2 conv3d_s2b; a sum of two (dense or pending) in front of conv_c16b.  ops.conv falls back to the passes
+    themselves for a shape its dispatch sends elsewhere."""
+    if not (cfg.sum_on_load and cfg.norm3d) or cfg.force_impl is not None or not cfg.conv_c16 or ksize != 3 or rate != 1 \
+            or src.dim() != 5:
+        return False
+    cin = int(src.shape[-1])
+    if isinstance(src, PendingBN):
+        if src._final is not None or src.planar or not src.raw.is_contiguous() or cin % 16:
+            return False
+        if stride == 2:
+            return split_on('s2b') and filters in (32, 64)
+        return stride == 1 and ((cin == 16 and filters == 16 and split_on('c16b')) or (filters in (32, 64) and split_on('c3b')))
+    if isinstance(src, PendingSum):
+        if src._final is not None or len(src.items) != 2 or stride != 1 or cin != 16 or filters != 16 or not split_on('c16b'):
+            return False
+        gs = set()
+        for t in src.items:
+            raw = t.raw if isinstance(t, PendingBN) else t
+            if isinstance(t, PendingBN) and t._final is None:
+                gs.add(_param_groups(t.params))
+            if not raw.is_contiguous() or (isinstance(t, PendingBN) and t.planar):
+                return False
+        return len(gs) <= 1
+    return False
+
+
 def conv2d_lds_ok(cin, cout, dilation, H, W):
     """Is the LDS-tiled 2-D kernel (atvs_conv2d_lds_f32) used for a 3x3 stride-1 SAME convolution of this shape?"""
     # tiny maps (the pyramid branches' pooled maps, 2 x 3 ... 8 x 10 pixels): the split-operand kernel covers them with one masked
@@ -1219,14 +1251,16 @@ def _from5(y5, nsp, groups):
 
 def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None, bias=None, residual=None,
          relu=False, want_stats=False, out=None, y_coff=0, plane_bias=None, groups=None, in_params=None,
-         in_relu=False):
+         in_relu=False, in_sum=None):
     """Forward convolution of a channel-last tensor x: (H,W,C) or (D,H,W,C); with groups=G, G independent samples
     (G,H,W,C) / (G,D,H,W,C) in one launch (per-sample batch-norm moments).
 
     w_host: TF-layout numpy kernel [k.., Cin, Cout]; `key` names it for the pack cache.
     padding: 'SAME' | 'VALID'; explicit_pad = (before, after) per spatial axis overrides it
     (bottleneck conv2, network.py:589-595).  in_params (G,3,Cin) [+ in_relu]: x is a raw convolution output whose
-    batch norm is applied on load (only where the kernel of this shape supports it, see norm_on_load_ok).
+    batch norm is applied on load (only where the kernel of this shape supports it: norm_on_load_2d_ok / norm_on_load_3d_ok;
+    a 3-D shape without such a form gets the normalised tensor from a bn_apply pass here).  in_sum = (x1, params1 | None,
+    relu1) (3-D 16 -> 16 only): the input is x [normalised by in_params] + x1 [normalised by params1], formed on load.
     Returns y or (y, Stats).
     """
     x5, nsp = _to5(x, groups, 'conv input')
@@ -1308,8 +1342,31 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         y4, st = r if want_stats else (r, None)
         y = out if out is not None else _from5(y4.unsqueeze(1), nsp, groups)
         return (y, st) if want_stats else y
-    if in_params is not None:
+    if (in_params is not None or in_sum is not None) and nsp == 2:
         raise ValueError('conv %s: no normalise-on-load form for this shape' % (key,))
+    # 3-D: which split-operand kernel (if any) takes this shape, and does it form a lazy input on load?
+    c16_shape = nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
+        and residual is None and plane_bias is None and cfg.conv_c16 and cfg.force_impl is None \
+        and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
+        and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0))
+    b3 = split_on('c3b') and cin % 16 == 0 and cout in (32, 64) and bool(_lib.lib().atvs_conv3d_b_supported(int(cin), int(cout)))
+    b16 = split_on('c16b') and cin in (8, 16) and cout == 16
+    s2b = nsp == 3 and stride == 2 and dilation == 1 and ks == (3, 3, 3) and padding == 'SAME' and explicit_pad is None \
+        and split_on('s2b') and cfg.conv_c16 and cfg.force_impl is None and residual is None and plane_bias is None \
+        and bool(_lib.lib().atvs_conv3d_s2b_supported(int(cin), int(cout))) and outs[2] >= 8 \
+        and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
+        and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0))
+    lazy_ok = cfg.sum_on_load and cfg.norm3d and ((c16_shape and ((b3 and in_sum is None) or (b16 and cin == 16))) or (s2b and in_sum is None))
+    if (in_params is not None or in_sum is not None) and not lazy_ok:
+        # no form of this shape forms its input on load: the passes the lazy input stands for, then the plain convolution
+        if in_sum is not None:
+            a = PendingBN(x, in_params, in_relu) if in_params is not None else x
+            b = PendingBN(in_sum[0], in_sum[1], in_sum[2]) if in_sum[1] is not None else in_sum[0]
+            x = PendingSum([a, b]).materialize()
+        else:
+            x = bn_apply(x, in_params, in_relu, out=_new(x, x.shape))
+        x5, _ = _to5(x, groups, 'conv input')
+        in_params, in_sum = None, None
 
     # ---- 3-D, 3x3x3, 1-2 input channels -> 8: the refinement stems, HBM-bound FMA kernel
     if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) and cout == 8 \
@@ -1341,13 +1398,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
 
     # ---- 3-D, 3x3x3, 8 / 16 / 32 -> 16 and 16..64 -> 32 channels: one workgroup per CU, fully unrolled (the half- and
     # quarter-resolution U-Net layers, the AANet modules' shared | unique convolution)
-    b3 = split_on('c3b') and cin % 16 == 0 and cout in (32, 64) and bool(_lib.lib().atvs_conv3d_b_supported(int(cin), int(cout)))
-    if nsp == 3 and stride == 1 and dilation == 1 and ks == (3, 3, 3) and tuple(pads) == (1, 1, 1) \
-            and ((cout == 16 and cin in (8, 16, 32)) or (cout == 32 and cin in (16, 32, 48, 64)) or b3) \
-            and residual is None and plane_bias is None and cfg.conv_c16 and cfg.force_impl is None \
-            and tuple(outs) == ins and ins[2] >= 12 and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
-            and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
-        b16 = split_on('c16b') and cin in (8, 16) and cout == 16
+    if c16_shape and ((cout == 16 and cin in (8, 16, 32)) or (cout == 32 and cin in (16, 32, 48, 64)) or b3):
         pk = pack_conv3d_b(key, w_host, x.device) if b3 else \
             pack_conv_c16b(key, w_host, x.device) if b16 else pack_conv_c16(key, w_host, x.device)
         if y5 is None:
@@ -1360,9 +1411,17 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, cout, M, G
         if _dev_ok(x5, y5, bias):
             with _Timed(key, x5.shape[1:], cout, G):
-                if b3:
+                if b3 and in_params is not None:
+                    _call('atvs_conv3d_b_norm_f32', _p(x5), _p(in_params), int(bool(in_relu)), _p(pk.wp), _p(bias), _p(y5), _p(sbuf),
+                          G, outs[0], outs[1], outs[2], cin, cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                elif b3:
                     _call('atvs_conv3d_b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
                           cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                elif b16 and (in_params is not None or in_sum is not None):
+                    x1, p1, r1 = in_sum if in_sum is not None else (None, None, False)
+                    mask = (1 if in_relu else 0) | (2 if r1 else 0)
+                    _call('atvs_conv_c16b_sum_f32', _p(x5), _p(in_params), _p(x1), _p(p1), int(mask), _p(pk.wp), _p(bias), _p(y5),
+                          _p(sbuf), G, outs[0], outs[1], outs[2], cin, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
                 elif b16:
                     _call('atvs_conv_c16b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, outs[0], outs[1], outs[2], cin,
                           int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
@@ -1373,11 +1432,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         return (y, st) if want_stats else y
 
     # ---- 3-D, 3x3x3, stride 2, SAME, 16 k -> 32 / 64 channels: the U-Net encoders below half resolution on split-bf16 operands
-    if nsp == 3 and stride == 2 and dilation == 1 and ks == (3, 3, 3) and padding == 'SAME' and explicit_pad is None \
-            and split_on('s2b') and cfg.conv_c16 and cfg.force_impl is None and residual is None and plane_bias is None \
-            and bool(_lib.lib().atvs_conv3d_s2b_supported(int(cin), int(cout))) and outs[2] >= 8 \
-            and 4.0 * M * (cout if y5 is None else y5.shape[-1]) < 2.0 ** 32 \
-            and (y5 is None or (y5.shape[-1] % 4 == 0 and y_coff % 4 == 0)):
+    if s2b:
         pk = pack_conv3d_b(key, w_host, x.device, kind='s2b')
         if y5 is None:
             y5 = _new(x, (G,) + tuple(outs) + (cout,))
@@ -1389,8 +1444,12 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
             st.partial, st.blocks, st.cpad, st.count, st.groups = sbuf, rows, cout, M, G
         if _dev_ok(x5, y5, bias):
             with _Timed(key, x5.shape[1:], cout, G):
-                _call('atvs_conv3d_s2b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, ins[0], ins[1], ins[2], cin,
-                      cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                if in_params is not None:
+                    _call('atvs_conv3d_s2b_norm_f32', _p(x5), _p(in_params), int(bool(in_relu)), _p(pk.wp), _p(bias), _p(y5),
+                          _p(sbuf), G, ins[0], ins[1], ins[2], cin, cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
+                else:
+                    _call('atvs_conv3d_s2b_f32', _p(x5), _p(pk.wp), _p(bias), _p(y5), _p(sbuf), G, ins[0], ins[1], ins[2], cin,
+                          cout, int(y5.shape[-1]), int(y_coff), int(bool(relu)), _stream())
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 38
+#define ATVS_ABI_VERSION 39
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -413,6 +413,12 @@ int atvs_conv3d_b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_conv3d_b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
 int atvs_conv3d_b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
                       int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+/* The same convolution of relu?((x - mean) * scale + beta): x a raw convolution output, in_params (groups,3,Cin) its pending
+ * batch norm (conv_b*_{2,3}_1 read conv_b*_{2,3}_0, cnn_wrapper/atvsnet.py:20-26), applied per staged halo voxel -- the
+ * normalised tensor is never written.  Bit for bit atvs_bn_apply followed by atvs_conv3d_b_f32. */
+int atvs_conv3d_b_norm_f32(const float* x, const float* in_params, int in_relu, const unsigned char* packed_w, const float* bias,
+                           float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int Cout, int ldy,
+                           int y_coff, int relu, atvs_stream_t stream);
 
 /* The STRIDE-2 form (conv_b*_2_0: 16 -> 32, conv_b*_3_0: 32 -> 64, global_refine_3dconv{2,3}_0; network.py:172-215) with split
  * fp16 operands (conv3d_s2b.hip): x (groups,D,H,W,Cin) -> y (groups,Do,Ho,Wo,ldy)[..., y_coff : y_coff + Cout], Do = ceil(D / 2) ...,
@@ -424,6 +430,12 @@ int atvs_conv3d_s2b_pack_size(int Cin, int Cout, long* packed_bytes);
 int atvs_conv3d_s2b_pack(const float* w, int Cin, int Cout, unsigned char* packed);
 int atvs_conv3d_s2b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
                         int groups, int D, int H, int W, int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
+/* ... of relu?((x - mean) * scale + beta), in_params (groups,3,Cin) the pending batch norm of the raw convolution output x (the
+ * encoders conv_b*_{2,3}_0 read conv_b*_{1,2}_0, cnn_wrapper/atvsnet.py:10-12).  Bit for bit atvs_bn_apply followed by
+ * atvs_conv3d_s2b_f32. */
+int atvs_conv3d_s2b_norm_f32(const float* x, const float* in_params, int in_relu, const unsigned char* packed_w,
+                             const float* bias, float* y, double* stats_partial, int groups, int D, int H, int W, int Cin,
+                             int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 /* atvs_deconv_up_f32's layers and contract with SPLIT operands on the 16-bit matrix cores (deconv_up_b.hip; the arithmetic of
  * atvs_conv_c16b_f32: two fp16 pieces per operand, three products, the cross terms in an accumulator of their own).  Grid /
@@ -631,6 +643,16 @@ int atvs_conv_c16b_pack_size(int Cin, long* packed_bytes);
 int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packed);
 int atvs_conv_c16b_f32(const float* x, const unsigned char* packed_w, const float* bias, float* y, double* stats_partial,
                        int groups, int D, int H, int W, int Cin, int ldy, int y_coff, int relu, atvs_stream_t stream);
+/* The 16 -> 16 form of an input that is never written: x_in = t(x0, params0, bit 0) [+ t(x1, params1, bit 1)] with
+ * t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v -- one term: a pending batch norm applied while the halo is staged
+ * (conv_b0_1_1 reads conv_b0_1_0; atvs_bn_apply's arithmetic); two terms: the U-Net's skip sum (conv_b{1,2}_1_1_concat,
+ * cnn_wrapper/atvsnet.py:45-46,75-76,140-141,170-171; atvs_bn_add's arithmetic and order).  params_i (groups,3,16) or NULL (that
+ * term is a finished tensor); x1 NULL: one term (params0 required).  relu_mask bit i: ReLU after term i's batch norm.  Bit for
+ * bit atvs_bn_apply / atvs_bn_add followed by atvs_conv_c16b_f32. */
+int atvs_conv_c16b_sum_supported(int Cin);
+int atvs_conv_c16b_sum_f32(const float* x0, const float* params0, const float* x1, const float* params1, int relu_mask,
+                           const unsigned char* packed_w, const float* bias, float* y, double* stats_partial, int groups, int D,
+                           int H, int W, int Cin, int ldy, int y_coff, int relu, atvs_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -527,6 +527,68 @@ def test_deconv_sums_its_inputs_on_load_bitwise(cuda, G, shape, nterms):
     assert torch.equal(ops.bn_params(st, cout, got), ops.bn_params(st_ref, cout, ref))
 
 
+def _pending_seeded(G, shape, cin, seed, relu, cuda):
+    from atvsnet_amd import ops
+    raw = _rand((G,) + shape + (cin,), seed).to(cuda)
+    par = torch.stack([_rand((G, cin), seed + 10) * 0.1, _rand((G, cin), seed + 30).abs() + 0.5,
+                       _rand((G, cin), seed + 20) * 0.1], 1).to(cuda).contiguous()
+    return ops.PendingBN(raw, par, relu=relu)
+
+
+@pytest.mark.parametrize('G,shape,cin,cout,stride,relu', [
+    (2, (8, 16, 32), 16, 16, 1, True), (1, (9, 11, 19), 16, 16, 1, False), (3, (5, 9, 13), 16, 16, 1, True),    # conv_c16b
+    (2, (8, 16, 24), 32, 32, 1, True), (1, (6, 9, 17), 64, 64, 1, True), (2, (5, 8, 12), 16, 32, 1, False),     # conv3d_b
+    (2, (16, 32, 48), 16, 32, 2, True), (1, (9, 17, 33), 32, 64, 2, True), (3, (7, 10, 18), 16, 32, 2, False)])  # conv3d_s2b
+def test_conv3d_normalises_its_input_on_load_bitwise(cuda, G, shape, cin, cout, stride, relu):
+    """The U-Nets' encoders conv_b*_{1,2,3}_0 hand their consumers (conv_b*_{2,3}_0 stride 2, conv_b*_{1,2,3}_1; reference
+    cnn_wrapper/atvsnet.py:10-26) the RAW output + moments: conv_c16b / conv3d_b / conv3d_s2b apply the batch norm (+ ReLU) while
+    they stage the halo (atvs_*_norm_f32, atvs_conv_c16b_sum_f32 with one term) -- against the same layer behind the bn_apply
+    pass it replaces: every bit and the moments, several samples per launch, ragged tiles (the zero padding must stay zero)."""
+    from atvsnet_amd import ops
+    w = (_rand((3, 3, 3, cin, cout), 5) * 0.1).numpy()
+    pend = _pending_seeded(G, shape, cin, 60, relu, cuda)
+    assert ops.norm_on_load_3d_ok(pend, 3, cout, stride)
+    x, pro = pend.prologue()
+    got, st = ops.conv(x, ('norm3d', cin, cout, stride), w, stride=stride, want_stats=True, groups=G, in_params=pro[1],
+                       in_relu=pro[3])
+    assert pend._final is None                                        # never materialised
+    with ops.configure(sum_on_load=False):
+        assert not ops.norm_on_load_3d_ok(pend, 3, cout, stride)
+        ref, st_ref = ops.conv(x, ('norm3d', cin, cout, stride), w, stride=stride, want_stats=True, groups=G, in_params=pro[1],
+                               in_relu=pro[3])                         # ops.conv's own fallback: bn_apply, then the plain kernel
+    want, st_w = ops.conv(pend.materialize(), ('norm3d', cin, cout, stride), w, stride=stride, want_stats=True, groups=G)
+    assert torch.equal(ref, want)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.bn_params(st, cout, got), ops.bn_params(st_w, cout, want))
+
+
+@pytest.mark.parametrize('G,shape,forms', [(2, (8, 16, 32), 'pp'), (1, (9, 11, 19), 'pd'), (3, (5, 9, 13), 'dp'), (2, (4, 8, 16), 'pp')])
+def test_conv_c16b_sums_its_inputs_on_load_bitwise(cuda, G, shape, forms):
+    """conv_b{1,2}_1_1 behind conv_b{1,2}_1_1_concat = conv_b*_1_0 + conv_b{0,1}_5_0 (reference cnn_wrapper/atvsnet.py:45-46,
+    75-76): the 16 -> 16 kernel forms the sum of two pending batch norms (or a pending one and a finished tensor) while it
+    stages the halo (atvs_conv_c16b_sum_f32) -- against bn_add followed by the plain kernel, every bit and the moments."""
+    from atvsnet_amd import ops
+    w = (_rand((3, 3, 3, 16, 16), 7) * 0.1).numpy()
+
+    def items(seed):
+        out = []
+        for k, f in enumerate(forms):
+            out.append(_pending_seeded(G, shape, 16, seed + 100 * k, k == 0, cuda) if f == 'p'
+                       else _rand((G,) + shape + (16,), seed + 100 * k).to(cuda))
+        return out
+    s_on = ops.PendingSum(items(80))
+    assert ops.norm_on_load_3d_ok(s_on, 3, 16, 1)
+    x, (x1, pa, pb, ra, rb) = s_on.prologue()
+    got, st = ops.conv(x, ('sum16',), w, want_stats=True, groups=G, in_params=pa, in_relu=ra, in_sum=(x1, pb, rb))
+    assert s_on._final is None
+    want, st_w = ops.conv(ops.PendingSum(items(80)).materialize(), ('sum16',), w, want_stats=True, groups=G)
+    assert torch.equal(got, want)
+    assert torch.equal(ops.bn_params(st, 16, got), ops.bn_params(st_w, 16, want))
+    with ops.configure(sum_on_load=False):                             # ops.conv's own fallback
+        ref = ops.conv(x, ('sum16',), w, groups=G, in_params=pa, in_relu=ra, in_sum=(x1, pb, rb))
+    assert torch.equal(ref, want)
+
+
 @pytest.mark.parametrize('nv,shape', [(4, (16, 24, 40)), (2, (9, 13, 35)), (3, (4, 8, 16)), (1, (6, 10, 20)), (4, (5, 9, 17))])
 def test_aanet_module_in_one_launch_bitwise(cuda, weights, nv, shape):
     """aanet_b.hip: the shared | unique score convolutions of every view and the cross-view softmax + weighted sum (reference
