@@ -245,6 +245,25 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     return o;
   };
 
+  // PRO: slot i of the stage in flight -> the two fp16 pieces of its sum, kept in pf[i] (p0 | p1).  Done where the vector unit has
+  // nothing else to do -- behind the K loop's later phases (slots 0..3: their loads are four phases old) and behind the epilogue's
+  // stores -- instead of in front of the next stage's LDS writes, where all four wavefronts waited for it (round 5: 384 -> .. us)
+  auto pro_slot = [&](int i) __attribute__((always_inline)) {
+    float4 a = pro_term(pf[i], 0, p.pa);
+    const float4 b = pro_term(pf2[i], 1, p.pb);
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    if (xg3) {
+      const float4 d = pro_term(pf3[i], 2, p.pc);
+      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+    }
+    const bool in = (okm_next >> i) & 1u;
+    uint2 p0, p1;
+    atvs_split2_f16(in ? a.x : 0.f, in ? a.y : 0.f, UB_RS, &p0.x, &p1.x);
+    atvs_split2_f16(in ? a.z : 0.f, in ? a.w : 0.f, UB_RS, &p0.y, &p1.y);
+    pf[i] = make_float4(__uint_as_float(p0.x), __uint_as_float(p0.y), __uint_as_float(p1.x), __uint_as_float(p1.y));
+  };
+  constexpr int PRO_INLOOP = 4;            // slots transformed behind phases 4..7 of the K loop
+
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};       // scalar on purpose (two workgroups share a CU)
   f32x4 acc[TY][NT], accx[TY][NT];       // h0 g0 | (h0 g1 + h1 g0) * 2^11
   const unsigned ybytes = (unsigned)(p.gy * 4);
@@ -254,6 +273,10 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     const PfTile T0 = pf_tile(0);
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
+    if (PRO) {
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) pro_slot(i);
+    }
   }
 
   UDBG(6)
@@ -273,24 +296,17 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
       float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
       for (int i = tid; i < U::WCH / 16; i += 256) dst[i] = src[i];
     }
-    const unsigned okm = okm_next;
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) {
-        if (PRO) {
-          float4 a = pro_term(pf[i], 0, p.pa);
-          const float4 b = pro_term(pf2[i], 1, p.pb);
-          a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-          if (xg3) {
-            const float4 d = pro_term(pf3[i], 2, p.pc);
-            a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-          }
-          const bool in = (okm >> i) & 1u;
-          pf[i] = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
-        }
         uint2 p0, p1;
-        atvs_split2_f16(pf[i].x, pf[i].y, UB_RS, &p0.x, &p1.x);
-        atvs_split2_f16(pf[i].z, pf[i].w, UB_RS, &p0.y, &p1.y);
+        if (PRO) {                           // already the pieces (pro_slot)
+          p0 = make_uint2(__float_as_uint(pf[i].x), __float_as_uint(pf[i].y));
+          p1 = make_uint2(__float_as_uint(pf[i].z), __float_as_uint(pf[i].w));
+        } else {
+          atvs_split2_f16(pf[i].x, pf[i].y, UB_RS, &p0.x, &p1.x);
+          atvs_split2_f16(pf[i].z, pf[i].w, UB_RS, &p0.y, &p1.y);
+        }
         *reinterpret_cast<uint2*>(smem + laddr[i]) = p0;
         *reinterpret_cast<uint2*>(smem + U::IMG + laddr[i]) = p1;
       }
@@ -355,6 +371,10 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         __builtin_amdgcn_sched_barrier(0);
         request_A1(IC<g + 1>{});
       }
+      if constexpr (PRO && ph >= UB_NP * NG - PRO_INLOOP) {      // a slot whose loads are four phases old
+        constexpr int sl = ph - (UB_NP * NG - PRO_INLOOP);
+        if constexpr (sl < MAXS) pro_slot(sl);
+      }
     });
     static_assert(UB_NP * NG >= MAXS, "every halo slot is requested inside the K loop");
     UDBG(4)
@@ -397,6 +417,10 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         ssq[2] = __builtin_fmaf(b2, b2, ssq[2]); ssq[3] = __builtin_fmaf(b3, b3, ssq[3]);
       });
     });
+    if (PRO) {                               // the remaining slots, behind the stores
+#pragma unroll
+      for (int i = PRO_INLOOP; i < MAXS; ++i) pro_slot(i);
+    }
     UDBG(5)
   }
 
