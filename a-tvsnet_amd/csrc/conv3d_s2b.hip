@@ -186,6 +186,30 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     nbnm = ld4(q3); nbns = ld4(q3 + p.Cin); nbnb = ld4(q3 + 2 * p.Cin);
   };
   if (NORM) norm_rows(0);
+  // slot i of a stage -> its two fp16 pieces, kept in pf[i] (p0 | p1) until the stage's LDS writes.  Slots [0, NIN) of the stage in
+  // flight are transformed behind MFMAs of the K loop, LAG slots (LAG / 2 steps) after their loads were issued -- in front of the
+  // LDS writes all four wavefronts wait for it (tools_dev/phase_s2.py: split + LDS write 26 % of a stage).  rm / rs / rb: the rows
+  // of that stage's chunk.
+  constexpr int LAG = 8, NIN = (2 * JC - LAG) < MAXS ? (2 * JC - LAG) : MAXS;
+  auto xform_slot = [&](int i, const PfTile& TT, const float4& rm, const float4& rs, const float4& rb) __attribute__((always_inline)) {
+    float4 a = pf[i];
+    if (NORM) {
+      const float nfloor = p.in_relu ? 0.f : -INFINITY;
+      a.x = (a.x - rm.x) * rs.x + rb.x;
+      a.y = (a.y - rm.y) * rs.y + rb.y;
+      a.z = (a.z - rm.z) * rs.z + rb.z;
+      a.w = (a.w - rm.w) * rs.w + rb.w;
+      a.x = fmaxf(a.x, nfloor); a.y = fmaxf(a.y, nfloor); a.z = fmaxf(a.z, nfloor); a.w = fmaxf(a.w, nfloor);     // ReLU or nothing
+      // a halo slot outside the volume: its padding stays zero
+      const unsigned t1 = pg[i] - TT.lo;
+      const unsigned t2 = TT.hi1 + ~pg[i];
+      const bool in = ((t1 & t2) & 0x808080u) == 0x808080u;
+      a = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
+    }
+    uint2 h0, h1;
+    atvs_split4_f16(a, &h0, &h1);
+    pf[i] = make_float4(__uint_as_float(h0.x), __uint_as_float(h0.y), __uint_as_float(h1.x), __uint_as_float(h1.y));
+  };
 
   f32x4 acc[NTW][TY], accx[NTW][TY];   // h0 g0 | (h0 g1 + h1 g0) * 2^11
   f32x2 ssum2[NTW][2], ssq2[NTW][2];
@@ -198,6 +222,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
   if (nstage > 0) {
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) pf_slot(Tn, i);
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) xform_slot(i, Tn, nbnm, nbns, nbnb);      // (later stages: inside the previous stage's K loop)
   }
 
 #ifdef ATVS_S2_DEBUG
@@ -230,32 +256,15 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     SDBG(2)
 #endif
-    const PfTile Tc = Tn;                 // NORM: which slots lie inside the volume (a padding zero is not zero after its batch norm)
-    const bool edge = Tc.lo != 0u || (Tc.hi1 & 0xffu) < (unsigned)S2_HZ || ((Tc.hi1 >> 8) & 0xffu) < (unsigned)HY || ((Tc.hi1 >> 16) & 0xffu) < (unsigned)S2_HX;
+    const PfTile Tc = Tn;                  // the stage being staged
     if (NORM) { bnm = nbnm; bns = nbns; bnb = nbnb; }
-    const float nfloor = p.in_relu ? 0.f : -INFINITY;
+#pragma unroll
+    for (int i = NIN; i < MAXS; ++i) xform_slot(i, Tc, bnm, bns, bnb);
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < S2_SLOTS) {
-        if (NORM) {
-          float4 a = pf[i];
-          a.x = (a.x - bnm.x) * bns.x + bnb.x;
-          a.y = (a.y - bnm.y) * bns.y + bnb.y;
-          a.z = (a.z - bnm.z) * bns.z + bnb.z;
-          a.w = (a.w - bnm.w) * bns.w + bnb.w;
-          a.x = fmaxf(a.x, nfloor); a.y = fmaxf(a.y, nfloor); a.z = fmaxf(a.z, nfloor); a.w = fmaxf(a.w, nfloor);     // ReLU or nothing
-          if (edge) {                        // (uniform) a halo that leaves the volume: its padding stays zero
-            const unsigned t1 = pg[i] - Tc.lo;
-            const unsigned t2 = Tc.hi1 + ~pg[i];
-            const bool in = ((t1 & t2) & 0x808080u) == 0x808080u;
-            a = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
-          }
-          pf[i] = a;
-        }
-        f16x4 p0, p1;
-        s2_split(pf[i], &p0, &p1);
-        *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
-        *reinterpret_cast<f16x4*>(smem + S2_IMG + laddr[i]) = p1;
+        *reinterpret_cast<uint2*>(smem + laddr[i]) = make_uint2(__float_as_uint(pf[i].x), __float_as_uint(pf[i].y));
+        *reinterpret_cast<uint2*>(smem + S2_IMG + laddr[i]) = make_uint2(__float_as_uint(pf[i].z), __float_as_uint(pf[i].w));
       }
     }
     SDBG(3)
@@ -294,6 +303,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
         } else if constexpr (m == S2_NP * TY + S2_NP * NTW || m == S2_NP * TY + S2_NP * NTW + 1) {
           constexpr int s = 2 * j + (m - S2_NP * TY - S2_NP * NTW);
           if constexpr (s < MAXS) pf_slot(T, s);
+          if constexpr (s >= LAG && s - LAG < NIN) xform_slot(s - LAG, T, nbnm, nbns, nbnb);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
