@@ -203,6 +203,29 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     return o;
   };
 
+  // slot i of a tile -> its two fp16 pieces, kept in pf[i] (p0 | p1) until the tile's LDS writes.  The slots of the tile in flight are
+  // transformed behind MFMAs of the K loop, LAG slots (LAG / 2 steps) after their loads were issued -- in front of the LDS writes
+  // all four wavefronts wait for it (conv3d_s2b.hip)
+  constexpr int LAG = 8, NIN = (2 * JC - LAG) < MAXS ? (2 * JC - LAG) : MAXS;
+  auto xform_slot = [&](int i, const PfTile& TT) __attribute__((always_inline)) {
+    float4 a = pf[i];
+    if (PRO) {
+      a = pro_term(a, 0, p.pa);
+      if (PRO == 2) {
+        const float4 b = pro_term(pf2[i], 1, p.pb);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+      }
+      // a halo slot outside the volume: its padding stays zero (it is not zero after a batch norm)
+      const unsigned t1 = pg[i] - TT.lo;
+      const unsigned t2 = TT.hi1 + ~pg[i];
+      const bool in = ((t1 & t2) & 0x808080u) == 0x808080u;
+      a = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
+    }
+    uint2 h0, h1;
+    atvs_split4_f16(a, &h0, &h1);
+    pf[i] = make_float4(__uint_as_float(h0.x), __uint_as_float(h0.y), __uint_as_float(h1.x), __uint_as_float(h1.y));
+  };
+
   f32x2 ssum2[2], ssq2[2];
   ssum2[0] = ssum2[1] = ssq2[0] = ssq2[1] = (f32x2){0.f, 0.f};
   f32x4 acc[TY], accx[TY];             // h0 g0 | (h0 g1 + h1 g0) * 2^11
@@ -214,36 +237,23 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
   if (my_tiles > 0) {
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) pf_slot(Tn, i);
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) xform_slot(i, Tn);      // (later tiles: inside the previous tile's K loop)
   }
 
   for (int k = 0; k < my_tiles; ++k) {
 #pragma unroll
     for (int t = 0; t < TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();                       // every wavefront is done reading the previous tile's images
-    // split the staged fp32 halo into its two fp16 pieces on the way into LDS
-    const PfTile Tc = Tn;                     // PRO: which slots lie inside the volume (a padding zero is not zero after its batch norm)
-    const bool edge = Tc.lo != 0u || (Tc.hi1 & 0xffu) < (unsigned)B16_HZ || ((Tc.hi1 >> 8) & 0xffu) < (unsigned)HY || ((Tc.hi1 >> 16) & 0xffu) < (unsigned)B16_HX;
+    // the staged halo's two fp16 pieces into LDS
+    const PfTile Tc = Tn;
+#pragma unroll
+    for (int i = NIN; i < MAXS; ++i) xform_slot(i, Tc);
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) {
       if (i < MAXS - 1 || tid + i * 256 < B16_SLOTS) {
-        if (PRO) {
-          float4 a = pro_term(pf[i], 0, p.pa);
-          if (PRO == 2) {
-            const float4 b = pro_term(pf2[i], 1, p.pb);
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-          }
-          if (edge) {                        // (uniform) a halo that leaves the volume: its padding stays zero
-            const unsigned t1 = pg[i] - Tc.lo;
-            const unsigned t2 = Tc.hi1 + ~pg[i];
-            const bool in = ((t1 & t2) & 0x808080u) == 0x808080u;
-            a = make_float4(in ? a.x : 0.f, in ? a.y : 0.f, in ? a.z : 0.f, in ? a.w : 0.f);
-          }
-          pf[i] = a;
-        }
-        f16x4 p0, p1;
-        b16_split(pf[i], &p0, &p1);
-        *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
-        *reinterpret_cast<f16x4*>(smem + B16_IMG + laddr[i]) = p1;
+        *reinterpret_cast<uint2*>(smem + laddr[i]) = make_uint2(__float_as_uint(pf[i].x), __float_as_uint(pf[i].y));
+        *reinterpret_cast<uint2*>(smem + B16_IMG + laddr[i]) = make_uint2(__float_as_uint(pf[i].z), __float_as_uint(pf[i].w));
       }
     }
     __syncthreads();
@@ -298,6 +308,9 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
         } else if constexpr (m == TY + 3 || m == TY + 6) {
           constexpr int slot = 2 * j + (m == TY + 6 ? 1 : 0);
           if constexpr (slot < MAXS) pf_slot(T, slot);
+        } else if constexpr (m == TY + 4 || m == TY + 7) {
+          constexpr int slot = 2 * j + (m == TY + 7 ? 1 : 0) - LAG;
+          if constexpr (slot >= 0 && slot < NIN) xform_slot(slot, T);
         }
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
