@@ -60,9 +60,11 @@ def infer_twoview(images, cams, max_d=None, batched=None):
     if BATCHED if batched is None else batched:
         # model.TVSNet (reference model.py:346-377) with both towers, both siamese directions in one pass each
         feats = feature_extraction_batch(images)
-        _, prob_b2, depth_b2, dview = base_stage_batch(feats, cams, max_d, depth_start, depth_interval, fwd=[1], rev=[1])
+        hom = {}
+        _, prob_b2, depth_b2, dview = base_stage_batch(feats, cams, max_d, depth_start, depth_interval, fwd=[1], rev=[1], hom=hom)
         shallow = shallow_feature_batch(images)
-        _, prob_residual = refinement_batch(depth_b2, dview, prob_b2, cams, max_d, depth_start, depth_interval, [1], shallow)
+        _, prob_residual = refinement_batch(depth_b2, dview, prob_b2, cams, max_d, depth_start, depth_interval, [1], shallow,
+                                            hom=hom)
         refined_prob_volume = ops.add_n([prob_b2, prob_residual])
         _, depth_refined = prob2depth_upsample(refined_prob_volume, max_d, depth_start, depth_interval, out_prob_map=False)
         return depth_refined
@@ -140,7 +142,8 @@ def _infer_multiview_batched(images, cams, max_d, stages, out_prob_map):
     src = list(range(1, n))
     depth_start, depth_interval = depth_range(cams)
     feats = feature_extraction_batch(images)
-    filtered, _, _, depth_view = base_stage_batch(feats, cams, max_d, depth_start, depth_interval, fwd=src, rev=src)
+    hom = {}                       # the plane sweeps of the camera pairs: computed once per depth map
+    filtered, _, _, depth_view = base_stage_batch(feats, cams, max_d, depth_start, depth_interval, fwd=src, rev=src, hom=hom)
     del feats
     # AAM1
     cost_volume_agg = cost_volume_aggregation(filtered, reuse=False, keepchannel=True)
@@ -150,7 +153,7 @@ def _infer_multiview_batched(images, cams, max_d, stages, out_prob_map):
     # refinement of every source against the aggregated estimate
     shallow = shallow_feature_batch(images)
     cost_residual, _ = refinement_batch(depth_agg_init, depth_view, prob_volume_agg, cams, max_d, depth_start,
-                                        depth_interval, src, shallow)
+                                        depth_interval, src, shallow, hom=hom)
     refined = torch.empty_like(cost_residual)
     for b in range(len(src)):                                   # refined_cost = filtered_cost + residual (model.py:438)
         ops.add_n([cost_volume_agg[0], cost_residual[b]], out=refined[b])

@@ -137,8 +137,19 @@ def cost_volume_reasoning(cost_volume, output_prob=True, output_filtered_cost=Fa
     return tower.get_output_by_name('conv_b2_6_1')
 
 
+def _cached_homographies(hom, key, left_cam, right_cam, D, depth_start, depth_interval):
+    """get_homographies(...)[0] of the camera pair `key` = (left view id, right view id); `hom`: a dict shared by the stages of one
+    depth map (the sweep of pair (0, v) is needed by the cost volume, the refinement volumes and the visual hull) or None."""
+    if hom is not None and key is not None and key in hom:
+        return hom[key]
+    Hm = get_homographies(left_cam, right_cam, depth_num=D, depth_start=depth_start, depth_interval=depth_interval)[0].contiguous()
+    if hom is not None and key is not None:
+        hom[key] = Hm
+    return Hm
+
+
 def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_cam, ref_f, view_f, D, ds, di, depth_start,
-                        depth_interval):
+                        depth_interval, hom=None, keys=(None, None)):
     """The volume construction of reference :247-330 for ONE (reference, source) pair, written into sample b of the
     batched buffers `bufs` = (photo_var (B,D,h,w,F), photo_const (B,h,w,2F), geo_var (B,D,h,w,2), geo_const (B,h,w,2),
     vis_hull (B,D,h,w,1)).  init_ref / init_view (1,h,w,1); ref_f / view_f (1,h,w,F); cams (1,2,4,4).
@@ -148,7 +159,7 @@ def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_ca
     h, w = init_ref.shape[1:3]
     chan = ref_f.shape[3]
     init_view_trans = transform_depth(init_view, view_cam, ref_cam)
-    Hm = get_homographies(ref_cam, view_cam, depth_num=D, depth_start=depth_start, depth_interval=depth_interval)[0].contiguous()
+    Hm = _cached_homographies(hom, keys[0], ref_cam, view_cam, D, depth_start, depth_interval)
     rf, vf = ref_f[0].contiguous(), view_f[0].contiguous()
     dref = init_ref.reshape(h, w).contiguous()
     dvt = init_view_trans.reshape(h, w, 1).contiguous()
@@ -169,8 +180,7 @@ def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_ca
     if hull_cam is view_cam:
         h_hull, vt_hull = Hm, init_view_trans
     else:
-        h_hull = get_homographies(ref_cam, hull_cam, depth_num=D, depth_start=depth_start,
-                                  depth_interval=depth_interval)[0].contiguous()
+        h_hull = _cached_homographies(hom, keys[1], ref_cam, hull_cam, D, depth_start, depth_interval)
         vt_hull = transform_depth(init_view, hull_cam, ref_cam)
     ops.visual_hull(dref, vt_hull.reshape(h, w).contiguous(), h_hull, ds, di, FLAGS.inverse_depth,
                     out=hull[b].reshape(D, h, w))
@@ -238,12 +248,13 @@ def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, 
 
 
 def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_start, depth_interval, sources,
-                     shallow, ref_id=0, shallow_index=None):
+                     shallow, ref_id=0, shallow_index=None, hom=None):
     """`refinement` of several source views against one reference estimate in ONE pass of the network
     (the reference calls it once per source, example.py:163-172): depth_ref (1,h,w,1), depth_views {source: (1,h,w,1)},
     prob_vol (1,D,h,w) shared, shallow (N,h,w,16) features of every view (shallow_index: {view id: row of shallow} when
     it holds a subset) -> (cost residuals (S,D,h,w,8), prob residuals (S,D,h,w)), S = len(sources), each sample with
-    its own batch statistics.  cams are indexed by the view ids themselves."""
+    its own batch statistics.  cams are indexed by the view ids themselves.  hom: the depth map's homography cache
+    (_cached_homographies), e.g. the one base_stage_batch filled."""
     si = (lambda v: v) if shallow_index is None else (lambda v: shallow_index[v])
     D = int(depth_num)
     S = len(sources)
@@ -256,7 +267,7 @@ def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_st
         hull_cam = view_cam if _hull_view(ref_id) == v else cams[:, _hull_view(ref_id)]
         _refinement_volumes(b, bufs, depth_ref, depth_views[v], cams[:, ref_id], view_cam, hull_cam,
                             shallow[si(ref_id):si(ref_id) + 1], shallow[si(v):si(v) + 1], D, ds, di, depth_start,
-                            depth_interval)
+                            depth_interval, hom, ((ref_id, v), (ref_id, _hull_view(ref_id))))
     pv = ops.stack([prob_vol[0].unsqueeze(-1)] * S, 0) if S > 1 else prob_vol.unsqueeze(-1)      # the shared volume, once per sample
     return _refine_net(bufs, pv, chan, True)
 
@@ -273,7 +284,7 @@ def shallow_feature_batch(images):
                                     independent_samples=True).get_output()
 
 
-def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_interval, feature_index=None):
+def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_interval, feature_index=None, hom=None):
     """build_cost_volume for several (reference view, source view) pairs as ONE SplitVolume of len(pairs) samples:
     features (N,h,w,F) of every view; pair (r, s) sweeps r's frustum and warps s's features into it (the depth range is
     the given one for every pair -- quirk C11: the reverse direction of a siamese pair uses the reference's too).
@@ -291,21 +302,21 @@ def build_cost_volumes(features, cams, pairs, depth_num, depth_start, depth_inte
     var = torch.empty((B, F // 8, ops.planar_stride(D, h, w)) if planar else (B, D, h, w, F), dtype=torch.float32,
                       device=features.device)
     for b, (r, s) in enumerate(pairs):
-        Hm = get_homographies(cams[:, r], cams[:, s], depth_num=D, depth_start=depth_start, depth_interval=depth_interval)
-        ops.warp_planes(features[fi(s)], Hm[0].contiguous(), out=var[b], planar=planar, pieces=pieces)
+        Hm = _cached_homographies(hom, (r, s), cams[:, r], cams[:, s], D, depth_start, depth_interval)
+        ops.warp_planes(features[fi(s)], Hm, out=var[b], planar=planar, pieces=pieces)
     const = ops.stack([features[fi(r)] for r, _ in pairs], 0) if B > 1 else features[fi(pairs[0][0]):fi(pairs[0][0]) + 1]
     return ops.SplitVolume(var, const.contiguous(), [('c', i) for i in range(F)] + [('v', i) for i in range(F)],
                            planar=(D, h, w) if planar else False, pieces=pieces)
 
 
-def base_stage_batch(features, cams, depth_num, depth_start, depth_interval, fwd, rev, ref_i=0, feature_index=None):
+def base_stage_batch(features, cams, depth_num, depth_start, depth_interval, fwd, rev, ref_i=0, feature_index=None, hom=None):
     """TVSNet_base_siamese for several source views in ONE pass of the regulariser (the reference runs it per source,
     example.py:144-149): `fwd` = sources whose reference->source direction is wanted (filtered cost volume, probability
     volume, depth), `rev` = sources whose source->reference direction is wanted (depth_view).
     -> (filtered (F,D,h,w,8), prob (F,D,h,w), depth_b2 (F,h,w,1), depth_view {source: (1,h,w,1)})."""
     D = int(depth_num)
     pairs = [(ref_i, v) for v in fwd] + [(v, ref_i) for v in rev]
-    cv = build_cost_volumes(features, cams, pairs, D, depth_start, depth_interval, feature_index)
+    cv = build_cost_volumes(features, cams, pairs, D, depth_start, depth_interval, feature_index, hom)
     tower = StackedUNet_prob({'data': cv}, is_training=True, reuse=AUTO_REUSE, independent_samples=True)
     del cv
     prob = tower.get_output().squeeze(-1)                        # (B,D,h,w)
