@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void transform_depth_kernel(const float* __res
   }
 }
 
-// The whole of transform_depth for a small map (<= 64 pixels per thread of ONE workgroup of 1,024): max of the input, the
+// The whole of transform_depth for a small map (<= 32 pixels per thread of ONE workgroup of 1,024): max of the input, the
 // transformed z and its max, the clip -- the four launches of the general form as one (round 5: a dependent launch costs ~4.7 us
 // of dispatch latency in a replayed graph, the map of configs[2] has 20,480 pixels).  The same operations per pixel; a maximum
 // is order-independent: identical bits.
@@ -735,46 +735,66 @@ __device__ __forceinline__ float block_max_1024(float v, float* sm) {
   return m;
 }
 
+// A thread keeps its (up to 32) pixels in registers: the loads are issued back to back (ONE memory round trip instead of one per
+// pixel and pass: 26 -> .. us at 20,480 pixels), the transformed depths are computed once.
 __global__ __launch_bounds__(1024) void transform_depth_small_kernel(const float* __restrict__ depth, const float* __restrict__ left_cam,
                                                                      const float* __restrict__ right_cam, float* __restrict__ out,
                                                                      int h, int w, int inverse_depth) {
+  constexpr int ITEMS = 32;                  // pixels per thread: maps up to 32,768 pixels
   __shared__ float pose[12];
   __shared__ float sm[16];
-  workgroup_pose(left_cam, right_cam, pose);
-  const long npix = (long)h * w;
+  const int npix = h * w;
+  float d[ITEMS];
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int i = threadIdx.x + k * 1024;
+    d[k] = (i < npix) ? depth[i] : -INFINITY;
+  }
+  workgroup_pose(left_cam, right_cam, pose);      // (thread 0's serial arithmetic: under the loads' round trip)
   float v = -INFINITY;
-  for (long i = threadIdx.x; i < npix; i += 1024) v = fmaxf(v, depth[i]);
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) v = fmaxf(v, d[k]);
   const float dmax = block_max_1024(v, sm);
-  auto zof = [&](long pix, float* valid) __attribute__((always_inline)) {
-    float d = depth[pix];
-    *valid = 0.f;
-    if (inverse_depth) {
-      *valid = (d > 1e-10f) ? 1.f : 0.f;
-      d = fminf(fmaxf(d, 1e-10f), dmax);
-      d = 1.0f / d;
-      d = d * *valid;
-    }
-    const int y = (int)(pix / w), x = (int)(pix % w);
-    float gx = ((float)x + 0.5f) * d;
-    asm volatile("" : "+v"(gx));             // keeps the two products apart: no v_pk_mul_f32 here (Appendix B; tests/test_packed_fp32_census.py)
-    const float gy = ((float)y + 0.5f) * d;
-    return ((pose[6] * gx + pose[7] * gy) + pose[8] * d) + pose[11];
-  };
+  unsigned validm = 0;                       // bit k: pixel k of this thread has a positive depth
+  // pixel threadIdx.x + 1024 k = (y, x): by carries, no division per pixel
+  const int sy = 1024 / w, sx = 1024 % w;
+  int y = (int)threadIdx.x / w, x = (int)threadIdx.x % w;
   float zm = -INFINITY;
-  for (long i = threadIdx.x; i < npix; i += 1024) {
-    float valid;
-    zm = fmaxf(zm, zof(i, &valid));
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int pix = threadIdx.x + k * 1024;
+    if (pix < npix) {                        // d[k] <- the depth of the pixel's point in the right camera
+      float dd = d[k];
+      if (inverse_depth) {
+        const bool ok = dd > 1e-10f;
+        validm |= ok ? (1u << k) : 0u;
+        dd = fminf(fmaxf(dd, 1e-10f), dmax);
+        dd = 1.0f / dd;
+        dd = dd * (ok ? 1.f : 0.f);
+      }
+      float gx = ((float)x + 0.5f) * dd;
+      asm volatile("" : "+v"(gx));           // keeps the two products apart: no v_pk_mul_f32 here (Appendix B; tests/test_packed_fp32_census.py)
+      const float gy = ((float)y + 0.5f) * dd;
+      const float z = ((pose[6] * gx + pose[7] * gy) + pose[8] * dd) + pose[11];
+      d[k] = z;
+      zm = fmaxf(zm, z);
+    }
+    x += sx; y += sy;
+    if (x >= w) { x -= w; ++y; }
   }
   const float zmax = block_max_1024(zm, sm);
-  for (long i = threadIdx.x; i < npix; i += 1024) {
-    float valid;
-    float z = zof(i, &valid);
-    if (inverse_depth) {
-      z = fminf(fmaxf(z, 1e-10f), zmax);
-      z = 1.0f / z;
-      z = z * valid;
+#pragma unroll
+  for (int k = 0; k < ITEMS; ++k) {
+    const int pix = threadIdx.x + k * 1024;
+    if (pix < npix) {
+      float z = d[k];
+      if (inverse_depth) {
+        z = fminf(fmaxf(z, 1e-10f), zmax);
+        z = 1.0f / z;
+        z = z * (((validm >> k) & 1u) ? 1.f : 0.f);
+      }
+      out[pix] = z;
     }
-    out[i] = z;
   }
 }
 
@@ -784,7 +804,7 @@ extern "C" int atvs_transform_depth(const float* depth, const float* left_cam, c
   if (h <= 0 || w <= 0) return ATVS_ERR_SHAPE;
   hipStream_t s = as_stream(stream);
   long npix = (long)h * w;
-  if (npix <= 64 * 1024) {
+  if (npix <= 32 * 1024) {
     hipLaunchKernelGGL(transform_depth_small_kernel, dim3(1), dim3(1024), 0, s, depth, left_cam, right_cam, out, h, w, inverse_depth);
     ATVS_LAUNCH_CHECK();
     return ATVS_OK;
