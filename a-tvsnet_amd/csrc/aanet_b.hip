@@ -71,7 +71,7 @@ __device__ __forceinline__ void ab_split(const float4& v, f16x4* p0, f16x4* p1) 
 constexpr int ab_clamp26(int t) { return t < 26 ? t : 26; }
 constexpr int ab_disp(int t) { return ((t / 9) * AB_HY + (t / 3) % 3) * AB_ROWB + (t % 3) * AB_VB; }
 
-// NV: register slots for the views' [S|R] (the launch's nv <= NV)
+// NV: the number of views (compile time: no branches in the combine, exactly NV register slots for [S|R])
 template <int NV>
 __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
   asm volatile("" ::: "v255", "a255");                         // own the SIMD's register file (conv_c16b.hip)
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
   for (int k = 0; k < my_tiles; ++k) {
     // a run-time loop over the views (unrolled at compile time -- [S|R] into static register slots, no selects -- the launch
     // was SLOWER: 663 instead of 628 us, four copies of the stage body)
-    for (int v = 0; v < p.nv; ++v) {
+    for (int v = 0; v < NV; ++v) {
 #pragma unroll
       for (int t = 0; t < TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
       __syncthreads();                       // every wavefront is done reading the previous stage's images
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
       __syncthreads();
 
       // the next stage: the next view of this tile, else view 0 of the next tile (last stage: a harmless re-read)
-      const bool last_view = v + 1 == p.nv;
+      const bool last_view = v + 1 == NV;
       const int vn = last_view ? 0 : v + 1;
       const PfTile T = pf_tile(last_view ? min(k + 1, my_tiles - 1) : k);
       const float* __restrict__ xn = p.x[vn];
@@ -239,47 +239,49 @@ __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
       tile_origin(k, &tz0, &ty0, &tx0);
       const int zo = tz0 + wave, xo = tx0 + r;
       const bool evox_ok = zo < p.Di && xo < p.Wi;
-#pragma unroll
-      for (int t = 0; t < TY; ++t) {
+      const size_t vo0 = (((size_t)zo * p.Hi + ty0) * p.Wi + xo) * 8 + 2 * q;
+      const size_t vrow = (size_t)p.Wi * 8;
+      // the centre voxels of the views (L2 hits: the halo just came through), one row AHEAD of the arithmetic: requested where
+      // they are used (round 5, first form) every row waited a full round trip -- 8 per tile.  (All rows in front of the last view's
+      // K loop: 64 more live registers, 15 spilled, 628 -> 721 us.)  Rows outside the volume read the zero line.
+      float2 xv[2][NV];
+      auto request_x = [&](int t) __attribute__((always_inline)) {
         const bool ok = evox_ok && ty0 + t < p.Hi;
-        if (!ok) continue;
-        const size_t vo = (((size_t)zo * p.Hi + ty0 + t) * p.Wi + xo) * 8 + 2 * q;
-        // (these loads requested in front of the last view's K loop -- 64 more live registers -- spilled 15 and the launch went
-        // 628 -> 721 us)
-        float2 xv[NV];
 #pragma unroll
         for (int n = 0; n < NV; ++n)
-          if (n < p.nv) xv[n] = *reinterpret_cast<const float2*>(p.x[n] + vo);
+          xv[t & 1][n] = *reinterpret_cast<const float2*>(ok ? (p.x[n] + (vo0 + t * vrow)) : p.zeros);
+      };
+      request_x(0);
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        if (t + 1 < TY) request_x(t + 1);
+        const bool ok = evox_ok && ty0 + t < p.Hi;
         float sx = 0.f, sy = 0.f;
         float ux[NV], uy[NV];
 #pragma unroll
-        for (int n = 0; n < NV; ++n)
-          if (n < p.nv) {
-            sx += sr[n][t].x; sy += sr[n][t].y;
-            ux[n] = sr[n][t].z - sr[n][t].x; uy[n] = sr[n][t].w - sr[n][t].y;
-          }
+        for (int n = 0; n < NV; ++n) {
+          sx += sr[n][t].x; sy += sr[n][t].y;
+          ux[n] = sr[n][t].z - sr[n][t].x; uy[n] = sr[n][t].w - sr[n][t].y;
+        }
         float mx = -INFINITY, my = -INFINITY;
 #pragma unroll
-        for (int n = 0; n < NV; ++n)
-          if (n < p.nv) {
-            ux[n] += sx; uy[n] += sy;
-            mx = fmaxf(mx, ux[n]); my = fmaxf(my, uy[n]);
-          }
+        for (int n = 0; n < NV; ++n) {
+          ux[n] += sx; uy[n] += sy;
+          mx = fmaxf(mx, ux[n]); my = fmaxf(my, uy[n]);
+        }
         float dx = 0.f, dy = 0.f;
 #pragma unroll
-        for (int n = 0; n < NV; ++n)
-          if (n < p.nv) {
-            ux[n] = expf(ux[n] - mx); uy[n] = expf(uy[n] - my);
-            dx += ux[n]; dy += uy[n];
-          }
+        for (int n = 0; n < NV; ++n) {
+          ux[n] = expf(ux[n] - mx); uy[n] = expf(uy[n] - my);
+          dx += ux[n]; dy += uy[n];
+        }
         float ox = 0.f, oy = 0.f;
 #pragma unroll
-        for (int n = 0; n < NV; ++n)
-          if (n < p.nv) {
-            ox += (ux[n] / dx) * xv[n].x;
-            oy += (uy[n] / dy) * xv[n].y;
-          }
-        *reinterpret_cast<float2*>(p.out + vo) = make_float2(ox, oy);
+        for (int n = 0; n < NV; ++n) {
+          ox += (ux[n] / dx) * xv[t & 1][n].x;
+          oy += (uy[n] / dy) * xv[t & 1][n].y;
+        }
+        if (ok) *reinterpret_cast<float2*>(p.out + (vo0 + t * vrow)) = make_float2(ox, oy);
       }
     }
   }
@@ -358,7 +360,7 @@ extern "C" int atvs_aanet_b_f32(const float* const* x, int nv, const unsigned ch
   grid = (grid + 7) / 8 * 8;
   a.wg = (int)grid;
   hipStream_t st = as_stream(stream);
-  const int rc = launch_ab<4>(a, grid, st);
+  const int rc = nv == 1 ? launch_ab<1>(a, grid, st) : nv == 2 ? launch_ab<2>(a, grid, st) : nv == 3 ? launch_ab<3>(a, grid, st) : launch_ab<4>(a, grid, st);
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
