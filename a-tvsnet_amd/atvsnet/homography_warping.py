@@ -100,6 +100,17 @@ def transform_depth(left_depth, left_cam, right_cam):
     return out.reshape(shape)
 
 
+def transform_depth_batch(jobs):
+    """transform_depth(left_depth, left_cam, right_cam) for every job of `jobs`, in one launch where the maps allow it
+    (ops.transform_depth_batch); the maps keep their shapes."""
+    flat = []
+    for left_depth, left_cam, right_cam in jobs:
+        h, w = left_depth.shape[1], left_depth.shape[2]
+        flat.append((left_depth.reshape(h, w).contiguous(), _cam(left_cam), _cam(right_cam)))
+    outs = ops.transform_depth_batch(flat, FLAGS.inverse_depth)
+    return [o.reshape(job[0].shape) for o, job in zip(outs, jobs)]
+
+
 def get_visual_hull(depth_images, cams, depth_num, depth_start, depth_interval, ref_id=0, view_num=None):
     """(B,N,H,W) depths -> (B,D,H,W,1) (reference :329-387).  Only view_num == 2 (every call site:
     model.py:323-324 with num_depths=2) is built.  Quirk C6: the second map is paired with

@@ -22,7 +22,7 @@ from ..cnn_wrapper.atvsnet import (AttAggregation, AttAggregation_keepchannel, A
                                     OutputConv_refine, ResNetDS2SPP, ResNetDS2SPP_shallow_f16, StackedUNet,
                                     StackedUNet_prob)
 from ..flags import AUTO_REUSE, FLAGS
-from .homography_warping import (get_homographies, get_visual_hull, homography_warping,          # noqa: F401
+from .homography_warping import (get_homographies, get_visual_hull, homography_warping, transform_depth_batch,          # noqa: F401
                                  homography_warping_by_depth, transform_depth)
 
 
@@ -149,7 +149,7 @@ def _cached_homographies(hom, key, left_cam, right_cam, D, depth_start, depth_in
 
 
 def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_cam, ref_f, view_f, D, ds, di, depth_start,
-                        depth_interval, hom=None, keys=(None, None)):
+                        depth_interval, hom=None, keys=(None, None), transformed=None):
     """The volume construction of reference :247-330 for ONE (reference, source) pair, written into sample b of the
     batched buffers `bufs` = (photo_var (B,D,h,w,F), photo_const (B,h,w,2F), geo_var (B,D,h,w,2), geo_const (B,h,w,2),
     vis_hull (B,D,h,w,1)).  init_ref / init_view (1,h,w,1); ref_f / view_f (1,h,w,F); cams (1,2,4,4).
@@ -158,7 +158,9 @@ def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_ca
     photo_var, photo_const, geo_var, geo_const, hull = bufs
     h, w = init_ref.shape[1:3]
     chan = ref_f.shape[3]
-    init_view_trans = transform_depth(init_view, view_cam, ref_cam)
+    # transformed: (init_view in the reference camera, init_view in ... through the hull camera) computed by the caller for all
+    # views at once (refinement_batch), else here
+    init_view_trans = transformed[0] if transformed is not None else transform_depth(init_view, view_cam, ref_cam)
     Hm = _cached_homographies(hom, keys[0], ref_cam, view_cam, D, depth_start, depth_interval)
     rf, vf = ref_f[0].contiguous(), view_f[0].contiguous()
     dref = init_ref.reshape(h, w).contiguous()
@@ -181,7 +183,7 @@ def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_ca
         h_hull, vt_hull = Hm, init_view_trans
     else:
         h_hull = _cached_homographies(hom, keys[1], ref_cam, hull_cam, D, depth_start, depth_interval)
-        vt_hull = transform_depth(init_view, hull_cam, ref_cam)
+        vt_hull = transformed[1] if transformed is not None else transform_depth(init_view, hull_cam, ref_cam)
     ops.visual_hull(dref, vt_hull.reshape(h, w).contiguous(), h_hull, ds, di, FLAGS.inverse_depth,
                     out=hull[b].reshape(D, h, w))
     return chan
@@ -262,12 +264,22 @@ def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_st
     h, w = depth_ref.shape[1:3]
     chan = shallow.shape[-1]
     bufs = _refinement_buffers(S, D, h, w, chan, shallow)
+    # every source's depth map in the reference camera's frame, directly and through the hull camera (quirk C6): one launch
+    jobs, where = [], []
+    for v in sources:
+        jobs.append((depth_views[v], cams[:, v], cams[:, ref_id]))
+        where.append([len(jobs) - 1, None])
+        if _hull_view(ref_id) != v:
+            jobs.append((depth_views[v], cams[:, _hull_view(ref_id)], cams[:, ref_id]))
+            where[-1][1] = len(jobs) - 1
+    trans = transform_depth_batch(jobs)
     for b, v in enumerate(sources):
         view_cam = cams[:, v]
         hull_cam = view_cam if _hull_view(ref_id) == v else cams[:, _hull_view(ref_id)]
+        tr = (trans[where[b][0]], trans[where[b][1]] if where[b][1] is not None else None)
         _refinement_volumes(b, bufs, depth_ref, depth_views[v], cams[:, ref_id], view_cam, hull_cam,
                             shallow[si(ref_id):si(ref_id) + 1], shallow[si(v):si(v) + 1], D, ds, di, depth_start,
-                            depth_interval, hom, ((ref_id, v), (ref_id, _hull_view(ref_id))))
+                            depth_interval, hom, ((ref_id, v), (ref_id, _hull_view(ref_id))), tr)
     pv = ops.stack([prob_vol[0].unsqueeze(-1)] * S, 0) if S > 1 else prob_vol.unsqueeze(-1)      # the shared volume, once per sample
     return _refine_net(bufs, pv, chan, True)
 

@@ -737,9 +737,19 @@ __device__ __forceinline__ float block_max_1024(float v, float* sm) {
 
 // A thread keeps its (up to 32) pixels in registers: the loads are issued back to back (ONE memory round trip instead of one per
 // pixel and pass: 26 -> .. us at 20,480 pixels), the transformed depths are computed once.
-__global__ __launch_bounds__(1024) void transform_depth_small_kernel(const float* __restrict__ depth, const float* __restrict__ left_cam,
-                                                                     const float* __restrict__ right_cam, float* __restrict__ out,
-                                                                     int h, int w, int inverse_depth) {
+// Several maps per launch (workgroup = map): the refinement transforms the depth map of every source view into the reference camera
+// and into the hull camera (model.py:289,321-324: 7 maps of configs[2]) -- one launch instead of one per map.
+struct TdJobs {
+  const float* depth[16];
+  const float* left_cam[16];
+  const float* right_cam[16];
+  float* out[16];
+};
+__global__ __launch_bounds__(1024) void transform_depth_small_kernel(TdJobs jobs, int h, int w, int inverse_depth) {
+  const float* __restrict__ depth = jobs.depth[blockIdx.x];
+  const float* __restrict__ left_cam = jobs.left_cam[blockIdx.x];
+  const float* __restrict__ right_cam = jobs.right_cam[blockIdx.x];
+  float* __restrict__ out = jobs.out[blockIdx.x];
   constexpr int ITEMS = 32;                  // pixels per thread: maps up to 32,768 pixels
   __shared__ float pose[12];
   __shared__ float sm[16];
@@ -805,7 +815,9 @@ extern "C" int atvs_transform_depth(const float* depth, const float* left_cam, c
   hipStream_t s = as_stream(stream);
   long npix = (long)h * w;
   if (npix <= 32 * 1024) {
-    hipLaunchKernelGGL(transform_depth_small_kernel, dim3(1), dim3(1024), 0, s, depth, left_cam, right_cam, out, h, w, inverse_depth);
+    TdJobs jobs;
+    for (int i = 0; i < 16; ++i) { jobs.depth[i] = depth; jobs.left_cam[i] = left_cam; jobs.right_cam[i] = right_cam; jobs.out[i] = out; }
+    hipLaunchKernelGGL(transform_depth_small_kernel, dim3(1), dim3(1024), 0, s, jobs, h, w, inverse_depth);
     ATVS_LAUNCH_CHECK();
     return ATVS_OK;
   }
@@ -813,6 +825,25 @@ extern "C" int atvs_transform_depth(const float* depth, const float* left_cam, c
   hipLaunchKernelGGL(max_kernel, dim3(min(cdiv(npix, 256), 1024)), dim3(256), 0, s, depth, npix, ws14);
   hipLaunchKernelGGL((transform_depth_kernel<0>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, left_cam, right_cam, out, ws14, h, w, inverse_depth);
   hipLaunchKernelGGL((transform_depth_kernel<1>), dim3(cdiv(npix, 256)), dim3(256), 0, s, depth, left_cam, right_cam, out, ws14, h, w, inverse_depth);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
+// n <= 16 maps of one size in ONE launch where a map fits a workgroup (h * w <= 32,768: atvs_transform_depth_batch_supported), the
+// values of n calls of atvs_transform_depth.  depth / left_cam / right_cam / out: HOST arrays of n device pointers.
+extern "C" int atvs_transform_depth_batch_supported(int h, int w) { return (h > 0 && w > 0 && (long)h * w <= 32 * 1024) ? 1 : 0; }
+
+extern "C" int atvs_transform_depth_batch(const float* const* depth, const float* const* left_cam, const float* const* right_cam,
+                                          float* const* out, int n, int h, int w, int inverse_depth, atvs_stream_t stream) {
+  if (!depth || !left_cam || !right_cam || !out) return ATVS_ERR_NULL;
+  if (n <= 0 || n > 16 || !atvs_transform_depth_batch_supported(h, w)) return ATVS_ERR_SHAPE;
+  TdJobs jobs;
+  for (int i = 0; i < 16; ++i) {
+    const int k = i < n ? i : 0;
+    if (!depth[k] || !left_cam[k] || !right_cam[k] || !out[k]) return ATVS_ERR_NULL;
+    jobs.depth[i] = depth[k]; jobs.left_cam[i] = left_cam[k]; jobs.right_cam[i] = right_cam[k]; jobs.out[i] = out[k];
+  }
+  hipLaunchKernelGGL(transform_depth_small_kernel, dim3(n), dim3(1024), 0, as_stream(stream), jobs, h, w, inverse_depth);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

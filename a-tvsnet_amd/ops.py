@@ -314,6 +314,26 @@ def transform_depth(depth, left_cam, right_cam, inverse_depth=True):
     return out
 
 
+def transform_depth_batch(jobs, inverse_depth=True):
+    """transform_depth of several maps of one size: jobs = [(depth (h,w), left_cam, right_cam), ...] -> [(h,w), ...].  One launch
+    per 16 maps where a map fits a workgroup (atvs_transform_depth_batch_supported), else the single-map launches."""
+    if not jobs:
+        return []
+    h, w = jobs[0][0].shape[:2]
+    ok = all(tuple(d.shape[:2]) == (h, w) for d, _, _ in jobs) and not jobs[0][0].is_meta \
+        and bool(_lib.lib().atvs_transform_depth_batch_supported(int(h), int(w)))
+    if not ok or len(jobs) == 1:
+        return [transform_depth(d, lc, rc, inverse_depth) for d, lc, rc in jobs]
+    outs = [_new(d, (h, w)) for d, _, _ in jobs]
+    for lo in range(0, len(jobs), 16):
+        part = jobs[lo:lo + 16]
+        if _dev_ok(*([t for job in part for t in job])):
+            _call('atvs_transform_depth_batch', _ptr_array([d for d, _, _ in part]), _ptr_array([lc for _, lc, _ in part]),
+                  _ptr_array([rc for _, _, rc in part]), _ptr_array(outs[lo:lo + 16]), len(part), int(h), int(w),
+                  int(bool(inverse_depth)), _stream())
+    return outs
+
+
 def absdiff_mask(a, b, mask):
     """|a - b| * mask, a/b (h,w,C), mask (h,w)."""
     out = _new(a, a.shape)

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 39
+#define ATVS_ABI_VERSION 40
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -119,6 +119,12 @@ int atvs_pixel_grids(float* out, int h, int w, atvs_stream_t stream);
 /* transform_depth, homography_warping.py:275-326.  ws14: 14 floats of scratch. */
 int atvs_transform_depth(const float* depth, const float* left_cam, const float* right_cam, float* out,
                          float* ws14, int h, int w, int inverse_depth, atvs_stream_t stream);
+/* n <= 16 maps of one size in one launch (a map per workgroup; h * w <= 32,768: atvs_transform_depth_batch_supported): the values of n
+ * calls of atvs_transform_depth (the refinement transforms every source view's depth map twice, model.py:289,321-324).  The four
+ * arguments are HOST arrays of n device pointers. */
+int atvs_transform_depth_batch_supported(int h, int w);
+int atvs_transform_depth_batch(const float* const* depth, const float* const* left_cam, const float* const* right_cam,
+                               float* const* out, int n, int h, int w, int inverse_depth, atvs_stream_t stream);
 
 /* tf.abs(a - b) * tile(mask): photo_err / geo_err, model.py:310,315.
  * a, b, out (npix, C); mask (npix). */
