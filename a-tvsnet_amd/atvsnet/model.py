@@ -176,8 +176,7 @@ def _refinement_volumes(b, bufs, init_ref, init_view, ref_cam, view_cam, hull_ca
     ops.warp_by_depth_err(dvt, dref.reshape(h, w, 1), rc, vc, dref, geo_const[b], 0, 'nearest', FLAGS.inverse_depth, copy_ref=True)
     pieces = photo_var.dim() == 3            # (B, chan/8, planar_stride): chunk-planar fp16 pieces for the photo stem (ops.photo_pieces_ok)
     ops.warp_planes(vf, Hm, out=photo_var[b], mode=1, ref=rf, planar=pieces, pieces=pieces)    # (D,h,w,chan)
-    ops.geo_ref_planes(dref, ds, di, geo_var[b], 0)
-    ops.warp_planes(dvt, Hm, out=geo_var[b], c_off=1, mode=2, depth_start=ds, depth_interval=di, rep=1)
+    ops.geo_volume(dref, dvt.reshape(h, w), Hm, ds, di, geo_var[b], 0, 1)      # geo_ref | geo_view: one launch, one 8-byte store per voxel
     # get_visual_hull(view_num = 2) (:321-324; homography_warping.py:329-387)
     if hull_cam is view_cam:
         h_hull, vt_hull = Hm, init_view_trans

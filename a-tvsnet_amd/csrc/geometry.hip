@@ -420,6 +420,49 @@ extern "C" int atvs_geo_ref_planes(const float* depth_ref, const float* depth_st
   return ATVS_OK;
 }
 
+// The refinement's geo volume in one launch (model.py:285-300): out[d, pix, c_off] = geo_ref (geo_ref_kernel),
+// out[d, pix, c_off + 1 .. + rep] = (|warp_d(view_depth) - delta_d| / interval / D) * mask (warp_planes_kernel<2, 1>) -- the same
+// operations; with rep = 1 and an even c_off the two channels leave as one 8-byte store.
+__global__ __launch_bounds__(256) void geo_volume_kernel(const float* __restrict__ depth_ref, const float* __restrict__ src,
+                                                         const float* __restrict__ Hmats, const float* __restrict__ depth_start,
+                                                         const float* __restrict__ depth_interval, float* __restrict__ out, int D,
+                                                         int h, int w, int ld, int c_off, int rep) {
+  const int d = blockIdx.y;
+  const long pix = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long npix = (long)h * w;
+  if (pix >= npix) return;
+  const int y = (int)(pix / w), x = (int)(pix % w);
+  float Hm[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) Hm[i] = Hmats[d * 9 + i];
+  float xw, yw;
+  homography_apply(Hm, x, y, &xw, &yw);
+  const Tap4 t = bilinear_taps(xw, yw, h, w);
+  const float v = ((t.wa * src[t.i00] + t.wb * src[t.i01]) + t.wc * src[t.i10]) + t.wd * src[t.i11];
+  const float val = depth_start[0] + (float)d * depth_interval[0];
+  const float g = (fabsf(v - val) / depth_interval[0] / (float)D) * t.valid;
+  const float gr = fabsf(depth_ref[pix] - val) / depth_interval[0] / (float)D;
+  float* o = out + ((size_t)d * npix + pix) * (size_t)ld + c_off;
+  if (rep == 1 && ((ld | c_off) & 1) == 0) {
+    *reinterpret_cast<float2*>(o) = make_float2(gr, g);
+  } else {
+    o[0] = gr;
+    for (int r = 0; r < rep; ++r) o[1 + r] = g;
+  }
+}
+
+extern "C" int atvs_geo_volume(const float* depth_ref, const float* view_depth, const float* homographies,
+                               const float* depth_start, const float* depth_interval, float* out, int D, int h, int w,
+                               int ld_out, int c_off, int rep, atvs_stream_t stream) {
+  if (!depth_ref || !view_depth || !homographies || !depth_start || !depth_interval || !out) return ATVS_ERR_NULL;
+  if (D <= 0 || h <= 0 || w <= 0 || rep < 1 || c_off < 0 || c_off + 1 + rep > ld_out) return ATVS_ERR_SHAPE;
+  const long npix = (long)h * w;
+  hipLaunchKernelGGL(geo_volume_kernel, dim3(cdiv(npix, 256), D), dim3(256), 0, as_stream(stream), depth_ref, view_depth,
+                     homographies, depth_start, depth_interval, out, D, h, w, ld_out, c_off, rep);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+
 // ---------------------------------------------------------------------------
 // Visual hull for two depth maps (homography_warping.py:329-387 with view_num = 2,
 // the only configuration the path uses: model.py:323-324 via :436 / :373):

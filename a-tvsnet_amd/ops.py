@@ -243,6 +243,17 @@ def geo_ref_planes(depth_ref, depth_start, depth_interval, out, c_off):
     return out
 
 
+def geo_volume(depth_ref, view_depth, homographies, depth_start, depth_interval, out, c_off=0, rep=1):
+    """geo_ref_planes(depth_ref) into out[..., c_off] and warp_planes(view_depth, mode=2, rep) into out[..., c_off + 1 ..] as one
+    launch (the refinement's geo volume); out (D,h,w,ld)."""
+    h, w = depth_ref.shape[:2]
+    D, ld = out.shape[0], out.shape[-1]
+    if _dev_ok(depth_ref, view_depth, homographies, depth_start, depth_interval, out):
+        _call('atvs_geo_volume', _p(depth_ref), _p(view_depth), _p(homographies), _p(depth_start), _p(depth_interval), _p(out),
+              D, h, w, ld, int(c_off), int(rep), _stream())
+    return out
+
+
 def visual_hull(ref_depth, view_depth_in_ref, homographies, depth_start, depth_interval, inverse_depth=True, out=None):
     """(h,w) x2 -> (D,h,w) (written into `out` when given)."""
     h, w = ref_depth.shape[:2]

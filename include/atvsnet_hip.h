@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 40
+#define ATVS_ABI_VERSION 41
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -87,6 +87,11 @@ int atvs_tile_planes(const float* src, float* out, int D, int h, int w, int C, i
 /* cost_volume_geo_ref, model.py:289-290: |depth_ref - delta_d| / interval / D into channel c_off. */
 int atvs_geo_ref_planes(const float* depth_ref, const float* depth_start, const float* depth_interval,
                         float* out, int D, int h, int w, int ld_out, int c_off, atvs_stream_t stream);
+/* geo_ref and geo_view of the refinement (model.py:285-300) in one launch: out (D,h,w,ld)[..., c_off] = atvs_geo_ref_planes,
+ * [..., c_off + 1 .. c_off + rep] = atvs_warp_planes(mode 2, rep) of the one-channel map view_depth (h,w) -- the same values. */
+int atvs_geo_volume(const float* depth_ref, const float* view_depth, const float* homographies, const float* depth_start,
+                    const float* depth_interval, float* out, int D, int h, int w, int ld_out, int c_off, int rep,
+                    atvs_stream_t stream);
 
 /* get_visual_hull with view_num = 2, homography_warping.py:329-387: out (D,h,w).
  * view_depth_in_ref = transform_depth(view depth, view_cam, ref_cam). */
