@@ -152,12 +152,9 @@ def _infer_multiview_batched(images, cams, max_d, stages, out_prob_map):
     del filtered
     # refinement of every source against the aggregated estimate
     shallow = shallow_feature_batch(images)
-    cost_residual, _ = refinement_batch(depth_agg_init, depth_view, prob_volume_agg, cams, max_d, depth_start,
-                                        depth_interval, src, shallow, hom=hom)
-    refined = torch.empty_like(cost_residual)
-    for b in range(len(src)):                                   # refined_cost = filtered_cost + residual (model.py:438)
-        ops.add_n([cost_volume_agg[0], cost_residual[b]], out=refined[b])
-    del cost_residual
+    # refined_cost = filtered_cost + residual (model.py:438) of every source: formed by the pass that forms the residuals
+    _, _, refined = refinement_batch(depth_agg_init, depth_view, prob_volume_agg, cams, max_d, depth_start, depth_interval, src,
+                                     shallow, hom=hom, residual_base=cost_volume_agg)
     # AAM2
     refined_cost_volume_agg = cost_volume_aggregation_refine(refined, reuse=False, keepchannel=True)
     refined_prob_volume_agg = output_conv_refine(refined_cost_volume_agg, reuse=False)

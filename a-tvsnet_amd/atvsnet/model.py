@@ -197,7 +197,7 @@ def _hull_view(ref_id):
     return ids[1]
 
 
-def _refine_net(bufs, prob_vol, chan, independent):
+def _refine_net(bufs, prob_vol, chan, independent, residual_base=None):
     photo_var, photo_const, geo_var, geo_const, hull = bufs
     cmap = [('v', i) for i in range(chan)] + [('c', i) for i in range(2 * chan)]
     if photo_var.dim() == 3:
@@ -205,9 +205,14 @@ def _refine_net(bufs, prob_vol, chan, independent):
     else:
         photo = ops.SplitVolume(photo_var, photo_const, cmap)
     geo = ops.SplitVolume(geo_var, geo_const, [('v', 0)] + [('v', 1)] * chan + [('c', 0), ('c', 1)])
-    tower = CostVolRefineNet({'photo_group': photo, 'geo_group': geo, 'prob_vol': prob_vol, 'vis_hull': hull},
-                             is_training=True, reuse=AUTO_REUSE, independent_samples=independent)
-    return tower.get_output_by_name('global_refine_3dconv6_1'), tower.get_output().squeeze(-1)
+    inputs = {'photo_group': photo, 'geo_group': geo, 'prob_vol': prob_vol, 'vis_hull': hull}
+    if residual_base is not None:
+        inputs['residual_base'] = residual_base
+    tower = CostVolRefineNet(inputs, is_training=True, reuse=AUTO_REUSE, independent_samples=independent)
+    out = (tower.get_output_by_name('global_refine_3dconv6_1'), tower.get_output().squeeze(-1))
+    if residual_base is not None:
+        out += (tower.get_output_by_name('global_refine_3dconv6_1_plus'),)
+    return out
 
 
 def _refinement_buffers(B, D, h, w, chan, like):
@@ -249,13 +254,15 @@ def refinement(init_depth_images, cams, depth_num, depth_start, depth_interval, 
 
 
 def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_start, depth_interval, sources,
-                     shallow, ref_id=0, shallow_index=None, hom=None):
+                     shallow, ref_id=0, shallow_index=None, hom=None, residual_base=None):
     """`refinement` of several source views against one reference estimate in ONE pass of the network
     (the reference calls it once per source, example.py:163-172): depth_ref (1,h,w,1), depth_views {source: (1,h,w,1)},
     prob_vol (1,D,h,w) shared, shallow (N,h,w,16) features of every view (shallow_index: {view id: row of shallow} when
     it holds a subset) -> (cost residuals (S,D,h,w,8), prob residuals (S,D,h,w)), S = len(sources), each sample with
     its own batch statistics.  cams are indexed by the view ids themselves.  hom: the depth map's homography cache
-    (_cached_homographies), e.g. the one base_stage_batch filled."""
+    (_cached_homographies), e.g. the one base_stage_batch filled.  residual_base (1,D,h,w,8): the cost volume the residuals are
+    added to (TVSNet_refine, reference :439) -- a third result, residual_base + cost residual (S,D,h,w,8), then comes out of the
+    pass that forms the residuals."""
     si = (lambda v: v) if shallow_index is None else (lambda v: shallow_index[v])
     D = int(depth_num)
     S = len(sources)
@@ -280,7 +287,7 @@ def refinement_batch(depth_ref, depth_views, prob_vol, cams, depth_num, depth_st
                             shallow[si(ref_id):si(ref_id) + 1], shallow[si(v):si(v) + 1], D, ds, di, depth_start,
                             depth_interval, hom, ((ref_id, v), (ref_id, _hull_view(ref_id))), tr)
     pv = ops.stack([prob_vol[0].unsqueeze(-1)] * S, 0) if S > 1 else prob_vol.unsqueeze(-1)      # the shared volume, once per sample
-    return _refine_net(bufs, pv, chan, True)
+    return _refine_net(bufs, pv, chan, True, residual_base)
 
 
 def feature_extraction_batch(images):

@@ -182,6 +182,8 @@ class CostVolRefineNet(Network):
         (self.feed(g + '3dconv5_0', g + '3dconv1_1')
              .add(name=g + '3dconv5_1', defer=True)          # summed on load by the transposed convolution
              .deconv_bn(3, f, 2, name=g + '3dconv6_0', defer_bn=True))
+        # extension: with an input 'residual_base' (the aggregated cost volume every source's residual is added to, model.py:438)
+        # the layer global_refine_3dconv6_1_plus = residual_base + global_refine_3dconv6_1 comes out of the same pass
         (self.feed(g + '3dconv6_0', g + '3dconv0_1')
-             .add(name=g + '3dconv6_1')
+             .add(name=g + '3dconv6_1', plus=('residual_base' if 'residual_base' in self.layers else None))
              .conv(3, 1, 1, relu=False, name='global_refined_cost_vol'))

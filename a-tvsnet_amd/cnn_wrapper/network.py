@@ -587,18 +587,33 @@ class Network(object):
         return ops.concat_channels([self._bt(t, name) for t in inputs])
 
     @layer
-    def add(self, inputs, name, defer=False):
+    def add(self, inputs, name, defer=False, plus=None):
         '''tf.add_n (reference network.py:695-697).  Inputs whose batch norm is still pending (conv_bn /
         deconv_bn with defer_bn=True) are normalised inside the add kernel.  defer=True (extension): a sum of two or three
-        whose consumer can add on load (conv_bn_siblings, deconv_bn) is handed over unformed.'''
+        whose consumer can add on load (conv_bn_siblings, deconv_bn) is handed over unformed.  plus (extension): the name of an
+        input layer holding ONE sample; the layer `name + '_plus'` = that sample + this sum (per sample of the sum) is formed in
+        the same pass where the add kernel runs, else by add_n per sample.'''
         inputs = [t.materialize() if isinstance(t, (ops.PendingSum, ops.LazySlice)) else t for t in inputs]
-        if defer and self.training and len(inputs) in (2, 3) and all(t.dim() == 5 for t in inputs):
+        if defer and plus is None and self.training and len(inputs) in (2, 3) and all(t.dim() == 5 for t in inputs):
             return ops.PendingSum([t if isinstance(t, ops.PendingBN) else self._bt(t, name) for t in inputs])
+        base = None
+        if plus is not None:
+            base = self.layers[plus]
+            base = (base[0] if base.dim() == inputs[0].dim() else base).contiguous()
         if len(inputs) in (2, 3) and any(isinstance(t, ops.PendingBN) for t in inputs) \
                 and inputs[0].shape[-1] % 4 == 0:
             items = [t if isinstance(t, ops.PendingBN) else self._bt(t, name) for t in inputs]
-            return ops.bn_add(items)
-        return ops.add_n([self._bt(t, name) for t in inputs])
+            if base is None:
+                return ops.bn_add(items)
+            y, self.layers[name + '_plus'] = ops.bn_add(items, plus=base)
+            return y
+        y = ops.add_n([self._bt(t, name) for t in inputs])
+        if base is not None:
+            y2 = torch.empty_like(y)
+            for b in range(y.shape[0]):
+                ops.add_n([base, y[b]], out=y2[b])
+            self.layers[name + '_plus'] = y2
+        return y
 
     def attention_activation(self, input, kernel_size, name, filters=None, second_weight=False, relu=True,
                              padding=DEFAULT_PADDING, biased=False, n_view=None):

@@ -190,7 +190,8 @@ __global__ __launch_bounds__(256) void bn_add_kernel(const float* __restrict__ x
                                                      const float* __restrict__ x1, const float* __restrict__ p1,
                                                      const float* __restrict__ x2, const float* __restrict__ p2,
                                                      float* __restrict__ y, long n, int C, int relu_mask,
-                                                     long group_n) {
+                                                     long group_n, const float* __restrict__ base = nullptr,
+                                                     float* __restrict__ y2 = nullptr) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i >= n) return;
   int c = (int)(i % C);
@@ -217,6 +218,11 @@ __global__ __launch_bounds__(256) void bn_add_kernel(const float* __restrict__ x
     a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
   }
   st4_stream(y + i, a);
+  if (y2) {                                  // y2 = base + y, base one sample shared by all (atvs_add_n's arithmetic)
+    float4 u = ld4(base + i % group_n);
+    u.x += a.x; u.y += a.y; u.z += a.z; u.w += a.w;
+    st4_stream(y2 + i, u);
+  }
 }
 
 extern "C" int atvs_bn_add(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
@@ -230,3 +236,20 @@ extern "C" int atvs_bn_add(const float* x0, const float* params0, const float* x
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }
+
+// atvs_bn_add that ALSO writes y2 = base + y, base (rows, C) ONE sample shared by the `groups` samples: the refinement's last skip
+// add global_refine_3dconv6_1 (the cost residual, read by the 8 -> 1 head) together with refined_cost = filtered_cost +
+// cost_residual (model.py:438) of every source view -- one pass instead of the add and a tf.add_n per view.  y and y2: the bits of
+// atvs_bn_add and atvs_add_n(base, y).
+extern "C" int atvs_bn_add_plus(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
+                                const float* params2, float* y, const float* base, float* y2, int groups, long rows, int C,
+                                int relu_mask, atvs_stream_t stream) {
+  if (!x0 || !x1 || !y || !base || !y2) return ATVS_ERR_NULL;
+  if (groups <= 0 || rows <= 0 || C <= 0 || (C % 4) != 0) return ATVS_ERR_SHAPE;
+  long n = (long)groups * rows * C;
+  hipLaunchKernelGGL(bn_add_kernel, dim3(cdiv(n / 4, 256)), dim3(256), 0, as_stream(stream), x0, params0, x1, params1, x2,
+                     params2, y, n, C, relu_mask, rows * C, base, y2);
+  ATVS_LAUNCH_CHECK();
+  return ATVS_OK;
+}
+

@@ -2227,8 +2227,9 @@ def siblings_prologue_ok(src):
     return False
 
 
-def bn_add(items):
-    """Sum of 2 or 3 items, each a dense tensor or a PendingBN (normalised on the fly); dims without batch."""
+def bn_add(items, plus=None):
+    """Sum of 2 or 3 items, each a dense tensor or a PendingBN (normalised on the fly); dims without batch.
+    plus: ONE sample (the items' shape without the leading axis) -> (sum, plus + sum) from the same pass."""
     xs, ps, mask = [], [], 0
     for i, it in enumerate(items):
         if isinstance(it, PendingBN) and it._final is None and not it.planar:
@@ -2245,8 +2246,16 @@ def bn_add(items):
     if len(gs) != 1:
         raise ValueError('bn_add: the pending batch norms disagree on the number of independent samples')
     G = gs.pop()
+    x2, p2 = (xs[2], ps[2]) if len(xs) > 2 else (None, None)
+    if plus is not None:
+        if tuple(plus.shape) != tuple(out.shape[1:]) or out.shape[0] != G or not plus.is_contiguous():
+            raise ValueError('bn_add: plus must be one contiguous sample of the items')
+        out2 = _new(out, out.shape)
+        if _dev_ok(*(xs + [p for p in ps if p is not None] + [plus])):
+            _call('atvs_bn_add_plus', _p(xs[0]), _p(ps[0]), _p(xs[1]), _p(ps[1]), _p(x2), _p(p2), _p(out), _p(plus), _p(out2), G,
+                  ctypes.c_long(out.numel() // C // G), C, int(mask), _stream())
+        return out, out2
     if _dev_ok(*(xs + [p for p in ps if p is not None])):
-        x2, p2 = (xs[2], ps[2]) if len(xs) > 2 else (None, None)
         _call('atvs_bn_add', _p(xs[0]), _p(ps[0]), _p(xs[1]), _p(ps[1]), _p(x2), _p(p2), _p(out), G,
               ctypes.c_long(out.numel() // C // G), C, int(mask), _stream())
     return out

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 41
+#define ATVS_ABI_VERSION 42
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -539,6 +539,12 @@ int atvs_bn_apply(const float* x, const float* params, float* y, int groups, lon
  * for an already-final tensor; x2 may be NULL.  C % 4 == 0; rows per sample.  (network.py:172-215 + :695-697 fused.) */
 int atvs_bn_add(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
                 const float* params2, float* y, int groups, long rows, int C, int relu_mask, atvs_stream_t stream);
+/* atvs_bn_add that also writes y2 = base + y, base (rows,C) ONE sample shared by the `groups` samples (global_refine_3dconv6_1 and
+ * refined_cost = filtered_cost + cost_residual of every source view, model.py:438, in one pass): y / y2 bit for bit atvs_bn_add /
+ * atvs_add_n(base, y). */
+int atvs_bn_add_plus(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
+                     const float* params2, float* y, const float* base, float* y2, int groups, long rows, int C, int relu_mask,
+                     atvs_stream_t stream);
 
 /* tf.add_n of two or three tensors (c may be NULL), network.py:695-697. */
 int atvs_add_n(const float* a, const float* b, const float* c, float* y, long n, atvs_stream_t stream);

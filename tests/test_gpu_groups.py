@@ -589,6 +589,20 @@ def test_conv_c16b_sums_its_inputs_on_load_bitwise(cuda, G, shape, forms):
     assert torch.equal(ref, want)
 
 
+@pytest.mark.parametrize('G,shape', [(4, (6, 10, 20)), (1, (5, 7, 9)), (3, (4, 4, 16))])
+def test_skip_add_with_the_residual_base_in_one_pass_bitwise(cuda, G, shape):
+    """global_refine_3dconv6_1 (two pending batch norms) and refined_cost = filtered_cost + cost_residual of every source view
+    (reference atvsnet/model.py:438-439) from ONE pass (atvs_bn_add_plus) -- the bits of bn_add and of add_n per sample."""
+    from atvsnet_amd import ops
+    items = [_pending_seeded(G, shape, 8, 300 + 100 * k, True, cuda) for k in range(2)]
+    base = _rand(shape + (8,), 9).to(cuda)
+    y, y2 = ops.bn_add(items, plus=base)
+    want = ops.bn_add([_pending_seeded(G, shape, 8, 300 + 100 * k, True, cuda) for k in range(2)])
+    assert torch.equal(y, want)
+    for g in range(G):
+        assert torch.equal(y2[g], ops.add_n([base, want[g]]))
+
+
 @pytest.mark.parametrize('nv,shape', [(4, (16, 24, 40)), (2, (9, 13, 35)), (3, (4, 8, 16)), (1, (6, 10, 20)), (4, (5, 9, 17))])
 def test_aanet_module_in_one_launch_bitwise(cuda, weights, nv, shape):
     """aanet_b.hip: the shared | unique score convolutions of every view and the cross-view softmax + weighted sum (reference
