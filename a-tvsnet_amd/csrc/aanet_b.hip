@@ -43,7 +43,6 @@ struct AbArgs {
   const unsigned char* wp;     // atvs_aanet_b_pack
   const float* zeros;
   float* out;                  // (D,H,W,8)
-  int nv;
   int Di, Hi, Wi;
   int tiles_y, tiles_x, ntiles;
   int wg;
@@ -156,8 +155,9 @@ __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
   }
 
   for (int k = 0; k < my_tiles; ++k) {
-    // a run-time loop over the views (unrolled at compile time -- [S|R] into static register slots, no selects -- the launch
-    // was SLOWER: 663 instead of 628 us, four copies of the stage body)
+    // the views as a ROLLED loop (unrolled -- [S|R] into static register slots, no selects -- the launch was SLOWER: 663 instead
+    // of 628 us, four copies of the stage body)
+#pragma unroll 1
     for (int v = 0; v < NV; ++v) {
 #pragma unroll
       for (int t = 0; t < TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -352,7 +352,7 @@ extern "C" int atvs_aanet_b_f32(const float* const* x, int nv, const unsigned ch
   long pb;
   atvs_aanet_b_pack_size(&pb);
   a.wp = packed_w; a.zeros = reinterpret_cast<const float*>(packed_w + (pb - 16));
-  a.out = out; a.nv = nv;
+  a.out = out;
   a.Di = D; a.Hi = H; a.Wi = W;
   a.tiles_y = (H + AB_TY - 1) / AB_TY; a.tiles_x = (W + AB_TX - 1) / AB_TX;
   a.ntiles = ((D + AB_TZ - 1) / AB_TZ) * a.tiles_y * a.tiles_x;
