@@ -79,9 +79,38 @@ struct UpB {
     return n;
   }
   static constexpr int NSTEP = first_step(NG);
-  static constexpr int WCH = NSTEP * UB_NP * 1024;     // bytes of packed weights per chunk
+  static constexpr int WCH = NSTEP * UB_NP * 1024;     // bytes of packed weights per chunk (global memory: 1 KB per step and piece)
+  // In LDS the steps of the odd-px tiles of the 16-channel form keep only lanes 0..31: lane groups q = 2, 3 carry the x offset
+  // whose tap is a structural zero for px = 1 (kw < 0 in pack_upb) -- those lanes read one shared line of zeros instead.
+  // 27 KB instead of 36 KB per chunk: the two chunks of the 32 -> 16 layers (conv_b*_5_0) stay RESIDENT beside the images with
+  // two workgroups per CU (70 KB each); streamed (round 4) the copy of a chunk was 41 % of a stage (tools_dev/phase_ub.py).
+  static constexpr int tile_of_step(int s) {
+    int g = 0;
+    while (g + 1 < NG && first_step(g + 1) <= s) ++g;
+    return tile(g, s - first_step(g));
+  }
+  static constexpr bool half_step(int s) { return COUT == 16 && (tile_of_step(s) & 1) != 0; }
+  static constexpr int step_bytes(int s) { return half_step(s) ? 512 : 1024; }      // per piece
+  static constexpr int woff(int s, int piece) {        // LDS byte offset of (step, piece) inside a chunk
+    int o = 0;
+    for (int k = 0; k < s; ++k) o += UB_NP * step_bytes(k);
+    return o + piece * step_bytes(s);
+  }
+  static constexpr int WLDS = woff(NSTEP, 0);          // bytes of a chunk's weights in LDS
+  // the same as closed forms for run-time step indices (the copy loop): the half steps of the 16-channel form are the odd ones
+  __host__ __device__ static constexpr int lanes_rt(int s) { return (COUT == 16 && (s & 1)) ? 32 : 64; }
+  __host__ __device__ static constexpr int woff_rt(int s, int piece) {
+    return COUT == 8 ? (s * UB_NP + piece) * 1024 : (s >> 1) * 3072 + ((s & 1) ? 2048 + piece * 512 : piece * 1024);
+  }
+  static constexpr bool closed_forms_ok() {
+    for (int s = 0; s < NSTEP; ++s)
+      for (int pc = 0; pc < UB_NP; ++pc)
+        if (woff_rt(s, pc) != woff(s, pc) || lanes_rt(s) * 16 != step_bytes(s)) return false;
+    return true;
+  }
 };
 static_assert(UpB<8>::NSTEP == 9 && UpB<16>::NSTEP == 18, "(tile, oz, oy) steps");
+static_assert(UpB<8>::closed_forms_ok() && UpB<16>::closed_forms_ok(), "closed forms of the LDS weight layout");
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -140,14 +169,32 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
 #endif
 
   // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
-  if (!STREAMW) {
-    const float4* src = reinterpret_cast<const float4*>(p.wp);
-    float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
-    for (int i = tid; i < p.nchunk * (U::WCH / 16); i += 256) dst[i] = src[i];
-  }
+  // (step, piece) blocks of 64 lanes x 16 bytes in global memory -> 64 or 32 lanes in LDS (U::woff; for the 16-channel form the
+  // half steps are the odd ones: U::woff_rt, checked against U::woff at compile time).  Wavefront w copies the blocks w, w + 4, ...
+  auto copy_chunk = [&](int ch, int lds_chunk) __attribute__((always_inline)) {
+    const float4* src = reinterpret_cast<const float4*>(p.wp + (size_t)ch * U::WCH);
+    unsigned char* dstb = smem + UB_NP * U::IMG + lds_chunk * U::WLDS;
+    for (int sp = wave; sp < U::NSTEP * UB_NP; sp += 4) {
+      const int st = sp / UB_NP, pc = sp % UB_NP;
+      if (lane < U::lanes_rt(st)) reinterpret_cast<float4*>(dstb + U::woff_rt(st, pc))[lane] = src[sp * 64 + lane];
+    }
+  };
+  if (!STREAMW)
+    for (int ch = 0; ch < p.nchunk; ++ch) copy_chunk(ch, ch);
+  // the line of zeros the dropped lanes read (behind the last chunk's weights)
+  const int wzero = UB_NP * U::IMG + p.nchunk * U::WLDS;
+  if (!STREAMW && tid == 0) *reinterpret_cast<float4*>(smem + wzero) = make_float4(0.f, 0.f, 0.f, 0.f);
   // this lane's fragment at halo voxel (wave, 0, r + 1 - ox), ox = q >> 1: offset (-1, -1, ox) of row 0 of the wavefront's plane
   const int fbase = ((wave * HY) * UB_HX + r + 1 - (q >> 1)) * UB_VB + (q & 1) * 16;
-  const int wbase = UB_NP * U::IMG + lane * 16;
+  // LDS address of this lane's weight fragment of (step, piece) of the chunk at wb: its own 16 bytes, or the zero line for the
+  // dropped lanes of a half step
+  const int lane16 = lane * 16;
+  auto wfrag = [&](int wb, auto ST, auto PC) __attribute__((always_inline)) {
+    constexpr int st = decltype(ST)::value, pc = decltype(PC)::value;
+    if constexpr (STREAMW) return wb + (st * UB_NP + pc) * 1024 + lane16;         // streamed: the global layout, 1 KB per block
+    else if constexpr (U::half_step(st)) return (lane < 32) ? wb + U::woff(st, pc) + lane16 : wzero;
+    else return wb + U::woff(st, pc) + lane16;
+  };
 
   int goff[MAXS], laddr[MAXS];
   unsigned pg[MAXS];
@@ -291,7 +338,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     }
     __syncthreads();                       // every wavefront is done reading the previous stage's images (and weights)
     UDBG(1)
-    if (STREAMW) {
+    if (STREAMW) {                           // (the streamed form keeps the global layout: whole 1 KB blocks)
       const float4* src = reinterpret_cast<const float4*>(p.wp + (size_t)ch * U::WCH);
       float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
       for (int i = tid; i < U::WCH / 16; i += 256) dst[i] = src[i];
@@ -315,7 +362,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     UDBG(3)
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
-    const int wb = wbase + (STREAMW ? 0 : ch * U::WCH);
+    const int wb = UB_NP * U::IMG + (STREAMW ? 0 : ch * U::WLDS);      // this chunk's weights in LDS (streamed: the one chunk)
 
     // ---- K loop: groups of tiles sharing (oz, oy), two phases each: input piece h0 with the weight pieces g0 (main) and g1
     // (cross), then h1 with g0 (cross)
@@ -333,14 +380,14 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
       constexpr int g = decltype(GT)::value;
       ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
         constexpr int i = decltype(IT)::value;
-        A0[g & 1][i] = *reinterpret_cast<const f16x8*>(smem + wb + ((U::first_step(g) + i) * UB_NP + 0) * 1024);
+        A0[g & 1][i] = *reinterpret_cast<const f16x8*>(smem + wfrag(wb, IC<U::first_step(g) + i>{}, IC<0>{}));
       });
     };
     auto request_A1 = [&](auto GT) __attribute__((always_inline)) {
       constexpr int g = decltype(GT)::value;
       ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
         constexpr int i = decltype(IT)::value;
-        A1[i] = *reinterpret_cast<const f16x8*>(smem + wb + ((U::first_step(g) + i) * UB_NP + 1) * 1024);
+        A1[i] = *reinterpret_cast<const f16x8*>(smem + wfrag(wb, IC<U::first_step(g) + i>{}, IC<1>{}));
       });
     };
     request_A0(IC<0>{});
@@ -478,13 +525,15 @@ bool ub_put(uint16_t* out, size_t base, float v) {
   return back - back == 0.f;                             // finite
 }
 
-size_t ub_lds(int Cin, int Cout) {
-  return Cout == 8 ? UB_NP * (size_t)UpB<8>::IMG + (size_t)(Cin / 16) * UpB<8>::WCH
-                   : UB_NP * (size_t)UpB<16>::IMG + (size_t)(Cin / 16) * UpB<16>::WCH;
+size_t ub_lds(int Cin, int Cout) {      // images + all chunks' weights + the zero line
+  return (Cout == 8 ? UB_NP * (size_t)UpB<8>::IMG + (size_t)(Cin / 16) * UpB<8>::WLDS
+                    : UB_NP * (size_t)UpB<16>::IMG + (size_t)(Cin / 16) * UpB<16>::WLDS) + 16;
 }
-// Cout 16: all chunks resident only while TWO workgroups still fit the CU's 160 KB (one chunk: 52 KB) -- with two chunks resident
-// (88 KB, the 32 -> 16 layer) one workgroup ran per CU whatever __launch_bounds__ says (measured: the second half of the grid
-// started when the first had finished); else one chunk at a time, re-read from L2 at every stage (~500 cycles of a ~6,000 cycle stage)
+// Cout 16: all chunks resident only while TWO workgroups still fit the CU's 160 KB -- with 88 KB (two chunks of whole 1 KB
+// blocks, the 32 -> 16 layer until round 5) one workgroup ran per CU whatever __launch_bounds__ says (measured: the second half
+// of the grid started when the first had finished).  The 32 -> 16 layers now keep both chunks resident in the compact layout
+// (UpB::woff: 70 KB with the images; phase timers: the per-stage copy of a chunk had been 4.4 k of a 10.8 k-cycle stage, 0.7 k
+// now); more input channels: one chunk at a time, whole blocks, re-read from L2 at every stage
 #ifndef ATVS_UB_RESIDENT_MAX
 #define ATVS_UB_RESIDENT_MAX (80 * 1024)
 #endif
