@@ -150,14 +150,16 @@ __device__ __forceinline__ void ub_static_for(F&& f) {
   ub_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-// STREAMW: the packed weights of ONE chunk live in LDS and are re-read from L2 at every stage (Cin too large for all chunks to
-// stay resident: the 64 -> 32 layer as two 16-channel launches)
+// STREAMW: Cin too large for all chunks to stay resident (the 64 -> 32 layers as two 16-channel launches): TWO weight buffers of
+// one chunk each (compact layout, 2 x 27 KB: two workgroups per CU still fit), the NEXT stage's chunk fetched by LDS-DMA
+// (global_load ... lds: no registers) while this stage's K loop runs.  (Round 4: one buffer, copied through registers between
+// the barriers of every stage -- 3.8 k of an 8.3 k-cycle stage, tools_dev/phase_ub.py.)
 // PRO: the skip sum formed on load (Cin = 16: one chunk; one workgroup per CU -- the three sources of a stage are in flight in
 // 84 registers, which two workgroups per CU do not have)
 template <int COUT, bool STREAMW, bool PRO>
 __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(UpBArgs p) {
   using U = UpB<COUT>;
-  constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
+  constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG, WCH = U::WCH;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -168,6 +170,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
   const unsigned long long dbg_w0 = wall_clock64();
 #endif
 
+  const int lane16_ = lane * 16;
   // packed weights of every chunk -> LDS, once (visible after the first stage's barriers)
   // (step, piece) blocks of 64 lanes x 16 bytes in global memory -> 64 or 32 lanes in LDS (U::woff; for the 16-channel form the
   // half steps are the odd ones: U::woff_rt, checked against U::woff at compile time).  Wavefront w copies the blocks w, w + 4, ...
@@ -179,11 +182,27 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
       if (lane < U::lanes_rt(st)) reinterpret_cast<float4*>(dstb + U::woff_rt(st, pc))[lane] = src[sp * 64 + lane];
     }
   };
+  // the same copy by LDS-DMA into weight buffer `buf` (asynchronous: complete after the issuing wavefront's s_waitcnt vmcnt(0))
+  // (a buffer descriptor over the packed weights: the per-lane part of the address is lane * 16 for every block, the rest scalar)
+  const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(p.wp), 0, p.nchunk * WCH, 0x00020000);
+  auto dma_chunk = [&](int ch, int buf) __attribute__((always_inline)) {
+    unsigned char* dstb = smem + UB_NP * U::IMG + buf * U::WLDS;
+    for (int sp = wave; sp < U::NSTEP * UB_NP; sp += 4) {
+      const int st = sp / UB_NP, pc = sp % UB_NP;
+      if (lane < U::lanes_rt(st))
+        // (WCH: a local constant -- with U::WCH inside this argument list the HOST pass of hipcc 7.2 emits no stub for the kernel,
+        // without a diagnostic: the library then fails to load with an undefined symbol)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (void __attribute__((address_space(3)))*)(dstb + U::woff_rt(st, pc)), 16, lane16_,
+                                                 ch * WCH + sp * 1024, 0, 0);
+    }
+  };
   if (!STREAMW)
     for (int ch = 0; ch < p.nchunk; ++ch) copy_chunk(ch, ch);
-  // the line of zeros the dropped lanes read (behind the last chunk's weights)
-  const int wzero = UB_NP * U::IMG + p.nchunk * U::WLDS;
-  if (!STREAMW && tid == 0) *reinterpret_cast<float4*>(smem + wzero) = make_float4(0.f, 0.f, 0.f, 0.f);
+  else
+    dma_chunk(0, 0);
+  // the line of zeros the dropped lanes read (behind the weights)
+  const int wzero = UB_NP * U::IMG + (STREAMW ? 2 : p.nchunk) * U::WLDS;
+  if (tid == 0) *reinterpret_cast<float4*>(smem + wzero) = make_float4(0.f, 0.f, 0.f, 0.f);
   // this lane's fragment at halo voxel (wave, 0, r + 1 - ox), ox = q >> 1: offset (-1, -1, ox) of row 0 of the wavefront's plane
   const int fbase = ((wave * HY) * UB_HX + r + 1 - (q >> 1)) * UB_VB + (q & 1) * 16;
   // LDS address of this lane's weight fragment of (step, piece) of the chunk at wb: its own 16 bytes, or the zero line for the
@@ -191,8 +210,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
   const int lane16 = lane * 16;
   auto wfrag = [&](int wb, auto ST, auto PC) __attribute__((always_inline)) {
     constexpr int st = decltype(ST)::value, pc = decltype(PC)::value;
-    if constexpr (STREAMW) return wb + (st * UB_NP + pc) * 1024 + lane16;         // streamed: the global layout, 1 KB per block
-    else if constexpr (U::half_step(st)) return (lane < 32) ? wb + U::woff(st, pc) + lane16 : wzero;
+    if constexpr (U::half_step(st)) return (lane < 32) ? wb + U::woff(st, pc) + lane16 : wzero;
     else return wb + U::woff(st, pc) + lane16;
   };
 
@@ -338,11 +356,6 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     }
     __syncthreads();                       // every wavefront is done reading the previous stage's images (and weights)
     UDBG(1)
-    if (STREAMW) {                           // (the streamed form keeps the global layout: whole 1 KB blocks)
-      const float4* src = reinterpret_cast<const float4*>(p.wp + (size_t)ch * U::WCH);
-      float4* dst = reinterpret_cast<float4*>(smem + UB_NP * U::IMG);
-      for (int i = tid; i < U::WCH / 16; i += 256) dst[i] = src[i];
-    }
 #pragma unroll
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) {
@@ -358,11 +371,15 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         *reinterpret_cast<uint2*>(smem + U::IMG + laddr[i]) = p1;
       }
     UDBG(2)
+    if (STREAMW) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wavefront's share of the stage's weights has landed
     __syncthreads();
     UDBG(3)
 
     const PfTile T = pf_tile(min(stage + 1, nstage - 1));      // last stage: harmless re-read of its own halo
-    const int wb = UB_NP * U::IMG + (STREAMW ? 0 : ch * U::WLDS);      // this chunk's weights in LDS (streamed: the one chunk)
+    // this chunk's weights in LDS; streamed: buffer stage & 1, and the next stage's chunk on its way into the other one (free:
+    // every wavefront has left the K loop that read it)
+    const int wb = UB_NP * U::IMG + (STREAMW ? (stage & 1) : ch) * U::WLDS;
+    if (STREAMW && stage + 1 < nstage) dma_chunk(ch + 1 == p.nchunk ? 0 : ch + 1, (stage + 1) & 1);
 
     // ---- K loop: groups of tiles sharing (oz, oy), two phases each: input piece h0 with the weight pieces g0 (main) and g1
     // (cross), then h1 with g0 (cross)
@@ -686,7 +703,7 @@ int upb_launch(const float* x, const float* x2, const float* x3, const float* pa
   if (blocks * groups > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipStream_t st = as_stream(stream);
   const bool stream_w = ub_stream(Cin, Cout);
-  const size_t lds = stream_w ? UB_NP * (size_t)UpB<16>::IMG + UpB<16>::WCH : ub_lds(Cin, Cout);
+  const size_t lds = stream_w ? UB_NP * (size_t)UpB<16>::IMG + 2 * (size_t)UpB<16>::WLDS + 16 : ub_lds(Cin, Cout);
   int rc = pro ? launch_upb<8, false, true>(a, blocks * groups, lds, st)
                : (Cout == 8) ? launch_upb<8, false>(a, blocks * groups, lds, st)
                              : stream_w ? launch_upb<16, true>(a, blocks * groups, lds, st) : launch_upb<16, false>(a, blocks * groups, lds, st);
