@@ -42,3 +42,5 @@ for _ in range(20):
 torch.cuda.synchronize()
 r = bench.power_probe(run, secs)
 print(which, r if r is None else {k: v for k, v in r.items() if k != 'note'})
+if r is not None:       # (eager launches incl. the moments' finalize: ms_per_step is an upper bound of the launch's own duration)
+    print('%s: %.2f J per launch (%.0f W x %.3f ms)' % (which, r['socket_W'] * r['ms_per_step'] * 1e-3, r['socket_W'], r['ms_per_step']))
