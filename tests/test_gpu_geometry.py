@@ -159,6 +159,48 @@ def test_refinement_volumes_bit_exact(cuda):
     assert torch.equal(hull.cpu(), want['vis_hull'][0, ..., 0])
 
 
+def test_refinement_glue_launches_equal_their_parts_bitwise(cuda):
+    """The refinement's fused / batched geometry launches (round 5) against the launches they replace, bit for bit:
+    atvs_geo_volume = geo_ref_planes + warp_planes(mode 2) (reference atvsnet/model.py:285-300), rep 1 (one 8-byte store per voxel)
+    and rep 16 (the reference's replicated channel, quirk C7); atvs_transform_depth_batch = n x transform_depth (:289,321-324) for
+    more maps than one launch holds (18 > 16), distinct cameras per map, invalid depths; atvs_warp_by_depth_err with copy_ref =
+    warp_by_depth + absdiff_mask + the tiled reference (:309-316,329-334)."""
+    from atvsnet_amd import ops
+    cams = _example_cams(4)
+    ds, di = OM.depth_start_interval(cams)
+    D, h, w = 12, 24, 40
+    g = torch.Generator().manual_seed(17)
+    c = lambda t: t.to(cuda).contiguous()                       # noqa: E731
+    cam = [c(cams[0, i]) for i in range(4)]
+    dsg, dig = c(ds), c(di)
+    d_ref = c(0.05 + 0.3 * torch.rand(h, w, generator=g))
+    maps = []
+    for k in range(18):
+        m = 0.05 + 0.3 * torch.rand(h, w, generator=g)
+        m[k % h, : 1 + k % 5] = 0.0                              # invalid depths: the 1e-10 clip / mask
+        maps.append(c(m))
+    jobs = [(maps[k], cam[1 + k % 3], cam[(k // 3) % 4]) for k in range(18)]
+    got = ops.transform_depth_batch(jobs)
+    for (m, lc, rc), o in zip(jobs, got):
+        assert torch.equal(o, ops.transform_depth(m, lc, rc))
+    H = ops.get_homographies(cam[0], cam[1], dsg, dig, D)
+    for ld, c_off, rep in ((2, 0, 1), (19, 0, 16), (4, 1, 2)):
+        a = torch.zeros(D, h, w, ld, device=cuda)
+        b = torch.zeros(D, h, w, ld, device=cuda)
+        ops.geo_volume(d_ref, got[0], H, dsg, dig, a, c_off, rep)
+        ops.geo_ref_planes(d_ref, dsg, dig, b, c_off)
+        ops.warp_planes(got[0].reshape(h, w, 1), H, out=b, c_off=c_off + 1, mode=2, depth_start=dsg, depth_interval=dig, rep=rep)
+        assert torch.equal(a, b), (ld, c_off, rep)
+    for C, method in ((16, 'bilinear'), (1, 'nearest')):
+        src, ref = c(torch.randn(h, w, C, generator=g)), c(torch.randn(h, w, C, generator=g))
+        out = torch.zeros(h, w, 2 * C + 3, device=cuda)
+        ops.warp_by_depth_err(src, ref, cam[0], cam[1], d_ref, out, 1, method, True, copy_ref=True)
+        wf, mask = ops.warp_by_depth(src, cam[0], cam[1], d_ref, method=method)
+        assert torch.equal(out[..., 1:1 + C], ops.absdiff_mask(wf, ref, mask))
+        assert torch.equal(out[..., 1 + C:1 + 2 * C], ref)
+        assert float(out[..., 0].abs().max()) == 0.0 and float(out[..., 1 + 2 * C:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize('D,h,w', [(32, 32, 40), (192, 16, 24), (1, 5, 7), (7, 3, 130)])
 def test_softargmin(cuda, D, h, w):
     from atvsnet_amd import ops
