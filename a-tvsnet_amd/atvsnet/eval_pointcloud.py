@@ -134,7 +134,9 @@ class _Pipelines(object):
         images = torch.from_numpy(np.ascontiguousarray(images_data, dtype=np.float32)).to(self.device)
         cams = torch.from_numpy(np.ascontiguousarray(cams_data, dtype=np.float32)).to(self.device)
         if not self.use_graph:
-            self.pending.append((None, example.infer_multiview(images, cams, FLAGS.max_d, out_prob_map=True)))
+            # eager: computed here, with the drivers' range guard (an fp16-range overflow reruns the map on the fp32 kernels)
+            self.pending.append((None, example.infer_checked(
+                lambda: example.infer_multiview(images, cams, FLAGS.max_d, out_prob_map=True), self.device)))
             return
         key = tuple(images.shape)
         p = self.cache.get(key)
@@ -148,7 +150,7 @@ class _Pipelines(object):
 
     def fetch(self):
         p, t = self.pending.pop(0)
-        out = t if p is None else p.result(t)
+        out = t if p is None else p.result(t)       # result(): the fp32 rerun of a map whose split-operand replay overflowed
         return [example.check_finite(o.cpu().numpy(), 'a network output') for o in out]
 
     def __call__(self, images_data, cams_data):

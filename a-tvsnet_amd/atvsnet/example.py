@@ -227,7 +227,10 @@ class GraphedInference(object):
     """
 
     def __init__(self, images, cams, max_d=None, view_streams=True, out_prob_map=False, batched=None):
+        from .. import ops
         self.max_d = FLAGS.max_d if max_d is None else max_d
+        self.split16 = bool(ops.cfg.split16)    # the kernels this graph was captured with (a replay ignores later switches)
+        self._fp32 = None                       # the same pipeline captured on the fp32 matrix cores, built on first need
         self.out_prob_map = out_prob_map
         self.batched = BATCHED if batched is None else batched
         self.images = images.clone()
@@ -246,7 +249,6 @@ class GraphedInference(object):
             self.out = self._run()
         # the graph holds raw pointers to the weights it was captured with: keep those copies alive even if the
         # variable store is reloaded afterwards (the graph then goes on computing with the captured weights)
-        from .. import ops
         self._weights = (ops.cache_snapshot(), variables.default_store().device_snapshot())
 
     def _run(self):
@@ -264,10 +266,34 @@ class GraphedInference(object):
         return self.out
 
     def checked(self, images=None, cams=None):
-        """__call__, then wait for the depth map and raise FloatingPointError if a batch norm of this replay saw non-finite
-        moments (an fp16-range overflow of the split-operand kernels; check_device)."""
+        """__call__, then wait for the depth map; if a batch norm of this replay saw non-finite moments (an fp16-range overflow
+        of the split-operand kernels) THAT map is recomputed on the fp32 matrix cores (`fp32_rerun`) and the fp32 result is
+        returned -- the reference is fp32 end to end (cnn_wrapper/network.py:165-167, 570-601), a drop-in must not need a
+        user action to have fp32's range.  FloatingPointError only if the fp32 kernels see non-finite values too."""
         out = self(images, cams)
-        check_device(out.device)
+        dev = self.images.device
+        from .. import ops
+        if ops.nonfinite_seen(dev):
+            out = self.fp32_rerun()
+        return out
+
+    def fp32_rerun(self):
+        """The depth map of the inputs now in this graph's static buffers on the fp32-MFMA kernels: a second captured graph
+        (built once, in this process -- never a re-exec of a process that has touched the GPU), replayed synchronously.
+        Raises FloatingPointError if this graph already IS the fp32 form or the fp32 kernels see non-finite moments too."""
+        from .. import ops
+        dev = self.images.device
+        if not self.split16:
+            raise FloatingPointError('a batch norm saw non-finite moments on the fp32 kernels: ' + _NONFINITE_HINT)
+        _log_fp32_fallback()
+        if self._fp32 is None:
+            with ops.configure(split16=False):
+                self._fp32 = GraphedInference(self.images, self.cams, self.max_d, view_streams=self.view_streams,
+                                              out_prob_map=self.out_prob_map, batched=self.batched)
+            ops.nonfinite_seen(dev)            # the capture's warm-up ran on the inputs too: start from a clear flag
+        out = self._fp32(self.images, self.cams)
+        if ops.nonfinite_seen(dev):
+            raise FloatingPointError('a batch norm saw non-finite moments on the fp32 kernels too: ' + _NONFINITE_HINT)
         return out
 
 
@@ -301,6 +327,7 @@ class PipelinedInference(object):
         self.streams = [torch.cuda.Stream(self.device) for _ in range(slots)]
         self.events = [torch.cuda.Event() for _ in range(slots)]
         self.busy = [False] * slots
+        self.suspect = set()             # slots in flight when the non-finite flag was found set: their maps are recomputed in fp32
         self.next = 0
 
     @property
@@ -334,7 +361,18 @@ class PipelinedInference(object):
             raise RuntimeError('PipelinedInference: nothing in flight on slot %d' % ticket)
         self.events[ticket].synchronize()
         self.busy[ticket] = False
-        check_device(self.device)                 # an fp16-range overflow of the split-operand kernels is reported, not returned
+        from .. import ops
+        if ops.nonfinite_seen(self.device):
+            # an fp16-range overflow of the split-operand kernels is never returned.  The sticky flag does not say WHICH of the
+            # maps in flight set it: every map that was in flight when it is found up is recomputed on the fp32 kernels
+            # (GraphedInference.fp32_rerun: synchronous, from the slot's static input buffers)
+            torch.cuda.synchronize(self.device)
+            ops.nonfinite_seen(self.device)
+            self.suspect.update(t for t, b in enumerate(self.busy) if b)
+            self.suspect.add(ticket)
+        if ticket in self.suspect:
+            self.suspect.discard(ticket)
+            return self.graphs[ticket].fp32_rerun()
         return self.graphs[ticket].out
 
     def run(self, count):
@@ -408,6 +446,44 @@ def write_error_xlsx(path, error, view_num):
     workbook.close()
 
 
+_NONFINITE_HINT = 'the inputs or the weights are not finite (the fp32 kernels have the reference\'s range)'
+_fallback_logged = [False]
+
+
+def _log_fp32_fallback():
+    if not _fallback_logged[0]:
+        _fallback_logged[0] = True
+        print(Notify.INFO, 'an activation left the fp16 range of the split-operand kernels: this depth map is recomputed on the '
+              'fp32 matrix cores (ATVS_SPLIT16=0 selects them from the start)', Notify.ENDC)
+
+
+def infer_checked(fn, device=None):
+    """fn() -> device tensor(s), with the range guard of the host drivers: if a batch norm saw non-finite moments (the sticky
+    device flag) or an output is not finite, fn() runs again under ops.configure(split16=False) -- every convolution on the
+    fp32 matrix cores, the reference's arithmetic range (cnn_wrapper/network.py:165-167) -- and THAT result is returned.
+    FloatingPointError only if the fp32 kernels fail as well (non-finite inputs / weights).  Synchronises."""
+    from .. import ops
+    device = torch.device('cuda', torch.cuda.current_device()) if device is None else device
+
+    def finite(out):
+        ts = out if isinstance(out, (list, tuple)) else [out]
+        return all(bool(torch.isfinite(t).all()) for t in ts if isinstance(t, torch.Tensor))
+    ops.nonfinite_seen(device)                 # start from a clear flag: only THIS map's batch norms count
+    out = fn()
+    if not ops.nonfinite_seen(device) and finite(out):
+        return out
+    if not ops.cfg.split16:
+        raise FloatingPointError('non-finite values on the fp32 kernels: ' + _NONFINITE_HINT)
+    _log_fp32_fallback()
+    del out
+    with ops.configure(split16=False):
+        out = fn()
+        bad = ops.nonfinite_seen(device) or not finite(out)
+    if bad:
+        raise FloatingPointError('non-finite values on the fp32 kernels too: ' + _NONFINITE_HINT)
+    return out
+
+
 _RANGE_HINT = ('an activation or weight left the fp16 range of the split-operand kernels (or the inputs were not finite); rerun with '
                'ATVS_SPLIT16=0 for the fp32 kernels')
 
@@ -451,7 +527,7 @@ def run_test_multiview(savepath, images_data, cams_data, depth_gt=None):
     _load_weights()
     images, cams = _to_device(images_data, cams_data)
     print(Notify.INFO, 'running test......', Notify.ENDC)
-    out_depth_map = check_finite(infer_multiview(images, cams, FLAGS.max_d).cpu().numpy())
+    out_depth_map = check_finite(infer_checked(lambda: infer_multiview(images, cams, FLAGS.max_d)).cpu().numpy())
     out_disp_map = out_depth_map.copy()
     if FLAGS.inverse_depth:
         out_depth_map[out_depth_map < 1e-10] = float("inf")
@@ -466,7 +542,7 @@ def run_test_twoview(savepath, images_data, cams_data, depth_gt=None):
     _load_weights()
     images, cams = _to_device(images_data, cams_data)
     print(Notify.INFO, 'running test......', Notify.ENDC)
-    out_depth_map = check_finite(infer_twoview(images, cams, FLAGS.max_d).cpu().numpy())
+    out_depth_map = check_finite(infer_checked(lambda: infer_twoview(images, cams, FLAGS.max_d)).cpu().numpy())
     out_disp_map = out_depth_map.copy()
     if FLAGS.inverse_depth:
         out_depth_map[out_depth_map <= 0] = float("inf")

@@ -16,6 +16,10 @@
 
 #define AANET_MAX_VIEWS 16
 
+// e^(u - max) exactly as atvs_aanet_softmax_sum (common.h) forms it: 2^(u log2 e - ml), ml = max * log2 e
+#define AA_L2E 1.44269504088896340736f
+__device__ __forceinline__ float aa_exp(float u, float ml) { return __builtin_amdgcn_exp2f(__builtin_fmaf(u, AA_L2E, -ml)); }
+
 struct ViewPtrs {
   const float* sr[AANET_MAX_VIEWS];
   const float* x[AANET_MAX_VIEWS];
@@ -38,26 +42,16 @@ __global__ __launch_bounds__(256) void aanet_combine_kernel(ViewPtrs p, int nv_r
     ssum.x += s.x; ssum.y += s.y; ssum.z += s.z; ssum.w += s.w;
     u[n] = make_float4(r.x - s.x, r.y - s.y, r.z - s.z, r.w - s.w);
   }
-  float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  float ux[NV], uy[NV], uz[NV], uw[NV];
 #pragma unroll
   for (int n = 0; n < NV; ++n) {
-    u[n].x += ssum.x; u[n].y += ssum.y; u[n].z += ssum.z; u[n].w += ssum.w;      // (R - S) + S_sum
-    m.x = fmaxf(m.x, u[n].x); m.y = fmaxf(m.y, u[n].y); m.z = fmaxf(m.z, u[n].z); m.w = fmaxf(m.w, u[n].w);
+    ux[n] = u[n].x + ssum.x; uy[n] = u[n].y + ssum.y; uz[n] = u[n].z + ssum.z; uw[n] = u[n].w + ssum.w;      // (R - S) + S_sum
   }
-  float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int n = 0; n < NV; ++n) {
-    u[n].x = expf(u[n].x - m.x); u[n].y = expf(u[n].y - m.y); u[n].z = expf(u[n].z - m.z); u[n].w = expf(u[n].w - m.w);
-    den.x += u[n].x; den.y += u[n].y; den.z += u[n].z; den.w += u[n].w;
-  }
-  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-  for (int n = 0; n < NV; ++n) {
-    o.x += (u[n].x / den.x) * x[n].x;
-    o.y += (u[n].y / den.y) * x[n].y;
-    o.z += (u[n].z / den.z) * x[n].z;
-    o.w += (u[n].w / den.w) * x[n].w;
-  }
+  float4 o;
+  atvs_aanet_softmax_sum<NV>(ux, [&](int n) { return x[n].x; }, &o.x);
+  atvs_aanet_softmax_sum<NV>(uy, [&](int n) { return x[n].y; }, &o.y);
+  atvs_aanet_softmax_sum<NV>(uz, [&](int n) { return x[n].z; }, &o.z);
+  atvs_aanet_softmax_sum<NV>(uw, [&](int n) { return x[n].w; }, &o.w);
   st4(out + xo, o);
 }
 
@@ -81,23 +75,19 @@ __global__ __launch_bounds__(256) void aanet_combine_generic_kernel(ViewPtrs p, 
     m.z = fmaxf(m.z, (r.z - s.z) + ssum.z);
     m.w = fmaxf(m.w, (r.w - s.w) + ssum.w);
   }
-  float4 den = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int n = 0; n < nv; ++n) {
-    float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8);
-    den.x += expf(((r.x - s.x) + ssum.x) - m.x);
-    den.y += expf(((r.y - s.y) + ssum.y) - m.y);
-    den.z += expf(((r.z - s.z) + ssum.z) - m.z);
-    den.w += expf(((r.w - s.w) + ssum.w) - m.w);
-  }
-  float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  // atvs_aanet_softmax_sum's arithmetic (common.h) with the operands re-read per pass
+  const float4 ml = make_float4(m.x * AA_L2E, m.y * AA_L2E, m.z * AA_L2E, m.w * AA_L2E);
+  float4 den = make_float4(0.f, 0.f, 0.f, 0.f), num = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int n = 0; n < nv; ++n) {
     float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8), x = ld4(p.x[n] + xo);
-    o.x += (expf(((r.x - s.x) + ssum.x) - m.x) / den.x) * x.x;
-    o.y += (expf(((r.y - s.y) + ssum.y) - m.y) / den.y) * x.y;
-    o.z += (expf(((r.z - s.z) + ssum.z) - m.z) / den.z) * x.z;
-    o.w += (expf(((r.w - s.w) + ssum.w) - m.w) / den.w) * x.w;
+    const float ex = aa_exp((r.x - s.x) + ssum.x, ml.x), ey = aa_exp((r.y - s.y) + ssum.y, ml.y);
+    const float ez = aa_exp((r.z - s.z) + ssum.z, ml.z), ew = aa_exp((r.w - s.w) + ssum.w, ml.w);
+    den.x += ex; den.y += ey; den.z += ez; den.w += ew;
+    num.x = __builtin_fmaf(ex, x.x, num.x); num.y = __builtin_fmaf(ey, x.y, num.y);
+    num.z = __builtin_fmaf(ez, x.z, num.z); num.w = __builtin_fmaf(ew, x.w, num.w);
   }
-  st4(out + xo, o);
+  st4(out + xo, make_float4(num.x * __builtin_amdgcn_rcpf(den.x), num.y * __builtin_amdgcn_rcpf(den.y),
+                            num.z * __builtin_amdgcn_rcpf(den.z), num.w * __builtin_amdgcn_rcpf(den.w)));
 }
 
 static int fill_ptrs(ViewPtrs* p, const float* const* sr, const float* const* x, int nv) {
@@ -172,13 +162,15 @@ __global__ __launch_bounds__(256) void aanet_partial_kernel(ViewPtrs p, int nv, 
     return;
   }
   float4 m = ld4(umax + xo);
+  const float4 ml = make_float4(m.x * AA_L2E, m.y * AA_L2E, m.z * AA_L2E, m.w * AA_L2E);
   float4 den = make_float4(0.f, 0.f, 0.f, 0.f), num = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int n = 0; n < nv; ++n) {
     float4 s = ld4(p.sr[n] + so), r = ld4(p.sr[n] + so + 8), x = ld4(p.x[n] + xo);
-    float ex = expf(((r.x - s.x) + ss.x) - m.x), ey = expf(((r.y - s.y) + ss.y) - m.y);
-    float ez = expf(((r.z - s.z) + ss.z) - m.z), ew = expf(((r.w - s.w) + ss.w) - m.w);
+    float ex = aa_exp((r.x - s.x) + ss.x, ml.x), ey = aa_exp((r.y - s.y) + ss.y, ml.y);
+    float ez = aa_exp((r.z - s.z) + ss.z, ml.z), ew = aa_exp((r.w - s.w) + ss.w, ml.w);
     den.x += ex; den.y += ey; den.z += ez; den.w += ew;
-    num.x += ex * x.x; num.y += ey * x.y; num.z += ez * x.z; num.w += ew * x.w;
+    num.x = __builtin_fmaf(ex, x.x, num.x); num.y = __builtin_fmaf(ey, x.y, num.y);
+    num.z = __builtin_fmaf(ez, x.z, num.z); num.w = __builtin_fmaf(ew, x.w, num.w);
   }
   st4(out + xo, den);
   st4(out + V8 + xo, num);

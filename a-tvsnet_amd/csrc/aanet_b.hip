@@ -6,18 +6,41 @@
 //   S_n = relu(conv3d(X_n, W_shared)),  R_n = relu(conv3d(X_n, W_unique))           (8 -> 8 channels each, per view n)
 //   S_sum = sum_n S_n;  U_n = (R_n - S_n) + S_sum;  score = softmax_n(U);  out = sum_n score_n * X_n
 // Until round 4 this was two launches per module: conv_c16b<8> wrote [S|R] of every view (960 MB at 4 views of configs[2]) and
-// aanet_combine read it back with the X_n (295 us of pure traffic at the HBM rate).  Here a workgroup owns a 4(z) x 8(y) x 16(x)
-// tile and walks the views: per view conv_c16b's stage (halo of the next stage fetched during the K loop, split on the way into
-// LDS, 7 K steps of four taps x 8 channels, three products) whose results stay in REGISTERS; after the last view the lanes combine.
+// aanet_combine read it back with the X_n (295 us of pure traffic at the HBM rate).  Round 5 made it one launch of four wavefronts
+// that did everything in turn (608 us, matrix pipe 24 % busy: split + LDS writes, barriers, 64 expf + 64 divisions per lane and
+// tile with nothing beside them).
+//
+// Round 6: ONE workgroup of EIGHT wavefronts per CU, two roles (conv_xb's structure).  A workgroup owns a 4(z) x 8(y) x 16(x)
+// tile and walks the views; a STAGE is one (tile, view).
+//   * wavefronts 0..3 (one per SIMD) MULTIPLY: LDS fragment reads + MFMAs only (7 K steps of four taps x 8 channels, three
+//     products: conv_c16b's K order), then conv_c16b's epilogue arithmetic (zero bias, ReLU) and 8 ds_write_b128 that hand the
+//     view's [S|R] of the wavefront's plane to its partner -- no vector-memory instruction at all;
+//   * wavefronts 4..7 (the second wavefront of each SIMD) STAGE and COMBINE: they fetch the fp32 halo of the stage after next,
+//     split the next stage's into its two fp16 pieces and write the OTHER of two image buffers; they read the previous stage's
+//     hand-off ([S|R] of one view) and keep S_sum and R_n - S_n of their lane's 8 voxels x 2 channels in registers
+//     ((NV + 1) x 16 values instead of the 2 NV x 16 of [S|R]: eight views fit); after a tile's last view they run
+//     aanet_combine_kernel's arithmetic in its order (64..128 expf and divisions per lane) and store the output -- beside the
+//     multiplying wavefronts' K loop of the NEXT tile.
+// ONE LDS-only barrier per stage (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would drain the halo requests in flight):
+// it publishes the next image buffer and this stage's hand-off and retires the buffers both will be overwritten in.
 // The 16 MFMA rows are ordered (S[2q], S[2q+1], R[2q], R[2q+1]) for lane group q (atvs_aanet_b_pack), so a lane holds S AND R of
 // its two channels -- no cross-lane exchange -- and reads the matching two channels of every X_n's centre voxel (L2 hits: the
-// halo just came through).  The arithmetic and its order are conv_c16b's and aanet_combine_kernel's: bit for bit the two launches.
-// One workgroup per CU, register file reserved, scalar fp32 arithmetic.
+// halo just came through).  The arithmetic and its order are conv_c16b's and aanet_combine_kernel's (S_sum accumulates in view
+// order from 0.f, U_n = (R_n - S_n) + S_sum): bit for bit the two launches.
+// Scalar fp32 arithmetic (-fno-slp-vectorize): the staging wavefronts compute beside the kernel's own 16x16x32 MFMA wavefronts
+// (DESIGN.md appendix B); two wavefronts of 256 registers per SIMD: no other kernel's wavefront fits beside them.
+#include <atomic>
 #include <cstring>
 #include <type_traits>
 #include <utility>
 
 #include "conv_common.h"
+
+// buffer_load_dwordx4 (offen).  hipcc 7.2's __builtin_amdgcn_raw_buffer_load_b128 compiles to a ONE-dword load whose value is
+// splat over the four components (geometry.hip), so the LLVM intrinsic is bound by name instead.
+typedef float ab_f32x4 __attribute__((ext_vector_type(4)));
+__device__ ab_f32x4 ab_buffer_load_x4(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
 
 namespace {
 
@@ -27,13 +50,18 @@ constexpr int AB_VB = 16;                                      // bytes per voxe
 constexpr int AB_ROWB = AB_HX * AB_VB;
 constexpr int AB_IMG = AB_HZ * AB_HY * AB_ROWB;                // 17,280 bytes per piece
 constexpr int AB_SLOTS = AB_HZ * AB_HY * AB_HX * 2;            // float4 slots of the fp32 halo
-constexpr int AB_MAXS = (AB_SLOTS + 255) / 256;                // 9 per thread
+constexpr int AB_MAXS = (AB_SLOTS + 255) / 256;                // 9 per staging thread
 constexpr int AB_JC = 7;                                       // K steps: taps 4 j + q (tap 27 = zero weights)
 constexpr int AB_NP = 2;
 constexpr int AB_WSTEP = AB_NP * 1024;
-constexpr int AB_MAXV = 4;                                     // views per launch: [S|R] of 4 views x 8 rows = 128 registers (8 views spill)
+constexpr int AB_MAXV = 8;                                     // views per launch
 constexpr float AB_RS = 2048.f, AB_IRS = 1.f / 2048.f;
-static_assert(AB_MAXS <= 2 * AB_JC, "two halo slots per K step");
+// LDS map: two image buffers (two piece images each) | packed weights | two hand-off buffers ([wavefront][row][lane] float4)
+constexpr int AB_BUF = AB_NP * AB_IMG;                         // 34,560
+constexpr int AB_WOFF = 2 * AB_BUF;                            // 69,120
+constexpr int AB_HOFF = AB_WOFF + AB_JC * AB_WSTEP;            // 83,456
+constexpr int AB_HBUF = 4 * AB_TY * 1024;                      // 32,768
+constexpr int AB_LDS = AB_HOFF + 2 * AB_HBUF;                  // 148,992 of 163,840
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -67,40 +95,36 @@ __device__ __forceinline__ void ab_split(const float4& v, f16x4* p0, f16x4* p1) 
   *p1 = __builtin_bit_cast(f16x4, b);
 }
 
-constexpr int ab_clamp26(int t) { return t < 26 ? t : 26; }
-constexpr int ab_disp(int t) { return ((t / 9) * AB_HY + (t / 3) % 3) * AB_ROWB + (t % 3) * AB_VB; }
+#ifdef ATVS_AB_DEBUG
+// development build (tools_dev/phase_ab.py): per-wavefront tick counts of the phases of a stage
+__device__ unsigned long long atvs_dbg_ab[2048 * 8];
+extern "C" int atvs_debug_read_ab(void* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(atvs_dbg_ab), sizeof(atvs_dbg_ab));
+}
+#define ABDBG(i) { unsigned long long t_ = clock64(); dbg_acc[i] += t_ - dbg_t; dbg_t = t_; }
+#else
+#define ABDBG(i)
+#endif
 
-// NV: the number of views (compile time: no branches in the combine, exactly NV register slots for [S|R])
+// LDS-only barrier: the staging wavefronts' halo requests stay in flight across it
+__device__ __forceinline__ void ab_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// NV: the number of views (compile time: no branches in the combine, exactly NV + 1 register slots per lane value)
 template <int NV>
-__global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
-  asm volatile("" ::: "v255", "a255");                         // own the SIMD's register file (conv_c16b.hip)
+__global__ __launch_bounds__(512, 1) void aanet_b_kernel(AbArgs p) {
+  // the workgroup's two wavefronts per SIMD take the SIMD's whole register file (256 each): no wavefront of ANOTHER kernel runs
+  // beside this one's 16-bit MFMAs
+  asm volatile("" ::: "v255");
   constexpr int TY = AB_TY, HY = AB_HY, MAXS = AB_MAXS, JC = AB_JC;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave: a scalar (uniform branches)
   const int r = lane & 15, q = lane >> 4;
 
   {
     const float4* src = reinterpret_cast<const float4*>(p.wp);
-    float4* dst = reinterpret_cast<float4*>(smem + AB_NP * AB_IMG);
-    for (int i = tid; i < JC * (AB_WSTEP / 16); i += 256) dst[i] = src[i];
-  }
-  const int fbase = ((wave * HY) * AB_HX + r) * AB_VB;
-  const int wbase = AB_NP * AB_IMG + lane * 16;
-
-  int goff[MAXS], laddr[MAXS];
-  unsigned pg[MAXS];
-#pragma unroll
-  for (int i = 0; i < MAXS; ++i) {
-    int s = tid + i * 256;
-    const bool live = s < AB_SLOTS;
-    s = min(s, AB_SLOTS - 1);
-    const int c4 = s % 2, v = s / 2;
-    const int xx = v % AB_HX, v2 = v / AB_HX;
-    const int yy = v2 % HY, zz = v2 / HY;
-    goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * 8 + c4 * 4;
-    laddr[i] = ((zz * HY + yy) * AB_HX + xx) * AB_VB + c4 * 8;
-    pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+    float4* dst = reinterpret_cast<float4*>(smem + AB_WOFF);
+    for (int i = tid; i < JC * (AB_WSTEP / 16); i += 512) dst[i] = src[i];
   }
 
   const int G = p.wg;
@@ -113,6 +137,11 @@ __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
     int last = min(per_xcd, p.ntiles - xcd * per_xcd);
     if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
   }
+  const int nstages = my_tiles * NV;
+#ifdef ATVS_AB_DEBUG
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+#endif
   auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
     int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
     int bx = tl % p.tiles_x;
@@ -121,82 +150,35 @@ __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
     *y0 = (rest % p.tiles_y) * TY;
     *z0 = (rest / p.tiles_y) * AB_TZ;
   };
-  struct PfTile {
-    int org;
-    unsigned lo, hi1;
-  };
-  auto pf_tile = [&](int k) __attribute__((always_inline)) {
-    PfTile T;
-    int z0, y0, x0;
-    tile_origin(k, &z0, &y0, &x0);
-    const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
-    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * 8;
-    T.lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
-    T.hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
-            ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
-    return T;
-  };
-  float4 pf[MAXS];
-  auto pf_slot = [&](const PfTile& T, const float* xg, int i) __attribute__((always_inline)) {
-    const unsigned t1 = pg[i] - T.lo;
-    const unsigned t2 = T.hi1 + ~pg[i];
-    const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
-    pf[i] = ld4(ok ? (xg + (T.org + goff[i])) : p.zeros);
-  };
 
-  // [S(2q) S(2q+1) R(2q) R(2q+1)] of voxel (z0 + wave, y0 + t, x0 + r) per view
-  float4 sr[NV][TY];
-  f32x4 acc[TY], accx[TY];
-
-  if (my_tiles > 0) {
-    const PfTile T0 = pf_tile(0);
+  if (wave < 4) {
+    // ======================= MULTIPLYING wavefronts: wavefront w owns plane z0 + w of the tile =======================
+    const int fbase = ((wave * HY) * AB_HX + r) * AB_VB;
+    int dq[JC];                                                // the lane group's tap displacement per K step (tap 4 j + q, 27 -> 26)
 #pragma unroll
-    for (int i = 0; i < MAXS; ++i) pf_slot(T0, p.x[0], i);
-  }
-
-  for (int k = 0; k < my_tiles; ++k) {
-    // the views as a ROLLED loop (unrolled -- [S|R] into static register slots, no selects -- the launch was SLOWER: 663 instead
-    // of 628 us, four copies of the stage body)
+    for (int j = 0; j < JC; ++j) {
+      const int t = min(4 * j + q, 26);
+      dq[j] = fbase + ((t / 9) * HY + (t / 3) % 3) * AB_ROWB + (t % 3) * AB_VB;
+    }
+    const int wbase = AB_WOFF + lane * 16;
+    const int hbase = AB_HOFF + (wave * TY) * 1024 + lane * 16;
+    __syncthreads();                                           // weights + stage 0 are in LDS
+    f32x4 acc[TY], accx[TY];
 #pragma unroll 1
-    for (int v = 0; v < NV; ++v) {
+    for (int s = 0; s < nstages; ++s) {
+      const int ib = (s & 1) * AB_BUF;
 #pragma unroll
       for (int t = 0; t < TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      __syncthreads();                       // every wavefront is done reading the previous stage's images
-#pragma unroll
-      for (int i = 0; i < MAXS; ++i) {
-        if (i < MAXS - 1 || tid + i * 256 < AB_SLOTS) {
-          f16x4 p0, p1;
-          ab_split(pf[i], &p0, &p1);
-          *reinterpret_cast<f16x4*>(smem + laddr[i]) = p0;
-          *reinterpret_cast<f16x4*>(smem + AB_IMG + laddr[i]) = p1;
-        }
-      }
-      __syncthreads();
-
-      // the next stage: the next view of this tile, else view 0 of the next tile (last stage: a harmless re-read)
-      const bool last_view = v + 1 == NV;
-      const int vn = last_view ? 0 : v + 1;
-      const PfTile T = pf_tile(last_view ? min(k + 1, my_tiles - 1) : k);
-      const float* __restrict__ xn = p.x[vn];
-
       f16x8 Bq[2][TY], A[2][AB_NP];
-      auto request_B = [&](auto PH) __attribute__((always_inline)) {
-        constexpr int ph = decltype(PH)::value, j = ph / AB_NP, pc = ph % AB_NP;
-        constexpr int tA = ab_clamp26(4 * j), tB = ab_clamp26(4 * j + 1), tC = ab_clamp26(4 * j + 2), tD = ab_clamp26(4 * j + 3);
-        const int a = fbase + ((q & 2) ? ((q & 1) ? ab_disp(tD) : ab_disp(tC)) : ((q & 1) ? ab_disp(tB) : ab_disp(tA)));
-#pragma unroll
-        for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * AB_IMG + a + t * AB_ROWB);
-      };
       auto request_B1 = [&](auto PH, auto TT) __attribute__((always_inline)) {
         constexpr int ph = decltype(PH)::value, j = ph / AB_NP, pc = ph % AB_NP, t = decltype(TT)::value;
-        constexpr int tA = ab_clamp26(4 * j), tB = ab_clamp26(4 * j + 1), tC = ab_clamp26(4 * j + 2), tD = ab_clamp26(4 * j + 3);
-        const int a = fbase + ((q & 2) ? ((q & 1) ? ab_disp(tD) : ab_disp(tC)) : ((q & 1) ? ab_disp(tB) : ab_disp(tA)));
-        Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * AB_IMG + a + t * AB_ROWB);
+        Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + ib + dq[j] + (pc * AB_IMG + t * AB_ROWB));
       };
 #pragma unroll
       for (int pc = 0; pc < AB_NP; ++pc) A[0][pc] = *reinterpret_cast<const f16x8*>(smem + wbase + pc * 1024);
-      request_B(IC<0>{});
+      ab_static_for<TY>([&](auto TT) __attribute__((always_inline)) { request_B1(IC<0>{}, TT); });
       asm volatile("" ::: "memory");
+      ABDBG(0)
       ab_static_for<AB_NP * JC>([&](auto PH) __attribute__((always_inline)) {
         constexpr int ph = decltype(PH)::value, j = ph / AB_NP, pc = ph % AB_NP;
         ab_static_for<(2 - pc) * TY>([&](auto M) __attribute__((always_inline)) {
@@ -207,90 +189,263 @@ __global__ __launch_bounds__(256, 1) void aanet_b_kernel(AbArgs p) {
             if constexpr (ph + 1 < AB_NP * JC) request_B1(IC<ph + 1>{}, IC<m>{});
           } else if constexpr (m < TY + AB_NP) {
             if constexpr (j + 1 < JC) A[(j + 1) & 1][m - TY] = *reinterpret_cast<const f16x8*>(smem + wbase + (j + 1) * AB_WSTEP + (m - TY) * 1024);
-          } else if constexpr (m == TY + 3 || m == TY + 6) {
-            constexpr int slot = 2 * j + (m == TY + 6 ? 1 : 0);
-            if constexpr (slot < MAXS) pf_slot(T, xn, slot);
           }
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
         });
       });
-
-      // this view's [S|R] of the lane's voxels: conv_c16b's epilogue arithmetic (zero bias, ReLU), kept in registers
+      ABDBG(1)
+      // this view's [S|R] of the lane's voxels: conv_c16b's epilogue arithmetic (zero bias, ReLU) -> the partner wavefront
+      const int hb = hbase + (s & 1) * AB_HBUF;
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
         float a0 = (acc[t][0] + accx[t][0] * AB_IRS) + 0.f, a1 = (acc[t][1] + accx[t][1] * AB_IRS) + 0.f;
         float a2 = (acc[t][2] + accx[t][2] * AB_IRS) + 0.f, a3 = (acc[t][3] + accx[t][3] * AB_IRS) + 0.f;
-        a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
+        a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;      // compare + select, not v_max: a NaN stays a NaN
         a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {                         // v is a run-time index: a register array takes it as selects
-          const bool here = v == n;
-          sr[n][t].x = here ? a0 : sr[n][t].x;
-          sr[n][t].y = here ? a1 : sr[n][t].y;
-          sr[n][t].z = here ? a2 : sr[n][t].z;
-          sr[n][t].w = here ? a3 : sr[n][t].w;
-        }
+        *reinterpret_cast<float4*>(smem + hb + t * 1024) = make_float4(a0, a1, a2, a3);
       }
-      if (!last_view) continue;
+      ABDBG(2)
+      ab_lds_barrier();
+      ABDBG(3)
+    }
+#ifdef ATVS_AB_DEBUG
+    if (lane == 0 && blockIdx.x < 256) {
+      dbg_acc[7] = (unsigned long long)nstages;
+      for (int i = 0; i < 8; ++i) atvs_dbg_ab[(blockIdx.x * 8 + wave) * 8 + i] = dbg_acc[i];
+    }
+#endif
+    return;
+  }
 
-      // ---- combine (aanet_combine_kernel's arithmetic and order) for channels 2q, 2q+1 of the lane's TY voxels
-      int tz0, ty0, tx0;
-      tile_origin(k, &tz0, &ty0, &tx0);
-      const int zo = tz0 + wave, xo = tx0 + r;
-      const bool evox_ok = zo < p.Di && xo < p.Wi;
-      const size_t vo0 = (((size_t)zo * p.Hi + ty0) * p.Wi + xo) * 8 + 2 * q;
-      const size_t vrow = (size_t)p.Wi * 8;
-      // the centre voxels of the views (L2 hits: the halo just came through), one row AHEAD of the arithmetic: requested where
-      // they are used (round 5, first form) every row waited a full round trip -- 8 per tile.  (All rows in front of the last view's
-      // K loop: 64 more live registers, 15 spilled, 628 -> 721 us.)  Rows outside the volume read the zero line.
-      float2 xv[2][NV];
-      auto request_x = [&](int t) __attribute__((always_inline)) {
-        const bool ok = evox_ok && ty0 + t < p.Hi;
+  // ========================== STAGING / COMBINING wavefronts: wavefront 4 + w is the partner of w ==========================
+  // (their vector instructions share the SIMD's issue with the partner's MFMAs -- an MFMA holds it for 8 of its 16 cycles -- so
+  // this role is written for FEW instructions: halo requests through a buffer descriptor at the tile's origin with per-lane
+  // constant offsets and a per-tile validity mask (2 instructions per request), 2^(x log2 e) and one reciprocal in the softmax)
+  const int stid = tid - 256, sw = wave - 4;
+  // the multiplying partner always has an MFMA ready and, being older, wins every arbitration for the SIMD's vector issue: this
+  // role then advances one instruction per MFMA.  Raised priority lets its instructions go first when they are ready (the
+  // partner's MFMAs fill what is left): split + LDS writes 2.1k -> 1.3k cycles per stage, launch -5 %.
+#ifndef ATVS_AB_PRIO
+#define ATVS_AB_PRIO 3
+#endif
+  __builtin_amdgcn_s_setprio(ATVS_AB_PRIO);
+  int goff[MAXS], laddr[MAXS];
+  // slot i of this lane = float4 c4 of halo voxel (zz, yy, xx); packed coordinates for the border tiles' validity test (recomputed
+  // there instead of kept: nine registers this role does not have)
+  auto slot_pg = [&](int i, int stid_now) __attribute__((always_inline)) {
+    int s = stid_now + i * 256;
+    const bool live = s < AB_SLOTS;
+    s = min(s, AB_SLOTS - 1);
+    const int v = s / 2;
+    const int xx = v % AB_HX, v2 = v / AB_HX;
+    const int yy = v2 % HY, zz = v2 / HY;
+    return 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+  };
 #pragma unroll
-        for (int n = 0; n < NV; ++n)
-          xv[t & 1][n] = *reinterpret_cast<const float2*>(ok ? (p.x[n] + (vo0 + t * vrow)) : p.zeros);
-      };
-      request_x(0);
+  for (int i = 0; i < MAXS; ++i) {
+    int s = stid + i * 256;
+    s = min(s, AB_SLOTS - 1);
+    const int c4 = s % 2, v = s / 2;
+    const int xx = v % AB_HX, v2 = v / AB_HX;
+    const int yy = v2 % HY, zz = v2 / HY;
+    goff[i] = (((zz * p.Hi + yy) * p.Wi + xx) * 8 + c4 * 4) * 4;       // BYTES from the halo's origin
+    laddr[i] = ((zz * HY + yy) * AB_HX + xx) * AB_VB + c4 * 8;
+  }
+  struct PfTile {
+    int org;                   // element offset of the halo's origin (may lie outside the volume: masked lanes never read)
+    unsigned vmask;            // per lane: bit i = slot i lies outside the volume
+    int z0, y0, x0;
+  };
+  auto pf_tile = [&](int k) __attribute__((always_inline)) {
+    PfTile T;
+    tile_origin(min(k, max(my_tiles - 1, 0)), &T.z0, &T.y0, &T.x0);      // past the last tile: a harmless re-read
+    const int gz0 = T.z0 - 1, gy0 = T.y0 - 1, gx0 = T.x0 - 1;
+    T.org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * 8;
+    const unsigned lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+    const unsigned hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+                         ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+    T.vmask = 0;
+    const bool interior = lo == 0 && gz0 + AB_HZ <= p.Di && gy0 + HY <= p.Hi && gx0 + AB_HX <= p.Wi;      // uniform
+    if (!interior) {
+      int stid_now = stid;
+      asm volatile("" : "+v"(stid_now));                       // opaque: or the nine coordinates are hoisted out of the tile loop (and spilled)
 #pragma unroll
-      for (int t = 0; t < TY; ++t) {
-        if (t + 1 < TY) request_x(t + 1);
-        const bool ok = evox_ok && ty0 + t < p.Hi;
-        float sx = 0.f, sy = 0.f;
-        float ux[NV], uy[NV];
+      for (int i = 0; i < MAXS; ++i) {
+        const unsigned pgi = slot_pg(i, stid_now);
+        const unsigned t1 = pgi - lo;
+        const unsigned t2 = hi1 + ~pgi;
+        const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
+        T.vmask |= ok ? 0u : (1u << i);
+      }
+    } else if (stid + (MAXS - 1) * 256 >= AB_SLOTS) {
+      T.vmask = 1u << (MAXS - 1);                                       // the lanes beyond the last slot
+    }
+    return T;
+  };
+  float4 pf[MAXS];
+  auto pf_request = [&](const PfTile& T, const float* xg) __attribute__((always_inline)) {
+    // descriptor at the halo's origin, no bounds but 2 GB: lanes outside the volume get an offset beyond it and read zeros
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xg + T.org), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-          sx += sr[n][t].x; sy += sr[n][t].y;
-          ux[n] = sr[n][t].z - sr[n][t].x; uy[n] = sr[n][t].w - sr[n][t].y;
-        }
-        float mx = -INFINITY, my = -INFINITY;
+    for (int i = 0; i < MAXS; ++i) {
+      const int voff = goff[i] | __builtin_amdgcn_sbfe((int)T.vmask, i, 1);      // all ones when outside
+      const ab_f32x4 v = ab_buffer_load_x4(rs, voff, 0, 0);
+      pf[i] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+  };
+  auto pf_write = [&](int ib) __attribute__((always_inline)) {
 #pragma unroll
-        for (int n = 0; n < NV; ++n) {
-          ux[n] += sx; uy[n] += sy;
-          mx = fmaxf(mx, ux[n]); my = fmaxf(my, uy[n]);
-        }
-        float dx = 0.f, dy = 0.f;
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-          ux[n] = expf(ux[n] - mx); uy[n] = expf(uy[n] - my);
-          dx += ux[n]; dy += uy[n];
-        }
-        float ox = 0.f, oy = 0.f;
-#pragma unroll
-        for (int n = 0; n < NV; ++n) {
-          ox += (ux[n] / dx) * xv[t & 1][n].x;
-          oy += (uy[n] / dy) * xv[t & 1][n].y;
-        }
-        if (ok) *reinterpret_cast<float2*>(p.out + (vo0 + t * vrow)) = make_float2(ox, oy);
+    for (int i = 0; i < MAXS; ++i) {
+      if (i < MAXS - 1 || stid + i * 256 < AB_SLOTS) {
+        f16x4 p0, p1;
+        ab_split(pf[i], &p0, &p1);
+        *reinterpret_cast<f16x4*>(smem + ib + laddr[i]) = p0;
+        *reinterpret_cast<f16x4*>(smem + ib + AB_IMG + laddr[i]) = p1;
       }
     }
+  };
+
+  // stage 0 -> image buffer 0; the halo of stage 1 requested
+  PfTile Tk = pf_tile(0), Tk1 = pf_tile(1), Tp = Tk, Tk2 = Tk1;
+  if (my_tiles > 0) {
+    pf_request(Tk, p.x[0]);
+    pf_write(0);
+    pf_request(NV > 1 ? Tk : Tk1, p.x[NV > 1 ? 1 : 0]);
   }
+  __syncthreads();
+
+  // S_sum and R_n - S_n of channels 2q, 2q+1 of voxels (z0 + sw, y0 + t, x0 + r), t < TY: TWO sets, tiles alternate.  The set of
+  // tile k fills view by view during the stages of tile k (+ the first of tile k + 1) while the set of tile k - 1 is combined ROW
+  // GROUP by row group, one group per stage of tile k (rows [v TY / NV, (v + 1) TY / NV) in stage v): the 16 NV exponentials of a
+  // tile in ONE stage made that stage twice as long as the multiplying wavefronts' (they waited 1.7k cycles per stage on average).
+  constexpr bool SPREAD = NV <= 4;                           // more views: two sets do not fit the registers, one set + a long first stage
+  constexpr int NSET = SPREAD ? 2 : 1;
+  float ssx[NSET][TY], ssy[NSET][TY], dvx[NSET][NV][TY], dvy[NSET][NV][TY];
+  const int hread = AB_HOFF + (sw * TY) * 1024 + lane * 16;
+  int s = 0;
+  auto stage_body = [&](auto PP, auto VV, int k) __attribute__((always_inline)) {
+    constexpr int P = decltype(PP)::value, v = decltype(VV)::value;
+    constexpr int vp = (v + NV - 1) % NV;                      // the view whose hand-off arrives: of this tile (v > 0) or the previous one
+    constexpr int HS = !SPREAD ? 0 : v == 0 ? 1 - P : P;       // ... and the set it belongs to
+    constexpr int CS = SPREAD ? 1 - P : 0;                     // the set of tile k - 1
+    // the row group of tile k - 1 combined in this stage (not SPREAD: all rows in the tile's first stage, before view 0 arrives)
+    constexpr int r0 = SPREAD ? v * TY / NV : 0, r1 = SPREAD ? (v + 1) * TY / NV : (v == 0 ? TY : 0);
+    constexpr int NR = r1 - r0 > 0 ? r1 - r0 : 1;
+    const bool live = k < my_tiles;                            // k == my_tiles: only the last tile's hand-off and combine are left
+    const bool comb = k > 0 && r1 > r0;
+    // (1) the hand-off of stage s - 1 and (2) the centre voxels of this stage's rows, requested first: both are consumed at the end
+    // of the stage, and the X loads must be OLDER than the halo requests below (vector-memory results return in order: a wait for a
+    // younger load would wait for the whole halo of the stage after next)
+    // (UNCONDITIONALLY: in the very first stage and in the drain stages behind the last tile the buffer holds stale values, which
+    // land in slots that are assigned again before they are read -- a conditional update would keep both sets alive across the loop)
+    float4 h[TY];
+    const int hb = hread + ((s - 1) & 1) * AB_HBUF;
+    if (SPREAD) {                                              // (not SPREAD: no room for 32 more registers across the staging)
+#pragma unroll
+      for (int t = 0; t < TY; ++t) h[t] = *reinterpret_cast<const float4*>(smem + hb + t * 1024);
+    }
+    const int zo = Tp.z0 + sw, xo = Tp.x0 + r, ty0 = Tp.y0;
+    const bool evox_ok = zo < p.Di && xo < p.Wi;
+    const size_t vo0 = (((size_t)zo * p.Hi + ty0) * p.Wi + xo) * 8 + 2 * q;
+    const size_t vrow = (size_t)p.Wi * 8;
+    float2 xv[SPREAD ? NR : 2][NV];
+    auto request_x = [&](int t, int slot) __attribute__((always_inline)) {
+      const bool ok = evox_ok && ty0 + t < p.Hi;               // rows outside the volume read the zero line
+#pragma unroll
+      for (int n = 0; n < NV; ++n)
+        xv[slot][n] = *reinterpret_cast<const float2*>(ok ? (p.x[n] + (vo0 + t * vrow)) : p.zeros);
+    };
+    if (SPREAD && comb) {
+#pragma unroll
+      for (int t = r0; t < r1; ++t) {
+        const bool ok = evox_ok && ty0 + t < p.Hi;             // rows outside the volume read the zero line
+#pragma unroll
+        for (int n = 0; n < NV; ++n)
+          xv[t - r0][n] = *reinterpret_cast<const float2*>(ok ? (p.x[n] + (vo0 + t * vrow)) : p.zeros);
+      }
+    }
+    if (SPREAD) __builtin_amdgcn_sched_barrier(0);
+    if (live) {
+      // the image of stage s + 1 (requested one stage ago) -> the buffer the multiplying wavefronts read LAST stage
+#ifdef ATVS_AB_DEBUG
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ABDBG(5)
+#endif
+      pf_write(((s + 1) & 1) * AB_BUF);
+      ABDBG(0)
+      // the halo of stage s + 2
+      constexpr int idx = v + 2, dk = idx / NV, vn = idx % NV;
+      pf_request(dk == 0 ? Tk : dk == 1 ? Tk1 : Tk2, p.x[vn]);
+      ABDBG(1)
+    }
+    {
+#pragma unroll
+      for (int t = 0; t < TY; ++t) {
+        if (!SPREAD) h[t] = *reinterpret_cast<const float4*>(smem + hb + t * 1024);      // read where it is consumed
+        if constexpr (vp == 0) { ssx[HS][t] = 0.f + h[t].x; ssy[HS][t] = 0.f + h[t].y; }
+        else { ssx[HS][t] += h[t].x; ssy[HS][t] += h[t].y; }
+        dvx[HS][vp][t] = h[t].z - h[t].x; dvy[HS][vp][t] = h[t].w - h[t].y;
+      }
+      ABDBG(2)
+    }
+    if (comb) {
+      // ---- combine (aanet_combine_kernel's arithmetic and order) of rows r0..r1-1 of tile k - 1, channels 2q, 2q+1
+      // (not SPREAD: 8 rows x NV centre voxels do not fit the registers; they are requested one row ahead of the arithmetic)
+      if (!SPREAD) request_x(r0, 0);
+#pragma unroll
+      for (int t = r0; t < r1; ++t) {
+        if (!SPREAD && t + 1 < r1) request_x(t + 1, (t + 1 - r0) & 1);
+        const bool ok = evox_ok && ty0 + t < p.Hi;
+        float ux[NV], uy[NV];
+#pragma unroll
+        for (int n = 0; n < NV; ++n) { ux[n] = dvx[CS][n][t] + ssx[CS][t]; uy[n] = dvy[CS][n][t] + ssy[CS][t]; }
+        float ox, oy;
+        const int xs = SPREAD ? t - r0 : (t - r0) & 1;
+        atvs_aanet_softmax_sum<NV>(ux, [&](int n) __attribute__((always_inline)) { return xv[xs][n].x; }, &ox);
+        atvs_aanet_softmax_sum<NV>(uy, [&](int n) __attribute__((always_inline)) { return xv[xs][n].y; }, &oy);
+        if (ok) *reinterpret_cast<float2*>(p.out + (vo0 + t * vrow)) = make_float2(ox, oy);
+        if (!SPREAD) __builtin_amdgcn_sched_barrier(0);        // row by row: interleaved rows do not fit the registers beside 8 views' state
+      }
+    }
+    ABDBG(3)
+    if (live) {
+      ab_lds_barrier();
+      ++s;
+    }
+    ABDBG(4)
+  };
+  auto tile_body = [&](auto PP, int k) __attribute__((always_inline)) {
+    if (k > my_tiles) return;
+    if (NV == 1) Tk2 = pf_tile(k + 2);                         // the stage after next lies two tiles ahead only with one view
+    else Tk2 = Tk1;
+    ab_static_for<NV>([&](auto VV) __attribute__((always_inline)) { stage_body(PP, VV, k); });
+    Tp = Tk;
+    Tk = Tk1;
+    Tk1 = pf_tile(k + 2);
+  };
+#pragma unroll 1
+  for (int k = 0; k <= my_tiles; k += SPREAD ? 2 : 1) {
+    tile_body(IC<0>{}, k);
+    if constexpr (SPREAD) tile_body(IC<1>{}, k + 1);
+  }
+#ifdef ATVS_AB_DEBUG
+  if (lane == 0 && blockIdx.x < 256) {
+    dbg_acc[7] = (unsigned long long)nstages;
+    for (int i = 0; i < 8; ++i) atvs_dbg_ab[(blockIdx.x * 8 + wave) * 8 + i] = dbg_acc[i];
+  }
+#endif
 }
 
 template <int NV>
 int launch_ab(const AbArgs& a, long grid, hipStream_t s) {
-  const size_t lds = AB_NP * (size_t)AB_IMG + (size_t)AB_JC * AB_WSTEP;
-  hipLaunchKernelGGL((aanet_b_kernel<NV>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  static std::atomic<bool> attr_set{false};                     // per instantiation; the attribute is idempotent, the flag only saves calls
+  if (!attr_set.load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&aanet_b_kernel<NV>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS) != hipSuccess)
+      return ATVS_ERR_LAUNCH;
+    attr_set.store(true, std::memory_order_release);
+  }
+  hipLaunchKernelGGL((aanet_b_kernel<NV>), dim3((unsigned)grid), dim3(512), AB_LDS, s, a);
   return ATVS_OK;
 }
 
@@ -336,7 +491,7 @@ extern "C" int atvs_aanet_b_pack(const float* w_shared, const float* w_unique, u
 extern "C" int atvs_aanet_b_supported(int C, int nv) { return (C == 8 && nv >= 1 && nv <= AB_MAXV) ? 1 : 0; }
 
 // out (D,H,W,8) = sum_n softmax_n((R_n - S_n) + sum_m S_m) * X_n with S_n | R_n = relu(conv3d(X_n, W_shared | W_unique, SAME)):
-// the AANet module (reference cnn_wrapper/network.py:282-351,378-408) over nv <= 4 views in one launch (more views: the two-launch form).  x: HOST array of nv
+// the AANet module (reference cnn_wrapper/network.py:282-351,378-408) over nv <= 8 views in one launch (more views: the two-launch form).  x: HOST array of nv
 // device pointers, each (D,H,W,8); packed_w: atvs_aanet_b_pack.  Bit for bit atvs_conv_c16b_f32 (shared | unique, ReLU) per
 // view followed by atvs_aanet_combine.
 extern "C" int atvs_aanet_b_f32(const float* const* x, int nv, const unsigned char* packed_w, float* out, int D, int H, int W,
@@ -360,7 +515,17 @@ extern "C" int atvs_aanet_b_f32(const float* const* x, int nv, const unsigned ch
   grid = (grid + 7) / 8 * 8;
   a.wg = (int)grid;
   hipStream_t st = as_stream(stream);
-  const int rc = nv == 1 ? launch_ab<1>(a, grid, st) : nv == 2 ? launch_ab<2>(a, grid, st) : nv == 3 ? launch_ab<3>(a, grid, st) : launch_ab<4>(a, grid, st);
+  int rc = ATVS_ERR_SHAPE;
+  switch (nv) {
+    case 1: rc = launch_ab<1>(a, grid, st); break;
+    case 2: rc = launch_ab<2>(a, grid, st); break;
+    case 3: rc = launch_ab<3>(a, grid, st); break;
+    case 4: rc = launch_ab<4>(a, grid, st); break;
+    case 5: rc = launch_ab<5>(a, grid, st); break;
+    case 6: rc = launch_ab<6>(a, grid, st); break;
+    case 7: rc = launch_ab<7>(a, grid, st); break;
+    case 8: rc = launch_ab<8>(a, grid, st); break;
+  }
   if (rc) return rc;
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;

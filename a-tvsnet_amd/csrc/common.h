@@ -133,6 +133,31 @@ __device__ __forceinline__ void atvs_split4_f16(const float4& v, uint2* h0, uint
   atvs_split2_f16(v.z, v.w, 2048.f, &h0->y, &h1->y);
 }
 
+// The AANet's softmax over views and weighted sum for ONE value (reference cnn_wrapper/network.py:326-406: tf.nn.softmax over the
+// view axis, then sum_n score_n * X_n):  *out = sum_n softmax_n(u)[n] * x(n) = (sum_n e_n x_n) / (sum_n e_n), e_n = e^(u_n - max).
+// ONE definition for aanet_combine_kernel (aanet.hip) and the fused module (aanet_b.hip), which must agree bit for bit.  u[] is
+// overwritten.  Written for FEW vector instructions -- in aanet_b it runs on wavefronts that share their SIMD's issue slots with MFMA
+// wavefronts: e_n = 2^(u_n log2 e - max log2 e) as one fused multiply-add + v_exp_f32 (the rounding of max log2 e is a factor
+// common to every e_n: it cancels in the ratio), numerator and denominator accumulated side by side, ONE v_rcp_f32 (1 ulp) and one
+// multiplication at the end: 5 NV + 3 instructions instead of ~25 NV for expf and NV IEEE divisions; within a few ulp of the exact
+// softmax-weighted sum wherever a term matters (tests: 2e-5 of the output maximum against the oracle).
+template <int NV, class X>
+__device__ __forceinline__ void atvs_aanet_softmax_sum(float* u, X&& x, float* out) {
+  constexpr float L2E = 1.44269504088896340736f;
+  float m = -INFINITY;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) m = fmaxf(m, u[n]);
+  const float ml = m * L2E;
+  float den = 0.f, num = 0.f;
+#pragma unroll
+  for (int n = 0; n < NV; ++n) {
+    const float e = __builtin_amdgcn_exp2f(__builtin_fmaf(u[n], L2E, -ml));
+    den += e;
+    num = __builtin_fmaf(e, x(n), num);
+  }
+  *out = num * __builtin_amdgcn_rcpf(den);
+}
+
 __device__ __forceinline__ float4 blend4(const Tap4& t, float4 a, float4 b, float4 c, float4 d) {
   float4 o;
   o.x = ((t.wa * a.x + t.wb * b.x) + t.wc * c.x) + t.wd * d.x;

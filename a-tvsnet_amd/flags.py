@@ -22,6 +22,7 @@ class _Flags(object):
         self.sample_scale = 0.25
         self.batch_size = 1
         self.inverse_depth = True
+        self.synthetic_weights = False   # not a reference flag: seeded random weights instead of a checkpoint (example.cli)
         # eval_pointcloud.py (reference :31-57; its own defaults for view_num / max_d are set by its cli)
         self.data_root = '../data/'
         self.savepath = '../eval/pointcloud/'

@@ -581,10 +581,11 @@ int atvs_stack(const float* const* srcs, int n, long elems, float* dst, atvs_str
 int atvs_aanet_combine(const float* const* sr_ptrs, const float* const* x_ptrs, int nv, float* out, long V,
                        atvs_stream_t stream);
 
-/* The whole AANet module in ONE launch (aanet_b.hip, round 5): the shared | unique 3x3x3 score convolutions of every view (split
- * fp16 operands, conv_c16b's stage) with their results kept in registers, then the cross-view softmax and weighted sum --
+/* The whole AANet module in ONE launch (aanet_b.hip; round 6: eight wavefronts in two roles -- four multiply, four stage the next
+ * halo and run the softmax of the previous tile beside them): the shared | unique 3x3x3 score convolutions of every view (split
+ * fp16 operands, conv_c16b's K order), their results handed over in LDS, then the cross-view softmax and weighted sum --
  *   out (D,H,W,8) = sum_n softmax_n((R_n - S_n) + sum_m S_m) * X_n,   S_n | R_n = relu(conv3d(X_n, W_shared | W_unique, SAME))
- * (reference cnn_wrapper/network.py:282-351,378-408).  x: HOST array of nv <= 4 device pointers (D,H,W,8) (atvs_aanet_b_supported; more views: the two-launch form); packed_w:
+ * (reference cnn_wrapper/network.py:282-351,378-408).  x: HOST array of nv <= 8 device pointers (D,H,W,8) (atvs_aanet_b_supported; more views: the two-launch form); packed_w:
  * atvs_aanet_b_pack(w_shared, w_unique) (HOST; [3,3,3,8,8] each; size in BYTES).  [S|R] is never written: bit for bit
  * atvs_conv_c16b_f32 (ReLU) per view followed by atvs_aanet_combine. */
 int atvs_aanet_b_supported(int C, int nv);

@@ -603,11 +603,14 @@ def test_skip_add_with_the_residual_base_in_one_pass_bitwise(cuda, G, shape):
         assert torch.equal(y2[g], ops.add_n([base, want[g]]))
 
 
-@pytest.mark.parametrize('nv,shape', [(4, (16, 24, 40)), (2, (9, 13, 35)), (3, (4, 8, 16)), (1, (6, 10, 20)), (4, (5, 9, 17))])
+@pytest.mark.parametrize('nv,shape', [(4, (16, 24, 40)), (2, (9, 13, 35)), (3, (4, 8, 16)), (1, (6, 10, 20)), (4, (5, 9, 17)),
+                                      (5, (12, 16, 48)), (8, (8, 24, 33)), (6, (5, 13, 16)), (7, (9, 12, 20)), (4, (64, 48, 64))])
 def test_aanet_module_in_one_launch_bitwise(cuda, weights, nv, shape):
     """aanet_b.hip: the shared | unique score convolutions of every view and the cross-view softmax + weighted sum (reference
-    cnn_wrapper/network.py:282-351,378-408) as ONE launch with [S|R] in registers -- against the two-launch form (conv_c16b per
-    view + aanet_combine) bit for bit, and against the oracle's attention_aggregation; ragged tiles, 1 to 4 views."""
+    cnn_wrapper/network.py:282-351,378-408) as ONE launch (multiplying + staging / combining wavefronts, [S|R] handed over in LDS)
+    -- against the two-launch form (conv_c16b per view + aanet_combine) bit for bit, and against the oracle's
+    attention_aggregation; ragged tiles, 1 to 8 views (configs[3] has 8 sources), workgroups with two tiles (64 x 48 x 64 = 384 tiles on
+    256 workgroups) and with fewer tiles than workgroups."""
     from atvsnet_amd import ops
     from atvsnet_amd.cnn_wrapper.atvsnet import AttAggregation_keepchannel
     from oracle import nets

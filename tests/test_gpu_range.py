@@ -88,3 +88,85 @@ def test_an_activation_beyond_the_fp16_range_is_reported_and_fp32_kernels_comput
         for n in names:
             store.set(n, saved[n])
         ops.clear_pack_cache()
+
+
+class _overflowing_tower(object):
+    """The seeded weights with one residual unit's conv1 / conv2 kernels scaled by 2000 (legal fp16 weights): r2 of that unit leaves
+    the fp16 range on the split-operand kernels; fp32 kernels and the oracle compute it."""
+    NAMES = ['conv1_x_1/conv1/weights', 'conv1_x_1/conv2/weights']
+
+    def __init__(self, weights):
+        self.weights = weights
+
+    def __enter__(self):
+        from atvsnet_amd import ops, variables
+        self.store = variables.default_store()
+        self.saved = {n: self.weights[n].numpy().copy() for n in self.NAMES}
+        scaled = dict(self.weights)
+        for n in self.NAMES:
+            self.store.set(n, self.saved[n] * 2000.0)
+            scaled[n] = torch.from_numpy(self.saved[n] * 2000.0)
+        ops.clear_pack_cache()
+        return scaled
+
+    def __exit__(self, *exc):
+        from atvsnet_amd import ops
+        for n in self.NAMES:
+            self.store.set(n, self.saved[n])
+        ops.clear_pack_cache()
+        return False
+
+
+def test_the_drivers_return_the_fp32_map_when_the_split_kernels_overflow(cuda, weights, capsys):
+    """VERDICT r5 #4 / reference cnn_wrapper/network.py:165-167,570-601 (fp32 end to end): an fp16-range overflow is not the user's
+    problem.  The eager drivers' guard (example.infer_checked), GraphedInference.checked() and PipelinedInference.result() each
+    recompute THAT map on the fp32 matrix cores in-process and return it: finite, bit for bit the map ops.configure(split16=False)
+    computes, inside the bar against the oracle evaluated with the same weights.  The plain split path on these weights does set
+    the flag (else this test would test nothing)."""
+    from atvsnet_amd import ops, synthetic
+    from atvsnet_amd.atvsnet import example as ex
+    from oracle import model as OM
+    imgs, cams = synthetic.make_inputs(2, 128, 160, 32)
+    imgs_t, cams_t = torch.from_numpy(imgs), torch.from_numpy(cams)
+    di, dc = imgs_t.to(cuda), cams_t.to(cuda)
+    with _overflowing_tower(weights) as scaled:
+        want = OM.run_twoview(imgs_t, cams_t, scaled, 32)
+        assert bool(torch.isfinite(want).all())
+        ops.nonfinite_seen(cuda)
+        ex.infer_twoview(di, dc, 32)
+        assert ops.nonfinite_seen(cuda), 'the scaled weights no longer overflow the split-operand towers'
+        with ops.configure(split16=False):
+            fp32 = ex.infer_twoview(di, dc, 32).cpu()
+        assert not ops.nonfinite_seen(cuda) and bool(torch.isfinite(fp32).all())
+        err = float(((fp32 - want).abs() / want.abs()).mean())
+        print('fp32 kernels vs the oracle on the overflowing weights: rel-L1 %.2e' % err)
+        assert err <= 1e-3
+        # (1) the eager drivers' guard
+        ex._fallback_logged[0] = False
+        got = ex.infer_checked(lambda: ex.infer_twoview(di, dc, 32), cuda).cpu()
+        assert torch.equal(got, fp32)
+        assert 'recomputed on the fp32 matrix cores' in capsys.readouterr().out
+        assert ops.cfg.split16 == (ops.Config._DEFAULTS['split16'])            # the switch is restored
+        # (2) a captured graph
+        g = ex.GraphedInference(di, dc, 32)
+        ops.nonfinite_seen(cuda)
+        assert torch.equal(g.checked().cpu(), fp32)
+        assert g._fp32 is not None and not g._fp32.split16
+        assert torch.equal(g.checked(di, dc).cpu(), fp32)                       # second time: the fallback graph is replayed
+        # (3) the queue
+        p = ex.PipelinedInference(di, dc, 32, slots=2)
+        ops.nonfinite_seen(cuda)
+        t0 = p.submit(di, dc)
+        t1 = p.submit(di, dc)
+        assert torch.equal(p.result(t0).cpu(), fp32)
+        assert torch.equal(p.result(t1).cpu(), fp32)
+        # (4) what the fp32 kernels cannot compute either is still an error, not a map
+        bad = di.clone()
+        bad[0, 0, 5, 7, 1] = float('nan')
+        with pytest.raises(FloatingPointError, match='fp32 kernels'):
+            ex.infer_checked(lambda: ex.infer_twoview(bad, dc, 32), cuda)
+    # with the seeded weights nothing falls back
+    ops.nonfinite_seen(cuda)
+    g2 = ex.GraphedInference(di, dc, 32)
+    g2.checked()
+    assert g2._fp32 is None

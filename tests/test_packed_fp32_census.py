@@ -21,7 +21,7 @@ from atvsnet_amd import _lib
 
 OBJDUMP = '/opt/rocm/lib/llvm/bin/llvm-objdump'
 # kernels that reserve the whole register file of their SIMD (asm volatile("" ::: "v255", "a255")): nothing runs beside them
-OWNS_ITS_SIMD = ('conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel', 'aanet_b_kernel')
+OWNS_ITS_SIMD = ('conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel')
 # fp32-MFMA predecessors (A/B path, ops.configure(split16=False)): one workgroup per CU with 450-512 registers; packed fp32 by design
 FP32_ONE_WORKGROUP = ('conv_xw_kernel', 'deconv_up_kernel', 'conv_c16_kernel')
 # FMA-bound kernels with hand-written packed FMAs that share their SIMDs: the reason PipelinedInference(co_resident=True) is opt-in
@@ -62,6 +62,8 @@ def test_packed_fp32_only_where_it_is_accounted_for(tmp_path):
         assert 'conv2d_b_kernel' not in k and 'conv1x1_b_kernel' not in k and 'bottleneck_b_kernel' not in k, k
     # conv_xb's staging wavefronts compute (batch norm, operand split) beside its own MFMA wavefronts on the same SIMD: scalar fp32 only
     assert not any('conv_xb_kernel' in k for k in counts), [k for k in counts if 'conv_xb_kernel' in k]
+    # aanet_b (round 6): the same constellation -- staging / softmax wavefronts beside its own MFMA wavefronts
+    assert not any('aanet_b_kernel' in k for k in counts), [k for k in counts if 'aanet_b_kernel' in k]
     # deconv_up_b: two workgroups per CU, wavefronts of the same kernel share SIMDs
     assert not any('deconv_up_b_kernel' in k for k in counts), [k for k in counts if 'deconv_up_b_kernel' in k]
     # the geometry / soft-argmin / norm kernels (the round-3 victims) are scalar
