@@ -139,7 +139,7 @@ def lib():
         _lib.atvs_avg_pool_ws_floats.restype = ctypes.c_long
         _lib.atvs_conv_tiled_num_blocks.restype = ctypes.c_long
         _lib.atvs_conv_tiled_grid.restype = ctypes.c_long
-        _lib.atvs_conv_xp_grid.restype = ctypes.c_long
+        _lib.atvs_conv_xpair_grid.restype = ctypes.c_long
         _lib.atvs_conv2d_lds_rows.restype = ctypes.c_long
         _lib.atvs_conv_stem_rows.restype = ctypes.c_long
         _lib.atvs_conv1x1_rows.restype = ctypes.c_long

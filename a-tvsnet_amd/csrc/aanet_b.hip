@@ -29,7 +29,6 @@
 // order from 0.f, U_n = (R_n - S_n) + S_sum): bit for bit the two launches.
 // Scalar fp32 arithmetic (-fno-slp-vectorize): the staging wavefronts compute beside the kernel's own 16x16x32 MFMA wavefronts
 // (DESIGN.md appendix B); two wavefronts of 256 registers per SIMD: no other kernel's wavefront fits beside them.
-#include <atomic>
 #include <cstring>
 #include <type_traits>
 #include <utility>
@@ -439,12 +438,8 @@ __global__ __launch_bounds__(512, 1) void aanet_b_kernel(AbArgs p) {
 
 template <int NV>
 int launch_ab(const AbArgs& a, long grid, hipStream_t s) {
-  static std::atomic<bool> attr_set{false};                     // per instantiation; the attribute is idempotent, the flag only saves calls
-  if (!attr_set.load(std::memory_order_acquire)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&aanet_b_kernel<NV>), hipFuncAttributeMaxDynamicSharedMemorySize, AB_LDS) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set.store(true, std::memory_order_release);
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(&aanet_b_kernel<NV>), AB_LDS)) return rc_;
   hipLaunchKernelGGL((aanet_b_kernel<NV>), dim3((unsigned)grid), dim3(512), AB_LDS, s, a);
   return ATVS_OK;
 }

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/atvsnet_hip.h"
 
 #define ATVS_LAUNCH_CHECK()                                   \
@@ -12,6 +14,23 @@
   } while (0)
 
 static inline hipStream_t as_stream(atvs_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) ONCE per (kernel instantiation, device ordinal of this process).  The entry points
+// are re-entrant per stream and may be called from several host threads (include/atvsnet_hip.h): the flags are atomics -- a thread
+// reads `true` (acquire) only after the call it stands for has returned (release); two threads that race on a clear flag both make
+// the (idempotent) call.  No other process-global state exists behind the ABI.
+struct AtvsAttrOnce {
+  std::atomic<bool> done[64];
+};
+static inline int atvs_set_max_lds_once(AtvsAttrOnce& once, const void* kernel, int bytes) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
+  if (!once.done[dev].load(std::memory_order_acquire)) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return ATVS_ERR_LAUNCH;
+    once.done[dev].store(true, std::memory_order_release);
+  }
+  return ATVS_OK;
+}
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

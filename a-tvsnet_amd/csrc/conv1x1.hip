@@ -161,15 +161,8 @@ int launch_c1(const C1Args& a, int groups, hipStream_t s) {
   size_t lds = (size_t)(a.Cin / 16) * NT * 64 * sizeof(float4);
   const size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double);
   if (lds < red) lds = red;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            80 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv1x1_kernel<NT>), 80 * 1024)) return rc_;
   const long blocks = (long)a.wgs * groups;
   if (blocks > 0x7fffffffL) return ATVS_ERR_SHAPE;
   hipLaunchKernelGGL((conv1x1_kernel<NT>), dim3((unsigned)blocks), dim3(256), lds, s, a);

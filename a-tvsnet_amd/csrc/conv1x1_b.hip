@@ -308,7 +308,7 @@ extern "C" int atvs_conv1x1_b_pack(const float* w, int Cin, int Cout, unsigned c
 }
 
 // Same contract as atvs_conv1x1_f32 except the statistics rows (atvs_conv1x1_b_rows: 128 pixels per workgroup) and the weights
-// (atvs_conv1x1_b_pack); split-bf16 operands, fp32-class results.
+// (atvs_conv1x1_b_pack); split-fp16 operands, fp32-class results.
 extern "C" int atvs_conv1x1_b_f32(const float* x, const unsigned char* packed_w, const float* bias, const float* residual,
                                   const float* in_params, int in_relu, float* y, double* stats_partial, int groups, long pixels,
                                   int Cin, int Cout, int ldy, int y_coff, int relu, atvs_stream_t stream) {

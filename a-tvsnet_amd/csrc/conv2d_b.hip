@@ -423,7 +423,7 @@ extern "C" int atvs_conv2d_b_pack(const float* w, int Cin, int Cout, unsigned ch
   return fits ? ATVS_OK : ATVS_ERR_ARG;
 }
 
-// Same contract as atvs_conv2d_lds_f32 (shapes, statistics rows = atvs_conv2d_lds_rows) with split-bf16 operands; weights from
+// Same contract as atvs_conv2d_lds_f32 (shapes, statistics rows = atvs_conv2d_lds_rows) with split-fp16 operands; weights from
 // atvs_conv2d_b_pack.  fp32-class results; rounding differs from the fp32 MFMA form.
 namespace {
 int c2b_run(const float* x, const unsigned char* packed_w, const float* bias, const float* residual, const float* in_params,

@@ -382,15 +382,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
 template <int NT, bool NORM>
 int launch_c3b(const C3bArgs& a, long grid, hipStream_t s) {
   const size_t lds = C3B_NP * (size_t)C3B_IMG + (NORM ? 3 * (size_t)a.Cin * 4 : 0);
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_b_kernel<NT, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv3d_b_kernel<NT, NORM>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((conv3d_b_kernel<NT, NORM>), dim3((unsigned)(grid * a.nhalf)), dim3(256), lds, s, a);
   return ATVS_OK;
 }

@@ -383,15 +383,8 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
 template <int NT, bool WLDS, bool NORM>
 int launch_s2b(const S2Args& a, long grid, hipStream_t s) {
   const size_t lds = S2_NP * (size_t)S2_IMG + (WLDS ? (size_t)a.nchunk * S2_JC * NT * S2_NP * 1024 : 0);
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv3d_s2b_kernel<NT, WLDS, NORM>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv3d_s2b_kernel<NT, WLDS, NORM>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((conv3d_s2b_kernel<NT, WLDS, NORM>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }

@@ -354,15 +354,8 @@ template <int C4, int NT, bool RELU>
 int launch_c16(const C16Args& a, long grid, atvs_stream_t stream) {
   const size_t lds = (size_t)C16<C4>::IMG + (NT == 1 ? (size_t)a.nchunk * C16<C4>::WCH : 0);
   // the attribute is per device: one flag per device ordinal of this process (and per instantiation)
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_kernel<C4, NT, RELU>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv_c16_kernel<C4, NT, RELU>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((conv_c16_kernel<C4, NT, RELU>), dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
   return ATVS_OK;
 }

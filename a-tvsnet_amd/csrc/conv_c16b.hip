@@ -418,15 +418,8 @@ namespace {
 template <int CIN, bool RELU, int PRO = 0>
 int launch_c16b(const B16Args& a, long grid, hipStream_t s) {
   const size_t lds = B16_NP * (size_t)B16<CIN>::IMG + (size_t)B16<CIN>::JC * B16_WSTEP;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16b_kernel<CIN, RELU, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv_c16b_kernel<CIN, RELU, PRO>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((conv_c16b_kernel<CIN, RELU, PRO>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }

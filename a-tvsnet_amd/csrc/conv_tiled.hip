@@ -788,16 +788,8 @@ static int launch_tiled(const TiledArgs& a, long blocks, hipStream_t s) {
   size_t red = (size_t)4 * 2 * NT * 16 * sizeof(double) + 16;
   if (red < 256 * sizeof(double)) red = 256 * sizeof(double);
   if (lds < red) lds = red;
-  // the attribute is per device: one flag per device ordinal of this process
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((conv_tiled_f32_kernel<NT, TY, C4, FULL, XP>), dim3((unsigned)(blocks * a_groups(a))), dim3(256), lds, s, a);
   return ATVS_OK;
 }

@@ -817,15 +817,8 @@ long xb_ntiles(int D, int H, int W) {
 template <bool SIB, int PRO, bool WS, bool PIECES = false>
 int launch_xb(const XbArgs& a, long blocks, hipStream_t s) {
   const size_t lds = XB_LDS;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xb_kernel<SIB, PRO, WS, PIECES>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv_xb_kernel<SIB, PRO, WS, PIECES>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((conv_xb_kernel<SIB, PRO, WS, PIECES>), dim3((unsigned)blocks), dim3(512), lds, s, a);
   return ATVS_OK;
 }
@@ -904,7 +897,7 @@ extern "C" int atvs_conv_xb_pack_sibling(const float* w2, int Cin, unsigned char
 }
 
 // Same contract as atvs_conv_xw_f32 (x_planar included), weights packed by atvs_conv_xb_pack[_sibling]; grid and statistics
-// rows = atvs_conv_xp_grid.  fp32-class results (split-bf16 operands, fp32 accumulation); rounding differs from the fp32 forms.
+// rows = atvs_conv_xpair_grid.  fp32-class results (split-fp16 operands, fp32 accumulation); rounding differs from the fp32 forms.
 // Beyond atvs_conv_xw_f32: x_planar may come WITH in_params (one pending batch norm, the refinement's chunk-planar concat;
 // not with x2), and y_group_stride != 0 = floats between the samples of y (default D*H*W*ldy): the photo stem writes
 // plane 0 of each sample's chunk-planar concat (ldy = 8, y_group_stride = 4 * plane stride).
@@ -945,7 +938,7 @@ extern "C" int atvs_conv_xb_f32(const float* x, const unsigned char* packed_w, c
   a.wp2 = reinterpret_cast<const f16x8*>(packed_w2); a.pbias2 = plane_bias2; a.y2 = y2; a.stats2 = stats_partial2;
   a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
   a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;
-  a.wg = (int)atvs_conv_xp_grid(D, H, W, groups);
+  a.wg = (int)atvs_conv_xpair_grid(D, H, W, groups);
   a.gx = x_planar ? x_planar * (Cin / 8) : (long)D * H * W * Cin; a.gy = y_group_stride ? y_group_stride : (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
   a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
   const long blocks = (long)a.wg * groups;

@@ -553,15 +553,8 @@ long xw_ntiles(int D, int H, int W) {
 template <bool SIB, int PRO>
 int launch_xw(const XwArgs& a, long blocks, hipStream_t s) {
   const size_t lds = 2 * (size_t)XW_IMG;
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_xw_kernel<SIB, PRO>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(conv_xw_kernel<SIB, PRO>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((conv_xw_kernel<SIB, PRO>), dim3((unsigned)blocks), dim3(256), lds, s, a);
   return ATVS_OK;
 }
@@ -570,7 +563,7 @@ int launch_xw(const XwArgs& a, long blocks, hipStream_t s) {
 
 // workgroups PER SAMPLE of an x-pair launch (atvs_conv_xw_f32 / atvs_conv_xb_f32) over `groups` independent samples (rows of the
 // statistics buffer = groups * this): one workgroup per CU in all, shared out among the samples, a multiple of 8 each
-extern "C" long atvs_conv_xp_grid(int D, int H, int W, int groups) {
+extern "C" long atvs_conv_xpair_grid(int D, int H, int W, int groups) {
   if (groups < 1) groups = 1;
   long nt = xw_ntiles(D, H, W);
   long share = 256 / groups / 8 * 8;
@@ -646,7 +639,7 @@ extern "C" int atvs_conv_xw_pack_sibling(const float* w2, int Cin, float* packed
 }
 
 // Same contract as atvs_conv_xp_f32 (include/atvsnet_hip.h) with weights packed by atvs_conv_xw_pack[_sibling]; grid and
-// statistics rows = atvs_conv_xp_grid.  Results differ from the direct sum by fp32 rounding only (F(2,3) along y).
+// statistics rows = atvs_conv_xpair_grid.  Results differ from the direct sum by fp32 rounding only (F(2,3) along y).
 extern "C" int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias,
                                 float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,
                                 int relu, const float* packed_w2, const float* plane_bias2, float* y2,
@@ -678,7 +671,7 @@ extern "C" int atvs_conv_xw_f32(const float* x, const float* packed_w, const flo
   a.wp2 = packed_w2; a.pbias2 = plane_bias2; a.y2 = y2; a.stats2 = stats_partial2;
   a.Do2 = (D + 1) / 2; a.Ho2 = (H + 1) / 2; a.Wo2 = (W + 1) / 2; a.ldy2 = ldy2; a.ycoff2 = y_coff2;
   a.pbz = D & 1; a.pby = H & 1; a.pbx = W & 1;
-  a.wg = (int)atvs_conv_xp_grid(D, H, W, groups);
+  a.wg = (int)atvs_conv_xpair_grid(D, H, W, groups);
   a.gx = x_planar ? x_planar * (Cin / 8) : (long)D * H * W * Cin; a.gy = (long)D * H * W * ldy; a.gpb = (long)H * W * 24;
   a.gy2 = (long)a.Do2 * a.Ho2 * a.Wo2 * ldy2; a.gpb2 = (long)a.Ho2 * a.Wo2 * 48;
   const long blocks = (long)a.wg * groups;

@@ -378,15 +378,8 @@ template <int COUT, bool SINGLE, bool RELU>
 int launch_up(const UpArgs& a, long grid, atvs_stream_t stream) {
   const size_t lds = (size_t)Up<COUT>::IMG + (size_t)a.nchunk * Up<COUT>::WCH;
   // the attribute is per device: one flag per device ordinal of this process (and per instantiation)
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_up_kernel<COUT, SINGLE, RELU>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(deconv_up_kernel<COUT, SINGLE, RELU>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((deconv_up_kernel<COUT, SINGLE, RELU>), dim3((unsigned)grid), dim3(256), lds, as_stream(stream), a);
   return ATVS_OK;
 }

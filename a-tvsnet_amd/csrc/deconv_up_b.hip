@@ -558,15 +558,8 @@ bool ub_stream(int Cin, int Cout) { return Cout == 16 && ub_lds(Cin, Cout) > ATV
 
 template <int COUT, bool STREAMW, bool PRO = false>
 int launch_upb(const UpBArgs& a, long grid, size_t lds, hipStream_t s) {
-  static bool attr_set[64] = {};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return ATVS_ERR_LAUNCH;
-  if (!attr_set[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(deconv_up_b_kernel<COUT, STREAMW, PRO>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            160 * 1024) != hipSuccess)
-      return ATVS_ERR_LAUNCH;
-    attr_set[dev] = true;
-  }
+  static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(deconv_up_b_kernel<COUT, STREAMW, PRO>), 160 * 1024)) return rc_;
   hipLaunchKernelGGL((deconv_up_b_kernel<COUT, STREAMW, PRO>), dim3((unsigned)grid), dim3(256), lds, s, a);
   return ATVS_OK;
 }

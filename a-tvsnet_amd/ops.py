@@ -582,7 +582,7 @@ def pack_conv_xp(key, w_host, device):
 
 
 def pack_deconv_up(key, w_host, device, kind=''):
-    """Packed weights of the 8- / 16-channel transposed-convolution kernels (atvs_deconv_up_f32; kind '_b': the split-bf16
+    """Packed weights of the 8- / 16-channel transposed-convolution kernels (atvs_deconv_up_f32; kind '_b': the split-fp16
     atvs_deconv_up_b_f32, bytes of fp16 pieces); cached."""
     import numpy as np
     ck = ('up' + kind, key, str(device))
@@ -812,7 +812,7 @@ def pack_conv2d_lds(key, w_host, device):
     import numpy as np
     w = np.ascontiguousarray(w_host, dtype=np.float32)
     cin, cout = int(w.shape[-2]), int(w.shape[-1])
-    split = split_on('c2b') and cin % 32 == 0      # conv2d_b.hip: split-bf16 operands (its chunk loop runs in pairs)
+    split = split_on('c2b') and cin % 32 == 0      # conv2d_b.hip: split-fp16 operands (its chunk loop runs in pairs)
     kind = 'b' if split else 'lds'
     ck = ('c2' + kind, key, str(device))
     pk = _pack_cache.get(ck)
@@ -1011,7 +1011,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
     if pk2 is not None and pk2.kind != kind:
         raise ValueError('conv_xp: the main and the sibling weights are packed for different kernels')
     if (y_gstride or (planar and prologue is not None)) and kind != 'xb':
-        raise ValueError('conv_xp: a strided output / a prologue over a chunk-planar input belong to the split-bf16 kernel')
+        raise ValueError('conv_xp: a strided output / a prologue over a chunk-planar input belong to the split-fp16 kernel')
     if _dev_ok(x5, y, bias, plane_bias, y2, pb2, x2, ipa, ipb):
         with _Timed(pk.key, (D, H, W, Cin), pk.cout + (16 if pk2 is not None else 0), G):
             yp = ctypes.c_void_p(y.data_ptr() + 4 * int(y_off))     # y_off: floats into a chunk-planar buffer (with ldy / y_gstride)
@@ -1028,7 +1028,7 @@ def conv_xp_launch(x5, pk, y, y_coff, bias=None, relu=False, stats_buf=None, pla
 
 def xp_blocks(D, H, W, groups=1):
     """Workgroups per sample of an x-pair launch."""
-    return int(_lib.lib().atvs_conv_xp_grid(int(D), int(H), int(W), int(groups)))
+    return int(_lib.lib().atvs_conv_xpair_grid(int(D), int(H), int(W), int(groups)))
 
 
 
@@ -1462,7 +1462,7 @@ def conv(x, key, w_host, stride=1, dilation=1, padding='SAME', explicit_pad=None
         y = out if out is not None else _from5(y5, nsp, groups)
         return (y, st) if want_stats else y
 
-    # ---- 3-D, 3x3x3, stride 2, SAME, 16 k -> 32 / 64 channels: the U-Net encoders below half resolution on split-bf16 operands
+    # ---- 3-D, 3x3x3, stride 2, SAME, 16 k -> 32 / 64 channels: the U-Net encoders below half resolution on split-fp16 operands
     if s2b:
         pk = pack_conv3d_b(key, w_host, x.device, kind='s2b')
         if y5 is None:
@@ -1659,7 +1659,7 @@ def conv_split(sv, key, w_host, stride=1, want_stats=False, out=None, y_coff=0):
 
 def planar_concat_ok(shape):
     """(D,h,w): should CostVolRefineNet's concat be chunk-planar?  Only when both its producer (the photo stem) and its
-    consumer run on the split-bf16 x-pair kernel, which writes / reads planes."""
+    consumer run on the split-fp16 x-pair kernel, which writes / reads planes."""
     D, h, w = (int(v) for v in shape)
     return (cfg.planar_concat and cfg.planar and _xkind() == 'xb' and cfg.prologue and cfg.force_impl is None
             and siblings_ok((D, h, w), 32, 8, 16) and 4.0 * 4 * planar_stride(D, h, w) < 2.0 ** 40)
@@ -1685,7 +1685,7 @@ def conv_split_into_plane(sv, key, w_host, buf, plane, planar):
     pb = conv(sv.const, (key, 'planes'), planes, stride=1, groups=B)                   # (B, h, w, 24)
     pk = pack_conv_xp((key, 'var'), wv, buf.device)
     if pk.kind != 'xb':
-        raise ValueError('conv_split_into_plane: the split-bf16 x-pair kernel only')
+        raise ValueError('conv_split_into_plane: the split-fp16 x-pair kernel only')
     blocks = xp_blocks(D, H, W, B)
     sbuf = _stats_buffer(buf, blocks, 16, groups=B)
     st = Stats()
@@ -1766,7 +1766,7 @@ def conv_siblings(x, key, w_host, key2, w2_host, plane_bias=None, plane_bias2=No
         if (prologue is not None and _xkind() != 'xb') or groups is None or x.dim() != 3 \
                 or not x.is_contiguous() or x.shape[2] != planar_stride(D, H, W):
             raise ValueError('conv_siblings(planar=(D,H,W)): a contiguous (G, Cin/8, planar_stride) buffer (a prologue only '
-                             'on the split-bf16 kernel)')
+                             'on the split-fp16 kernel)')
         G, K = x.shape[:2]
         x5, nsp, cin = x, 3, K * 8
     else:
@@ -1912,7 +1912,7 @@ def conv3d_transpose_s2(x, key, w_host, relu=False, want_stats=False, groups=Non
         return (y, st) if want_stats else y
     if cout == 32 and cfg.deconv_up and split_on('upb') and cfg.force_impl is None and 32.0 * M * cout < 2.0 ** 32 \
             and bool(_lib.lib().atvs_deconv_up_b_supported(int(Cin), 16)):
-        # the 64 -> 32 layer (conv_b*_4_0) as two 16-channel launches of the split-bf16 kernel into the halves of y
+        # the 64 -> 32 layer (conv_b*_4_0) as two 16-channel launches of the split-fp16 kernel into the halves of y
         import numpy as np
         blocks = int(_lib.lib().atvs_deconv_up_b_grid(int(D), int(H), int(W), 16, int(G)))
         st, sbuf = None, None

@@ -25,6 +25,8 @@ every xGMI link busy at once, and no second pass over the local volumes.  The X_
 convolution is issued, so their transfer overlaps it.
 """
 import numpy as np
+import warnings
+
 import torch
 import torch.distributed as dist
 
@@ -363,12 +365,21 @@ class ShardedGraphedInference(object):
             item = None
             # thread_local: the RCCL watchdog thread polls its events (hipEventQuery) while this thread captures;
             # in the default global mode that call is "not permitted when stream is capturing" and aborts the process
-            with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
-                try:
-                    item = next(gen)
-                except StopIteration as e:
-                    self.out, done = e.value, True
-            self.graphs.append(g)
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter('always')
+                with torch.cuda.graph(g, pool=pool, capture_error_mode='thread_local'):
+                    try:
+                        item = next(gen)
+                    except StopIteration as e:
+                        self.out, done = e.value, True
+            # a segment that only allocates (the receive buffers between the depth-view all-reduce and the first AANet's first
+            # exchange) captures NO node: torch says so in a warning at capture_end -- the exact signal -- and such a segment is
+            # kept as None (its slot in the chain stays: graphs[i] is followed by colls[i]) instead of being replayed per map
+            empty = any('Graph is empty' in str(w.message) for w in caught)
+            for w in caught:
+                if 'Graph is empty' not in str(w.message):
+                    warnings.warn_explicit(w.message, w.category, w.filename, w.lineno)
+            self.graphs.append(None if empty else g)
             if not done:
                 # during capture nothing ran: the tensors hold whatever the pool had; performing the step keeps the
                 # ranks' communication sequences aligned and is repeated, on real data, in every replay
@@ -389,7 +400,8 @@ class ShardedGraphedInference(object):
         if cams is not None:
             self.cams.copy_(cams)
         for i, g in enumerate(self.graphs):
-            g.replay()
+            if g is not None:
+                g.replay()
             if i < len(self.colls):
                 self._comm(self.colls[i])
         return self.out
@@ -402,7 +414,8 @@ class ShardedGraphedInference(object):
         marks[0].record()
         kinds = []
         for i, g in enumerate(self.graphs):
-            g.replay()
+            if g is not None:
+                g.replay()
             m = ev()
             m.record()
             marks.append(m)

@@ -36,7 +36,7 @@ enum {
 
 /* ABI version of this header (bumped on any signature change).  atvs_abi_version() returns the value the library
  * was compiled with; the loader (a-tvsnet_amd/_lib.py) refuses a library whose version differs from this header's. */
-#define ATVS_ABI_VERSION 42
+#define ATVS_ABI_VERSION 43
 int atvs_abi_version(void);
 /* "gfx950" -- the only code object in the library. */
 const char* atvs_target_arch(void);
@@ -268,7 +268,7 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
  * operands on the 16-bit matrix cores: the product's kernel) and conv_xw.hip (fp32 matrix cores, Winograd F(2,3) along y:
  * the A/B form, ops.configure(split16=False)).
  *   atvs_conv_x{w,b}_pack_size / _pack  HOST: pack the TF kernel [3,3,3,Cin,8] (upload the result)
- *   atvs_conv_xp_grid                   workgroups of a launch PER SAMPLE = rows of stats_partial per sample ([2][16] doubles
+ *   atvs_conv_xpair_grid                   workgroups of a launch PER SAMPLE = rows of stats_partial per sample ([2][16] doubles
  *                                       each, columns 0..7 = channels, the layout atvs_bn_finalize takes with cpad 16)
  *   atvs_conv_x{w,b}_f32                y (D,H,W,ldy)[..., y_coff + co] = conv(x) (+ bias, + plane_bias (H,W,24), ReLU)
  * Sibling: the U-Nets feed the same tensor to conv_b*_0_1 (8 channels, stride 1) and to the encoder branch
@@ -283,7 +283,7 @@ int atvs_conv_tiled_f32(const float* x, const float* packed_w, const int32_t* ta
  * U-Net's skip add (network.py:695-697) formed while the halo is staged.  Out-of-volume taps stay zero.  Built for the
  * shapes the path has: in_params with Cin % 16 == 0 and a sibling; x2 with a sibling and Cin % 16 == 8 (conv_xw) /
  * Cin == 8 (conv_xb) -- else ATVS_ERR_ARG / ATVS_ERR_SHAPE. */
-long atvs_conv_xp_grid(int D, int H, int W, int groups);
+long atvs_conv_xpair_grid(int D, int H, int W, int groups);
 
 /* The fp32 form, conv_xw.hip: x-pair rows x minimal filtering F(2,3) along y -- two output rows from 4 products per
  * (kd, x offset, channel) instead of 6.  The filter transform

@@ -1,4 +1,4 @@
-"""16 -> 16 channel 3x3x3 convolution (conv_b*_1_1: 8 volumes of 96x64x80): fp32 MFMA (conv_c16.hip) vs split-bf16 (conv_c16b.hip),
+"""16 -> 16 channel 3x3x3 convolution (conv_b*_1_1: 8 volumes of 96x64x80): fp32 MFMA (conv_c16.hip) vs split-fp16 (conv_c16b.hip),
 time and error against a float64 reference on a sub-volume."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -13,7 +13,7 @@ for cin, G, D, H, W in ((16, 8, 96, 64, 80), (8, 4, 192, 128, 160)):
   x = torch.randn(G, D, H, W, cin, device=dev)
   w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, 16)) * 0.1).astype(np.float32)
   ref = T.conv(x[:1, :12].cpu().double(), torch.from_numpy(w).double(), 1, 'SAME')[0, 1:-1]
-  for name, flag in (('fp32 MFMA (conv_c16)', False), ('split bf16 x3 (conv_c16b)', True)):
+  for name, flag in (('fp32 MFMA (conv_c16)', False), ('split fp16 x2 (conv_c16b)', True)):
     ops.cfg.split16 = flag
     ops.clear_pack_cache()
     run = lambda: ops.conv(x, ('b', cin), w, want_stats=True, groups=G, relu=(cin == 8))      # noqa: E731

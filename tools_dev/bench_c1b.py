@@ -1,4 +1,4 @@
-"""1x1 tower convolutions, 5 images of 128x160 per launch: fp32 MFMA (conv1x1.hip) vs split-bf16 (conv1x1_b.hip)."""
+"""1x1 tower convolutions, 5 images of 128x160 per launch: fp32 MFMA (conv1x1.hip) vs split-fp16 (conv1x1_b.hip)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +10,7 @@ G, H, W = 5, 128, 160
 for cin, cout in ((128, 128), (128, 32), (32, 128), (64, 128), (64, 64), (32, 64)):
     x = torch.randn(G, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((1, 1, cin, cout)) * 0.05).astype(np.float32)
-    for name, flag in (('fp32', False), ('split-bf16', True)):
+    for name, flag in (('fp32', False), ('split-fp16', True)):
         ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv1x1(x, ('b', cin, cout), w, want_stats=True)      # noqa: E731

@@ -1,4 +1,4 @@
-"""3x3 tower convolutions, 5 images of 128x160 per launch: fp32 MFMA (conv2d_lds.hip) vs split-bf16 (conv2d_b.hip)."""
+"""3x3 tower convolutions, 5 images of 128x160 per launch: fp32 MFMA (conv2d_lds.hip) vs split-fp16 (conv2d_b.hip)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,7 +10,7 @@ G, H, W = 5, 128, 160
 for cin, cout, dil in ((128, 128, 2), (128, 128, 4), (320, 128, 1), (64, 64, 1), (32, 32, 1)):
     x = torch.randn(G, H * (2 if cout == 32 else 1), W * (2 if cout == 32 else 1), cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, cin, cout)) * 0.05).astype(np.float32)
-    for name, flag in (('fp32', False), ('split-bf16', True)):
+    for name, flag in (('fp32', False), ('split-fp16', True)):
         ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv2d_lds(x, ('b', cin, cout, dil), w, dil, want_stats=True)      # noqa: E731

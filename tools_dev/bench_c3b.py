@@ -1,4 +1,4 @@
-"""Quarter- / eighth-resolution 3x3x3 layers, 8 volumes per launch: fp32 MFMA (conv_c16.hip / conv_mfma.hip) vs split-bf16 (conv3d_b.hip)."""
+"""Quarter- / eighth-resolution 3x3x3 layers, 8 volumes per launch: fp32 MFMA (conv_c16.hip / conv_mfma.hip) vs split-fp16 (conv3d_b.hip)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,7 @@ dev = torch.device('cuda:0')
 for G, D, H, W, cin, cout in ((8, 48, 32, 40, 32, 32), (4, 48, 32, 40, 32, 32), (8, 24, 16, 20, 64, 64), (4, 24, 16, 20, 64, 64)):
     x = torch.randn(G, D, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, cout)) * 0.05).astype(np.float32)
-    for name, flag in (('fp32', False), ('split-bf16', True)):
+    for name, flag in (('fp32', False), ('split-fp16', True)):
         ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv(x, ('b', cin, cout), w, want_stats=True, groups=G)      # noqa: E731
@@ -28,7 +28,7 @@ for G, D, H, W, cin, cout in ((8, 48, 32, 40, 32, 32), (4, 48, 32, 40, 32, 32), 
 for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 32), (4, 96, 64, 80, 16, 32), (8, 48, 32, 40, 32, 64), (4, 48, 32, 40, 32, 64)):
     x = torch.randn(G, D, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, 3, cin, cout)) * 0.05).astype(np.float32)
-    for name, flag in (('fp32', False), ('split-bf16', True)):
+    for name, flag in (('fp32', False), ('split-fp16', True)):
         ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv(x, ('s', cin, cout), w, stride=2, want_stats=True, groups=G)      # noqa: E731

@@ -1,4 +1,4 @@
-"""The transposed convolutions to 8 / 16 channels: fp32 MFMA (deconv_up.hip) vs split-bf16 (deconv_up_b.hip)."""
+"""The transposed convolutions to 8 / 16 channels: fp32 MFMA (deconv_up.hip) vs split-fp16 (deconv_up_b.hip)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,7 +9,7 @@ dev = torch.device('cuda:0')
 for G, D, H, W, cin, cout in ((8, 96, 64, 80, 16, 8), (4, 96, 64, 80, 16, 8), (8, 48, 32, 40, 32, 16), (4, 48, 32, 40, 32, 16), (8, 24, 16, 20, 64, 32), (4, 24, 16, 20, 64, 32)):
     x = torch.randn(G, D, H, W, cin, device=dev)
     w = (np.random.default_rng(0).standard_normal((3, 3, 3, cout, cin)) * 0.05).astype(np.float32)
-    for name, flag in (('fp32', False), ('split-bf16', True)):
+    for name, flag in (('fp32', False), ('split-fp16', True)):
         ops.cfg.split16 = flag
         ops.clear_pack_cache()
         run = lambda: ops.conv3d_transpose_s2(x, ('u', cin, cout), w, want_stats=True, groups=G)      # noqa: E731

@@ -4,6 +4,9 @@ import json
 import os
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import pmc_derive as PD                                      # noqa: E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, out = sys.argv[1], sys.argv[2]
 S = json.load(open(os.path.join(ROOT, 'gpurun_out', 'pmc_' + tag, 'summary.json')))
@@ -20,28 +23,29 @@ FORMS = {   # kernel name -> (description, volumes per launch, algorithmic FLOP,
 }
 res = {'note': 'rocprofv3 --pmc passes (one counter group per pass, --kernel-trace only) over `bench.py --eager --inflight 1` on '
                'MI355X (tools_dev/pmc_bench.sh): the launches of the timed graph, per-launch averages.  mfma_busy = '
-               'SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); clock = GRBM_GUI_ACTIVE / 8 / duration; '
+               'SQ_VALU_MFMA_BUSY_CYCLES / (cycles * 1024 SIMDs); cycles / clock as tools_dev/pmc_derive.py derives them; '
                'FETCH_SIZE / WRITE_SIZE are KB at the L2 memory side (Infinity-Cache hits included; wide coalesced reads count at '
                'half their bytes on gfx950, other widths uncalibrated: MI355X_MICROARCH.md).  Durations are under the profiler.',
        'kernels': {}}
+REF = PD.reference_clock((v['counters'], v.get('duration_ns_under_profiler', 0)) for v in S.values())
 for name, (desc, vols, flop, rd, wr) in FORMS.items():
     k = S.get(name)
     if not k:
         continue
     c = k['counters']
     dur = k['duration_ns_under_profiler'] * 1e-9
-    gui = c.get('GRBM_GUI_ACTIVE', 0.0)
     mf = c.get('SQ_INSTS_MFMA', 0.0)
+    dv = PD.derive(c, k['duration_ns_under_profiler'], REF)
     e = {'layer': desc, 'volumes_per_launch': vols, 'launches_profiled': k['launches'],
          'duration_ns_under_profiler': round(k['duration_ns_under_profiler']),
          'counters_per_launch': {n: round(v) for n, v in sorted(c.items())},
          'algorithmic_flops': flop * vols, 'algorithmic_read_bytes': rd * vols, 'algorithmic_write_bytes': wr * vols,
          'achieved_TFLOPs_algorithmic': round(flop * vols / dur / 1e12, 1),
          'fraction_of_fp32_mfma_peak_157.3': round(flop * vols / dur / 1e12 / 157.3, 3),
-         'clock_GHz': round(gui / 8 / dur / 1e9, 3) if gui else None,
-         'mfma_busy_fraction_of_simd_cycles': round(c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui / 8 * 1024), 3) if gui else None,
-         'lds_active_fraction_of_cu_cycles': round(c.get('SQ_LDS_IDX_ACTIVE', 0.0) / (gui / 8 * 256), 3) if gui else None,
-         'issued_mfma': round(mf), 'valu_per_mfma': round((c.get('SQ_INSTS_VALU', 0.0) - mf) / mf, 2) if mf else None,
+         'clock_GHz': dv.get('clock_GHz'), 'clock_source': dv.get('clock_source'),
+         'mfma_busy_fraction_of_simd_cycles': dv.get('mfma_busy'),
+         'lds_active_fraction_of_cu_cycles': dv.get('lds_active'),
+         'issued_mfma': round(mf), 'valu_per_mfma': dv.get('valu_per_mfma'),
          'lds_bank_conflict_cycles': round(c.get('SQ_LDS_BANK_CONFLICT', 0.0)),
          'write_bytes': round(c.get('WRITE_SIZE', 0.0) * 1024), 'fetch_bytes_raw': round(c.get('FETCH_SIZE', 0.0) * 1024)}
     alg = (rd + wr) * vols
@@ -54,11 +58,11 @@ for name, k in S.items():
     if name in FORMS or 'total_ms_under_profiler' not in k or k['total_ms_under_profiler'] < 0.5:
         continue
     c = k['counters']
-    gui, mf = c.get('GRBM_GUI_ACTIVE', 0.0), c.get('SQ_INSTS_MFMA', 0.0)
+    dv = PD.derive(c, k['duration_ns_under_profiler'], REF)
     others[name] = {'launches_profiled': k['launches'], 'avg_us': round(k['duration_ns_under_profiler'] / 1e3, 1),
                     'fetch_MB_raw': round(c.get('FETCH_SIZE', 0.0) / 1024, 1), 'write_MB': round(c.get('WRITE_SIZE', 0.0) / 1024, 1),
-                    'mfma_busy': round(c.get('SQ_VALU_MFMA_BUSY_CYCLES', 0.0) / (gui / 8 * 1024), 3) if gui else None,
-                    'valu_per_mfma': round((c.get('SQ_INSTS_VALU', 0.0) - mf) / mf, 2) if mf else None,
+                    'mfma_busy': dv.get('mfma_busy'), 'clock_GHz': dv.get('clock_GHz'),
+                    'valu_per_mfma': dv.get('valu_per_mfma'),
                     'lds_bank_conflict_cycles': round(c.get('SQ_LDS_BANK_CONFLICT', 0.0))}
 res['other_kernels_of_the_step'] = others
 json.dump(res, open(os.path.join(ROOT, out), 'w'), indent=1)
