@@ -160,6 +160,10 @@ template <int COUT, bool STREAMW, bool PRO>
 __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(UpBArgs p) {
   using U = UpB<COUT>;
   constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG, WCH = U::WCH;
+  // the forms that run ONE workgroup per CU (one wavefront per SIMD) reserve the SIMD's whole register file like conv_c16b: no
+  // wavefront of another kernel then runs beside their 16x16x32 MFMAs (such a neighbour with packed fp32
+  // arithmetic computed wrong lane quarters; only reachable with co-residency switched on).  The two-per-CU forms cannot.
+  if constexpr (PRO || UB_WGS_PER_CU(COUT) == 1) asm volatile("" ::: "v255", "a255");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;

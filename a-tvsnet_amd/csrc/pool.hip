@@ -7,38 +7,77 @@
 // /root/reference/cnn_wrapper/atvsnet.py:269-290.  All trivially small next to the volumes.
 #include "common.h"
 
-// Stage 1: one workgroup per (output pixel, slice of the window rows): partial sums -> ws
-// (Ho, Wo, POOL_SLICES, C).  Stage 2: fixed-order sum of the slices / valid count.  Deterministic.
-#define POOL_SLICES 16
+// Stage 1: one workgroup per (output pixel, slice of the window's PIXELS): partial sums -> ws (Ho, Wo, SL, C).  Stage 2: fixed-
+// order sum of the slices / valid count.  Deterministic.  SL (pool_slices) is chosen so that an image has ~640 workgroups whatever the
+// window: the pyramid's 64 x 64 windows of a 128 x 160 map (2 x 3 outputs) get 64 slices of 64 pixels, the 8 x 8 windows (16 x 20
+// outputs) two.  C % 4 == 0: a thread owns four channels of every 256 / (C / 4)-th pixel of its slice (16-byte loads, whole rows
+// of the channel-last map per wavefront); its float4 partial sums meet in LDS.  (Round 5's form -- 16 row slices, 4-byte loads -- took
+// 28 us per pool at configs[2]; the grouping of the partial sums, hence the last bit of the means, differs from it.)
+static inline int pool_slices(int Ho, int Wo) {
+  long s = 640 / ((long)Ho * Wo);
+  return (int)(s < 1 ? 1 : s > 64 ? 64 : s);
+}
+
 __global__ __launch_bounds__(256) void avg_pool_partial_kernel(const float* __restrict__ x, float* __restrict__ ws, int H,
-                                                               int W, int C, int Wo, int k, int s, int pad_t, int pad_l) {
-  __shared__ float sm[256];
-  const int oy = blockIdx.y, ox = blockIdx.x, sl = blockIdx.z % POOL_SLICES, grp = blockIdx.z / POOL_SLICES;
+                                                               int W, int C, int Wo, int k, int s, int pad_t, int pad_l, int SL) {
+  __shared__ float4 sm[256];
+  const int oy = blockIdx.y, ox = blockIdx.x, sl = blockIdx.z % SL, grp = blockIdx.z / SL;
   x += (size_t)grp * H * W * C;                               // independent image
-  ws += (size_t)grp * gridDim.y * Wo * POOL_SLICES * C;
+  ws += (size_t)grp * gridDim.y * Wo * SL * C;
   const int y0 = max(oy * s - pad_t, 0), y1 = min(oy * s - pad_t + k, H);
   const int x0 = max(ox * s - pad_l, 0), x1 = min(ox * s - pad_l + k, W);
-  const int rows = y1 - y0;
-  const int ra = y0 + (rows * sl) / POOL_SLICES, rb = y0 + (rows * (sl + 1)) / POOL_SLICES;
-  const int ww = x1 - x0, n = (rb - ra) * ww;
+  const int ww = x1 - x0, n = (y1 - y0) * ww;
+  const int i0 = (int)(((long)n * sl) / SL), i1 = (int)(((long)n * (sl + 1)) / SL);
+  const int t = threadIdx.x;
+  if ((C & 3) == 0) {
+    const int c4n = C >> 2;
+    for (int cb = 0; cb < c4n; cb += 256) {
+      const int cw = min(c4n - cb, 256);                      // channel groups of this block
+      const int lanes = 256 / cw;                             // pixel lanes
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (t < lanes * cw) {
+        const int cg = cb + t % cw;
+        int i = i0 + t / cw;
+        int yy = y0 + i / ww, xx = x0 + i % ww;
+        for (; i < i1; i += lanes) {
+          const float4 v = ld4(x + ((size_t)yy * W + xx) * C + cg * 4);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+          xx += lanes;
+          while (xx >= x1) { xx -= ww; ++yy; }
+        }
+      }
+      sm[t] = acc;
+      __syncthreads();
+      if (t < cw) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < lanes; ++j) {
+          const float4 u = sm[j * cw + t];
+          v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+        }
+        st4(ws + (((size_t)oy * Wo + ox) * SL + sl) * C + (cb + t) * 4, v);
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  float* smf = reinterpret_cast<float*>(sm);
   for (int cb = 0; cb < C; cb += 256) {
     const int cw = min(C - cb, 256);
     const int lanes = 256 / cw;
-    const int t = threadIdx.x;
     float acc = 0.f;
     if (t < lanes * cw) {
       const int c = cb + t % cw;
-      for (int i = t / cw; i < n; i += lanes) {
-        int yy = ra + i / ww, xx = x0 + i % ww;
+      for (int i = i0 + t / cw; i < i1; i += lanes) {
+        int yy = y0 + i / ww, xx = x0 + i % ww;
         acc += x[((size_t)yy * W + xx) * C + c];
       }
     }
-    sm[t] = acc;
+    smf[t] = acc;
     __syncthreads();
     if (t < cw) {
       float v = 0.f;
-      for (int j = 0; j < lanes; ++j) v += sm[j * cw + t];
-      ws[(((size_t)oy * Wo + ox) * POOL_SLICES + sl) * C + cb + t] = v;
+      for (int j = 0; j < lanes; ++j) v += smf[j * cw + t];
+      ws[(((size_t)oy * Wo + ox) * SL + sl) * C + cb + t] = v;
     }
     __syncthreads();
   }
@@ -46,7 +85,7 @@ __global__ __launch_bounds__(256) void avg_pool_partial_kernel(const float* __re
 
 __global__ __launch_bounds__(256) void avg_pool_finish_kernel(const float* __restrict__ ws, float* __restrict__ y, int H, int W,
                                                               int C, int Ho, int Wo, int k, int s, int pad_t, int pad_l,
-                                                              int groups) {
+                                                              int groups, int SL) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (long)groups * Ho * Wo * C) return;
   int c = (int)(i % C);
@@ -55,26 +94,29 @@ __global__ __launch_bounds__(256) void avg_pool_finish_kernel(const float* __res
   const int y0 = max(oy * s - pad_t, 0), y1 = min(oy * s - pad_t + k, H);
   const int x0 = max(ox * s - pad_l, 0), x1 = min(ox * s - pad_l + k, W);
   float v = 0.f;
-  for (int sl = 0; sl < POOL_SLICES; ++sl) v += ws[((size_t)pix * POOL_SLICES + sl) * C + c];
+  for (int sl = 0; sl < SL; ++sl) v += ws[((size_t)pix * SL + sl) * C + c];
   y[i] = v / (float)((y1 - y0) * (x1 - x0));
 }
 
 extern "C" long atvs_avg_pool_ws_floats(int H, int W, int C, int stride) {      // per image
   long Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
-  return Ho * Wo * POOL_SLICES * C;
+  return Ho * Wo * pool_slices((int)Ho, (int)Wo) * C;
 }
 
 extern "C" int atvs_avg_pool_same(const float* x, float* y, float* ws, int groups, int H, int W, int C, int pool, int stride,
                                   atvs_stream_t stream) {
   if (!x || !y || !ws) return ATVS_ERR_NULL;
-  if (groups <= 0 || groups * POOL_SLICES > 65535 || H <= 0 || W <= 0 || C <= 0 || pool <= 0 || stride <= 0) return ATVS_ERR_SHAPE;
+  if (groups <= 0 || H <= 0 || W <= 0 || C <= 0 || pool <= 0 || stride <= 0) return ATVS_ERR_SHAPE;
   int Ho = (H + stride - 1) / stride, Wo = (W + stride - 1) / stride;
+  const int SL = pool_slices(Ho, Wo);
+  if ((long)groups * SL > 65535 || Ho > 65535) return ATVS_ERR_SHAPE;
+  if ((C & 3) == 0 && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(ws)) & 15)) return ATVS_ERR_ARG;
   int ph = max((Ho - 1) * stride + pool - H, 0), pw = max((Wo - 1) * stride + pool - W, 0);
   hipStream_t s = as_stream(stream);
-  hipLaunchKernelGGL(avg_pool_partial_kernel, dim3(Wo, Ho, POOL_SLICES * groups), dim3(256), 0, s, x, ws, H, W, C, Wo, pool,
-                     stride, ph / 2, pw / 2);
+  hipLaunchKernelGGL(avg_pool_partial_kernel, dim3(Wo, Ho, SL * groups), dim3(256), 0, s, x, ws, H, W, C, Wo, pool,
+                     stride, ph / 2, pw / 2, SL);
   hipLaunchKernelGGL(avg_pool_finish_kernel, dim3(cdiv((long)groups * Ho * Wo * C, 256)), dim3(256), 0, s, ws, y, H, W, C, Ho, Wo,
-                     pool, stride, ph / 2, pw / 2, groups);
+                     pool, stride, ph / 2, pw / 2, groups, SL);
   ATVS_LAUNCH_CHECK();
   return ATVS_OK;
 }

@@ -2286,7 +2286,7 @@ def avg_pool_same(x, pool, stride, groups=None):
     Ho, Wo = -(-H // stride), -(-W // stride)
     lead = () if groups is None else (G,)
     y = _new(x, lead + (Ho, Wo, C))
-    ws = _new(x, (G, Ho, Wo, 16, C))
+    ws = _new(x, (G, int(_lib.lib().atvs_avg_pool_ws_floats(int(H), int(W), int(C), int(stride)))))
     if _dev_ok(x):
         _call('atvs_avg_pool_same', _p(x), _p(y), _p(ws), G, H, W, C, int(pool), int(stride), _stream())
     return y
