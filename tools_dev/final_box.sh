@@ -1,6 +1,6 @@
 #!/bin/bash
 # The GPU-box half of tools_dev/final_run.sh (run from the repository root of the snapshot):  bash tools_dev/final_box.sh <tag>
-tag=${1:-r5final}
+tag=${1:-r6final}
 root=$PWD
 out=$root/gpurun_out/$tag
 mkdir -p $out

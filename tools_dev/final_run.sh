@@ -4,11 +4,11 @@
 #   2. writes `git rev-parse HEAD` to profiles/.measured_head (git-ignored; it travels to the GPU box with the snapshot, which
 #      carries no .git) and sends tools_dev/final_box.sh to an MI355X: the full -m gpu suite, smoke(), the default bench line, the
 #      other workloads, a rocprofv3 kernel trace of the bench and the PMC passes (one counter group per pass);
-#   3. tools_dev/collect_profiles.py copies the summaries into profiles/round5_* -- every JSON carries "head", every CSV a first
+#   3. tools_dev/collect_profiles.py copies the summaries into profiles/round6_* -- every JSON carries "head", every CSV a first
 #      line "# head <hash>", and <name>.head sits beside each file -- ready to be committed as the round's LAST commit (that commit
 #      touches profiles/ and documents only: the measured tree is its parent).
 set -e
-tag=${1:-r5final}
+tag=${1:-r6final}
 root=$(cd $(dirname $0)/.. && pwd)
 cd $root
 if [ -n "$(git status --porcelain)" ]; then
