@@ -17,16 +17,19 @@
 //     view's [S|R] of the wavefront's plane to its partner -- no vector-memory instruction at all;
 //   * wavefronts 4..7 (the second wavefront of each SIMD) STAGE and COMBINE: they fetch the fp32 halo of the stage after next,
 //     split the next stage's into its two fp16 pieces and write the OTHER of two image buffers; they read the previous stage's
-//     hand-off ([S|R] of one view) and keep S_sum and R_n - S_n of their lane's 8 voxels x 2 channels in registers
-//     ((NV + 1) x 16 values instead of the 2 NV x 16 of [S|R]: eight views fit); after a tile's last view they run
-//     aanet_combine_kernel's arithmetic in its order (64..128 expf and divisions per lane) and store the output -- beside the
-//     multiplying wavefronts' K loop of the NEXT tile.
+//     hand-off ([S|R] of one view) and run the cross-view softmax + weighted sum beside the multiplying wavefronts' K loops:
+//       1 .. 4 views: the reference's literal arithmetic (aanet_combine_kernel's, in its order: S_sum accumulates in view order from
+//         0.f, U_n = (R_n - S_n) + S_sum) on S_sum and R_n - S_n kept in registers -- (NV + 1) x 16 values instead of the 2 NV x 16
+//         of [S|R], twice (tiles alternate): the previous tile is combined row group by row group, one group per stage.  Bit for
+//         bit the two-launch form;
+//       5 .. 8 views: a RUNNING softmax over the arriving views -- (max, sum e, sum e x) per value, 48 registers whatever NV, the
+//         same work in every stage -- of R_n - S_n alone: the S_sum term shifts every view's score alike and cancels in the
+//         softmax.  Within 1e-6 of the two-launch form, tolerance-tested.
 // ONE LDS-only barrier per stage (s_waitcnt lgkmcnt(0); s_barrier -- __syncthreads() would drain the halo requests in flight):
 // it publishes the next image buffer and this stage's hand-off and retires the buffers both will be overwritten in.
 // The 16 MFMA rows are ordered (S[2q], S[2q+1], R[2q], R[2q+1]) for lane group q (atvs_aanet_b_pack), so a lane holds S AND R of
 // its two channels -- no cross-lane exchange -- and reads the matching two channels of every X_n's centre voxel (L2 hits: the
-// halo just came through).  The arithmetic and its order are conv_c16b's and aanet_combine_kernel's (S_sum accumulates in view
-// order from 0.f, U_n = (R_n - S_n) + S_sum): bit for bit the two launches.
+// halo just came through).
 // Scalar fp32 arithmetic (-fno-slp-vectorize): the staging wavefronts compute beside the kernel's own 16x16x32 MFMA wavefronts
 // (DESIGN.md appendix B); two wavefronts of 256 registers per SIMD: no other kernel's wavefront fits beside them.
 #include <cstring>
@@ -40,6 +43,11 @@
 typedef float ab_f32x4 __attribute__((ext_vector_type(4)));
 __device__ ab_f32x4 ab_buffer_load_x4(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
     __asm("llvm.amdgcn.raw.ptr.buffer.load.v4f32");
+typedef float ab_f32x2 __attribute__((ext_vector_type(2)));
+__device__ ab_f32x2 ab_buffer_load_x2(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.load.v2f32");
+__device__ void ab_buffer_store_x2(ab_f32x2 v, __amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux)
+    __asm("llvm.amdgcn.raw.ptr.buffer.store.v2f32");
 
 namespace {
 
@@ -314,119 +322,197 @@ __global__ __launch_bounds__(512, 1) void aanet_b_kernel(AbArgs p) {
   }
   __syncthreads();
 
-  // S_sum and R_n - S_n of channels 2q, 2q+1 of voxels (z0 + sw, y0 + t, x0 + r), t < TY: TWO sets, tiles alternate.  The set of
-  // tile k fills view by view during the stages of tile k (+ the first of tile k + 1) while the set of tile k - 1 is combined ROW
-  // GROUP by row group, one group per stage of tile k (rows [v TY / NV, (v + 1) TY / NV) in stage v): the 16 NV exponentials of a
-  // tile in ONE stage made that stage twice as long as the multiplying wavefronts' (they waited 1.7k cycles per stage on average).
-  constexpr bool SPREAD = NV <= 4;                           // more views: two sets do not fit the registers, one set + a long first stage
-  constexpr int NSET = SPREAD ? 2 : 1;
-  float ssx[NSET][TY], ssy[NSET][TY], dvx[NSET][NV][TY], dvy[NSET][NV][TY];
   const int hread = AB_HOFF + (sw * TY) * 1024 + lane * 16;
   int s = 0;
-  auto stage_body = [&](auto PP, auto VV, int k) __attribute__((always_inline)) {
-    constexpr int P = decltype(PP)::value, v = decltype(VV)::value;
-    constexpr int vp = (v + NV - 1) % NV;                      // the view whose hand-off arrives: of this tile (v > 0) or the previous one
-    constexpr int HS = !SPREAD ? 0 : v == 0 ? 1 - P : P;       // ... and the set it belongs to
-    constexpr int CS = SPREAD ? 1 - P : 0;                     // the set of tile k - 1
-    // the row group of tile k - 1 combined in this stage (not SPREAD: all rows in the tile's first stage, before view 0 arrives)
-    constexpr int r0 = SPREAD ? v * TY / NV : 0, r1 = SPREAD ? (v + 1) * TY / NV : (v == 0 ? TY : 0);
-    constexpr int NR = r1 - r0 > 0 ? r1 - r0 : 1;
-    const bool live = k < my_tiles;                            // k == my_tiles: only the last tile's hand-off and combine are left
-    const bool comb = k > 0 && r1 > r0;
-    // (1) the hand-off of stage s - 1 and (2) the centre voxels of this stage's rows, requested first: both are consumed at the end
-    // of the stage, and the X loads must be OLDER than the halo requests below (vector-memory results return in order: a wait for a
-    // younger load would wait for the whole halo of the stage after next)
-    // (UNCONDITIONALLY: in the very first stage and in the drain stages behind the last tile the buffer holds stale values, which
-    // land in slots that are assigned again before they are read -- a conditional update would keep both sets alive across the loop)
-    float4 h[TY];
-    const int hb = hread + ((s - 1) & 1) * AB_HBUF;
-    if (SPREAD) {                                              // (not SPREAD: no room for 32 more registers across the staging)
+  if constexpr (NV > 4) {
+    // ---- 5 .. 8 views: the softmax over views as a RUNNING one.  softmax_n((R_n - S_n) + S_sum) = softmax_n(R_n - S_n): the sum of
+    // the shared scores is the same shift for every view and cancels (the oracle and the two-launch form keep the reference's
+    // literal formula; the difference is the rounding of d_n + S_sum, ~|S_sum| 2^-24 relative in a weight).  Per lane value only
+    // (max, sum e, sum e x) live on -- 48 registers whatever NV, where S_sum and R_n - S_n of eight views are 144 and spilled
+    // (1.91 ms at configs[3]) -- and every stage does the same work: the arriving view's hand-off and centre voxels update the
+    // running triple, e' = 2^((max - max') log2 e) rescales it; after the last view out = sum e x / sum e.
+    // Tolerance-tested against the oracle and the two-launch form (2e-5 of the output maximum), not bit for bit.
+    constexpr float L2E = 1.44269504088896340736f;
+    float mx[TY], my[TY], dnx[TY], dny[TY], nmx[TY], nmy[TY];
+    const int lane_xoff = (r * 8 + 2 * q) * 4;
+    auto stage_body = [&](auto VV, int k) __attribute__((always_inline)) {
+      constexpr int v = decltype(VV)::value;
+      constexpr int vp = (v + NV - 1) % NV;                    // the view whose hand-off arrives: of this tile (v > 0) or the previous one
+      const bool live = k < my_tiles;
+      const bool have = s > 0;
+      const PfTile& Tt = v == 0 ? Tp : Tk;                     // the tile that view belongs to
+      const int zo = Tt.z0 + sw, ty0 = Tt.y0;
+      // the lane's voxel column of the tile's plane: a buffer descriptor at (zo, ty0, x0) of the view (scalar), the lane's constant
+      // byte offset (or all ones = beyond the descriptor: reads zeros, stores nothing), the row as the scalar offset -- no per-row
+      // 64-bit addresses (hoisted out of the tile loop they were 16 spilled registers per view, reloaded in every stage)
+      const size_t tbase = (((size_t)zo * p.Hi + ty0) * p.Wi + Tt.x0) * 8;
+      const int voff = (zo < p.Di && Tt.x0 + r < p.Wi) ? lane_xoff : -1;
+      const int vrowb = p.Wi * 32;
+      const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[vp] + tbase), 0, 0x7ffffff0, 0x00020000);
+      // the hand-off and the view's centre voxels, requested FIRST (older than the halo requests below: vector-memory results
+      // return in order)
+      float4 h[TY];
+      ab_f32x2 xv[TY];
+      if (have) {
+        const int hb = hread + ((s - 1) & 1) * AB_HBUF;
+#pragma unroll
+        for (int t = 0; t < TY; ++t) h[t] = *reinterpret_cast<const float4*>(smem + hb + t * 1024);
+#pragma unroll
+        for (int t = 0; t < TY; ++t) xv[t] = ab_buffer_load_x2(xrs, (ty0 + t < p.Hi) ? voff : -1, t * vrowb, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (live) {
+#ifdef ATVS_AB_DEBUG
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ABDBG(5)
+#endif
+        pf_write(((s + 1) & 1) * AB_BUF);
+        ABDBG(0)
+        constexpr int idx = v + 2, dk = idx / NV, vn = idx % NV;
+        pf_request(dk == 0 ? Tk : Tk1, p.x[vn]);
+        ABDBG(1)
+      }
+      if (have) {
+#pragma unroll
+        for (int t = 0; t < TY; ++t) {
+          const float dx = h[t].z - h[t].x, dy = h[t].w - h[t].y;           // R - S
+          if constexpr (vp == 0) {
+            mx[t] = dx; my[t] = dy; dnx[t] = 1.f; dny[t] = 1.f; nmx[t] = xv[t][0]; nmy[t] = xv[t][1];
+          } else {
+            const float m2x = fmaxf(mx[t], dx), m2y = fmaxf(my[t], dy);
+            const float lx = m2x * L2E, ly = m2y * L2E;
+            const float ax = __builtin_amdgcn_exp2f(__builtin_fmaf(mx[t], L2E, -lx)), ay = __builtin_amdgcn_exp2f(__builtin_fmaf(my[t], L2E, -ly));
+            const float bx = __builtin_amdgcn_exp2f(__builtin_fmaf(dx, L2E, -lx)), by = __builtin_amdgcn_exp2f(__builtin_fmaf(dy, L2E, -ly));
+            dnx[t] = __builtin_fmaf(dnx[t], ax, bx); dny[t] = __builtin_fmaf(dny[t], ay, by);
+            nmx[t] = __builtin_fmaf(nmx[t], ax, bx * xv[t][0]); nmy[t] = __builtin_fmaf(nmy[t], ay, by * xv[t][1]);
+            mx[t] = m2x; my[t] = m2y;
+          }
+          if constexpr (vp == NV - 1) {
+            const ab_f32x2 o = {nmx[t] * __builtin_amdgcn_rcpf(dnx[t]), nmy[t] * __builtin_amdgcn_rcpf(dny[t])};
+            const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + tbase, 0, 0x7ffffff0, 0x00020000);
+            ab_buffer_store_x2(o, ors, (ty0 + t < p.Hi) ? voff : -1, t * vrowb, 0);
+          }
+        }
+        ABDBG(2)
+      }
+      ABDBG(3)
+      if (live) {
+        ab_lds_barrier();
+        ++s;
+      }
+      ABDBG(4)
+    };
+#pragma unroll 1
+    for (int k = 0; k <= my_tiles; ++k) {
+      if (k < my_tiles) {
+        ab_static_for<NV>([&](auto VV) __attribute__((always_inline)) { stage_body(VV, k); });
+      } else {
+        stage_body(IC<0>{}, k);                                  // the last view of the last tile
+      }
+      Tp = Tk;
+      Tk = Tk1;
+      Tk1 = pf_tile(k + 2);
+    }
+  } else {
+    // ---- 1 .. 4 views: the reference's literal arithmetic, bit for bit the two-launch form.
+    // S_sum and R_n - S_n of channels 2q, 2q+1 of voxels (z0 + sw, y0 + t, x0 + r), t < TY: TWO sets, tiles alternate.  The set of
+    // tile k fills view by view during the stages of tile k (+ the first of tile k + 1) while the set of tile k - 1 is combined ROW
+    // GROUP by row group, one group per stage of tile k (rows [v TY / NV, (v + 1) TY / NV) in stage v): the 16 NV exponentials of a
+    // tile in ONE stage made that stage twice as long as the multiplying wavefronts' (they waited 1.7k cycles per stage on average).
+    float ssx[2][TY], ssy[2][TY], dvx[2][NV][TY], dvy[2][NV][TY];
+    const int lane_xoff = (r * 8 + 2 * q) * 4;
+    auto stage_body = [&](auto PP, auto VV, int k) __attribute__((always_inline)) {
+      constexpr int P = decltype(PP)::value, v = decltype(VV)::value;
+      constexpr int vp = (v + NV - 1) % NV;                    // the view whose hand-off arrives: of this tile (v > 0) or the previous one
+      constexpr int HS = v == 0 ? 1 - P : P;                   // ... and the set it belongs to
+      constexpr int CS = 1 - P;                                // the set of tile k - 1
+      constexpr int r0 = v * TY / NV, r1 = (v + 1) * TY / NV;  // the row group of tile k - 1 combined in this stage
+      constexpr int NR = r1 - r0 > 0 ? r1 - r0 : 1;
+      const bool live = k < my_tiles;                          // k == my_tiles: only the last tile's hand-off and combine are left
+      const bool comb = k > 0 && r1 > r0;
+      // (1) the hand-off of stage s - 1 and (2) the centre voxels of this stage's rows, requested first: both are consumed at the
+      // end of the stage, and the X loads must be OLDER than the halo requests below (vector-memory results return in order: a wait
+      // for a younger load would wait for the whole halo of the stage after next).
+      // (The hand-off UNCONDITIONALLY: in the very first stage and in the drain stages behind the last tile the buffer holds stale
+      // values, which land in slots that are assigned again before they are read -- a conditional update would keep both sets alive
+      // across the loop.)
+      float4 h[TY];
+      const int hb = hread + ((s - 1) & 1) * AB_HBUF;
 #pragma unroll
       for (int t = 0; t < TY; ++t) h[t] = *reinterpret_cast<const float4*>(smem + hb + t * 1024);
-    }
-    const int zo = Tp.z0 + sw, xo = Tp.x0 + r, ty0 = Tp.y0;
-    const bool evox_ok = zo < p.Di && xo < p.Wi;
-    const size_t vo0 = (((size_t)zo * p.Hi + ty0) * p.Wi + xo) * 8 + 2 * q;
-    const size_t vrow = (size_t)p.Wi * 8;
-    float2 xv[SPREAD ? NR : 2][NV];
-    auto request_x = [&](int t, int slot) __attribute__((always_inline)) {
-      const bool ok = evox_ok && ty0 + t < p.Hi;               // rows outside the volume read the zero line
+      // the lane's voxel column of tile k - 1's plane: a buffer descriptor per view at (zo, ty0, x0) (scalar), the lane's constant
+      // byte offset (all ones outside the volume: reads zeros, stores nothing), the row as the scalar offset
+      const int zo = Tp.z0 + sw, ty0 = Tp.y0;
+      const size_t tbase = (((size_t)zo * p.Hi + ty0) * p.Wi + Tp.x0) * 8;
+      const int voff = (zo < p.Di && Tp.x0 + r < p.Wi) ? lane_xoff : -1;
+      const int vrowb = p.Wi * 32;
+      ab_f32x2 xv[NR][NV];
+      if (comb) {
 #pragma unroll
-      for (int n = 0; n < NV; ++n)
-        xv[slot][n] = *reinterpret_cast<const float2*>(ok ? (p.x[n] + (vo0 + t * vrow)) : p.zeros);
-    };
-    if (SPREAD && comb) {
+        for (int n = 0; n < NV; ++n) {
+          const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x[n] + tbase), 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-      for (int t = r0; t < r1; ++t) {
-        const bool ok = evox_ok && ty0 + t < p.Hi;             // rows outside the volume read the zero line
-#pragma unroll
-        for (int n = 0; n < NV; ++n)
-          xv[t - r0][n] = *reinterpret_cast<const float2*>(ok ? (p.x[n] + (vo0 + t * vrow)) : p.zeros);
+          for (int t = r0; t < r1; ++t) xv[t - r0][n] = ab_buffer_load_x2(xrs, (ty0 + t < p.Hi) ? voff : -1, t * vrowb, 0);
+        }
       }
-    }
-    if (SPREAD) __builtin_amdgcn_sched_barrier(0);
-    if (live) {
-      // the image of stage s + 1 (requested one stage ago) -> the buffer the multiplying wavefronts read LAST stage
+      __builtin_amdgcn_sched_barrier(0);
+      if (live) {
+        // the image of stage s + 1 (requested one stage ago) -> the buffer the multiplying wavefronts read LAST stage
 #ifdef ATVS_AB_DEBUG
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ABDBG(5)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ABDBG(5)
 #endif
-      pf_write(((s + 1) & 1) * AB_BUF);
-      ABDBG(0)
-      // the halo of stage s + 2
-      constexpr int idx = v + 2, dk = idx / NV, vn = idx % NV;
-      pf_request(dk == 0 ? Tk : dk == 1 ? Tk1 : Tk2, p.x[vn]);
-      ABDBG(1)
-    }
-    {
+        pf_write(((s + 1) & 1) * AB_BUF);
+        ABDBG(0)
+        // the halo of stage s + 2
+        constexpr int idx = v + 2, dk = idx / NV, vn = idx % NV;
+        pf_request(dk == 0 ? Tk : dk == 1 ? Tk1 : Tk2, p.x[vn]);
+        ABDBG(1)
+      }
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
-        if (!SPREAD) h[t] = *reinterpret_cast<const float4*>(smem + hb + t * 1024);      // read where it is consumed
         if constexpr (vp == 0) { ssx[HS][t] = 0.f + h[t].x; ssy[HS][t] = 0.f + h[t].y; }
         else { ssx[HS][t] += h[t].x; ssy[HS][t] += h[t].y; }
         dvx[HS][vp][t] = h[t].z - h[t].x; dvy[HS][vp][t] = h[t].w - h[t].y;
       }
       ABDBG(2)
-    }
-    if (comb) {
-      // ---- combine (aanet_combine_kernel's arithmetic and order) of rows r0..r1-1 of tile k - 1, channels 2q, 2q+1
-      // (not SPREAD: 8 rows x NV centre voxels do not fit the registers; they are requested one row ahead of the arithmetic)
-      if (!SPREAD) request_x(r0, 0);
+      if (comb) {
+        // ---- combine (aanet_combine_kernel's arithmetic and order) of rows r0..r1-1 of tile k - 1, channels 2q, 2q+1
+        const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(p.out + tbase, 0, 0x7ffffff0, 0x00020000);
 #pragma unroll
-      for (int t = r0; t < r1; ++t) {
-        if (!SPREAD && t + 1 < r1) request_x(t + 1, (t + 1 - r0) & 1);
-        const bool ok = evox_ok && ty0 + t < p.Hi;
-        float ux[NV], uy[NV];
+        for (int t = r0; t < r1; ++t) {
+          float ux[NV], uy[NV];
 #pragma unroll
-        for (int n = 0; n < NV; ++n) { ux[n] = dvx[CS][n][t] + ssx[CS][t]; uy[n] = dvy[CS][n][t] + ssy[CS][t]; }
-        float ox, oy;
-        const int xs = SPREAD ? t - r0 : (t - r0) & 1;
-        atvs_aanet_softmax_sum<NV>(ux, [&](int n) __attribute__((always_inline)) { return xv[xs][n].x; }, &ox);
-        atvs_aanet_softmax_sum<NV>(uy, [&](int n) __attribute__((always_inline)) { return xv[xs][n].y; }, &oy);
-        if (ok) *reinterpret_cast<float2*>(p.out + (vo0 + t * vrow)) = make_float2(ox, oy);
-        if (!SPREAD) __builtin_amdgcn_sched_barrier(0);        // row by row: interleaved rows do not fit the registers beside 8 views' state
+          for (int n = 0; n < NV; ++n) { ux[n] = dvx[CS][n][t] + ssx[CS][t]; uy[n] = dvy[CS][n][t] + ssy[CS][t]; }
+          ab_f32x2 o;
+          float ox, oy;
+          atvs_aanet_softmax_sum<NV>(ux, [&](int n) __attribute__((always_inline)) { return xv[t - r0][n][0]; }, &ox);
+          atvs_aanet_softmax_sum<NV>(uy, [&](int n) __attribute__((always_inline)) { return xv[t - r0][n][1]; }, &oy);
+          o[0] = ox; o[1] = oy;
+          ab_buffer_store_x2(o, ors, (ty0 + t < p.Hi) ? voff : -1, t * vrowb, 0);
+        }
       }
-    }
-    ABDBG(3)
-    if (live) {
-      ab_lds_barrier();
-      ++s;
-    }
-    ABDBG(4)
-  };
-  auto tile_body = [&](auto PP, int k) __attribute__((always_inline)) {
-    if (k > my_tiles) return;
-    if (NV == 1) Tk2 = pf_tile(k + 2);                         // the stage after next lies two tiles ahead only with one view
-    else Tk2 = Tk1;
-    ab_static_for<NV>([&](auto VV) __attribute__((always_inline)) { stage_body(PP, VV, k); });
-    Tp = Tk;
-    Tk = Tk1;
-    Tk1 = pf_tile(k + 2);
-  };
+      ABDBG(3)
+      if (live) {
+        ab_lds_barrier();
+        ++s;
+      }
+      ABDBG(4)
+    };
+    auto tile_body = [&](auto PP, int k) __attribute__((always_inline)) {
+      if (k > my_tiles) return;
+      if (NV == 1) Tk2 = pf_tile(k + 2);                       // the stage after next lies two tiles ahead only with one view
+      else Tk2 = Tk1;
+      ab_static_for<NV>([&](auto VV) __attribute__((always_inline)) { stage_body(PP, VV, k); });
+      Tp = Tk;
+      Tk = Tk1;
+      Tk1 = pf_tile(k + 2);
+    };
 #pragma unroll 1
-  for (int k = 0; k <= my_tiles; k += SPREAD ? 2 : 1) {
-    tile_body(IC<0>{}, k);
-    if constexpr (SPREAD) tile_body(IC<1>{}, k + 1);
+    for (int k = 0; k <= my_tiles; k += 2) {
+      tile_body(IC<0>{}, k);
+      tile_body(IC<1>{}, k + 1);
+    }
   }
 #ifdef ATVS_AB_DEBUG
   if (lane == 0 && blockIdx.x < 256) {

@@ -608,8 +608,8 @@ def test_skip_add_with_the_residual_base_in_one_pass_bitwise(cuda, G, shape):
 def test_aanet_module_in_one_launch_bitwise(cuda, weights, nv, shape):
     """aanet_b.hip: the shared | unique score convolutions of every view and the cross-view softmax + weighted sum (reference
     cnn_wrapper/network.py:282-351,378-408) as ONE launch (multiplying + staging / combining wavefronts, [S|R] handed over in LDS)
-    -- against the two-launch form (conv_c16b per view + aanet_combine) bit for bit, and against the oracle's
-    attention_aggregation; ragged tiles, 1 to 8 views (configs[3] has 8 sources), workgroups with two tiles (64 x 48 x 64 = 384 tiles on
+    -- against the two-launch form (conv_c16b per view + aanet_combine) bit for bit up to 4 views (within 2e-6 of the maximum for the
+    running softmax of 5 .. 8 views), and against the oracle's attention_aggregation; ragged tiles, 1 to 8 views (configs[3] has 8 sources), workgroups with two tiles (64 x 48 x 64 = 384 tiles on
     256 workgroups) and with fewer tiles than workgroups."""
     from atvsnet_amd import ops
     from atvsnet_amd.cnn_wrapper.atvsnet import AttAggregation_keepchannel
@@ -622,6 +622,15 @@ def test_aanet_module_in_one_launch_bitwise(cuda, weights, nv, shape):
         with ops.configure(aanet_fused=fused):
             net = AttAggregation_keepchannel({'data': stacked}, is_training=True)
             outs[fused] = net.get_output().clone()
-    assert torch.equal(outs[True], outs[False])
     want = nets.attention_aggregation(torch.stack(xs, -1)[None], weights, 'attention_aggregate')
-    assert float((outs[True].cpu() - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    scale = float(want.abs().max())
+    if nv <= 4:
+        assert torch.equal(outs[True], outs[False])
+    else:
+        # 5 .. 8 views: the running softmax over views without the (shift-invariant) S_sum term -- the reference's literal formula up
+        # to the rounding of (R_n - S_n) + S_sum, not its bits (aanet_b.hip); a tenth of the oracle bar against the two-launch form
+        d = float((outs[True] - outs[False]).abs().max())
+        print('%d views: one launch vs two launches max |diff| %.2e of %.2e' % (nv, d, scale))
+        assert d <= 2e-6 * scale
+    assert float((outs[True].cpu() - want).abs().max()) <= 2e-5 * scale
+    assert float((outs[False].cpu() - want).abs().max()) <= 2e-5 * scale

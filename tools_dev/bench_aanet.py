@@ -35,5 +35,6 @@ for nv, shape in ((4, (192, 128, 160)), (5, (192, 128, 160)), (8, (256, 120, 232
             outs[fused] = (y.clone(), e0.elapsed_time(e1) / reps)
     V = float(np.prod(shape))
     gf = nv * 2.0 * 27 * 8 * 16 * V / 1e9
-    print('%d views %s: one launch %.3f ms (%.0f TFLOP/s algorithmic), two launches %.3f ms, bitwise equal: %s'
-          % (nv, shape, outs[True][1], gf / outs[True][1], outs[False][1], torch.equal(outs[True][0], outs[False][0])), flush=True)
+    print('%d views %s: one launch %.3f ms (%.0f TFLOP/s algorithmic), two launches %.3f ms, bitwise equal: %s, max |diff| / max %.1e'
+          % (nv, shape, outs[True][1], gf / outs[True][1], outs[False][1], torch.equal(outs[True][0], outs[False][0]),
+             float((outs[True][0] - outs[False][0]).abs().max() / outs[False][0].abs().max())), flush=True)
