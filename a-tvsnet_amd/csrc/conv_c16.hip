@@ -10,7 +10,7 @@
 // pipe busy 58 %, 2.75 other VALU instructions per MFMA: run-time tap tables, rotating register copies, a halo burst in
 // front of the K loop, two workgroups per CU on half the register file each).
 //
-// Built like conv_xp.hip / deconv_up.hip: ONE workgroup of 4 wavefronts per CU with the whole register file; tile =
+// Built like conv_xw.hip / deconv_up.hip: ONE workgroup of 4 wavefronts per CU with the whole register file; tile =
 // 4(z) x 8(y) x 16(x) output voxels, wavefront w owns plane z0 + w (8 accumulator tiles); the K loop is fully unrolled
 // (27 taps x 4 MFMAs x 8 rows per 16-channel chunk), every LDS read is one of three swizzled base registers (the x
 // displacement) + an immediate (the row pitch of the image is a multiple of 512 bytes); the fragments and the weights of
@@ -84,7 +84,7 @@ __device__ __forceinline__ void c16_static_for(F&& f) {
 }
 
 // NT = 16-channel output tiles: 1 (16 channels; packed weights of every chunk resident in LDS) or 2 (32 channels: the
-// weights no longer fit next to the image and stream from L2, requested C16_LOOK steps ahead like conv_xp.hip's).
+// weights no longer fit next to the image and stream from L2, requested C16_LOOK steps ahead like conv_xw.hip's).
 constexpr int C16_LOOK = 4;
 
 template <int C4, int NT, bool RELU>

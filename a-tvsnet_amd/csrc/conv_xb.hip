@@ -113,7 +113,7 @@ struct XbArgs {
 // the bytes between them are unused.  A fragment read takes lane group q to parity q & 1, index (q >> 1) + r; with this
 // interleave the 16 lanes of every ds_read_b128 lane group ({0-3,12-15 | 20-27}, ...: MI355X_MICROARCH.md) cover all 64
 // banks once (index 16 of the odd run must land on banks 32..35: byte 128 modulo 256) -- with the even | odd column split of
-// conv_xp.hip (16-byte voxels) every fragment read was 2-way conflicted (PMC: half of the LDS cycles).
+// the round-2 kernel conv_xp (16-byte voxels; removed in round 4) every fragment read was 2-way conflicted (PMC: half of the LDS cycles).
 __device__ __forceinline__ constexpr int xb_col(int par, int i) {
   return i < 16 ? (i >> 3) * 256 + par * 128 + (i & 7) * 16 : 512 + par * 128;
 }
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
   const bool producer = wave >= 4;
   const int r = lane & 15, q = lane >> 4;
 
-  // persistent tile list (conv_xp.hip)
+  // persistent tile list (conv_xw.hip)
   const int G = p.wg;
   const int grp = p.sample_major ? (int)(blockIdx.x & 7) : (int)(blockIdx.x / p.wg);
   const int lbk = p.sample_major ? (int)(blockIdx.x >> 3) : (int)(blockIdx.x - grp * p.wg);
@@ -386,7 +386,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
     else asm volatile("s_waitcnt vmcnt(%1)" : "+v"(pf[i]) : "n"(N));                                       \
   } while (0)
 
-    // prologue transform: arithmetic of bn_apply / bn_add (norm.hip), as conv_xp.hip / conv_xw.hip.  The parameters of all
+    // prologue transform: arithmetic of bn_apply / bn_add (norm.hip), as conv_xw.hip.  The parameters of all
     // chunks sit in LDS behind the weight buffers (copied there before the first barrier; a source WITHOUT a pending batch norm
     // gets the identity -- mean 0, scale 1, beta 0, no floor: (v - 0) * 1 + 0 == v, a -0 becomes +0: the same sums).
     struct Par { float4 ma, sa, ba, mb, sb, bb; };
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
       }
       XDBG(3)
       if (last_chunk) {
-        // ---- epilogue (conv_xp.hip): this lane holds channels co..co+3 of voxel xo for the 4 rows of plane zo
+        // ---- epilogue (conv_xw.hip's layout): this lane holds channels co..co+3 of voxel xo for the 4 rows of plane zo
         // Every loaded epilogue operand passes through an (empty) assembly statement FIRST: the compiler waits for them here,
         // once.  Otherwise its loop-carried bookkeeping puts s_waitcnt vmcnt(0) in front of each row's first use of the bias --
         // loads and stores share the counter, so every row waited for the previous row's store to be acknowledged (an HBM
@@ -751,7 +751,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
   }
 #endif
 
-  // ---- per-workgroup partial moments -> row `srow` of stats: [2][16] doubles (columns 0..7 = channels), as conv_xp.hip
+  // ---- per-workgroup partial moments -> row `srow` of stats: [2][16] doubles (columns 0..7 = channels), as conv_xw.hip
   // (after the last barrier nobody reads the images: the reduction borrows their first bytes; the producers hold zeros)
   if (p.stats) {
     double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][8]

@@ -638,7 +638,7 @@ extern "C" int atvs_conv_xw_pack_sibling(const float* w2, int Cin, float* packed
   return ATVS_OK;
 }
 
-// Same contract as atvs_conv_xp_f32 (include/atvsnet_hip.h) with weights packed by atvs_conv_xw_pack[_sibling]; grid and
+// The x-pair contract of include/atvsnet_hip.h (atvs_conv_xw_f32) with weights packed by atvs_conv_xw_pack[_sibling]; grid and
 // statistics rows = atvs_conv_xpair_grid.  Results differ from the direct sum by fp32 rounding only (F(2,3) along y).
 extern "C" int atvs_conv_xw_f32(const float* x, const float* packed_w, const float* bias, const float* plane_bias,
                                 float* y, double* stats_partial, int groups, int D, int H, int W, int Cin, int ldy, int y_coff,

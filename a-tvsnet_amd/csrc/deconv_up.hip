@@ -14,7 +14,7 @@
 //   Cout =  8: 4 tiles, tile m = (pz,py), rows = (px, channel); 18 of 32 blocks (the x pair shares a tile: 3/4 useful);
 //   Cout = 16: 8 tiles, tile m = (pz,py,px), rows = channel;    27 of 64 blocks (all useful).
 //
-// Kernel.  Built like conv_xp.hip (the measurements behind that file apply): ONE workgroup of 4 wavefronts per CU with
+// Kernel.  Built like conv_xw.hip (the measurements behind its round-2 predecessor conv_xp apply): ONE workgroup of 4 wavefronts per CU with
 // the whole register file, a fully unrolled K loop whose LDS reads are base register + immediate, the next tile's halo
 // requested between the MFMAs.  Tile = 4(z) x TY(y) x 16(x) INPUT voxels, TY = 8 / 4 for Cout = 8 / 16; wavefront w
 // owns input plane z0 + w with TY rows x NT tiles = 32 accumulator tiles.  The halo is one-sided (offsets 0 / -1 only):
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void deconv_up_kernel(UpArgs p) {
   }
 
   // ---- per-workgroup partial moments (sum, sum of squares) per output channel -> row blockIdx of stats: [2][16]
-  // doubles (Cout 8: columns 8..15 = 0, the layout of conv_xp.hip)
+  // doubles (Cout 8: columns 8..15 = 0, the layout of conv_xw.hip)
   if (p.stats) {
     __syncthreads();
     double* s_red = reinterpret_cast<double*>(smem);   // [4 waves][2][16]
