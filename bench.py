@@ -796,8 +796,15 @@ def rank_main(args):
             five = {'config': {'workload': '1 depth map per step: 6 views (1 ref + 5 src) %dx%d, D=%d' % (args.width, args.height, args.depths)},
                     'value': round(args.steps / dt6, 4), 'unit': 'depth-maps/sec', 'ms_per_step': round(1e3 * dt6 / args.steps, 3),
                     'source_views_per_sec': round(5 * args.steps / dt6, 3), 'graph_equals_eager_bitwise': bool(torch.equal(o6, e6)),
-                    'finite': bool(torch.isfinite(o6).all()), 'note': 'no oracle fixture at this view count: parity is covered by cfg3 (4 '
-                    'sources) and cfg4 (8 sources) at full size and by the 1..8-view AANet module tests'}
+                    'finite': bool(torch.isfinite(o6).all())}
+            fx = os.path.join(ROOT, 'tests', 'golden', 'fullsize_cfg3s5.npz')
+            if os.path.exists(fx) and not args.no_parity:
+                want6 = torch.from_numpy(np.load(fx)['depth'])
+                got6 = o6.reshape(want6.shape).cpu()
+                five['parity'] = {'fixture': os.path.relpath(fx, ROOT), 'bar': 1e-3,
+                                  'rel_l1': float(((got6 - want6).abs() / want6.abs()).mean()),
+                                  'rel_l1_inverse': float(((1.0 / got6 - 1.0 / want6).abs() / (1.0 / want6).abs()).mean())}
+                five['parity']['ok'] = bool(five['parity']['rel_l1'] <= 1e-3 and five['parity']['rel_l1_inverse'] <= 1e-3)
             del g6, e6, o6, im6, cm6
         except Exception as e:
             five = {'error': repr(e)}

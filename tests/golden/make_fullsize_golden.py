@@ -6,6 +6,7 @@ configurations on the seeded synthetic inputs and weights (the same ones bench.p
     cfg2f64 the same with the oracle's NETWORKS evaluated in float64 (geometry stays float32 so the same
             pixels are sampled): the value both float32 pipelines approximate = the noise floor
     cfg3    5 views 640x512, D=192, multi-view     (BASELINE configs[2], the metric's configuration)
+    cfg3s5  the same with 6 views = five sources (bench.py's `five_sources` line; both AANet modules run the 5-view form)
     cfg4    9 views 928x480, D=256, multi-view     (BASELINE configs[3]: 8 sources)
     cfg5    two-view 1600x1184, D=256              (BASELINE configs[4])
     cfg5f64 the float64-network evaluation of cfg5.  The plain oracle call keeps both 15.5 GB float64 cost volumes and every
@@ -43,6 +44,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CONFIGS = {            # name: (views, H, W, D)
     'cfg2': (2, 512, 640, 192),
     'cfg3': (5, 512, 640, 192),
+    'cfg3s5': (6, 512, 640, 192),        # the metric's configuration with FIVE source views ("also report 5-source N = 6")
     'cfg4': (9, 480, 928, 256),
     'cfg5': (2, 1184, 1600, 256),
     'cfg5h': (2, 576, 800, 256),

@@ -20,6 +20,7 @@ BAR = 1e-3
 CONFIGS = {            # name: (views, H, W, D)
     'cfg2': (2, 512, 640, 192),
     'cfg3': (5, 512, 640, 192),
+    'cfg3s5': (6, 512, 640, 192),         # the metric's configuration with five source views
     'cfg4': (9, 480, 928, 256),
     'cfg5': (2, 1184, 1600, 256),
     'cfg5h': (2, 576, 800, 256),          # configs[4] at half the image size: the largest case whose float64 floor fits the build container
@@ -122,6 +123,27 @@ def test_cfg3_multiview_fullsize(cuda, weights):
     assert torch.equal(rep, ex.infer_multiview(imgs, cams, D))          # per-view streams, eager
     assert torch.equal(rep, got)
     print('cfg3 peak device memory %.1f GB of 288' % (torch.cuda.max_memory_allocated() / 1e9))
+
+
+def test_cfg3_five_sources_fullsize(cuda, weights):
+    """SURVEY 8(d) "also report 5-source N = 6": the metric's shape with SIX views (five sources) -- both AANet modules run the
+    five-view form of aanet_b.hip (the running softmax) inside the whole pipeline; bench.py prints its rate as `five_sources`."""
+    from atvsnet_amd.atvsnet import example as ex
+    gold = _gold('cfg3s5')
+    imgs, cams, D = _inputs('cfg3s5', cuda)
+    G = {}
+    got = ex.infer_multiview(imgs, cams, D, G, view_streams=False)
+    _check_depth('cfg3s5', got, gold, cams, D)
+    e = rel_l1(G['depth_agg_init'].cpu()[0, ..., 0], torch.from_numpy(gold['depth_agg_init']))
+    print('cfg3s5 depth_agg_init rel-L1 %.3e' % e)
+    assert e <= BAR
+    w = torch.from_numpy(gold['cost_agg_mid'])                       # AAM1's output: the five-view softmax, before any discontinuous step
+    diff = (G['cost_volume_agg'].cpu()[0, D // 2] - w).abs()
+    print('cfg3s5 cost_volume_agg plane %d: max abs diff %.3e of max %.3e' % (D // 2, float(diff.max()), float(w.abs().max())))
+    assert float(diff.max()) <= 1e-3 * float(w.abs().max())
+    del G
+    gr = ex.GraphedInference(imgs, cams, D)
+    assert torch.equal(gr(), got)
 
 
 def test_cfg4_eight_sources_fullsize(cuda, weights):
