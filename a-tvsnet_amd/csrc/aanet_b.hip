@@ -13,7 +13,7 @@
 // Round 6: ONE workgroup of EIGHT wavefronts per CU, two roles (conv_xb's structure).  A workgroup owns a 4(z) x 8(y) x 16(x)
 // tile and walks the views; a STAGE is one (tile, view).
 //   * wavefronts 0..3 (one per SIMD) MULTIPLY: LDS fragment reads + MFMAs only (7 K steps of four taps x 8 channels, three
-//     products: conv_c16b's K order), then conv_c16b's epilogue arithmetic (zero bias, ReLU) and 8 ds_write_b128 that hand the
+//     products: the K order atvs_tap8 shared with conv_c16b's Cin = 8 form -- every halo row fetched once per column group), then conv_c16b's epilogue arithmetic (zero bias, ReLU) and 8 ds_write_b128 that hand the
 //     view's [S|R] of the wavefront's plane to its partner -- no vector-memory instruction at all;
 //   * wavefronts 4..7 (the second wavefront of each SIMD) STAGE and COMBINE: they fetch the fp32 halo of the stage after next,
 //     split the next stage's into its two fp16 pieces and write the OTHER of two image buffers; they read the previous stage's
@@ -58,7 +58,7 @@ constexpr int AB_ROWB = AB_HX * AB_VB;
 constexpr int AB_IMG = AB_HZ * AB_HY * AB_ROWB;                // 17,280 bytes per piece
 constexpr int AB_SLOTS = AB_HZ * AB_HY * AB_HX * 2;            // float4 slots of the fp32 halo
 constexpr int AB_MAXS = (AB_SLOTS + 255) / 256;                // 9 per staging thread
-constexpr int AB_JC = 7;                                       // K steps: taps 4 j + q (tap 27 = zero weights)
+constexpr int AB_JC = 7;                                       // K steps of four taps x 8 channels: atvs_tap8 (conv_common.h)
 constexpr int AB_NP = 2;
 constexpr int AB_WSTEP = AB_NP * 1024;
 constexpr int AB_MAXV = 8;                                     // views per launch
@@ -161,12 +161,18 @@ __global__ __launch_bounds__(512, 1) void aanet_b_kernel(AbArgs p) {
   if (wave < 4) {
     // ======================= MULTIPLYING wavefronts: wavefront w owns plane z0 + w of the tile =======================
     const int fbase = ((wave * HY) * AB_HX + r) * AB_VB;
-    int dq[JC];                                                // the lane group's tap displacement per K step (tap 4 j + q, 27 -> 26)
+    // K order atvs_tap8 (conv_common.h): steps 3 G .. 3 G + 2 (G = 0, 1) carry four (kd, kw) columns at kh = 0, 1, 2 -- row t of step kh
+    // reads halo row t + kh of the lane group's column, so each of a group's ten halo rows is fetched ONCE and multiplied by the (up to)
+    // three steps that want it; step 6 carries the ninth column at kh = q.  56 fragment reads per stage instead of 112: the LDS array
+    // (51 % busy, shared with the staging role's writes and hand-off) was what both roles waited for -- 0.45 -> 0.37 ms at 4 views
+    // in a development build that simply skipped half the reads.
+    int cb[2];                                                 // this lane group's column of groups 0 | 1: (kd, kw) of combination 4 G + q
 #pragma unroll
-    for (int j = 0; j < JC; ++j) {
-      const int t = min(4 * j + q, 26);
-      dq[j] = fbase + ((t / 9) * HY + (t / 3) % 3) * AB_ROWB + (t % 3) * AB_VB;
+    for (int G2 = 0; G2 < 2; ++G2) {
+      const int c = G2 * 4 + q;
+      cb[G2] = fbase + ((c / 3) * HY) * AB_ROWB + (c % 3) * AB_VB;
     }
+    const int c8 = fbase + (2 * HY + min(q, 2)) * AB_ROWB + 2 * AB_VB;      // step 6: column (2, 2) at kh = q (q = 3: zero weights)
     const int wbase = AB_WOFF + lane * 16;
     const int hbase = AB_HOFF + (wave * TY) * 1024 + lane * 16;
     __syncthreads();                                           // weights + stage 0 are in LDS
@@ -176,29 +182,68 @@ __global__ __launch_bounds__(512, 1) void aanet_b_kernel(AbArgs p) {
       const int ib = (s & 1) * AB_BUF;
 #pragma unroll
       for (int t = 0; t < TY; ++t) acc[t] = accx[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      f16x8 Bq[2][TY], A[2][AB_NP];
-      auto request_B1 = [&](auto PH, auto TT) __attribute__((always_inline)) {
-        constexpr int ph = decltype(PH)::value, j = ph / AB_NP, pc = ph % AB_NP, t = decltype(TT)::value;
-        Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + ib + dq[j] + (pc * AB_IMG + t * AB_ROWB));
+      // a UNIT = one halo row y of a group (20 units: two fragment reads -- both pieces -- and up to nine MFMAs) or one output row
+      // of step 6 (8 units of three MFMAs).  F[u % 3]: a group unit's fragments, requested TWO units ahead (the short units at a
+      // group's ends -- 3 and 6 MFMAs -- do not cover an LDS round trip under load); F6[t]: step 6's fragments, requested during
+      // group 1's units (its 24 MFMAs then run without a wait); A[set][kh][piece]: a group's weight fragments (group 0: set 0,
+      // group 1: set 1, step 6: set 0 again), requested during the previous group.
+      constexpr int NG = 20, NU = 28;
+      f16x8 F[3][AB_NP], F6[TY][AB_NP], A[2][3][AB_NP];
+      auto request_F = [&](auto UU, auto PC) __attribute__((always_inline)) {
+        constexpr int u = decltype(UU)::value, pc = decltype(PC)::value;
+        F[u % 3][pc] = *reinterpret_cast<const f16x8*>(smem + ib + cb[u / 10] + ((u % 10) * AB_ROWB + pc * AB_IMG));
       };
-#pragma unroll
-      for (int pc = 0; pc < AB_NP; ++pc) A[0][pc] = *reinterpret_cast<const f16x8*>(smem + wbase + pc * 1024);
-      ab_static_for<TY>([&](auto TT) __attribute__((always_inline)) { request_B1(IC<0>{}, TT); });
+      auto request_F6 = [&](auto TT, auto PC) __attribute__((always_inline)) {
+        constexpr int t = decltype(TT)::value, pc = decltype(PC)::value;
+        F6[t][pc] = *reinterpret_cast<const f16x8*>(smem + ib + c8 + (t * AB_ROWB + pc * AB_IMG));
+      };
+      auto request_A = [&](auto SS, auto PC) __attribute__((always_inline)) {       // K step S -> set (S / 3) & 1, slot S % 3
+        constexpr int S = decltype(SS)::value, pc = decltype(PC)::value;
+        A[(S / 3) & 1][S % 3][pc] = *reinterpret_cast<const f16x8*>(smem + wbase + S * AB_WSTEP + pc * 1024);
+      };
+      ab_static_for<3>([&](auto SS) __attribute__((always_inline)) { request_A(SS, IC<0>{}); request_A(SS, IC<1>{}); });
+      ab_static_for<2>([&](auto UU) __attribute__((always_inline)) { request_F(UU, IC<0>{}); request_F(UU, IC<1>{}); });
       asm volatile("" ::: "memory");
       ABDBG(0)
-      ab_static_for<AB_NP * JC>([&](auto PH) __attribute__((always_inline)) {
-        constexpr int ph = decltype(PH)::value, j = ph / AB_NP, pc = ph % AB_NP;
-        ab_static_for<(2 - pc) * TY>([&](auto M) __attribute__((always_inline)) {
-          constexpr int m = decltype(M)::value, jw = m / TY, t = m % TY;
-          if constexpr (pc == 0 && jw == 0) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][0], Bq[ph & 1][t], acc[t], 0, 0, 0);
-          else accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[j & 1][pc == 0 ? 1 : 0], Bq[ph & 1][t], accx[t], 0, 0, 0);
-          if constexpr (m < TY) {
-            if constexpr (ph + 1 < AB_NP * JC) request_B1(IC<ph + 1>{}, IC<m>{});
-          } else if constexpr (m < TY + AB_NP) {
-            if constexpr (j + 1 < JC) A[(j + 1) & 1][m - TY] = *reinterpret_cast<const f16x8*>(smem + wbase + (j + 1) * AB_WSTEP + (m - TY) * 1024);
+      ab_static_for<NU>([&](auto UU) __attribute__((always_inline)) {
+        constexpr int u = decltype(UU)::value;
+        constexpr int G = u < NG ? u / 10 : 2, y = u < NG ? u % 10 : u - NG;
+        constexpr int set = G == 1 ? 1 : 0;
+        // the rows this unit feeds: group units row t = y - kh for every step kh with 0 <= t < TY; a step-6 unit its own row
+        constexpr int kh_lo = G == 2 ? 0 : (y - (TY - 1) > 0 ? y - (TY - 1) : 0), kh_hi = G == 2 ? 0 : (y < 2 ? y : 2);
+        constexpr int nr = kh_hi - kh_lo + 1;
+        // every LDS read behind ONE MFMA: MFMA m of the unit is followed by hook(m)
+        auto hook = [&](auto MM) __attribute__((always_inline)) {
+          constexpr int m = decltype(MM)::value;
+          if constexpr (u + 2 < NG) {
+            if constexpr (m == 0) request_F(IC<u + 2>{}, IC<0>{});
+            if constexpr (m == 1) request_F(IC<u + 2>{}, IC<1>{});
           }
+          // the next group's weights during this group's 9-MFMA units y = 3, 4, 5 (two fragments each); step 6's during group 1's y = 3
+          if constexpr (G < 2 && nr == 3 && (m == 2 || m == 3)) {
+            if constexpr (G == 0 && y >= 3 && y <= 5) request_A(IC<3 + (y - 3)>{}, IC<m - 2>{});
+            if constexpr (G == 1 && y == 3) request_A(IC<6>{}, IC<m - 2>{});
+          }
+          // step 6's fragments of row y - 1 during group 1's units y = 1 .. 8 (six MFMAs or more each)
+          if constexpr (G == 1 && y >= 1 && y <= TY && (m == 4 || m == 5)) request_F6(IC<y - 1>{}, IC<m - 4>{});
           asm volatile("" ::: "memory");
           __builtin_amdgcn_sched_barrier(0);
+        };
+        // input piece h0 with both weight pieces (main | cross), row by row; then h1 with g0 (cross): per accumulator the order of
+        // conv_c16b's phases -- main: g0 h0; cross: g1 h0, g0 h1 -- and steps in ascending order
+        ab_static_for<nr>([&](auto RR) __attribute__((always_inline)) {
+          constexpr int i = decltype(RR)::value, kh = G == 2 ? 0 : kh_lo + i, t = G == 2 ? y : y - kh;
+          const f16x8& f0 = G == 2 ? F6[y][0] : F[u % 3][0];
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[set][kh][0], f0, acc[t], 0, 0, 0);
+          hook(IC<2 * i>{});
+          accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[set][kh][1], f0, accx[t], 0, 0, 0);
+          hook(IC<2 * i + 1>{});
+        });
+        ab_static_for<nr>([&](auto RR) __attribute__((always_inline)) {
+          constexpr int i = decltype(RR)::value, kh = G == 2 ? 0 : kh_lo + i, t = G == 2 ? y : y - kh;
+          const f16x8& f1 = G == 2 ? F6[y][1] : F[u % 3][1];
+          accx[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A[set][kh][0], f1, accx[t], 0, 0, 0);
+          hook(IC<2 * nr + i>{});
         });
       });
       ABDBG(1)
@@ -539,7 +584,7 @@ extern "C" int atvs_aanet_b_pack_size(long* packed_bytes) {
 }
 
 // HOST function.  w_shared, w_unique: TF kernels [3,3,3,8,8] (attention_activation/weight_shared, weight_unique).
-// packed[step j][piece][lane = q*16 + row][8 fp16] = piece of w[tap 4 j + q][ci = e][row -> (S | R, channel)]: row 4 g + i of lane group
+// packed[step j][piece][lane = q*16 + row][8 fp16] = piece of w[tap atvs_tap8(j, q)][ci = e][row -> (S | R, channel)]: row 4 g + i of lane group
 // g is channel 2 g + (i & 1) of W_shared (i < 2) or W_unique (i >= 2) -- a lane of the kernel then holds S and R of ITS two channels.
 // Pieces as atvs_conv_c16b_pack; ATVS_ERR_ARG for a weight beyond fp16's range.
 extern "C" int atvs_aanet_b_pack(const float* w_shared, const float* w_unique, unsigned char* packed) {
@@ -551,7 +596,7 @@ extern "C" int atvs_aanet_b_pack(const float* w_shared, const float* w_unique, u
   bool fits = true;
   for (int j = 0; j < AB_JC; ++j)
     for (int q = 0; q < 4; ++q) {
-      const int tap = 4 * j + q;
+      const int tap = atvs_tap8(j, q);
       if (tap > 26) continue;
       for (int row = 0; row < 16; ++row) {
         const int g = row >> 2, i = row & 3, c = 2 * g + (i & 1);

@@ -42,6 +42,9 @@ struct B16 {
   static_assert(MAXS <= 2 * JC, "two halo slots per K step");
   // byte displacement of tap t from halo voxel (wave, 0, r): (kd, kh) rows + kw voxels
   static constexpr int clamp26(int t) { return t < 26 ? t : 26; }
+  // the tap of lane-group slot i of K step j (fragment ADDRESS: a tap past 26 has zero weights and re-reads tap 26): Cin = 16 walks the
+  // taps in order, two per step; Cin = 8 uses the shared order of aanet_b.hip (atvs_tap8, conv_common.h)
+  static constexpr int tap(int j, int i) { return clamp26(CIN == 8 ? atvs_tap8(j, i) : TPS * j + i); }
   static constexpr int disp(int t) { return ((t / 9) * B16_HY + (t / 3) % 3) * ROWB + (t % 3) * VB; }
 };
 constexpr int B16_NP = 2;                                     // operand pieces
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     auto request_B = [&](auto PH) __attribute__((always_inline)) {
       constexpr int ph = decltype(PH)::value, j = ph / B16_NP, pc = ph % B16_NP;
       // this lane group's tap of the step (taps past 26 have zero weights: re-read tap 26's fragment)
-      constexpr int tA = K::clamp26(K::TPS * j), tB = K::clamp26(K::TPS * j + 1), tC = K::clamp26(K::TPS * j + 2), tD = K::clamp26(K::TPS * j + 3);
+      constexpr int tA = K::tap(j, 0), tB = K::tap(j, 1), tC = K::tap(j, 2), tD = K::tap(j, 3);
       int a;
       if constexpr (K::TPS == 2) a = fbase + ((q >> 1) ? K::disp(tB) : K::disp(tA));
       else a = fbase + ((q & 2) ? ((q & 1) ? K::disp(tD) : K::disp(tC)) : ((q & 1) ? K::disp(tB) : K::disp(tA)));
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
     };
     auto request_B1 = [&](auto PH, auto TT) __attribute__((always_inline)) {      // row t of phase ph
       constexpr int ph = decltype(PH)::value, j = ph / B16_NP, pc = ph % B16_NP, t = decltype(TT)::value;
-      constexpr int tA = K::clamp26(K::TPS * j), tB = K::clamp26(K::TPS * j + 1), tC = K::clamp26(K::TPS * j + 2), tD = K::clamp26(K::TPS * j + 3);
+      constexpr int tA = K::tap(j, 0), tB = K::tap(j, 1), tC = K::tap(j, 2), tD = K::tap(j, 3);
       int a;
       if constexpr (K::TPS == 2) a = fbase + ((q >> 1) ? K::disp(tB) : K::disp(tA));
       else a = fbase + ((q & 2) ? ((q & 1) ? K::disp(tD) : K::disp(tC)) : ((q & 1) ? K::disp(tB) : K::disp(tA)));
@@ -384,8 +387,9 @@ extern "C" int atvs_conv_c16b_pack_size(int Cin, long* packed_bytes) {
   return ATVS_OK;
 }
 
-// HOST function.  packed[step j][piece][lane = q*16 + co][8 bf16] = piece of w[tap = TPS*j + q / LPT][ci = (q % LPT)*8 + e][co]
-// (TPS = 32 / Cin taps per step, LPT = 4 / TPS lane groups per tap; zero for taps past 26), pieces g0 = f16(w),
+// HOST function.  packed[step j][piece][lane = q*16 + co][8 fp16] = piece of w[tap][ci = (q % LPT)*8 + e][co], tap = TPS*j + q / LPT
+// for Cin = 16 (TPS = 32 / Cin taps per step, LPT = 4 / TPS lane groups per tap) and atvs_tap8(j, q) for Cin = 8 (conv_common.h); zero
+// for taps past 26; pieces g0 = f16(w),
 // g1 = f16((w - g0) * 2048), round to nearest even.  ATVS_ERR_ARG if a weight does not fit fp16's range (|w| > 65504).
 extern "C" int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packed) {
   if (!w || !packed) return ATVS_ERR_NULL;
@@ -398,7 +402,7 @@ extern "C" int atvs_conv_c16b_pack(const float* w, int Cin, unsigned char* packe
   bool fits = true;
   for (int j = 0; j < JC; ++j)
     for (int q = 0; q < 4; ++q) {
-      const int tap = TPS * j + q / LPT;
+      const int tap = Cin == 8 ? atvs_tap8(j, q) : TPS * j + q / LPT;
       if (tap > 26) continue;
       for (int co = 0; co < 16; ++co)
         for (int e = 0; e < 8; ++e) {
