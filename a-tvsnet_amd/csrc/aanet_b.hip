@@ -251,8 +251,12 @@ __global__ __launch_bounds__(512, 1) void aanet_b_kernel(AbArgs p) {
       const int hb = hbase + (s & 1) * AB_HBUF;
 #pragma unroll
       for (int t = 0; t < TY; ++t) {
-        float a0 = (acc[t][0] + accx[t][0] * AB_IRS) + 0.f, a1 = (acc[t][1] + accx[t][1] * AB_IRS) + 0.f;
-        float a2 = (acc[t][2] + accx[t][2] * AB_IRS) + 0.f, a3 = (acc[t][3] + accx[t][3] * AB_IRS) + 0.f;
+        // conv_c16b's (main + cross * 2^-11) + bias(0), ReLU in THREE instructions per value instead of five: the product by a power
+        // of two is exact, so the fused multiply-add rounds what the separate add rounds; "+ 0.f" only turns -0 into +0, which the
+        // partner's arithmetic cannot tell apart (S enters as 0.f + S and as R - S).  These instructions share the SIMD's issue with
+        // the partner: every one of them is stage time.
+        float a0 = __builtin_fmaf(accx[t][0], AB_IRS, acc[t][0]), a1 = __builtin_fmaf(accx[t][1], AB_IRS, acc[t][1]);
+        float a2 = __builtin_fmaf(accx[t][2], AB_IRS, acc[t][2]), a3 = __builtin_fmaf(accx[t][3], AB_IRS, acc[t][3]);
         a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;      // compare + select, not v_max: a NaN stays a NaN
         a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
         *reinterpret_cast<float4*>(smem + hb + t * 1024) = make_float4(a0, a1, a2, a3);
