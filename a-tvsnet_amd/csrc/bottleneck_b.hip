@@ -64,12 +64,30 @@ __device__ __forceinline__ void bt_split(const float v[4], f16x4* p0, f16x4* p1)
   *p0 = a.h;
   *p1 = b.h;
 }
+// ... of eight values that go STRAIGHT into a matrix instruction (conv1's B operand, never through LDS): the C form, not the
+// inline assembly.  The hazard recogniser does not look inside an asm statement: with atvs_split2_f16 here the compiler placed a
+// v_mfma_f32_16x16x32_f16 directly behind the v_cvt_pk_f16_f32 that wrote its B registers, without the wait states a
+// compiler-visible VALU write gets, and on gfx950 the multiply then read stale registers (round 6: garbage in the last row group of
+// the 64-channel unit as soon as the one-fma batch norm removed the few instructions that used to sit between the two).  Eight to
+// nine instructions per two values instead of five, ~100 per tile; the values are the same (every step is exact before its one
+// rounding), so the unit stays bitwise the three launches.
+typedef float bt_f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 bt_f16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void bt_split8(const float v[8], f16x8* p0, f16x8* p1) {
-  BtO a, b;
+  f16x8 a, b;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) atvs_split2_f16(v[2 * i], v[2 * i + 1], BT_RS, &a.u[i], &b.u[i]);
-  *p0 = a.h;
-  *p1 = b.h;
+  for (int i = 0; i < 4; ++i) {
+    const bt_f32x2 x = {v[2 * i], v[2 * i + 1]};
+    const bt_f16x2 h = __builtin_convertvector(x, bt_f16x2);
+    const bt_f32x2 r = {(x[0] - (float)h[0]) * BT_RS, (x[1] - (float)h[1]) * BT_RS};
+    const bt_f16x2 l = __builtin_convertvector(r, bt_f16x2);
+    a[2 * i] = h[0];
+    a[2 * i + 1] = h[1];
+    b[2 * i] = l[0];
+    b[2 * i + 1] = l[1];
+  }
+  *p0 = a;
+  *p1 = b;
 }
 
 // Workgroup barrier for LDS hand-offs that leaves global loads IN FLIGHT: __syncthreads() drains vmcnt too, which would turn every
@@ -187,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void bottleneck_b_kernel(BtArgs p) {
         float v[8] = {xa[i][ch].x, xa[i][ch].y, xa[i][ch].z, xa[i][ch].w, xb[i][ch].x, xb[i][ch].y, xb[i][ch].z, xb[i][ch].w};
         f16x8 h0, h1;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = in[i] ? fmaxf((v[e] - mm[ch][e]) * ss[ch][e] + cc[ch][e], 0.f) : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = in[i] ? fmaxf(atvs_bn1(v[e], ss[ch][e], atvs_bn_shift(mm[ch][e], ss[ch][e], cc[ch][e])), 0.f) : 0.f;
         bt_split8(v, &h0, &h1);
 #pragma unroll
         for (int n = 0; n < NT; ++n) {

@@ -100,6 +100,21 @@ __device__ __forceinline__ void homography_apply(const float* __restrict__ Hm, i
   *yw = ya / dv;
 }
 
+// Training-mode batch norm of one value, y = (x - mean) * scale + beta, as ONE fused multiply-add: x * scale + shift with
+// shift = beta - mean * scale formed once per channel -- the form tf.nn.batch_normalization itself computes (inv = rsqrt(var + eps);
+// x * inv + (offset - mean * inv); the reference's 3-D batch norms take that path: tf.layers.batch_normalization on 5-D inputs,
+// /root/reference/cnn_wrapper/network.py:206-212).  ONE definition for every kernel that normalises: the element-wise passes
+// (norm.hip) and every convolution that normalises its input on load must agree bit for bit.  Two instructions per value with the
+// ReLU instead of four (sub, mul, add, max): in the two-role kernels every staging instruction is stage time.
+__device__ __forceinline__ float atvs_bn_shift(float mean, float scale, float beta) { return __builtin_fmaf(-mean, scale, beta); }
+__device__ __forceinline__ float atvs_bn1(float x, float scale, float shift) { return __builtin_fmaf(x, scale, shift); }
+__device__ __forceinline__ float4 atvs_bn_shift4(const float4& m, const float4& s, const float4& b) {
+  return make_float4(atvs_bn_shift(m.x, s.x, b.x), atvs_bn_shift(m.y, s.y, b.y), atvs_bn_shift(m.z, s.z, b.z), atvs_bn_shift(m.w, s.w, b.w));
+}
+__device__ __forceinline__ float4 atvs_bn4(const float4& v, const float4& s, const float4& sh) {
+  return make_float4(atvs_bn1(v.x, s.x, sh.x), atvs_bn1(v.y, s.y, sh.y), atvs_bn1(v.z, s.z, sh.z), atvs_bn1(v.w, s.w, sh.w));
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 // 16-byte store of data its producer does not read again (large volumes consumed by a LATER kernel): the non-temporal hint

@@ -54,13 +54,11 @@ __global__ __launch_bounds__(256, 2) void conv1x1_kernel(C1Args p) {
     if (!ip) return;
     const int c = j * 16 + q * 4;
     const float4 m = ld4(ip + c), s = ld4(ip + p.Cin + c), be = ld4(ip + 2 * p.Cin + c);
+    const float4 sh = atvs_bn_shift4(m, s, be);
 #pragma unroll
     for (int t = 0; t < TM; ++t) {
       float4 v = b[t];
-      v.x = (v.x - m.x) * s.x + be.x;
-      v.y = (v.y - m.y) * s.y + be.y;
-      v.z = (v.z - m.z) * s.z + be.z;
-      v.w = (v.w - m.w) * s.w + be.w;
+      v = atvs_bn4(v, s, sh);
       if (p.in_relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }

@@ -132,10 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_b_kernel(C2bArgs p) {
       if (ip && ((valid >> i) & 1u)) {
         const int c = ((tid + i * 256) & 3) * 4;
         const float4 m = ld4(ip + c), s = ld4(ip + p.Cin + c), b = ld4(ip + 2 * p.Cin + c);
-        v.x = (v.x - m.x) * s.x + b.x;
-        v.y = (v.y - m.y) * s.y + b.y;
-        v.z = (v.z - m.z) * s.z + b.z;
-        v.w = (v.w - m.w) * s.w + b.w;
+        v = atvs_bn4(v, s, atvs_bn_shift4(m, s, b));
         if (p.in_relu) {
           v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }

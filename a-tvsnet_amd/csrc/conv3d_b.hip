@@ -209,10 +209,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_b_kernel(C3bArgs p) {
       if (i < MAXS - 1 || tid + i * 256 < C3B_SLOTS) {
         if (NORM) {
           float4 a = pf[i];
-          a.x = (a.x - bnm.x) * bns.x + bnb.x;
-          a.y = (a.y - bnm.y) * bns.y + bnb.y;
-          a.z = (a.z - bnm.z) * bns.z + bnb.z;
-          a.w = (a.w - bnm.w) * bns.w + bnb.w;
+          a = atvs_bn4(a, bns, atvs_bn_shift4(bnm, bns, bnb));
           a.x = fmaxf(a.x, nfloor); a.y = fmaxf(a.y, nfloor); a.z = fmaxf(a.z, nfloor); a.w = fmaxf(a.w, nfloor);     // ReLU or nothing
           const unsigned t1 = pg[i] - Tc.lo;
           const unsigned t2 = Tc.hi1 + ~pg[i];

@@ -195,10 +195,7 @@ __global__ __launch_bounds__(256, 1) void conv3d_s2b_kernel(S2Args p) {
     float4 a = pf[i];
     if (NORM) {
       const float nfloor = p.in_relu ? 0.f : -INFINITY;
-      a.x = (a.x - rm.x) * rs.x + rb.x;
-      a.y = (a.y - rm.y) * rs.y + rb.y;
-      a.z = (a.z - rm.z) * rs.z + rb.z;
-      a.w = (a.w - rm.w) * rs.w + rb.w;
+      a = atvs_bn4(a, rs, atvs_bn_shift4(rm, rs, rb));
       a.x = fmaxf(a.x, nfloor); a.y = fmaxf(a.y, nfloor); a.z = fmaxf(a.z, nfloor); a.w = fmaxf(a.w, nfloor);     // ReLU or nothing
       // a halo slot outside the volume: its padding stays zero
       const unsigned t1 = pg[i] - TT.lo;

@@ -196,10 +196,7 @@ __global__ __launch_bounds__(256, 1) void conv_c16b_kernel(B16Args p) {
   auto pro_term = [&](const float4& v, int k, const float* par) __attribute__((always_inline)) {
     float4 o = v;
     if (par) {
-      o.x = (v.x - bnm[k].x) * bns[k].x + bnb[k].x;
-      o.y = (v.y - bnm[k].y) * bns[k].y + bnb[k].y;
-      o.z = (v.z - bnm[k].z) * bns[k].z + bnb[k].z;
-      o.w = (v.w - bnm[k].w) * bns[k].w + bnb[k].w;
+      o = atvs_bn4(v, bns[k], atvs_bn_shift4(bnm[k], bns[k], bnb[k]));
       const float fl = ((p.relu_mask >> k) & 1) ? 0.f : -INFINITY;      // ReLU or nothing, branch-free
       o.x = fmaxf(o.x, fl); o.y = fmaxf(o.y, fl); o.z = fmaxf(o.z, fl); o.w = fmaxf(o.w, fl);
     }

@@ -406,7 +406,7 @@ __global__ __launch_bounds__(512, 1) void conv_xb_kernel(XbArgs p) {
     const float lo_a = __builtin_canonicalizef(has_a ? floor_a : -__builtin_huge_valf()),
                 lo_b = __builtin_canonicalizef(has_b ? floor_b : -__builtin_huge_valf());
     auto bn1 = [&](float v, float m, float sc, float be, float lo) __attribute__((always_inline)) {
-      return fmaxf((v - m) * sc + be, lo);               // bn_apply's arithmetic (norm.hip): sub, mul, add -- no contraction
+      return fmaxf(atvs_bn1(v, sc, atvs_bn_shift(m, sc, be)), lo);      // bn_apply's arithmetic (norm.hip, common.h): one fused multiply-add on the shift
     };
     // slot i of the stage in the registers (prologue, split) -> image buffer at byte `ib`
     auto stage_slot = [&](int i, const Par& P, unsigned vmask, int ib) __attribute__((always_inline)) {

@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 1) void conv_xw_kernel(XwArgs p) {
     return P;
   };
   auto bn2 = [&](f32x2 v, f32x2 m, f32x2 sc, f32x2 be, float lo, bool has) __attribute__((always_inline)) {
-    f32x2 t = (v - m) * sc + be;
+    f32x2 t = __builtin_elementwise_fma(v, sc, __builtin_elementwise_fma(-m, sc, be));      // atvs_bn1 (common.h) on a pair
     t.x = fmaxf(t.x, lo);
     t.y = fmaxf(t.y, lo);
     t.x = has ? t.x : v.x;

@@ -303,10 +303,7 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
   auto pro_term = [&](const float4& v, int k, const float* par) __attribute__((always_inline)) {
     float4 o = v;
     if (par) {
-      o.x = (v.x - bnm[k].x) * bns[k].x + bnb[k].x;
-      o.y = (v.y - bnm[k].y) * bns[k].y + bnb[k].y;
-      o.z = (v.z - bnm[k].z) * bns[k].z + bnb[k].z;
-      o.w = (v.w - bnm[k].w) * bns[k].w + bnb[k].w;
+      o = atvs_bn4(v, bns[k], atvs_bn_shift4(bnm[k], bns[k], bnb[k]));
       if ((p.relu_mask >> k) & 1) {
         o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
       }

@@ -3,7 +3,7 @@
 //
 // Reference: tf.layers.batch_normalization(center=False, scale=False, training=True)
 // at /root/reference/cnn_wrapper/network.py:206-212, 541-547; slim.batch_norm
-// (center=True) at :570-571; tf.add_n at :695-697.  y = (x - mean) * rsqrt(var + 1e-3)
+// (center=True) at :570-571; tf.add_n at :695-697.  y = (x - mean) * rsqrt(var + 1e-3) (as x * scale + (beta - mean * scale): atvs_bn1, common.h)
 // [+ beta], biased variance over every axis but the channel.
 //
 // Statistics are deterministic: fixed-shape per-workgroup partial sums (written by
@@ -125,16 +125,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   long a = (ld == C) ? i : (i / C) * ld + c_off + c;
   if (VEC == 4) {
     float4 v = ld4(x + a), m = ld4(params + c), s = ld4(params + C + c), b = ld4(params + 2 * C + c);
-    v.x = (v.x - m.x) * s.x + b.x;
-    v.y = (v.y - m.y) * s.y + b.y;
-    v.z = (v.z - m.z) * s.z + b.z;
-    v.w = (v.w - m.w) * s.w + b.w;
+    v = atvs_bn4(v, s, atvs_bn_shift4(m, s, b));
     if (relu) {
       v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     st4(y + a, v);
   } else {
-    float v = (x[a] - params[c]) * params[C + c] + params[2 * C + c];
+    float v = atvs_bn1(x[a], params[C + c], atvs_bn_shift(params[c], params[C + c], params[2 * C + c]));
     y[a] = relu ? fmaxf(v, 0.f) : v;
   }
 }
@@ -201,10 +198,7 @@ __global__ __launch_bounds__(256) void bn_add_kernel(const float* __restrict__ x
     if (p) {
       p += pg;
       float4 m = ld4(p + c), s = ld4(p + C + c), b = ld4(p + 2 * C + c);
-      v.x = (v.x - m.x) * s.x + b.x;
-      v.y = (v.y - m.y) * s.y + b.y;
-      v.z = (v.z - m.z) * s.z + b.z;
-      v.w = (v.w - m.w) * s.w + b.w;
+      v = atvs_bn4(v, s, atvs_bn_shift4(m, s, b));
       if (relu) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
       }
