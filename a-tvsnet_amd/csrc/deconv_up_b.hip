@@ -117,7 +117,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 struct UpBArgs {
   const float* x;
-  // PRO form: the input is the U-Net's skip SUM, formed while the halo is staged (the bn_add pass it replaces, norm.hip):
+  // summing form (deconv_up_b_sum_kernel): the input is the U-Net's skip SUM, formed while the halo is staged (the bn_add pass it replaces, norm.hip):
   //   x_in = t(x, pa, bit 0) + t(x2, pb, bit 1) [+ t(x3, pc, bit 2)],  t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v
   const float* x2;
   const float* x3;            // null: two terms
@@ -154,16 +154,15 @@ __device__ __forceinline__ void ub_static_for(F&& f) {
 // one chunk each (compact layout, 2 x 27 KB: two workgroups per CU still fit), the NEXT stage's chunk fetched by LDS-DMA
 // (global_load ... lds: no registers) while this stage's K loop runs.  (Round 4: one buffer, copied through registers between
 // the barriers of every stage -- 3.8 k of an 8.3 k-cycle stage, tools_dev/phase_ub.py.)
-// PRO: the skip sum formed on load (Cin = 16: one chunk; one workgroup per CU -- the three sources of a stage are in flight in
-// 84 registers, which two workgroups per CU do not have)
-template <int COUT, bool STREAMW, bool PRO>
-__global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(UpBArgs p) {
+// (The skip sum formed on load was a third form of this kernel in rounds 5 / 6; it is deconv_up_b_sum_kernel below: two roles.)
+template <int COUT, bool STREAMW>
+__global__ __launch_bounds__(256, UB_WGS_PER_CU(COUT)) void deconv_up_b_kernel(UpBArgs p) {
   using U = UpB<COUT>;
   constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG, WCH = U::WCH;
   // the forms that run ONE workgroup per CU (one wavefront per SIMD) reserve the SIMD's whole register file like conv_c16b: no
   // wavefront of another kernel then runs beside their 16x16x32 MFMAs (such a neighbour with packed fp32
   // arithmetic computed wrong lane quarters; only reachable with co-residency switched on).  The two-per-CU forms cannot.
-  if constexpr (PRO || UB_WGS_PER_CU(COUT) == 1) asm volatile("" ::: "v255", "a255");
+  if constexpr (UB_WGS_PER_CU(COUT) == 1) asm volatile("" ::: "v255", "a255");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -246,20 +245,6 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
   }
   const int nstage = my_tiles * p.nchunk;
-  // PRO: the other sources and the batch-norm rows of this thread's four channels (c4 = tid & 3 in every slot; one chunk)
-  const float* __restrict__ xg2 = PRO ? p.x2 + (size_t)grp * p.gx : nullptr;
-  const float* __restrict__ xg3 = (PRO && p.x3) ? p.x3 + (size_t)grp * p.gx : nullptr;
-  float4 bnm[3], bns[3], bnb[3];
-  if (PRO) {
-    const float* pr[3] = {p.pa, p.pb, p.pc};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const float* q3 = pr[k] ? pr[k] + (size_t)grp * 3 * p.Cin + (tid & 3) * 4 : nullptr;
-      bnm[k] = q3 ? ld4(q3) : make_float4(0.f, 0.f, 0.f, 0.f);
-      bns[k] = q3 ? ld4(q3 + p.Cin) : make_float4(1.f, 1.f, 1.f, 1.f);
-      bnb[k] = q3 ? ld4(q3 + 2 * p.Cin) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
   auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
     int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
     int bx = tl % p.tiles_x;
@@ -286,50 +271,13 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
             ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
     return T;
   };
-  float4 pf[MAXS], pf2[PRO ? MAXS : 1], pf3[PRO ? MAXS : 1];
-  unsigned okm_next = 0;                   // PRO: which slots of the stage being fetched lie inside the volume (a term of 0 is not 0 after its batch norm)
+  float4 pf[MAXS];
   auto pf_slot = [&](const PfTile& T, int i) __attribute__((always_inline)) {
     const unsigned t1 = pg[i] - T.lo;
     const unsigned t2 = T.hi1 + ~pg[i];
     const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
     pf[i] = ld4(ok ? (T.xb + (T.org + goff[i])) : p.zeros);
-    if (PRO) {
-      pf2[i] = ld4(ok ? (xg2 + (T.xb - xg) + (T.org + goff[i])) : p.zeros);
-      if (xg3) pf3[i] = ld4(ok ? (xg3 + (T.xb - xg) + (T.org + goff[i])) : p.zeros);
-      okm_next = (okm_next & ~(1u << i)) | ((ok ? 1u : 0u) << i);
-    }
   };
-  // one term of the sum: bn_add_kernel's arithmetic (norm.hip), term k of this thread's channel group
-  auto pro_term = [&](const float4& v, int k, const float* par) __attribute__((always_inline)) {
-    float4 o = v;
-    if (par) {
-      o = atvs_bn4(v, bns[k], atvs_bn_shift4(bnm[k], bns[k], bnb[k]));
-      if ((p.relu_mask >> k) & 1) {
-        o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
-      }
-    }
-    return o;
-  };
-
-  // PRO: slot i of the stage in flight -> the two fp16 pieces of its sum, kept in pf[i] (p0 | p1).  Done where the vector unit has
-  // nothing else to do -- behind the K loop's later phases (slots 0..3: their loads are four phases old) and behind the epilogue's
-  // stores -- instead of in front of the next stage's LDS writes, where all four wavefronts waited for it (round 5: 384 -> .. us)
-  auto pro_slot = [&](int i) __attribute__((always_inline)) {
-    float4 a = pro_term(pf[i], 0, p.pa);
-    const float4 b = pro_term(pf2[i], 1, p.pb);
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    if (xg3) {
-      const float4 d = pro_term(pf3[i], 2, p.pc);
-      a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
-    }
-    const bool in = (okm_next >> i) & 1u;
-    uint2 p0, p1;
-    atvs_split2_f16(in ? a.x : 0.f, in ? a.y : 0.f, UB_RS, &p0.x, &p1.x);
-    atvs_split2_f16(in ? a.z : 0.f, in ? a.w : 0.f, UB_RS, &p0.y, &p1.y);
-    pf[i] = make_float4(__uint_as_float(p0.x), __uint_as_float(p0.y), __uint_as_float(p1.x), __uint_as_float(p1.y));
-  };
-  constexpr int PRO_INLOOP = 4;            // slots transformed behind phases 4..7 of the K loop
-
   float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};       // scalar on purpose (two workgroups share a CU)
   f32x4 acc[TY][NT], accx[TY][NT];       // h0 g0 | (h0 g1 + h1 g0) * 2^11
   const unsigned ybytes = (unsigned)(p.gy * 4);
@@ -339,10 +287,6 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     const PfTile T0 = pf_tile(0);
 #pragma unroll
     for (int i = 0; i < MAXS; ++i) pf_slot(T0, i);
-    if (PRO) {
-#pragma unroll
-      for (int i = 0; i < MAXS; ++i) pro_slot(i);
-    }
   }
 
   UDBG(6)
@@ -361,13 +305,8 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
     for (int i = 0; i < MAXS; ++i)
       if (i < MAXS - 1 || tid + i * 256 < U::SLOTS) {
         uint2 p0, p1;
-        if (PRO) {                           // already the pieces (pro_slot)
-          p0 = make_uint2(__float_as_uint(pf[i].x), __float_as_uint(pf[i].y));
-          p1 = make_uint2(__float_as_uint(pf[i].z), __float_as_uint(pf[i].w));
-        } else {
-          atvs_split2_f16(pf[i].x, pf[i].y, UB_RS, &p0.x, &p1.x);
-          atvs_split2_f16(pf[i].z, pf[i].w, UB_RS, &p0.y, &p1.y);
-        }
+        atvs_split2_f16(pf[i].x, pf[i].y, UB_RS, &p0.x, &p1.x);
+        atvs_split2_f16(pf[i].z, pf[i].w, UB_RS, &p0.y, &p1.y);
         *reinterpret_cast<uint2*>(smem + laddr[i]) = p0;
         *reinterpret_cast<uint2*>(smem + U::IMG + laddr[i]) = p1;
       }
@@ -436,10 +375,6 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         __builtin_amdgcn_sched_barrier(0);
         request_A1(IC<g + 1>{});
       }
-      if constexpr (PRO && ph >= UB_NP * NG - PRO_INLOOP) {      // a slot whose loads are four phases old
-        constexpr int sl = ph - (UB_NP * NG - PRO_INLOOP);
-        if constexpr (sl < MAXS) pro_slot(sl);
-      }
     });
     static_assert(UB_NP * NG >= MAXS, "every halo slot is requested inside the K loop");
     UDBG(4)
@@ -482,10 +417,6 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
         ssq[2] = __builtin_fmaf(b2, b2, ssq[2]); ssq[3] = __builtin_fmaf(b3, b3, ssq[3]);
       });
     });
-    if (PRO) {                               // the remaining slots, behind the stores
-#pragma unroll
-      for (int i = PRO_INLOOP; i < MAXS; ++i) pro_slot(i);
-    }
     UDBG(5)
   }
 
@@ -532,6 +463,326 @@ __global__ __launch_bounds__(256, PRO ? 1 : UB_WGS_PER_CU(COUT)) void deconv_up_
   }
 }
 
+// ---- The summing decoder in TWO ROLES (round 6, second half) ------------------------------------------------------------------
+// The full-resolution decoder conv_b*_6_0 / global_refine_3dconv6_0 (16 -> 8) whose input is the U-Net's skip SUM, formed while the halo
+// is staged (the bn_add pass it replaces, norm.hip):  x_in = t(x, pa, bit 0) + t(x2, pb, bit 1) [+ t(x3, pc, bit 2)],
+// t(v, par, relu) = par ? relu?(bn(v)) : v.  Rounds 5 / 6 first half: a form of the kernel above with ONE workgroup of four wavefronts
+// per CU (the three sources of a stage in flight in 84 registers), every stage a chain -- barrier, the pieces into LDS, barrier, the K
+// loop (the next halo's 21 loads per thread issued and four slots transformed in its shadow), the epilogue's stores (three more slots
+// transformed behind them): 13.4 k cycles per stage against 9.1 k of the plain form on a materialised sum (phase timers at the bench's
+// shape, three terms, cold inputs; 459 / 407 us per launch with three / two terms, 360 us inside a depth map).
+// Here wavefronts 0-3 MULTIPLY (LDS fragment reads, MFMAs, the epilogue's stores and moments: the instruction stream of the plain form
+// without its halo requests) and wavefronts 4-7 STAGE the next tile (its 21 loads per thread stay in flight across a whole stage, then
+// the batch norms, the sum, the split, the LDS writes into the OTHER image pair): one LDS-only barrier per stage, global loads and
+// stores stay in flight across it.  400 / 317 us cold, 318 us inside a depth map (-0.17 ms per map).  What a stage now waits for is
+// memory on BOTH sides (tools_dev/phase_ub_sum.py, -DATVS_UB_DEBUG): with three terms the staging role spends 5.6 k of its 10.6 k
+// cycles ISSUING the next 21 loads (the queue is full) and the multiply role 4.7 k in the epilogue's stores; with two terms the
+// epilogue's stores are 6.1 k of 9.4 k -- a stage moves 82 KB of halo reads (1.66 x its tile: 5 x 5 x 17 voxels for 4 x 4 x 16) and
+// 66 KB of stores per CU, 6 TB/s over the 256 CUs counting the halo's re-reads.
+// Same tiles, same lanes, same order per value as the one-role form: bit for bit bn_add followed by the plain decoder, moments included
+// (tests/test_gpu_groups.py::test_deconv_sums_its_inputs_on_load_bitwise).
+__device__ __forceinline__ void ub_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(512, 1) void deconv_up_b_sum_kernel(UpBArgs p) {
+  using U = UpB<8>;
+  constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
+  constexpr int IMG2 = UB_NP * U::IMG;                  // one image pair (h0 | h1)
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const bool staging = wave >= 4;                       // wave-uniform
+  const int mw = wave & 3;                              // multiply: the z plane of the tile; staging: rank among the staging wavefronts
+  const int stid = tid & 255;
+  const int r = lane & 15, q = lane >> 4;
+#ifdef ATVS_UB_DEBUG
+  // multiply: 0 = K loop, 1 = epilogue, 2 = waiting at the barrier; staging: 0 = batch norms + sum + split + LDS writes (behind the wait
+  // for the loads), 1 = the next requests, 2 = waiting at the barrier
+  unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long dbg_t = clock64();
+  const unsigned long long dbg_w0 = wall_clock64();
+#endif
+
+  // packed weights of the one chunk -> LDS behind the two image pairs, once, by all eight wavefronts
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.wp);
+    unsigned char* dstb = smem + 2 * IMG2;
+    for (int sp = wave; sp < U::NSTEP * UB_NP; sp += 8) reinterpret_cast<float4*>(dstb + sp * 1024)[lane] = src[sp * 64 + lane];
+  }
+  const int wb = 2 * IMG2;
+
+  const int G = p.wg;
+  const int grp = blockIdx.x / p.wg, lbk = blockIdx.x - grp * p.wg;
+  const int xcd = lbk & 7, tslot = lbk >> 3;
+  const float* __restrict__ xg = p.x + (size_t)grp * p.gx;
+  const float* __restrict__ xg2 = p.x2 + (size_t)grp * p.gx;
+  const float* __restrict__ xg3 = p.x3 ? p.x3 + (size_t)grp * p.gx : nullptr;
+  float* __restrict__ yg = p.y + (size_t)grp * p.gy;
+  const int per_xcd = (p.ntiles + 7) >> 3;
+  const int slots_per_xcd = G >> 3;
+  int my_tiles = 0;
+  {
+    int last = min(per_xcd, p.ntiles - xcd * per_xcd);
+    if (tslot < last) my_tiles = (last - tslot + slots_per_xcd - 1) / slots_per_xcd;
+  }
+  const int nstage = my_tiles;
+  auto tile_origin = [&](int k, int* z0, int* y0, int* x0) __attribute__((always_inline)) {
+    int tl = xcd * per_xcd + tslot + k * slots_per_xcd;
+    int bx = tl % p.tiles_x;
+    int rest = tl / p.tiles_x;
+    *x0 = bx * UB_TX;
+    *y0 = (rest % p.tiles_y) * TY;
+    *z0 = (rest / p.tiles_y) * UB_TZ;
+  };
+  float ssum[4] = {0.f, 0.f, 0.f, 0.f}, ssq[4] = {0.f, 0.f, 0.f, 0.f};
+
+  if (staging) {
+    // ======== staging role: halo slots stid, stid + 256, ... (4 channels of a halo voxel each) of the NEXT stage
+    __builtin_amdgcn_s_setprio(3);
+    int goff[MAXS], laddr[MAXS];
+    unsigned pg[MAXS];
+#pragma unroll
+    for (int i = 0; i < MAXS; ++i) {
+      int sl = stid + i * 256;
+      const bool live = sl < U::SLOTS;
+      sl = min(sl, U::SLOTS - 1);
+      const int c4 = sl & 3, v = sl >> 2;
+      const int xx = v % UB_HX, v2 = v / UB_HX;
+      const int yy = v2 % HY, zz = v2 / HY;
+      goff[i] = ((zz * p.Hi + yy) * p.Wi + xx) * p.Cin + c4 * 4;
+      laddr[i] = ((zz * HY + yy) * UB_HX + xx) * UB_VB + c4 * 8;
+      pg[i] = 0x808080u | (unsigned)(live ? zz : 0x7f) | ((unsigned)yy << 8) | ((unsigned)xx << 16);
+    }
+    // the batch-norm rows of this thread's four channels (c4 = stid & 3 in every slot): scale and shift (atvs_bn_shift4: the one-fma
+    // form every site of a batch norm uses)
+    float4 bns[3], bsh[3];
+    {
+      const float* pr[3] = {p.pa, p.pb, p.pc};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const float* q3 = pr[k] ? pr[k] + (size_t)grp * 3 * p.Cin + (stid & 3) * 4 : nullptr;
+        const float4 m = q3 ? ld4(q3) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bns[k] = q3 ? ld4(q3 + p.Cin) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 b = q3 ? ld4(q3 + 2 * p.Cin) : make_float4(0.f, 0.f, 0.f, 0.f);
+        bsh[k] = atvs_bn_shift4(m, bns[k], b);
+      }
+    }
+    float4 pf[MAXS], pf2[MAXS], pf3[MAXS];
+    unsigned okm = 0;                        // which slots of the stage in flight lie inside the volume
+    auto request = [&](int stage) __attribute__((always_inline)) {
+      int z0, y0, x0;
+      tile_origin(stage, &z0, &y0, &x0);
+      const int gz0 = z0 - 1, gy0 = y0 - 1, gx0 = x0 - 1;
+      const int org = ((gz0 * p.Hi + gy0) * p.Wi + gx0) * p.Cin;
+      const unsigned lo = (unsigned)(gz0 < 0) | ((unsigned)(gy0 < 0) << 8) | ((unsigned)(gx0 < 0) << 16);
+      const unsigned hi1 = (unsigned)(min(p.Di - 1 - gz0, 0x7e) + 1) | ((unsigned)(min(p.Hi - 1 - gy0, 0x7e) + 1) << 8) |
+                           ((unsigned)(min(p.Wi - 1 - gx0, 0x7e) + 1) << 16);
+      okm = 0;
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        const unsigned t1 = pg[i] - lo;
+        const unsigned t2 = hi1 + ~pg[i];
+        const bool ok = ((t1 & t2) & 0x808080u) == 0x808080u;
+        pf[i] = ld4(ok ? (xg + (org + goff[i])) : p.zeros);
+        pf2[i] = ld4(ok ? (xg2 + (org + goff[i])) : p.zeros);
+        if (xg3) pf3[i] = ld4(ok ? (xg3 + (org + goff[i])) : p.zeros);
+        okm |= (ok ? 1u : 0u) << i;
+      }
+    };
+    // one term of the sum: bn_add_kernel's arithmetic (norm.hip)
+    auto term = [&](const float4& v, int k, const float* par) __attribute__((always_inline)) {
+      float4 o = v;
+      if (par) {
+        o = atvs_bn4(v, bns[k], bsh[k]);
+        if ((p.relu_mask >> k) & 1) {
+          o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+        }
+      }
+      return o;
+    };
+    // the stage in flight -> its two pieces, into image pair `img`
+    auto deliver = [&](int img) __attribute__((always_inline)) {
+      unsigned char* base = smem + img * IMG2;
+#pragma unroll
+      for (int i = 0; i < MAXS; ++i) {
+        float4 a = term(pf[i], 0, p.pa);
+        const float4 b = term(pf2[i], 1, p.pb);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        if (xg3) {
+          const float4 d = term(pf3[i], 2, p.pc);
+          a.x += d.x; a.y += d.y; a.z += d.z; a.w += d.w;
+        }
+        const bool in = (okm >> i) & 1u;
+        uint2 p0, p1;
+        atvs_split2_f16(in ? a.x : 0.f, in ? a.y : 0.f, UB_RS, &p0.x, &p1.x);
+        atvs_split2_f16(in ? a.z : 0.f, in ? a.w : 0.f, UB_RS, &p0.y, &p1.y);
+        if (i < MAXS - 1 || stid + i * 256 < U::SLOTS) {
+          *reinterpret_cast<uint2*>(base + laddr[i]) = p0;
+          *reinterpret_cast<uint2*>(base + U::IMG + laddr[i]) = p1;
+        }
+      }
+    };
+    if (nstage > 0) {
+      request(0);
+      deliver(0);
+      if (nstage > 1) request(1);
+      ub_lds_barrier();                      // image pair 0 (and the weights) are in LDS; stage 1's loads stay in flight
+      UDBG(6)
+      for (int stage = 0; stage < nstage; ++stage) {
+        if (stage + 1 < nstage) {
+          deliver((stage + 1) & 1);          // the other pair: its last readers left it at the previous barrier
+          UDBG(0)
+          if (stage + 2 < nstage) request(stage + 2);
+          UDBG(1)
+        }
+        ub_lds_barrier();
+        UDBG(2)
+      }
+    }
+  } else {
+    // ======== multiply role: the plain form's K loop and epilogue
+    if (tid == 0) *reinterpret_cast<float4*>(smem + wb + U::WLDS) = make_float4(0.f, 0.f, 0.f, 0.f);      // (unused by the 8-channel form; keeps the layout of ub_lds)
+    const int fbase = ((mw * HY) * UB_HX + r + 1 - (q >> 1)) * UB_VB + (q & 1) * 16;
+    const int lane16 = lane * 16;
+    f32x4 acc[TY][NT], accx[TY][NT];
+    const unsigned ybytes = (unsigned)(p.gy * 4);
+    const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, ybytes, 0x00020000);
+    if (nstage > 0) ub_lds_barrier();
+    UDBG(6)
+    for (int stage = 0; stage < nstage; ++stage) {
+#pragma unroll
+      for (int t = 0; t < TY; ++t)
+#pragma unroll
+        for (int m = 0; m < NT; ++m) acc[t][m] = accx[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      const int fb = fbase + (stage & 1) * IMG2;
+      f16x8 Bq[2][TY], A0[2][4], A1[4];
+      auto request_B = [&](auto PH) __attribute__((always_inline)) {
+        constexpr int ph = decltype(PH)::value, g = ph / UB_NP, pc = ph % UB_NP, o2 = U::o2_of(g), oz = o2 >> 1, oy = o2 & 1;
+        constexpr int disp = ((1 - oz) * HY + (1 - oy)) * UB_ROWB;
+#pragma unroll
+        for (int t = 0; t < TY; ++t) Bq[ph & 1][t] = *reinterpret_cast<const f16x8*>(smem + pc * U::IMG + fb + (disp + t * UB_ROWB));
+      };
+      auto request_A0 = [&](auto GT) __attribute__((always_inline)) {
+        constexpr int g = decltype(GT)::value;
+        ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
+          constexpr int i = decltype(IT)::value;
+          A0[g & 1][i] = *reinterpret_cast<const f16x8*>(smem + wb + U::woff(U::first_step(g) + i, 0) + lane16);
+        });
+      };
+      auto request_A1 = [&](auto GT) __attribute__((always_inline)) {
+        constexpr int g = decltype(GT)::value;
+        ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
+          constexpr int i = decltype(IT)::value;
+          A1[i] = *reinterpret_cast<const f16x8*>(smem + wb + U::woff(U::first_step(g) + i, 1) + lane16);
+        });
+      };
+      request_A0(IC<0>{});
+      request_A1(IC<0>{});
+      request_B(IC<0>{});
+      asm volatile("" ::: "memory");
+      ub_static_for<UB_NP * NG>([&](auto PH) __attribute__((always_inline)) {
+        constexpr int ph = decltype(PH)::value, g = ph / UB_NP, pc = ph % UB_NP;
+        if constexpr (ph + 1 < UB_NP * NG) request_B(IC<ph + 1>{});
+        if constexpr (pc == 0 && g + 1 < NG) request_A0(IC<g + 1>{});
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        ub_static_for<U::ntg(g)>([&](auto IT) __attribute__((always_inline)) {
+          constexpr int i = decltype(IT)::value, m = U::tile(g, i);
+          if constexpr (pc == 0) {
+#pragma unroll
+            for (int t = 0; t < TY; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0[g & 1][i], Bq[ph & 1][t], acc[t][m], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < TY; ++t) accx[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A1[i], Bq[ph & 1][t], accx[t][m], 0, 0, 0);
+          } else {
+#pragma unroll
+            for (int t = 0; t < TY; ++t) accx[t][m] = __builtin_amdgcn_mfma_f32_16x16x32_f16(A0[g & 1][i], Bq[ph & 1][t], accx[t][m], 0, 0, 0);
+          }
+        });
+        if constexpr (pc == 0 && g + 1 < NG) {
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
+          request_A1(IC<g + 1>{});
+        }
+      });
+      UDBG(0)
+      // ---- epilogue: this lane holds, of tile m = (pz, py), channels (q&1)*4..+3 of output voxel (2z+pz, 2(y0+t)+py, 2(x0+r) + (q>>1))
+      int tz0, ty0, tx0;
+      tile_origin(stage, &tz0, &ty0, &tx0);
+      const int zo = tz0 + mw, xo = tx0 + r;
+      const bool evox_ok = zo < p.Di && xo < p.Wi;
+      const unsigned Hy = 2u * p.Hi, Wy = 2u * p.Wi;
+      const unsigned erow = Wy * p.ldy;
+      const unsigned eplane = Hy * erow;
+      const unsigned lane_c = (unsigned)((q >> 1) * p.ldy + (q & 1) * 4);
+      const unsigned eo = (((unsigned)(2 * zo) * Hy + 2 * ty0) * Wy + 2 * xo) * p.ldy + p.ycoff + lane_c;
+      const unsigned vo_ok = evox_ok ? eo * 4u : ybytes;
+      ub_static_for<NT>([&](auto MT) __attribute__((always_inline)) {
+        ub_static_for<TY>([&](auto TT) __attribute__((always_inline)) {
+          constexpr int m = decltype(MT)::value, t = decltype(TT)::value;
+          constexpr int pz = m >> 1, py = m & 1;
+          float a0 = __builtin_fmaf(accx[t][m][0], UB_IRS, acc[t][m][0]), a1 = __builtin_fmaf(accx[t][m][1], UB_IRS, acc[t][m][1]);
+          float a2 = __builtin_fmaf(accx[t][m][2], UB_IRS, acc[t][m][2]), a3 = __builtin_fmaf(accx[t][m][3], UB_IRS, acc[t][m][3]);
+          if (p.relu) {
+            a0 = (a0 < 0.f) ? 0.f : a0; a1 = (a1 < 0.f) ? 0.f : a1;
+            a2 = (a2 < 0.f) ? 0.f : a2; a3 = (a3 < 0.f) ? 0.f : a3;
+          }
+          const unsigned soff = (pz * eplane + (2 * t + py) * erow) * 4u;
+          const u32x4 bits = {__builtin_bit_cast(unsigned, a0), __builtin_bit_cast(unsigned, a1),
+                              __builtin_bit_cast(unsigned, a2), __builtin_bit_cast(unsigned, a3)};
+          const bool row_ok = ty0 + t < p.Hi;
+          __builtin_amdgcn_raw_buffer_store_b128(bits, yrsrc, row_ok ? vo_ok : ybytes, soff, ATVS_BUF_NT);
+          const bool ok = evox_ok && row_ok;
+          const float b0 = ok ? a0 : 0.f, b1 = ok ? a1 : 0.f, b2 = ok ? a2 : 0.f, b3 = ok ? a3 : 0.f;
+          ssum[0] += b0; ssum[1] += b1; ssum[2] += b2; ssum[3] += b3;
+          ssq[0] = __builtin_fmaf(b0, b0, ssq[0]); ssq[1] = __builtin_fmaf(b1, b1, ssq[1]);
+          ssq[2] = __builtin_fmaf(b2, b2, ssq[2]); ssq[3] = __builtin_fmaf(b3, b3, ssq[3]);
+        });
+      });
+      UDBG(1)
+      ub_lds_barrier();                      // this pair is free for the stage after next; the stores stay in flight
+      UDBG(2)
+    }
+  }
+#ifdef ATVS_UB_DEBUG
+  if (lane == 0 && blockIdx.x < 512) {       // rows (block, wave 0..7): wavefronts 4..7 are the staging role
+    dbg_acc[7] = (unsigned long long)nstage | ((wall_clock64() - dbg_w0) << 16);
+    for (int i = 0; i < 8; ++i) atvs_dbg_ub[(blockIdx.x * 8 + wave) * 8 + i] = dbg_acc[i];
+  }
+#endif
+
+  // ---- per-workgroup partial moments -> row blockIdx of stats: [2][16] doubles (columns 8..15 = 0): the one-role form's reduction
+  if (p.stats) {
+    __syncthreads();
+    double* s_red = reinterpret_cast<double*>(smem);   // [4 multiply waves][2][16]
+    if (!staging) {
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        double a = (double)ssum[kk], bq = (double)ssq[kk];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          a += __shfl_xor(a, o);
+          bq += __shfl_xor(bq, o);
+        }
+        a += __shfl_xor(a, 32);
+        bq += __shfl_xor(bq, 32);
+        const int col = (q & 1) * 4 + kk;
+        if (r == 0 && q < 2) {
+          s_red[(mw * 2 + 0) * 16 + col] = a;
+          s_red[(mw * 2 + 1) * 16 + col] = bq;
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 32) {
+      const int which = tid >> 4, col = tid & 15;
+      double v = 0.0;
+      if (col < 8)
+        v = (s_red[(0 * 2 + which) * 16 + col] + s_red[(1 * 2 + which) * 16 + col]) +
+            (s_red[(2 * 2 + which) * 16 + col] + s_red[(3 * 2 + which) * 16 + col]);
+      if (col < 8 || p.stats_ld == 16) p.stats[((size_t)blockIdx.x * 2 + which) * p.stats_ld + p.stats_coff + col] = v;
+    }
+  }
+}
+
 // HOST: the two fp16 pieces of v (round to nearest even; the kernel's atvs_split2_f16) at out[base + piece * 64 * 8]; false if v
 // does not fit fp16's range
 bool ub_put(uint16_t* out, size_t base, float v) {
@@ -557,11 +808,20 @@ size_t ub_lds(int Cin, int Cout) {      // images + all chunks' weights + the ze
 #endif
 bool ub_stream(int Cin, int Cout) { return Cout == 16 && ub_lds(Cin, Cout) > ATVS_UB_RESIDENT_MAX; }
 
-template <int COUT, bool STREAMW, bool PRO = false>
+template <int COUT, bool STREAMW>
 int launch_upb(const UpBArgs& a, long grid, size_t lds, hipStream_t s) {
   static AtvsAttrOnce lds_once;                   // per kernel instantiation (this function is a template / has one kernel)
-  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(deconv_up_b_kernel<COUT, STREAMW, PRO>), 160 * 1024)) return rc_;
-  hipLaunchKernelGGL((deconv_up_b_kernel<COUT, STREAMW, PRO>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(deconv_up_b_kernel<COUT, STREAMW>), 160 * 1024)) return rc_;
+  hipLaunchKernelGGL((deconv_up_b_kernel<COUT, STREAMW>), dim3((unsigned)grid), dim3(256), lds, s, a);
+  return ATVS_OK;
+}
+
+// the summing decoder in two roles: 512 threads, two image pairs + the chunk's weights + the zero line
+int launch_upb_sum2(const UpBArgs& a, long grid, hipStream_t s) {
+  static AtvsAttrOnce lds_once;
+  if (const int rc_ = atvs_set_max_lds_once(lds_once, reinterpret_cast<const void*>(deconv_up_b_sum_kernel), 160 * 1024)) return rc_;
+  const size_t lds = 2 * UB_NP * (size_t)UpB<8>::IMG + UpB<8>::WLDS + 16;
+  hipLaunchKernelGGL(deconv_up_b_sum_kernel, dim3((unsigned)grid), dim3(512), lds, s, a);
   return ATVS_OK;
 }
 
@@ -698,7 +958,7 @@ int upb_launch(const float* x, const float* x2, const float* x3, const float* pa
   hipStream_t st = as_stream(stream);
   const bool stream_w = ub_stream(Cin, Cout);
   const size_t lds = stream_w ? UB_NP * (size_t)UpB<16>::IMG + 2 * (size_t)UpB<16>::WLDS + 16 : ub_lds(Cin, Cout);
-  int rc = pro ? launch_upb<8, false, true>(a, blocks * groups, lds, st)
+  int rc = pro ? launch_upb_sum2(a, blocks * groups, st)
                : (Cout == 8) ? launch_upb<8, false>(a, blocks * groups, lds, st)
                              : stream_w ? launch_upb<16, true>(a, blocks * groups, lds, st) : launch_upb<16, false>(a, blocks * groups, lds, st);
   if (rc) return rc;

@@ -562,7 +562,7 @@ def conv3d_busy(args):
         return None
     tw = d.get('conv3d_mfma_busy_time_weighted')
     if not tw:
-        names = ('conv_xb_kernel', 'conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel', 'deconv_up_b_kernel', 'aanet_b_kernel')
+        names = ('conv_xb_kernel', 'conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel', 'deconv_up_b_kernel', 'deconv_up_b_sum_kernel', 'aanet_b_kernel')
         t = b = 0.0
         for name, e in d.get('kernels', {}).items():
             if any(k in name for k in names) and e.get('mfma_busy') is not None and e.get('total_ms') and (e.get('clock_GHz') or 0) <= 2.4:

@@ -66,6 +66,8 @@ def test_packed_fp32_only_where_it_is_accounted_for(tmp_path):
     assert not any('aanet_b_kernel' in k for k in counts), [k for k in counts if 'aanet_b_kernel' in k]
     # deconv_up_b: two workgroups per CU, wavefronts of the same kernel share SIMDs
     assert not any('deconv_up_b_kernel' in k for k in counts), [k for k in counts if 'deconv_up_b_kernel' in k]
+    # ... and the summing decoder (round 6): staging wavefronts beside its own MFMA wavefronts, as in conv_xb / aanet_b
+    assert not any('deconv_up_b_sum_kernel' in k for k in counts), [k for k in counts if 'deconv_up_b_sum_kernel' in k]
     # the geometry / soft-argmin / norm kernels (the round-3 victims) are scalar
     for src in ('warp_planes', 'homographies_kernel', 'bn_add_kernel', 'bn_apply_kernel', 'softargmin_kernel', 'aanet_combine'):
         assert not any(src in k for k in counts), src

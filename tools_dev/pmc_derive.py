@@ -8,7 +8,7 @@ spec, the kernel's cycles are duration x the REFERENCE clock: the duration-weigh
 200 us (where both counters agree).  `clock_source` says which was used; a clock above 2.4 GHz is never printed."""
 SPEC_GHZ = 2.4
 LONG_NS = 200e3
-CONV3D = ('conv_xb_kernel', 'conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel', 'deconv_up_b_kernel', 'aanet_b_kernel')
+CONV3D = ('conv_xb_kernel', 'conv_c16b_kernel', 'conv3d_b_kernel', 'conv3d_s2b_kernel', 'deconv_up_b_kernel', 'deconv_up_b_sum_kernel', 'aanet_b_kernel')
 
 
 def raw_cycles(c):
