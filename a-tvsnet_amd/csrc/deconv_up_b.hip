@@ -487,6 +487,9 @@ __global__ __launch_bounds__(512, 1) void deconv_up_b_sum_kernel(UpBArgs p) {
   using U = UpB<8>;
   constexpr int NT = U::NT, TY = U::TY, HY = U::HY, MAXS = U::MAXS, NG = U::NG;
   constexpr int IMG2 = UB_NP * U::IMG;                  // one image pair (h0 | h1)
+  // two wavefronts per SIMD, 256 registers each: the workgroup fills its SIMDs' register file like conv_xb / aanet_b, so that no
+  // wavefront of another kernel runs beside its 16x16x32 MFMAs (only reachable with co-residency switched on)
+  asm volatile("" ::: "v255");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;

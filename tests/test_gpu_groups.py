@@ -493,7 +493,9 @@ def test_refinement_net_planar_concat_equals_channel_last_concat(cuda, weights):
         assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize('G,shape,nterms', [(2, (6, 10, 20), 3), (1, (9, 17, 33), 2), (3, (4, 4, 16), 3), (2, (5, 7, 37), 2)])
+@pytest.mark.parametrize('G,shape,nterms', [(2, (6, 10, 20), 3), (1, (9, 17, 33), 2), (3, (4, 4, 16), 3), (2, (5, 7, 37), 2),
+                                            # the two-role kernel's pipeline: three stages per workgroup, a single tile, idle workgroups
+                                            (1, (32, 32, 160), 3), (1, (1, 2, 3), 2), (8, (8, 8, 32), 3)])
 def test_deconv_sums_its_inputs_on_load_bitwise(cuda, G, shape, nterms):
     """The full-resolution decoder conv_b*_6_0 (16 -> 8, reference cnn_wrapper/atvsnet.py:156-158,186-188) with its skip sum formed
     while the halo is staged (atvs_deconv_up_b_sum_f32) against the same layer behind the bn_add pass it replaces: pending batch
