@@ -39,6 +39,17 @@ elif which == 'refine':
     w8, w16 = wt(32, 8), wt(32, 16)
     run = lambda: ops.conv_siblings(ops.PendingBN(x, par, True), 'c8', w8, 'c16', w16, groups=G)   # noqa: E731
     mf = (384, 112)
+elif which == 'stemp':                                # the refinement's photo stem as the pipeline launches it: 16 channels as fp16 pieces
+    G = 4
+    ps = ops.planar_stride(D, H, W)
+    xv = torch.zeros(G, 2, ps, device=dev)
+    xv[..., :D * H * W * 8] = (torch.randn(G, 2, D * H * W * 16, device=dev) * 0.5).half().view(torch.float32)
+    cst = torch.randn(G, H, W, 16, device=dev)
+    sv = ops.SplitVolume(xv, cst, [('v', i) for i in range(16)] + [('c', i) for i in range(16)], planar=(D, H, W), pieces=True)
+    u8 = wt(32, 8)
+    buf = torch.zeros(G, 4, ps, device=dev)
+    run = lambda: ops.conv_split_into_plane(sv, 'e8', u8, buf, 0, (D, H, W))   # noqa: E731
+    mf = (384, 0)
 else:
     G = 4
     x = torch.randn(G, D, H, W, 16, device=dev)
