@@ -470,7 +470,8 @@ int atvs_deconv_up_b_f32(const float* x, const unsigned char* packed_w, float* y
  *   t(v, par, relu) = par ? relu?((v - mean) * scale + beta) : v                  (relu = that bit of relu_mask)
  * -- atvs_bn_add's arithmetic and order, formed per staged halo voxel; params_i (groups,3,Cin) or NULL (a finished tensor),
  * x2 NULL: two terms.  Bit for bit atvs_bn_add followed by atvs_deconv_up_b_f32.  Shapes: atvs_deconv_up_b_sum_supported
- * (Cin = 16, Cout = 8: the full-resolution decoder; one workgroup per CU). */
+ * (Cin = 16, Cout = 8: the full-resolution decoder; one workgroup of eight wavefronts per CU, four multiply and store, four stage
+ * the next tile's sources). */
 int atvs_deconv_up_b_sum_supported(int Cin, int Cout);
 int atvs_deconv_up_b_sum_f32(const float* x0, const float* params0, const float* x1, const float* params1, const float* x2,
                              const float* params2, int relu_mask, const unsigned char* packed_w, float* y, double* stats_partial,
@@ -530,7 +531,10 @@ long atvs_channel_stats_num_blocks(long rows);
 int atvs_channel_stats(const float* x, int groups, long rows, int C, double* stats_partial, atvs_stream_t stream);
 
 /* y = (x - mean) * rstd + beta [, relu]; y may alias x.  x and y are groups * rows rows of width ld of which the C
- * channels starting at c_off are touched (ld = C, c_off = 0 for a dense tensor); params (groups, 3, C). */
+ * channels starting at c_off are touched (ld = C, c_off = 0 for a dense tensor); params (groups, 3, C).
+ * Arithmetic (here and wherever an entry point of this header applies a pending batch norm while it loads -- the in_params /
+ * params_i arguments): ONE fused multiply-add per value, fma(x, rstd, beta - mean * rstd), tf.nn.batch_normalization's own form
+ * (x * inv + (offset - mean * inv)); every site uses the same two helpers, so a fused form equals the passes it replaces bit for bit. */
 int atvs_bn_apply(const float* x, const float* params, float* y, int groups, long rows, int C, int ld, int c_off,
                   int relu, atvs_stream_t stream);
 
