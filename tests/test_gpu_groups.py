@@ -529,12 +529,65 @@ def test_deconv_sums_its_inputs_on_load_bitwise(cuda, G, shape, nterms):
     assert torch.equal(ops.bn_params(st, cout, got), ops.bn_params(st_ref, cout, ref))
 
 
+@pytest.mark.parametrize('G,shape,nterms', [(2, (6, 10, 20), 3), (1, (9, 17, 33), 2), (2, (12, 16, 48), 3)])
+def test_deconv_sum_on_load_against_the_oracle(cuda, G, shape, nterms):
+    """The same fused launch against the CPU ORACLE, not against other HIP launches: tf.layers.conv3d_transpose (oracle/tf_ops.py,
+    reference cnn_wrapper/network.py:510-550) of the skip sum relu(bn(a)) + c + bn(b) evaluated in float64 from the same parameters
+    (reference cnn_wrapper/atvsnet.py:156-158: conv_b*_5_1 = add(conv_b*_5_0, conv_b*_1_1 [, conv_b0_1_1]) -> conv_b*_6_0).
+    Tolerance 2e-5 of the output scale (the split-operand products, a different accumulation order); the moments against the
+    float64 mean / variance of the oracle's output."""
+    from oracle import tf_ops as T
+    from atvsnet_amd import ops
+    cin, cout = 16, 8
+    w = _rand((3, 3, 3, cout, cin), 5) * 0.2
+    raws = [_rand((G,) + shape + (cin,), 60 + k) for k in range(nterms)]
+    pars = [torch.stack([_rand((G, cin), 70 + k) * 0.1, _rand((G, cin), 90 + k).abs() + 0.5, _rand((G, cin), 80 + k) * 0.1], 1).contiguous()
+            for k in range(nterms)]
+    finished = 1 if nterms == 3 else None                 # a finished tensor among the terms
+    ts = [raws[k].to(cuda) if k == finished else ops.PendingBN(raws[k].to(cuda), pars[k].to(cuda), relu=(k != 2)) for k in range(nterms)]
+    s_on = ops.PendingSum(ts)
+    assert ops.deconv_sum_ok(s_on, cout, G)
+    got, st = ops.conv3d_transpose_s2(s_on, ('up-sum-oracle', cin), w.numpy(), want_stats=True, groups=G)
+    assert s_on._final is None
+    params = ops.bn_params(st, cout, got)
+    for g in range(G):
+        x = torch.zeros(shape + (cin,), dtype=torch.float64)
+        for k in range(nterms):
+            v = raws[k][g].double()
+            if k != finished:
+                m, sc, be = pars[k][g, 0].double(), pars[k][g, 1].double(), pars[k][g, 2].double()
+                v = (v - m) * sc + be
+                if k != 2:
+                    v = torch.clamp(v, min=0)
+            x = x + v
+        want = T.conv3d_transpose_same(x[None], w.double(), 2)[0]
+        scale = float(want.abs().max())
+        assert float((got[g].cpu().double() - want).abs().max()) <= 2e-5 * scale, g
+        flat = want.reshape(-1, cout)
+        pg = params[g] if G > 1 else params
+        assert float((pg[0].cpu().double() - flat.mean(0)).abs().max()) <= 1e-5 * scale
+        rstd = 1.0 / torch.sqrt(flat.var(0, unbiased=False) + 1e-3)
+        assert float((pg[1].cpu().double() / rstd - 1).abs().max()) <= 1e-5
+
+
 def _pending_seeded(G, shape, cin, seed, relu, cuda):
     from atvsnet_amd import ops
     raw = _rand((G,) + shape + (cin,), seed).to(cuda)
     par = torch.stack([_rand((G, cin), seed + 10) * 0.1, _rand((G, cin), seed + 30).abs() + 0.5,
                        _rand((G, cin), seed + 20) * 0.1], 1).to(cuda).contiguous()
     return ops.PendingBN(raw, par, relu=relu)
+
+
+def _term64(t):
+    """A term of a skip sum in float64 on the CPU: a finished tensor, or relu?((raw - mean) * rstd + beta) of a PendingBN."""
+    from atvsnet_amd import ops
+    if not isinstance(t, ops.PendingBN):
+        return t.cpu().double()
+    raw, par = t.raw.cpu().double(), t.params.cpu().double()
+    G, C = raw.shape[0], raw.shape[-1]
+    bc = (G,) + (1,) * (raw.dim() - 2) + (C,)
+    v = (raw - par[:, 0].reshape(bc)) * par[:, 1].reshape(bc) + par[:, 2].reshape(bc)
+    return torch.clamp(v, min=0) if t.relu else v
 
 
 @pytest.mark.parametrize('G,shape,cin,cout,stride,relu', [
@@ -562,6 +615,10 @@ def test_conv3d_normalises_its_input_on_load_bitwise(cuda, G, shape, cin, cout, 
     assert torch.equal(ref, want)
     assert torch.equal(got, want)
     assert torch.equal(ops.bn_params(st, cout, got), ops.bn_params(st_w, cout, want))
+    # ... and against the ORACLE's convolution of the float64 batch norm (not only against other HIP launches)
+    from oracle import tf_ops as T
+    want64 = T.conv(_term64(_pending_seeded(G, shape, cin, 60, relu, cuda)), torch.from_numpy(w).double(), stride, 'SAME')      # (materialize() normalised pend.raw in place)
+    assert float((got.cpu().double() - want64).abs().max()) <= 3e-5 * float(want64.abs().max())
 
 
 @pytest.mark.parametrize('G,shape,forms', [(2, (8, 16, 32), 'pp'), (1, (9, 11, 19), 'pd'), (3, (5, 9, 13), 'dp'), (2, (4, 8, 16), 'pp')])
@@ -586,6 +643,11 @@ def test_conv_c16b_sums_its_inputs_on_load_bitwise(cuda, G, shape, forms):
     want, st_w = ops.conv(ops.PendingSum(items(80)).materialize(), ('sum16',), w, want_stats=True, groups=G)
     assert torch.equal(got, want)
     assert torch.equal(ops.bn_params(st, 16, got), ops.bn_params(st_w, 16, want))
+    # ... and against the ORACLE's convolution of the float64 sum (not only against other HIP launches)
+    from oracle import tf_ops as T
+    its = items(80)
+    want64 = T.conv(_term64(its[0]) + _term64(its[1]), torch.from_numpy(w).double(), 1, 'SAME')
+    assert float((got.cpu().double() - want64).abs().max()) <= 3e-5 * float(want64.abs().max())
     with ops.configure(sum_on_load=False):                             # ops.conv's own fallback
         ref = ops.conv(x, ('sum16',), w, groups=G, in_params=pa, in_relu=ra, in_sum=(x1, pb, rb))
     assert torch.equal(ref, want)
