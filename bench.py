@@ -364,10 +364,10 @@ def cpu_baseline(args):
     cfg1 = float(np.median(runs[1:]))
     D = args.depths
     n_src = args.views - 1
-    base = {'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'restatement',
+    base = {'unit': 'depth-maps/sec', 'cores': threads, 'kind': 'port',
             'thread_sweep_s': {str(k): v for k, v in sorted(sweep.items())},
             'thread_sweep_sample': 'two-view 320x256, D=96 (1/8 of configs[1]) once per thread count; the fastest count is `cores`',
-            'kind_detail': 'restatement ("port" in the contract\'s vocabulary): the CPU oracle (torch-CPU / numpy restatement of the reference\'s TF-1.5 path, oracle/), '
+            'kind_detail': '"port" = the CPU oracle (torch-CPU / numpy restatement of the reference\'s TF-1.5 path, oracle/), '
                            'NOT TensorFlow and not a build of the reference -- TensorFlow 1.5 cannot be installed here',
             'host_cpus': ncpu, 'cpu_model': model_name,
             'configs0_s': round(cfg1, 3), 'configs0_runs_s': [round(r, 3) for r in runs]}
