@@ -297,6 +297,40 @@ class GraphedInference(object):
         return out
 
 
+_hip_runtime = None
+
+
+def cu_split_streams(device, parts):
+    """`parts` HIP streams whose kernels run on DISJOINT sets of compute units: part k of every XCD (hipExtStreamCreateWithCUMask;
+    mask bit i = CU i / 8 of XCD i % 8 on MI355X, so part k owns the CUs with (i / 8) % parts == k -- an equal share of every
+    XCD, of its L2 and of the memory channels behind it).  Kernels of different streams then never share a CU, hence never a
+    SIMD: the one condition of the co-residency fault cannot arise between them.
+    (Masks that leave an XCD without a CU -- "even / odd bits" -- are not honoured by the runtime: the stream then runs on the whole
+    chip.  tests/test_gpu_pipeline.py checks that a stream of this function really is confined.)  The streams live as long as the
+    process (a handful per process; nothing to free in a driver run)."""
+    import ctypes
+    global _hip_runtime
+    props = torch.cuda.get_device_properties(device)
+    ncu, nxcd = int(props.multi_processor_count), 8
+    if parts < 1 or ncu % nxcd or (ncu // nxcd) < parts:
+        raise ValueError('cu_split_streams: %d parts of %d compute units' % (parts, ncu))
+    if _hip_runtime is None:
+        _hip_runtime = ctypes.CDLL('libamdhip64.so')          # the runtime torch has loaded (same soname: the same instance)
+    out = []
+    with torch.cuda.device(device):
+        for k in range(parts):
+            words = (ctypes.c_uint32 * ((ncu + 31) // 32))()
+            for i in range(ncu):
+                if (i // nxcd) % parts == k:
+                    words[i // 32] |= (1 << (i % 32))
+            st = ctypes.c_void_p()
+            rc = _hip_runtime.hipExtStreamCreateWithCUMask(ctypes.byref(st), len(words), words)
+            if rc != 0 or not st.value:
+                raise RuntimeError('hipExtStreamCreateWithCUMask failed (%d)' % rc)
+            out.append(torch.cuda.ExternalStream(st.value, device=device))
+    return out
+
+
 class PipelinedInference(object):
     """`slots` depth maps queued: one captured graph (static buffers) and one HIP stream per slot.
 
@@ -312,6 +346,11 @@ class PipelinedInference(object):
     tests/test_packed_fp32_census.py, and conv2d_b / conv1x1_b / bottleneck_b / deconv_up_b run two workgroups per CU, so
     nothing reserves their SIMDs).  bench.py measures it under `pipelined` and fails the run if a slot's output differs from
     the single-map output.
+    `co_resident='cu_split'` (round 6): the slots' graphs run concurrently, each on its OWN share of every XCD's compute units
+    (cu_split_streams): no SIMD ever holds wavefronts of two kernels, so the fault above cannot occur, and every slot still
+    produces the single-map bits.  Two slots: +1.5 ... 4 % depth maps/s at config 3 (each map has half the chip; what is gained
+    is the overlap of one map's launch tails and latency-bound kernels with the other's work), +19 % for two-view maps
+    (configs[1]: 184 -> 218 maps/s); the latency of ONE map roughly doubles.  bench.py reports it under `pipelined_cu_split`.
 
         t = p.submit(images, cams)      # asynchronous: copies the inputs, replays the slot's graph on its stream
         out = p.result(t)               # waits for that depth map; the tensors are valid until the slot is re-used
@@ -321,10 +360,13 @@ class PipelinedInference(object):
         if slots < 1:
             raise ValueError('PipelinedInference: slots >= 1')
         self.device = images.device
+        if co_resident not in (False, True, 'cu_split'):
+            raise ValueError("PipelinedInference: co_resident is False, True or 'cu_split'")
+        self.cu_split = co_resident == 'cu_split'
         self.co_resident = bool(co_resident)
         self.last = None                 # slot of the most recent submission (its event orders the next one behind it)
         self.graphs = [GraphedInference(images, cams, max_d, **kw) for _ in range(slots)]
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(slots)]
+        self.streams = cu_split_streams(self.device, slots) if self.cu_split else [torch.cuda.Stream(self.device) for _ in range(slots)]
         self.events = [torch.cuda.Event() for _ in range(slots)]
         self.busy = [False] * slots
         self.suspect = set()             # slots in flight when the non-finite flag was found set: their maps are recomputed in fp32
@@ -333,6 +375,19 @@ class PipelinedInference(object):
     @property
     def slots(self):
         return len(self.graphs)
+
+    def set_mode(self, co_resident):
+        """Switch the way the slots share the GPU (False | True | 'cu_split') with nothing in flight: the captured graphs stay,
+        the slots' streams are replaced."""
+        if any(self.busy):
+            raise RuntimeError('PipelinedInference.set_mode: results still in flight')
+        if co_resident not in (False, True, 'cu_split'):
+            raise ValueError("PipelinedInference: co_resident is False, True or 'cu_split'")
+        torch.cuda.synchronize(self.device)
+        split = co_resident == 'cu_split'
+        if split != self.cu_split:
+            self.streams = cu_split_streams(self.device, self.slots) if split else [torch.cuda.Stream(self.device) for _ in range(self.slots)]
+        self.cu_split, self.co_resident, self.last = split, bool(co_resident), None
 
     def submit(self, images=None, cams=None):
         """Issue one depth map on the next slot (its previous result must have been fetched); returns the ticket."""
@@ -388,8 +443,11 @@ class PipelinedInference(object):
                 self.graphs[s].graph.replay()
                 self.events[s].record(self.streams[s])
             self.last = s
-        for st in self.streams:
-            torch.cuda.current_stream(self.device).wait_stream(st)
+        # wait on the HOST for every slot's last event -- not `current_stream.wait_stream(slot stream)`: the CU-masked streams are
+        # blocking streams in the legacy sense, and an operation on the default stream while their queues are full cost 13 % of the
+        # run's throughput (round 6, tools_dev/cu_mask_probe.py: 61.4 -> 53.9 maps/s; plain side streams are unaffected)
+        for s in range(min(count, len(self.graphs))):
+            self.events[s].synchronize()
 
 
 def _load_weights():

@@ -20,6 +20,9 @@ with their kernels CO-RESIDENT on the GPU (example.PipelinedInference(co_residen
 depth maps of a scene are independent (one per reference view) and a second one in flight fills the phases in which one
 pipeline leaves the GPU under-filled; that throughput is reported under `pipelined`, never as `value`, and the run FAILS
 (exit code 4, "ok": false) if any slot's depth map differs from the single-map output by one bit.
+A THIRD region repeats it with every map confined to its own share of every XCD's compute units (hipExtStreamCreateWithCUMask,
+example.PipelinedInference(co_resident='cu_split')): kernels of different maps then never share a SIMD -- the safe form of maps in
+flight -- reported under `pipelined_cu_split`, same bitwise check.
 
 --gpus N > 1: this process touches no GPU; it starts N ranks (one process per GPU, RANK / LOCAL_RANK /
 WORLD_SIZE / MASTER_* set, 127.0.0.1 rendezvous), prints ONE JSON line and exits non-zero if a rank of the primary
@@ -769,6 +772,35 @@ def rank_main(args):
                      'note': '%d depth maps in flight with their kernels co-resident on the GPU (example.PipelinedInference('
                              'co_resident=True): opt-in, the product default runs one map at a time -- DESIGN.md appendix B): '
                              'throughput of independent depth maps of a scene, NOT the per-map rate `value` reports' % pipe.slots}
+    pipelined_cu_split = None
+    if pipe is not None and pipe.slots > 1:
+        # the same `inflight` maps in flight, each on its own share of every XCD's compute units (example.cu_split_streams): no SIMD
+        # is shared by two kernels, so the co-residency fault cannot occur -- the SAFE form of maps in flight
+        try:
+            pipe.set_mode('cu_split')
+            pipe.run(args.warmup)
+            barrier()
+            t1 = time.perf_counter()
+            pipe.run(args.steps)
+            barrier()
+            dts = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dts], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dts = float(t.item())
+            same = all(bool(torch.equal(g.out, out)) for g in pipe.graphs)
+            pipelined_cu_split = {'value': round(n_groups * args.steps / dts, 4), 'unit': 'depth-maps/sec', 'inflight': pipe.slots,
+                                  'ms_per_step': round(1e3 * dts / args.steps, 3), 'equals_single_map_bitwise': same,
+                                  'note': '%d depth maps in flight, each confined to its own 1/%d of every XCD (hipExtStreamCreateWithCUMask, '
+                                          "example.PipelinedInference(co_resident='cu_split')): kernels of different maps never share a "
+                                          'SIMD; throughput of independent depth maps, NOT the per-map rate `value` reports' % (pipe.slots, pipe.slots)}
+        except Exception as e:                 # a runtime without the CU-mask extension: reported, the primary number stands
+            pipelined_cu_split = {'error': repr(e)}
+        finally:
+            try:
+                pipe.set_mode(True)
+            except Exception:
+                pass
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1003,6 +1035,7 @@ def rank_main(args):
             'source_views_per_sec': round(n_groups * args.steps * (args.views - 1) / dt, 3),
             'latency_ms': round(1e3 * dt / args.steps, 3),
             'pipelined': pipelined,
+            'pipelined_cu_split': pipelined_cu_split,
             'split_operands': split,
             'five_sources': five,
             'roofline': roof, 'roofline_hbm': roof_hbm, 'power': power, 'kernels': top_kernels(),
@@ -1022,6 +1055,8 @@ def rank_main(args):
         problems = []
         if pipelined is not None and not pipelined['equals_single_map_bitwise']:
             problems.append('pipelined: a slot of the co-resident run differs from the single-map output')
+        if pipelined_cu_split is not None and pipelined_cu_split.get('equals_single_map_bitwise') is False:
+            problems.append('pipelined_cu_split: a slot of the CU-split run differs from the single-map output')
         if isinstance(line.get('parity'), dict) and line['parity'].get('ok') is False:
             problems.append('parity: rel-L1 above the bar')
         if isinstance(line.get('parity'), dict) and line['parity'].get('graph_equals_eager_bitwise') is False:

@@ -184,11 +184,12 @@ def test_graft_entry_build_then_smoke_in_one_process(cuda):
     assert r.returncode == 0 and 'smoke ok' in out, out[-2000:]
 
 
-@pytest.mark.parametrize('co_resident', [False, True])
+@pytest.mark.parametrize('co_resident', [False, True, 'cu_split'])
 def test_pipelined_inference_two_in_flight(cuda, weights, co_resident):
     """example.PipelinedInference: two depth maps queued (independent reference views of a scene, reference
     eval_pointcloud.py:399-424) give, per depth map, exactly what one pipeline gives -- with the GPU running one map at
-    a time (the default) and with both maps' kernels on the GPU at once (co_resident=True, opt-in)."""
+    a time (the default), with both maps' kernels on the GPU at once (co_resident=True, opt-in) and with each map on its own
+    share of every XCD's compute units (co_resident='cu_split': no SIMD shared between the maps)."""
     from atvsnet_amd.atvsnet import example as ex
     from atvsnet_amd import synthetic
     imgs, cams = _inputs(3)
@@ -304,3 +305,50 @@ def test_two_depth_maps_in_flight_fullsize(cuda, weights):
         g1 = p.result(t1).clone()
         g2 = p.result(t2).clone()
         assert torch.equal(g1, w1) and torch.equal(g2, w2), rep
+
+
+def test_cu_split_streams_confine_their_kernels(cuda, weights):
+    """example.cu_split_streams: the runtime silently IGNORES a CU mask it does not like (one that leaves an XCD without a compute
+    unit runs on the whole chip) -- and a stream that is not confined gives no protection against the co-residency fault.  So: the
+    same captured depth map replayed on one of the two half-chip streams must be clearly slower than on a plain stream (measured:
+    1.25 x here, 1.6 x at configs[2]), on one of four quarter-chip streams slower again, with every bit unchanged; and two / four maps in flight on the parts
+    give the single-map bits."""
+    import time
+    from atvsnet_amd.atvsnet import example as ex
+    from atvsnet_amd import synthetic
+    i, c = synthetic.make_inputs(3, 256, 320, 96)
+    imgs, cams = torch.from_numpy(i).to(cuda), torch.from_numpy(c).to(cuda)
+    g = ex.GraphedInference(imgs, cams, 96)
+    want = g().clone()
+    torch.cuda.synchronize()                 # the replays below run on other streams: the copy must have read the buffer first
+
+    def timed(stream, n=10):
+        with torch.cuda.stream(stream):
+            g.graph.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.cuda.stream(stream):
+            for _ in range(n):
+                g.graph.replay()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / n
+    plain = timed(torch.cuda.Stream(cuda))
+    halves, quarters = ex.cu_split_streams(cuda, 2), ex.cu_split_streams(cuda, 4)
+    th = [timed(st) for st in halves]
+    assert torch.equal(g.out, want)
+    tq = timed(quarters[3])
+    assert torch.equal(g.out, want)
+    print('one map: plain stream %.2f ms, half-chip streams %.2f / %.2f ms, a quarter-chip stream %.2f ms' % (1e3 * plain, 1e3 * th[0], 1e3 * th[1], 1e3 * tq))
+    assert min(th) >= 1.15 * plain, (plain, th)           # half the compute units: measured 1.25 x at this size (1.6 x at configs[2])
+    assert tq >= 1.15 * max(th), (th, tq)                 # a quarter: measured 1.5 x the halves
+    with pytest.raises(ValueError):
+        ex.cu_split_streams(cuda, 0)
+    for parts in (2, 4):
+        p = ex.PipelinedInference(imgs, cams, 96, slots=parts, co_resident='cu_split')
+        assert p.cu_split and p.co_resident
+        for _ in range(3):
+            ts = [p.submit(imgs, cams) for _ in range(parts)]
+            for t in ts:
+                assert torch.equal(p.result(t), want)
+        p.set_mode(False)
+        assert not p.cu_split and torch.equal(p.result(p.submit(imgs, cams)), want)
