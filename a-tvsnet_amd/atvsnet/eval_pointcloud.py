@@ -121,7 +121,8 @@ class _Pipelines(object):
     CO_RESIDENT = False: the GPU runs one depth map at a time (the reference's scene loop, eval_pointcloud.py:291-396, is
     serial too); the second slot only lets the host load / submit the next view and write the previous one's files
     meanwhile.  True runs both maps' kernels concurrently (+4.5 % maps/s) and stays off until the co-residency fault of
-    DESIGN.md appendix B is root-caused or a >= 10,000-map full-size soak is clean."""
+    DESIGN.md appendix B is root-caused or a >= 10,000-map full-size soak is clean; 'cu_split' (cli --maps_in_flight cu_split)
+    runs them concurrently on disjoint halves of every XCD, where that fault cannot occur."""
 
     SLOTS = 2
     CO_RESIDENT = False
@@ -238,10 +239,15 @@ def cli(argv=None):
     parser.add_argument('--synthetic_weights', action='store_true')
     parser.add_argument('--write_upsampled', action='store_true')
     parser.add_argument('--eager', action='store_true')
+    parser.add_argument('--maps_in_flight', choices=('serial', 'cu_split'), default='serial',
+                        help='serial: one depth map on the GPU at a time (default); cu_split: the two queued depth maps run concurrently, '
+                             'each on its own half of every XCD (example.cu_split_streams: no SIMD shared between them; same bits, '
+                             'more depth maps per second, twice the latency of one)')
     args = parser.parse_args(argv)
     scenes = args.scenes.split(',') if args.scenes else None
+    _Pipelines.CO_RESIDENT = 'cu_split' if args.maps_in_flight == 'cu_split' else False
     for k, v in vars(args).items():
-        if k != 'scenes':
+        if k not in ('scenes', 'maps_in_flight'):
             setattr(FLAGS, k, v)
     print('Evaluate A-TVSNet pointcloud with %d views' % (FLAGS.view_num))
     main(scenes)

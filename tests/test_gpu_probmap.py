@@ -117,5 +117,15 @@ def test_eth3d_driver_end_to_end(cuda, tmp_path, weights):
         with open(os.path.join(out, '00000000.txt')) as f:
             cam = P.load_cam(f)
         assert np.allclose(cam[1, 3, 2], 16) and cam[1, 0, 0] > 0
+        # the same scene with the two queued depth maps on disjoint halves of every XCD: the files' bytes are the serial run's
+        E.cli(['--data_root', root, '--savepath', os.path.join(root, 'out2'), '--view_num', '3', '--max_d', '16', '--max_w', '160',
+               '--max_h', '128', '--synthetic_weights', '--scenes', 'toy', '--maps_in_flight', 'cu_split'])
+        assert E._Pipelines.CO_RESIDENT == 'cu_split'
+        for idx in (0, 1):
+            for suffix in ('.pfm', '_prob.pfm'):
+                a = open(os.path.join(out, '%08d%s' % (idx, suffix)), 'rb').read()
+                b = open(os.path.join(root, 'out2', 'toy', 'depths_atvsnet', '%08d%s' % (idx, suffix)), 'rb').read()
+                assert a == b, (idx, suffix)
     finally:
+        E._Pipelines.CO_RESIDENT = False
         FLAGS.reset()
