@@ -132,14 +132,20 @@ class _Pipelines(object):
         self.pending = []            # (pipeline, ticket) or (None, tensors) in submission order
 
     def submit(self, images_data, cams_data):
-        images = torch.from_numpy(np.ascontiguousarray(images_data, dtype=np.float32)).to(self.device)
-        cams = torch.from_numpy(np.ascontiguousarray(cams_data, dtype=np.float32)).to(self.device)
+        images = torch.from_numpy(np.ascontiguousarray(images_data, dtype=np.float32))
+        cams = torch.from_numpy(np.ascontiguousarray(cams_data, dtype=np.float32))
+        split = self.use_graph and self.CO_RESIDENT == 'cu_split'
+        key = tuple(images.shape)
+        if not (split and key in self.cache):
+            # (cu_split: the slot's own stream copies the HOST tensors -- an upload on the default stream would wait for the map in
+            # flight on the other half of the chip, example.PipelinedInference.submit; the first map of a shape still needs device
+            # tensors to capture the graphs from)
+            images, cams = images.to(self.device), cams.to(self.device)
         if not self.use_graph:
             # eager: computed here, with the drivers' range guard (an fp16-range overflow reruns the map on the fp32 kernels)
             self.pending.append((None, example.infer_checked(
                 lambda: example.infer_multiview(images, cams, FLAGS.max_d, out_prob_map=True), self.device)))
             return
-        key = tuple(images.shape)
         p = self.cache.get(key)
         if p is None:
             p = self.cache[key] = example.PipelinedInference(images, cams, FLAGS.max_d, slots=self.SLOTS,
@@ -151,7 +157,8 @@ class _Pipelines(object):
 
     def fetch(self):
         p, t = self.pending.pop(0)
-        out = t if p is None else p.result(t)       # result(): the fp32 rerun of a map whose split-operand replay overflowed
+        # result(): the fp32 rerun of a map whose split-operand replay overflowed; host=True: copied by the slot's own stream
+        out = t if p is None else p.result(t, host=True)
         return [example.check_finite(o.cpu().numpy(), 'a network output') for o in out]
 
     def __call__(self, images_data, cams_data):

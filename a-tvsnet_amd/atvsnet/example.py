@@ -396,7 +396,18 @@ class PipelinedInference(object):
             raise RuntimeError('PipelinedInference: slot %d still holds an unfetched result' % s)
         self.next = (s + 1) % len(self.graphs)
         st = self.streams[s]
-        st.wait_stream(torch.cuda.current_stream(self.device))      # inputs prepared on the caller's stream
+        # inputs prepared on the caller's stream are ordered in front of the slot's work.  cu_split: the CU-masked streams are BLOCKING
+        # streams in the legacy sense -- any operation on the default stream (an event record, a copy) waits for every map in flight
+        # and holds the next one back, which serialises the slots (34 instead of 62 maps/s at configs[2]); so HOST tensors (or None)
+        # are copied by the slot's own stream with no default-stream operation at all, and only device inputs pay for the ordering
+        if not self.cu_split or any(t is not None and t.is_cuda for t in (images, cams)):
+            cur = torch.cuda.current_stream(self.device)
+            if self.cu_split and cur == torch.cuda.default_stream(self.device) and not getattr(self, '_warned', False):
+                self._warned = True
+                print(Notify.WARNING, "PipelinedInference(co_resident='cu_split'): device inputs prepared on the default stream order "
+                      'every submission behind ALL maps in flight (the slots then run one after the other, each on its share of the '
+                      'chip); pass host tensors or prepare the inputs on a side stream', Notify.ENDC)
+            st.wait_stream(cur)
         if not self.co_resident and self.last is not None and self.last != s:
             st.wait_event(self.events[self.last])                   # one depth map on the GPU at a time
         for t in (images, cams):
@@ -411,10 +422,19 @@ class PipelinedInference(object):
         self.last = s
         return s
 
-    def result(self, ticket):
+    def result(self, ticket, host=False):
+        """The depth map (tuple of outputs with out_prob_map) of `ticket`; host=True: as CPU tensors, copied by the slot's own stream
+        (cu_split: the way to fetch results without an operation on the default stream, see submit)."""
         if not self.busy[ticket]:
             raise RuntimeError('PipelinedInference: nothing in flight on slot %d' % ticket)
         self.events[ticket].synchronize()
+        with torch.cuda.stream(self.streams[ticket]):          # the flag read and the copies below: on the slot's (idle) stream
+            out = self._result(ticket)
+            if host:
+                out = tuple(o.cpu() for o in out) if isinstance(out, (tuple, list)) else out.cpu()
+        return out
+
+    def _result(self, ticket):
         self.busy[ticket] = False
         from .. import ops
         if ops.nonfinite_seen(self.device):

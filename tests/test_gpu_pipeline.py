@@ -346,9 +346,13 @@ def test_cu_split_streams_confine_their_kernels(cuda, weights):
     for parts in (2, 4):
         p = ex.PipelinedInference(imgs, cams, 96, slots=parts, co_resident='cu_split')
         assert p.cu_split and p.co_resident
-        for _ in range(3):
-            ts = [p.submit(imgs, cams) for _ in range(parts)]
+        himgs, hcams = imgs.cpu(), cams.cpu()
+        for rep in range(3):
+            # host tensors in, host tensors out: the slots' own streams do the copies (no operation on the default stream, which would
+            # order every submission behind all maps in flight); device tensors work too, serialised
+            ts = [p.submit(himgs, hcams) if rep else p.submit(imgs, cams) for _ in range(parts)]
             for t in ts:
-                assert torch.equal(p.result(t), want)
+                got = p.result(t, host=bool(rep))
+                assert got.is_cuda != bool(rep) and torch.equal(got.to(cuda), want)
         p.set_mode(False)
         assert not p.cu_split and torch.equal(p.result(p.submit(imgs, cams)), want)
