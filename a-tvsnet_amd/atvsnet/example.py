@@ -315,7 +315,18 @@ def cu_split_streams(device, parts):
     if parts < 1 or ncu % nxcd or (ncu // nxcd) < parts:
         raise ValueError('cu_split_streams: %d parts of %d compute units' % (parts, ncu))
     if _hip_runtime is None:
-        _hip_runtime = ctypes.CDLL('libamdhip64.so')          # the runtime torch has loaded (same soname: the same instance)
+        # the HIP runtime torch has ALREADY loaded (a stream of a second copy of the runtime would mean nothing to torch): its path from
+        # this process's mappings, the soname as a fallback (dlopen returns the loaded instance for a matching soname)
+        path = 'libamdhip64.so'
+        try:
+            with open('/proc/self/maps') as f:
+                for ln in f:
+                    if 'libamdhip64.so' in ln:
+                        path = ln.split()[-1]
+                        break
+        except OSError:
+            pass
+        _hip_runtime = ctypes.CDLL(path)
     out = []
     with torch.cuda.device(device):
         for k in range(parts):
